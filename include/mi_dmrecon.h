@@ -1,0 +1,163 @@
+/*
+ * mi_dmrecon.h -- C ABI of the MI355X-native depth-map reconstruction library
+ * (libmi_dmrecon.so), the drop-in replacement for the compute inside MVE's
+ * libs/dmrecon.  Paths below are relative to the reference tree
+ * (simonfuhrmann/mve).
+ *
+ * The reference has no FFI: its boundary is the C++ class mvs::DMRecon
+ * (libs/dmrecon/dmrecon.h:40-68) driven by apps/dmrecon/dmrecon.cc:53-65.
+ * The host shim mve_amd/host/ re-implements that class (same headers, same
+ * names, same exceptions) on top of the entry points declared here; see
+ * INTEGRATION.md.  Every entry point cites the reference code it replaces.
+ *
+ * Conventions: plain pointers and sizes only; all buffers are caller-owned
+ * host memory unless stated; every function returns 0 on success and a
+ * negative MI_DMRECON_E* code on failure (message: mi_dmrecon_last_error(),
+ * thread-local); nothing throws across this boundary.  A context is bound to
+ * one GPU and must be used by one host thread at a time; distinct contexts are
+ * independent (one per GPU = the multi-GPU sharding unit).
+ */
+#ifndef MI_DMRECON_H
+#define MI_DMRECON_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_DMRECON_OK            0
+#define MI_DMRECON_EINVAL       -1   /* std::invalid_argument in the reference (dmrecon.cc:37-46,74-75) */
+#define MI_DMRECON_EGVS         -2   /* std::runtime_error("Global View Selection failed") (dmrecon.cc:223) */
+#define MI_DMRECON_EDEVICE      -3   /* HIP runtime error */
+#define MI_DMRECON_ECANCELLED   -4   /* progress.cancelled observed (dmrecon.cc:101-105) */
+#define MI_DMRECON_EFOOTPRINT   -5   /* std::out_of_range("Negative pixel footprint") (patch_sampler.cc:78-82) */
+
+#define MI_DMRECON_MAX_GLOBAL_VIEWS 32
+#define MI_DMRECON_MAX_LOCAL_VIEWS   4
+
+typedef struct mi_dmrecon_ctx mi_dmrecon_ctx;
+
+/* The mve::CameraInfo fields the path reads (libs/mve/camera.h; camera.cc:34-200). */
+typedef struct mi_dmrecon_camera {
+    float flen;
+    float paspect;
+    float ppoint[2];
+    float rot[9];     /* world -> camera, row-major */
+    float trans[3];
+} mi_dmrecon_camera;
+
+/* POD mirror of the algorithmic fields of mvs::Settings (libs/dmrecon/settings.h:22-52).
+ * refViewNr is passed per call; imageEmbedding / ply / keep* flags stay in the host shim. */
+typedef struct mi_dmrecon_settings {
+    int32_t filterWidth;        /* 5 (the only width the reference's hard-coded centre sample 12 is right for) */
+    float   minNCC;             /* 0.3 */
+    float   minParallax;        /* 10 */
+    float   acceptNCC;          /* 0.6 */
+    float   minRefineDiff;      /* 0.001 */
+    int32_t maxIterations;      /* 20 */
+    int32_t nrReconNeighbors;   /* 4; 1..MI_DMRECON_MAX_LOCAL_VIEWS */
+    int32_t globalVSMax;        /* 20; <= MI_DMRECON_MAX_GLOBAL_VIEWS */
+    int32_t scale;              /* 0 */
+    int32_t useColorScale;      /* 1 */
+    float   aabbMin[3];         /* -FLT_MAX */
+    float   aabbMax[3];         /* +FLT_MAX */
+} mi_dmrecon_settings;
+
+/* mvs::ReconStatus / mvs::Progress (libs/dmrecon/progress.h:17-43).  The caller may
+ * poll the fields from another thread and may set `cancelled` (as UMVE does). */
+enum { MI_RECON_IDLE = 0, MI_RECON_GLOBALVS, MI_RECON_FEATURES, MI_RECON_QUEUE, MI_RECON_SAVING, MI_RECON_CANCELLED };
+typedef struct mi_dmrecon_progress {
+    volatile int32_t  status;
+    volatile uint64_t filled;
+    volatile uint64_t queueSize;    /* size of the current propagation work list */
+    volatile uint64_t start_time;
+    volatile int32_t  cancelled;
+} mi_dmrecon_progress;
+
+/* Output maps of one reference view: what DMRecon::start() hands to View::set_image
+ * (dmrecon.cc:119-145).  Row-major, interleaved, W_s x H_s (mi_dmrecon_level_size at
+ * settings.scale).  Unfilled pixels are exactly 0.  Any pointer may be NULL. */
+typedef struct mi_dmrecon_maps {
+    float*   depth;     /* 1 channel  "depth-L<s>"  */
+    float*   normal;    /* 3 channels (SingleView::normalImg) */
+    float*   dz;        /* 2 channels "dz-L<s>"     */
+    float*   conf;      /* 1 channel  "conf-L<s>"   */
+    int32_t* views;     /* 4 channels: local view ids of the accepted patch, -1 padded (QueueData::localViewIDs) */
+} mi_dmrecon_maps;
+
+/* Work counters (device-counted) and timings of the last reconstruct call. */
+typedef struct mi_dmrecon_stats {
+    int64_t n_patch;        /* patch optimisations started (PatchOptimization objects) */
+    int64_t n_eval;         /* patch-view evaluations: 25 bilinear samples of one neighbour view (SURVEY 8d unit) */
+    int64_t n_filled;       /* pixels with depth (progress.filled) */
+    int64_t n_seeds;        /* features processed (dmrecon.cc:287) */
+    int64_t n_seeds_ok;     /* features whose optimisation succeeded (dmrecon.cc:301) */
+    int64_t n_rounds;       /* propagation sweeps */
+    int64_t n_launches;     /* launches of the optimisation kernel */
+    double  ms_total;       /* wall time of the call, host clock */
+    double  ms_opt_kernel;  /* sum of hipEvent durations of the optimisation kernel */
+    double  ms_sweep_kernels; /* sum of hipEvent durations of the generate/apply kernels */
+} mi_dmrecon_stats;
+
+int  mi_dmrecon_device_count(void);
+const char* mi_dmrecon_last_error(void);
+void mi_dmrecon_settings_default(mi_dmrecon_settings* s);              /* settings.h:25-51 */
+
+int  mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out);
+void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* ctx);
+/* The HIP stream all kernels of this context are launched on (hipStream_t as void*). */
+void* mi_dmrecon_ctx_stream(mi_dmrecon_ctx* ctx);
+
+/* Replaces SingleView::SingleView + ImagePyramidCache::get / buildPyramid / ensureImages
+ * (single_view.cc:24-50, image_pyramid.cc:21-132): registers view `view_id` with its camera
+ * and level-0 image (uint8, channels 1..4: grey is expanded, alpha dropped, image_pyramid.cc:65-73),
+ * builds the Gaussian pyramid on the device (image_tools.h:619-690) and keeps every level resident in HBM. */
+int  mi_dmrecon_set_view(mi_dmrecon_ctx* ctx, int32_t view_id, const mi_dmrecon_camera* cam,
+                         int32_t width, int32_t height, int32_t channels, const uint8_t* pixels);
+int  mi_dmrecon_evict_view(mi_dmrecon_ctx* ctx, int32_t view_id);     /* ImagePyramidCache::cleanup */
+
+/* mve::Bundle::Features (libs/mve/bundle.h:46-56) in CSR form: feature i has position pos[3i..3i+2]
+ * and is referenced by views ref_view_ids[ref_offsets[i] .. ref_offsets[i+1]). */
+int  mi_dmrecon_set_features(mi_dmrecon_ctx* ctx, int32_t n_features, const float* pos,
+                             const int32_t* ref_offsets, const int32_t* ref_view_ids);
+
+int  mi_dmrecon_num_levels(mi_dmrecon_ctx* ctx, int32_t view_id);
+int  mi_dmrecon_level_size(mi_dmrecon_ctx* ctx, int32_t view_id, int32_t level, int32_t* width, int32_t* height);
+/* Reads a pyramid level back (rgb: w*h*3, proj/invproj: 9 floats; any may be NULL) -- the
+ * "undist-L<s>" embedding (dmrecon.cc:135-140) and a test hook for the pyramid kernel. */
+int  mi_dmrecon_get_level(mi_dmrecon_ctx* ctx, int32_t view_id, int32_t level, uint8_t* rgb,
+                          float* proj, float* invproj);
+
+/* DMRecon::analyzeFeatures + DMRecon::globalViewSelection (dmrecon.cc:178-241,
+ * global_view_selection.cc:33-101).  ids_out: >= MI_DMRECON_MAX_GLOBAL_VIEWS entries, ascending. */
+int  mi_dmrecon_global_view_selection(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t ref_view,
+                                      int32_t* ids_out, int32_t* n_out);
+
+/* DMRecon::start() for n_refs reference views at once (dmrecon.cc:89-172: analyzeFeatures,
+ * globalViewSelection, processFeatures, processQueue).  The views are independent; batching
+ * them fills the GPU.  maps[i] / progress[i] belong to ref_views[i]; progress may be NULL.
+ * status_out[i] (may be NULL) receives the per-view error code (e.g. MI_DMRECON_EGVS). */
+int  mi_dmrecon_reconstruct(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t n_refs,
+                            const int32_t* ref_views, mi_dmrecon_maps* maps,
+                            mi_dmrecon_progress* progress, int32_t* status_out, mi_dmrecon_stats* stats);
+
+/* Patch-level entry (parity hook; = constructing mvs::PatchOptimization, doAutoOptimization,
+ * computeConfidence -- patch_optimization.cc:21-78,170-242,114-142) for n hypotheses in
+ * reference view ref_view: xy[2n]; hyp[3n] = depth,dzI,dzJ; local[4n] view ids (-1 = none, may be NULL).
+ * out[8n] = conf, depth, dzI, dzJ, nx, ny, nz, iterationCount; out_local[4n] ascending ids, -1 padded. */
+int  mi_dmrecon_patch_optimize(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n,
+                               const int32_t* xy, const float* hyp, const int32_t* local,
+                               float* out, int32_t* out_local);
+
+/* Patch-level evaluation hook (PatchSampler::getFastNCC + fastColAndDeriv, patch_sampler.cc:64-163)
+ * of ONE hypothesis against every global view g (order of mi_dmrecon_global_view_selection):
+ * master[5] = ok, masterMeanCol, normal; ncc[g]; ok[g]; level[g]; col/deriv [g][25][3]. */
+int  mi_dmrecon_patch_eval(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t ref_view,
+                           int32_t x, int32_t y, float depth, float dzI, float dzJ,
+                           float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_DMRECON_H */

@@ -1,0 +1,369 @@
+"""ctypes binding of the C ABI in include/mi_dmrecon.h (mve_amd/csrc/libmi_dmrecon.so).
+
+This is the Python face of the same boundary the C++ shim (mve_amd/host/, class
+``mvs::DMRecon``) uses: :class:`Settings` mirrors ``mvs::Settings``
+(libs/dmrecon/settings.h:22-52), :class:`DMRecon` mirrors ``mvs::DMRecon``
+(libs/dmrecon/dmrecon.h:40-68: ctor checks, ``start()``, ``getProgress()``,
+``getRefViewNr()``), with the reference's exception types mapped onto Python's:
+``std::invalid_argument`` -> ValueError, ``std::runtime_error`` -> RuntimeError.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible,
+everything that computes raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .scene_io import SceneData
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmi_dmrecon.so")
+
+MAX_GLOBAL_VIEWS = 32
+E_INVAL, E_GVS, E_DEVICE, E_CANCELLED, E_FOOTPRINT = -1, -2, -3, -4, -5
+
+EXPORTS = [
+    "mi_dmrecon_device_count", "mi_dmrecon_last_error", "mi_dmrecon_settings_default",
+    "mi_dmrecon_ctx_create", "mi_dmrecon_ctx_destroy", "mi_dmrecon_ctx_stream",
+    "mi_dmrecon_set_view", "mi_dmrecon_evict_view", "mi_dmrecon_set_features",
+    "mi_dmrecon_num_levels", "mi_dmrecon_level_size", "mi_dmrecon_get_level",
+    "mi_dmrecon_global_view_selection", "mi_dmrecon_reconstruct",
+    "mi_dmrecon_patch_optimize", "mi_dmrecon_patch_eval",
+]
+
+
+class CCamera(ctypes.Structure):
+    _fields_ = [("flen", ctypes.c_float), ("paspect", ctypes.c_float), ("ppoint", ctypes.c_float * 2),
+                ("rot", ctypes.c_float * 9), ("trans", ctypes.c_float * 3)]
+
+
+class CSettings(ctypes.Structure):
+    _fields_ = [("filterWidth", ctypes.c_int32), ("minNCC", ctypes.c_float), ("minParallax", ctypes.c_float),
+                ("acceptNCC", ctypes.c_float), ("minRefineDiff", ctypes.c_float),
+                ("maxIterations", ctypes.c_int32), ("nrReconNeighbors", ctypes.c_int32),
+                ("globalVSMax", ctypes.c_int32), ("scale", ctypes.c_int32), ("useColorScale", ctypes.c_int32),
+                ("aabbMin", ctypes.c_float * 3), ("aabbMax", ctypes.c_float * 3)]
+
+
+class CProgress(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("filled", ctypes.c_uint64), ("queueSize", ctypes.c_uint64),
+                ("start_time", ctypes.c_uint64), ("cancelled", ctypes.c_int32)]
+
+
+class CMaps(ctypes.Structure):
+    _fields_ = [("depth", ctypes.c_void_p), ("normal", ctypes.c_void_p), ("dz", ctypes.c_void_p),
+                ("conf", ctypes.c_void_p), ("views", ctypes.c_void_p)]
+
+
+class CStats(ctypes.Structure):
+    _fields_ = [("n_patch", ctypes.c_int64), ("n_eval", ctypes.c_int64), ("n_filled", ctypes.c_int64),
+                ("n_seeds", ctypes.c_int64), ("n_seeds_ok", ctypes.c_int64), ("n_rounds", ctypes.c_int64),
+                ("n_launches", ctypes.c_int64), ("ms_total", ctypes.c_double),
+                ("ms_opt_kernel", ctypes.c_double), ("ms_sweep_kernels", ctypes.c_double)]
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libmi_dmrecon.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP library %s is missing - build it with `make -C mve_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+    L.mi_dmrecon_device_count.restype = ctypes.c_int
+    L.mi_dmrecon_last_error.restype = ctypes.c_char_p
+    L.mi_dmrecon_settings_default.argtypes = [ctypes.POINTER(CSettings)]
+    L.mi_dmrecon_settings_default.restype = None
+    L.mi_dmrecon_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.mi_dmrecon_ctx_destroy.argtypes = [vp]
+    L.mi_dmrecon_ctx_destroy.restype = None
+    L.mi_dmrecon_ctx_stream.argtypes = [vp]
+    L.mi_dmrecon_ctx_stream.restype = vp
+    L.mi_dmrecon_set_view.argtypes = [vp, i32, ctypes.POINTER(CCamera), i32, i32, i32, vp]
+    L.mi_dmrecon_evict_view.argtypes = [vp, i32]
+    L.mi_dmrecon_set_features.argtypes = [vp, i32, vp, vp, vp]
+    L.mi_dmrecon_num_levels.argtypes = [vp, i32]
+    L.mi_dmrecon_level_size.argtypes = [vp, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.mi_dmrecon_get_level.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.mi_dmrecon_global_view_selection.argtypes = [vp, ctypes.POINTER(CSettings), i32, vp, ctypes.POINTER(i32)]
+    L.mi_dmrecon_reconstruct.argtypes = [vp, ctypes.POINTER(CSettings), i32, vp, ctypes.POINTER(CMaps),
+                                         ctypes.POINTER(CProgress), vp, ctypes.POINTER(CStats)]
+    L.mi_dmrecon_patch_optimize.argtypes = [vp, ctypes.POINTER(CSettings), i32, i32, vp, vp, vp, vp, vp]
+    L.mi_dmrecon_patch_eval.argtypes = [vp, ctypes.POINTER(CSettings), i32, i32, i32, f32, f32, f32,
+                                        vp, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def device_count() -> int:
+    return int(load_library().mi_dmrecon_device_count())
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def _raise(rc: int):
+    msg = load_library().mi_dmrecon_last_error().decode("utf-8", "replace")
+    if rc == E_INVAL:
+        raise ValueError(msg)                 # std::invalid_argument
+    if rc == E_FOOTPRINT:
+        raise IndexError(msg)                 # std::out_of_range
+    if rc == E_CANCELLED:
+        raise InterruptedError(msg)
+    raise RuntimeError(msg)                   # std::runtime_error
+
+
+@dataclass
+class Settings:
+    """mvs::Settings (libs/dmrecon/settings.h:22-52), same names and defaults."""
+    refViewNr: int = 0
+    imageEmbedding: str = "undistorted"
+    filterWidth: int = 5
+    minNCC: float = 0.3
+    minParallax: float = 10.0
+    acceptNCC: float = 0.6
+    minRefineDiff: float = 0.001
+    maxIterations: int = 20
+    nrReconNeighbors: int = 4
+    globalVSMax: int = 20
+    scale: int = 0
+    useColorScale: bool = True
+    writePlyFile: bool = False
+    aabbMin: Sequence[float] = field(default_factory=lambda: [-np.finfo(np.float32).max] * 3)
+    aabbMax: Sequence[float] = field(default_factory=lambda: [np.finfo(np.float32).max] * 3)
+    plyPath: str = ""
+    keepDzMap: bool = False
+    keepConfidenceMap: bool = False
+    quiet: bool = False
+
+    def to_c(self) -> CSettings:
+        s = CSettings()
+        s.filterWidth, s.minNCC, s.minParallax = self.filterWidth, self.minNCC, self.minParallax
+        s.acceptNCC, s.minRefineDiff, s.maxIterations = self.acceptNCC, self.minRefineDiff, self.maxIterations
+        s.nrReconNeighbors, s.globalVSMax, s.scale = self.nrReconNeighbors, self.globalVSMax, self.scale
+        s.useColorScale = 1 if self.useColorScale else 0
+        s.aabbMin[:] = [float(v) for v in self.aabbMin]
+        s.aabbMax[:] = [float(v) for v in self.aabbMax]
+        return s
+
+
+class Context:
+    """One GPU context (= one scene cache on one device).  Not thread-safe."""
+
+    def __init__(self, device: int = 0):
+        self._L = load_library()
+        h = ctypes.c_void_p()
+        rc = self._L.mi_dmrecon_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            _raise(rc)
+        self._h = h
+        self.device = device
+        self.n_views = 0
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_dmrecon_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def stream(self) -> int:
+        return int(self._L.mi_dmrecon_ctx_stream(self._h) or 0)
+
+    # -- scene upload --------------------------------------------------------
+    def set_view(self, view_id: int, cam, image: np.ndarray):
+        c = CCamera()
+        c.flen, c.paspect = cam.flen, cam.paspect
+        c.ppoint[:] = list(cam.ppoint)
+        c.rot[:] = list(cam.rot)
+        c.trans[:] = list(cam.trans)
+        img = np.ascontiguousarray(image, np.uint8)
+        if img.ndim == 2:
+            img = img[:, :, None]
+        rc = self._L.mi_dmrecon_set_view(self._h, view_id, ctypes.byref(c), img.shape[1], img.shape[0],
+                                         img.shape[2], _ptr(img))
+        if rc != 0:
+            _raise(rc)
+        self.n_views = max(self.n_views, view_id + 1)
+
+    def set_features(self, features):
+        pos = np.asarray([f.pos for f in features], np.float32).reshape(-1, 3)
+        off = np.zeros(len(features) + 1, np.int32)
+        off[1:] = np.cumsum([len(f.view_ids) for f in features])
+        refs = np.asarray([v for f in features for v in f.view_ids], np.int32)
+        if refs.size == 0:
+            refs = np.zeros(1, np.int32)
+        rc = self._L.mi_dmrecon_set_features(self._h, len(features), _ptr(pos), _ptr(off), _ptr(refs))
+        if rc != 0:
+            _raise(rc)
+
+    def load_scene(self, scene: SceneData):
+        for vid, (cam, img) in enumerate(zip(scene.cameras, scene.images)):
+            if img is not None:
+                self.set_view(vid, cam, img)
+        self.set_features(scene.features)
+
+    # -- queries -------------------------------------------------------------
+    def num_levels(self, view_id: int) -> int:
+        n = self._L.mi_dmrecon_num_levels(self._h, view_id)
+        if n < 0:
+            _raise(n)
+        return n
+
+    def level_size(self, view_id: int, level: int):
+        w, h = ctypes.c_int32(), ctypes.c_int32()
+        rc = self._L.mi_dmrecon_level_size(self._h, view_id, level, ctypes.byref(w), ctypes.byref(h))
+        if rc != 0:
+            _raise(rc)
+        return w.value, h.value
+
+    def get_level(self, view_id: int, level: int):
+        w, h = self.level_size(view_id, level)
+        rgb = np.zeros((h, w, 3), np.uint8)
+        proj = np.zeros(9, np.float32)
+        inv = np.zeros(9, np.float32)
+        rc = self._L.mi_dmrecon_get_level(self._h, view_id, level, _ptr(rgb), _ptr(proj), _ptr(inv))
+        if rc != 0:
+            _raise(rc)
+        return rgb, proj, inv
+
+    def global_view_selection(self, st: Settings, ref_view: Optional[int] = None) -> List[int]:
+        ids = np.zeros(MAX_GLOBAL_VIEWS, np.int32)
+        n = ctypes.c_int32()
+        cs = st.to_c()
+        rc = self._L.mi_dmrecon_global_view_selection(self._h, ctypes.byref(cs),
+                                                      st.refViewNr if ref_view is None else ref_view,
+                                                      _ptr(ids), ctypes.byref(n))
+        if rc != 0:
+            _raise(rc)
+        return [int(v) for v in ids[:n.value]]
+
+    # -- the hot path ----------------------------------------------------------
+    def reconstruct(self, st: Settings, ref_views: Sequence[int], want_normal=True, want_views=False,
+                    progress: Optional[ctypes.Array] = None) -> List[Dict]:
+        """DMRecon::start() for a batch of reference views; returns one dict of maps per view."""
+        n = len(ref_views)
+        refs = np.asarray(ref_views, np.int32)
+        cs = st.to_c()
+        maps = (CMaps * n)()
+        out = []
+        for i, r in enumerate(ref_views):
+            w, h = self.level_size(int(r), st.scale)
+            d = dict(depth=np.zeros((h, w), np.float32), dz=np.zeros((h, w, 2), np.float32),
+                     conf=np.zeros((h, w), np.float32))
+            if want_normal:
+                d["normal"] = np.zeros((h, w, 3), np.float32)
+            if want_views:
+                d["views"] = np.full((h, w, 4), -1, np.int32)
+            maps[i].depth, maps[i].dz, maps[i].conf = _ptr(d["depth"]), _ptr(d["dz"]), _ptr(d["conf"])
+            maps[i].normal = _ptr(d.get("normal"))
+            maps[i].views = _ptr(d.get("views"))
+            out.append(d)
+        status = np.zeros(n, np.int32)
+        stats = CStats()
+        rc = self._L.mi_dmrecon_reconstruct(self._h, ctypes.byref(cs), n, _ptr(refs), maps, progress,
+                                            _ptr(status), ctypes.byref(stats))
+        if rc != 0:
+            _raise(rc)
+        self.last_stats = {k: getattr(stats, k) for k, _ in CStats._fields_}
+        for i in range(n):
+            out[i]["status"] = int(status[i])
+        return out
+
+    def patch_optimize(self, st: Settings, ref_view: int, xy, hyp, local=None):
+        xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
+        n = len(xy)
+        hyp = np.ascontiguousarray(hyp, np.float32).reshape(n, 3)
+        loc = None if local is None else np.ascontiguousarray(local, np.int32).reshape(n, 4)
+        out = np.zeros((n, 8), np.float32)
+        out_local = np.zeros((n, 4), np.int32)
+        cs = st.to_c()
+        rc = self._L.mi_dmrecon_patch_optimize(self._h, ctypes.byref(cs), ref_view, n, _ptr(xy), _ptr(hyp),
+                                               _ptr(loc), _ptr(out), _ptr(out_local))
+        if rc != 0:
+            _raise(rc)
+        return out, out_local
+
+    def patch_eval(self, st: Settings, ref_view: int, x: int, y: int, depth: float, dzi=0.0, dzj=0.0):
+        g = MAX_GLOBAL_VIEWS
+        master = np.zeros(5, np.float32)
+        ncc = np.zeros(g, np.float32)
+        ok = np.zeros(g, np.int32)
+        col = np.zeros((g, 25, 3), np.float32)
+        der = np.zeros((g, 25, 3), np.float32)
+        lvl = np.zeros(g, np.int32)
+        cs = st.to_c()
+        n = self._L.mi_dmrecon_patch_eval(self._h, ctypes.byref(cs), ref_view, x, y, depth, dzi, dzj,
+                                          _ptr(master), _ptr(ncc), _ptr(ok), _ptr(col), _ptr(der), _ptr(lvl))
+        if n < 0:
+            _raise(n)
+        return dict(master=master, ncc=ncc[:n], ok=ok[:n], col=col[:n], deriv=der[:n], level=lvl[:n])
+
+
+class DMRecon:
+    """mvs::DMRecon (libs/dmrecon/dmrecon.h:40-68) over the C ABI.
+
+    ``scene`` is a :class:`Context` that already holds the views and features
+    (the role ``mve::Scene::Ptr`` plays in the reference).  ``start()`` stores the
+    maps under the embedding names the reference uses (dmrecon.cc:119-145).
+    """
+
+    def __init__(self, scene: Context, settings: Settings):
+        self.scene = scene
+        self.settings = settings
+        self.progress = CProgress()
+        self.images: Dict[str, np.ndarray] = {}
+        # ctor checks of dmrecon.cc:37-46,74-75
+        if settings.refViewNr < 0 or settings.refViewNr >= scene.n_views:
+            raise ValueError("Master view index out of bounds")
+        if settings.scale < 0:
+            raise ValueError("Invalid scale factor")
+        if not settings.imageEmbedding:
+            raise ValueError("Invalid image embedding")
+        try:
+            self.width, self.height = scene.level_size(settings.refViewNr, settings.scale)
+        except ValueError:
+            raise ValueError("Invalid master view")
+
+    def getRefViewNr(self) -> int:
+        return self.settings.refViewNr
+
+    def getProgress(self) -> CProgress:
+        return self.progress
+
+    def start(self):
+        st = self.settings
+        arr = (CProgress * 1)(self.progress)
+        try:
+            res = self.scene.reconstruct(st, [st.refViewNr], progress=arr)[0]
+        except InterruptedError:
+            self.progress.status = 5      # RECON_CANCELLED, nothing is written (dmrecon.cc:101-105)
+            return
+        finally:
+            for k, _ in CProgress._fields_:
+                if k != "cancelled":
+                    setattr(self.progress, k, getattr(arr[0], k))
+        name = "-L%d" % st.scale
+        self.images["depth" + name] = res["depth"]
+        if st.keepDzMap:
+            self.images["dz" + name] = res["dz"]
+        if st.keepConfidenceMap:
+            self.images["conf" + name] = res["conf"]
+        if st.scale != 0:
+            self.images["undist" + name] = self.scene.get_level(st.refViewNr, st.scale)[0]
+        self.normal = res.get("normal")
+        self.progress.filled = int((res["conf"] > 0).sum())

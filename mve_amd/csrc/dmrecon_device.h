@@ -1,0 +1,25 @@
+/* Host-callable launchers of the kernels in dmrecon_device.hip (internal). */
+#ifndef MI_DMRECON_DEVICE_H
+#define MI_DMRECON_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include "dmrecon_types.h"
+
+void mi_launch_optimize(hipStream_t s, const DevJob* jobs, const DevView* views, const float* lut,
+                        const DevSettings& st, const DevEntry* work, const DevHyp* hyp, DevResult* results,
+                        const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
+void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
+                          const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
+                          float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
+void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_pixels, DevEntry* work,
+                        DevCounters* counters, int round);
+void mi_launch_apply(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
+                     unsigned n_work, int round, DevCounters* counters);
+void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
+                           unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
+                           const unsigned* key_off);
+void mi_launch_pack_rgba(hipStream_t s, const uint8_t* src, uint32_t* dst, int n, int channels);
+void mi_launch_unpack_rgb(hipStream_t s, const uint32_t* src, uint8_t* dst, int n);
+void mi_launch_pyramid(hipStream_t s, const uint32_t* src, uint32_t* dst, int iw, int ih, int ow, int oh,
+                       float w1, float w2, float w3);
+#endif

@@ -1,0 +1,1095 @@
+/*
+ * dmrecon_device.hip -- gfx950 kernels of the MI355X-native dmrecon hot path.
+ *
+ * What the reference does one pixel at a time on one CPU thread
+ * (libs/dmrecon: DMRecon::processQueue -> PatchOptimization -> PatchSampler),
+ * this file does as data-parallel sweeps:
+ *
+ *   k_generate  one lane per reference-image pixel: "did a 4-neighbour get a
+ *               better hypothesis last round?" (the push rule of
+ *               dmrecon.cc:400-431 turned into a pull), ballot-compacted into a
+ *               dense work list.
+ *   k_optimize  the hot kernel.  A pixel's patch optimisation
+ *               (patch_optimization.cc:170-242) is run by a QUAD of lanes, one
+ *               lane per local neighbour view (nrReconNeighbors = 4): each lane
+ *               projects the 25 patch points into its view, gathers the
+ *               bilinear RGBA8 texels, and the Gauss-Newton / NCC sums are
+ *               combined with DPP quad permutes -- no LDS round trip, no
+ *               per-lane view loop.  A 64-wide wavefront therefore advances 16
+ *               pixels x 4 views in lock step.  Per-patch data shared by the quad
+ *               (25 master colours, 25 view rays, NCC scratch for view
+ *               selection) and the sRGB->linear table live in LDS.
+ *   k_apply     writes accepted results back to the state maps (Jacobi sweep:
+ *               all of a round's optimisations read the previous round's state).
+ *   k_pyramid   byte-exact 4x4 Gaussian half-size pyramid (image_tools.h:619-690).
+ *
+ * No MFMA: every reduction here is a 75-term dot product per lane.
+ * Reference citations are relative to /root/reference/libs/dmrecon unless noted.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dmrecon_types.h"
+#include "dmrecon_device.h"
+
+#define QUAD 4
+#define WAVE 64
+
+/* LDS of one 64-lane workgroup = 16 patches (file scope so that the one non-inlined
+ * device function below addresses it with ds_* instructions, not flat ones). */
+__shared__ float g_lut[256];                                   /* sRGB -> linear, mvs_tools.cc:22-93 */
+__shared__ float g_rays[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterViewDirs */
+__shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterColorSamples */
+__shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelection ncc[] */
+
+/* ------------------------------------------------------------------------- */
+/* quad (4-lane) communication through DPP quad_perm -- no LDS traffic.       */
+
+__device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_xor2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }
+template <int K> __device__ __forceinline__ int dpp_bcast(int v) { return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xF, 0xF, true); }
+
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(dpp_xor1(__float_as_int(v)));
+    v += __int_as_float(dpp_xor2(__float_as_int(v)));
+    return v;
+}
+__device__ __forceinline__ double quad_sum(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    v += __hiloint2double(dpp_xor1(hi), dpp_xor1(lo));
+    lo = __double2loint(v); hi = __double2hiint(v);
+    v += __hiloint2double(dpp_xor2(hi), dpp_xor2(lo));
+    return v;
+}
+__device__ __forceinline__ int quad_or(int v) { v |= dpp_xor1(v); v |= dpp_xor2(v); return v; }
+template <int K> __device__ __forceinline__ float quad_bcastf(float v) { return __int_as_float(dpp_bcast<K>(__float_as_int(v))); }
+/* 4-bit mask of a predicate over the lanes of my quad */
+__device__ __forceinline__ unsigned quad_ballot(bool p, int lane) {
+    unsigned long long b = __ballot(p);
+    return (unsigned)(b >> (lane & ~3)) & 0xFu;
+}
+
+/* ------------------------------------------------------------------------- */
+
+struct PatchState {
+    /* quad-uniform */
+    const DevJob* job;
+    int x, y;
+    float depth, dzI, dzJ;
+    float xbar0, xbar1, xbar2;   /* PatchSampler::meanX */
+    float sqrDevX, mmean;        /* PatchSampler::sqrDevX, masterMeanCol */
+    float mfp;                   /* footPrintScaled(centre point) at the current state */
+    float p0x, p0y, p0z;         /* centre patch point (patchPoints[12]) */
+    unsigned avail;              /* LocalViewSelection::available over global indices */
+    /* per lane */
+    int sel;                     /* my view: index into job->global_ids, or -1 */
+    float cs0, cs1, cs2;         /* PatchOptimization::colorScale[my view] */
+    float ncc;                   /* getFastNCC(my view) at the current state */
+    /* counters (per lane, flushed at kernel end) */
+    unsigned n_eval, n_pass;
+};
+
+struct NView {                   /* my neighbour view at the selected mip level */
+    float m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11;
+    float ax, ay, cx, cy;
+    int w, h;
+    const uint32_t* img;
+};
+
+__device__ __forceinline__ void project(const NView& nv, float px, float py, float pz, float& u, float& v) {
+    /* SingleView::worldToScreen, single_view.h:187-195 */
+    float cx_ = nv.m0 * px + nv.m1 * py + nv.m2 * pz + nv.m3;
+    float cy_ = nv.m4 * px + nv.m5 * py + nv.m6 * pz + nv.m7;
+    float cz_ = nv.m8 * px + nv.m9 * py + nv.m10 * pz + nv.m11;
+    float sx = nv.ax * cx_ + nv.cx * cz_;
+    float sy = nv.ay * cy_ + nv.cy * cz_;
+    u = sx / cz_ - 0.5f;
+    v = sy / cz_ - 0.5f;
+}
+
+/* mip level rule of patch_sampler.cc:72-91 / :353-373.  Returns false if nfp <= 0. */
+__device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, int view_id, const PatchState& ps,
+                                           NView& nv, int& level) {
+    const DevView* V = views + view_id;
+    nv.m0 = V->w2c[0]; nv.m1 = V->w2c[1]; nv.m2 = V->w2c[2]; nv.m3 = V->w2c[3];
+    nv.m4 = V->w2c[4]; nv.m5 = V->w2c[5]; nv.m6 = V->w2c[6]; nv.m7 = V->w2c[7];
+    nv.m8 = V->w2c[8]; nv.m9 = V->w2c[9]; nv.m10 = V->w2c[10]; nv.m11 = V->w2c[11];
+    float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
+    float nfp = z * V->lv[0].inv0;               /* SingleView::footPrint */
+    if (!(nfp > 0.f)) return false;
+    float ratio = nfp / ps.mfp;
+    int mm = 0;
+    while (ratio < 0.5f && mm < MI_MAX_LEVELS) { ++mm; ratio *= 2.f; }
+    int maxl = V->n_levels - 1;                  /* clampLevel with minLevel 0 (dmrecon.cc:240) */
+    mm = mm > maxl ? maxl : mm;
+    level = mm;
+    const DevLevel& L = V->lv[mm];
+    nv.ax = L.ax; nv.ay = L.ay; nv.cx = L.cx; nv.cy = L.cy;
+    nv.w = L.w; nv.h = L.h;
+    nv.img = V->img + L.tex_off;
+    return true;
+}
+
+struct ColorSums {               /* shifted one-pass sums of one colour pass */
+    float s0, s1, s2;            /* shift = colour of sample 0 */
+    float a0, a1, a2;            /* sum (n - s) */
+    float aa0, aa1, aa2;         /* sum (n - s)^2 */
+    float ba0, ba1, ba2;         /* sum (m - xbar)(n - s) */
+};
+
+enum { PASS_COLOR = 0, PASS_DEPTH = 1, PASS_NORMAL = 2, PASS_DUMP = 3 };
+
+struct GNSums {
+    float num, den;              /* optimizeDepthOnly */
+    double A00, A01, A02, A11, A12, A22, B0, B1, B2;   /* optimizeDepthAndNormal */
+};
+
+/*
+ * One patch-view evaluation: the 25 samples of my view (SURVEY 8d unit of work).
+ * PASS_COLOR  = computeNeighColorSamples + the sums getFastNCC / computeColorScale need
+ *               (patch_sampler.cc:347-393,135-163; patch_optimization.cc:81-111)
+ * PASS_DEPTH  = fastColAndDeriv + the sums of optimizeDepthOnly (patch_sampler.cc:64-133,
+ *               mvs_tools.cc:97-145, patch_optimization.cc:265-299)
+ * PASS_NORMAL = fastColAndDeriv + the normal equations of optimizeDepthAndNormal (:302-364)
+ * PASS_DUMP   = fastColAndDeriv, samples written to dump_col / dump_der (parity hook)
+ * Returns PatchSampler::success[v].
+ */
+template <int MODE>
+__device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& nv, const float* __restrict__ s_lut,
+                                            const float* __restrict__ rays, const float* __restrict__ mcol,
+                                            ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der) {
+    const float cpx = ps.job->cam_pos[0], cpy = ps.job->cam_pos[1], cpz = ps.job->cam_pos[2];
+    float step = 0.f;
+    if (MODE != PASS_COLOR) {
+        /* derivative step size from the centre sample (patch_sampler.cc:93-100; sample 12 hard-coded there) */
+        float rx = rays[36], ry = rays[37], rz = rays[38];
+        float u0, v0, u1, v1;
+        project(nv, ps.p0x, ps.p0y, ps.p0z, u0, v0);
+        project(nv, ps.p0x + rx, ps.p0y + ry, ps.p0z + rz, u1, v1);
+        float du = u1 - u0, dv = v1 - v0;
+        float d = sqrtf(du * du + dv * dv);
+        if (!(d > 0.f)) return false;
+        step = 1.f / d;
+    }
+    bool ok = true;
+    const float wlim = (float)(nv.w - 1), hlim = (float)(nv.h - 1);
+    ColorSums S;
+    S.s0 = S.s1 = S.s2 = 0.f; S.a0 = S.a1 = S.a2 = 0.f; S.aa0 = S.aa1 = S.aa2 = 0.f; S.ba0 = S.ba1 = S.ba2 = 0.f;
+    float num = 0.f, den = 0.f;
+    double A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, B0 = 0, B1 = 0, B2 = 0;
+
+    for (int i = 0; i < MI_NS; ++i) {
+        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
+        const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;      /* computePatchPoints */
+        const float px = cpx + t * rx, py = cpy + t * ry, pz = cpz + t * rz;
+        float u, v;
+        project(nv, px, py, pz, u, v);
+        /* strict interior test (patch_sampler.cc:116-119, :386-389) */
+        ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
+        float gu = 0.f, gv = 0.f;
+        if (MODE != PASS_COLOR) {
+            float u1, v1;
+            project(nv, px + rx * step, py + ry * step, pz + rz * step, u1, v1);
+            gu = u1 - u; gv = v1 - v;
+        }
+        /* memory-safe even when the sample is outside (result discarded through ok) */
+        float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
+        if (!(uc == uc)) uc = 0.f;
+        if (!(vc == vc)) vc = 0.f;
+        const int left = (int)floorf(uc), top = (int)floorf(vc);
+        const float fx = uc - (float)left, fy = vc - (float)top;
+        const uint32_t* r0 = nv.img + (size_t)top * nv.w + left;
+        const uint32_t t00 = r0[0], t10 = r0[1], t01 = r0[nv.w], t11 = r0[nv.w + 1];
+        float n[3], dr[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float c00 = s_lut[(t00 >> (8 * c)) & 255u], c10 = s_lut[(t10 >> (8 * c)) & 255u];
+            const float c01 = s_lut[(t01 >> (8 * c)) & 255u], c11 = s_lut[(t11 >> (8 * c)) & 255u];
+            /* mvs_tools.cc:119-128 */
+            const float xa = (1.f - fx) * c00 + fx * c10;
+            const float xb = (1.f - fx) * c01 + fx * c11;
+            n[c] = (1.f - fy) * xa + fy * xb;
+            if (MODE != PASS_COLOR) {
+                /* exact directional derivative of the bilinear surface, mvs_tools.cc:131-143; /= stepSize */
+                dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) / step;
+            }
+        }
+        const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
+        if (MODE == PASS_COLOR) {
+            if (i == 0) { S.s0 = n[0]; S.s1 = n[1]; S.s2 = n[2]; }
+            const float a0 = n[0] - S.s0, a1 = n[1] - S.s1, a2 = n[2] - S.s2;
+            S.a0 += a0; S.a1 += a1; S.a2 += a2;
+            S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
+            S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
+        } else if (MODE == PASS_DUMP) {
+            dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
+            dump_der[3 * i] = dr[0]; dump_der[3 * i + 1] = dr[1]; dump_der[3 * i + 2] = dr[2];
+        } else {
+            const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
+            const float r0_ = m0 - ps.cs0 * n[0], r1_ = m1 - ps.cs1 * n[1], r2_ = m2 - ps.cs2 * n[2];
+            const float gg = g0 * g0 + g1 * g1 + g2 * g2;
+            const float gr = g0 * r0_ + g1 * r1_ + g2 * r2_;
+            if (MODE == PASS_DEPTH) {
+                num += gr; den += gg;
+            } else {
+                const float fi = (float)di, fj = (float)dj;
+                A00 += (double)gg; A01 += (double)(fi * gg); A02 += (double)(fj * gg);
+                A11 += (double)(fi * fi * gg); A12 += (double)(fi * fj * gg); A22 += (double)(fj * fj * gg);
+                B0 += (double)gr; B1 += (double)(fi * gr); B2 += (double)(fj * gr);
+            }
+        }
+    }
+    if (MODE == PASS_COLOR) cs_out = S;
+    if (MODE == PASS_DEPTH) { gn.num = num; gn.den = den; }
+    if (MODE == PASS_NORMAL) { gn.A00 = A00; gn.A01 = A01; gn.A02 = A02; gn.A11 = A11; gn.A12 = A12; gn.A22 = A22; gn.B0 = B0; gn.B1 = B1; gn.B2 = B2; }
+    return ok;
+}
+
+/* getFastNCC from the shifted sums (patch_sampler.cc:135-163) */
+__device__ __forceinline__ float ncc_from_sums(const PatchState& ps, const ColorSums& S) {
+    const float inv_n = 1.f / (float)MI_NS;
+    const float sqrDevY = (S.aa0 - S.a0 * S.a0 * inv_n) + (S.aa1 - S.a1 * S.a1 * inv_n) + (S.aa2 - S.a2 * S.a2 * inv_n);
+    const float devXY = S.ba0 + S.ba1 + S.ba2;
+    const float tmp = sqrtf(ps.sqrDevX * fmaxf(sqrDevY, 0.f));
+    return tmp > 0.f ? devXY / tmp : -1.f;
+}
+
+/* Colour pass of view `gidx` (index into the job's global list) -> NCC; -1 on failure. */
+__device__ __forceinline__ float eval_color(PatchState& ps, const DevView* views, int gidx, const float* s_lut,
+                                            const float* rays, const float* mcol, ColorSums& S, bool& ok, bool count) {
+    NView nv; int level; GNSums gn;
+    ok = false;
+    if (gidx < 0) return -1.f;
+    if (!setup_view(views, ps.job->global_ids[gidx], ps, nv, level)) return -1.f;
+    ok = sample_pass<PASS_COLOR>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr);
+    ps.n_pass++;
+    if (!ok) return -1.f;
+    if (count) ps.n_eval++;
+    return ncc_from_sums(ps, S);
+}
+
+/* PatchSampler::update + the quantities that depend on the state (patch_sampler.cc:258-295) */
+__device__ __forceinline__ bool set_state(PatchState& ps, const float* rays, float depth, float dzI, float dzJ) {
+    ps.depth = depth; ps.dzI = dzI; ps.dzJ = dzJ;
+    /* tmpDepth is linear in (i, j): its minimum over the window is at a corner */
+    const float a = 2.f * fabsf(dzI) + 2.f * fabsf(dzJ);
+    bool ok = (depth - a) > 0.f && depth == depth && a == a;
+    const DevJob* J = ps.job;
+    ps.p0x = J->cam_pos[0] + depth * rays[36];
+    ps.p0y = J->cam_pos[1] + depth * rays[37];
+    ps.p0z = J->cam_pos[2] + depth * rays[38];
+    const float z = J->w2c_z[0] * ps.p0x + J->w2c_z[1] * ps.p0y + J->w2c_z[2] * ps.p0z + J->w2c_z[3];
+    ps.mfp = z * J->inv0_s;                           /* footPrintScaled */
+    return ok;
+}
+
+/* computeColorScale for my view from the colour-pass sums (patch_optimization.cc:81-111).
+ * Returns false where the reference sets optiSuccess = false. */
+__device__ __forceinline__ bool color_scale_update(PatchState& ps, const ColorSums& S) {
+    const float N = (float)MI_NS;
+    bool good = true;
+    float* cs[3] = {&ps.cs0, &ps.cs1, &ps.cs2};
+    const float s[3] = {S.s0, S.s1, S.s2}, a[3] = {S.a0, S.a1, S.a2}, aa_[3] = {S.aa0, S.aa1, S.aa2};
+    const float ba[3] = {S.ba0, S.ba1, S.ba2}, xb[3] = {ps.xbar0, ps.xbar1, ps.xbar2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float nn = aa_[c] + 2.f * s[c] * a[c] + N * s[c] * s[c];              /* sum n^2 */
+        const float mn = ba[c] + xb[c] * a[c] + N * xb[c] * s[c];                   /* sum m n  */
+        const float ab = mn - (*cs[c]) * nn;
+        if (fabsf(nn) > 1e-6f) {
+            *cs[c] += ab / nn;
+            if (*cs[c] > 1e3f) good = false;
+        } else
+            good = false;
+    }
+    return good;
+}
+
+__device__ __forceinline__ float parallax_to_weight(float p) {   /* mvs_tools.h:58-69 */
+    if (p < 0.f || p > 180.f) return 0.f;
+    const float sigma = (p <= 20.f) ? 5.f : 15.f;
+    const float d = p - 20.f;
+    return expf(-(d * d) / (2.f * sigma * sigma));
+}
+
+__device__ __forceinline__ void unit_dir(const float* cam, float px, float py, float pz, float& dx, float& dy, float& dz) {
+    dx = px - cam[0]; dy = py - cam[1]; dz = pz - cam[2];
+    const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx /= n; dy /= n; dz /= n;
+}
+__device__ __forceinline__ void unit_cross(float ax, float ay, float az, float bx, float by, float bz,
+                                           float& cx, float& cy, float& cz) {
+    cx = ay * bz - az * by; cy = az * bx - ax * bz; cz = ax * by - ay * bx;
+    const float n = sqrtf(cx * cx + cy * cy + cz * cz);
+    cx /= n; cy /= n; cz /= n;
+}
+#define RAD2DEG 57.29577951308232f
+
+/*
+ * LocalViewSelection::performVS (local_view_selection.cc:56-147), one quad per patch.
+ * Candidates (bits of ps.avail) are spread over the four lanes; NCCs go through s_ncc.
+ * On return each lane's ps.sel holds its view (or -1); returns success.
+ */
+__device__ __noinline__ bool local_view_selection(PatchState& ps, const DevSettings& st, const DevView* views, int lane) {
+    const float* s_lut = g_lut;
+    const float* rays = g_rays[lane >> 2];
+    const float* mcol = g_mcol[lane >> 2];
+    float* s_ncc = g_ncc[lane >> 2];
+    const int slot = lane & 3;
+    const int K = st.K;
+    unsigned selmask = quad_ballot(ps.sel >= 0, lane);
+    if (__popc(selmask) == K) return true;
+    const DevJob* J = ps.job;
+    const int G = J->n_global;
+    /* NCC of every available candidate at the current state; drop those below minNCC */
+    unsigned drop = 0;
+    for (int g = slot; g < G; g += QUAD) {
+        if (!((ps.avail >> g) & 1u)) continue;
+        ColorSums S; bool ok;
+        const float t = eval_color(ps, views, g, s_lut, rays, mcol, S, ok, true);
+        if (t < st.minNCC) drop |= 1u << g;
+        s_ncc[g] = t;
+    }
+    drop = (unsigned)quad_or((int)drop);
+    ps.avail &= ~drop;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    float rdx, rdy, rdz;
+    unit_dir(J->cam_pos, ps.p0x, ps.p0y, ps.p0z, rdx, rdy, rdz);       /* refDir */
+    for (;;) {
+        selmask = quad_ballot(ps.sel >= 0, lane);
+        if (__popc(selmask) >= K) break;
+        /* the currently selected views, visible to every lane of the quad */
+        int sl[4];
+        sl[0] = dpp_bcast<0>(ps.sel); sl[1] = dpp_bcast<1>(ps.sel); sl[2] = dpp_bcast<2>(ps.sel); sl[3] = dpp_bcast<3>(ps.sel);
+        float best = 0.f; int bestg = -1;
+        for (int g = slot; g < G; g += QUAD) {
+            if (!((ps.avail >> g) & 1u)) continue;
+            const DevView* V = views + J->global_ids[g];
+            float score = s_ncc[g];
+            const float z = V->w2c[8] * ps.p0x + V->w2c[9] * ps.p0y + V->w2c[10] * ps.p0z + V->w2c[11];
+            const float nfp = z * V->lv[0].inv0;
+            if (ps.mfp / nfp < 0.5f) score *= 0.01f;
+            float vx, vy, vz;
+            unit_dir(V->cam_pos, ps.p0x, ps.p0y, ps.p0z, vx, vy, vz);
+            float dp = fminf(fmaxf(rdx * vx + rdy * vy + rdz * vz, -1.f), 1.f);
+            score *= parallax_to_weight(acosf(dp) * RAD2DEG);
+            float ex, ey, ez;
+            unit_cross(vx, vy, vz, rdx, rdy, rdz, ex, ey, ez);          /* epipolarPlane[i] */
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (sl[k] < 0) continue;
+                const DevView* U = views + J->global_ids[sl[k]];
+                float sx, sy, sz;
+                unit_dir(U->cam_pos, ps.p0x, ps.p0y, ps.p0z, sx, sy, sz);
+                dp = fminf(fmaxf(sx * vx + sy * vy + sz * vz, -1.f), 1.f);
+                score *= parallax_to_weight(acosf(dp) * RAD2DEG);
+                float fx, fy, fz;
+                unit_cross(sx, sy, sz, rdx, rdy, rdz, fx, fy, fz);
+                dp = fminf(fmaxf(ex * fx + ey * fy + ez * fz, -1.f), 1.f);
+                float angle = fabsf(acosf(dp) * RAD2DEG);
+                if (angle > 90.f) angle = 180.f - angle;
+                angle = fmaxf(angle, 1.f);
+                if (angle < st.minParallax) score *= angle / st.minParallax;
+            }
+            if (score > best) { best = score; bestg = g; }
+        }
+        /* quad arg-max; ties -> lowest index (strict '>' in an ascending scan, :134-138) */
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float ob = __int_as_float(r == 0 ? dpp_xor1(__float_as_int(best)) : dpp_xor2(__float_as_int(best)));
+            const int og = r == 0 ? dpp_xor1(bestg) : dpp_xor2(bestg);
+            const bool take = og >= 0 && (bestg < 0 || ob > best || (ob == best && og < bestg));
+            if (take) { best = ob; bestg = og; }
+        }
+        if (bestg < 0) break;                                       /* foundOne == false */
+        ps.avail &= ~(1u << bestg);
+        /* give the view to the lowest free lane */
+        const unsigned freemask = ~selmask & ((1u << K) - 1u);
+        const int target = __ffs(freemask) - 1;
+        if (slot == target) {
+            ps.sel = bestg;
+            const float inv = 1.f / ps.mmean;                       /* colorScale init, patch_optimization.cc:73-76 */
+            ps.cs0 = ps.cs1 = ps.cs2 = inv;
+            ps.ncc = s_ncc[bestg];
+        }
+    }
+    selmask = quad_ballot(ps.sel >= 0, lane);
+    return __popc(selmask) == K;
+}
+
+/* rank of my view among the quad's selected views (std::set iteration order = ascending id) */
+__device__ __forceinline__ unsigned lower_ok_mask(const PatchState& ps, bool my_ok) {
+    /* returns true-ness of: every selected view with a smaller id sampled successfully */
+    int s[4]; int o[4];
+    const int mo = my_ok ? 1 : 0;
+    s[0] = dpp_bcast<0>(ps.sel); s[1] = dpp_bcast<1>(ps.sel); s[2] = dpp_bcast<2>(ps.sel); s[3] = dpp_bcast<3>(ps.sel);
+    o[0] = dpp_bcast<0>(mo); o[1] = dpp_bcast<1>(mo); o[2] = dpp_bcast<2>(mo); o[3] = dpp_bcast<3>(mo);
+    unsigned all = 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (s[k] >= 0 && s[k] < ps.sel && !o[k]) all = 0;
+    return all;
+}
+
+struct PatchResult { float conf, depth, dzI, dzJ, nx, ny, nz; unsigned views; int iters; };
+
+/* colour pass of my view + NCC (+ optional computeColorScale); returns false where optiSuccess turns false */
+__device__ __forceinline__ bool refresh_color(PatchState& ps, const DevSettings& st, const DevView* views,
+                                              const float* s_lut, const float* rays, const float* mcol,
+                                              bool do_scale, bool count, int lane) {
+    ColorSums S; bool ok;
+    ps.ncc = eval_color(ps, views, ps.sel, s_lut, rays, mcol, S, ok, count);
+    bool good = true;
+    if (do_scale && st.useColorScale) {
+        const bool active = ps.sel >= 0;
+        const unsigned lower = lower_ok_mask(ps, ok || !active);
+        if (active && ok && lower) good = color_scale_update(ps, S);
+    }
+    return quad_ballot(!good, lane) == 0;
+}
+
+/*
+ * PatchOptimization ctor + doAutoOptimization + computeConfidence for one patch, run by a quad.
+ * hyp_views: packed global indices of the propagated local view set (MI_VIEW_NONE = none).
+ */
+__device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
+                               float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane,
+                               PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err) {
+    const float* s_lut = g_lut;
+    float* rays = g_rays[lane >> 2];
+    float* mcol = g_mcol[lane >> 2];
+    const int slot = lane & 3;
+    res.conf = 0.f; res.depth = depth0; res.dzI = dzI0; res.dzJ = dzJ0; res.nx = res.ny = res.nz = 0.f;
+    res.views = 0xFFFFFFFFu; res.iters = 0;
+    PatchState ps;
+    ps.job = job; ps.x = x; ps.y = y; ps.n_eval = 0; ps.n_pass = 0;
+    ps.sel = -1; ps.cs0 = ps.cs1 = ps.cs2 = 1.f; ps.ncc = -1.f;
+    /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
+    if (x - 2 < 0 || y - 2 < 0 || x + 2 > job->w - 1 || y + 2 > job->h - 1) return;
+    /* view rays (single_view.cc:106-114, mve/depthmap.cc:149-156) and raw master colours into LDS */
+    const DevView* RV = views + job->ref_view;
+    const DevLevel& RL = RV->lv[job->scale];
+    const uint32_t* rimg = RV->img + RL.tex_off;
+    for (int i = slot; i < MI_NS; i += QUAD) {
+        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const float fx = (float)(x + di) + 0.5f, fy = (float)(y + dj) + 0.5f;
+        float rx = job->inv_a * fx + job->inv_c, ry = job->inv_b * fy + job->inv_d, rz = 1.f;
+        const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
+        rx /= nrm; ry /= nrm; rz /= nrm;
+        rays[3 * i] = job->rot_t[0] * rx + job->rot_t[1] * ry + job->rot_t[2] * rz;
+        rays[3 * i + 1] = job->rot_t[3] * rx + job->rot_t[4] * ry + job->rot_t[5] * rz;
+        rays[3 * i + 2] = job->rot_t[6] * rx + job->rot_t[7] * ry + job->rot_t[8] * rz;
+        const uint32_t t = rimg[(size_t)(y + dj) * RL.w + (x + di)];
+        mcol[3 * i] = s_lut[t & 255u]; mcol[3 * i + 1] = s_lut[(t >> 8) & 255u]; mcol[3 * i + 2] = s_lut[(t >> 16) & 255u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    /* computeMasterSamples (patch_sampler.cc:297-345): every lane of the quad redundantly */
+    float mm = 0.f;
+    for (int k = 0; k < 3 * MI_NS; ++k) mm += mcol[k];
+    mm /= 3.f * (float)MI_NS;
+    if (mm < 0.01f || mm > 0.99f) return;
+    ps.mmean = mm;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int i = slot; i < MI_NS; i += QUAD) { mcol[3 * i] /= mm; mcol[3 * i + 1] /= mm; mcol[3 * i + 2] /= mm; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    for (int i = 0; i < MI_NS; ++i) { x0 += mcol[3 * i]; x1 += mcol[3 * i + 1]; x2 += mcol[3 * i + 2]; }
+    x0 /= (float)MI_NS; x1 /= (float)MI_NS; x2 /= (float)MI_NS;
+    ps.xbar0 = x0; ps.xbar1 = x1; ps.xbar2 = x2;
+    float sd = 0.f;
+    for (int i = 0; i < MI_NS; ++i) {
+        const float a = mcol[3 * i] - x0, b = mcol[3 * i + 1] - x1, c = mcol[3 * i + 2] - x2;
+        sd += a * a + b * b + c * c;
+    }
+    ps.sqrDevX = sd;
+    /* computePatchPoints */
+    if (!set_state(ps, rays, depth0, dzI0, dzJ0)) return;
+    if (!(ps.mfp > 0.f)) { err |= 1u; return; }      /* reference throws std::out_of_range here */
+
+    /* --- LocalViewSelection ctor (local_view_selection.cc:19-54) */
+    ps.avail = job->n_global >= 32 ? 0xFFFFFFFFu : ((1u << job->n_global) - 1u);
+    {
+        int nprop = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned g = (hyp_views >> (8 * k)) & 0xFFu;
+            if (g != MI_VIEW_NONE) { ++nprop; ps.avail &= ~(1u << g); if (k == slot) ps.sel = (int)g; }
+        }
+        if (nprop > st.K) { ps.sel = -1; }          /* "Too many local neighbors propagated" */
+        if (slot >= st.K) ps.sel = -1;
+    }
+    const float inv_mm = 1.f / mm;
+    ps.cs0 = ps.cs1 = ps.cs2 = inv_mm;
+    bool propagated_all = true;
+    if (__popc(quad_ballot(ps.sel >= 0, lane)) != st.K) {
+        propagated_all = false;
+        if (!local_view_selection(ps, st, views, lane)) { n_eval += ps.n_eval; n_pass += ps.n_pass; return; }
+    }
+    /* computeColorScale() at the end of the ctor (patch_optimization.cc:77); the samples of views picked
+     * by the view selection are already in the reference's cache at this point -> not a new evaluation */
+    bool opti = refresh_color(ps, st, views, s_lut, rays, mcol, true, propagated_all, lane);
+    bool ncc_valid = true;
+    bool converged = false;
+    int iter = 0;
+    const bool active = ps.sel >= 0;
+    NView nv; int level; ColorSums Sdummy; GNSums gn;
+
+    /* --- doAutoOptimization (patch_optimization.cc:170-242) */
+    while (opti && iter < 4) {                          /* first four iterations: depth only */
+        bool okv = true;
+        gn.num = 0.f; gn.den = 0.f;
+        if (active) {
+            okv = setup_view(views, job->global_ids[ps.sel], ps, nv, level)
+                && sample_pass<PASS_DEPTH>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr);
+            ps.n_pass++;
+            if (okv) ps.n_eval++; else { gn.num = 0.f; gn.den = 0.f; }
+        }
+        if (quad_ballot(!okv, lane)) { opti = false; break; }
+        const float num = quad_sum(gn.num), den = quad_sum(gn.den);
+        if (den > 0.f) {
+            opti = set_state(ps, rays, ps.depth + num / den, ps.dzI, ps.dzJ);
+            ncc_valid = false;
+        }
+        ++iter;
+    }
+    bool viewRemoved = false;
+    while (opti && iter < st.maxIterations) {
+        if (!ncc_valid) { refresh_color(ps, st, views, s_lut, rays, mcol, false, true, lane); ncc_valid = true; }
+        const float oldncc = ps.ncc;
+        bool step_ok = false;
+        if (iter % 5 == 4 || viewRemoved) {
+            /* optimizeDepthAndNormal */
+            bool okv = true;
+            gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
+            if (active) {
+                okv = setup_view(views, job->global_ids[ps.sel], ps, nv, level)
+                    && sample_pass<PASS_NORMAL>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr);
+                ps.n_pass++;
+                if (okv) ps.n_eval++;
+                else gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
+            }
+            if (quad_ballot(!okv, lane)) { opti = false; break; }
+            const double m0 = quad_sum(gn.A00), m1 = quad_sum(gn.A01), m2 = quad_sum(gn.A02);
+            const double m4 = quad_sum(gn.A11), m5 = quad_sum(gn.A12), m8 = quad_sum(gn.A22);
+            const double b0 = quad_sum(gn.B0), b1 = quad_sum(gn.B1), b2 = quad_sum(gn.B2);
+            const double m3 = m1, m6 = m2, m7 = m5;
+            /* libs/math/matrix_tools.h:392-399 (determinant), :462-476 (inverse) */
+            const double det = m0 * m4 * m8 + m1 * m5 * m6 + m2 * m3 * m7 - m2 * m4 * m6 - m1 * m3 * m8 - m0 * m5 * m7;
+            if (det == 0.0 || !(det == det)) { opti = false; break; }
+            const double i0 = m4 * m8 - m5 * m7, i1 = m2 * m7 - m1 * m8, i2 = m1 * m5 - m2 * m4;
+            const double i3 = m5 * m6 - m3 * m8, i4 = m0 * m8 - m2 * m6, i5 = m2 * m3 - m0 * m5;
+            const double i6 = m3 * m7 - m4 * m6, i7 = m1 * m6 - m0 * m7, i8 = m0 * m4 - m1 * m3;
+            const float X0 = (float)((i0 * b0 + i1 * b1 + i2 * b2) / det);
+            const float X1 = (float)((i3 * b0 + i4 * b1 + i5 * b2) / det);
+            const float X2 = (float)((i6 * b0 + i7 * b1 + i8 * b2) / det);
+            step_ok = set_state(ps, rays, ps.depth + X0, ps.dzI + X1, ps.dzJ + X2);
+            /* computeColorScale() on the new state (needs the colour samples anyway for getFastNCC) */
+            const bool cs_ok = refresh_color(ps, st, views, s_lut, rays, mcol, true, true, lane);
+            step_ok = step_ok && cs_ok;
+            viewRemoved = false;
+        } else {
+            /* optimizeDepthOnly */
+            bool okv = true;
+            gn.num = 0.f; gn.den = 0.f;
+            if (active) {
+                okv = setup_view(views, job->global_ids[ps.sel], ps, nv, level)
+                    && sample_pass<PASS_DEPTH>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr);
+                ps.n_pass++;
+                if (okv) ps.n_eval++; else { gn.num = 0.f; gn.den = 0.f; }
+            }
+            if (quad_ballot(!okv, lane)) { opti = false; break; }
+            const float num = quad_sum(gn.num), den = quad_sum(gn.den);
+            if (den > 0.f) {
+                step_ok = set_state(ps, rays, ps.depth + num / den, ps.dzI, ps.dzJ);
+                refresh_color(ps, st, views, s_lut, rays, mcol, false, true, lane);
+            }
+        }
+        if (!step_ok) { opti = false; break; }
+        /* convergence / view replacement (patch_optimization.cc:207-239) */
+        const float dn = fabsf(ps.ncc - oldncc);
+        const bool moving = active && dn > st.minRefineDiff;
+        const bool replace = active && (ps.ncc < st.acceptNCC || (iter == 14 && dn > st.minRefineDiff));
+        const unsigned rmask = quad_ballot(replace, lane);
+        const bool conv = quad_ballot(moving, lane) == 0;
+        if (rmask) {
+            viewRemoved = true;
+            if (replace) ps.sel = -1;                  /* available[] already false for selected views */
+            if (!local_view_selection(ps, st, views, lane)) { opti = false; break; }
+            /* computeColorScale(): cached samples for the kept views, fresh ones for the new views */
+            if (!refresh_color(ps, st, views, s_lut, rays, mcol, true, false, lane)) {
+                /* optiSuccess false: the loop condition ends the optimisation unconverged */
+                opti = false; break;
+            }
+        } else if (conv) {
+            converged = true;
+            break;
+        }
+        ++iter;
+    }
+    n_eval += ps.n_eval; n_pass += ps.n_pass;
+    res.iters = iter;
+    res.depth = ps.depth; res.dzI = ps.dzI; res.dzJ = ps.dzJ;
+    /* local view ids, ascending (std::set order) */
+    {
+        int s[4];
+        s[0] = dpp_bcast<0>(ps.sel); s[1] = dpp_bcast<1>(ps.sel); s[2] = dpp_bcast<2>(ps.sel); s[3] = dpp_bcast<3>(ps.sel);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3 - a; ++b) {
+                const unsigned ua = s[b] < 0 ? 0xFFFu : (unsigned)s[b], ub = s[b + 1] < 0 ? 0xFFFu : (unsigned)s[b + 1];
+                if (ua > ub) { const int t = s[b]; s[b] = s[b + 1]; s[b + 1] = t; }
+            }
+        unsigned packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) packed |= (s[k] < 0 ? MI_VIEW_NONE : (unsigned)s[k]) << (8 * k);
+        res.views = packed;
+    }
+    if (!converged) return;
+    /* --- computeConfidence (patch_optimization.cc:114-142): NCCs summed in ascending view order */
+    {
+        int s[4]; float c[4];
+        s[0] = dpp_bcast<0>(ps.sel); s[1] = dpp_bcast<1>(ps.sel); s[2] = dpp_bcast<2>(ps.sel); s[3] = dpp_bcast<3>(ps.sel);
+        c[0] = quad_bcastf<0>(ps.ncc); c[1] = quad_bcastf<1>(ps.ncc); c[2] = quad_bcastf<2>(ps.ncc); c[3] = quad_bcastf<3>(ps.ncc);
+        float mean = 0.f; int cnt = 0;
+        /* selection sort by id, tiny */
+        unsigned used = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int bi = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (s[k] >= 0 && !((used >> k) & 1u) && (bi < 0 || s[k] < s[bi])) bi = k;
+            if (bi >= 0) { used |= 1u << bi; mean += c[bi]; ++cnt; }
+        }
+        mean /= (float)cnt;
+        const float score = (mean - st.acceptNCC) / (1.f - st.acceptNCC);
+        /* getPatchNormal (patch_sampler.cc:242-256): samples 14,10 (right,left) and 2,22 (top,bottom) */
+        const float tr = ps.depth + 2.f * ps.dzI, tl = ps.depth - 2.f * ps.dzI;
+        const float tt = ps.depth - 2.f * ps.dzJ, tb = ps.depth + 2.f * ps.dzJ;
+        const float ax = tr * rays[42] - tl * rays[30], ay = tr * rays[43] - tl * rays[31], az = tr * rays[44] - tl * rays[32];
+        const float bx = tt * rays[6] - tb * rays[66], by = tt * rays[7] - tb * rays[67], bz = tt * rays[8] - tb * rays[68];
+        float nx, ny, nz;
+        unit_cross(ax, ay, az, bx, by, bz, nx, ny, nz);
+        res.nx = nx; res.ny = ny; res.nz = nz;
+        const float dotP = -(nx * rays[36] + ny * rays[37] + nz * rays[38]);   /* viewRayScaled(midx, midy) = ray 12 */
+        res.conf = (dotP < 0.2f) ? 0.f : score;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+
+struct OptArgs {
+    const DevJob* jobs;
+    const DevView* views;
+    const float* lut;
+    DevSettings st;
+    const DevEntry* work;
+    const DevHyp* hyp;        /* explicit hypotheses (seeds / hook); null in propagate mode */
+    DevResult* results;
+    const unsigned* n_work_ptr;   /* device-side entry count (propagate) or null */
+    unsigned n_work;
+    int round;
+    DevCounters* counters;
+};
+
+__global__ __launch_bounds__(WAVE) void k_optimize(OptArgs a) {
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
+    __syncthreads();
+    const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
+    const int q = lane >> 2;
+    const unsigned e = blockIdx.x * MI_PATCHES_PER_WAVE + q;
+    unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
+    if (e < n) {
+        const DevEntry ent = a.work[e];
+        const DevJob* job = a.jobs + ent.job;
+        const int x = ent.xy & 0xFFFF, y = ent.xy >> 16;
+        DevResult out;
+        out.conf = 0.f; out.depth = 0.f; out.dzI = out.dzJ = 0.f; out.nx = out.ny = out.nz = 0.f;
+        out.views = 0xFFFFFFFFu; out.iters = 0; out.accepted = 0;
+        /* Hypotheses to try.  Explicit mode (seeds, parity hook): the one given.  Propagate mode:
+         * the queue semantics of dmrecon.cc:365-392 for the hypotheses pulled from the 4-neighbours
+         * that were written last round, best confidence first. */
+        const bool explicit_hyp = a.hyp != nullptr;
+        const int W = job->w;
+        const int pix = y * W + x;
+        const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+        float cc[4] = {0.f, 0.f, 0.f, 0.f};
+        bool use[4] = {false, false, false, false};
+        float best = 0.f;
+        if (!explicit_hyp) {
+            best = job->conf[pix];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cc[k] = job->conf[nb[k]];
+                use[k] = job->upd[nb[k]] == a.round - 1 && (best < cc[k] - 0.05f || best == 0.f);
+            }
+        }
+        for (int t = 0; t < 4; ++t) {
+            float hd, hi, hj; unsigned hv;
+            if (explicit_hyp) {
+                if (t > 0) break;
+                const DevHyp h = a.hyp[e];
+                hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = h.views;
+            } else {
+                int bi = -1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (use[k] && (bi < 0 || cc[k] > cc[bi])) bi = k;
+                if (bi < 0) break;
+                use[bi] = false;
+                if (best > cc[bi]) continue;                       /* dmrecon.cc:371 */
+                const int p = nb[bi];
+                hd = job->depth[p]; hi = job->dz[2 * p]; hj = job->dz[2 * p + 1]; hv = job->views[p];
+            }
+            PatchResult r;
+            optimize_patch(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
+            ++n_patch;
+            if (explicit_hyp) {
+                out.conf = r.conf; out.depth = r.depth; out.dzI = r.dzI; out.dzJ = r.dzJ;
+                out.nx = r.nx; out.ny = r.ny; out.nz = r.nz; out.views = r.views; out.iters = r.iters;
+                out.accepted = r.conf > 0.f;
+            } else if (r.conf > 0.f && best < r.conf) {            /* dmrecon.cc:378,391 */
+                best = r.conf;
+                out.conf = r.conf; out.depth = r.depth; out.dzI = r.dzI; out.dzJ = r.dzJ;
+                out.nx = r.nx; out.ny = r.ny; out.nz = r.nz; out.views = r.views; out.iters = r.iters;
+                out.accepted = 1;
+            }
+        }
+        if ((lane & 3) == 0) a.results[e] = out;
+    }
+    /* flush counters: one atomic per wave (n_patch counted once per quad) */
+    if ((lane & 3) != 0) n_patch = 0;
+    for (int off = 32; off > 0; off >>= 1) {
+        n_eval += __shfl_down(n_eval, off);
+        n_pass += __shfl_down(n_pass, off);
+        n_patch += __shfl_down(n_patch, off);
+        err |= __shfl_down(err, off);
+    }
+    if (lane == 0) {
+        if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
+        if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
+        if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
+        if (err) atomicOr(&a.counters->error_flags, err);
+    }
+}
+
+/* Parity hook: one hypothesis against every global view; one quad lane per 4 views. */
+struct EvalArgs {
+    const DevJob* job; const DevView* views; const float* lut; DevSettings st;
+    int x, y; float depth, dzI, dzJ;
+    float* master; float* ncc; int32_t* ok; float* col; float* deriv; int32_t* level;
+};
+__global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
+    float* s_lut = g_lut;
+    float* s_rays = g_rays[0];
+    float* s_mcol = g_mcol[0];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += WAVE) s_lut[i] = a.lut[i];
+    __syncthreads();
+    /* reuse optimize_patch's setup by replicating its prologue on quad 0 only */
+    const DevJob* job = a.job;
+    PatchState ps; ps.job = job; ps.x = a.x; ps.y = a.y; ps.n_eval = ps.n_pass = 0; ps.sel = -1;
+    if (lane == 0) for (int k = 0; k < 5; ++k) a.master[k] = 0.f;
+    if (a.x - 2 < 0 || a.y - 2 < 0 || a.x + 2 > job->w - 1 || a.y + 2 > job->h - 1) return;
+    const DevView* RV = a.views + job->ref_view;
+    const DevLevel& RL = RV->lv[job->scale];
+    const uint32_t* rimg = RV->img + RL.tex_off;
+    for (int i = lane; i < MI_NS; i += WAVE) {
+        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const float fx = (float)(a.x + di) + 0.5f, fy = (float)(a.y + dj) + 0.5f;
+        float rx = job->inv_a * fx + job->inv_c, ry = job->inv_b * fy + job->inv_d, rz = 1.f;
+        const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
+        rx /= nrm; ry /= nrm; rz /= nrm;
+        s_rays[3 * i] = job->rot_t[0] * rx + job->rot_t[1] * ry + job->rot_t[2] * rz;
+        s_rays[3 * i + 1] = job->rot_t[3] * rx + job->rot_t[4] * ry + job->rot_t[5] * rz;
+        s_rays[3 * i + 2] = job->rot_t[6] * rx + job->rot_t[7] * ry + job->rot_t[8] * rz;
+        const uint32_t t = rimg[(size_t)(a.y + dj) * RL.w + (a.x + di)];
+        s_mcol[3 * i] = s_lut[t & 255u]; s_mcol[3 * i + 1] = s_lut[(t >> 8) & 255u]; s_mcol[3 * i + 2] = s_lut[(t >> 16) & 255u];
+    }
+    __syncthreads();
+    float mm = 0.f;
+    for (int k = 0; k < 3 * MI_NS; ++k) mm += s_mcol[k];
+    mm /= 3.f * (float)MI_NS;
+    if (mm < 0.01f || mm > 0.99f) return;
+    __syncthreads();
+    for (int i = lane; i < 3 * MI_NS; i += WAVE) s_mcol[i] /= mm;
+    __syncthreads();
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    for (int i = 0; i < MI_NS; ++i) { x0 += s_mcol[3 * i]; x1 += s_mcol[3 * i + 1]; x2 += s_mcol[3 * i + 2]; }
+    x0 /= (float)MI_NS; x1 /= (float)MI_NS; x2 /= (float)MI_NS;
+    float sd = 0.f;
+    for (int i = 0; i < MI_NS; ++i) {
+        const float aa = s_mcol[3 * i] - x0, b = s_mcol[3 * i + 1] - x1, c = s_mcol[3 * i + 2] - x2;
+        sd += aa * aa + b * b + c * c;
+    }
+    ps.mmean = mm; ps.xbar0 = x0; ps.xbar1 = x1; ps.xbar2 = x2; ps.sqrDevX = sd;
+    ps.cs0 = ps.cs1 = ps.cs2 = 1.f / mm;
+    if (!set_state(ps, s_rays, a.depth, a.dzI, a.dzJ)) return;
+    if (lane == 0) {
+        a.master[0] = 1.f; a.master[1] = mm;
+        const float tr = ps.depth + 2.f * ps.dzI, tl = ps.depth - 2.f * ps.dzI;
+        const float tt = ps.depth - 2.f * ps.dzJ, tb = ps.depth + 2.f * ps.dzJ;
+        const float* rays = s_rays;
+        const float ax = tr * rays[42] - tl * rays[30], ay = tr * rays[43] - tl * rays[31], az = tr * rays[44] - tl * rays[32];
+        const float bx = tt * rays[6] - tb * rays[66], by = tt * rays[7] - tb * rays[67], bz = tt * rays[8] - tb * rays[68];
+        float nx, ny, nz;
+        unit_cross(ax, ay, az, bx, by, bz, nx, ny, nz);
+        a.master[2] = nx; a.master[3] = ny; a.master[4] = nz;
+    }
+    if (lane < job->n_global) {
+        const int g = lane;
+        ColorSums S; bool okc;
+        const float ncc = eval_color(ps, a.views, g, s_lut, s_rays, s_mcol, S, okc, true);
+        a.ncc[g] = ncc;
+        NView nv; int level = -1; GNSums gn;
+        bool okd = setup_view(a.views, job->global_ids[g], ps, nv, level)
+            && sample_pass<PASS_DUMP>(ps, nv, s_lut, s_rays, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS);
+        a.ok[g] = okd ? 1 : 0;
+        a.level[g] = level;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Sweep kernels: one lane per reference-image pixel.                          */
+
+struct SweepArgs {
+    const DevJob* jobs;
+    DevEntry* work;
+    DevCounters* counters;
+    int round;
+    int max_pixels;       /* max over jobs of w*h */
+};
+
+/* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull. */
+__global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
+    const DevJob* job = a.jobs + blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int W = job->w, H = job->h;
+    bool any = false;
+    int x = 0, y = 0;
+    if (pix < W * H) {
+        y = pix / W; x = pix - y * W;
+        /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
+        if (x >= 2 && y >= 2 && x < W - 2 && y < H - 2) {
+            const float own = job->conf[pix];
+            const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (job->upd[nb[k]] == a.round - 1) {
+                    const float c = job->conf[nb[k]];
+                    if (own < c - 0.05f || own == 0.f) any = true;
+                }
+        }
+    }
+    /* wave-aggregated append: one atomic per wavefront */
+    const unsigned long long m = __ballot(any);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(&a.counters->n_work, (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        if (any) {
+            const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            DevEntry e; e.job = blockIdx.y; e.xy = x | (y << 16);
+            a.work[idx] = e;
+        }
+    }
+}
+
+struct ApplyArgs {
+    const DevJob* jobs;
+    const DevEntry* work;
+    const DevResult* results;
+    const unsigned* n_work_ptr;
+    unsigned n_work;
+    int round;
+    DevCounters* counters;
+    unsigned long long* seed_keys;   /* seeds only: per job pixel arbitration keys */
+    const unsigned* key_off;         /* seeds only: per job offset into seed_keys */
+    int phase;                       /* seeds: 0 = vote, 1 = write */
+};
+
+__device__ __forceinline__ void write_pixel(const DevJob* job, int pix, const DevResult& r, int round) {
+    job->depth[pix] = r.depth;
+    job->dz[2 * pix] = r.dzI; job->dz[2 * pix + 1] = r.dzJ;
+    job->normal[3 * pix] = r.nx; job->normal[3 * pix + 1] = r.ny; job->normal[3 * pix + 2] = r.nz;
+    job->conf[pix] = r.conf;
+    job->views[pix] = r.views;
+    job->upd[pix] = round;
+}
+
+/* Jacobi write-back of one propagation round (dmrecon.cc:391-398). */
+__global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
+    const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
+    const unsigned e = blockIdx.x * 256 + threadIdx.x;
+    bool newly = false;
+    if (e < n) {
+        const DevResult r = a.results[e];
+        if (r.accepted) {
+            const DevEntry ent = a.work[e];
+            const DevJob* job = a.jobs + ent.job;
+            const int pix = (ent.xy >> 16) * job->w + (ent.xy & 0xFFFF);
+            newly = job->conf[pix] <= 0.f;
+            write_pixel(job, pix, r, a.round);
+        }
+    }
+    const unsigned long long m = __ballot(newly);
+    if (m && (threadIdx.x & 63) == __ffsll((long long)m) - 1)
+        atomicAdd(&a.counters->n_filled, (unsigned long long)__popcll(m));
+}
+
+/* Seeds (dmrecon.cc:297-330): several features may round to the same pixel; the sequential
+ * reference keeps the highest confidence, the earlier feature on ties.  Two phases:
+ * vote (64-bit atomicMax of conf | ~index) then write by the winner. */
+__global__ __launch_bounds__(256) void k_apply_seeds(ApplyArgs a) {
+    const unsigned e = blockIdx.x * 256 + threadIdx.x;
+    bool newly = false, okseed = false;
+    if (e < a.n_work) {
+        const DevResult r = a.results[e];
+        if (r.conf > 0.f) {
+            const DevEntry ent = a.work[e];
+            const DevJob* job = a.jobs + ent.job;
+            const int pix = (ent.xy >> 16) * job->w + (ent.xy & 0xFFFF);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(r.conf) << 32) | (0xFFFFFFFFu - e);
+            unsigned long long* slot = a.seed_keys + a.key_off[ent.job] + pix;
+            if (a.phase == 0) {
+                atomicMax(slot, key);
+                okseed = true;
+            } else if (*slot == key) {
+                newly = job->conf[pix] <= 0.f;
+                write_pixel(job, pix, r, a.round);
+            }
+        }
+    }
+    const unsigned long long m = __ballot(newly);
+    if (m && (threadIdx.x & 63) == __ffsll((long long)m) - 1)
+        atomicAdd(&a.counters->n_filled, (unsigned long long)__popcll(m));
+    const unsigned long long m2 = __ballot(okseed);
+    if (m2 && (threadIdx.x & 63) == __ffsll((long long)m2) - 1)
+        atomicAdd(&a.counters->n_seeds_ok, (unsigned long long)__popcll(m2));
+}
+
+/* ------------------------------------------------------------------------- */
+/* Image staging.                                                              */
+
+/* interleaved 1..4 channel uint8 -> RGBA8 (grey expanded, alpha dropped; image_pyramid.cc:65-73) */
+__global__ __launch_bounds__(256) void k_pack_rgba(const uint8_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                  int n, int channels) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r, g, b;
+    if (channels <= 2) { r = g = b = src[(size_t)i * channels]; }
+    else { r = src[(size_t)i * channels]; g = src[(size_t)i * channels + 1]; b = src[(size_t)i * channels + 2]; }
+    dst[i] = r | (g << 8) | (b << 16) | 0xFF000000u;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_rgb(const uint32_t* __restrict__ src, uint8_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = src[i];
+    dst[3 * (size_t)i] = t & 255u; dst[3 * (size_t)i + 1] = (t >> 8) & 255u; dst[3 * (size_t)i + 2] = (t >> 16) & 255u;
+}
+
+/*
+ * One level of the Gaussian pyramid: mve::image::rescale_half_size_gaussian<uint8_t>(img, 1.f)
+ * (libs/mve/image_tools.h:619-690) with math::Accum<unsigned char> (libs/math/accum.h:146-171):
+ * 16 taps accumulated in float in the reference's order (no FMA contraction, so the bytes
+ * match a non-contracting CPU build), clamped borders, divide by the accumulated weight,
+ * round half away from zero.
+ */
+__global__ __launch_bounds__(256) void k_pyramid(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                int iw, int ih, int ow, int oh, float w1, float w2, float w3) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    const int y2 = 2 * y, x2 = 2 * x;
+    int ry[4], rx[4];
+    ry[0] = max(0, y2 - 1); ry[1] = y2; ry[2] = min(ih - 1, y2 + 1); ry[3] = min(ih - 1, y2 + 2);
+    rx[0] = max(0, x2 - 1); rx[1] = x2; rx[2] = min(iw - 1, x2 + 1); rx[3] = min(iw - 1, x2 + 2);
+    const float wt[4][4] = {{w3, w2, w2, w3}, {w2, w1, w1, w2}, {w2, w1, w1, w2}, {w3, w2, w2, w3}};
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, wsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t t = src[(size_t)ry[r] * iw + rx[k]];
+            v0 = __fadd_rn(v0, __fmul_rn((float)(t & 255u), wt[r][k]));
+            v1 = __fadd_rn(v1, __fmul_rn((float)((t >> 8) & 255u), wt[r][k]));
+            v2 = __fadd_rn(v2, __fmul_rn((float)((t >> 16) & 255u), wt[r][k]));
+            wsum = __fadd_rn(wsum, wt[r][k]);
+        }
+    /* math::round: x > 0 ? floor(x + 0.5) : ceil(x - 0.5) */
+    const float q0 = __fdiv_rn(v0, wsum), q1 = __fdiv_rn(v1, wsum), q2 = __fdiv_rn(v2, wsum);
+    const uint32_t b0 = (uint32_t)(q0 > 0.f ? floorf(__fadd_rn(q0, 0.5f)) : 0.f);
+    const uint32_t b1 = (uint32_t)(q1 > 0.f ? floorf(__fadd_rn(q1, 0.5f)) : 0.f);
+    const uint32_t b2 = (uint32_t)(q2 > 0.f ? floorf(__fadd_rn(q2, 0.5f)) : 0.f);
+    dst[(size_t)y * ow + x] = (b0 & 255u) | ((b1 & 255u) << 8) | ((b2 & 255u) << 16) | 0xFF000000u;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Host-callable launchers (declared in dmrecon_device.h).                     */
+
+void mi_launch_optimize(hipStream_t s, const DevJob* jobs, const DevView* views, const float* lut,
+                        const DevSettings& st, const DevEntry* work, const DevHyp* hyp, DevResult* results,
+                        const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters) {
+    if (n_work == 0) return;
+    OptArgs a;
+    a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
+    a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.round = round; a.counters = counters;
+    const unsigned blocks = (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE;
+    hipLaunchKernelGGL(k_optimize, dim3(blocks), dim3(WAVE), 0, s, a);
+}
+
+void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
+                          const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
+                          float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level) {
+    EvalArgs a;
+    a.job = job; a.views = views; a.lut = lut; a.st = st; a.x = x; a.y = y; a.depth = depth; a.dzI = dzI; a.dzJ = dzJ;
+    a.master = master; a.ncc = ncc; a.ok = ok; a.col = col; a.deriv = deriv; a.level = level;
+    hipLaunchKernelGGL(k_patch_eval, dim3(1), dim3(WAVE), 0, s, a);
+}
+
+void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_pixels, DevEntry* work,
+                        DevCounters* counters, int round) {
+    SweepArgs a;
+    a.jobs = jobs; a.work = work; a.counters = counters; a.round = round; a.max_pixels = max_pixels;
+    hipLaunchKernelGGL(k_generate, dim3((max_pixels + 255) / 256, n_jobs), dim3(256), 0, s, a);
+}
+
+void mi_launch_apply(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
+                     unsigned n_work, int round, DevCounters* counters) {
+    if (n_work == 0) return;
+    ApplyArgs a;
+    a.jobs = jobs; a.work = work; a.results = results; a.n_work_ptr = nullptr; a.n_work = n_work; a.round = round;
+    a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0;
+    hipLaunchKernelGGL(k_apply, dim3((n_work + 255) / 256), dim3(256), 0, s, a);
+}
+
+void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
+                           unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
+                           const unsigned* key_off) {
+    if (n_work == 0) return;
+    ApplyArgs a;
+    a.jobs = jobs; a.work = work; a.results = results; a.n_work_ptr = nullptr; a.n_work = n_work; a.round = 0;
+    a.counters = counters; a.seed_keys = seed_keys; a.key_off = key_off;
+    a.phase = 0;
+    hipLaunchKernelGGL(k_apply_seeds, dim3((n_work + 255) / 256), dim3(256), 0, s, a);
+    a.phase = 1;
+    hipLaunchKernelGGL(k_apply_seeds, dim3((n_work + 255) / 256), dim3(256), 0, s, a);
+}
+
+void mi_launch_pack_rgba(hipStream_t s, const uint8_t* src, uint32_t* dst, int n, int channels) {
+    hipLaunchKernelGGL(k_pack_rgba, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n, channels);
+}
+void mi_launch_unpack_rgb(hipStream_t s, const uint32_t* src, uint8_t* dst, int n) {
+    hipLaunchKernelGGL(k_unpack_rgb, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
+}
+void mi_launch_pyramid(hipStream_t s, const uint32_t* src, uint32_t* dst, int iw, int ih, int ow, int oh,
+                       float w1, float w2, float w3) {
+    hipLaunchKernelGGL(k_pyramid, dim3((ow + 63) / 64, (oh + 3) / 4), dim3(256), 0, s, src, dst, iw, ih, ow, oh, w1, w2, w3);
+}

@@ -1,0 +1,822 @@
+/*
+ * dmrecon_host.cpp -- host side of libmi_dmrecon.so: the C ABI of include/mi_dmrecon.h.
+ *
+ * Keeps on the host only the serial, cheap stages of mvs::DMRecon::start()
+ * (reference: libs/dmrecon/dmrecon.cc): analyzeFeatures (:178-208), GlobalViewSelection
+ * (global_view_selection.cc:33-101) and the feature -> seed conversion of processFeatures
+ * (:243-296).  Everything per-pixel runs in the kernels of dmrecon_device.hip.
+ *
+ * Compiled with -ffp-contract=off so that the discrete decisions taken here
+ * (frustum tests, pixel rounding, the greedy arg-max of the view selection) see the
+ * same float values as the reference's unfused x86 arithmetic.
+ *
+ * There is no CPU fallback: every entry point that computes needs a HIP device and
+ * fails with MI_DMRECON_EDEVICE otherwise.
+ */
+#include "../../include/mi_dmrecon.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "dmrecon_device.h"
+#include "dmrecon_types.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(MI_DMRECON_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+/* ---- small float helpers with the accumulation order of libs/math (vector.h:434-458,542-551;
+ *      matrix.h:475-493): left-to-right sums starting from T(0). */
+struct V3 { float v[3]; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
+inline V3 mk(float a, float b, float c) { V3 r; r.v[0] = a; r.v[1] = b; r.v[2] = c; return r; }
+inline float dot3(const float* a, const float* b) { return ((0.f + a[0] * b[0]) + a[1] * b[1]) + a[2] * b[2]; }
+inline V3 sub(V3 const& a, V3 const& b) { return mk(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+inline float norm3(V3 const& a) { return std::sqrt(dot3(a.v, a.v)); }
+inline V3 normalized(V3 const& a) { float n = norm3(a); return mk(a[0] / n, a[1] / n, a[2] / n); }
+inline V3 xform(const float* w2c, V3 const& p) {          /* Matrix4f::mult(Vec3f, 1) */
+    V3 r;
+    for (int i = 0; i < 3; ++i) r[i] = dot3(w2c + 4 * i, p.v) + 1.f * w2c[4 * i + 3];
+    return r;
+}
+inline float mround(float x) { return x > 0.f ? std::floor(x + 0.5f) : std::ceil(x - 0.5f); }   /* math/functions.h:68-73 */
+const float kPi = 3.141592653589793f;
+
+struct HostLevel { int w, h; float proj[9], invproj[9]; uint32_t tex_off; };
+
+struct HostView {
+    bool valid = false;
+    mi_dmrecon_camera cam;
+    float cam_pos[3];
+    float w2c[16];
+    std::vector<HostLevel> levels;
+    uint32_t* d_img = nullptr;
+    size_t n_texels = 0;
+
+    V3 pos() const { return mk(cam_pos[0], cam_pos[1], cam_pos[2]); }
+    /* SingleView::pointInFrustum, single_view.cc:106-119 */
+    bool pointInFrustum(V3 const& wp) const {
+        V3 cp = xform(w2c, wp);
+        if (cp[2] <= 0.0f) return false;
+        const float* P = levels[0].proj;
+        float sx = dot3(P, cp.v), sy = dot3(P + 3, cp.v), sz = dot3(P + 6, cp.v);
+        float x = sx / sz - 0.5f, y = sy / sz - 0.5f;
+        return x >= 0 && x <= levels[0].w - 1 && y >= 0 && y <= levels[0].h - 1;
+    }
+    float footPrint(V3 const& p, int lvl) const { return xform(w2c, p)[2] * levels[lvl].invproj[0]; }
+};
+
+/* CameraInfo::fill_calibration / fill_inverse_calibration, libs/mve/camera.cc:124-144,179-200 */
+void calibration(mi_dmrecon_camera const& c, float width, float height, float* K, float* Ki) {
+    float dim_aspect = width / height;
+    float image_aspect = dim_aspect * c.paspect;
+    float ax, ay;
+    if (image_aspect < 1.0f) { ax = c.flen * height / c.paspect; ay = c.flen * height; }
+    else { ax = c.flen * width; ay = c.flen * width * c.paspect; }
+    K[0] = ax; K[1] = 0.f; K[2] = width * c.ppoint[0];
+    K[3] = 0.f; K[4] = ay; K[5] = height * c.ppoint[1];
+    K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;
+    Ki[0] = 1.0f / ax; Ki[1] = 0.f; Ki[2] = -width * c.ppoint[0] / ax;
+    Ki[3] = 0.f; Ki[4] = 1.0f / ay; Ki[5] = -height * c.ppoint[1] / ay;
+    Ki[6] = 0.f; Ki[7] = 0.f; Ki[8] = 1.f;
+}
+
+struct Feature { float pos[3]; int ref_begin, ref_end; };
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e != hipSuccess) return -1;
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct JobHost {          /* host-side plan of one reference view */
+    int ref_view = -1;
+    int status = MI_DMRECON_OK;
+    int w = 0, h = 0;
+    std::vector<int> global;                 /* ascending view ids */
+    std::vector<DevEntry> seeds;
+    std::vector<DevHyp> seed_hyp;
+    size_t n_seeds = 0;
+    size_t pix_off = 0;                      /* offset of this job's maps in the batch arrays */
+};
+
+}  // namespace
+
+struct mi_dmrecon_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<HostView> views;
+    std::vector<Feature> features;
+    std::vector<int> feat_refs;
+    bool views_dirty = true;
+    DevBuf<DevView> d_views;
+    float* d_lut = nullptr;
+    DevCounters* d_counters = nullptr;
+    DevBuf<DevJob> d_jobs;
+    DevBuf<DevEntry> d_work;
+    DevBuf<DevHyp> d_hyp;
+    DevBuf<DevResult> d_results;
+    DevBuf<float> d_maps;                    /* depth | dz | conf | normal per batch */
+    DevBuf<uint32_t> d_imaps;                /* views | upd */
+    DevBuf<unsigned long long> d_keys;
+    DevBuf<unsigned> d_keyoff;
+    DevBuf<uint8_t> d_stage;
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+int sync_views(mi_dmrecon_ctx* c) {
+    if (!c->views_dirty) return 0;
+    std::vector<DevView> hv(c->views.size());
+    for (size_t i = 0; i < c->views.size(); ++i) {
+        HostView const& v = c->views[i];
+        DevView& d = hv[i];
+        std::memset(&d, 0, sizeof(d));
+        if (!v.valid) continue;
+        std::memcpy(d.cam_pos, v.cam_pos, sizeof(d.cam_pos));
+        std::memcpy(d.w2c, v.w2c, sizeof(d.w2c));
+        d.n_levels = (int)v.levels.size();
+        d.img = v.d_img;
+        for (int l = 0; l < d.n_levels; ++l) {
+            HostLevel const& L = v.levels[l];
+            d.lv[l].ax = L.proj[0]; d.lv[l].ay = L.proj[4]; d.lv[l].cx = L.proj[2]; d.lv[l].cy = L.proj[5];
+            d.lv[l].inv0 = L.invproj[0]; d.lv[l].w = L.w; d.lv[l].h = L.h; d.lv[l].tex_off = L.tex_off;
+        }
+    }
+    if (c->d_views.reserve(hv.size())) return fail(MI_DMRECON_EDEVICE, "hipMalloc(views) failed");
+    HIP_TRY(hipMemcpyAsync(c->d_views.p, hv.data(), hv.size() * sizeof(DevView), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->views_dirty = false;
+    return 0;
+}
+
+int check_settings(const mi_dmrecon_settings* st) {
+    if (!st) return fail(MI_DMRECON_EINVAL, "null settings");
+    if (st->scale < 0) return fail(MI_DMRECON_EINVAL, "Invalid scale factor");            /* dmrecon.cc:41-42 */
+    if (st->filterWidth != 5) return fail(MI_DMRECON_EINVAL, "filterWidth %d unsupported (only 5)", st->filterWidth);
+    if (st->nrReconNeighbors < 1 || st->nrReconNeighbors > MI_DMRECON_MAX_LOCAL_VIEWS)
+        return fail(MI_DMRECON_EINVAL, "nrReconNeighbors must be in 1..%d", MI_DMRECON_MAX_LOCAL_VIEWS);
+    if (st->globalVSMax < 1 || st->globalVSMax > MI_DMRECON_MAX_GLOBAL_VIEWS)
+        return fail(MI_DMRECON_EINVAL, "globalVSMax must be in 1..%d", MI_DMRECON_MAX_GLOBAL_VIEWS);
+    return 0;
+}
+
+inline bool contains_view(mi_dmrecon_ctx const* c, Feature const& f, int id) {
+    for (int j = f.ref_begin; j < f.ref_end; ++j) if (c->feat_refs[j] == id) return true;
+    return false;
+}
+inline bool in_box(V3 const& p, const float* lo, const float* hi) {          /* math::geom::point_box_overlap */
+    for (int i = 0; i < 3; ++i) if (p[i] < lo[i] || p[i] > hi[i]) return false;
+    return true;
+}
+inline float parallax(V3 const& p, HostView const& v1, HostView const& v2) {   /* mvs_tools.h:46-56 */
+    V3 d1 = normalized(sub(p, v1.pos())), d2 = normalized(sub(p, v2.pos()));
+    float dp = std::max(std::min(dot3(d1.v, d2.v), 1.f), -1.f);
+    return std::acos(dp) * 180.f / kPi;
+}
+
+/* analyzeFeatures + GlobalViewSelection::performVS for one reference view; fills plan.global.
+ * Same arithmetic and tie-breaking as the reference; the only change is that
+ * SingleView::seesFeature's linear scan (single_view.h:166-173) is a bitmap lookup. */
+int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref, std::vector<int>& global) {
+    const size_t nv = c->views.size();
+    if (ref < 0 || (size_t)ref >= nv) return fail(MI_DMRECON_EINVAL, "Master view index out of bounds");
+    HostView const& R = c->views[ref];
+    if (!R.valid) return fail(MI_DMRECON_EINVAL, "Invalid master view");
+    if ((size_t)st->scale >= R.levels.size()) return fail(MI_DMRECON_EINVAL, "scale %d beyond pyramid of view %d", st->scale, ref);
+    const size_t nf = c->features.size();
+    std::vector<std::vector<int> > featInd(nv);
+    std::vector<std::vector<uint8_t> > sees(nv);
+    for (size_t v = 0; v < nv; ++v) sees[v].assign(nf, 0);
+    for (size_t i = 0; i < nf; ++i) {                                       /* dmrecon.cc:185-207 */
+        Feature const& f = c->features[i];
+        if (!contains_view(c, f, ref)) continue;
+        V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
+        if (!R.pointInFrustum(p)) continue;
+        if (!in_box(p, st->aabbMin, st->aabbMax)) continue;
+        for (int j = f.ref_begin; j < f.ref_end; ++j) {
+            int id = c->feat_refs[j];
+            if (id < 0 || id >= (int)nv || !c->views[id].valid) continue;
+            if (c->views[id].pointInFrustum(p)) { featInd[id].push_back((int)i); sees[id][i] = 1; }
+        }
+    }
+    std::vector<char> available(nv, 1);                                     /* global_view_selection.cc:23-30 */
+    available[ref] = 0;
+    for (size_t i = 0; i < nv; ++i) if (!c->views[i].valid) available[i] = 0;
+    std::vector<int> selected;          /* kept sorted ascending = std::set order */
+    bool foundOne = true;
+    while (foundOne && selected.size() < (size_t)st->globalVSMax) {
+        float maxBenefit = 0.f; size_t maxView = 0; foundOne = false;
+        for (size_t i = 0; i < nv; ++i) {
+            if (!available[i]) continue;
+            HostView const& T = c->views[i];
+            float benefit = 0;
+            for (size_t k = 0; k < featInd[i].size(); ++k) {                /* benefitFromView, :62-101 */
+                float score = 1.f;
+                Feature const& f = c->features[featInd[i][k]];
+                V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
+                float plx = parallax(p, R, T);
+                if (plx < st->minParallax) score *= (plx / 10.f) * (plx / 10.f);
+                float mfp = R.footPrint(p, st->scale);
+                float nfp = T.footPrint(p, 0);
+                float ratio = mfp / nfp;
+                if (ratio > 2.) ratio = 2. / ratio;
+                else if (ratio > 1.) ratio = 1.;
+                score *= ratio;
+                for (size_t s = 0; s < selected.size(); ++s) {
+                    if (!sees[selected[s]][featInd[i][k]]) continue;
+                    plx = parallax(p, c->views[selected[s]], T);
+                    if (plx < st->minParallax) score *= (plx / 10.f) * (plx / 10.f);
+                }
+                benefit += score;
+            }
+            if (benefit > maxBenefit) { maxBenefit = benefit; maxView = i; foundOne = true; }
+        }
+        if (foundOne) {
+            selected.insert(std::upper_bound(selected.begin(), selected.end(), (int)maxView), (int)maxView);
+            available[maxView] = 0;
+        }
+    }
+    global = selected;
+    return 0;
+}
+
+/* The host half of DMRecon::processFeatures (dmrecon.cc:258-296): feature -> (pixel, initDepth) */
+void plan_seeds(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost& job, int job_index) {
+    HostView const& R = c->views[job.ref_view];
+    HostLevel const& L = R.levels[st->scale];
+    for (size_t i = 0; i < c->features.size(); ++i) {
+        Feature const& f = c->features[i];
+        bool use = contains_view(c, f, job.ref_view);
+        for (size_t g = 0; !use && g < job.global.size(); ++g)
+            if (contains_view(c, f, job.global[g])) use = true;
+        if (!use) continue;
+        V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
+        if (!R.pointInFrustum(p)) continue;
+        if (!in_box(p, st->aabbMin, st->aabbMax)) continue;
+        ++job.n_seeds;
+        V3 cp = xform(R.w2c, p);                                            /* worldToScreenScaled */
+        float sx = dot3(L.proj, cp.v), sy = dot3(L.proj + 3, cp.v), sz = dot3(L.proj + 6, cp.v);
+        int const x = (int)mround(sx / sz - 0.5f);
+        int const y = (int)mround(sy / sz - 0.5f);
+        if (x < 0 || y < 0 || x >= L.w || y >= L.h) continue;              /* the sampler's border test fails anyway */
+        DevEntry e; e.job = job_index; e.xy = x | (y << 16);
+        DevHyp h; h.depth = norm3(sub(p, R.pos())); h.dzI = 0.f; h.dzJ = 0.f; h.views = 0xFFFFFFFFu;
+        job.seeds.push_back(e);
+        job.seed_hyp.push_back(h);
+    }
+}
+
+void fill_job(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost const& jh, DevJob& d) {
+    HostView const& R = c->views[jh.ref_view];
+    HostLevel const& L = R.levels[st->scale];
+    std::memset(&d, 0, sizeof(d));
+    d.ref_view = jh.ref_view; d.scale = st->scale; d.w = L.w; d.h = L.h;
+    d.inv_a = L.invproj[0]; d.inv_c = L.invproj[2]; d.inv_b = L.invproj[4]; d.inv_d = L.invproj[5];
+    const float* r = R.cam.rot;
+    const float rt[9] = {r[0], r[3], r[6], r[1], r[4], r[7], r[2], r[5], r[8]};
+    std::memcpy(d.rot_t, rt, sizeof(rt));
+    std::memcpy(d.cam_pos, R.cam_pos, sizeof(d.cam_pos));
+    d.w2c_z[0] = R.w2c[8]; d.w2c_z[1] = R.w2c[9]; d.w2c_z[2] = R.w2c[10]; d.w2c_z[3] = R.w2c[11];
+    d.inv0_s = L.invproj[0];
+    d.n_global = (int)jh.global.size();
+    for (size_t g = 0; g < jh.global.size(); ++g) d.global_ids[g] = jh.global[g];
+}
+
+DevSettings dev_settings(const mi_dmrecon_settings* st) {
+    DevSettings d;
+    d.minNCC = st->minNCC; d.minParallax = st->minParallax; d.acceptNCC = st->acceptNCC;
+    d.minRefineDiff = st->minRefineDiff; d.maxIterations = st->maxIterations; d.K = st->nrReconNeighbors;
+    d.useColorScale = st->useColorScale;
+    return d;
+}
+
+/* Lays the per-pixel state maps of a batch out in the two map buffers and points the jobs at them. */
+int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px) {
+    total_px = 0;
+    for (size_t j = 0; j < jobs.size(); ++j) { jobs[j].pix_off = total_px; total_px += (size_t)jobs[j].w * jobs[j].h; }
+    if (c->d_maps.reserve(total_px * 7)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
+    if (c->d_imaps.reserve(total_px * 2)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
+    float* base = c->d_maps.p;
+    uint32_t* ibase = c->d_imaps.p;
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        const size_t o = jobs[j].pix_off;
+        dj[j].depth = base + o;
+        dj[j].conf = base + total_px + o;
+        dj[j].dz = base + 2 * total_px + 2 * o;
+        dj[j].normal = base + 4 * total_px + 3 * o;
+        dj[j].views = ibase + o;
+        dj[j].upd = (int32_t*)(ibase + total_px + o);
+    }
+    HIP_TRY(hipMemsetAsync(c->d_maps.p, 0, total_px * 7 * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * 2 * sizeof(uint32_t), c->stream));
+    return 0;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+/* =========================================================================== */
+extern "C" {
+
+int mi_dmrecon_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* mi_dmrecon_last_error(void) { return g_err.c_str(); }
+
+void mi_dmrecon_settings_default(mi_dmrecon_settings* s) {          /* libs/dmrecon/settings.h:25-51 */
+    s->filterWidth = 5; s->minNCC = 0.3f; s->minParallax = 10.f; s->acceptNCC = 0.6f; s->minRefineDiff = 0.001f;
+    s->maxIterations = 20; s->nrReconNeighbors = 4; s->globalVSMax = 20; s->scale = 0; s->useColorScale = 1;
+    for (int i = 0; i < 3; ++i) {
+        s->aabbMin[i] = -std::numeric_limits<float>::max();
+        s->aabbMax[i] = std::numeric_limits<float>::max();
+    }
+}
+
+int mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out) {
+    if (!out) return fail(MI_DMRECON_EINVAL, "null out pointer");
+    int n = mi_dmrecon_device_count();
+    if (n <= 0) return fail(MI_DMRECON_EDEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(MI_DMRECON_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    mi_dmrecon_ctx* c = new mi_dmrecon_ctx;
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    /* sRGB -> linear table: the formula documented at mvs_tools.cc:22-29 evaluated in double and
+     * rounded to float reproduces the literal table at :30-93 bit for bit (tests/test_host_logic.py). */
+    float lut[256];
+    for (int i = 0; i < 256; ++i) {
+        double x = i / 255.0;
+        lut[i] = (float)((i <= 0.04045 * 255.0) ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4));
+    }
+    lut[255] = 1.0f;
+    HIP_TRY(hipMalloc((void**)&c->d_lut, sizeof(lut)));
+    HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(DevCounters)));
+    *out = c;
+    return 0;
+}
+
+void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (size_t i = 0; i < c->views.size(); ++i) if (c->views[i].d_img) (void)hipFree(c->views[i].d_img);
+    for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
+    c->d_views.release(); c->d_jobs.release(); c->d_work.release(); c->d_hyp.release(); c->d_results.release();
+    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release();
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* mi_dmrecon_ctx_stream(mi_dmrecon_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int mi_dmrecon_set_view(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_camera* cam, int32_t width,
+                        int32_t height, int32_t channels, const uint8_t* pixels) {
+    if (!c || !cam || !pixels) return fail(MI_DMRECON_EINVAL, "null argument");
+    if (view_id < 0 || view_id >= (1 << 20)) return fail(MI_DMRECON_EINVAL, "bad view id %d", view_id);
+    if (width < 2 || height < 2 || width > 65535 || height > 65535) return fail(MI_DMRECON_EINVAL, "bad image size %dx%d", width, height);
+    if (channels < 1 || channels > 4) return fail(MI_DMRECON_EINVAL, "Image with invalid number of channels");
+    HIP_TRY(hipSetDevice(c->device));
+    if ((size_t)view_id >= c->views.size()) c->views.resize(view_id + 1);
+    HostView& v = c->views[view_id];
+    if (v.d_img) { (void)hipFree(v.d_img); v.d_img = nullptr; }
+    v.cam = *cam;
+    v.valid = cam->flen != 0.f;                                   /* CameraInfo::is_valid (View::is_camera_valid) */
+    const float* rot = cam->rot; const float* t = cam->trans;
+    v.cam_pos[0] = -rot[0] * t[0] - rot[3] * t[1] - rot[6] * t[2];      /* camera.cc:34-39 */
+    v.cam_pos[1] = -rot[1] * t[0] - rot[4] * t[1] - rot[7] * t[2];
+    v.cam_pos[2] = -rot[2] * t[0] - rot[5] * t[1] - rot[8] * t[2];
+    float* m = v.w2c;                                                   /* camera.cc:63-69 */
+    m[0] = rot[0]; m[1] = rot[1]; m[2] = rot[2]; m[3] = t[0];
+    m[4] = rot[3]; m[5] = rot[4]; m[6] = rot[5]; m[7] = t[1];
+    m[8] = rot[6]; m[9] = rot[7]; m[10] = rot[8]; m[11] = t[2];
+    m[12] = 0.f; m[13] = 0.f; m[14] = 0.f; m[15] = 1.f;
+    /* buildPyramid, image_pyramid.cc:21-53 */
+    v.levels.clear();
+    mi_dmrecon_camera pc = *cam;
+    int cw = width, ch = height;
+    size_t off = 0;
+    HostLevel l0; l0.w = cw; l0.h = ch; l0.tex_off = 0;
+    calibration(pc, (float)cw, (float)ch, l0.proj, l0.invproj);
+    v.levels.push_back(l0);
+    off += (size_t)cw * ch;
+    while (std::min(cw, ch) >= 30 && v.levels.size() < MI_MAX_LEVELS) {
+        if (cw % 2 == 1) pc.ppoint[0] = pc.ppoint[0] * float(cw) / float(cw + 1);
+        if (ch % 2 == 1) pc.ppoint[1] = pc.ppoint[1] * float(ch) / float(ch + 1);
+        cw = (cw + 1) / 2; ch = (ch + 1) / 2;
+        HostLevel l; l.w = cw; l.h = ch; l.tex_off = (uint32_t)off;
+        calibration(pc, (float)cw, (float)ch, l.proj, l.invproj);
+        v.levels.push_back(l);
+        off += (size_t)cw * ch;
+    }
+    v.n_texels = off;
+    HIP_TRY(hipMalloc((void**)&v.d_img, off * sizeof(uint32_t)));
+    /* ensureImages, image_pyramid.cc:55-95: upload, strip alpha / expand grey, then the Gaussian levels */
+    const size_t nbytes = (size_t)width * height * channels;
+    if (c->d_stage.reserve(nbytes)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(stage) failed");
+    HIP_TRY(hipMemcpyAsync(c->d_stage.p, pixels, nbytes, hipMemcpyHostToDevice, c->stream));
+    mi_launch_pack_rgba(c->stream, c->d_stage.p, v.d_img, width * height, channels);
+    const float w1 = std::exp(-0.5f / (2.0f * 1.f)), w2 = std::exp(-2.5f / (2.0f * 1.f)), w3 = std::exp(-4.5f / (2.0f * 1.f));
+    for (size_t l = 1; l < v.levels.size(); ++l) {
+        HostLevel const& a = v.levels[l - 1]; HostLevel const& b = v.levels[l];
+        mi_launch_pyramid(c->stream, v.d_img + a.tex_off, v.d_img + b.tex_off, a.w, a.h, b.w, b.h, w1, w2, w3);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->views_dirty = true;
+    return 0;
+}
+
+int mi_dmrecon_evict_view(mi_dmrecon_ctx* c, int32_t view_id) {
+    if (!c || view_id < 0 || (size_t)view_id >= c->views.size()) return fail(MI_DMRECON_EINVAL, "bad view id");
+    HostView& v = c->views[view_id];
+    if (v.d_img) { (void)hipFree(v.d_img); v.d_img = nullptr; }
+    v.valid = false; v.levels.clear();
+    c->views_dirty = true;
+    return 0;
+}
+
+int mi_dmrecon_set_features(mi_dmrecon_ctx* c, int32_t n, const float* pos, const int32_t* off, const int32_t* ids) {
+    if (!c || n < 0 || (n > 0 && (!pos || !off || !ids))) return fail(MI_DMRECON_EINVAL, "null argument");
+    c->features.resize(n);
+    for (int i = 0; i < n; ++i) {
+        Feature& f = c->features[i];
+        f.pos[0] = pos[3 * i]; f.pos[1] = pos[3 * i + 1]; f.pos[2] = pos[3 * i + 2];
+        f.ref_begin = off[i]; f.ref_end = off[i + 1];
+    }
+    c->feat_refs.assign(ids, ids + (n ? off[n] : 0));
+    return 0;
+}
+
+int mi_dmrecon_num_levels(mi_dmrecon_ctx* c, int32_t view_id) {
+    if (!c || view_id < 0 || (size_t)view_id >= c->views.size() || !c->views[view_id].d_img)
+        return fail(MI_DMRECON_EINVAL, "unknown view %d", view_id);
+    return (int)c->views[view_id].levels.size();
+}
+
+int mi_dmrecon_level_size(mi_dmrecon_ctx* c, int32_t view_id, int32_t level, int32_t* w, int32_t* h) {
+    int n = mi_dmrecon_num_levels(c, view_id);
+    if (n < 0) return n;
+    if (level < 0 || level >= n) return fail(MI_DMRECON_EINVAL, "level %d out of range", level);
+    if (w) *w = c->views[view_id].levels[level].w;
+    if (h) *h = c->views[view_id].levels[level].h;
+    return 0;
+}
+
+int mi_dmrecon_get_level(mi_dmrecon_ctx* c, int32_t view_id, int32_t level, uint8_t* rgb, float* proj, float* invproj) {
+    int n = mi_dmrecon_num_levels(c, view_id);
+    if (n < 0) return n;
+    if (level < 0 || level >= n) return fail(MI_DMRECON_EINVAL, "level %d out of range", level);
+    HIP_TRY(hipSetDevice(c->device));
+    HostView const& v = c->views[view_id];
+    HostLevel const& L = v.levels[level];
+    if (proj) std::memcpy(proj, L.proj, sizeof(L.proj));
+    if (invproj) std::memcpy(invproj, L.invproj, sizeof(L.invproj));
+    if (rgb) {
+        const size_t np = (size_t)L.w * L.h;
+        if (c->d_stage.reserve(np * 3)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(stage) failed");
+        mi_launch_unpack_rgb(c->stream, v.d_img + L.tex_off, c->d_stage.p, (int)np);
+        HIP_TRY(hipMemcpyAsync(rgb, c->d_stage.p, np * 3, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int mi_dmrecon_global_view_selection(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view,
+                                     int32_t* ids_out, int32_t* n_out) {
+    if (!c || !ids_out || !n_out) return fail(MI_DMRECON_EINVAL, "null argument");
+    int rc = check_settings(st);
+    if (rc) return rc;
+    std::vector<int> g;
+    rc = plan_global_views(c, st, ref_view, g);
+    if (rc) return rc;
+    for (size_t i = 0; i < g.size(); ++i) ids_out[i] = g[i];
+    *n_out = (int)g.size();
+    return 0;
+}
+
+int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views,
+                           mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out,
+                           mi_dmrecon_stats* stats) {
+    const double t_begin = now_ms();
+    if (!c || !ref_views || !maps || n_refs <= 0) return fail(MI_DMRECON_EINVAL, "null argument");
+    int rc = check_settings(st);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    auto cancelled = [&]() {
+        if (!progress) return false;
+        for (int i = 0; i < n_refs; ++i) if (progress[i].cancelled) return true;
+        return false;
+    };
+    for (int i = 0; progress && i < n_refs; ++i) {
+        progress[i].start_time = (uint64_t)std::time(nullptr);
+        progress[i].status = MI_RECON_GLOBALVS;
+    }
+    /* ---- host planning: global view selection and seeds, one plan per reference view */
+    std::vector<JobHost> plans(n_refs);
+    std::vector<int> job_of(n_refs, -1);
+    std::vector<int> plan_rc(n_refs, 0);
+    std::vector<std::string> plan_err(n_refs);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n_refs; ++i) {
+        plans[i].ref_view = ref_views[i];
+        int r = plan_global_views(c, st, ref_views[i], plans[i].global);
+        if (r == 0 && plans[i].global.empty()) r = fail(MI_DMRECON_EGVS, "Global View Selection failed");
+        plan_rc[i] = r;
+        if (r) plan_err[i] = g_err;
+    }
+    std::vector<JobHost> jobs;
+    for (int i = 0; i < n_refs; ++i) {
+        if (status_out) status_out[i] = plan_rc[i];
+        if (plan_rc[i]) {
+            if (n_refs == 1) { g_err = plan_err[i]; return plan_rc[i]; }
+            continue;
+        }
+        HostLevel const& L = c->views[ref_views[i]].levels[st->scale];
+        plans[i].w = L.w; plans[i].h = L.h;
+        job_of[i] = (int)jobs.size();
+        jobs.push_back(plans[i]);
+    }
+    if (jobs.empty()) return fail(MI_DMRECON_EGVS, "Global View Selection failed for every reference view");
+    for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_FEATURES;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int j = 0; j < (int)jobs.size(); ++j) plan_seeds(c, st, jobs[j], j);
+    if (cancelled()) { for (int i = 0; i < n_refs; ++i) progress[i].status = MI_RECON_CANCELLED; return fail(MI_DMRECON_ECANCELLED, "cancelled"); }
+
+    rc = sync_views(c);
+    if (rc) return rc;
+    const int nj = (int)jobs.size();
+    std::vector<DevJob> dj(nj);
+    int max_px = 0;
+    for (int j = 0; j < nj; ++j) { fill_job(c, st, jobs[j], dj[j]); max_px = std::max(max_px, jobs[j].w * jobs[j].h); }
+    size_t total_px = 0;
+    rc = alloc_maps(c, jobs, dj, total_px);
+    if (rc) return rc;
+    if (c->d_jobs.reserve(nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(jobs) failed");
+    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), nj * sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
+    /* seeds of all jobs, concatenated */
+    std::vector<DevEntry> seeds; std::vector<DevHyp> hyps; std::vector<unsigned> keyoff(nj);
+    size_t n_seed_feats = 0;
+    for (int j = 0; j < nj; ++j) {
+        seeds.insert(seeds.end(), jobs[j].seeds.begin(), jobs[j].seeds.end());
+        hyps.insert(hyps.end(), jobs[j].seed_hyp.begin(), jobs[j].seed_hyp.end());
+        keyoff[j] = (unsigned)jobs[j].pix_off;
+        n_seed_feats += jobs[j].n_seeds;
+    }
+    const size_t work_cap = std::max(total_px, seeds.size());
+    if (c->d_work.reserve(work_cap) || c->d_results.reserve(work_cap) || c->d_hyp.reserve(std::max<size_t>(seeds.size(), 1))
+        || c->d_keys.reserve(total_px) || c->d_keyoff.reserve(nj))
+        return fail(MI_DMRECON_EDEVICE, "hipMalloc(work lists) failed");
+    const DevSettings ds = dev_settings(st);
+    /* events for the kernel timings */
+    auto get_event = [&](size_t i) -> hipEvent_t {
+        while (c->events.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; c->events.push_back(e); }
+        return c->events[i];
+    };
+    size_t n_ev = 0;
+    std::vector<std::pair<size_t, int> > ev_kind;     /* (start event index, kind) kind 0 = optimise, 1 = sweep */
+    auto ev_begin = [&](int kind) { hipEvent_t e = get_event(n_ev); if (e) (void)hipEventRecord(e, c->stream); ev_kind.push_back(std::make_pair(n_ev, kind)); n_ev += 2; };
+    auto ev_end = [&]() { hipEvent_t e = get_event(ev_kind.back().first + 1); if (e) (void)hipEventRecord(e, c->stream); };
+
+    int64_t n_launch = 0;
+    if (!seeds.empty()) {
+        HIP_TRY(hipMemcpyAsync(c->d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), c->stream));
+        ev_begin(0);
+        mi_launch_optimize(c->stream, c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
+                           nullptr, (unsigned)seeds.size(), 0, c->d_counters);
+        ev_end();
+        ++n_launch;
+        ev_begin(1);
+        mi_launch_apply_seeds(c->stream, c->d_jobs.p, c->d_work.p, c->d_results.p, (unsigned)seeds.size(), c->d_counters,
+                              c->d_keys.p, c->d_keyoff.p);
+        ev_end();
+    }
+    for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_QUEUE;
+    /* ---- propagation sweeps (replace DMRecon::processQueue, dmrecon.cc:333-434) */
+    int round = 1;
+    const int max_rounds = 4 * (max_px > 0 ? (int)std::sqrt((double)max_px) * 4 : 1) + 64;
+    DevCounters hc;
+    bool was_cancelled = false;
+    for (; round < max_rounds; ++round) {
+        HIP_TRY(hipMemsetAsync(&c->d_counters->n_work, 0, sizeof(unsigned), c->stream));
+        ev_begin(1);
+        mi_launch_generate(c->stream, c->d_jobs.p, nj, max_px, c->d_work.p, c->d_counters, round);
+        ev_end();
+        HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (hc.error_flags & 1u) return fail(MI_DMRECON_EFOOTPRINT, "Negative pixel footprint");
+        for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = hc.n_work; }
+        if (hc.n_work == 0) break;
+        if (cancelled()) { was_cancelled = true; break; }
+        ev_begin(0);
+        mi_launch_optimize(c->stream, c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p, nullptr, c->d_results.p,
+                           nullptr, hc.n_work, round, c->d_counters);
+        ev_end();
+        ++n_launch;
+        ev_begin(1);
+        mi_launch_apply(c->stream, c->d_jobs.p, c->d_work.p, c->d_results.p, hc.n_work, round, c->d_counters);
+        ev_end();
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hc.error_flags & 1u) return fail(MI_DMRECON_EFOOTPRINT, "Negative pixel footprint");
+    if (was_cancelled) {
+        for (int i = 0; i < n_refs; ++i) progress[i].status = MI_RECON_CANCELLED;
+        return fail(MI_DMRECON_ECANCELLED, "cancelled");
+    }
+    /* ---- results back to the caller's buffers */
+    for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_SAVING;
+    std::vector<uint32_t> packed;
+    for (int i = 0; i < n_refs; ++i) {
+        const int j = job_of[i];
+        if (j < 0) continue;
+        const size_t np = (size_t)jobs[j].w * jobs[j].h;
+        mi_dmrecon_maps& m = maps[i];
+        if (m.depth) HIP_TRY(hipMemcpyAsync(m.depth, dj[j].depth, np * 4, hipMemcpyDeviceToHost, c->stream));
+        if (m.conf) HIP_TRY(hipMemcpyAsync(m.conf, dj[j].conf, np * 4, hipMemcpyDeviceToHost, c->stream));
+        if (m.dz) HIP_TRY(hipMemcpyAsync(m.dz, dj[j].dz, np * 8, hipMemcpyDeviceToHost, c->stream));
+        if (m.normal) HIP_TRY(hipMemcpyAsync(m.normal, dj[j].normal, np * 12, hipMemcpyDeviceToHost, c->stream));
+        if (m.views) {
+            packed.resize(np);
+            HIP_TRY(hipMemcpyAsync(packed.data(), dj[j].views, np * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (size_t p = 0; p < np; ++p)
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned g = (packed[p] >> (8 * k)) & 0xFFu;
+                    m.views[4 * p + k] = (g == MI_VIEW_NONE || g >= jobs[j].global.size()) ? -1 : jobs[j].global[g];
+                }
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stats) {
+        stats->n_patch = (int64_t)hc.n_patch; stats->n_eval = (int64_t)hc.n_eval; stats->n_filled = (int64_t)hc.n_filled;
+        stats->n_seeds = (int64_t)n_seed_feats; stats->n_seeds_ok = (int64_t)hc.n_seeds_ok;
+        stats->n_rounds = round; stats->n_launches = n_launch;
+        for (size_t k = 0; k < ev_kind.size(); ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->events[ev_kind[k].first], c->events[ev_kind[k].first + 1]) == hipSuccess) {
+                if (ev_kind[k].second == 0) stats->ms_opt_kernel += ms; else stats->ms_sweep_kernels += ms;
+            }
+        }
+        stats->ms_total = now_ms() - t_begin;
+    }
+    for (int i = 0; progress && i < n_refs; ++i) { progress[i].status = MI_RECON_IDLE; }
+    return 0;
+}
+
+int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n,
+                              const int32_t* xy, const float* hyp, const int32_t* local, float* out, int32_t* out_local) {
+    if (!c || !xy || !hyp || !out || !out_local || n < 0) return fail(MI_DMRECON_EINVAL, "null argument");
+    int rc = check_settings(st);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    JobHost jh; jh.ref_view = ref_view;
+    rc = plan_global_views(c, st, ref_view, jh.global);
+    if (rc) return rc;
+    if (jh.global.empty()) return fail(MI_DMRECON_EGVS, "Global View Selection failed");
+    rc = sync_views(c);
+    if (rc) return rc;
+    HostLevel const& L = c->views[ref_view].levels[st->scale];
+    jh.w = L.w; jh.h = L.h;
+    std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
+    fill_job(c, st, jobs[0], dj[0]);
+    size_t total_px = 0;
+    rc = alloc_maps(c, jobs, dj, total_px);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    std::vector<DevEntry> ent(n); std::vector<DevHyp> hy(n);
+    for (int i = 0; i < n; ++i) {
+        ent[i].job = 0;
+        int x = xy[2 * i], y = xy[2 * i + 1];
+        if (x < 0 || y < 0 || x >= L.w || y >= L.h) { x = 0; y = 0; }     /* fails the border test -> conf 0 */
+        ent[i].xy = x | (y << 16);
+        hy[i].depth = hyp[3 * i]; hy[i].dzI = hyp[3 * i + 1]; hy[i].dzJ = hyp[3 * i + 2];
+        unsigned packed = 0; int cnt = 0;
+        for (int k = 0; k < 4; ++k) {
+            int id = local ? local[4 * i + k] : -1;
+            if (id < 0) continue;
+            std::vector<int>::const_iterator it = std::lower_bound(jh.global.begin(), jh.global.end(), id);
+            if (it == jh.global.end() || *it != id) return fail(MI_DMRECON_EINVAL, "local view %d is not a global view", id);
+            packed |= (unsigned)(it - jh.global.begin()) << (8 * cnt);
+            ++cnt;
+        }
+        for (; cnt < 4; ++cnt) packed |= MI_VIEW_NONE << (8 * cnt);
+        hy[i].views = packed;
+    }
+    if (c->d_jobs.reserve(1) || c->d_work.reserve(n) || c->d_hyp.reserve(n) || c->d_results.reserve(n))
+        return fail(MI_DMRECON_EDEVICE, "hipMalloc failed");
+    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_work.p, ent.data(), n * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hy.data(), n * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
+    mi_launch_optimize(c->stream, c->d_jobs.p, c->d_views.p, c->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
+                       c->d_results.p, nullptr, (unsigned)n, 0, c->d_counters);
+    HIP_TRY(hipGetLastError());
+    std::vector<DevResult> res(n);
+    HIP_TRY(hipMemcpyAsync(res.data(), c->d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) {
+        float* o = out + 8 * i;
+        o[0] = res[i].conf; o[1] = res[i].depth; o[2] = res[i].dzI; o[3] = res[i].dzJ;
+        o[4] = res[i].nx; o[5] = res[i].ny; o[6] = res[i].nz; o[7] = (float)res[i].iters;
+        for (int k = 0; k < 4; ++k) {
+            const unsigned g = (res[i].views >> (8 * k)) & 0xFFu;
+            out_local[4 * i + k] = (g == MI_VIEW_NONE || g >= jh.global.size()) ? -1 : jh.global[g];
+        }
+    }
+    return 0;
+}
+
+int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t x, int32_t y,
+                          float depth, float dzI, float dzJ, float* master, float* ncc, int32_t* ok, float* col,
+                          float* deriv, int32_t* level) {
+    if (!c || !master || !ncc || !ok || !col || !deriv || !level) return fail(MI_DMRECON_EINVAL, "null argument");
+    int rc = check_settings(st);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    JobHost jh; jh.ref_view = ref_view;
+    rc = plan_global_views(c, st, ref_view, jh.global);
+    if (rc) return rc;
+    if (jh.global.empty()) return fail(MI_DMRECON_EGVS, "Global View Selection failed");
+    rc = sync_views(c);
+    if (rc) return rc;
+    HostLevel const& L = c->views[ref_view].levels[st->scale];
+    jh.w = L.w; jh.h = L.h;
+    std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
+    fill_job(c, st, jobs[0], dj[0]);
+    size_t total_px = 0;
+    rc = alloc_maps(c, jobs, dj, total_px);
+    if (rc) return rc;
+    const int G = (int)jh.global.size();
+    const size_t nfl = 5 + G + 2 * (size_t)G * 75;
+    DevBuf<float> dout; DevBuf<int32_t> diout;
+    if (dout.reserve(nfl) || diout.reserve(2 * G) || c->d_jobs.reserve(1)) return fail(MI_DMRECON_EDEVICE, "hipMalloc failed");
+    HIP_TRY(hipMemsetAsync(dout.p, 0, nfl * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(diout.p, 0, 2 * G * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
+    float* d_master = dout.p; float* d_ncc = dout.p + 5; float* d_col = d_ncc + G; float* d_der = d_col + (size_t)G * 75;
+    mi_launch_patch_eval(c->stream, c->d_jobs.p, c->d_views.p, c->d_lut, dev_settings(st), x, y, depth, dzI, dzJ,
+                         d_master, d_ncc, diout.p, d_col, d_der, diout.p + G);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(master, d_master, 5 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(ncc, d_ncc, G * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(col, d_col, (size_t)G * 75 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(deriv, d_der, (size_t)G * 75 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(ok, diout.p, G * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(level, diout.p + G, G * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dout.release(); diout.release();
+    return G;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,82 @@
+/*
+ * Internal POD layouts shared by the host pipeline (dmrecon_host.cpp) and the
+ * device kernels (dmrecon_device.hip).  Not part of the public ABI.
+ */
+#ifndef MI_DMRECON_TYPES_H
+#define MI_DMRECON_TYPES_H
+
+#include <stdint.h>
+
+#define MI_MAX_LEVELS 16
+#define MI_MAX_GLOBAL 32
+#define MI_NS 25            /* filterWidth^2 samples per patch */
+#define MI_PATCHES_PER_WAVE 16
+#define MI_VIEW_NONE 0xFFu
+
+/* One pyramid level of one view, as the sampler needs it (ImagePyramidLevel,
+ * libs/dmrecon/image_pyramid.h:28-54; K = [ax 0 cx; 0 ay cy; 0 0 1]). */
+struct DevLevel {
+    float ax, ay, cx, cy;
+    float inv0;              /* invproj[0] = 1/ax */
+    int32_t w, h;
+    uint32_t tex_off;        /* offset (in texels) of this level inside DevView::img */
+};
+
+/* One view resident in HBM (SingleView + its ImagePyramid). */
+struct DevView {
+    float cam_pos[3];
+    float w2c[12];           /* rows of [R|t] */
+    int32_t n_levels;
+    const uint32_t* img;     /* all levels back to back, RGBA8 (A unused), row-major */
+    DevLevel lv[MI_MAX_LEVELS];
+};
+
+/* One reference view being reconstructed (one mvs::DMRecon instance). */
+struct DevJob {
+    int32_t ref_view, scale, w, h;
+    float inv_a, inv_c, inv_b, inv_d;   /* invproj at `scale`: x' = inv_a*x + inv_c, y' = inv_b*y + inv_d */
+    float rot_t[9];                     /* R^T (camera -> world rotation) */
+    float cam_pos[3];
+    float w2c_z[4];                     /* third row of [R|t] of the reference view */
+    float inv0_s;                       /* footPrintScaled factor */
+    int32_t n_global;
+    int32_t global_ids[MI_MAX_GLOBAL];  /* ascending view ids (GlobalViewSelection result) */
+    /* per-pixel state maps (device), zero = unfilled (single_view.cc:78-81) */
+    float* depth;
+    float* dz;        /* 2 ch */
+    float* conf;
+    float* normal;    /* 3 ch */
+    uint32_t* views;  /* 4 x 8-bit indices into global_ids, MI_VIEW_NONE padded */
+    int32_t* upd;     /* round in which the pixel was last written, -1 = never */
+};
+
+/* Settings as the kernels see them. */
+struct DevSettings {
+    float minNCC, minParallax, acceptNCC, minRefineDiff;
+    int32_t maxIterations, K, useColorScale;
+};
+
+/* Work list entry + result of one patch optimisation attempt chain. */
+struct DevEntry {
+    int32_t job;
+    int32_t xy;              /* x | y << 16 */
+};
+struct DevHyp {              /* explicit hypothesis (seeds / parity hook) */
+    float depth, dzI, dzJ;
+    uint32_t views;          /* packed global indices or all MI_VIEW_NONE */
+};
+struct DevResult {
+    float conf, depth, dzI, dzJ;
+    float nx, ny, nz;
+    uint32_t views;
+    int32_t iters;
+    int32_t accepted;        /* propagate mode: 1 if the pixel state must be overwritten */
+};
+
+struct DevCounters {
+    unsigned long long n_patch, n_eval, n_pass, n_filled, n_seeds_ok;
+    unsigned int n_work;       /* size of the work list being built */
+    unsigned int error_flags;  /* bit0: non-positive master footprint (patch_sampler.cc:78-82) */
+};
+
+#endif
