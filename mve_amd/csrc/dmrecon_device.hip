@@ -1004,6 +1004,9 @@ __global__ __launch_bounds__(256) void k_unpack_rgb(const uint32_t* __restrict__
  */
 __global__ __launch_bounds__(256) void k_pyramid(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                 int iw, int ih, int ow, int oh, float w1, float w2, float w3) {
+    /* hipcc contracts a*b+c into an FMA by default (even through __fmul_rn/__fadd_rn); the reference
+     * bytes come from separately rounded multiply and add, and ties at x.5 do occur in practice. */
+#pragma clang fp contract(off)
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= ow || y >= oh) return;
@@ -1018,16 +1021,18 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint32_t* __restrict__ sr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t t = src[(size_t)ry[r] * iw + rx[k]];
-            v0 = __fadd_rn(v0, __fmul_rn((float)(t & 255u), wt[r][k]));
-            v1 = __fadd_rn(v1, __fmul_rn((float)((t >> 8) & 255u), wt[r][k]));
-            v2 = __fadd_rn(v2, __fmul_rn((float)((t >> 16) & 255u), wt[r][k]));
-            wsum = __fadd_rn(wsum, wt[r][k]);
+            /* plain operators: they (unlike the __f*_rn header wrappers) obey the pragma above */
+            const float p0 = (float)(t & 255u) * wt[r][k];
+            const float p1 = (float)((t >> 8) & 255u) * wt[r][k];
+            const float p2 = (float)((t >> 16) & 255u) * wt[r][k];
+            v0 = v0 + p0; v1 = v1 + p1; v2 = v2 + p2;
+            wsum = wsum + wt[r][k];
         }
     /* math::round: x > 0 ? floor(x + 0.5) : ceil(x - 0.5) */
-    const float q0 = __fdiv_rn(v0, wsum), q1 = __fdiv_rn(v1, wsum), q2 = __fdiv_rn(v2, wsum);
-    const uint32_t b0 = (uint32_t)(q0 > 0.f ? floorf(__fadd_rn(q0, 0.5f)) : 0.f);
-    const uint32_t b1 = (uint32_t)(q1 > 0.f ? floorf(__fadd_rn(q1, 0.5f)) : 0.f);
-    const uint32_t b2 = (uint32_t)(q2 > 0.f ? floorf(__fadd_rn(q2, 0.5f)) : 0.f);
+    const float q0 = v0 / wsum, q1 = v1 / wsum, q2 = v2 / wsum;
+    const uint32_t b0 = (uint32_t)(q0 > 0.f ? floorf(q0 + 0.5f) : 0.f);
+    const uint32_t b1 = (uint32_t)(q1 > 0.f ? floorf(q1 + 0.5f) : 0.f);
+    const uint32_t b2 = (uint32_t)(q2 > 0.f ? floorf(q2 + 0.5f) : 0.f);
     dst[(size_t)y * ow + x] = (b0 & 255u) | ((b1 & 255u) << 8) | ((b2 & 255u) << 16) | 0xFF000000u;
 }
 

@@ -1,0 +1,78 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` through gpurun)")
+
+
+def scene_from_golden(g):
+    from mve_amd.scene_io import Camera, Feature, SceneData
+    cams = []
+    for c in g["cams"]:
+        cams.append(Camera(flen=float(c[0]), paspect=float(c[1]), ppoint=[float(c[2]), float(c[3])],
+                           rot=[float(v) for v in c[4:13]], trans=[float(v) for v in c[13:16]]))
+    imgs = [np.ascontiguousarray(im) for im in g["imgs"]]
+    off, ref = g["foff"], g["fref"]
+    feats = [Feature([float(v) for v in g["fpos"][i]], [int(v) for v in ref[off[i]:off[i + 1]]])
+             for i in range(len(g["fpos"]))]
+    return SceneData(cams, imgs, feats)
+
+
+@pytest.fixture(scope="session")
+def g1():
+    return dict(np.load(os.path.join(GOLDEN, "g1_5views_160x120.npz")))
+
+
+@pytest.fixture(scope="session")
+def g1b():
+    return dict(np.load(os.path.join(GOLDEN, "g1b_5views_322x241_scale1.npz")))
+
+
+@pytest.fixture(scope="session")
+def g2():
+    return dict(np.load(os.path.join(GOLDEN, "g2_2views_160x120_k1.npz")))
+
+
+@pytest.fixture(scope="session")
+def g1_scene(g1):
+    return scene_from_golden(g1)
+
+
+@pytest.fixture(scope="session")
+def g1b_scene(g1b):
+    return scene_from_golden(g1b)
+
+
+@pytest.fixture(scope="session")
+def g2_scene(g2):
+    return scene_from_golden(g2)
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One HIP context for the whole GPU test session (fails loudly without the library / a GPU)."""
+    from mve_amd import api
+    assert api.device_count() > 0, "no HIP device visible: -m gpu tests need an MI355X"
+    return api.Context(0)
+
+
+def map_parity(a_depth, a_conf, b_depth, b_conf):
+    """Map-level parity metrics between two reconstructions of the same view."""
+    ma, mb = a_depth > 0, b_depth > 0
+    both = ma & mb
+    iou = both.sum() / max((ma | mb).sum(), 1)
+    rel = np.abs(a_depth[both] - b_depth[both]) / b_depth[both]
+    cd = np.abs(a_conf[both] - b_conf[both])
+    return dict(iou=float(iou), rel_med=float(np.median(rel)), rel_p99=float(np.percentile(rel, 99)),
+                conf_med=float(np.median(cd)), conf_p99=float(np.percentile(cd, 99)),
+                n_a=int(ma.sum()), n_b=int(mb.sum()))

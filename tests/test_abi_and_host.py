@@ -1,0 +1,93 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/mi_dmrecon.h declares, error behaviour without a GPU, and the host-side mirror of
+mvs::Settings / mvs::DMRecon (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mve_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mi_dmrecon.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_dmrecon_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.load_library()
+    names = header_functions()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(L, n), "libmi_dmrecon.so does not export %s" % n
+    assert sorted(api.EXPORTS) == names
+
+
+def test_settings_defaults_match_reference():
+    # libs/dmrecon/settings.h:25-51
+    L = api.load_library()
+    cs = api.CSettings()
+    L.mi_dmrecon_settings_default(ctypes.byref(cs))
+    assert (cs.filterWidth, cs.maxIterations, cs.nrReconNeighbors, cs.globalVSMax, cs.scale, cs.useColorScale) == (5, 20, 4, 20, 0, 1)
+    assert np.allclose([cs.minNCC, cs.minParallax, cs.acceptNCC, cs.minRefineDiff], [0.3, 10.0, 0.6, 0.001])
+    assert cs.aabbMin[0] == -np.finfo(np.float32).max and cs.aabbMax[2] == np.finfo(np.float32).max
+    s = api.Settings()
+    c2 = s.to_c()
+    for f, _ in api.CSettings._fields_:
+        a, b = getattr(cs, f), getattr(c2, f)
+        if hasattr(a, "__len__"):
+            assert list(a) == list(b)
+        else:
+            assert a == pytest.approx(b)
+    assert s.imageEmbedding == "undistorted" and not s.keepDzMap and not s.keepConfidenceMap
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if api.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        api.Context(0)
+    L = api.load_library()
+    h = ctypes.c_void_p()
+    assert L.mi_dmrecon_ctx_create(0, ctypes.byref(h)) == api.E_DEVICE
+    assert b"no CPU path" in L.mi_dmrecon_last_error()
+
+
+class _FakeScene:
+    n_views = 3
+
+    def level_size(self, v, s):
+        if s > 4:
+            raise ValueError("level out of range")
+        return 64, 48
+
+
+def test_dmrecon_ctor_checks_mirror_reference():
+    # libs/dmrecon/dmrecon.cc:37-46,74-75 throw std::invalid_argument -> ValueError
+    with pytest.raises(ValueError, match="Master view index out of bounds"):
+        api.DMRecon(_FakeScene(), api.Settings(refViewNr=3))
+    with pytest.raises(ValueError, match="Invalid scale factor"):
+        api.DMRecon(_FakeScene(), api.Settings(scale=-1))
+    with pytest.raises(ValueError, match="Invalid image embedding"):
+        api.DMRecon(_FakeScene(), api.Settings(imageEmbedding=""))
+    with pytest.raises(ValueError, match="Invalid master view"):
+        api.DMRecon(_FakeScene(), api.Settings(scale=7))
+    r = api.DMRecon(_FakeScene(), api.Settings(refViewNr=2, scale=1))
+    assert r.getRefViewNr() == 2 and (r.width, r.height) == (64, 48)
+    assert r.getProgress().status == 0 and r.getProgress().filled == 0      # RECON_IDLE
+
+
+def test_oracle_is_not_reachable_from_the_product():
+    # the product package must never import, load or link anything under oracle/
+    pkg = os.path.join(ROOT, "mve_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".cc", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "liboracle" not in txt and "dmrecon_oracle" not in txt and "from oracle" not in txt \
+                    and "import oracle" not in txt, "%s references the oracle" % f

@@ -1,0 +1,87 @@
+"""CPU tests: the oracle restatement (oracle/dmrecon_oracle.cc) against fixtures produced by the
+REAL reference (tests/golden/make_golden.py ran oracle/_ref/dmrecon_ref_strict and
+oracle/_ref/ref_patch_driver, i.e. the unmodified libs/dmrecon compiled -O2 -ffp-contract=off).
+
+The restatement mirrors the reference's float accumulation order, so these are exact comparisons.
+"""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+def test_srgb_table_matches_reference_literal(g1):
+    # the literal table of libs/dmrecon/mvs_tools.cc:30-93 vs the formula at :22-29 in double
+    i = np.arange(256)
+    x = i / 255.0
+    y = np.where(i <= 0.04045 * 255.0, x / 12.92, ((x + 0.055) / 1.055) ** 2.4).astype(np.float32)
+    y[255] = 1.0
+    assert np.array_equal(y, g1["srgb2lin"])
+
+
+def test_global_view_selection(g1, g1_scene):
+    S = orc.OracleScene(g1_scene)
+    assert S.global_vs(orc.make_settings(ref_view=0)) == list(g1["gvs"])
+
+
+def test_full_maps_scale0_bit_exact(g1, g1_scene):
+    S = orc.OracleScene(g1_scene)
+    r = S.reconstruct(orc.make_settings(ref_view=0, scale=0))
+    assert np.array_equal(r["depth"], g1["s0v0_depth"])
+    assert np.array_equal(r["conf"], g1["s0v0_conf"])
+    assert np.array_equal(r["dz"], g1["s0v0_dz"])
+    assert r["stats"]["n_filled"] == int((g1["s0v0_depth"] > 0).sum())
+
+
+def test_full_maps_scale1_odd_size_bit_exact(g1b, g1b_scene):
+    # 322x241 -> 161x121: exercises the principal-point rescale on odd sizes (image_pyramid.cc:39-44)
+    S = orc.OracleScene(g1b_scene)
+    img, _, _ = S.pyramid_level(2, 1)
+    assert np.array_equal(img, g1b["s1v2_undist"])          # byte-exact Gaussian pyramid level
+    r = S.reconstruct(orc.make_settings(ref_view=2, scale=1))
+    assert np.array_equal(r["depth"], g1b["s1v2_depth"])
+    assert np.array_equal(r["conf"], g1b["s1v2_conf"])
+    assert np.array_equal(r["dz"], g1b["s1v2_dz"])
+
+
+def test_two_views_local_neighbors_1(g2, g2_scene):
+    # BASELINE config 1 shape: 2 views need --local-neighbors=1
+    S = orc.OracleScene(g2_scene)
+    r = S.reconstruct(orc.make_settings(ref_view=0, scale=0, local_neighbors=1))
+    assert np.array_equal(r["depth"], g2["s0v0_depth"])
+    assert np.array_equal(r["conf"], g2["s0v0_conf"])
+    r4 = S.reconstruct(orc.make_settings(ref_view=0, scale=0, local_neighbors=4))
+    assert (r4["depth"] > 0).sum() == 0                      # default settings fill nothing with 2 views
+
+
+def test_patch_optimization_vs_reference_classes(g1, g1_scene):
+    S = orc.OracleScene(g1_scene)
+    out, loc = S.patch_optimize(orc.make_settings(ref_view=0), g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
+    ref, ref_loc = g1["opt"], g1["opt_local"]
+    assert np.array_equal(out[:, 0] > 0, ref[:, 0] > 0)
+    assert (ref[:4, 0] == 0).all()                           # border patches fail
+    ok = ref[:, 0] > 0
+    assert ok.sum() >= 10
+    # text round trip of the driver prints 9 significant digits -> exact float32
+    assert np.array_equal(out[ok, :7], ref[ok, :7])
+    assert np.array_equal(loc[ok], ref_loc[ok])
+
+
+def test_patch_sampler_vs_reference_classes(g1, g1_scene):
+    S = orc.OracleScene(g1_scene)
+    st = orc.make_settings(ref_view=0)
+    n_checked = 0
+    for i in range(len(g1["seeds_xy"])):
+        x, y = [int(v) for v in g1["seeds_xy"][i]]
+        d, dzi, dzj = [float(v) for v in g1["seeds_hyp"][i]]
+        e = S.patch_eval(st, x, y, d, dzi, dzj)
+        assert e["master"][0] == g1["ev_master"][i, 0]
+        if not e["master"][0]:
+            continue
+        assert np.array_equal(e["master"][1:], g1["ev_master"][i, 1:])
+        assert np.array_equal(e["ncc"], g1["ev_ncc"][i])
+        assert np.array_equal(e["ok"], g1["ev_ok"][i])
+        okv = e["ok"] > 0
+        assert np.array_equal(e["col"][okv], g1["ev_col"][i][okv])
+        assert np.array_equal(e["deriv"][okv], g1["ev_der"][i][okv])
+        n_checked += int(okv.sum())
+    assert n_checked > 50
