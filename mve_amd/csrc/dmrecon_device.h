@@ -5,16 +5,19 @@
 #include <hip/hip_runtime.h>
 #include "dmrecon_types.h"
 
-void mi_launch_optimize(hipStream_t s, const DevJob* jobs, const DevView* views, const float* lut,
-                        const DevSettings& st, const DevEntry* work, const DevHyp* hyp, DevResult* results,
-                        const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
+/* lanes_per_view: 1 = 16 patches per wavefront (throughput), 16 = one patch per wavefront (latency).
+ * The launch only acts if min_work <= n < max_work, n = *n_work_ptr (if given) or n_work. */
+void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
+                        const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
+                        DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
+                        unsigned max_work, int round, DevCounters* counters);
 void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                           const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
                           float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
 void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_pixels, DevEntry* work,
-                        DevCounters* counters, int round);
-void mi_launch_apply(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
-                     unsigned n_work, int round, DevCounters* counters);
+                        unsigned* round_work, int round);
+void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
+                     const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
                            const unsigned* key_off);

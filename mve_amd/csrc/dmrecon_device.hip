@@ -43,36 +43,108 @@ __shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::
 __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelection ncc[] */
 
 /* ------------------------------------------------------------------------- */
-/* quad (4-lane) communication through DPP quad_perm -- no LDS traffic.       */
+/* Lane layouts.  A patch is optimised by 4 "view slots" (one per local neighbour view);
+ * each view slot is LPV lanes wide and its lanes split the 25 samples of a pass.
+ *   Lay<1>  : view slot = 1 lane, patch = a quad, 16 patches per wavefront.  Throughput layout
+ *             (every lane busy on its own view) used while the work list is large.
+ *   Lay<16> : view slot = a 16-lane DPP row, patch = the whole wavefront.  Latency layout for
+ *             the long tail of small propagation rounds: a pass is 2 samples deep instead of 25.
+ * All cross-lane traffic is DPP (quad_perm / row mirrors) plus a few readlanes; no LDS. */
 
 __device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ int dpp_xor2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_half_mirror(int v) { return __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_mirror(int v) { return __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); }
 template <int K> __device__ __forceinline__ int dpp_bcast(int v) { return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xF, 0xF, true); }
 
-__device__ __forceinline__ float quad_sum(float v) {
-    v += __int_as_float(dpp_xor1(__float_as_int(v)));
-    v += __int_as_float(dpp_xor2(__float_as_int(v)));
-    return v;
+__device__ __forceinline__ float fadd_i(float a, int b) { return a + __int_as_float(b); }
+__device__ __forceinline__ double dmov(double v, int (*f)(int)) {
+    return __hiloint2double(f(__double2hiint(v)), f(__double2loint(v)));
 }
-__device__ __forceinline__ double quad_sum(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    v += __hiloint2double(dpp_xor1(hi), dpp_xor1(lo));
-    lo = __double2loint(v); hi = __double2hiint(v);
-    v += __hiloint2double(dpp_xor2(hi), dpp_xor2(lo));
-    return v;
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+    return __hiloint2double(__shfl_xor(__double2hiint(v), m), __shfl_xor(__double2loint(v), m));
 }
-__device__ __forceinline__ int quad_or(int v) { v |= dpp_xor1(v); v |= dpp_xor2(v); return v; }
-template <int K> __device__ __forceinline__ float quad_bcastf(float v) { return __int_as_float(dpp_bcast<K>(__float_as_int(v))); }
-/* 4-bit mask of a predicate over the lanes of my quad */
-__device__ __forceinline__ unsigned quad_ballot(bool p, int lane) {
-    unsigned long long b = __ballot(p);
-    return (unsigned)(b >> (lane & ~3)) & 0xFu;
-}
+
+template <int LPV> struct Lay;
+
+template <> struct Lay<1> {
+    static constexpr int PATCHES = 16;
+    __device__ static __forceinline__ int vslot(int lane) { return lane & 3; }
+    __device__ static __forceinline__ int sub(int) { return 0; }
+    __device__ static __forceinline__ int patch(int lane) { return lane >> 2; }
+    __device__ static __forceinline__ float view_sum(float v) { return v; }
+    __device__ static __forceinline__ double view_sum(double v) { return v; }
+    __device__ static __forceinline__ bool view_all(bool p) { return p; }
+    __device__ static __forceinline__ float patch_sum(float v) {
+        v = fadd_i(v, dpp_xor1(__float_as_int(v)));
+        v = fadd_i(v, dpp_xor2(__float_as_int(v)));
+        return v;
+    }
+    __device__ static __forceinline__ double patch_sum(double v) {
+        v += dmov(v, dpp_xor1);
+        v += dmov(v, dpp_xor2);
+        return v;
+    }
+    __device__ static __forceinline__ int patch_or(int v) { v |= dpp_xor1(v); v |= dpp_xor2(v); return v; }
+    template <int K> __device__ static __forceinline__ int from_view(int v) { return dpp_bcast<K>(v); }
+    __device__ static __forceinline__ int view_xor1(int v) { return dpp_xor1(v); }
+    __device__ static __forceinline__ int view_xor2(int v) { return dpp_xor2(v); }
+    /* bit k = predicate of view slot k of my patch */
+    __device__ static __forceinline__ unsigned view_ballot(bool p, int lane) {
+        const unsigned long long b = __ballot(p);
+        return (unsigned)(b >> (lane & ~3)) & 0xFu;
+    }
+};
+
+template <> struct Lay<16> {
+    static constexpr int PATCHES = 1;
+    __device__ static __forceinline__ int vslot(int lane) { return lane >> 4; }
+    __device__ static __forceinline__ int sub(int lane) { return lane & 15; }
+    __device__ static __forceinline__ int patch(int) { return 0; }
+    __device__ static __forceinline__ float view_sum(float v) {      /* all 16 lanes of the row get the sum */
+        v = fadd_i(v, dpp_xor1(__float_as_int(v)));
+        v = fadd_i(v, dpp_xor2(__float_as_int(v)));
+        v = fadd_i(v, dpp_half_mirror(__float_as_int(v)));
+        v = fadd_i(v, dpp_mirror(__float_as_int(v)));
+        return v;
+    }
+    __device__ static __forceinline__ double view_sum(double v) {
+        v += dmov(v, dpp_xor1);
+        v += dmov(v, dpp_xor2);
+        v += dmov(v, dpp_half_mirror);
+        v += dmov(v, dpp_mirror);
+        return v;
+    }
+    __device__ static __forceinline__ bool view_all(bool p) {
+        int v = p ? 1 : 0;
+        v &= dpp_xor1(v); v &= dpp_xor2(v); v &= dpp_half_mirror(v); v &= dpp_mirror(v);
+        return v != 0;
+    }
+    /* inputs are already uniform within each row */
+    __device__ static __forceinline__ float patch_sum(float v) {
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return v;
+    }
+    __device__ static __forceinline__ double patch_sum(double v) {
+        v += shfl_xor_d(v, 16);
+        v += shfl_xor_d(v, 32);
+        return v;
+    }
+    __device__ static __forceinline__ int patch_or(int v) { v |= __shfl_xor(v, 16); v |= __shfl_xor(v, 32); return v; }
+    template <int K> __device__ static __forceinline__ int from_view(int v) { return __builtin_amdgcn_readlane(v, 16 * K); }
+    __device__ static __forceinline__ int view_xor1(int v) { return __shfl_xor(v, 16); }
+    __device__ static __forceinline__ int view_xor2(int v) { return __shfl_xor(v, 32); }
+    __device__ static __forceinline__ unsigned view_ballot(bool p, int) {
+        const unsigned long long b = __ballot(p);
+        return (unsigned)((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull));
+    }
+};
 
 /* ------------------------------------------------------------------------- */
 
 struct PatchState {
-    /* quad-uniform */
+    /* uniform over the lanes of a patch */
     const DevJob* job;
     int x, y;
     float depth, dzI, dzJ;
@@ -81,11 +153,11 @@ struct PatchState {
     float mfp;                   /* footPrintScaled(centre point) at the current state */
     float p0x, p0y, p0z;         /* centre patch point (patchPoints[12]) */
     unsigned avail;              /* LocalViewSelection::available over global indices */
-    /* per lane */
+    /* per view slot */
     int sel;                     /* my view: index into job->global_ids, or -1 */
     float cs0, cs1, cs2;         /* PatchOptimization::colorScale[my view] */
     float ncc;                   /* getFastNCC(my view) at the current state */
-    /* counters (per lane, flushed at kernel end) */
+    /* counters (flushed at kernel end) */
     unsigned n_eval, n_pass;
 };
 
@@ -131,7 +203,7 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, in
 }
 
 struct ColorSums {               /* shifted one-pass sums of one colour pass */
-    float s0, s1, s2;            /* shift = colour of sample 0 */
+    float s0, s1, s2;            /* shift (any value near the mean colour; only conditions the sums) */
     float a0, a1, a2;            /* sum (n - s) */
     float aa0, aa1, aa2;         /* sum (n - s)^2 */
     float ba0, ba1, ba2;         /* sum (m - xbar)(n - s) */
@@ -145,19 +217,21 @@ struct GNSums {
 };
 
 /*
- * One patch-view evaluation: the 25 samples of my view (SURVEY 8d unit of work).
+ * One patch-view evaluation: the 25 samples of my view (SURVEY 8d unit of work), split over the
+ * LPV lanes of my view slot.
  * PASS_COLOR  = computeNeighColorSamples + the sums getFastNCC / computeColorScale need
  *               (patch_sampler.cc:347-393,135-163; patch_optimization.cc:81-111)
  * PASS_DEPTH  = fastColAndDeriv + the sums of optimizeDepthOnly (patch_sampler.cc:64-133,
  *               mvs_tools.cc:97-145, patch_optimization.cc:265-299)
  * PASS_NORMAL = fastColAndDeriv + the normal equations of optimizeDepthAndNormal (:302-364)
- * PASS_DUMP   = fastColAndDeriv, samples written to dump_col / dump_der (parity hook)
- * Returns PatchSampler::success[v].
+ * PASS_DUMP   = fastColAndDeriv, samples written to dump_col / dump_der (parity hook, LPV = 1)
+ * Returns PatchSampler::success[v]; sums are complete (reduced over the view slot) on return.
  */
-template <int MODE>
+template <int MODE, int LPV>
 __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& nv, const float* __restrict__ s_lut,
                                             const float* __restrict__ rays, const float* __restrict__ mcol,
-                                            ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der) {
+                                            ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub) {
+    typedef Lay<LPV> L;
     const float cpx = ps.job->cam_pos[0], cpy = ps.job->cam_pos[1], cpz = ps.job->cam_pos[2];
     float step = 0.f;
     if (MODE != PASS_COLOR) {
@@ -174,11 +248,12 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     bool ok = true;
     const float wlim = (float)(nv.w - 1), hlim = (float)(nv.h - 1);
     ColorSums S;
-    S.s0 = S.s1 = S.s2 = 0.f; S.a0 = S.a1 = S.a2 = 0.f; S.aa0 = S.aa1 = S.aa2 = 0.f; S.ba0 = S.ba1 = S.ba2 = 0.f;
+    S.s0 = ps.xbar0 * ps.mmean; S.s1 = ps.xbar1 * ps.mmean; S.s2 = ps.xbar2 * ps.mmean;
+    S.a0 = S.a1 = S.a2 = 0.f; S.aa0 = S.aa1 = S.aa2 = 0.f; S.ba0 = S.ba1 = S.ba2 = 0.f;
     float num = 0.f, den = 0.f;
     double A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, B0 = 0, B1 = 0, B2 = 0;
 
-    for (int i = 0; i < MI_NS; ++i) {
+    for (int i = sub; i < MI_NS; i += LPV) {
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
         const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
         const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;      /* computePatchPoints */
@@ -217,7 +292,6 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         }
         const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
         if (MODE == PASS_COLOR) {
-            if (i == 0) { S.s0 = n[0]; S.s1 = n[1]; S.s2 = n[2]; }
             const float a0 = n[0] - S.s0, a1 = n[1] - S.s1, a2 = n[2] - S.s2;
             S.a0 += a0; S.a1 += a1; S.a2 += a2;
             S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
@@ -240,10 +314,19 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             }
         }
     }
-    if (MODE == PASS_COLOR) cs_out = S;
-    if (MODE == PASS_DEPTH) { gn.num = num; gn.den = den; }
-    if (MODE == PASS_NORMAL) { gn.A00 = A00; gn.A01 = A01; gn.A02 = A02; gn.A11 = A11; gn.A12 = A12; gn.A22 = A22; gn.B0 = B0; gn.B1 = B1; gn.B2 = B2; }
-    return ok;
+    if (MODE == PASS_COLOR) {
+        S.a0 = L::view_sum(S.a0); S.a1 = L::view_sum(S.a1); S.a2 = L::view_sum(S.a2);
+        S.aa0 = L::view_sum(S.aa0); S.aa1 = L::view_sum(S.aa1); S.aa2 = L::view_sum(S.aa2);
+        S.ba0 = L::view_sum(S.ba0); S.ba1 = L::view_sum(S.ba1); S.ba2 = L::view_sum(S.ba2);
+        cs_out = S;
+    }
+    if (MODE == PASS_DEPTH) { gn.num = L::view_sum(num); gn.den = L::view_sum(den); }
+    if (MODE == PASS_NORMAL) {
+        gn.A00 = L::view_sum(A00); gn.A01 = L::view_sum(A01); gn.A02 = L::view_sum(A02);
+        gn.A11 = L::view_sum(A11); gn.A12 = L::view_sum(A12); gn.A22 = L::view_sum(A22);
+        gn.B0 = L::view_sum(B0); gn.B1 = L::view_sum(B1); gn.B2 = L::view_sum(B2);
+    }
+    return L::view_all(ok);
 }
 
 /* getFastNCC from the shifted sums (patch_sampler.cc:135-163) */
@@ -256,13 +339,14 @@ __device__ __forceinline__ float ncc_from_sums(const PatchState& ps, const Color
 }
 
 /* Colour pass of view `gidx` (index into the job's global list) -> NCC; -1 on failure. */
+template <int LPV>
 __device__ __forceinline__ float eval_color(PatchState& ps, const DevView* views, int gidx, const float* s_lut,
-                                            const float* rays, const float* mcol, ColorSums& S, bool& ok, bool count) {
+                                            const float* rays, const float* mcol, ColorSums& S, bool& ok, bool count, int sub) {
     NView nv; int level; GNSums gn;
     ok = false;
     if (gidx < 0) return -1.f;
     if (!setup_view(views, ps.job->global_ids[gidx], ps, nv, level)) return -1.f;
-    ok = sample_pass<PASS_COLOR>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr);
+    ok = sample_pass<PASS_COLOR, LPV>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
     ps.n_pass++;
     if (!ok) return -1.f;
     if (count) ps.n_eval++;
@@ -327,18 +411,20 @@ __device__ __forceinline__ void unit_cross(float ax, float ay, float az, float b
 #define RAD2DEG 57.29577951308232f
 
 /*
- * LocalViewSelection::performVS (local_view_selection.cc:56-147), one quad per patch.
- * Candidates (bits of ps.avail) are spread over the four lanes; NCCs go through s_ncc.
- * On return each lane's ps.sel holds its view (or -1); returns success.
+ * LocalViewSelection::performVS (local_view_selection.cc:56-147) for one patch.
+ * Candidates (bits of ps.avail) are spread over the four view slots; NCCs go through g_ncc.
+ * On return each view slot's ps.sel holds its view (or -1); returns success.
  */
+template <int LPV>
 __device__ __noinline__ bool local_view_selection(PatchState& ps, const DevSettings& st, const DevView* views, int lane) {
+    typedef Lay<LPV> L;
     const float* s_lut = g_lut;
-    const float* rays = g_rays[lane >> 2];
-    const float* mcol = g_mcol[lane >> 2];
-    float* s_ncc = g_ncc[lane >> 2];
-    const int slot = lane & 3;
+    const float* rays = g_rays[L::patch(lane)];
+    const float* mcol = g_mcol[L::patch(lane)];
+    float* s_ncc = g_ncc[L::patch(lane)];
+    const int slot = L::vslot(lane), sub = L::sub(lane);
     const int K = st.K;
-    unsigned selmask = quad_ballot(ps.sel >= 0, lane);
+    unsigned selmask = L::view_ballot(ps.sel >= 0, lane);
     if (__popc(selmask) == K) return true;
     const DevJob* J = ps.job;
     const int G = J->n_global;
@@ -347,22 +433,23 @@ __device__ __noinline__ bool local_view_selection(PatchState& ps, const DevSetti
     for (int g = slot; g < G; g += QUAD) {
         if (!((ps.avail >> g) & 1u)) continue;
         ColorSums S; bool ok;
-        const float t = eval_color(ps, views, g, s_lut, rays, mcol, S, ok, true);
+        const float t = eval_color<LPV>(ps, views, g, s_lut, rays, mcol, S, ok, true, sub);
         if (t < st.minNCC) drop |= 1u << g;
-        s_ncc[g] = t;
+        if (sub == 0) s_ncc[g] = t;
     }
-    drop = (unsigned)quad_or((int)drop);
+    drop = (unsigned)L::patch_or((int)drop);
     ps.avail &= ~drop;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     float rdx, rdy, rdz;
     unit_dir(J->cam_pos, ps.p0x, ps.p0y, ps.p0z, rdx, rdy, rdz);       /* refDir */
     for (;;) {
-        selmask = quad_ballot(ps.sel >= 0, lane);
+        selmask = L::view_ballot(ps.sel >= 0, lane);
         if (__popc(selmask) >= K) break;
-        /* the currently selected views, visible to every lane of the quad */
+        /* the currently selected views, visible to every lane of the patch */
         int sl[4];
-        sl[0] = dpp_bcast<0>(ps.sel); sl[1] = dpp_bcast<1>(ps.sel); sl[2] = dpp_bcast<2>(ps.sel); sl[3] = dpp_bcast<3>(ps.sel);
+        sl[0] = L::template from_view<0>(ps.sel); sl[1] = L::template from_view<1>(ps.sel);
+        sl[2] = L::template from_view<2>(ps.sel); sl[3] = L::template from_view<3>(ps.sel);
         float best = 0.f; int bestg = -1;
         for (int g = slot; g < G; g += QUAD) {
             if (!((ps.avail >> g) & 1u)) continue;
@@ -395,17 +482,17 @@ __device__ __noinline__ bool local_view_selection(PatchState& ps, const DevSetti
             }
             if (score > best) { best = score; bestg = g; }
         }
-        /* quad arg-max; ties -> lowest index (strict '>' in an ascending scan, :134-138) */
+        /* arg-max over the view slots; ties -> lowest index (strict '>' in an ascending scan, :134-138) */
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const float ob = __int_as_float(r == 0 ? dpp_xor1(__float_as_int(best)) : dpp_xor2(__float_as_int(best)));
-            const int og = r == 0 ? dpp_xor1(bestg) : dpp_xor2(bestg);
+            const float ob = __int_as_float(r == 0 ? L::view_xor1(__float_as_int(best)) : L::view_xor2(__float_as_int(best)));
+            const int og = r == 0 ? L::view_xor1(bestg) : L::view_xor2(bestg);
             const bool take = og >= 0 && (bestg < 0 || ob > best || (ob == best && og < bestg));
             if (take) { best = ob; bestg = og; }
         }
         if (bestg < 0) break;                                       /* foundOne == false */
         ps.avail &= ~(1u << bestg);
-        /* give the view to the lowest free lane */
+        /* give the view to the lowest free view slot */
         const unsigned freemask = ~selmask & ((1u << K) - 1u);
         const int target = __ffs(freemask) - 1;
         if (slot == target) {
@@ -415,52 +502,61 @@ __device__ __noinline__ bool local_view_selection(PatchState& ps, const DevSetti
             ps.ncc = s_ncc[bestg];
         }
     }
-    selmask = quad_ballot(ps.sel >= 0, lane);
+    selmask = L::view_ballot(ps.sel >= 0, lane);
     return __popc(selmask) == K;
 }
 
-/* rank of my view among the quad's selected views (std::set iteration order = ascending id) */
-__device__ __forceinline__ unsigned lower_ok_mask(const PatchState& ps, bool my_ok) {
-    /* returns true-ness of: every selected view with a smaller id sampled successfully */
+/* true iff every selected view with a smaller id than mine sampled successfully
+ * (computeColorScale returns at the first failing view; std::set iterates ascending ids) */
+template <int LPV>
+__device__ __forceinline__ bool lower_views_ok(const PatchState& ps, bool my_ok) {
+    typedef Lay<LPV> L;
     int s[4]; int o[4];
     const int mo = my_ok ? 1 : 0;
-    s[0] = dpp_bcast<0>(ps.sel); s[1] = dpp_bcast<1>(ps.sel); s[2] = dpp_bcast<2>(ps.sel); s[3] = dpp_bcast<3>(ps.sel);
-    o[0] = dpp_bcast<0>(mo); o[1] = dpp_bcast<1>(mo); o[2] = dpp_bcast<2>(mo); o[3] = dpp_bcast<3>(mo);
-    unsigned all = 1;
+    s[0] = L::template from_view<0>(ps.sel); s[1] = L::template from_view<1>(ps.sel);
+    s[2] = L::template from_view<2>(ps.sel); s[3] = L::template from_view<3>(ps.sel);
+    o[0] = L::template from_view<0>(mo); o[1] = L::template from_view<1>(mo);
+    o[2] = L::template from_view<2>(mo); o[3] = L::template from_view<3>(mo);
+    bool all = true;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (s[k] >= 0 && s[k] < ps.sel && !o[k]) all = 0;
+        if (s[k] >= 0 && s[k] < ps.sel && !o[k]) all = false;
     return all;
 }
 
 struct PatchResult { float conf, depth, dzI, dzJ, nx, ny, nz; unsigned views; int iters; };
 
 /* colour pass of my view + NCC (+ optional computeColorScale); returns false where optiSuccess turns false */
+template <int LPV>
 __device__ __forceinline__ bool refresh_color(PatchState& ps, const DevSettings& st, const DevView* views,
                                               const float* s_lut, const float* rays, const float* mcol,
                                               bool do_scale, bool count, int lane) {
+    typedef Lay<LPV> L;
     ColorSums S; bool ok;
-    ps.ncc = eval_color(ps, views, ps.sel, s_lut, rays, mcol, S, ok, count);
+    ps.ncc = eval_color<LPV>(ps, views, ps.sel, s_lut, rays, mcol, S, ok, count, L::sub(lane));
     bool good = true;
     if (do_scale && st.useColorScale) {
         const bool active = ps.sel >= 0;
-        const unsigned lower = lower_ok_mask(ps, ok || !active);
+        const bool lower = lower_views_ok<LPV>(ps, ok || !active);
         if (active && ok && lower) good = color_scale_update(ps, S);
     }
-    return quad_ballot(!good, lane) == 0;
+    return L::view_ballot(!good, lane) == 0;
 }
 
 /*
- * PatchOptimization ctor + doAutoOptimization + computeConfidence for one patch, run by a quad.
+ * PatchOptimization ctor + doAutoOptimization + computeConfidence for one patch.
  * hyp_views: packed global indices of the propagated local view set (MI_VIEW_NONE = none).
  */
+template <int LPV>
 __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
                                float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane,
                                PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err) {
+    typedef Lay<LPV> L;
     const float* s_lut = g_lut;
-    float* rays = g_rays[lane >> 2];
-    float* mcol = g_mcol[lane >> 2];
-    const int slot = lane & 3;
+    float* rays = g_rays[L::patch(lane)];
+    float* mcol = g_mcol[L::patch(lane)];
+    const int slot = L::vslot(lane), sub = L::sub(lane);
+    const int pl = slot * LPV + sub;                 /* lane index inside the patch */
     res.conf = 0.f; res.depth = depth0; res.dzI = dzI0; res.dzJ = dzJ0; res.nx = res.ny = res.nz = 0.f;
     res.views = 0xFFFFFFFFu; res.iters = 0;
     PatchState ps;
@@ -472,7 +568,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     const DevView* RV = views + job->ref_view;
     const DevLevel& RL = RV->lv[job->scale];
     const uint32_t* rimg = RV->img + RL.tex_off;
-    for (int i = slot; i < MI_NS; i += QUAD) {
+    for (int i = pl; i < MI_NS; i += 4 * LPV) {
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
         const float fx = (float)(x + di) + 0.5f, fy = (float)(y + dj) + 0.5f;
         float rx = job->inv_a * fx + job->inv_c, ry = job->inv_b * fy + job->inv_d, rz = 1.f;
@@ -485,14 +581,14 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         mcol[3 * i] = s_lut[t & 255u]; mcol[3 * i + 1] = s_lut[(t >> 8) & 255u]; mcol[3 * i + 2] = s_lut[(t >> 16) & 255u];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    /* computeMasterSamples (patch_sampler.cc:297-345): every lane of the quad redundantly */
+    /* computeMasterSamples (patch_sampler.cc:297-345): every lane of the patch redundantly */
     float mm = 0.f;
     for (int k = 0; k < 3 * MI_NS; ++k) mm += mcol[k];
     mm /= 3.f * (float)MI_NS;
     if (mm < 0.01f || mm > 0.99f) return;
     ps.mmean = mm;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int i = slot; i < MI_NS; i += QUAD) { mcol[3 * i] /= mm; mcol[3 * i + 1] /= mm; mcol[3 * i + 2] /= mm; }
+    for (int i = pl; i < MI_NS; i += 4 * LPV) { mcol[3 * i] /= mm; mcol[3 * i + 1] /= mm; mcol[3 * i + 2] /= mm; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     for (int i = 0; i < MI_NS; ++i) { x0 += mcol[3 * i]; x1 += mcol[3 * i + 1]; x2 += mcol[3 * i + 2]; }
@@ -523,13 +619,13 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     const float inv_mm = 1.f / mm;
     ps.cs0 = ps.cs1 = ps.cs2 = inv_mm;
     bool propagated_all = true;
-    if (__popc(quad_ballot(ps.sel >= 0, lane)) != st.K) {
+    if (__popc(L::view_ballot(ps.sel >= 0, lane)) != st.K) {
         propagated_all = false;
-        if (!local_view_selection(ps, st, views, lane)) { n_eval += ps.n_eval; n_pass += ps.n_pass; return; }
+        if (!local_view_selection<LPV>(ps, st, views, lane)) { n_eval += ps.n_eval; n_pass += ps.n_pass; return; }
     }
     /* computeColorScale() at the end of the ctor (patch_optimization.cc:77); the samples of views picked
      * by the view selection are already in the reference's cache at this point -> not a new evaluation */
-    bool opti = refresh_color(ps, st, views, s_lut, rays, mcol, true, propagated_all, lane);
+    bool opti = refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, true, propagated_all, lane);
     bool ncc_valid = true;
     bool converged = false;
     int iter = 0;
@@ -542,12 +638,12 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         gn.num = 0.f; gn.den = 0.f;
         if (active) {
             okv = setup_view(views, job->global_ids[ps.sel], ps, nv, level)
-                && sample_pass<PASS_DEPTH>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr);
+                && sample_pass<PASS_DEPTH, LPV>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr, sub);
             ps.n_pass++;
             if (okv) ps.n_eval++; else { gn.num = 0.f; gn.den = 0.f; }
         }
-        if (quad_ballot(!okv, lane)) { opti = false; break; }
-        const float num = quad_sum(gn.num), den = quad_sum(gn.den);
+        if (L::view_ballot(!okv, lane)) { opti = false; break; }
+        const float num = L::patch_sum(gn.num), den = L::patch_sum(gn.den);
         if (den > 0.f) {
             opti = set_state(ps, rays, ps.depth + num / den, ps.dzI, ps.dzJ);
             ncc_valid = false;
@@ -556,7 +652,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     }
     bool viewRemoved = false;
     while (opti && iter < st.maxIterations) {
-        if (!ncc_valid) { refresh_color(ps, st, views, s_lut, rays, mcol, false, true, lane); ncc_valid = true; }
+        if (!ncc_valid) { refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, false, true, lane); ncc_valid = true; }
         const float oldncc = ps.ncc;
         bool step_ok = false;
         if (iter % 5 == 4 || viewRemoved) {
@@ -565,15 +661,15 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
             gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
             if (active) {
                 okv = setup_view(views, job->global_ids[ps.sel], ps, nv, level)
-                    && sample_pass<PASS_NORMAL>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr);
+                    && sample_pass<PASS_NORMAL, LPV>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr, sub);
                 ps.n_pass++;
                 if (okv) ps.n_eval++;
                 else gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
             }
-            if (quad_ballot(!okv, lane)) { opti = false; break; }
-            const double m0 = quad_sum(gn.A00), m1 = quad_sum(gn.A01), m2 = quad_sum(gn.A02);
-            const double m4 = quad_sum(gn.A11), m5 = quad_sum(gn.A12), m8 = quad_sum(gn.A22);
-            const double b0 = quad_sum(gn.B0), b1 = quad_sum(gn.B1), b2 = quad_sum(gn.B2);
+            if (L::view_ballot(!okv, lane)) { opti = false; break; }
+            const double m0 = L::patch_sum(gn.A00), m1 = L::patch_sum(gn.A01), m2 = L::patch_sum(gn.A02);
+            const double m4 = L::patch_sum(gn.A11), m5 = L::patch_sum(gn.A12), m8 = L::patch_sum(gn.A22);
+            const double b0 = L::patch_sum(gn.B0), b1 = L::patch_sum(gn.B1), b2 = L::patch_sum(gn.B2);
             const double m3 = m1, m6 = m2, m7 = m5;
             /* libs/math/matrix_tools.h:392-399 (determinant), :462-476 (inverse) */
             const double det = m0 * m4 * m8 + m1 * m5 * m6 + m2 * m3 * m7 - m2 * m4 * m6 - m1 * m3 * m8 - m0 * m5 * m7;
@@ -586,7 +682,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
             const float X2 = (float)((i6 * b0 + i7 * b1 + i8 * b2) / det);
             step_ok = set_state(ps, rays, ps.depth + X0, ps.dzI + X1, ps.dzJ + X2);
             /* computeColorScale() on the new state (needs the colour samples anyway for getFastNCC) */
-            const bool cs_ok = refresh_color(ps, st, views, s_lut, rays, mcol, true, true, lane);
+            const bool cs_ok = refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, true, true, lane);
             step_ok = step_ok && cs_ok;
             viewRemoved = false;
         } else {
@@ -595,15 +691,15 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
             gn.num = 0.f; gn.den = 0.f;
             if (active) {
                 okv = setup_view(views, job->global_ids[ps.sel], ps, nv, level)
-                    && sample_pass<PASS_DEPTH>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr);
+                    && sample_pass<PASS_DEPTH, LPV>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr, sub);
                 ps.n_pass++;
                 if (okv) ps.n_eval++; else { gn.num = 0.f; gn.den = 0.f; }
             }
-            if (quad_ballot(!okv, lane)) { opti = false; break; }
-            const float num = quad_sum(gn.num), den = quad_sum(gn.den);
+            if (L::view_ballot(!okv, lane)) { opti = false; break; }
+            const float num = L::patch_sum(gn.num), den = L::patch_sum(gn.den);
             if (den > 0.f) {
                 step_ok = set_state(ps, rays, ps.depth + num / den, ps.dzI, ps.dzJ);
-                refresh_color(ps, st, views, s_lut, rays, mcol, false, true, lane);
+                refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, false, true, lane);
             }
         }
         if (!step_ok) { opti = false; break; }
@@ -611,14 +707,14 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         const float dn = fabsf(ps.ncc - oldncc);
         const bool moving = active && dn > st.minRefineDiff;
         const bool replace = active && (ps.ncc < st.acceptNCC || (iter == 14 && dn > st.minRefineDiff));
-        const unsigned rmask = quad_ballot(replace, lane);
-        const bool conv = quad_ballot(moving, lane) == 0;
+        const unsigned rmask = L::view_ballot(replace, lane);
+        const bool conv = L::view_ballot(moving, lane) == 0;
         if (rmask) {
             viewRemoved = true;
             if (replace) ps.sel = -1;                  /* available[] already false for selected views */
-            if (!local_view_selection(ps, st, views, lane)) { opti = false; break; }
+            if (!local_view_selection<LPV>(ps, st, views, lane)) { opti = false; break; }
             /* computeColorScale(): cached samples for the kept views, fresh ones for the new views */
-            if (!refresh_color(ps, st, views, s_lut, rays, mcol, true, false, lane)) {
+            if (!refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, true, false, lane)) {
                 /* optiSuccess false: the loop condition ends the optimisation unconverged */
                 opti = false; break;
             }
@@ -632,29 +728,31 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     res.iters = iter;
     res.depth = ps.depth; res.dzI = ps.dzI; res.dzJ = ps.dzJ;
     /* local view ids, ascending (std::set order) */
+    int s[4];
+    s[0] = L::template from_view<0>(ps.sel); s[1] = L::template from_view<1>(ps.sel);
+    s[2] = L::template from_view<2>(ps.sel); s[3] = L::template from_view<3>(ps.sel);
     {
-        int s[4];
-        s[0] = dpp_bcast<0>(ps.sel); s[1] = dpp_bcast<1>(ps.sel); s[2] = dpp_bcast<2>(ps.sel); s[3] = dpp_bcast<3>(ps.sel);
+        int t[4] = {s[0], s[1], s[2], s[3]};
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3 - a; ++b) {
-                const unsigned ua = s[b] < 0 ? 0xFFFu : (unsigned)s[b], ub = s[b + 1] < 0 ? 0xFFFu : (unsigned)s[b + 1];
-                if (ua > ub) { const int t = s[b]; s[b] = s[b + 1]; s[b + 1] = t; }
+                const unsigned ua = t[b] < 0 ? 0xFFFu : (unsigned)t[b], ub = t[b + 1] < 0 ? 0xFFFu : (unsigned)t[b + 1];
+                if (ua > ub) { const int tmp = t[b]; t[b] = t[b + 1]; t[b + 1] = tmp; }
             }
         unsigned packed = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) packed |= (s[k] < 0 ? MI_VIEW_NONE : (unsigned)s[k]) << (8 * k);
+        for (int k = 0; k < 4; ++k) packed |= (t[k] < 0 ? MI_VIEW_NONE : (unsigned)t[k]) << (8 * k);
         res.views = packed;
     }
     if (!converged) return;
     /* --- computeConfidence (patch_optimization.cc:114-142): NCCs summed in ascending view order */
     {
-        int s[4]; float c[4];
-        s[0] = dpp_bcast<0>(ps.sel); s[1] = dpp_bcast<1>(ps.sel); s[2] = dpp_bcast<2>(ps.sel); s[3] = dpp_bcast<3>(ps.sel);
-        c[0] = quad_bcastf<0>(ps.ncc); c[1] = quad_bcastf<1>(ps.ncc); c[2] = quad_bcastf<2>(ps.ncc); c[3] = quad_bcastf<3>(ps.ncc);
+        float c[4];
+        const int ni = __float_as_int(ps.ncc);
+        c[0] = __int_as_float(L::template from_view<0>(ni)); c[1] = __int_as_float(L::template from_view<1>(ni));
+        c[2] = __int_as_float(L::template from_view<2>(ni)); c[3] = __int_as_float(L::template from_view<3>(ni));
         float mean = 0.f; int cnt = 0;
-        /* selection sort by id, tiny */
         unsigned used = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -689,21 +787,27 @@ struct OptArgs {
     const DevEntry* work;
     const DevHyp* hyp;        /* explicit hypotheses (seeds / hook); null in propagate mode */
     DevResult* results;
-    const unsigned* n_work_ptr;   /* device-side entry count (propagate) or null */
+    const unsigned* n_work_ptr;   /* device-side entry count (propagate, blind rounds) or null */
     unsigned n_work;
+    unsigned min_work, max_work;  /* this launch only acts if min_work <= n < max_work (layout selection on device) */
     int round;
     DevCounters* counters;
 };
 
+/*
+ * The hot kernel.  LPV = 1: 16 patches per wavefront (throughput); LPV = 16: one patch per
+ * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
+ */
+template <int LPV>
 __global__ __launch_bounds__(WAVE) void k_optimize(OptArgs a) {
+    typedef Lay<LPV> L;
     const int lane = threadIdx.x;
+    const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
+    if (n < a.min_work || n >= a.max_work) return;
     for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
     __syncthreads();
-    const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
-    const int q = lane >> 2;
-    const unsigned e = blockIdx.x * MI_PATCHES_PER_WAVE + q;
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
-    if (e < n) {
+    for (unsigned e = blockIdx.x * L::PATCHES + L::patch(lane); e < n; e += gridDim.x * L::PATCHES) {
         const DevEntry ent = a.work[e];
         const DevJob* job = a.jobs + ent.job;
         const int x = ent.xy & 0xFFFF, y = ent.xy >> 16;
@@ -746,7 +850,7 @@ __global__ __launch_bounds__(WAVE) void k_optimize(OptArgs a) {
                 hd = job->depth[p]; hi = job->dz[2 * p]; hj = job->dz[2 * p + 1]; hv = job->views[p];
             }
             PatchResult r;
-            optimize_patch(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
+            optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
             ++n_patch;
             if (explicit_hyp) {
                 out.conf = r.conf; out.depth = r.depth; out.dzI = r.dzI; out.dzJ = r.dzJ;
@@ -759,10 +863,12 @@ __global__ __launch_bounds__(WAVE) void k_optimize(OptArgs a) {
                 out.accepted = 1;
             }
         }
-        if ((lane & 3) == 0) a.results[e] = out;
+        if (L::vslot(lane) == 0 && L::sub(lane) == 0) a.results[e] = out;
     }
-    /* flush counters: one atomic per wave (n_patch counted once per quad) */
-    if ((lane & 3) != 0) n_patch = 0;
+    /* flush counters: one atomic per wave (per-view counters live in the first lane of each view slot,
+     * the patch counter in the first lane of each patch) */
+    if (L::sub(lane) != 0) { n_eval = 0; n_pass = 0; }
+    if (L::vslot(lane) != 0 || L::sub(lane) != 0) n_patch = 0;
     for (int off = 32; off > 0; off >>= 1) {
         n_eval += __shfl_down(n_eval, off);
         n_pass += __shfl_down(n_pass, off);
@@ -843,11 +949,11 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     if (lane < job->n_global) {
         const int g = lane;
         ColorSums S; bool okc;
-        const float ncc = eval_color(ps, a.views, g, s_lut, s_rays, s_mcol, S, okc, true);
+        const float ncc = eval_color<1>(ps, a.views, g, s_lut, s_rays, s_mcol, S, okc, true, 0);
         a.ncc[g] = ncc;
         NView nv; int level = -1; GNSums gn;
         bool okd = setup_view(a.views, job->global_ids[g], ps, nv, level)
-            && sample_pass<PASS_DUMP>(ps, nv, s_lut, s_rays, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS);
+            && sample_pass<PASS_DUMP, 1>(ps, nv, s_lut, s_rays, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0);
         a.ok[g] = okd ? 1 : 0;
         a.level[g] = level;
     }
@@ -859,7 +965,7 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
 struct SweepArgs {
     const DevJob* jobs;
     DevEntry* work;
-    DevCounters* counters;
+    unsigned* round_work;  /* [round] = size of the work list of that round (zeroed before the call) */
     int round;
     int max_pixels;       /* max over jobs of w*h */
 };
@@ -891,7 +997,7 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
         const int lane = threadIdx.x & 63;
         unsigned base = 0;
         const int leader = __ffsll((long long)m) - 1;
-        if (lane == leader) base = atomicAdd(&a.counters->n_work, (unsigned)__popcll(m));
+        if (lane == leader) base = atomicAdd(&a.round_work[a.round], (unsigned)__popcll(m));
         base = __shfl(base, leader);
         if (any) {
             const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
@@ -926,21 +1032,23 @@ __device__ __forceinline__ void write_pixel(const DevJob* job, int pix, const De
 /* Jacobi write-back of one propagation round (dmrecon.cc:391-398). */
 __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
     const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
-    const unsigned e = blockIdx.x * 256 + threadIdx.x;
-    bool newly = false;
-    if (e < n) {
-        const DevResult r = a.results[e];
-        if (r.accepted) {
-            const DevEntry ent = a.work[e];
-            const DevJob* job = a.jobs + ent.job;
-            const int pix = (ent.xy >> 16) * job->w + (ent.xy & 0xFFFF);
-            newly = job->conf[pix] <= 0.f;
-            write_pixel(job, pix, r, a.round);
+    unsigned filled = 0;
+    for (unsigned base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+        const unsigned e = base + threadIdx.x;
+        bool newly = false;
+        if (e < n) {
+            const DevResult r = a.results[e];
+            if (r.accepted) {
+                const DevEntry ent = a.work[e];
+                const DevJob* job = a.jobs + ent.job;
+                const int pix = (ent.xy >> 16) * job->w + (ent.xy & 0xFFFF);
+                newly = job->conf[pix] <= 0.f;
+                write_pixel(job, pix, r, a.round);
+            }
         }
+        filled += (unsigned)__popcll(__ballot(newly));
     }
-    const unsigned long long m = __ballot(newly);
-    if (m && (threadIdx.x & 63) == __ffsll((long long)m) - 1)
-        atomicAdd(&a.counters->n_filled, (unsigned long long)__popcll(m));
+    if (filled && (threadIdx.x & 63) == 0) atomicAdd(&a.counters->n_filled, (unsigned long long)filled);
 }
 
 /* Seeds (dmrecon.cc:297-330): several features may round to the same pixel; the sequential
@@ -1039,15 +1147,19 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint32_t* __restrict__ sr
 /* ------------------------------------------------------------------------- */
 /* Host-callable launchers (declared in dmrecon_device.h).                     */
 
-void mi_launch_optimize(hipStream_t s, const DevJob* jobs, const DevView* views, const float* lut,
-                        const DevSettings& st, const DevEntry* work, const DevHyp* hyp, DevResult* results,
-                        const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters) {
-    if (n_work == 0) return;
+void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
+                        const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
+                        DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
+                        unsigned max_work, int round, DevCounters* counters) {
+    if (grid_blocks == 0) return;
     OptArgs a;
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
-    a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.round = round; a.counters = counters;
-    const unsigned blocks = (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE;
-    hipLaunchKernelGGL(k_optimize, dim3(blocks), dim3(WAVE), 0, s, a);
+    a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
+    a.round = round; a.counters = counters;
+    if (lanes_per_view == 16)
+        hipLaunchKernelGGL(k_optimize<16>, dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_optimize<1>, dim3(grid_blocks), dim3(WAVE), 0, s, a);
 }
 
 void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
@@ -1060,19 +1172,19 @@ void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views
 }
 
 void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_pixels, DevEntry* work,
-                        DevCounters* counters, int round) {
+                        unsigned* round_work, int round) {
     SweepArgs a;
-    a.jobs = jobs; a.work = work; a.counters = counters; a.round = round; a.max_pixels = max_pixels;
+    a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round; a.max_pixels = max_pixels;
     hipLaunchKernelGGL(k_generate, dim3((max_pixels + 255) / 256, n_jobs), dim3(256), 0, s, a);
 }
 
-void mi_launch_apply(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
-                     unsigned n_work, int round, DevCounters* counters) {
-    if (n_work == 0) return;
+void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
+                     const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters) {
+    if (grid_blocks == 0) return;
     ApplyArgs a;
-    a.jobs = jobs; a.work = work; a.results = results; a.n_work_ptr = nullptr; a.n_work = n_work; a.round = round;
+    a.jobs = jobs; a.work = work; a.results = results; a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.round = round;
     a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0;
-    hipLaunchKernelGGL(k_apply, dim3((n_work + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_apply, dim3(grid_blocks), dim3(256), 0, s, a);
 }
 
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,

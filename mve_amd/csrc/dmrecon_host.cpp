@@ -16,12 +16,14 @@
 #include "../../include/mi_dmrecon.h"
 
 #include <hip/hip_runtime.h>
+#include <omp.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <limits>
@@ -155,6 +157,7 @@ struct mi_dmrecon_ctx {
     DevBuf<unsigned long long> d_keys;
     DevBuf<unsigned> d_keyoff;
     DevBuf<uint8_t> d_stage;
+    DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
     std::vector<hipEvent_t> events;
 };
 
@@ -210,59 +213,93 @@ inline float parallax(V3 const& p, HostView const& v1, HostView const& v2) {   /
     return std::acos(dp) * 180.f / kPi;
 }
 
-/* analyzeFeatures + GlobalViewSelection::performVS for one reference view; fills plan.global.
- * Same arithmetic and tie-breaking as the reference; the only change is that
- * SingleView::seesFeature's linear scan (single_view.h:166-173) is a bitmap lookup. */
+/* analyzeFeatures + GlobalViewSelection::performVS for one reference view; fills `global`.
+ * Same arithmetic, operation order and tie-breaking as the reference (dmrecon.cc:178-208,
+ * global_view_selection.cc:33-101), so the greedy arg-max sees the same floats.  What differs is
+ * bookkeeping only: SingleView::seesFeature's linear scan (single_view.h:166-173) is a bitmap, the
+ * unit directions feature->camera are computed once, and the pairwise parallax penalty of a newly
+ * selected view is computed once instead of once per greedy round (multiplying by a cached factor,
+ * or by 1.0f where the reference skips, gives bit-identical products). */
 int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref, std::vector<int>& global) {
     const size_t nv = c->views.size();
     if (ref < 0 || (size_t)ref >= nv) return fail(MI_DMRECON_EINVAL, "Master view index out of bounds");
     HostView const& R = c->views[ref];
     if (!R.valid) return fail(MI_DMRECON_EINVAL, "Invalid master view");
     if ((size_t)st->scale >= R.levels.size()) return fail(MI_DMRECON_EINVAL, "scale %d beyond pyramid of view %d", st->scale, ref);
-    const size_t nf = c->features.size();
-    std::vector<std::vector<int> > featInd(nv);
-    std::vector<std::vector<uint8_t> > sees(nv);
-    for (size_t v = 0; v < nv; ++v) sees[v].assign(nf, 0);
-    for (size_t i = 0; i < nf; ++i) {                                       /* dmrecon.cc:185-207 */
+    /* features attached to the reference view (dmrecon.cc:185-196), local index = position in `feat` */
+    std::vector<int> feat;
+    for (size_t i = 0; i < c->features.size(); ++i) {
         Feature const& f = c->features[i];
         if (!contains_view(c, f, ref)) continue;
         V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
         if (!R.pointInFrustum(p)) continue;
         if (!in_box(p, st->aabbMin, st->aabbMax)) continue;
+        feat.push_back((int)i);
+    }
+    const size_t nf = feat.size();
+    std::vector<std::vector<int> > featInd(nv);             /* per view: local feature indices, ascending */
+    std::vector<std::vector<uint8_t> > sees(nv);
+    for (size_t v = 0; v < nv; ++v) sees[v].assign(nf, 0);
+    for (size_t l = 0; l < nf; ++l) {                       /* dmrecon.cc:198-206 */
+        Feature const& f = c->features[feat[l]];
+        V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
         for (int j = f.ref_begin; j < f.ref_end; ++j) {
             int id = c->feat_refs[j];
             if (id < 0 || id >= (int)nv || !c->views[id].valid) continue;
-            if (c->views[id].pointInFrustum(p)) { featInd[id].push_back((int)i); sees[id][i] = 1; }
+            if (c->views[id].pointInFrustum(p)) { featInd[id].push_back((int)l); sees[id][l] = 1; }
+        }
+    }
+    /* unit directions camera -> feature for every view that has features (parallax(), mvs_tools.h:46-56) */
+    std::vector<std::vector<V3> > dir(nv);
+    for (size_t v = 0; v < nv; ++v) {
+        if (featInd[v].empty() && (int)v != ref) continue;
+        dir[v].resize(nf);
+        for (size_t l = 0; l < nf; ++l) {
+            Feature const& f = c->features[feat[l]];
+            dir[v][l] = normalized(sub(mk(f.pos[0], f.pos[1], f.pos[2]), c->views[v].pos()));
+        }
+    }
+    auto parallax_l = [&](size_t l, size_t v1, size_t v2) {
+        float dp = std::max(std::min(dot3(dir[v1][l].v, dir[v2][l].v), 1.f), -1.f);
+        return std::acos(dp) * 180.f / kPi;
+    };
+    /* the part of benefitFromView's score that does not depend on the selected set (:76-89) */
+    std::vector<std::vector<float> > base(nv);
+    for (size_t i = 0; i < nv; ++i) {
+        if ((int)i == ref || !c->views[i].valid) continue;
+        base[i].resize(featInd[i].size());
+        for (size_t k = 0; k < featInd[i].size(); ++k) {
+            const size_t l = featInd[i][k];
+            Feature const& f = c->features[feat[l]];
+            V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
+            float score = 1.f;
+            float plx = parallax_l(l, ref, i);
+            if (plx < st->minParallax) score *= (plx / 10.f) * (plx / 10.f);
+            float mfp = R.footPrint(p, st->scale);
+            float nfp = c->views[i].footPrint(p, 0);
+            float ratio = mfp / nfp;
+            if (ratio > 2.) ratio = 2. / ratio;
+            else if (ratio > 1.) ratio = 1.;
+            score *= ratio;
+            base[i][k] = score;
         }
     }
     std::vector<char> available(nv, 1);                                     /* global_view_selection.cc:23-30 */
     available[ref] = 0;
     for (size_t i = 0; i < nv; ++i) if (!c->views[i].valid) available[i] = 0;
     std::vector<int> selected;          /* kept sorted ascending = std::set order */
+    /* pen[c][i][k]: factor view c (once selected) contributes to feature k of candidate i (:91-98) */
+    std::vector<std::vector<std::vector<float> > > pen(nv);
     bool foundOne = true;
     while (foundOne && selected.size() < (size_t)st->globalVSMax) {
         float maxBenefit = 0.f; size_t maxView = 0; foundOne = false;
         for (size_t i = 0; i < nv; ++i) {
             if (!available[i]) continue;
-            HostView const& T = c->views[i];
             float benefit = 0;
-            for (size_t k = 0; k < featInd[i].size(); ++k) {                /* benefitFromView, :62-101 */
-                float score = 1.f;
-                Feature const& f = c->features[featInd[i][k]];
-                V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
-                float plx = parallax(p, R, T);
-                if (plx < st->minParallax) score *= (plx / 10.f) * (plx / 10.f);
-                float mfp = R.footPrint(p, st->scale);
-                float nfp = T.footPrint(p, 0);
-                float ratio = mfp / nfp;
-                if (ratio > 2.) ratio = 2. / ratio;
-                else if (ratio > 1.) ratio = 1.;
-                score *= ratio;
-                for (size_t s = 0; s < selected.size(); ++s) {
-                    if (!sees[selected[s]][featInd[i][k]]) continue;
-                    plx = parallax(p, c->views[selected[s]], T);
-                    if (plx < st->minParallax) score *= (plx / 10.f) * (plx / 10.f);
-                }
+            const size_t nk = featInd[i].size();
+            for (size_t k = 0; k < nk; ++k) {
+                float score = base[i][k];
+                for (size_t s = 0; s < selected.size(); ++s) score *= pen[selected[s]][i][k];
                 benefit += score;
             }
             if (benefit > maxBenefit) { maxBenefit = benefit; maxView = i; foundOne = true; }
@@ -270,6 +307,20 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
         if (foundOne) {
             selected.insert(std::upper_bound(selected.begin(), selected.end(), (int)maxView), (int)maxView);
             available[maxView] = 0;
+            if (selected.size() < (size_t)st->globalVSMax) {
+                pen[maxView].resize(nv);
+                for (size_t i = 0; i < nv; ++i) {
+                    if (!available[i]) continue;
+                    std::vector<float>& pv = pen[maxView][i];
+                    pv.assign(featInd[i].size(), 1.f);
+                    for (size_t k = 0; k < featInd[i].size(); ++k) {
+                        const size_t l = featInd[i][k];
+                        if (!sees[maxView][l]) continue;
+                        float plx = parallax_l(l, maxView, i);
+                        if (plx < st->minParallax) pv[k] = (plx / 10.f) * (plx / 10.f);
+                    }
+                }
+            }
         }
     }
     global = selected;
@@ -405,7 +456,7 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     for (size_t i = 0; i < c->views.size(); ++i) if (c->views[i].d_img) (void)hipFree(c->views[i].d_img);
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
     c->d_views.release(); c->d_jobs.release(); c->d_work.release(); c->d_hyp.release(); c->d_results.release();
-    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release();
+    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_round_work.release();
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
@@ -543,6 +594,14 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                            mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out,
                            mi_dmrecon_stats* stats) {
     const double t_begin = now_ms();
+    double t_mark = t_begin;
+    const bool trace_phases = std::getenv("MI_DMRECON_TRACE") != nullptr;
+    auto mark = [&](const char* what) {
+        if (!trace_phases) return;
+        const double t = now_ms();
+        fprintf(stderr, "[mi_dmrecon] phase %-22s %8.3f ms\n", what, t - t_mark);
+        t_mark = t;
+    };
     if (!c || !ref_views || !maps || n_refs <= 0) return fail(MI_DMRECON_EINVAL, "null argument");
     int rc = check_settings(st);
     if (rc) return rc;
@@ -562,7 +621,8 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     std::vector<int> job_of(n_refs, -1);
     std::vector<int> plan_rc(n_refs, 0);
     std::vector<std::string> plan_err(n_refs);
-#pragma omp parallel for schedule(dynamic, 1)
+    const int n_threads = std::max(1, std::min(std::min(n_refs, omp_get_num_procs()), 32));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
     for (int i = 0; i < n_refs; ++i) {
         plans[i].ref_view = ref_views[i];
         int r = plan_global_views(c, st, ref_views[i], plans[i].global);
@@ -570,6 +630,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         plan_rc[i] = r;
         if (r) plan_err[i] = g_err;
     }
+    mark("global view selection");
     std::vector<JobHost> jobs;
     for (int i = 0; i < n_refs; ++i) {
         if (status_out) status_out[i] = plan_rc[i];
@@ -584,10 +645,11 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     }
     if (jobs.empty()) return fail(MI_DMRECON_EGVS, "Global View Selection failed for every reference view");
     for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_FEATURES;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
     for (int j = 0; j < (int)jobs.size(); ++j) plan_seeds(c, st, jobs[j], j);
     if (cancelled()) { for (int i = 0; i < n_refs; ++i) progress[i].status = MI_RECON_CANCELLED; return fail(MI_DMRECON_ECANCELLED, "cancelled"); }
 
+    mark("seed planning");
     rc = sync_views(c);
     if (rc) return rc;
     const int nj = (int)jobs.size();
@@ -621,18 +683,24 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     };
     size_t n_ev = 0;
     std::vector<std::pair<size_t, int> > ev_kind;     /* (start event index, kind) kind 0 = optimise, 1 = sweep */
+    std::vector<unsigned> ev_work;                    /* work-list size of each optimise launch (trace only) */
+    const bool trace = std::getenv("MI_DMRECON_TRACE") != nullptr;
     auto ev_begin = [&](int kind) { hipEvent_t e = get_event(n_ev); if (e) (void)hipEventRecord(e, c->stream); ev_kind.push_back(std::make_pair(n_ev, kind)); n_ev += 2; };
     auto ev_end = [&]() { hipEvent_t e = get_event(ev_kind.back().first + 1); if (e) (void)hipEventRecord(e, c->stream); };
 
+    mark("setup + uploads (async)");
     int64_t n_launch = 0;
+    if (c->d_round_work.reserve(MI_MAX_ROUNDS)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(round counters) failed");
+    HIP_TRY(hipMemsetAsync(c->d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), c->stream));
     if (!seeds.empty()) {
         HIP_TRY(hipMemcpyAsync(c->d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), c->stream));
-        ev_begin(0);
-        mi_launch_optimize(c->stream, c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
-                           nullptr, (unsigned)seeds.size(), 0, c->d_counters);
+        ev_begin(0); ev_work.push_back((unsigned)seeds.size());
+        mi_launch_optimize(c->stream, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
+                           c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
+                           nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0, c->d_counters);
         ev_end();
         ++n_launch;
         ev_begin(1);
@@ -641,30 +709,72 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         ev_end();
     }
     for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_QUEUE;
-    /* ---- propagation sweeps (replace DMRecon::processQueue, dmrecon.cc:333-434) */
+    /* ---- propagation sweeps (replace DMRecon::processQueue, dmrecon.cc:333-434).
+     * Phase A: while the work list is large, one host-visible round at a time with the throughput
+     *          layout (16 patches per wavefront), grid sized to the list.
+     * Phase B: the long tail of small rounds is enqueued blind in chunks -- the kernels read the
+     *          round's list size from device memory -- with the latency layout (one patch per
+     *          wavefront), so a round costs a few tens of microseconds instead of a host round trip. */
+    const unsigned TAIL_THRESHOLD = 12288, TAIL_GRID = 3072, TAIL_CHUNK = 32;
     int round = 1;
-    const int max_rounds = 4 * (max_px > 0 ? (int)std::sqrt((double)max_px) * 4 : 1) + 64;
+    const int max_rounds = std::min<int>(MI_MAX_ROUNDS - TAIL_CHUNK - 2, 4 * (max_px > 0 ? (int)std::sqrt((double)max_px) * 4 : 1) + 64);
     DevCounters hc;
-    bool was_cancelled = false;
-    for (; round < max_rounds; ++round) {
-        HIP_TRY(hipMemsetAsync(&c->d_counters->n_work, 0, sizeof(unsigned), c->stream));
+    std::memset(&hc, 0, sizeof(hc));
+    bool was_cancelled = false, done = false;
+    std::vector<unsigned> rw(TAIL_CHUNK);
+    /* phase A */
+    for (; round < max_rounds && !done; ++round) {
         ev_begin(1);
-        mi_launch_generate(c->stream, c->d_jobs.p, nj, max_px, c->d_work.p, c->d_counters, round);
+        mi_launch_generate(c->stream, c->d_jobs.p, nj, max_px, c->d_work.p, c->d_round_work.p, round);
         ev_end();
+        unsigned n_work = 0;
+        HIP_TRY(hipMemcpyAsync(&n_work, c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (hc.error_flags & 1u) return fail(MI_DMRECON_EFOOTPRINT, "Negative pixel footprint");
-        for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = hc.n_work; }
-        if (hc.n_work == 0) break;
+        for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = n_work; }
+        if (n_work == 0) { done = true; break; }
         if (cancelled()) { was_cancelled = true; break; }
-        ev_begin(0);
-        mi_launch_optimize(c->stream, c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p, nullptr, c->d_results.p,
-                           nullptr, hc.n_work, round, c->d_counters);
+        const bool tail = n_work < TAIL_THRESHOLD;
+        ev_begin(0); ev_work.push_back(n_work);
+        if (tail)
+            mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p,
+                               nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters);
+        else
+            mi_launch_optimize(c->stream, 1, (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE, c->d_jobs.p, c->d_views.p,
+                               c->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
+                               c->d_counters);
         ev_end();
         ++n_launch;
         ev_begin(1);
-        mi_launch_apply(c->stream, c->d_jobs.p, c->d_work.p, c->d_results.p, hc.n_work, round, c->d_counters);
+        mi_launch_apply(c->stream, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
         ev_end();
+        if (tail) { ++round; break; }
+    }
+    mark("seeds + phase A rounds");
+    /* phase B */
+    while (!done && !was_cancelled && round < max_rounds) {
+        const int first = round;
+        for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
+            mi_launch_generate(c->stream, c->d_jobs.p, nj, max_px, c->d_work.p, c->d_round_work.p, round);
+            ev_begin(0); ev_work.push_back(0u);
+            mi_launch_optimize(c->stream, 16, TAIL_GRID, c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p, nullptr,
+                               c->d_results.p, c->d_round_work.p + round, 0u, 1u, 0xFFFFFFFFu, round, c->d_counters);
+            ev_end();
+            mi_launch_apply(c->stream, 64, c->d_jobs.p, c->d_work.p, c->d_results.p, c->d_round_work.p + round, 0u, round,
+                            c->d_counters);
+        }
+        HIP_TRY(hipMemcpyAsync(rw.data(), c->d_round_work.p + first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (hc.error_flags & 1u) return fail(MI_DMRECON_EFOOTPRINT, "Negative pixel footprint");
+        for (unsigned k = 0; k < TAIL_CHUNK; ++k) {
+            ev_work[ev_work.size() - TAIL_CHUNK + k] = rw[k];
+            if (rw[k] == 0) { done = true; round = first + (int)k; break; }
+            ++n_launch;
+        }
+        for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = rw[TAIL_CHUNK - 1]; }
+        if (cancelled()) was_cancelled = true;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
@@ -674,6 +784,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         for (int i = 0; i < n_refs; ++i) progress[i].status = MI_RECON_CANCELLED;
         return fail(MI_DMRECON_ECANCELLED, "cancelled");
     }
+    mark("phase B rounds");
     /* ---- results back to the caller's buffers */
     for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_SAVING;
     std::vector<uint32_t> packed;
@@ -698,6 +809,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    mark("download");
     if (stats) {
         stats->n_patch = (int64_t)hc.n_patch; stats->n_eval = (int64_t)hc.n_eval; stats->n_filled = (int64_t)hc.n_filled;
         stats->n_seeds = (int64_t)n_seed_feats; stats->n_seeds_ok = (int64_t)hc.n_seeds_ok;
@@ -709,6 +821,17 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             }
         }
         stats->ms_total = now_ms() - t_begin;
+    }
+    if (trace) {
+        size_t w = 0;
+        for (size_t k = 0; k < ev_kind.size(); ++k) {
+            if (ev_kind[k].second != 0) continue;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, c->events[ev_kind[k].first], c->events[ev_kind[k].first + 1]);
+            if (ev_work[w] || ms > 0.02f) fprintf(stderr, "[mi_dmrecon] optimise launch %zu: %u entries, %.3f ms\n", w, ev_work[w], ms);
+            ++w;
+        }
+        fprintf(stderr, "[mi_dmrecon] total %.2f ms host wall\n", now_ms() - t_begin);
     }
     for (int i = 0; progress && i < n_refs; ++i) { progress[i].status = MI_RECON_IDLE; }
     return 0;
@@ -759,8 +882,12 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     HIP_TRY(hipMemcpyAsync(c->d_work.p, ent.data(), n * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hy.data(), n * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
-    mi_launch_optimize(c->stream, c->d_jobs.p, c->d_views.p, c->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
-                       c->d_results.p, nullptr, (unsigned)n, 0, c->d_counters);
+    /* MI_DMRECON_HOOK_LPV=16 runs the hook through the latency layout (tests cover both layouts) */
+    const char* lpv_env = std::getenv("MI_DMRECON_HOOK_LPV");
+    const int lpv = (lpv_env && std::atoi(lpv_env) == 16) ? 16 : 1;
+    mi_launch_optimize(c->stream, lpv, lpv == 16 ? (unsigned)n : ((unsigned)n + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
+                       c->d_jobs.p, c->d_views.p, c->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
+                       c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters);
     HIP_TRY(hipGetLastError());
     std::vector<DevResult> res(n);
     HIP_TRY(hipMemcpyAsync(res.data(), c->d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));

@@ -12,6 +12,7 @@
 #define MI_NS 25            /* filterWidth^2 samples per patch */
 #define MI_PATCHES_PER_WAVE 16
 #define MI_VIEW_NONE 0xFFu
+#define MI_MAX_ROUNDS 8192      /* per-round work counters kept on the device */
 
 /* One pyramid level of one view, as the sampler needs it (ImagePyramidLevel,
  * libs/dmrecon/image_pyramid.h:28-54; K = [ax 0 cx; 0 ay cy; 0 0 1]). */
@@ -75,8 +76,8 @@ struct DevResult {
 
 struct DevCounters {
     unsigned long long n_patch, n_eval, n_pass, n_filled, n_seeds_ok;
-    unsigned int n_work;       /* size of the work list being built */
     unsigned int error_flags;  /* bit0: non-positive master footprint (patch_sampler.cc:78-82) */
+    unsigned int pad;
 };
 
 #endif

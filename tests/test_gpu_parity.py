@@ -137,6 +137,22 @@ def test_patch_optimization_vs_oracle_many(ctx_g1, g1_scene):
         assert (np.abs(go[ok, 4:7] - oo[ok, 4:7]).max(1) <= 1e-3).mean() >= 0.98   # normals
 
 
+def test_latency_layout_matches_throughput_layout(ctx_g1, g1, monkeypatch):
+    # the tail rounds run one patch per wavefront (16 lanes per view); same maths, different lane layout
+    st = api.Settings(refViewNr=0)
+    a, al = ctx_g1.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
+    monkeypatch.setenv("MI_DMRECON_HOOK_LPV", "16")
+    b, bl = ctx_g1.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
+    assert np.array_equal(a[:, 0] > 0, b[:, 0] > 0)
+    ok = a[:, 0] > 0
+    assert np.abs(a[ok, 1] - b[ok, 1]).max() / 10.0 <= 1e-5      # only the summation order differs
+    assert np.abs(a[ok, 0] - b[ok, 0]).max() <= 1e-4
+    assert np.array_equal(al[ok], bl[ok]) and np.array_equal(a[ok, 7], b[ok, 7])
+    ref = g1["opt"]
+    okr = (b[:, 0] > 0) & (ref[:, 0] > 0)
+    assert (np.abs(b[okr, 1] - ref[okr, 1]) / ref[okr, 1] <= 1e-3).mean() >= 0.99
+
+
 def test_maps_vs_reference_scale0(ctx_g1, g1):
     r = ctx_g1.reconstruct(api.Settings(refViewNr=0), [0])[0]
     assert_map_parity(map_parity(r["depth"], r["conf"], g1["s0v0_depth"], g1["s0v0_conf"]))
