@@ -175,8 +175,9 @@ __device__ __forceinline__ void project(const NView& nv, float px, float py, flo
     float cz_ = nv.m8 * px + nv.m9 * py + nv.m10 * pz + nv.m11;
     float sx = nv.ax * cx_ + nv.cx * cz_;
     float sy = nv.ay * cy_ + nv.cy * cz_;
-    u = sx / cz_ - 0.5f;
-    v = sy / cz_ - 0.5f;
+    const float iz = __frcp_rn(cz_);          /* v_rcp_f32 (1 ulp): far inside the 1e-5 colour tolerance */
+    u = sx * iz - 0.5f;
+    v = sy * iz - 0.5f;
 }
 
 /* mip level rule of patch_sampler.cc:72-91 / :353-373.  Returns false if nfp <= 0. */
@@ -202,7 +203,7 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, in
     return true;
 }
 
-struct ColorSums {               /* shifted one-pass sums of one colour pass */
+struct ColorSums {               /* shifted one-pass sums of the colours of one view at one state */
     float s0, s1, s2;            /* shift (any value near the mean colour; only conditions the sums) */
     float a0, a1, a2;            /* sum (n - s) */
     float aa0, aa1, aa2;         /* sum (n - s)^2 */
@@ -211,20 +212,28 @@ struct ColorSums {               /* shifted one-pass sums of one colour pass */
 
 enum { PASS_COLOR = 0, PASS_DEPTH = 1, PASS_NORMAL = 2, PASS_DUMP = 3 };
 
+/* Gauss-Newton sums of one view at one state.
+ * Depth-only form, per colour channel c and independent of later colour-scale changes:
+ *   dr_c = sum d_c (m_c - cs0_c n_c)   (cs0 = the colour scale at pass time)
+ *   dn_c = sum d_c n_c,  dd_c = sum d_c^2
+ * so that for any colour scale cs:  num = sum_c cs_c (dr_c - (cs_c - cs0_c) dn_c),  den = sum_c cs_c^2 dd_c
+ * which is optimizeDepthOnly's  sum (cs d)(m - cs n) / sum (cs d)^2  (patch_optimization.cc:283-290). */
 struct GNSums {
-    float num, den;              /* optimizeDepthOnly */
-    double A00, A01, A02, A11, A12, A22, B0, B1, B2;   /* optimizeDepthAndNormal */
+    float dr0, dr1, dr2, dn0, dn1, dn2, dd0, dd1, dd2;
+    float c00, c01, c02;                               /* cs0 */
+    double A00, A01, A02, A11, A12, A22, B0, B1, B2;   /* optimizeDepthAndNormal (:312-343), colour scale baked in */
 };
 
 /*
- * One patch-view evaluation: the 25 samples of my view (SURVEY 8d unit of work), split over the
- * LPV lanes of my view slot.
- * PASS_COLOR  = computeNeighColorSamples + the sums getFastNCC / computeColorScale need
- *               (patch_sampler.cc:347-393,135-163; patch_optimization.cc:81-111)
- * PASS_DEPTH  = fastColAndDeriv + the sums of optimizeDepthOnly (patch_sampler.cc:64-133,
- *               mvs_tools.cc:97-145, patch_optimization.cc:265-299)
- * PASS_NORMAL = fastColAndDeriv + the normal equations of optimizeDepthAndNormal (:302-364)
- * PASS_DUMP   = fastColAndDeriv, samples written to dump_col / dump_der (parity hook, LPV = 1)
+ * One pass over the 25 samples of my view (split over the LPV lanes of my view slot) at the current
+ * patch state.  It always yields the colour sums that getFastNCC / computeColorScale need
+ * (patch_sampler.cc:347-393,135-163; patch_optimization.cc:81-111), and in addition
+ *   PASS_DEPTH  the colour-scale independent sums of optimizeDepthOnly,
+ *   PASS_NORMAL the normal equations of optimizeDepthAndNormal (with the current colour scale),
+ *   PASS_DUMP   the raw samples (parity hook, LPV = 1).
+ * The reference samples the same texels twice per Gauss-Newton iteration -- computeNeighColorSamples
+ * on the new state, then fastColAndDeriv on that same state in the next iteration (patch_sampler.cc:64-133,
+ * mvs_tools.cc:97-145); one fused pass here gathers them once.
  * Returns PatchSampler::success[v]; sums are complete (reduced over the view slot) on return.
  */
 template <int MODE, int LPV>
@@ -233,7 +242,8 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
                                             ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub) {
     typedef Lay<LPV> L;
     const float cpx = ps.job->cam_pos[0], cpy = ps.job->cam_pos[1], cpz = ps.job->cam_pos[2];
-    float step = 0.f;
+    float step = 0.f, dnorm = 0.f;
+    bool ok = true;
     if (MODE != PASS_COLOR) {
         /* derivative step size from the centre sample (patch_sampler.cc:93-100; sample 12 hard-coded there) */
         float rx = rays[36], ry = rays[37], rz = rays[38];
@@ -241,19 +251,24 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         project(nv, ps.p0x, ps.p0y, ps.p0z, u0, v0);
         project(nv, ps.p0x + rx, ps.p0y + ry, ps.p0z + rz, u1, v1);
         float du = u1 - u0, dv = v1 - v0;
-        float d = sqrtf(du * du + dv * dv);
-        if (!(d > 0.f)) return false;
-        step = 1.f / d;
+        dnorm = sqrtf(du * du + dv * dv);              /* deriv /= stepSize  ==  deriv * dnorm */
+        ok = dnorm > 0.f;
+        step = ok ? __frcp_rn(dnorm) : 0.f;
     }
-    bool ok = true;
     const float wlim = (float)(nv.w - 1), hlim = (float)(nv.h - 1);
     ColorSums S;
     S.s0 = ps.xbar0 * ps.mmean; S.s1 = ps.xbar1 * ps.mmean; S.s2 = ps.xbar2 * ps.mmean;
     S.a0 = S.a1 = S.a2 = 0.f; S.aa0 = S.aa1 = S.aa2 = 0.f; S.ba0 = S.ba1 = S.ba2 = 0.f;
-    float num = 0.f, den = 0.f;
+    float dr0 = 0.f, dr1 = 0.f, dr2 = 0.f, dn0 = 0.f, dn1 = 0.f, dn2 = 0.f, dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
     double A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, B0 = 0, B1 = 0, B2 = 0;
 
-    for (int i = sub; i < MI_NS; i += LPV) {
+    constexpr int NITER = (LPV == 1) ? MI_NS : (MI_NS + LPV - 1) / LPV;
+    constexpr int NITER_UNROLL = (LPV == 1) ? 1 : NITER;
+#pragma unroll NITER_UNROLL
+    for (int it = 0; it < NITER; ++it) {
+        const int iraw = sub + it * LPV;
+        const bool live = iraw < MI_NS;                /* LPV = 16: second trip only for lanes 0..8 */
+        const int i = live ? iraw : (MI_NS - 1);
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
         const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
         const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;      /* computePatchPoints */
@@ -287,26 +302,29 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             n[c] = (1.f - fy) * xa + fy * xb;
             if (MODE != PASS_COLOR) {
                 /* exact directional derivative of the bilinear surface, mvs_tools.cc:131-143; /= stepSize */
-                dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) / step;
+                dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) * dnorm;
             }
         }
+        const float wgt = live ? 1.f : 0.f;            /* dead trips contribute nothing */
         const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
-        if (MODE == PASS_COLOR) {
-            const float a0 = n[0] - S.s0, a1 = n[1] - S.s1, a2 = n[2] - S.s2;
-            S.a0 += a0; S.a1 += a1; S.a2 += a2;
-            S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
-            S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
-        } else if (MODE == PASS_DUMP) {
+        if (MODE == PASS_DUMP) {
             dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
             dump_der[3 * i] = dr[0]; dump_der[3 * i + 1] = dr[1]; dump_der[3 * i + 2] = dr[2];
         } else {
-            const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
-            const float r0_ = m0 - ps.cs0 * n[0], r1_ = m1 - ps.cs1 * n[1], r2_ = m2 - ps.cs2 * n[2];
-            const float gg = g0 * g0 + g1 * g1 + g2 * g2;
-            const float gr = g0 * r0_ + g1 * r1_ + g2 * r2_;
+            const float a0 = (n[0] - S.s0) * wgt, a1 = (n[1] - S.s1) * wgt, a2 = (n[2] - S.s2) * wgt;
+            S.a0 += a0; S.a1 += a1; S.a2 += a2;
+            S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
+            S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
             if (MODE == PASS_DEPTH) {
-                num += gr; den += gg;
-            } else {
+                const float e0 = dr[0] * wgt, e1 = dr[1] * wgt, e2 = dr[2] * wgt;
+                dr0 += e0 * (m0 - ps.cs0 * n[0]); dr1 += e1 * (m1 - ps.cs1 * n[1]); dr2 += e2 * (m2 - ps.cs2 * n[2]);
+                dn0 += e0 * n[0]; dn1 += e1 * n[1]; dn2 += e2 * n[2];
+                dd0 += e0 * dr[0]; dd1 += e1 * dr[1]; dd2 += e2 * dr[2];
+            } else if (MODE == PASS_NORMAL) {
+                const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
+                const float r0_ = m0 - ps.cs0 * n[0], r1_ = m1 - ps.cs1 * n[1], r2_ = m2 - ps.cs2 * n[2];
+                const float gg = (g0 * g0 + g1 * g1 + g2 * g2) * wgt;
+                const float gr = (g0 * r0_ + g1 * r1_ + g2 * r2_) * wgt;
                 const float fi = (float)di, fj = (float)dj;
                 A00 += (double)gg; A01 += (double)(fi * gg); A02 += (double)(fj * gg);
                 A11 += (double)(fi * fi * gg); A12 += (double)(fi * fj * gg); A22 += (double)(fj * fj * gg);
@@ -314,13 +332,18 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             }
         }
     }
-    if (MODE == PASS_COLOR) {
+    if (MODE != PASS_DUMP) {
         S.a0 = L::view_sum(S.a0); S.a1 = L::view_sum(S.a1); S.a2 = L::view_sum(S.a2);
         S.aa0 = L::view_sum(S.aa0); S.aa1 = L::view_sum(S.aa1); S.aa2 = L::view_sum(S.aa2);
         S.ba0 = L::view_sum(S.ba0); S.ba1 = L::view_sum(S.ba1); S.ba2 = L::view_sum(S.ba2);
         cs_out = S;
     }
-    if (MODE == PASS_DEPTH) { gn.num = L::view_sum(num); gn.den = L::view_sum(den); }
+    if (MODE == PASS_DEPTH) {
+        gn.dr0 = L::view_sum(dr0); gn.dr1 = L::view_sum(dr1); gn.dr2 = L::view_sum(dr2);
+        gn.dn0 = L::view_sum(dn0); gn.dn1 = L::view_sum(dn1); gn.dn2 = L::view_sum(dn2);
+        gn.dd0 = L::view_sum(dd0); gn.dd1 = L::view_sum(dd1); gn.dd2 = L::view_sum(dd2);
+        gn.c00 = ps.cs0; gn.c01 = ps.cs1; gn.c02 = ps.cs2;
+    }
     if (MODE == PASS_NORMAL) {
         gn.A00 = L::view_sum(A00); gn.A01 = L::view_sum(A01); gn.A02 = L::view_sum(A02);
         gn.A11 = L::view_sum(A11); gn.A12 = L::view_sum(A12); gn.A22 = L::view_sum(A22);
@@ -526,21 +549,38 @@ __device__ __forceinline__ bool lower_views_ok(const PatchState& ps, bool my_ok)
 
 struct PatchResult { float conf, depth, dzI, dzJ, nx, ny, nz; unsigned views; int iters; };
 
-/* colour pass of my view + NCC (+ optional computeColorScale); returns false where optiSuccess turns false */
+/* computeColorScale over the selected views from their colour sums (patch_optimization.cc:81-111):
+ * ascending view order, stops at the first view whose sampling failed.  Returns false where the
+ * reference sets optiSuccess = false. */
 template <int LPV>
-__device__ __forceinline__ bool refresh_color(PatchState& ps, const DevSettings& st, const DevView* views,
-                                              const float* s_lut, const float* rays, const float* mcol,
-                                              bool do_scale, bool count, int lane) {
+__device__ __forceinline__ bool color_scale_step(PatchState& ps, const DevSettings& st, const ColorSums& S, bool okv, int lane) {
     typedef Lay<LPV> L;
-    ColorSums S; bool ok;
-    ps.ncc = eval_color<LPV>(ps, views, ps.sel, s_lut, rays, mcol, S, ok, count, L::sub(lane));
+    if (!st.useColorScale) return true;
+    const bool active = ps.sel >= 0;
+    const bool lower = lower_views_ok<LPV>(ps, okv || !active);
     bool good = true;
-    if (do_scale && st.useColorScale) {
-        const bool active = ps.sel >= 0;
-        const bool lower = lower_views_ok<LPV>(ps, ok || !active);
-        if (active && ok && lower) good = color_scale_update(ps, S);
-    }
+    if (active && okv && lower) good = color_scale_update(ps, S);
     return L::view_ballot(!good, lane) == 0;
+}
+
+/* One fused pass of my view at the current state; sets ps.ncc (getFastNCC).  Returns success[v]. */
+template <int MODE, int LPV>
+__device__ __forceinline__ bool run_pass(PatchState& ps, const DevView* views, const float* s_lut, const float* rays,
+                                         const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int sub) {
+    bool okv = true;
+    ps.ncc = -1.f;
+    if (MODE == PASS_NORMAL) gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
+    if (ps.sel >= 0) {
+        NView nv; int level;
+        okv = setup_view(views, ps.job->global_ids[ps.sel], ps, nv, level)
+            && sample_pass<MODE, LPV>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
+        ps.n_pass++;
+        if (okv) {
+            ps.ncc = ncc_from_sums(ps, S);
+            if (count_color) ps.n_eval++;
+        }
+    }
+    return okv;
 }
 
 /*
@@ -623,50 +663,66 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         propagated_all = false;
         if (!local_view_selection<LPV>(ps, st, views, lane)) { n_eval += ps.n_eval; n_pass += ps.n_pass; return; }
     }
-    /* computeColorScale() at the end of the ctor (patch_optimization.cc:77); the samples of views picked
-     * by the view selection are already in the reference's cache at this point -> not a new evaluation */
-    bool opti = refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, true, propagated_all, lane);
-    bool ncc_valid = true;
-    bool converged = false;
-    int iter = 0;
+    /*
+     * doAutoOptimization (patch_optimization.cc:170-242) as a pass-driven state machine.  Each turn of the
+     * loop runs ONE fused pass at the current state (colour sums + the Gauss-Newton sums the NEXT step
+     * needs), then finishes the decision of the step that led here, then takes the next step.
+     */
+    enum { CTX_CTOR, CTX_FIRST4, CTX_STEP, CTX_REPLACED, CTX_REPASS };
+    bool opti = true, converged = false, viewRemoved = false, step_was_normal = false;
+    int iter = 0, need = PASS_DEPTH, ctx = CTX_CTOR;
+    bool count_color = propagated_all;   /* samples of views picked by the view selection are already cached there */
+    float oldncc = -1.f;
     const bool active = ps.sel >= 0;
-    NView nv; int level; ColorSums Sdummy; GNSums gn;
-
-    /* --- doAutoOptimization (patch_optimization.cc:170-242) */
-    while (opti && iter < 4) {                          /* first four iterations: depth only */
-        bool okv = true;
-        gn.num = 0.f; gn.den = 0.f;
-        if (active) {
-            okv = setup_view(views, job->global_ids[ps.sel], ps, nv, level)
-                && sample_pass<PASS_DEPTH, LPV>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr, sub);
-            ps.n_pass++;
-            if (okv) ps.n_eval++; else { gn.num = 0.f; gn.den = 0.f; }
-        }
-        if (L::view_ballot(!okv, lane)) { opti = false; break; }
-        const float num = L::patch_sum(gn.num), den = L::patch_sum(gn.den);
-        if (den > 0.f) {
-            opti = set_state(ps, rays, ps.depth + num / den, ps.dzI, ps.dzJ);
-            ncc_valid = false;
-        }
-        ++iter;
-    }
-    bool viewRemoved = false;
-    while (opti && iter < st.maxIterations) {
-        if (!ncc_valid) { refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, false, true, lane); ncc_valid = true; }
-        const float oldncc = ps.ncc;
-        bool step_ok = false;
-        if (iter % 5 == 4 || viewRemoved) {
-            /* optimizeDepthAndNormal */
-            bool okv = true;
-            gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
-            if (active) {
-                okv = setup_view(views, job->global_ids[ps.sel], ps, nv, level)
-                    && sample_pass<PASS_NORMAL, LPV>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr, sub);
-                ps.n_pass++;
-                if (okv) ps.n_eval++;
-                else gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
+    ColorSums S; GNSums gn;
+    S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
+    for (;;) {
+        bool okv;
+        if (need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, S, gn, count_color, sub);
+        else if (need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, views, s_lut, rays, mcol, S, gn, count_color, sub);
+        else okv = run_pass<PASS_COLOR, LPV>(ps, views, s_lut, rays, mcol, S, gn, count_color, sub);
+        /* ---- finish what led to this pass */
+        if (ctx == CTX_CTOR || ctx == CTX_REPLACED) {
+            /* computeColorScale() at the end of the ctor (:77) / after replaceViews (:231) */
+            if (!color_scale_step<LPV>(ps, st, S, okv, lane)) { opti = false; break; }
+        } else if (ctx == CTX_STEP) {
+            if (step_was_normal) {
+                /* optimizeDepthAndNormal is followed by computeColorScale on the new state (:197-199) */
+                if (!color_scale_step<LPV>(ps, st, S, okv, lane)) { opti = false; break; }
             }
-            if (L::view_ballot(!okv, lane)) { opti = false; break; }
+            /* convergence / view replacement (:207-239) */
+            const float dn = fabsf(ps.ncc - oldncc);
+            const bool moving = active && dn > st.minRefineDiff;
+            const bool replace = active && (ps.ncc < st.acceptNCC || (iter == 14 && dn > st.minRefineDiff));
+            const unsigned rmask = L::view_ballot(replace, lane);
+            const bool conv = L::view_ballot(moving, lane) == 0;
+            if (rmask) {
+                viewRemoved = true;
+                if (replace) ps.sel = -1;              /* available[] is already false for selected views */
+                if (!local_view_selection<LPV>(ps, st, views, lane)) { opti = false; break; }
+                ++iter;
+                need = PASS_COLOR; ctx = CTX_REPLACED; count_color = false;   /* cached / VS-evaluated samples */
+                continue;
+            }
+            if (conv) { converged = true; break; }
+            ++iter;
+            if (step_was_normal && need == PASS_NORMAL) {
+                /* the colour scale baked into these normal equations has just changed: redo the pass */
+                ctx = CTX_REPASS; count_color = false; step_was_normal = false;
+                continue;
+            }
+        }
+        /* ---- loop condition of the main loop (:185-186) */
+        if (iter >= 4 && iter >= st.maxIterations) break;
+        /* ---- take the step of iteration `iter` from the sums of this pass */
+        const bool first4 = iter < 4;
+        const int want = (!first4 && (iter % 5 == 4 || viewRemoved)) ? PASS_NORMAL : PASS_DEPTH;
+        if (need != want) { need = want; ctx = CTX_REPASS; count_color = false; continue; }
+        if (L::view_ballot(!okv, lane)) { opti = false; break; }       /* fastColAndDeriv failed (:277-280,:321-324) */
+        if (active) ps.n_eval++;                                       /* this pass stood in for fastColAndDeriv */
+        oldncc = ps.ncc;
+        bool step_ok = false;
+        if (want == PASS_NORMAL) {
             const double m0 = L::patch_sum(gn.A00), m1 = L::patch_sum(gn.A01), m2 = L::patch_sum(gn.A02);
             const double m4 = L::patch_sum(gn.A11), m5 = L::patch_sum(gn.A12), m8 = L::patch_sum(gn.A22);
             const double b0 = L::patch_sum(gn.B0), b1 = L::patch_sum(gn.B1), b2 = L::patch_sum(gn.B2);
@@ -681,49 +737,34 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
             const float X1 = (float)((i3 * b0 + i4 * b1 + i5 * b2) / det);
             const float X2 = (float)((i6 * b0 + i7 * b1 + i8 * b2) / det);
             step_ok = set_state(ps, rays, ps.depth + X0, ps.dzI + X1, ps.dzJ + X2);
-            /* computeColorScale() on the new state (needs the colour samples anyway for getFastNCC) */
-            const bool cs_ok = refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, true, true, lane);
-            step_ok = step_ok && cs_ok;
             viewRemoved = false;
+            step_was_normal = true;
         } else {
-            /* optimizeDepthOnly */
-            bool okv = true;
-            gn.num = 0.f; gn.den = 0.f;
-            if (active) {
-                okv = setup_view(views, job->global_ids[ps.sel], ps, nv, level)
-                    && sample_pass<PASS_DEPTH, LPV>(ps, nv, s_lut, rays, mcol, Sdummy, gn, nullptr, nullptr, sub);
-                ps.n_pass++;
-                if (okv) ps.n_eval++; else { gn.num = 0.f; gn.den = 0.f; }
+            /* optimizeDepthOnly (:265-299) from the colour-scale independent sums */
+            float num = 0.f, den = 0.f;
+            if (active && okv) {
+                num = ps.cs0 * (gn.dr0 - (ps.cs0 - gn.c00) * gn.dn0) + ps.cs1 * (gn.dr1 - (ps.cs1 - gn.c01) * gn.dn1)
+                    + ps.cs2 * (gn.dr2 - (ps.cs2 - gn.c02) * gn.dn2);
+                den = ps.cs0 * ps.cs0 * gn.dd0 + ps.cs1 * ps.cs1 * gn.dd1 + ps.cs2 * ps.cs2 * gn.dd2;
             }
-            if (L::view_ballot(!okv, lane)) { opti = false; break; }
-            const float num = L::patch_sum(gn.num), den = L::patch_sum(gn.den);
-            if (den > 0.f) {
-                step_ok = set_state(ps, rays, ps.depth + num / den, ps.dzI, ps.dzJ);
-                refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, false, true, lane);
-            }
+            num = L::patch_sum(num); den = L::patch_sum(den);
+            if (den > 0.f) step_ok = set_state(ps, rays, ps.depth + num / den, ps.dzI, ps.dzJ);
+            else step_ok = first4;                     /* the first four iterations tolerate denom <= 0 (:177-180) */
+            step_was_normal = false;
         }
         if (!step_ok) { opti = false; break; }
-        /* convergence / view replacement (patch_optimization.cc:207-239) */
-        const float dn = fabsf(ps.ncc - oldncc);
-        const bool moving = active && dn > st.minRefineDiff;
-        const bool replace = active && (ps.ncc < st.acceptNCC || (iter == 14 && dn > st.minRefineDiff));
-        const unsigned rmask = L::view_ballot(replace, lane);
-        const bool conv = L::view_ballot(moving, lane) == 0;
-        if (rmask) {
-            viewRemoved = true;
-            if (replace) ps.sel = -1;                  /* available[] already false for selected views */
-            if (!local_view_selection<LPV>(ps, st, views, lane)) { opti = false; break; }
-            /* computeColorScale(): cached samples for the kept views, fresh ones for the new views */
-            if (!refresh_color<LPV>(ps, st, views, s_lut, rays, mcol, true, false, lane)) {
-                /* optiSuccess false: the loop condition ends the optimisation unconverged */
-                opti = false; break;
-            }
-        } else if (conv) {
-            converged = true;
-            break;
+        if (first4) {
+            ++iter;
+            need = (iter >= 4 && iter % 5 == 4) ? PASS_NORMAL : PASS_DEPTH;
+            ctx = CTX_FIRST4;
+            count_color = (iter == 4);                 /* the reference first asks for NCCs when the main loop starts */
+        } else {
+            need = ((iter + 1) % 5 == 4) ? PASS_NORMAL : PASS_DEPTH;
+            ctx = CTX_STEP;
+            count_color = true;
         }
-        ++iter;
     }
+    (void)opti;
     n_eval += ps.n_eval; n_pass += ps.n_pass;
     res.iters = iter;
     res.depth = ps.depth; res.dzI = ps.dzI; res.dzJ = ps.dzJ;
