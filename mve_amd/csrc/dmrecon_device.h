@@ -18,6 +18,8 @@ void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_p
                         unsigned* round_work, int round);
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                      const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
+void mi_launch_expand(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
+                      const unsigned* n_work_ptr, DevEntry* next_work, unsigned* round_work, int round);
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
                            const unsigned* key_off);

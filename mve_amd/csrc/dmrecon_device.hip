@@ -41,6 +41,11 @@ __shared__ float g_lut[256];                                   /* sRGB -> linear
 __shared__ float g_rays[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterViewDirs */
 __shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterColorSamples */
 __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelection ncc[] */
+/* per (patch, view slot): the selected neighbour view as the sampler needs it, so that a pass starts
+ * from LDS instead of three dependent global loads (view -> level -> texels) */
+#define VC_WORDS 24
+__shared__ float g_vc[MI_PATCHES_PER_WAVE][4][VC_WORDS];
+enum { VC_M = 0, VC_AX = 12, VC_AY, VC_CX, VC_CY, VC_W, VC_H, VC_IMG_LO, VC_IMG_HI, VC_INV0, VC_NLEV, VC_LEVEL, VC_GIDX };
 
 /* ------------------------------------------------------------------------- */
 /* Lane layouts.  A patch is optimised by 4 "view slots" (one per local neighbour view);
@@ -152,6 +157,9 @@ struct PatchState {
     float sqrDevX, mmean;        /* PatchSampler::sqrDevX, masterMeanCol */
     float mfp;                   /* footPrintScaled(centre point) at the current state */
     float p0x, p0y, p0z;         /* centre patch point (patchPoints[12]) */
+    float jcx, jcy, jcz;         /* reference camera centre */
+    float jz0, jz1, jz2, jz3;    /* third row of the reference [R|t] */
+    float jinv0;                 /* invproj[0] of the reference level */
     unsigned avail;              /* LocalViewSelection::available over global indices */
     /* per view slot */
     int sel;                     /* my view: index into job->global_ids, or -1 */
@@ -241,7 +249,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
                                             const float* __restrict__ rays, const float* __restrict__ mcol,
                                             ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub) {
     typedef Lay<LPV> L;
-    const float cpx = ps.job->cam_pos[0], cpy = ps.job->cam_pos[1], cpz = ps.job->cam_pos[2];
+    const float cpx = ps.jcx, cpy = ps.jcy, cpz = ps.jcz;
     float step = 0.f, dnorm = 0.f;
     bool ok = true;
     if (MODE != PASS_COLOR) {
@@ -382,12 +390,11 @@ __device__ __forceinline__ bool set_state(PatchState& ps, const float* rays, flo
     /* tmpDepth is linear in (i, j): its minimum over the window is at a corner */
     const float a = 2.f * fabsf(dzI) + 2.f * fabsf(dzJ);
     bool ok = (depth - a) > 0.f && depth == depth && a == a;
-    const DevJob* J = ps.job;
-    ps.p0x = J->cam_pos[0] + depth * rays[36];
-    ps.p0y = J->cam_pos[1] + depth * rays[37];
-    ps.p0z = J->cam_pos[2] + depth * rays[38];
-    const float z = J->w2c_z[0] * ps.p0x + J->w2c_z[1] * ps.p0y + J->w2c_z[2] * ps.p0z + J->w2c_z[3];
-    ps.mfp = z * J->inv0_s;                           /* footPrintScaled */
+    ps.p0x = ps.jcx + depth * rays[36];
+    ps.p0y = ps.jcy + depth * rays[37];
+    ps.p0z = ps.jcz + depth * rays[38];
+    const float z = ps.jz0 * ps.p0x + ps.jz1 * ps.p0y + ps.jz2 * ps.p0z + ps.jz3;
+    ps.mfp = z * ps.jinv0;                            /* footPrintScaled */
     return ok;
 }
 
@@ -563,16 +570,65 @@ __device__ __forceinline__ bool color_scale_step(PatchState& ps, const DevSettin
     return L::view_ballot(!good, lane) == 0;
 }
 
+/* setup_view through the per-(patch, view slot) LDS record: global memory is touched only when my view
+ * or its mip level changed since the last pass.  Same level rule as setup_view. */
+template <int LPV>
+__device__ __forceinline__ bool setup_view_cached(const DevView* __restrict__ views, const PatchState& ps, float* vc,
+                                                  NView& nv, int sub) {
+    const int view_id = ps.job->global_ids[ps.sel];
+    if (__float_as_int(vc[VC_GIDX]) != ps.sel) {
+        const DevView* V = views + view_id;
+        if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) vc[VC_M + k] = V->w2c[k];
+            vc[VC_INV0] = V->lv[0].inv0;
+            vc[VC_NLEV] = __int_as_float(V->n_levels);
+            vc[VC_LEVEL] = __int_as_float(-1);
+            vc[VC_GIDX] = __int_as_float(ps.sel);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    nv.m8 = vc[VC_M + 8]; nv.m9 = vc[VC_M + 9]; nv.m10 = vc[VC_M + 10]; nv.m11 = vc[VC_M + 11];
+    const float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
+    const float nfp = z * vc[VC_INV0];               /* SingleView::footPrint */
+    if (!(nfp > 0.f)) return false;
+    float ratio = nfp / ps.mfp;
+    int mm = 0;
+    while (ratio < 0.5f && mm < MI_MAX_LEVELS) { ++mm; ratio *= 2.f; }
+    const int maxl = __float_as_int(vc[VC_NLEV]) - 1;
+    mm = mm > maxl ? maxl : mm;
+    if (__float_as_int(vc[VC_LEVEL]) != mm) {
+        const DevView* V = views + view_id;
+        const DevLevel& Lv = V->lv[mm];
+        const unsigned long long img = (unsigned long long)(V->img + Lv.tex_off);
+        if (sub == 0) {
+            vc[VC_AX] = Lv.ax; vc[VC_AY] = Lv.ay; vc[VC_CX] = Lv.cx; vc[VC_CY] = Lv.cy;
+            vc[VC_W] = __int_as_float(Lv.w); vc[VC_H] = __int_as_float(Lv.h);
+            vc[VC_IMG_LO] = __int_as_float((int)(img & 0xFFFFFFFFull)); vc[VC_IMG_HI] = __int_as_float((int)(img >> 32));
+            vc[VC_LEVEL] = __int_as_float(mm);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    nv.m0 = vc[VC_M + 0]; nv.m1 = vc[VC_M + 1]; nv.m2 = vc[VC_M + 2]; nv.m3 = vc[VC_M + 3];
+    nv.m4 = vc[VC_M + 4]; nv.m5 = vc[VC_M + 5]; nv.m6 = vc[VC_M + 6]; nv.m7 = vc[VC_M + 7];
+    nv.ax = vc[VC_AX]; nv.ay = vc[VC_AY]; nv.cx = vc[VC_CX]; nv.cy = vc[VC_CY];
+    nv.w = __float_as_int(vc[VC_W]); nv.h = __float_as_int(vc[VC_H]);
+    const unsigned long long img = ((unsigned long long)(unsigned)__float_as_int(vc[VC_IMG_HI]) << 32)
+                                 | (unsigned long long)(unsigned)__float_as_int(vc[VC_IMG_LO]);
+    nv.img = (const uint32_t*)img;
+    return true;
+}
+
 /* One fused pass of my view at the current state; sets ps.ncc (getFastNCC).  Returns success[v]. */
 template <int MODE, int LPV>
 __device__ __forceinline__ bool run_pass(PatchState& ps, const DevView* views, const float* s_lut, const float* rays,
-                                         const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int sub) {
+                                         const float* mcol, float* vc, ColorSums& S, GNSums& gn, bool count_color, int sub) {
     bool okv = true;
     ps.ncc = -1.f;
     if (MODE == PASS_NORMAL) gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
     if (ps.sel >= 0) {
-        NView nv; int level;
-        okv = setup_view(views, ps.job->global_ids[ps.sel], ps, nv, level)
+        NView nv;
+        okv = setup_view_cached<LPV>(views, ps, vc, nv, sub)
             && sample_pass<MODE, LPV>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
         ps.n_pass++;
         if (okv) {
@@ -604,6 +660,10 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     ps.sel = -1; ps.cs0 = ps.cs1 = ps.cs2 = 1.f; ps.ncc = -1.f;
     /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
     if (x - 2 < 0 || y - 2 < 0 || x + 2 > job->w - 1 || y + 2 > job->h - 1) return;
+    ps.jcx = job->cam_pos[0]; ps.jcy = job->cam_pos[1]; ps.jcz = job->cam_pos[2];
+    ps.jz0 = job->w2c_z[0]; ps.jz1 = job->w2c_z[1]; ps.jz2 = job->w2c_z[2]; ps.jz3 = job->w2c_z[3];
+    ps.jinv0 = job->inv0_s;
+    g_vc[L::patch(lane)][slot][VC_GIDX] = __int_as_float(-1);
     /* view rays (single_view.cc:106-114, mve/depthmap.cc:149-156) and raw master colours into LDS */
     const DevView* RV = views + job->ref_view;
     const DevLevel& RL = RV->lv[job->scale];
@@ -674,13 +734,14 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     bool count_color = propagated_all;   /* samples of views picked by the view selection are already cached there */
     float oldncc = -1.f;
     const bool active = ps.sel >= 0;
+    float* vc = g_vc[L::patch(lane)][slot];
     ColorSums S; GNSums gn;
     S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
     for (;;) {
         bool okv;
-        if (need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, S, gn, count_color, sub);
-        else if (need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, views, s_lut, rays, mcol, S, gn, count_color, sub);
-        else okv = run_pass<PASS_COLOR, LPV>(ps, views, s_lut, rays, mcol, S, gn, count_color, sub);
+        if (need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
+        else if (need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
+        else okv = run_pass<PASS_COLOR, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
         /* ---- finish what led to this pass */
         if (ctx == CTX_CTOR || ctx == CTX_REPLACED) {
             /* computeColorScale() at the end of the ctor (:77) / after replaceViews (:231) */
@@ -940,6 +1001,9 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     /* reuse optimize_patch's setup by replicating its prologue on quad 0 only */
     const DevJob* job = a.job;
     PatchState ps; ps.job = job; ps.x = a.x; ps.y = a.y; ps.n_eval = ps.n_pass = 0; ps.sel = -1;
+    ps.jcx = job->cam_pos[0]; ps.jcy = job->cam_pos[1]; ps.jcz = job->cam_pos[2];
+    ps.jz0 = job->w2c_z[0]; ps.jz1 = job->w2c_z[1]; ps.jz2 = job->w2c_z[2]; ps.jz3 = job->w2c_z[3];
+    ps.jinv0 = job->inv0_s;
     if (lane == 0) for (int k = 0; k < 5; ++k) a.master[k] = 0.f;
     if (a.x - 2 < 0 || a.y - 2 < 0 || a.x + 2 > job->w - 1 || a.y + 2 > job->h - 1) return;
     const DevView* RV = a.views + job->ref_view;
@@ -1092,6 +1156,47 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
     if (filled && (threadIdx.x & 63) == 0) atomicAdd(&a.counters->n_filled, (unsigned long long)filled);
 }
 
+/* Sparse successor of k_generate for the long tail of small rounds: instead of scanning every pixel,
+ * walk the pixels written in round `round` and put their 4-neighbours that satisfy the push rule
+ * (dmrecon.cc:400-431, evaluated after all of the round's writes) on the work list of round + 1.
+ * A per-pixel atomicMax mark makes each pixel appear once.  The list order depends on atomic order;
+ * the results do not (every entry is optimised against the same frozen state). */
+struct ExpandArgs {
+    const DevJob* jobs;
+    const DevEntry* work;
+    const DevResult* results;
+    const unsigned* n_work_ptr;
+    DevEntry* next_work;
+    unsigned* round_work;
+    int round;
+};
+__global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
+    const unsigned n = *a.n_work_ptr;
+    for (unsigned base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+        const unsigned e = base + threadIdx.x;
+        if (e >= n) continue;
+        if (!a.results[e].accepted) continue;
+        const DevEntry ent = a.work[e];
+        const DevJob* job = a.jobs + ent.job;
+        const int W = job->w, H = job->h;
+        const int x = ent.xy & 0xFFFF, y = ent.xy >> 16;
+        const float c = job->conf[y * W + x];
+        const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int qx = x + dx[k], qy = y + dy[k];
+            if (qx < 2 || qy < 2 || qx >= W - 2 || qy >= H - 2) continue;     /* patch_sampler.cc:47-50 */
+            const int q = qy * W + qx;
+            const float own = job->conf[q];
+            if (!(own < c - 0.05f || own == 0.f)) continue;
+            if (atomicMax(&job->mark[q], a.round + 1) >= a.round + 1) continue;   /* already listed */
+            const unsigned idx = atomicAdd(&a.round_work[a.round + 1], 1u);
+            DevEntry o; o.job = ent.job; o.xy = qx | (qy << 16);
+            a.next_work[idx] = o;
+        }
+    }
+}
+
 /* Seeds (dmrecon.cc:297-330): several features may round to the same pixel; the sequential
  * reference keeps the highest confidence, the earlier feature on ties.  Two phases:
  * vote (64-bit atomicMax of conf | ~index) then write by the winner. */
@@ -1226,6 +1331,14 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
     a.jobs = jobs; a.work = work; a.results = results; a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.round = round;
     a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0;
     hipLaunchKernelGGL(k_apply, dim3(grid_blocks), dim3(256), 0, s, a);
+}
+
+void mi_launch_expand(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
+                      const unsigned* n_work_ptr, DevEntry* next_work, unsigned* round_work, int round) {
+    ExpandArgs a;
+    a.jobs = jobs; a.work = work; a.results = results; a.n_work_ptr = n_work_ptr; a.next_work = next_work;
+    a.round_work = round_work; a.round = round;
+    hipLaunchKernelGGL(k_expand, dim3(grid_blocks), dim3(256), 0, s, a);
 }
 
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,

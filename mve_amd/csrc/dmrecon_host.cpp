@@ -150,6 +150,7 @@ struct mi_dmrecon_ctx {
     DevCounters* d_counters = nullptr;
     DevBuf<DevJob> d_jobs;
     DevBuf<DevEntry> d_work;
+    DevBuf<DevEntry> d_work2;                /* ping-pong partner of d_work in the tail rounds */
     DevBuf<DevHyp> d_hyp;
     DevBuf<DevResult> d_results;
     DevBuf<float> d_maps;                    /* depth | dz | conf | normal per batch */
@@ -382,7 +383,7 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
     total_px = 0;
     for (size_t j = 0; j < jobs.size(); ++j) { jobs[j].pix_off = total_px; total_px += (size_t)jobs[j].w * jobs[j].h; }
     if (c->d_maps.reserve(total_px * 7)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
-    if (c->d_imaps.reserve(total_px * 2)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
+    if (c->d_imaps.reserve(total_px * 3)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
     float* base = c->d_maps.p;
     uint32_t* ibase = c->d_imaps.p;
     for (size_t j = 0; j < jobs.size(); ++j) {
@@ -393,9 +394,10 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
         dj[j].normal = base + 4 * total_px + 3 * o;
         dj[j].views = ibase + o;
         dj[j].upd = (int32_t*)(ibase + total_px + o);
+        dj[j].mark = (int32_t*)(ibase + 2 * total_px + o);
     }
     HIP_TRY(hipMemsetAsync(c->d_maps.p, 0, total_px * 7 * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * 3 * sizeof(uint32_t), c->stream));
     return 0;
 }
 
@@ -455,7 +457,7 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->views.size(); ++i) if (c->views[i].d_img) (void)hipFree(c->views[i].d_img);
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
-    c->d_views.release(); c->d_jobs.release(); c->d_work.release(); c->d_hyp.release(); c->d_results.release();
+    c->d_views.release(); c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release();
     c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_round_work.release();
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -672,7 +674,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         n_seed_feats += jobs[j].n_seeds;
     }
     const size_t work_cap = std::max(total_px, seeds.size());
-    if (c->d_work.reserve(work_cap) || c->d_results.reserve(work_cap) || c->d_hyp.reserve(std::max<size_t>(seeds.size(), 1))
+    if (c->d_work.reserve(work_cap) || c->d_work2.reserve(work_cap) || c->d_results.reserve(work_cap) || c->d_hyp.reserve(std::max<size_t>(seeds.size(), 1))
         || c->d_keys.reserve(total_px) || c->d_keyoff.reserve(nj))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(work lists) failed");
     const DevSettings ds = dev_settings(st);
@@ -752,17 +754,21 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         if (tail) { ++round; break; }
     }
     mark("seeds + phase A rounds");
-    /* phase B */
+    /* phase B: round r+1's list is built by k_expand from round r's accepted entries (ping-pong lists) */
+    DevEntry* wcur = c->d_work.p;        /* list of the last executed round (round - 1) */
+    DevEntry* wnext = c->d_work2.p;
     while (!done && !was_cancelled && round < max_rounds) {
         const int first = round;
         for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
-            mi_launch_generate(c->stream, c->d_jobs.p, nj, max_px, c->d_work.p, c->d_round_work.p, round);
+            mi_launch_expand(c->stream, 64, c->d_jobs.p, wcur, c->d_results.p, c->d_round_work.p + (round - 1), wnext,
+                             c->d_round_work.p, round - 1);
             ev_begin(0); ev_work.push_back(0u);
-            mi_launch_optimize(c->stream, 16, TAIL_GRID, c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p, nullptr,
+            mi_launch_optimize(c->stream, 16, TAIL_GRID, c->d_jobs.p, c->d_views.p, c->d_lut, ds, wnext, nullptr,
                                c->d_results.p, c->d_round_work.p + round, 0u, 1u, 0xFFFFFFFFu, round, c->d_counters);
             ev_end();
-            mi_launch_apply(c->stream, 64, c->d_jobs.p, c->d_work.p, c->d_results.p, c->d_round_work.p + round, 0u, round,
+            mi_launch_apply(c->stream, 64, c->d_jobs.p, wnext, c->d_results.p, c->d_round_work.p + round, 0u, round,
                             c->d_counters);
+            std::swap(wcur, wnext);
         }
         HIP_TRY(hipMemcpyAsync(rw.data(), c->d_round_work.p + first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
@@ -775,14 +781,6 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         }
         for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = rw[TAIL_CHUNK - 1]; }
         if (cancelled()) was_cancelled = true;
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (hc.error_flags & 1u) return fail(MI_DMRECON_EFOOTPRINT, "Negative pixel footprint");
-    if (was_cancelled) {
-        for (int i = 0; i < n_refs; ++i) progress[i].status = MI_RECON_CANCELLED;
-        return fail(MI_DMRECON_ECANCELLED, "cancelled");
     }
     mark("phase B rounds");
     /* ---- results back to the caller's buffers */

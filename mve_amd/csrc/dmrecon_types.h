@@ -49,6 +49,7 @@ struct DevJob {
     float* normal;    /* 3 ch */
     uint32_t* views;  /* 4 x 8-bit indices into global_ids, MI_VIEW_NONE padded */
     int32_t* upd;     /* round in which the pixel was last written, -1 = never */
+    int32_t* mark;    /* last round for which the pixel was put on a work list by k_expand, -1 = never */
 };
 
 /* Settings as the kernels see them. */
