@@ -35,6 +35,15 @@
 #define QUAD 4
 #define WAVE 64
 
+#ifdef MI_TIMING
+/* development aid: wave 0 / lane 0 logs shader clock stamps into counters->tstamp[] */
+__device__ unsigned long long* g_tbuf;
+__device__ unsigned g_tcnt;
+#define TSTAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0 && g_tbuf) { unsigned k = g_tcnt++; if (k < 250) { g_tbuf[2 * k] = (id); g_tbuf[2 * k + 1] = __builtin_readcyclecounter(); } } } while (0)
+#else
+#define TSTAMP(id) do { } while (0)
+#endif
+
 /* LDS of one 64-lane workgroup = 16 patches (file scope so that the one non-inlined
  * device function below addresses it with ds_* instructions, not flat ones). */
 __shared__ float g_lut[256];                                   /* sRGB -> linear, mvs_tools.cc:22-93 */
@@ -70,6 +79,13 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     return __hiloint2double(__shfl_xor(__double2hiint(v), m), __shfl_xor(__double2loint(v), m));
 }
 
+/* 1-ulp hardware reciprocal / square root / rsqrt: the parity tolerances (1e-5 on colours, 1e-3 on
+ * depth) leave six orders of magnitude of room, and the IEEE sequences cost ~10 instructions each */
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
 template <int LPV> struct Lay;
 
 template <> struct Lay<1> {
@@ -91,6 +107,7 @@ template <> struct Lay<1> {
         return v;
     }
     __device__ static __forceinline__ int patch_or(int v) { v |= dpp_xor1(v); v |= dpp_xor2(v); return v; }
+    __device__ static __forceinline__ float wave_sum(float v) { return v; }      /* unused in this layout */
     template <int K> __device__ static __forceinline__ int from_view(int v) { return dpp_bcast<K>(v); }
     __device__ static __forceinline__ int view_xor1(int v) { return dpp_xor1(v); }
     __device__ static __forceinline__ int view_xor2(int v) { return dpp_xor2(v); }
@@ -125,17 +142,22 @@ template <> struct Lay<16> {
         v &= dpp_xor1(v); v &= dpp_xor2(v); v &= dpp_half_mirror(v); v &= dpp_mirror(v);
         return v != 0;
     }
-    /* inputs are already uniform within each row */
+    /* inputs are already uniform within each row: four readlanes instead of LDS permutes */
     __device__ static __forceinline__ float patch_sum(float v) {
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        return v;
+        const int i = __float_as_int(v);
+        return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16)))
+             + (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
     }
     __device__ static __forceinline__ double patch_sum(double v) {
-        v += shfl_xor_d(v, 16);
-        v += shfl_xor_d(v, 32);
-        return v;
+        const int hi = __double2hiint(v), lo = __double2loint(v);
+        const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+        const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+        const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+        const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+        return (r0 + r1) + (r2 + r3);
     }
+    /* sum over all 64 lanes (inputs arbitrary) */
+    __device__ static __forceinline__ float wave_sum(float v) { return patch_sum(view_sum(v)); }
     __device__ static __forceinline__ int patch_or(int v) { v |= __shfl_xor(v, 16); v |= __shfl_xor(v, 32); return v; }
     template <int K> __device__ static __forceinline__ int from_view(int v) { return __builtin_amdgcn_readlane(v, 16 * K); }
     __device__ static __forceinline__ int view_xor1(int v) { return __shfl_xor(v, 16); }
@@ -183,7 +205,7 @@ __device__ __forceinline__ void project(const NView& nv, float px, float py, flo
     float cz_ = nv.m8 * px + nv.m9 * py + nv.m10 * pz + nv.m11;
     float sx = nv.ax * cx_ + nv.cx * cz_;
     float sy = nv.ay * cy_ + nv.cy * cz_;
-    const float iz = __frcp_rn(cz_);          /* v_rcp_f32 (1 ulp): far inside the 1e-5 colour tolerance */
+    const float iz = fast_rcp(cz_);
     u = sx * iz - 0.5f;
     v = sy * iz - 0.5f;
 }
@@ -218,7 +240,10 @@ struct ColorSums {               /* shifted one-pass sums of the colours of one 
     float ba0, ba1, ba2;         /* sum (m - xbar)(n - s) */
 };
 
-enum { PASS_COLOR = 0, PASS_DEPTH = 1, PASS_NORMAL = 2, PASS_DUMP = 3 };
+enum { PASS_COLOR = 0, PASS_DEPTH = 1, PASS_NORMAL = 2, PASS_DUMP = 3, PASS_DEPTH_FIXED = 4 };
+
+template <int LPV> struct NormalAcc { typedef float type; };     /* 2 terms per lane: float partial sums */
+template <> struct NormalAcc<1> { typedef double type; };          /* 25 terms per lane: accumulate in double as the reference */
 
 /* Gauss-Newton sums of one view at one state.
  * Depth-only form, per colour channel c and independent of later colour-scale changes:
@@ -227,6 +252,7 @@ enum { PASS_COLOR = 0, PASS_DEPTH = 1, PASS_NORMAL = 2, PASS_DUMP = 3 };
  * so that for any colour scale cs:  num = sum_c cs_c (dr_c - (cs_c - cs0_c) dn_c),  den = sum_c cs_c^2 dd_c
  * which is optimizeDepthOnly's  sum (cs d)(m - cs n) / sum (cs d)^2  (patch_optimization.cc:283-290). */
 struct GNSums {
+    float num, den;                                    /* PASS_DEPTH_FIXED: optimizeDepthOnly's sums with the current colour scale */
     float dr0, dr1, dr2, dn0, dn1, dn2, dd0, dd1, dd2;
     float c00, c01, c02;                               /* cs0 */
     double A00, A01, A02, A11, A12, A22, B0, B1, B2;   /* optimizeDepthAndNormal (:312-343), colour scale baked in */
@@ -236,7 +262,9 @@ struct GNSums {
  * One pass over the 25 samples of my view (split over the LPV lanes of my view slot) at the current
  * patch state.  It always yields the colour sums that getFastNCC / computeColorScale need
  * (patch_sampler.cc:347-393,135-163; patch_optimization.cc:81-111), and in addition
- *   PASS_DEPTH  the colour-scale independent sums of optimizeDepthOnly,
+ *   PASS_DEPTH  the colour-scale independent sums of optimizeDepthOnly (used when computeColorScale may
+ *               still change the scale between this pass and the step: ctor, after a normal step),
+ *   PASS_DEPTH_FIXED  optimizeDepthOnly's numerator / denominator directly (colour scale fixed until the step),
  *   PASS_NORMAL the normal equations of optimizeDepthAndNormal (with the current colour scale),
  *   PASS_DUMP   the raw samples (parity hook, LPV = 1).
  * The reference samples the same texels twice per Gauss-Newton iteration -- computeNeighColorSamples
@@ -259,16 +287,20 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         project(nv, ps.p0x, ps.p0y, ps.p0z, u0, v0);
         project(nv, ps.p0x + rx, ps.p0y + ry, ps.p0z + rz, u1, v1);
         float du = u1 - u0, dv = v1 - v0;
-        dnorm = sqrtf(du * du + dv * dv);              /* deriv /= stepSize  ==  deriv * dnorm */
+        dnorm = fast_sqrt(du * du + dv * dv);          /* deriv /= stepSize  ==  deriv * dnorm */
         ok = dnorm > 0.f;
-        step = ok ? __frcp_rn(dnorm) : 0.f;
+        step = ok ? fast_rcp(dnorm) : 0.f;
     }
     const float wlim = (float)(nv.w - 1), hlim = (float)(nv.h - 1);
     ColorSums S;
     S.s0 = ps.xbar0 * ps.mmean; S.s1 = ps.xbar1 * ps.mmean; S.s2 = ps.xbar2 * ps.mmean;
     S.a0 = S.a1 = S.a2 = 0.f; S.aa0 = S.aa1 = S.aa2 = 0.f; S.ba0 = S.ba1 = S.ba2 = 0.f;
     float dr0 = 0.f, dr1 = 0.f, dr2 = 0.f, dn0 = 0.f, dn1 = 0.f, dn2 = 0.f, dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
-    double A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, B0 = 0, B1 = 0, B2 = 0;
+    float num = 0.f, den = 0.f;
+    typedef typename NormalAcc<LPV>::type acc_t;
+    acc_t A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, B0 = 0, B1 = 0, B2 = 0;
+    /* per-channel colour sums are only needed when computeColorScale may follow this pass */
+    constexpr bool PER_CHANNEL = (MODE == PASS_COLOR || MODE == PASS_DEPTH);
 
     constexpr int NITER = (LPV == 1) ? MI_NS : (MI_NS + LPV - 1) / LPV;
     constexpr int NITER_UNROLL = (LPV == 1) ? 1 : NITER;
@@ -321,9 +353,18 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         } else {
             const float a0 = (n[0] - S.s0) * wgt, a1 = (n[1] - S.s1) * wgt, a2 = (n[2] - S.s2) * wgt;
             S.a0 += a0; S.a1 += a1; S.a2 += a2;
-            S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
-            S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
-            if (MODE == PASS_DEPTH) {
+            if (PER_CHANNEL) {
+                S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
+                S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
+            } else {
+                S.aa0 += a0 * a0 + a1 * a1 + a2 * a2;
+                S.ba0 += (m0 - ps.xbar0) * a0 + (m1 - ps.xbar1) * a1 + (m2 - ps.xbar2) * a2;
+            }
+            if (MODE == PASS_DEPTH_FIXED) {
+                const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
+                num += wgt * (g0 * (m0 - ps.cs0 * n[0]) + g1 * (m1 - ps.cs1 * n[1]) + g2 * (m2 - ps.cs2 * n[2]));
+                den += wgt * (g0 * g0 + g1 * g1 + g2 * g2);
+            } else if (MODE == PASS_DEPTH) {
                 const float e0 = dr[0] * wgt, e1 = dr[1] * wgt, e2 = dr[2] * wgt;
                 dr0 += e0 * (m0 - ps.cs0 * n[0]); dr1 += e1 * (m1 - ps.cs1 * n[1]); dr2 += e2 * (m2 - ps.cs2 * n[2]);
                 dn0 += e0 * n[0]; dn1 += e1 * n[1]; dn2 += e2 * n[2];
@@ -334,18 +375,22 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
                 const float gg = (g0 * g0 + g1 * g1 + g2 * g2) * wgt;
                 const float gr = (g0 * r0_ + g1 * r1_ + g2 * r2_) * wgt;
                 const float fi = (float)di, fj = (float)dj;
-                A00 += (double)gg; A01 += (double)(fi * gg); A02 += (double)(fj * gg);
-                A11 += (double)(fi * fi * gg); A12 += (double)(fi * fj * gg); A22 += (double)(fj * fj * gg);
-                B0 += (double)gr; B1 += (double)(fi * gr); B2 += (double)(fj * gr);
+                A00 += (acc_t)gg; A01 += (acc_t)(fi * gg); A02 += (acc_t)(fj * gg);
+                A11 += (acc_t)(fi * fi * gg); A12 += (acc_t)(fi * fj * gg); A22 += (acc_t)(fj * fj * gg);
+                B0 += (acc_t)gr; B1 += (acc_t)(fi * gr); B2 += (acc_t)(fj * gr);
             }
         }
     }
     if (MODE != PASS_DUMP) {
         S.a0 = L::view_sum(S.a0); S.a1 = L::view_sum(S.a1); S.a2 = L::view_sum(S.a2);
-        S.aa0 = L::view_sum(S.aa0); S.aa1 = L::view_sum(S.aa1); S.aa2 = L::view_sum(S.aa2);
-        S.ba0 = L::view_sum(S.ba0); S.ba1 = L::view_sum(S.ba1); S.ba2 = L::view_sum(S.ba2);
+        S.aa0 = L::view_sum(S.aa0); S.ba0 = L::view_sum(S.ba0);
+        if (PER_CHANNEL) {
+            S.aa1 = L::view_sum(S.aa1); S.aa2 = L::view_sum(S.aa2);
+            S.ba1 = L::view_sum(S.ba1); S.ba2 = L::view_sum(S.ba2);
+        }
         cs_out = S;
     }
+    if (MODE == PASS_DEPTH_FIXED) { gn.num = L::view_sum(num); gn.den = L::view_sum(den); }
     if (MODE == PASS_DEPTH) {
         gn.dr0 = L::view_sum(dr0); gn.dr1 = L::view_sum(dr1); gn.dr2 = L::view_sum(dr2);
         gn.dn0 = L::view_sum(dn0); gn.dn1 = L::view_sum(dn1); gn.dn2 = L::view_sum(dn2);
@@ -353,9 +398,9 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         gn.c00 = ps.cs0; gn.c01 = ps.cs1; gn.c02 = ps.cs2;
     }
     if (MODE == PASS_NORMAL) {
-        gn.A00 = L::view_sum(A00); gn.A01 = L::view_sum(A01); gn.A02 = L::view_sum(A02);
-        gn.A11 = L::view_sum(A11); gn.A12 = L::view_sum(A12); gn.A22 = L::view_sum(A22);
-        gn.B0 = L::view_sum(B0); gn.B1 = L::view_sum(B1); gn.B2 = L::view_sum(B2);
+        gn.A00 = (double)L::view_sum(A00); gn.A01 = (double)L::view_sum(A01); gn.A02 = (double)L::view_sum(A02);
+        gn.A11 = (double)L::view_sum(A11); gn.A12 = (double)L::view_sum(A12); gn.A22 = (double)L::view_sum(A22);
+        gn.B0 = (double)L::view_sum(B0); gn.B1 = (double)L::view_sum(B1); gn.B2 = (double)L::view_sum(B2);
     }
     return L::view_all(ok);
 }
@@ -365,8 +410,8 @@ __device__ __forceinline__ float ncc_from_sums(const PatchState& ps, const Color
     const float inv_n = 1.f / (float)MI_NS;
     const float sqrDevY = (S.aa0 - S.a0 * S.a0 * inv_n) + (S.aa1 - S.a1 * S.a1 * inv_n) + (S.aa2 - S.a2 * S.a2 * inv_n);
     const float devXY = S.ba0 + S.ba1 + S.ba2;
-    const float tmp = sqrtf(ps.sqrDevX * fmaxf(sqrDevY, 0.f));
-    return tmp > 0.f ? devXY / tmp : -1.f;
+    const float tmp = fast_sqrt(ps.sqrDevX * fmaxf(sqrDevY, 0.f));
+    return tmp > 0.f ? fast_div(devXY, tmp) : -1.f;
 }
 
 /* Colour pass of view `gidx` (index into the job's global list) -> NCC; -1 on failure. */
@@ -412,7 +457,7 @@ __device__ __forceinline__ bool color_scale_update(PatchState& ps, const ColorSu
         const float mn = ba[c] + xb[c] * a[c] + N * xb[c] * s[c];                   /* sum m n  */
         const float ab = mn - (*cs[c]) * nn;
         if (fabsf(nn) > 1e-6f) {
-            *cs[c] += ab / nn;
+            *cs[c] += fast_div(ab, nn);
             if (*cs[c] > 1e3f) good = false;
         } else
             good = false;
@@ -592,7 +637,7 @@ __device__ __forceinline__ bool setup_view_cached(const DevView* __restrict__ vi
     const float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
     const float nfp = z * vc[VC_INV0];               /* SingleView::footPrint */
     if (!(nfp > 0.f)) return false;
-    float ratio = nfp / ps.mfp;
+    float ratio = fast_div(nfp, ps.mfp);
     int mm = 0;
     while (ratio < 0.5f && mm < MI_MAX_LEVELS) { ++mm; ratio *= 2.f; }
     const int maxl = __float_as_int(vc[VC_NLEV]) - 1;
@@ -668,37 +713,57 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     const DevView* RV = views + job->ref_view;
     const DevLevel& RL = RV->lv[job->scale];
     const uint32_t* rimg = RV->img + RL.tex_off;
+    float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;       /* LPV = 16: my sample's raw master colour */
     for (int i = pl; i < MI_NS; i += 4 * LPV) {
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
         const float fx = (float)(x + di) + 0.5f, fy = (float)(y + dj) + 0.5f;
         float rx = job->inv_a * fx + job->inv_c, ry = job->inv_b * fy + job->inv_d, rz = 1.f;
-        const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
-        rx /= nrm; ry /= nrm; rz /= nrm;
+        const float inrm = fast_rsqrt(rx * rx + ry * ry + rz * rz);
+        rx *= inrm; ry *= inrm; rz *= inrm;
         rays[3 * i] = job->rot_t[0] * rx + job->rot_t[1] * ry + job->rot_t[2] * rz;
         rays[3 * i + 1] = job->rot_t[3] * rx + job->rot_t[4] * ry + job->rot_t[5] * rz;
         rays[3 * i + 2] = job->rot_t[6] * rx + job->rot_t[7] * ry + job->rot_t[8] * rz;
         const uint32_t t = rimg[(size_t)(y + dj) * RL.w + (x + di)];
-        mcol[3 * i] = s_lut[t & 255u]; mcol[3 * i + 1] = s_lut[(t >> 8) & 255u]; mcol[3 * i + 2] = s_lut[(t >> 16) & 255u];
+        raw0 = s_lut[t & 255u]; raw1 = s_lut[(t >> 8) & 255u]; raw2 = s_lut[(t >> 16) & 255u];
+        if (LPV == 1) { mcol[3 * i] = raw0; mcol[3 * i + 1] = raw1; mcol[3 * i + 2] = raw2; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    /* computeMasterSamples (patch_sampler.cc:297-345): every lane of the patch redundantly */
-    float mm = 0.f;
-    for (int k = 0; k < 3 * MI_NS; ++k) mm += mcol[k];
-    mm /= 3.f * (float)MI_NS;
-    if (mm < 0.01f || mm > 0.99f) return;
+    /* computeMasterSamples (patch_sampler.cc:297-345) */
+    float mm, x0, x1, x2, sd;
+    if (LPV == 1) {
+        /* every lane of the quad redundantly, in the reference's summation order */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        mm = 0.f;
+        for (int k = 0; k < 3 * MI_NS; ++k) mm += mcol[k];
+        mm /= 3.f * (float)MI_NS;
+        if (mm < 0.01f || mm > 0.99f) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int i = pl; i < MI_NS; i += 4 * LPV) { mcol[3 * i] /= mm; mcol[3 * i + 1] /= mm; mcol[3 * i + 2] /= mm; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        x0 = 0.f; x1 = 0.f; x2 = 0.f;
+        for (int i = 0; i < MI_NS; ++i) { x0 += mcol[3 * i]; x1 += mcol[3 * i + 1]; x2 += mcol[3 * i + 2]; }
+        x0 /= (float)MI_NS; x1 /= (float)MI_NS; x2 /= (float)MI_NS;
+        sd = 0.f;
+        for (int i = 0; i < MI_NS; ++i) {
+            const float a = mcol[3 * i] - x0, b = mcol[3 * i + 1] - x1, c = mcol[3 * i + 2] - x2;
+            sd += a * a + b * b + c * c;
+        }
+    } else {
+        /* one sample per lane (lanes 0..24): wave-wide DPP reductions instead of 3 x 75 LDS reads */
+        const bool mine = pl < MI_NS;
+        mm = L::wave_sum(mine ? (raw0 + raw1 + raw2) : 0.f) / (3.f * (float)MI_NS);
+        if (mm < 0.01f || mm > 0.99f) return;
+        const float im = fast_rcp(mm);
+        raw0 *= im; raw1 *= im; raw2 *= im;
+        if (mine) { mcol[3 * pl] = raw0; mcol[3 * pl + 1] = raw1; mcol[3 * pl + 2] = raw2; }
+        x0 = L::wave_sum(mine ? raw0 : 0.f) / (float)MI_NS;
+        x1 = L::wave_sum(mine ? raw1 : 0.f) / (float)MI_NS;
+        x2 = L::wave_sum(mine ? raw2 : 0.f) / (float)MI_NS;
+        const float a = raw0 - x0, b = raw1 - x1, c = raw2 - x2;
+        sd = L::wave_sum(mine ? (a * a + b * b + c * c) : 0.f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     ps.mmean = mm;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int i = pl; i < MI_NS; i += 4 * LPV) { mcol[3 * i] /= mm; mcol[3 * i + 1] /= mm; mcol[3 * i + 2] /= mm; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    for (int i = 0; i < MI_NS; ++i) { x0 += mcol[3 * i]; x1 += mcol[3 * i + 1]; x2 += mcol[3 * i + 2]; }
-    x0 /= (float)MI_NS; x1 /= (float)MI_NS; x2 /= (float)MI_NS;
     ps.xbar0 = x0; ps.xbar1 = x1; ps.xbar2 = x2;
-    float sd = 0.f;
-    for (int i = 0; i < MI_NS; ++i) {
-        const float a = mcol[3 * i] - x0, b = mcol[3 * i + 1] - x1, c = mcol[3 * i + 2] - x2;
-        sd += a * a + b * b + c * c;
-    }
     ps.sqrDevX = sd;
     /* computePatchPoints */
     if (!set_state(ps, rays, depth0, dzI0, dzJ0)) return;
@@ -737,11 +802,15 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     float* vc = g_vc[L::patch(lane)][slot];
     ColorSums S; GNSums gn;
     S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
+    TSTAMP(10);
     for (;;) {
         bool okv;
+        TSTAMP(20 + need);
         if (need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
+        else if (need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
         else if (need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
         else okv = run_pass<PASS_COLOR, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
+        TSTAMP(30);
         /* ---- finish what led to this pass */
         if (ctx == CTX_CTOR || ctx == CTX_REPLACED) {
             /* computeColorScale() at the end of the ctor (:77) / after replaceViews (:231) */
@@ -767,23 +836,22 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
             }
             if (conv) { converged = true; break; }
             ++iter;
-            if (step_was_normal && need == PASS_NORMAL) {
-                /* the colour scale baked into these normal equations has just changed: redo the pass */
-                ctx = CTX_REPASS; count_color = false; step_was_normal = false;
-                continue;
-            }
         }
         /* ---- loop condition of the main loop (:185-186) */
         if (iter >= 4 && iter >= st.maxIterations) break;
         /* ---- take the step of iteration `iter` from the sums of this pass */
         const bool first4 = iter < 4;
-        const int want = (!first4 && (iter % 5 == 4 || viewRemoved)) ? PASS_NORMAL : PASS_DEPTH;
-        if (need != want) { need = want; ctx = CTX_REPASS; count_color = false; continue; }
+        const bool want_normal = !first4 && (iter % 5 == 4 || viewRemoved);
+        const bool have_normal = need == PASS_NORMAL, have_depth = need == PASS_DEPTH || need == PASS_DEPTH_FIXED;
+        if (want_normal ? !have_normal : !have_depth) {
+            need = want_normal ? PASS_NORMAL : PASS_DEPTH_FIXED; ctx = CTX_REPASS; count_color = false; continue;
+        }
+        TSTAMP(31);
         if (L::view_ballot(!okv, lane)) { opti = false; break; }       /* fastColAndDeriv failed (:277-280,:321-324) */
         if (active) ps.n_eval++;                                       /* this pass stood in for fastColAndDeriv */
         oldncc = ps.ncc;
         bool step_ok = false;
-        if (want == PASS_NORMAL) {
+        if (want_normal) {
             const double m0 = L::patch_sum(gn.A00), m1 = L::patch_sum(gn.A01), m2 = L::patch_sum(gn.A02);
             const double m4 = L::patch_sum(gn.A11), m5 = L::patch_sum(gn.A12), m8 = L::patch_sum(gn.A22);
             const double b0 = L::patch_sum(gn.B0), b1 = L::patch_sum(gn.B1), b2 = L::patch_sum(gn.B2);
@@ -803,29 +871,34 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         } else {
             /* optimizeDepthOnly (:265-299) from the colour-scale independent sums */
             float num = 0.f, den = 0.f;
-            if (active && okv) {
+            if (active && okv && need == PASS_DEPTH_FIXED) { num = gn.num; den = gn.den; }
+            else if (active && okv) {
                 num = ps.cs0 * (gn.dr0 - (ps.cs0 - gn.c00) * gn.dn0) + ps.cs1 * (gn.dr1 - (ps.cs1 - gn.c01) * gn.dn1)
                     + ps.cs2 * (gn.dr2 - (ps.cs2 - gn.c02) * gn.dn2);
                 den = ps.cs0 * ps.cs0 * gn.dd0 + ps.cs1 * ps.cs1 * gn.dd1 + ps.cs2 * ps.cs2 * gn.dd2;
             }
             num = L::patch_sum(num); den = L::patch_sum(den);
-            if (den > 0.f) step_ok = set_state(ps, rays, ps.depth + num / den, ps.dzI, ps.dzJ);
+            if (den > 0.f) step_ok = set_state(ps, rays, ps.depth + fast_div(num, den), ps.dzI, ps.dzJ);
             else step_ok = first4;                     /* the first four iterations tolerate denom <= 0 (:177-180) */
             step_was_normal = false;
         }
         if (!step_ok) { opti = false; break; }
+        /* the colour scale only changes right after a normal step (and in the ctor): every other pass can
+         * bake it in, which leaves 7 instead of 21 values to reduce across the view slot */
         if (first4) {
             ++iter;
-            need = (iter >= 4 && iter % 5 == 4) ? PASS_NORMAL : PASS_DEPTH;
+            need = (iter >= 4 && iter % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED;
             ctx = CTX_FIRST4;
             count_color = (iter == 4);                 /* the reference first asks for NCCs when the main loop starts */
         } else {
-            need = ((iter + 1) % 5 == 4) ? PASS_NORMAL : PASS_DEPTH;
+            /* after a normal step computeColorScale follows: that pass must carry per-channel colour sums */
+            need = step_was_normal ? PASS_DEPTH : (((iter + 1) % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED);
             ctx = CTX_STEP;
             count_color = true;
         }
     }
     (void)opti;
+    TSTAMP(40);
     n_eval += ps.n_eval; n_pass += ps.n_pass;
     res.iters = iter;
     res.depth = ps.depth; res.dzI = ps.dzI; res.dzJ = ps.dzJ;
@@ -894,6 +967,7 @@ struct OptArgs {
     unsigned min_work, max_work;  /* this launch only acts if min_work <= n < max_work (layout selection on device) */
     int round;
     DevCounters* counters;
+    unsigned long long* tbuf;     /* MI_TIMING builds only */
 };
 
 /*
@@ -904,10 +978,15 @@ template <int LPV>
 __global__ __launch_bounds__(WAVE) void k_optimize(OptArgs a) {
     typedef Lay<LPV> L;
     const int lane = threadIdx.x;
+#ifdef MI_TIMING
+    if (threadIdx.x == 0 && blockIdx.x == 0) { g_tbuf = a.tbuf; g_tcnt = 0; }
+#endif
+    TSTAMP(1);
     const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
     if (n < a.min_work || n >= a.max_work) return;
     for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
     __syncthreads();
+    TSTAMP(2);
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
     for (unsigned e = blockIdx.x * L::PATCHES + L::patch(lane); e < n; e += gridDim.x * L::PATCHES) {
         const DevEntry ent = a.work[e];
@@ -952,7 +1031,9 @@ __global__ __launch_bounds__(WAVE) void k_optimize(OptArgs a) {
                 hd = job->depth[p]; hi = job->dz[2 * p]; hj = job->dz[2 * p + 1]; hv = job->views[p];
             }
             PatchResult r;
+            TSTAMP(3);
             optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
+            TSTAMP(4);
             ++n_patch;
             if (explicit_hyp) {
                 out.conf = r.conf; out.depth = r.depth; out.dzI = r.dzI; out.dzJ = r.dzJ;
@@ -1293,6 +1374,8 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint32_t* __restrict__ sr
 /* ------------------------------------------------------------------------- */
 /* Host-callable launchers (declared in dmrecon_device.h).                     */
 
+unsigned long long* mi_debug_tbuf = nullptr;   /* set by MI_TIMING probes */
+
 void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
@@ -1301,7 +1384,7 @@ void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks,
     OptArgs a;
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
     a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
-    a.round = round; a.counters = counters;
+    a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
     if (lanes_per_view == 16)
         hipLaunchKernelGGL(k_optimize<16>, dim3(grid_blocks), dim3(WAVE), 0, s, a);
     else

@@ -944,4 +944,12 @@ int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int3
     return G;
 }
 
+/* development aid (not in the public header): allocate / fetch the MI_TIMING stamp buffer */
+int mi_dmrecon_debug_timing(unsigned long long* out, int n) {
+    if (!mi_debug_tbuf) { if (hipMalloc((void**)&mi_debug_tbuf, 500 * sizeof(unsigned long long)) != hipSuccess) return -1; (void)hipMemset(mi_debug_tbuf, 0, 500 * 8); return 0; }
+    if (out) (void)hipMemcpy(out, mi_debug_tbuf, std::min(n, 500) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipMemset(mi_debug_tbuf, 0, 500 * 8);
+    return 0;
+}
+
 }  /* extern "C" */
