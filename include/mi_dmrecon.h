@@ -20,6 +20,7 @@
 #ifndef MI_DMRECON_H
 #define MI_DMRECON_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -106,6 +107,16 @@ void mi_dmrecon_settings_default(mi_dmrecon_settings* s);              /* settin
 
 int  mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out);
 void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* ctx);
+/* A sibling context on the same GPU that SHARES the parent's resident views and features (read-only)
+ * but has its own HIP stream and scratch memory.  This is how several mvs::DMRecon instances run
+ * concurrently, as the OpenMP loop of apps/dmrecon/dmrecon.cc:285-318 does with one shared mve::Scene:
+ * one fork per host thread, their kernels overlap on the GPU.  Views/features must not be changed
+ * while forks are reconstructing.  Destroy forks and parent in any order. */
+int  mi_dmrecon_ctx_fork(mi_dmrecon_ctx* parent, mi_dmrecon_ctx** out);
+/* Optional page-locked host buffers for mi_dmrecon_maps (any host memory works; pinned memory makes the
+ * final device->host copy of the maps run at PCIe rate).  Returns NULL on failure. */
+void* mi_dmrecon_host_alloc(size_t bytes);
+void  mi_dmrecon_host_free(void* p);
 /* The HIP stream all kernels of this context are launched on (hipStream_t as void*). */
 void* mi_dmrecon_ctx_stream(mi_dmrecon_ctx* ctx);
 

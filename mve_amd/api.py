@@ -29,7 +29,8 @@ E_INVAL, E_GVS, E_DEVICE, E_CANCELLED, E_FOOTPRINT = -1, -2, -3, -4, -5
 
 EXPORTS = [
     "mi_dmrecon_device_count", "mi_dmrecon_last_error", "mi_dmrecon_settings_default",
-    "mi_dmrecon_ctx_create", "mi_dmrecon_ctx_destroy", "mi_dmrecon_ctx_stream",
+    "mi_dmrecon_ctx_create", "mi_dmrecon_ctx_destroy", "mi_dmrecon_ctx_fork", "mi_dmrecon_ctx_stream",
+    "mi_dmrecon_host_alloc", "mi_dmrecon_host_free",
     "mi_dmrecon_set_view", "mi_dmrecon_evict_view", "mi_dmrecon_set_features",
     "mi_dmrecon_num_levels", "mi_dmrecon_level_size", "mi_dmrecon_get_level",
     "mi_dmrecon_global_view_selection", "mi_dmrecon_reconstruct",
@@ -86,8 +87,13 @@ def load_library() -> ctypes.CDLL:
     L.mi_dmrecon_settings_default.restype = None
     L.mi_dmrecon_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.mi_dmrecon_ctx_destroy.argtypes = [vp]
+    L.mi_dmrecon_ctx_fork.argtypes = [vp, ctypes.POINTER(vp)]
     L.mi_dmrecon_ctx_destroy.restype = None
     L.mi_dmrecon_ctx_stream.argtypes = [vp]
+    L.mi_dmrecon_host_alloc.argtypes = [ctypes.c_size_t]
+    L.mi_dmrecon_host_alloc.restype = vp
+    L.mi_dmrecon_host_free.argtypes = [vp]
+    L.mi_dmrecon_host_free.restype = None
     L.mi_dmrecon_ctx_stream.restype = vp
     L.mi_dmrecon_set_view.argtypes = [vp, i32, ctypes.POINTER(CCamera), i32, i32, i32, vp]
     L.mi_dmrecon_evict_view.argtypes = [vp, i32]
@@ -107,6 +113,24 @@ def load_library() -> ctypes.CDLL:
 
 def device_count() -> int:
     return int(load_library().mi_dmrecon_device_count())
+
+
+class PinnedArray:
+    """A numpy view on page-locked host memory from mi_dmrecon_host_alloc (freed with the object)."""
+
+    def __init__(self, shape, dtype):
+        self._L = load_library()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = self._L.mi_dmrecon_host_alloc(max(n, 1))
+        if not self._p:
+            raise RuntimeError(self._L.mi_dmrecon_last_error().decode())
+        buf = (ctypes.c_char * max(n, 1)).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self._L.mi_dmrecon_host_free(self._p)
+            self._p = None
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -171,6 +195,16 @@ class Context:
         self.device = device
         self.n_views = 0
         self._keep = None
+
+    def fork(self) -> "Context":
+        """A sibling context sharing this one's resident scene, with its own stream (one per host thread)."""
+        h = ctypes.c_void_p()
+        rc = self._L.mi_dmrecon_ctx_fork(self._h, ctypes.byref(h))
+        if rc != 0:
+            _raise(rc)
+        c = Context.__new__(Context)
+        c._L, c._h, c.device, c.n_views, c._keep = self._L, h, self.device, self.n_views, None
+        return c
 
     def close(self):
         if getattr(self, "_h", None):
@@ -253,26 +287,42 @@ class Context:
         return [int(v) for v in ids[:n.value]]
 
     # -- the hot path ----------------------------------------------------------
+    def alloc_outputs(self, st: Settings, ref_views: Sequence[int], want_normal=True, want_views=False,
+                      pinned=False) -> List[Dict]:
+        """Output buffers for reconstruct(out=...); pinned=True puts them in page-locked memory."""
+        out = []
+        for r in ref_views:
+            w, h = self.level_size(int(r), st.scale)
+            spec = dict(depth=((h, w), np.float32), dz=((h, w, 2), np.float32), conf=((h, w), np.float32))
+            if want_normal:
+                spec["normal"] = ((h, w, 3), np.float32)
+            if want_views:
+                spec["views"] = ((h, w, 4), np.int32)
+            d = {}
+            for k, (shape, dt) in spec.items():
+                if pinned:
+                    pa = PinnedArray(shape, dt)
+                    d["_pin_" + k] = pa
+                    d[k] = pa.array
+                else:
+                    d[k] = np.zeros(shape, dt)
+            out.append(d)
+        return out
+
     def reconstruct(self, st: Settings, ref_views: Sequence[int], want_normal=True, want_views=False,
-                    progress: Optional[ctypes.Array] = None) -> List[Dict]:
+                    progress: Optional[ctypes.Array] = None, out: Optional[List[Dict]] = None) -> List[Dict]:
         """DMRecon::start() for a batch of reference views; returns one dict of maps per view."""
         n = len(ref_views)
         refs = np.asarray(ref_views, np.int32)
         cs = st.to_c()
         maps = (CMaps * n)()
-        out = []
+        if out is None:
+            out = self.alloc_outputs(st, ref_views, want_normal, want_views)
         for i, r in enumerate(ref_views):
-            w, h = self.level_size(int(r), st.scale)
-            d = dict(depth=np.zeros((h, w), np.float32), dz=np.zeros((h, w, 2), np.float32),
-                     conf=np.zeros((h, w), np.float32))
-            if want_normal:
-                d["normal"] = np.zeros((h, w, 3), np.float32)
-            if want_views:
-                d["views"] = np.full((h, w, 4), -1, np.int32)
+            d = out[i]
             maps[i].depth, maps[i].dz, maps[i].conf = _ptr(d["depth"]), _ptr(d["dz"]), _ptr(d["conf"])
             maps[i].normal = _ptr(d.get("normal"))
             maps[i].views = _ptr(d.get("views"))
-            out.append(d)
         status = np.zeros(n, np.int32)
         stats = CStats()
         rc = self._L.mi_dmrecon_reconstruct(self._h, ctypes.byref(cs), n, _ptr(refs), maps, progress,

@@ -27,6 +27,8 @@
 #include <cstring>
 #include <ctime>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -138,15 +140,29 @@ struct JobHost {          /* host-side plan of one reference view */
 
 }  // namespace
 
-struct mi_dmrecon_ctx {
+/* What mve::Scene + ImagePyramidCache are to the reference: the views (pyramids resident in HBM),
+ * the bundle features and the lookup table.  Shared, read-only, by a context and its forks. */
+struct SceneStore {
     int device = 0;
-    hipStream_t stream = nullptr;
+    std::mutex mu;                           /* guards the lazy upload of the DevView table */
     std::vector<HostView> views;
     std::vector<Feature> features;
     std::vector<int> feat_refs;
     bool views_dirty = true;
     DevBuf<DevView> d_views;
     float* d_lut = nullptr;
+    ~SceneStore() {
+        (void)hipSetDevice(device);
+        for (size_t i = 0; i < views.size(); ++i) if (views[i].d_img) (void)hipFree(views[i].d_img);
+        d_views.release();
+        if (d_lut) (void)hipFree(d_lut);
+    }
+};
+
+struct mi_dmrecon_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::shared_ptr<SceneStore> sc;
     DevCounters* d_counters = nullptr;
     DevBuf<DevJob> d_jobs;
     DevBuf<DevEntry> d_work;
@@ -165,10 +181,11 @@ struct mi_dmrecon_ctx {
 namespace {
 
 int sync_views(mi_dmrecon_ctx* c) {
-    if (!c->views_dirty) return 0;
-    std::vector<DevView> hv(c->views.size());
-    for (size_t i = 0; i < c->views.size(); ++i) {
-        HostView const& v = c->views[i];
+    std::lock_guard<std::mutex> lock(c->sc->mu);
+    if (!c->sc->views_dirty) return 0;
+    std::vector<DevView> hv(c->sc->views.size());
+    for (size_t i = 0; i < c->sc->views.size(); ++i) {
+        HostView const& v = c->sc->views[i];
         DevView& d = hv[i];
         std::memset(&d, 0, sizeof(d));
         if (!v.valid) continue;
@@ -182,10 +199,10 @@ int sync_views(mi_dmrecon_ctx* c) {
             d.lv[l].inv0 = L.invproj[0]; d.lv[l].w = L.w; d.lv[l].h = L.h; d.lv[l].tex_off = L.tex_off;
         }
     }
-    if (c->d_views.reserve(hv.size())) return fail(MI_DMRECON_EDEVICE, "hipMalloc(views) failed");
-    HIP_TRY(hipMemcpyAsync(c->d_views.p, hv.data(), hv.size() * sizeof(DevView), hipMemcpyHostToDevice, c->stream));
+    if (c->sc->d_views.reserve(hv.size())) return fail(MI_DMRECON_EDEVICE, "hipMalloc(views) failed");
+    HIP_TRY(hipMemcpyAsync(c->sc->d_views.p, hv.data(), hv.size() * sizeof(DevView), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->views_dirty = false;
+    c->sc->views_dirty = false;
     return 0;
 }
 
@@ -201,7 +218,7 @@ int check_settings(const mi_dmrecon_settings* st) {
 }
 
 inline bool contains_view(mi_dmrecon_ctx const* c, Feature const& f, int id) {
-    for (int j = f.ref_begin; j < f.ref_end; ++j) if (c->feat_refs[j] == id) return true;
+    for (int j = f.ref_begin; j < f.ref_end; ++j) if (c->sc->feat_refs[j] == id) return true;
     return false;
 }
 inline bool in_box(V3 const& p, const float* lo, const float* hi) {          /* math::geom::point_box_overlap */
@@ -222,15 +239,15 @@ inline float parallax(V3 const& p, HostView const& v1, HostView const& v2) {   /
  * selected view is computed once instead of once per greedy round (multiplying by a cached factor,
  * or by 1.0f where the reference skips, gives bit-identical products). */
 int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref, std::vector<int>& global) {
-    const size_t nv = c->views.size();
+    const size_t nv = c->sc->views.size();
     if (ref < 0 || (size_t)ref >= nv) return fail(MI_DMRECON_EINVAL, "Master view index out of bounds");
-    HostView const& R = c->views[ref];
+    HostView const& R = c->sc->views[ref];
     if (!R.valid) return fail(MI_DMRECON_EINVAL, "Invalid master view");
     if ((size_t)st->scale >= R.levels.size()) return fail(MI_DMRECON_EINVAL, "scale %d beyond pyramid of view %d", st->scale, ref);
     /* features attached to the reference view (dmrecon.cc:185-196), local index = position in `feat` */
     std::vector<int> feat;
-    for (size_t i = 0; i < c->features.size(); ++i) {
-        Feature const& f = c->features[i];
+    for (size_t i = 0; i < c->sc->features.size(); ++i) {
+        Feature const& f = c->sc->features[i];
         if (!contains_view(c, f, ref)) continue;
         V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
         if (!R.pointInFrustum(p)) continue;
@@ -242,12 +259,12 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
     std::vector<std::vector<uint8_t> > sees(nv);
     for (size_t v = 0; v < nv; ++v) sees[v].assign(nf, 0);
     for (size_t l = 0; l < nf; ++l) {                       /* dmrecon.cc:198-206 */
-        Feature const& f = c->features[feat[l]];
+        Feature const& f = c->sc->features[feat[l]];
         V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
         for (int j = f.ref_begin; j < f.ref_end; ++j) {
-            int id = c->feat_refs[j];
-            if (id < 0 || id >= (int)nv || !c->views[id].valid) continue;
-            if (c->views[id].pointInFrustum(p)) { featInd[id].push_back((int)l); sees[id][l] = 1; }
+            int id = c->sc->feat_refs[j];
+            if (id < 0 || id >= (int)nv || !c->sc->views[id].valid) continue;
+            if (c->sc->views[id].pointInFrustum(p)) { featInd[id].push_back((int)l); sees[id][l] = 1; }
         }
     }
     /* unit directions camera -> feature for every view that has features (parallax(), mvs_tools.h:46-56) */
@@ -256,8 +273,8 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
         if (featInd[v].empty() && (int)v != ref) continue;
         dir[v].resize(nf);
         for (size_t l = 0; l < nf; ++l) {
-            Feature const& f = c->features[feat[l]];
-            dir[v][l] = normalized(sub(mk(f.pos[0], f.pos[1], f.pos[2]), c->views[v].pos()));
+            Feature const& f = c->sc->features[feat[l]];
+            dir[v][l] = normalized(sub(mk(f.pos[0], f.pos[1], f.pos[2]), c->sc->views[v].pos()));
         }
     }
     auto parallax_l = [&](size_t l, size_t v1, size_t v2) {
@@ -267,17 +284,17 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
     /* the part of benefitFromView's score that does not depend on the selected set (:76-89) */
     std::vector<std::vector<float> > base(nv);
     for (size_t i = 0; i < nv; ++i) {
-        if ((int)i == ref || !c->views[i].valid) continue;
+        if ((int)i == ref || !c->sc->views[i].valid) continue;
         base[i].resize(featInd[i].size());
         for (size_t k = 0; k < featInd[i].size(); ++k) {
             const size_t l = featInd[i][k];
-            Feature const& f = c->features[feat[l]];
+            Feature const& f = c->sc->features[feat[l]];
             V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
             float score = 1.f;
             float plx = parallax_l(l, ref, i);
             if (plx < st->minParallax) score *= (plx / 10.f) * (plx / 10.f);
             float mfp = R.footPrint(p, st->scale);
-            float nfp = c->views[i].footPrint(p, 0);
+            float nfp = c->sc->views[i].footPrint(p, 0);
             float ratio = mfp / nfp;
             if (ratio > 2.) ratio = 2. / ratio;
             else if (ratio > 1.) ratio = 1.;
@@ -287,7 +304,7 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
     }
     std::vector<char> available(nv, 1);                                     /* global_view_selection.cc:23-30 */
     available[ref] = 0;
-    for (size_t i = 0; i < nv; ++i) if (!c->views[i].valid) available[i] = 0;
+    for (size_t i = 0; i < nv; ++i) if (!c->sc->views[i].valid) available[i] = 0;
     std::vector<int> selected;          /* kept sorted ascending = std::set order */
     /* pen[c][i][k]: factor view c (once selected) contributes to feature k of candidate i (:91-98) */
     std::vector<std::vector<std::vector<float> > > pen(nv);
@@ -330,10 +347,10 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
 
 /* The host half of DMRecon::processFeatures (dmrecon.cc:258-296): feature -> (pixel, initDepth) */
 void plan_seeds(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost& job, int job_index) {
-    HostView const& R = c->views[job.ref_view];
+    HostView const& R = c->sc->views[job.ref_view];
     HostLevel const& L = R.levels[st->scale];
-    for (size_t i = 0; i < c->features.size(); ++i) {
-        Feature const& f = c->features[i];
+    for (size_t i = 0; i < c->sc->features.size(); ++i) {
+        Feature const& f = c->sc->features[i];
         bool use = contains_view(c, f, job.ref_view);
         for (size_t g = 0; !use && g < job.global.size(); ++g)
             if (contains_view(c, f, job.global[g])) use = true;
@@ -355,7 +372,7 @@ void plan_seeds(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost& job, 
 }
 
 void fill_job(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost const& jh, DevJob& d) {
-    HostView const& R = c->views[jh.ref_view];
+    HostView const& R = c->sc->views[jh.ref_view];
     HostLevel const& L = R.levels[st->scale];
     std::memset(&d, 0, sizeof(d));
     d.ref_view = jh.ref_view; d.scale = st->scale; d.w = L.w; d.h = L.h;
@@ -435,6 +452,8 @@ int mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     mi_dmrecon_ctx* c = new mi_dmrecon_ctx;
     c->device = device;
+    c->sc = std::make_shared<SceneStore>();
+    c->sc->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     /* sRGB -> linear table: the formula documented at mvs_tools.cc:22-29 evaluated in double and
      * rounded to float reproduces the literal table at :30-93 bit for bit (tests/test_host_logic.py). */
@@ -444,8 +463,8 @@ int mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out) {
         lut[i] = (float)((i <= 0.04045 * 255.0) ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4));
     }
     lut[255] = 1.0f;
-    HIP_TRY(hipMalloc((void**)&c->d_lut, sizeof(lut)));
-    HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&c->sc->d_lut, sizeof(lut)));
+    HIP_TRY(hipMemcpy(c->sc->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(DevCounters)));
     *out = c;
     return 0;
@@ -455,15 +474,34 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (size_t i = 0; i < c->views.size(); ++i) if (c->views[i].d_img) (void)hipFree(c->views[i].d_img);
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
-    c->d_views.release(); c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release();
+    c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release();
     c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_round_work.release();
-    if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
-    delete c;
+    delete c;                                 /* the scene store goes with its last owner */
 }
+
+int mi_dmrecon_ctx_fork(mi_dmrecon_ctx* parent, mi_dmrecon_ctx** out) {
+    if (!parent || !out) return fail(MI_DMRECON_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(parent->device));
+    mi_dmrecon_ctx* c = new mi_dmrecon_ctx;
+    c->device = parent->device;
+    c->sc = parent->sc;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(DevCounters)));
+    *out = c;
+    return 0;
+}
+
+/* Page-locked host memory for the output maps: device->host copies into it run at full PCIe rate
+ * and without the staging copy that pageable memory needs. */
+void* mi_dmrecon_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { fail(MI_DMRECON_EDEVICE, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void mi_dmrecon_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 void* mi_dmrecon_ctx_stream(mi_dmrecon_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
@@ -474,8 +512,8 @@ int mi_dmrecon_set_view(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_cam
     if (width < 2 || height < 2 || width > 65535 || height > 65535) return fail(MI_DMRECON_EINVAL, "bad image size %dx%d", width, height);
     if (channels < 1 || channels > 4) return fail(MI_DMRECON_EINVAL, "Image with invalid number of channels");
     HIP_TRY(hipSetDevice(c->device));
-    if ((size_t)view_id >= c->views.size()) c->views.resize(view_id + 1);
-    HostView& v = c->views[view_id];
+    if ((size_t)view_id >= c->sc->views.size()) c->sc->views.resize(view_id + 1);
+    HostView& v = c->sc->views[view_id];
     if (v.d_img) { (void)hipFree(v.d_img); v.d_img = nullptr; }
     v.cam = *cam;
     v.valid = cam->flen != 0.f;                                   /* CameraInfo::is_valid (View::is_camera_valid) */
@@ -520,43 +558,43 @@ int mi_dmrecon_set_view(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_cam
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->views_dirty = true;
+    c->sc->views_dirty = true;
     return 0;
 }
 
 int mi_dmrecon_evict_view(mi_dmrecon_ctx* c, int32_t view_id) {
-    if (!c || view_id < 0 || (size_t)view_id >= c->views.size()) return fail(MI_DMRECON_EINVAL, "bad view id");
-    HostView& v = c->views[view_id];
+    if (!c || view_id < 0 || (size_t)view_id >= c->sc->views.size()) return fail(MI_DMRECON_EINVAL, "bad view id");
+    HostView& v = c->sc->views[view_id];
     if (v.d_img) { (void)hipFree(v.d_img); v.d_img = nullptr; }
     v.valid = false; v.levels.clear();
-    c->views_dirty = true;
+    c->sc->views_dirty = true;
     return 0;
 }
 
 int mi_dmrecon_set_features(mi_dmrecon_ctx* c, int32_t n, const float* pos, const int32_t* off, const int32_t* ids) {
     if (!c || n < 0 || (n > 0 && (!pos || !off || !ids))) return fail(MI_DMRECON_EINVAL, "null argument");
-    c->features.resize(n);
+    c->sc->features.resize(n);
     for (int i = 0; i < n; ++i) {
-        Feature& f = c->features[i];
+        Feature& f = c->sc->features[i];
         f.pos[0] = pos[3 * i]; f.pos[1] = pos[3 * i + 1]; f.pos[2] = pos[3 * i + 2];
         f.ref_begin = off[i]; f.ref_end = off[i + 1];
     }
-    c->feat_refs.assign(ids, ids + (n ? off[n] : 0));
+    c->sc->feat_refs.assign(ids, ids + (n ? off[n] : 0));
     return 0;
 }
 
 int mi_dmrecon_num_levels(mi_dmrecon_ctx* c, int32_t view_id) {
-    if (!c || view_id < 0 || (size_t)view_id >= c->views.size() || !c->views[view_id].d_img)
+    if (!c || view_id < 0 || (size_t)view_id >= c->sc->views.size() || !c->sc->views[view_id].d_img)
         return fail(MI_DMRECON_EINVAL, "unknown view %d", view_id);
-    return (int)c->views[view_id].levels.size();
+    return (int)c->sc->views[view_id].levels.size();
 }
 
 int mi_dmrecon_level_size(mi_dmrecon_ctx* c, int32_t view_id, int32_t level, int32_t* w, int32_t* h) {
     int n = mi_dmrecon_num_levels(c, view_id);
     if (n < 0) return n;
     if (level < 0 || level >= n) return fail(MI_DMRECON_EINVAL, "level %d out of range", level);
-    if (w) *w = c->views[view_id].levels[level].w;
-    if (h) *h = c->views[view_id].levels[level].h;
+    if (w) *w = c->sc->views[view_id].levels[level].w;
+    if (h) *h = c->sc->views[view_id].levels[level].h;
     return 0;
 }
 
@@ -565,7 +603,7 @@ int mi_dmrecon_get_level(mi_dmrecon_ctx* c, int32_t view_id, int32_t level, uint
     if (n < 0) return n;
     if (level < 0 || level >= n) return fail(MI_DMRECON_EINVAL, "level %d out of range", level);
     HIP_TRY(hipSetDevice(c->device));
-    HostView const& v = c->views[view_id];
+    HostView const& v = c->sc->views[view_id];
     HostLevel const& L = v.levels[level];
     if (proj) std::memcpy(proj, L.proj, sizeof(L.proj));
     if (invproj) std::memcpy(invproj, L.invproj, sizeof(L.invproj));
@@ -640,7 +678,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             if (n_refs == 1) { g_err = plan_err[i]; return plan_rc[i]; }
             continue;
         }
-        HostLevel const& L = c->views[ref_views[i]].levels[st->scale];
+        HostLevel const& L = c->sc->views[ref_views[i]].levels[st->scale];
         plans[i].w = L.w; plans[i].h = L.h;
         job_of[i] = (int)jobs.size();
         jobs.push_back(plans[i]);
@@ -701,7 +739,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), c->stream));
         ev_begin(0); ev_work.push_back((unsigned)seeds.size());
         mi_launch_optimize(c->stream, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
-                           c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
+                           c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
                            nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0, c->d_counters);
         ev_end();
         ++n_launch;
@@ -740,11 +778,11 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         const bool tail = n_work < TAIL_THRESHOLD;
         ev_begin(0); ev_work.push_back(n_work);
         if (tail)
-            mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->d_views.p, c->d_lut, ds, c->d_work.p,
+            mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters);
         else
-            mi_launch_optimize(c->stream, 1, (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE, c->d_jobs.p, c->d_views.p,
-                               c->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
+            mi_launch_optimize(c->stream, 1, (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE, c->d_jobs.p, c->sc->d_views.p,
+                               c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
                                c->d_counters);
         ev_end();
         ++n_launch;
@@ -763,7 +801,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             mi_launch_expand(c->stream, 64, c->d_jobs.p, wcur, c->d_results.p, c->d_round_work.p + (round - 1), wnext,
                              c->d_round_work.p, round - 1);
             ev_begin(0); ev_work.push_back(0u);
-            mi_launch_optimize(c->stream, 16, TAIL_GRID, c->d_jobs.p, c->d_views.p, c->d_lut, ds, wnext, nullptr,
+            mi_launch_optimize(c->stream, 16, TAIL_GRID, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wnext, nullptr,
                                c->d_results.p, c->d_round_work.p + round, 0u, 1u, 0xFFFFFFFFu, round, c->d_counters);
             ev_end();
             mi_launch_apply(c->stream, 64, c->d_jobs.p, wnext, c->d_results.p, c->d_round_work.p + round, 0u, round,
@@ -847,7 +885,7 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     if (jh.global.empty()) return fail(MI_DMRECON_EGVS, "Global View Selection failed");
     rc = sync_views(c);
     if (rc) return rc;
-    HostLevel const& L = c->views[ref_view].levels[st->scale];
+    HostLevel const& L = c->sc->views[ref_view].levels[st->scale];
     jh.w = L.w; jh.h = L.h;
     std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
     fill_job(c, st, jobs[0], dj[0]);
@@ -884,7 +922,7 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     const char* lpv_env = std::getenv("MI_DMRECON_HOOK_LPV");
     const int lpv = (lpv_env && std::atoi(lpv_env) == 16) ? 16 : 1;
     mi_launch_optimize(c->stream, lpv, lpv == 16 ? (unsigned)n : ((unsigned)n + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
-                       c->d_jobs.p, c->d_views.p, c->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
+                       c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
                        c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters);
     HIP_TRY(hipGetLastError());
     std::vector<DevResult> res(n);
@@ -915,7 +953,7 @@ int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int3
     if (jh.global.empty()) return fail(MI_DMRECON_EGVS, "Global View Selection failed");
     rc = sync_views(c);
     if (rc) return rc;
-    HostLevel const& L = c->views[ref_view].levels[st->scale];
+    HostLevel const& L = c->sc->views[ref_view].levels[st->scale];
     jh.w = L.w; jh.h = L.h;
     std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
     fill_job(c, st, jobs[0], dj[0]);
@@ -930,7 +968,7 @@ int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int3
     HIP_TRY(hipMemsetAsync(diout.p, 0, 2 * G * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
     float* d_master = dout.p; float* d_ncc = dout.p + 5; float* d_col = d_ncc + G; float* d_der = d_col + (size_t)G * 75;
-    mi_launch_patch_eval(c->stream, c->d_jobs.p, c->d_views.p, c->d_lut, dev_settings(st), x, y, depth, dzI, dzJ,
+    mi_launch_patch_eval(c->stream, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), x, y, depth, dzI, dzJ,
                          d_master, d_ncc, diout.p, d_col, d_der, diout.p + G);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(master, d_master, 5 * 4, hipMemcpyDeviceToHost, c->stream));
