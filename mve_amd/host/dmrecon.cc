@@ -1,0 +1,270 @@
+/*
+ * mvs::DMRecon on top of the C ABI of include/mi_dmrecon.h -- the host shim that makes
+ * libmi_dmrecon.so a drop-in for libmve_dmrecon.a.  Compiled against the reference's libs/mve,
+ * libs/math and libs/util headers (scene I/O stays MVE's); nothing from libs/dmrecon is used.
+ *
+ * Behaviour kept from the reference (libs/dmrecon/dmrecon.cc):
+ *   ctor  :37-46,74-75  std::invalid_argument for a bad master view / scale / embedding,
+ *         :50-59        std::runtime_error if the bundle cannot be read,
+ *         :81-86        "scaled image size" message unless quiet;
+ *   start :101-105      a set `cancelled` flag ends in RECON_CANCELLED and writes nothing,
+ *         :119-145      view->set_image for depth-L<s>, dz-L<s>, conf-L<s>, undist-L<s>,
+ *         :148-162      "Filled N pixels" / "MVS took" messages,
+ *         :223          std::runtime_error("Global View Selection failed") escapes to the caller.
+ * What replaces ImagePyramidCache (image_pyramid.cc:98-154): a process-wide registry that uploads a
+ * scene's views to each GPU once (pyramids are built on the device) and hands every host thread its
+ * own forked context, so the OpenMP loop of apps/dmrecon/dmrecon.cc:285-318 keeps all GPUs busy.
+ * Device choice: MI_DMRECON_DEVICES="0,2,5" (default: every visible GPU), threads round-robin.
+ */
+#include "dmrecon/dmrecon.h"
+
+#include <atomic>
+#include <cstdlib>
+#include <ctime>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+#include "mve/image.h"
+#include "mve/image_tools.h"
+#include "mve/view.h"
+#include "util/string_utils.h"
+#include "mi_dmrecon.h"
+
+MVS_NAMESPACE_BEGIN
+
+namespace {
+
+[[noreturn]] void raise_from(int rc)
+{
+    std::string msg = mi_dmrecon_last_error();
+    switch (rc) {
+        case MI_DMRECON_EINVAL: throw std::invalid_argument(msg);
+        case MI_DMRECON_EFOOTPRINT: throw std::out_of_range(msg);
+        default: throw std::runtime_error(msg);
+    }
+}
+
+/* One resident copy of a scene per GPU + one forked context per (GPU, host thread). */
+class Registry
+{
+public:
+    static Registry& get() { static Registry r; return r; }
+
+    mi_dmrecon_ctx* context_for(mve::Scene::Ptr scene, std::string const& embedding)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (devices.empty()) init_devices();
+        if (scene.get() != cached_scene || embedding != cached_embedding) {
+            /* like ImagePyramidCache: first scene/embedding wins; a different one re-uploads */
+            release_all();
+            cached_scene = scene.get();
+            cached_embedding = embedding;
+        }
+        std::thread::id me = std::this_thread::get_id();
+        std::map<std::thread::id, mi_dmrecon_ctx*>::iterator it = per_thread.find(me);
+        if (it != per_thread.end()) return it->second;
+        std::size_t slot = next_slot++ % devices.size();
+        if (parents[slot] == nullptr) upload(slot, scene, embedding);
+        mi_dmrecon_ctx* c = nullptr;
+        int rc = mi_dmrecon_ctx_fork(parents[slot], &c);
+        if (rc != 0) raise_from(rc);
+        per_thread[me] = c;
+        return c;
+    }
+
+private:
+    std::mutex mu;
+    std::vector<int> devices;
+    std::vector<mi_dmrecon_ctx*> parents;
+    std::map<std::thread::id, mi_dmrecon_ctx*> per_thread;
+    std::size_t next_slot = 0;
+    void* cached_scene = nullptr;
+    std::string cached_embedding;
+
+    void init_devices()
+    {
+        int n = mi_dmrecon_device_count();
+        if (n <= 0) throw std::runtime_error("mvs::DMRecon (MI355X build): no HIP device available; there is no CPU path");
+        char const* env = std::getenv("MI_DMRECON_DEVICES");
+        if (env && *env) {
+            std::stringstream ss(env);
+            std::string tok;
+            while (std::getline(ss, tok, ',')) {
+                int d = std::atoi(tok.c_str());
+                if (d >= 0 && d < n) devices.push_back(d);
+            }
+        }
+        if (devices.empty()) for (int d = 0; d < n; ++d) devices.push_back(d);
+        parents.assign(devices.size(), nullptr);
+    }
+
+    void release_all()
+    {
+        for (std::map<std::thread::id, mi_dmrecon_ctx*>::iterator it = per_thread.begin(); it != per_thread.end(); ++it)
+            mi_dmrecon_ctx_destroy(it->second);
+        per_thread.clear();
+        for (std::size_t i = 0; i < parents.size(); ++i) { if (parents[i]) mi_dmrecon_ctx_destroy(parents[i]); parents[i] = nullptr; }
+    }
+
+    /* SingleView::create for every usable view (dmrecon.cc:62-71) + ensureImages (image_pyramid.cc:55-95) */
+    void upload(std::size_t slot, mve::Scene::Ptr scene, std::string const& embedding)
+    {
+        mi_dmrecon_ctx* c = nullptr;
+        int rc = mi_dmrecon_ctx_create(devices[slot], &c);
+        if (rc != 0) raise_from(rc);
+        mve::Scene::ViewList const& views(scene->get_views());
+        for (std::size_t i = 0; i < views.size(); ++i) {
+            if (views[i] == nullptr || !views[i]->is_camera_valid()
+                || !views[i]->has_image(embedding, mve::IMAGE_TYPE_UINT8))
+                continue;
+            mve::ByteImage::Ptr img = views[i]->get_byte_image(embedding);
+            if (img == nullptr) continue;
+            mve::CameraInfo const& cam = views[i]->get_camera();
+            mi_dmrecon_camera mc;
+            mc.flen = cam.flen; mc.paspect = cam.paspect;
+            mc.ppoint[0] = cam.ppoint[0]; mc.ppoint[1] = cam.ppoint[1];
+            for (int k = 0; k < 9; ++k) mc.rot[k] = cam.rot[k];
+            for (int k = 0; k < 3; ++k) mc.trans[k] = cam.trans[k];
+            rc = mi_dmrecon_set_view(c, (int32_t)i, &mc, img->width(), img->height(), img->channels(), img->get_data_pointer());
+            views[i]->cache_cleanup();
+            if (rc != 0) { mi_dmrecon_ctx_destroy(c); raise_from(rc); }
+        }
+        mve::Bundle::Features const& feats = scene->get_bundle()->get_features();
+        std::vector<float> pos(feats.size() * 3);
+        std::vector<int32_t> off(feats.size() + 1, 0), ids;
+        for (std::size_t i = 0; i < feats.size(); ++i) {
+            for (int k = 0; k < 3; ++k) pos[3 * i + k] = feats[i].pos[k];
+            for (std::size_t j = 0; j < feats[i].refs.size(); ++j) ids.push_back(feats[i].refs[j].view_id);
+            off[i + 1] = (int32_t)ids.size();
+        }
+        if (ids.empty()) ids.push_back(0);
+        rc = mi_dmrecon_set_features(c, (int32_t)feats.size(), pos.data(), off.data(), ids.data());
+        if (rc != 0) { mi_dmrecon_ctx_destroy(c); raise_from(rc); }
+        parents[slot] = c;
+    }
+};
+
+}  // namespace
+
+DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
+    : scene(_scene), settings(_settings), ctx(nullptr), width(0), height(0)
+{
+    mve::Scene::ViewList const& mve_views(scene->get_views());
+    if (settings.refViewNr >= mve_views.size())
+        throw std::invalid_argument("Master view index out of bounds");
+    if (settings.scale < 0.f)
+        throw std::invalid_argument("Invalid scale factor");
+    if (settings.imageEmbedding.empty())
+        throw std::invalid_argument("Invalid image embedding");
+    try {
+        this->scene->get_bundle();
+    } catch (std::exception& e) {
+        throw std::runtime_error(std::string("Error reading bundle file: ") + e.what());
+    }
+    mve::View::Ptr ref = mve_views[settings.refViewNr];
+    if (ref == nullptr || !ref->is_camera_valid()
+        || !ref->has_image(settings.imageEmbedding, mve::IMAGE_TYPE_UINT8))
+        throw std::invalid_argument("Invalid master view");
+
+    this->ctx = Registry::get().context_for(scene, settings.imageEmbedding);
+    int32_t w = 0, h = 0;
+    if (mi_dmrecon_level_size(ctx, (int32_t)settings.refViewNr, settings.scale, &w, &h) != 0)
+        throw std::invalid_argument("Invalid master view");
+    this->width = w;
+    this->height = h;
+    if (!settings.quiet)
+        std::cout << "scaled image size: " << this->width << " x " << this->height << std::endl;
+}
+
+void
+DMRecon::start()
+{
+    progress.start_time = std::time(nullptr);
+    if (progress.cancelled) { progress.status = RECON_CANCELLED; return; }
+
+    mi_dmrecon_settings st;
+    mi_dmrecon_settings_default(&st);
+    st.filterWidth = (int32_t)settings.filterWidth;
+    st.minNCC = settings.minNCC; st.minParallax = settings.minParallax;
+    st.acceptNCC = settings.acceptNCC; st.minRefineDiff = settings.minRefineDiff;
+    st.maxIterations = (int32_t)settings.maxIterations;
+    st.nrReconNeighbors = (int32_t)settings.nrReconNeighbors;
+    st.globalVSMax = (int32_t)settings.globalVSMax;
+    st.scale = settings.scale;
+    st.useColorScale = settings.useColorScale ? 1 : 0;
+    for (int k = 0; k < 3; ++k) { st.aabbMin[k] = settings.aabbMin[k]; st.aabbMax[k] = settings.aabbMax[k]; }
+
+    mve::FloatImage::Ptr depthImg = mve::FloatImage::create(width, height, 1);
+    mve::FloatImage::Ptr dzImg = mve::FloatImage::create(width, height, 2);
+    mve::FloatImage::Ptr confImg = mve::FloatImage::create(width, height, 1);
+    mi_dmrecon_maps maps;
+    maps.depth = depthImg->get_data_pointer();
+    maps.dz = dzImg->get_data_pointer();
+    maps.conf = confImg->get_data_pointer();
+    maps.normal = nullptr;
+    maps.views = nullptr;
+
+    /* The library polls `cancelled` and publishes status/filled/queueSize through its own POD. */
+    mi_dmrecon_progress mp;
+    mp.status = MI_RECON_IDLE; mp.filled = 0; mp.queueSize = 0; mp.start_time = progress.start_time; mp.cancelled = 0;
+    std::atomic<bool> running(true);
+    std::thread relay([&]() {
+        while (running.load()) {
+            if (progress.cancelled) mp.cancelled = 1;
+            progress.status = (ReconStatus)mp.status;
+            progress.filled = mp.filled;
+            progress.queueSize = mp.queueSize;
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    });
+    int32_t ref = (int32_t)settings.refViewNr;
+    int32_t status = 0;
+    mi_dmrecon_stats stats;
+    int rc = mi_dmrecon_reconstruct(ctx, &st, 1, &ref, &maps, &mp, &status, &stats);
+    running.store(false);
+    relay.join();
+    if (rc == MI_DMRECON_ECANCELLED) { progress.status = RECON_CANCELLED; return; }
+    if (rc != 0) { progress.status = RECON_IDLE; raise_from(rc); }
+
+    progress.status = RECON_SAVING;
+    progress.filled = (std::size_t)stats.n_filled;
+    mve::View::Ptr view = scene->get_views()[settings.refViewNr];
+    std::string name("depth-L");
+    name += util::string::get(settings.scale);
+    view->set_image(depthImg, name);
+    if (settings.keepDzMap) {
+        name = "dz-L";
+        name += util::string::get(settings.scale);
+        view->set_image(dzImg, name);
+    }
+    if (settings.keepConfidenceMap) {
+        name = "conf-L";
+        name += util::string::get(settings.scale);
+        view->set_image(confImg, name);
+    }
+    if (settings.scale != 0) {
+        mve::ByteImage::Ptr undist = mve::ByteImage::create(width, height, 3);
+        rc = mi_dmrecon_get_level(ctx, ref, settings.scale, undist->get_data_pointer(), nullptr, nullptr);
+        if (rc != 0) raise_from(rc);
+        name = "undist-L";
+        name += util::string::get(settings.scale);
+        view->set_image(undist, name);
+    }
+    if (settings.writePlyFile && !settings.quiet)
+        std::cout << "Note: --writeply is not provided by the MI355X build (the PLY export of "
+                     "libs/dmrecon/single_view.cc:122-138 is downstream of the depth-map path)." << std::endl;
+    progress.status = RECON_IDLE;
+    if (!settings.quiet) {
+        float percent = (float)progress.filled / (float)(width * height);
+        std::cout << "Filled " << progress.filled << " pixels, i.e. "
+                  << util::string::get_fixed(percent * 100.f, 1) << " %." << std::endl;
+        std::cout << "MVS took " << (std::time(nullptr) - progress.start_time) << " seconds." << std::endl;
+    }
+}
+
+MVS_NAMESPACE_END

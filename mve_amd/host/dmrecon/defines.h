@@ -1,0 +1,22 @@
+/*
+ * Drop-in header set for MVE's libs/dmrecon public interface, backed by the MI355X library
+ * (include/mi_dmrecon.h).  apps/dmrecon/dmrecon.cc and UMVE include "dmrecon/settings.h" and
+ * "dmrecon/dmrecon.h" (apps/dmrecon/dmrecon.cc:14-15); putting this directory before the
+ * reference's libs/ on the include path swaps the implementation without touching the callers.
+ */
+#ifndef MI_DMRECON_SHIM_DEFINES_H
+#define MI_DMRECON_SHIM_DEFINES_H
+
+#include <set>
+#include <vector>
+
+#include "math/vector.h"
+
+#define MVS_NAMESPACE_BEGIN namespace mvs {
+#define MVS_NAMESPACE_END }
+
+MVS_NAMESPACE_BEGIN
+typedef std::set<std::size_t> IndexSet;
+MVS_NAMESPACE_END
+
+#endif

@@ -1,0 +1,58 @@
+"""GPU test of the drop-in boundary itself: MVE's UNMODIFIED apps/dmrecon driver (compiled from the
+reference sources where they lie, see mve_amd/host/Makefile) linked against the mvs::DMRecon shim and
+libmi_dmrecon.so instead of libmve_dmrecon.a, run on an MVE scene directory on disk."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import map_parity
+from mve_amd import scene_io
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+APP = os.path.join(ROOT, "build", "dmrecon_mi")
+
+
+@pytest.mark.skipif(not os.path.exists(APP), reason="build/dmrecon_mi not built (needs the reference tree at build time)")
+def test_unmodified_apps_dmrecon_on_the_gpu_library(tmp_path, g1, g1_scene, g1b, g1b_scene):
+    from oracle import oracle as orc
+    # --- all views of G1 through the app's OpenMP loop (apps/dmrecon/dmrecon.cc:285-318)
+    sdir = str(tmp_path / "g1")
+    scene_io.write_scene(sdir, g1_scene)
+    out = subprocess.run([APP, "-s0", "--keep-conf", "--keep-dz", "--force", "--progress=silent", sdir],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Reconstruction took" in out.stdout
+    vd = scene_io.view_dir(sdir, 0)
+    depth = scene_io.read_mvei(os.path.join(vd, "depth-L0.mvei"))[:, :, 0]
+    conf = scene_io.read_mvei(os.path.join(vd, "conf-L0.mvei"))[:, :, 0]
+    dz = scene_io.read_mvei(os.path.join(vd, "dz-L0.mvei"))
+    assert dz.shape == (120, 160, 2)
+    m = map_parity(depth, conf, g1["s0v0_depth"], g1["s0v0_conf"])          # vs the real reference's output
+    assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 5e-3, m
+    S = orc.OracleScene(g1_scene)
+    for v in (1, 4):
+        d = scene_io.read_mvei(os.path.join(scene_io.view_dir(sdir, v), "depth-L0.mvei"))[:, :, 0]
+        c = scene_io.read_mvei(os.path.join(scene_io.view_dir(sdir, v), "conf-L0.mvei"))[:, :, 0]
+        o = S.reconstruct(orc.make_settings(ref_view=v))
+        m = map_parity(d, c, o["depth"], o["conf"])
+        assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
+    # checkpoint/resume granularity kept: without --force existing depth maps are skipped (:304-307)
+    t0 = os.path.getmtime(os.path.join(vd, "depth-L0.mvei"))
+    out = subprocess.run([APP, "-s0", "--progress=silent", sdir], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and os.path.getmtime(os.path.join(vd, "depth-L0.mvei")) == t0
+    # --- single master view at scale 1 of the odd-sized scene: undist-L1 is written too (:135-140)
+    sdir2 = str(tmp_path / "g1b")
+    scene_io.write_scene(sdir2, g1b_scene)
+    out = subprocess.run([APP, "-s1", "-m2", "--keep-conf", "--force", "--progress=silent", sdir2],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    vd2 = scene_io.view_dir(sdir2, 2)
+    assert np.array_equal(scene_io.read_png(os.path.join(vd2, "undist-L1.png")), g1b["s1v2_undist"])
+    d = scene_io.read_mvei(os.path.join(vd2, "depth-L1.mvei"))[:, :, 0]
+    c = scene_io.read_mvei(os.path.join(vd2, "conf-L1.mvei"))[:, :, 0]
+    m = map_parity(d, c, g1b["s1v2_depth"], g1b["s1v2_conf"])
+    assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
