@@ -491,7 +491,7 @@ __device__ __forceinline__ void unit_cross(float ax, float ay, float az, float b
  * On return each view slot's ps.sel holds its view (or -1); returns success.
  */
 template <int LPV>
-__device__ __noinline__ bool local_view_selection(PatchState& ps, const DevSettings& st, const DevView* views, int lane) {
+__device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSettings& st, const DevView* views, int lane) {
     typedef Lay<LPV> L;
     const float* s_lut = g_lut;
     const float* rays = g_rays[L::patch(lane)];
@@ -783,11 +783,10 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     }
     const float inv_mm = 1.f / mm;
     ps.cs0 = ps.cs1 = ps.cs2 = inv_mm;
-    bool propagated_all = true;
-    if (__popc(L::view_ballot(ps.sel >= 0, lane)) != st.K) {
-        propagated_all = false;
-        if (!local_view_selection<LPV>(ps, st, views, lane)) { n_eval += ps.n_eval; n_pass += ps.n_pass; return; }
-    }
+    /* LocalViewSelection::performVS runs at exactly one place (top of the loop below): in the ctor when
+     * fewer than K views were propagated (:56-62), and after replaceViews (:149-160) */
+    bool need_vs = __popc(L::view_ballot(ps.sel >= 0, lane)) != st.K;
+    const bool propagated_all = !need_vs;
     /*
      * doAutoOptimization (patch_optimization.cc:170-242) as a pass-driven state machine.  Each turn of the
      * loop runs ONE fused pass at the current state (colour sums + the Gauss-Newton sums the NEXT step
@@ -798,12 +797,16 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     int iter = 0, need = PASS_DEPTH, ctx = CTX_CTOR;
     bool count_color = propagated_all;   /* samples of views picked by the view selection are already cached there */
     float oldncc = -1.f;
-    const bool active = ps.sel >= 0;
+    const bool active = slot < st.K;               /* view slots 0..K-1 carry a view once the selection succeeded */
     float* vc = g_vc[L::patch(lane)][slot];
     ColorSums S; GNSums gn;
     S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
     TSTAMP(10);
     for (;;) {
+        if (need_vs) {
+            need_vs = false;
+            if (!local_view_selection<LPV>(ps, st, views, lane)) { opti = false; break; }
+        }
         bool okv;
         TSTAMP(20 + need);
         if (need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
@@ -829,7 +832,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
             if (rmask) {
                 viewRemoved = true;
                 if (replace) ps.sel = -1;              /* available[] is already false for selected views */
-                if (!local_view_selection<LPV>(ps, st, views, lane)) { opti = false; break; }
+                need_vs = true;
                 ++iter;
                 need = PASS_COLOR; ctx = CTX_REPLACED; count_color = false;   /* cached / VS-evaluated samples */
                 continue;
@@ -1156,41 +1159,62 @@ struct SweepArgs {
     int max_pixels;       /* max over jobs of w*h */
 };
 
-/* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull. */
+/* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull.
+ * One lane per pixel, 8 pixels per lane; the block's hits are compacted through ballots + one LDS
+ * prefix so that the global work-list counter sees ONE atomic per 2048 pixels (a per-wave atomic on a
+ * single word costs ~10 ns each and dominated this kernel at 40 000 waves). */
+#define GEN_PER_THREAD 8
 __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
+    __shared__ unsigned s_wave_cnt[4];
+    __shared__ unsigned s_base;
     const DevJob* job = a.jobs + blockIdx.y;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int W = job->w, H = job->h;
-    bool any = false;
-    int x = 0, y = 0;
-    if (pix < W * H) {
-        y = pix / W; x = pix - y * W;
-        /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
-        if (x >= 2 && y >= 2 && x < W - 2 && y < H - 2) {
-            const float own = job->conf[pix];
-            const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+    const int W = job->w, H = job->h, npx = W * H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * (256 * GEN_PER_THREAD);
+    if (first >= npx) return;
+    unsigned hits = 0;                       /* bit t = pixel first + t*256 + threadIdx.x is a hit */
+    unsigned before[GEN_PER_THREAD];         /* hits of lower lanes of my wave in trip t */
+    unsigned wave_total = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (job->upd[nb[k]] == a.round - 1) {
-                    const float c = job->conf[nb[k]];
-                    if (own < c - 0.05f || own == 0.f) any = true;
-                }
+    for (int t = 0; t < GEN_PER_THREAD; ++t) {
+        const int pix = first + t * 256 + threadIdx.x;
+        bool any = false;
+        if (pix < npx) {
+            const int y = pix / W, x = pix - y * W;
+            /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
+            if (x >= 2 && y >= 2 && x < W - 2 && y < H - 2) {
+                const float own = job->conf[pix];
+                const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (job->upd[nb[k]] == a.round - 1) {
+                        const float c = job->conf[nb[k]];
+                        if (own < c - 0.05f || own == 0.f) any = true;
+                    }
+            }
         }
+        const unsigned long long m = __ballot(any);
+        before[t] = wave_total + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        wave_total += (unsigned)__popcll(m);
+        if (any) hits |= 1u << t;
     }
-    /* wave-aggregated append: one atomic per wavefront */
-    const unsigned long long m = __ballot(any);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        unsigned base = 0;
-        const int leader = __ffsll((long long)m) - 1;
-        if (lane == leader) base = atomicAdd(&a.round_work[a.round], (unsigned)__popcll(m));
-        base = __shfl(base, leader);
-        if (any) {
-            const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_cnt[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        s_base = tot ? atomicAdd(&a.round_work[a.round], tot) : 0u;
+    }
+    __syncthreads();
+    unsigned off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_wave_cnt[w];
+#pragma unroll
+    for (int t = 0; t < GEN_PER_THREAD; ++t)
+        if ((hits >> t) & 1u) {
+            const int pix = first + t * 256 + threadIdx.x;
+            const int y = pix / W, x = pix - y * W;
             DevEntry e; e.job = blockIdx.y; e.xy = x | (y << 16);
-            a.work[idx] = e;
+            a.work[off + before[t]] = e;
         }
-    }
 }
 
 struct ApplyArgs {
@@ -1404,7 +1428,7 @@ void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_p
                         unsigned* round_work, int round) {
     SweepArgs a;
     a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round; a.max_pixels = max_pixels;
-    hipLaunchKernelGGL(k_generate, dim3((max_pixels + 255) / 256, n_jobs), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_generate, dim3((max_pixels + 256 * GEN_PER_THREAD - 1) / (256 * GEN_PER_THREAD), n_jobs), dim3(256), 0, s, a);
 }
 
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
