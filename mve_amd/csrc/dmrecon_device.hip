@@ -978,7 +978,7 @@ struct OptArgs {
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
  */
 template <int LPV>
-__global__ __launch_bounds__(WAVE) void k_optimize(OptArgs a) {
+__global__ __launch_bounds__(WAVE, 2) void k_optimize(OptArgs a) {
     typedef Lay<LPV> L;
     const int lane = threadIdx.x;
 #ifdef MI_TIMING
