@@ -53,7 +53,9 @@ __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelec
 /* per (patch, view slot): the selected neighbour view as the sampler needs it, so that a pass starts
  * from LDS instead of three dependent global loads (view -> level -> texels) */
 #define VC_WORDS 24
+#ifdef MI_USE_VC
 __shared__ float g_vc[MI_PATCHES_PER_WAVE][4][VC_WORDS];
+#endif
 enum { VC_M = 0, VC_AX = 12, VC_AY, VC_CX, VC_CY, VC_W, VC_H, VC_IMG_LO, VC_IMG_HI, VC_INV0, VC_NLEV, VC_LEVEL, VC_GIDX };
 
 /* ------------------------------------------------------------------------- */
@@ -673,7 +675,12 @@ __device__ __forceinline__ bool run_pass(PatchState& ps, const DevView* views, c
     if (MODE == PASS_NORMAL) gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
     if (ps.sel >= 0) {
         NView nv;
+#ifdef MI_USE_VC
         okv = setup_view_cached<LPV>(views, ps, vc, nv, sub)
+#else
+        int level_unused;
+        okv = setup_view(views, ps.job->global_ids[ps.sel], ps, nv, level_unused)
+#endif
             && sample_pass<MODE, LPV>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
         ps.n_pass++;
         if (okv) {
@@ -708,7 +715,9 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     ps.jcx = job->cam_pos[0]; ps.jcy = job->cam_pos[1]; ps.jcz = job->cam_pos[2];
     ps.jz0 = job->w2c_z[0]; ps.jz1 = job->w2c_z[1]; ps.jz2 = job->w2c_z[2]; ps.jz3 = job->w2c_z[3];
     ps.jinv0 = job->inv0_s;
+#ifdef MI_USE_VC
     g_vc[L::patch(lane)][slot][VC_GIDX] = __int_as_float(-1);
+#endif
     /* view rays (single_view.cc:106-114, mve/depthmap.cc:149-156) and raw master colours into LDS */
     const DevView* RV = views + job->ref_view;
     const DevLevel& RL = RV->lv[job->scale];
@@ -798,7 +807,11 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     bool count_color = propagated_all;   /* samples of views picked by the view selection are already cached there */
     float oldncc = -1.f;
     const bool active = slot < st.K;               /* view slots 0..K-1 carry a view once the selection succeeded */
+#ifdef MI_USE_VC
     float* vc = g_vc[L::patch(lane)][slot];
+#else
+    float* vc = nullptr;
+#endif
     ColorSums S; GNSums gn;
     S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
     TSTAMP(10);
