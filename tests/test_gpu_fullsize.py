@@ -77,3 +77,23 @@ def test_c3_one_view_vs_oracle(c3):
     assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
     assert m["conf_med"] <= 1e-3 and m["conf_p99"] <= 5e-3, m
     assert ctx.global_view_selection(st, 3) == S.global_vs(orc.make_settings(ref_view=3, scale=cfg["scale"]))
+
+
+@pytest.mark.parametrize("name,ref", [("C1", 0), ("C2", 5)])
+def test_other_baseline_configs_vs_oracle(name, ref):
+    """BASELINE configs 1 (2 views 640x480, scale 0, --local-neighbors=1) and 2 (8 views 1280x720, scale 1)
+    at full size: one reference view against the CPU oracle, and the whole scene for sanity."""
+    from oracle import oracle as orc
+    cfg = CONFIGS[name]
+    scene = make_scene(cfg["params"])
+    ctx = api.Context(0)
+    ctx.load_scene(scene)
+    st = api.Settings(scale=cfg["scale"], nrReconNeighbors=cfg["local_neighbors"])
+    res = ctx.reconstruct(st, list(range(cfg["params"].n_views)))
+    assert all((r["conf"] > 0).mean() > 0.5 for r in res)
+    o = orc.OracleScene(scene).reconstruct(orc.make_settings(ref_view=ref, scale=cfg["scale"],
+                                                              local_neighbors=cfg["local_neighbors"]))
+    m = map_parity(res[ref]["depth"], res[ref]["conf"], o["depth"], o["conf"])
+    assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
+    assert m["conf_med"] <= 1e-3 and m["conf_p99"] <= (1e-2 if cfg["local_neighbors"] == 1 else 5e-3), m
+    ctx.close()
