@@ -35,6 +35,9 @@
 #define QUAD 4
 #define WAVE 64
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 u32x2_a4 __attribute__((aligned(4)));      /* gfx950 global loads only need dword alignment */
+
 #ifdef MI_TIMING
 /* development aid: wave 0 / lane 0 logs shader clock stamps into counters->tstamp[] */
 __device__ unsigned long long* g_tbuf;
@@ -331,8 +334,10 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         if (!(vc == vc)) vc = 0.f;
         const int left = (int)floorf(uc), top = (int)floorf(vc);
         const float fx = uc - (float)left, fy = vc - (float)top;
+        /* the two texels of a row are 8 contiguous bytes (dword aligned): one dwordx2 gather per row */
         const uint32_t* r0 = nv.img + (size_t)top * nv.w + left;
-        const uint32_t t00 = r0[0], t10 = r0[1], t01 = r0[nv.w], t11 = r0[nv.w + 1];
+        const u32x2 ra = *(const u32x2_a4*)r0, rb = *(const u32x2_a4*)(r0 + nv.w);
+        const uint32_t t00 = ra.x, t10 = ra.y, t01 = rb.x, t11 = rb.y;
         float n[3], dr[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -812,10 +817,12 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
 #else
     float* vc = nullptr;
 #endif
-    ColorSums S; GNSums gn;
-    S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
     TSTAMP(10);
     for (;;) {
+        /* the sums of a pass are consumed within the same turn: declared here so that nothing of them is
+         * live across the back edge (they are 44 registers) */
+        ColorSums S; GNSums gn;
+        S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
         if (need_vs) {
             need_vs = false;
             if (!local_view_selection<LPV>(ps, st, views, lane)) { opti = false; break; }
@@ -1008,27 +1015,23 @@ __global__ __launch_bounds__(WAVE, 2) void k_optimize(OptArgs a) {
         const DevEntry ent = a.work[e];
         const DevJob* job = a.jobs + ent.job;
         const int x = ent.xy & 0xFFFF, y = ent.xy >> 16;
-        DevResult out;
-        out.conf = 0.f; out.depth = 0.f; out.dzI = out.dzJ = 0.f; out.nx = out.ny = out.nz = 0.f;
-        out.views = 0xFFFFFFFFu; out.iters = 0; out.accepted = 0;
+        const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
+        if (writer) {
+            DevResult z;
+            z.conf = 0.f; z.depth = 0.f; z.dzI = z.dzJ = 0.f; z.nx = z.ny = z.nz = 0.f;
+            z.views = 0xFFFFFFFFu; z.iters = 0; z.accepted = 0;
+            a.results[e] = z;
+        }
         /* Hypotheses to try.  Explicit mode (seeds, parity hook): the one given.  Propagate mode:
          * the queue semantics of dmrecon.cc:365-392 for the hypotheses pulled from the 4-neighbours
-         * that were written last round, best confidence first. */
+         * that were written last round, best confidence first.  Nothing but `best` and a 4-bit mask is kept
+         * in registers across an optimisation (the candidates are re-read from the frozen state). */
         const bool explicit_hyp = a.hyp != nullptr;
         const int W = job->w;
         const int pix = y * W + x;
-        const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
-        float cc[4] = {0.f, 0.f, 0.f, 0.f};
-        bool use[4] = {false, false, false, false};
-        float best = 0.f;
-        if (!explicit_hyp) {
-            best = job->conf[pix];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                cc[k] = job->conf[nb[k]];
-                use[k] = job->upd[nb[k]] == a.round - 1 && (best < cc[k] - 0.05f || best == 0.f);
-            }
-        }
+        float best = explicit_hyp ? 0.f : job->conf[pix];
+        const float own = best;
+        unsigned tried = 0;
         for (int t = 0; t < 4; ++t) {
             float hd, hi, hj; unsigned hv;
             if (explicit_hyp) {
@@ -1036,13 +1039,18 @@ __global__ __launch_bounds__(WAVE, 2) void k_optimize(OptArgs a) {
                 const DevHyp h = a.hyp[e];
                 hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = h.views;
             } else {
-                int bi = -1;
+                const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+                int bi = -1; float bc = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (use[k] && (bi < 0 || cc[k] > cc[bi])) bi = k;
+                for (int k = 0; k < 4; ++k) {
+                    if ((tried >> k) & 1u) continue;
+                    const float c = job->conf[nb[k]];
+                    const bool use = job->upd[nb[k]] == a.round - 1 && (own < c - 0.05f || own == 0.f);
+                    if (use && (bi < 0 || c > bc)) { bi = k; bc = c; }
+                }
                 if (bi < 0) break;
-                use[bi] = false;
-                if (best > cc[bi]) continue;                       /* dmrecon.cc:371 */
+                tried |= 1u << bi;
+                if (best > bc) continue;                           /* dmrecon.cc:371 */
                 const int p = nb[bi];
                 hd = job->depth[p]; hi = job->dz[2 * p]; hj = job->dz[2 * p + 1]; hv = job->views[p];
             }
@@ -1051,18 +1059,18 @@ __global__ __launch_bounds__(WAVE, 2) void k_optimize(OptArgs a) {
             optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
             TSTAMP(4);
             ++n_patch;
-            if (explicit_hyp) {
-                out.conf = r.conf; out.depth = r.depth; out.dzI = r.dzI; out.dzJ = r.dzJ;
-                out.nx = r.nx; out.ny = r.ny; out.nz = r.nz; out.views = r.views; out.iters = r.iters;
-                out.accepted = r.conf > 0.f;
-            } else if (r.conf > 0.f && best < r.conf) {            /* dmrecon.cc:378,391 */
+            const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
+            if (accept) {
                 best = r.conf;
-                out.conf = r.conf; out.depth = r.depth; out.dzI = r.dzI; out.dzJ = r.dzJ;
-                out.nx = r.nx; out.ny = r.ny; out.nz = r.nz; out.views = r.views; out.iters = r.iters;
-                out.accepted = 1;
+                if (writer) {
+                    DevResult o;
+                    o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ;
+                    o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.iters = r.iters;
+                    o.accepted = explicit_hyp ? (r.conf > 0.f) : 1;
+                    a.results[e] = o;
+                }
             }
         }
-        if (L::vslot(lane) == 0 && L::sub(lane) == 0) a.results[e] = out;
     }
     /* flush counters: one atomic per wave (per-view counters live in the first lane of each view slot,
      * the patch counter in the first lane of each patch) */
