@@ -126,6 +126,13 @@ void* mi_dmrecon_ctx_stream(mi_dmrecon_ctx* ctx);
  * builds the Gaussian pyramid on the device (image_tools.h:619-690) and keeps every level resident in HBM. */
 int  mi_dmrecon_set_view(mi_dmrecon_ctx* ctx, int32_t view_id, const mi_dmrecon_camera* cam,
                          int32_t width, int32_t height, int32_t channels, const uint8_t* pixels);
+/* Same, without waiting: the host->device copy, the RGBA pack and the pyramid kernels are only enqueued.
+ * `pixels` must stay valid (and should be page-locked, mi_dmrecon_host_alloc, for the copy to be truly
+ * asynchronous) until mi_dmrecon_sync() -- the staging path for scenes whose level-0 images do not fit
+ * the time budget of a blocking upload (BASELINE config 5: 100 x 4032x3024). */
+int  mi_dmrecon_set_view_async(mi_dmrecon_ctx* ctx, int32_t view_id, const mi_dmrecon_camera* cam,
+                               int32_t width, int32_t height, int32_t channels, const uint8_t* pixels);
+int  mi_dmrecon_sync(mi_dmrecon_ctx* ctx);
 int  mi_dmrecon_evict_view(mi_dmrecon_ctx* ctx, int32_t view_id);     /* ImagePyramidCache::cleanup */
 
 /* mve::Bundle::Features (libs/mve/bundle.h:46-56) in CSR form: feature i has position pos[3i..3i+2]

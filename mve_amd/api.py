@@ -31,7 +31,7 @@ EXPORTS = [
     "mi_dmrecon_device_count", "mi_dmrecon_last_error", "mi_dmrecon_settings_default",
     "mi_dmrecon_ctx_create", "mi_dmrecon_ctx_destroy", "mi_dmrecon_ctx_fork", "mi_dmrecon_ctx_stream",
     "mi_dmrecon_host_alloc", "mi_dmrecon_host_free",
-    "mi_dmrecon_set_view", "mi_dmrecon_evict_view", "mi_dmrecon_set_features",
+    "mi_dmrecon_set_view", "mi_dmrecon_set_view_async", "mi_dmrecon_sync", "mi_dmrecon_evict_view", "mi_dmrecon_set_features",
     "mi_dmrecon_num_levels", "mi_dmrecon_level_size", "mi_dmrecon_get_level",
     "mi_dmrecon_global_view_selection", "mi_dmrecon_reconstruct",
     "mi_dmrecon_patch_optimize", "mi_dmrecon_patch_eval",
@@ -96,6 +96,8 @@ def load_library() -> ctypes.CDLL:
     L.mi_dmrecon_host_free.restype = None
     L.mi_dmrecon_ctx_stream.restype = vp
     L.mi_dmrecon_set_view.argtypes = [vp, i32, ctypes.POINTER(CCamera), i32, i32, i32, vp]
+    L.mi_dmrecon_set_view_async.argtypes = [vp, i32, ctypes.POINTER(CCamera), i32, i32, i32, vp]
+    L.mi_dmrecon_sync.argtypes = [vp]
     L.mi_dmrecon_evict_view.argtypes = [vp, i32]
     L.mi_dmrecon_set_features.argtypes = [vp, i32, vp, vp, vp]
     L.mi_dmrecon_num_levels.argtypes = [vp, i32]
@@ -219,7 +221,8 @@ class Context:
         return int(self._L.mi_dmrecon_ctx_stream(self._h) or 0)
 
     # -- scene upload --------------------------------------------------------
-    def set_view(self, view_id: int, cam, image: np.ndarray):
+    def set_view(self, view_id: int, cam, image: np.ndarray, asynchronous: bool = False):
+        """asynchronous=True only enqueues (image must stay alive, ideally pinned, until sync())."""
         c = CCamera()
         c.flen, c.paspect = cam.flen, cam.paspect
         c.ppoint[:] = list(cam.ppoint)
@@ -228,11 +231,16 @@ class Context:
         img = np.ascontiguousarray(image, np.uint8)
         if img.ndim == 2:
             img = img[:, :, None]
-        rc = self._L.mi_dmrecon_set_view(self._h, view_id, ctypes.byref(c), img.shape[1], img.shape[0],
-                                         img.shape[2], _ptr(img))
+        fn = self._L.mi_dmrecon_set_view_async if asynchronous else self._L.mi_dmrecon_set_view
+        rc = fn(self._h, view_id, ctypes.byref(c), img.shape[1], img.shape[0], img.shape[2], _ptr(img))
         if rc != 0:
             _raise(rc)
         self.n_views = max(self.n_views, view_id + 1)
+
+    def sync(self):
+        rc = self._L.mi_dmrecon_sync(self._h)
+        if rc != 0:
+            _raise(rc)
 
     def set_features(self, features):
         pos = np.asarray([f.pos for f in features], np.float32).reshape(-1, 3)
@@ -245,10 +253,28 @@ class Context:
         if rc != 0:
             _raise(rc)
 
-    def load_scene(self, scene: SceneData):
-        for vid, (cam, img) in enumerate(zip(scene.cameras, scene.images)):
-            if img is not None:
-                self.set_view(vid, cam, img)
+    def load_scene(self, scene: SceneData, pinned_staging: bool = False):
+        """Upload every view (pyramids are built on the device) and the features.
+        pinned_staging=True streams the images through two page-locked buffers with asynchronous
+        uploads: the host copies view i+1 into one buffer while the GPU ingests view i from the other."""
+        if not pinned_staging:
+            for vid, (cam, img) in enumerate(zip(scene.cameras, scene.images)):
+                if img is not None:
+                    self.set_view(vid, cam, img)
+        else:
+            nmax = max(int(np.prod(im.shape)) for im in scene.images if im is not None)
+            ring = [PinnedArray((nmax,), np.uint8) for _ in range(2)]
+            k = 0
+            for vid, (cam, img) in enumerate(zip(scene.cameras, scene.images)):
+                if img is None:
+                    continue
+                if k >= 2:
+                    self.sync()                  # the buffer about to be reused has been consumed
+                buf = ring[k % 2].array[:img.size].reshape(img.shape)
+                np.copyto(buf, img)
+                self.set_view(vid, cam, buf, asynchronous=True)
+                k += 1
+            self.sync()
         self.set_features(scene.features)
 
     # -- queries -------------------------------------------------------------

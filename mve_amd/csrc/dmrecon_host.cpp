@@ -174,6 +174,8 @@ struct mi_dmrecon_ctx {
     DevBuf<unsigned long long> d_keys;
     DevBuf<unsigned> d_keyoff;
     DevBuf<uint8_t> d_stage;
+    DevBuf<uint8_t> d_stage2;
+    int stage_flip = 0;
     DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
     std::vector<hipEvent_t> events;
 };
@@ -476,7 +478,7 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
     c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release();
-    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_round_work.release();
+    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
     delete c;                                 /* the scene store goes with its last owner */
@@ -505,8 +507,8 @@ void mi_dmrecon_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 void* mi_dmrecon_ctx_stream(mi_dmrecon_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-int mi_dmrecon_set_view(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_camera* cam, int32_t width,
-                        int32_t height, int32_t channels, const uint8_t* pixels) {
+static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_camera* cam, int32_t width,
+                         int32_t height, int32_t channels, const uint8_t* pixels, bool async) {
     if (!c || !cam || !pixels) return fail(MI_DMRECON_EINVAL, "null argument");
     if (view_id < 0 || view_id >= (1 << 20)) return fail(MI_DMRECON_EINVAL, "bad view id %d", view_id);
     if (width < 2 || height < 2 || width > 65535 || height > 65535) return fail(MI_DMRECON_EINVAL, "bad image size %dx%d", width, height);
@@ -548,17 +550,40 @@ int mi_dmrecon_set_view(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_cam
     HIP_TRY(hipMalloc((void**)&v.d_img, off * sizeof(uint32_t)));
     /* ensureImages, image_pyramid.cc:55-95: upload, strip alpha / expand grey, then the Gaussian levels */
     const size_t nbytes = (size_t)width * height * channels;
-    if (c->d_stage.reserve(nbytes)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(stage) failed");
-    HIP_TRY(hipMemcpyAsync(c->d_stage.p, pixels, nbytes, hipMemcpyHostToDevice, c->stream));
-    mi_launch_pack_rgba(c->stream, c->d_stage.p, v.d_img, width * height, channels);
+    /* two device staging buffers used alternately: the copy of view i+1 (from pinned memory) can start
+     * while the pack/pyramid kernels of view i still read the other one */
+    DevBuf<uint8_t>& stage = (c->stage_flip ^= 1) ? c->d_stage : c->d_stage2;
+    if (stage.cap < nbytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));          /* the buffer may still be in use */
+        if (stage.reserve(nbytes)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(stage) failed");
+    }
+    HIP_TRY(hipMemcpyAsync(stage.p, pixels, nbytes, hipMemcpyHostToDevice, c->stream));
+    mi_launch_pack_rgba(c->stream, stage.p, v.d_img, width * height, channels);
     const float w1 = std::exp(-0.5f / (2.0f * 1.f)), w2 = std::exp(-2.5f / (2.0f * 1.f)), w3 = std::exp(-4.5f / (2.0f * 1.f));
     for (size_t l = 1; l < v.levels.size(); ++l) {
         HostLevel const& a = v.levels[l - 1]; HostLevel const& b = v.levels[l];
         mi_launch_pyramid(c->stream, v.d_img + a.tex_off, v.d_img + b.tex_off, a.w, a.h, b.w, b.h, w1, w2, w3);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!async) HIP_TRY(hipStreamSynchronize(c->stream));
     c->sc->views_dirty = true;
+    return 0;
+}
+
+int mi_dmrecon_set_view(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_camera* cam, int32_t width,
+                        int32_t height, int32_t channels, const uint8_t* pixels) {
+    return set_view_impl(c, view_id, cam, width, height, channels, pixels, false);
+}
+
+int mi_dmrecon_set_view_async(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_camera* cam, int32_t width,
+                              int32_t height, int32_t channels, const uint8_t* pixels) {
+    return set_view_impl(c, view_id, cam, width, height, channels, pixels, true);
+}
+
+int mi_dmrecon_sync(mi_dmrecon_ctx* c) {
+    if (!c) return fail(MI_DMRECON_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
