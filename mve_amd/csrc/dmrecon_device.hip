@@ -697,37 +697,26 @@ __device__ __forceinline__ bool run_pass(PatchState& ps, const DevView* views, c
 }
 
 /*
- * PatchOptimization ctor + doAutoOptimization + computeConfidence for one patch.
+ * PatchOptimization ctor + doAutoOptimization + computeConfidence for one patch, as three pieces so that
+ * an optimisation can be suspended between two turns (k_optimize caps the turns of the bulk rounds and
+ * k_resume finishes the stragglers with freshly packed wavefronts):
+ *   run_begin  PatchSampler / LocalViewSelection / PatchOptimization constructors
+ *   run_turn   one turn of doAutoOptimization's pass-driven state machine
+ *   run_end    getLocalViewIDs, computeConfidence, getPatchNormal
  * hyp_views: packed global indices of the propagated local view set (MI_VIEW_NONE = none).
  */
-template <int LPV>
-__device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
-                               float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane,
-                               PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err) {
-    typedef Lay<LPV> L;
-    const float* s_lut = g_lut;
-    float* rays = g_rays[L::patch(lane)];
-    float* mcol = g_mcol[L::patch(lane)];
-    const int slot = L::vslot(lane), sub = L::sub(lane);
-    const int pl = slot * LPV + sub;                 /* lane index inside the patch */
-    res.conf = 0.f; res.depth = depth0; res.dzI = dzI0; res.dzJ = dzJ0; res.nx = res.ny = res.nz = 0.f;
-    res.views = 0xFFFFFFFFu; res.iters = 0;
+enum { CTX_CTOR, CTX_FIRST4, CTX_STEP, CTX_REPLACED, CTX_REPASS };
+
+struct Run {
     PatchState ps;
-    ps.job = job; ps.x = x; ps.y = y; ps.n_eval = 0; ps.n_pass = 0;
-    ps.sel = -1; ps.cs0 = ps.cs1 = ps.cs2 = 1.f; ps.ncc = -1.f;
-    /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
-    if (x - 2 < 0 || y - 2 < 0 || x + 2 > job->w - 1 || y + 2 > job->h - 1) return;
-    ps.jcx = job->cam_pos[0]; ps.jcy = job->cam_pos[1]; ps.jcz = job->cam_pos[2];
-    ps.jz0 = job->w2c_z[0]; ps.jz1 = job->w2c_z[1]; ps.jz2 = job->w2c_z[2]; ps.jz3 = job->w2c_z[3];
-    ps.jinv0 = job->inv0_s;
-#ifdef MI_USE_VC
-    g_vc[L::patch(lane)][slot][VC_GIDX] = __int_as_float(-1);
-#endif
-    /* view rays (single_view.cc:106-114, mve/depthmap.cc:149-156) and raw master colours into LDS */
-    const DevView* RV = views + job->ref_view;
-    const DevLevel& RL = RV->lv[job->scale];
-    const uint32_t* rimg = RV->img + RL.tex_off;
-    float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;       /* LPV = 16: my sample's raw master colour */
+    bool opti, converged, viewRemoved, step_was_normal, need_vs, count_color;
+    int iter, need, ctx;
+    float oldncc;                /* per view slot: getFastNCC before the step (:189-192) */
+};
+
+/* view rays (single_view.cc:106-114, mve/depthmap.cc:149-156) of the 5x5 window into LDS */
+template <int LPV>
+__device__ __forceinline__ void fill_rays(const DevJob* job, int x, int y, float* rays, int pl) {
     for (int i = pl; i < MI_NS; i += 4 * LPV) {
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
         const float fx = (float)(x + di) + 0.5f, fy = (float)(y + dj) + 0.5f;
@@ -737,6 +726,45 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         rays[3 * i] = job->rot_t[0] * rx + job->rot_t[1] * ry + job->rot_t[2] * rz;
         rays[3 * i + 1] = job->rot_t[3] * rx + job->rot_t[4] * ry + job->rot_t[5] * rz;
         rays[3 * i + 2] = job->rot_t[6] * rx + job->rot_t[7] * ry + job->rot_t[8] * rz;
+    }
+}
+
+__device__ __forceinline__ void load_job_constants(PatchState& ps, const DevJob* job) {
+    ps.jcx = job->cam_pos[0]; ps.jcy = job->cam_pos[1]; ps.jcz = job->cam_pos[2];
+    ps.jz0 = job->w2c_z[0]; ps.jz1 = job->w2c_z[1]; ps.jz2 = job->w2c_z[2]; ps.jz3 = job->w2c_z[3];
+    ps.jinv0 = job->inv0_s;
+}
+
+/* Returns false if the optimisation is over before it started (the result keeps confidence 0). */
+template <int LPV>
+__device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
+                                          float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane, unsigned& err) {
+    typedef Lay<LPV> L;
+    PatchState& ps = R.ps;
+    const float* s_lut = g_lut;
+    float* rays = g_rays[L::patch(lane)];
+    float* mcol = g_mcol[L::patch(lane)];
+    const int slot = L::vslot(lane), sub = L::sub(lane);
+    const int pl = slot * LPV + sub;                 /* lane index inside the patch */
+    ps.job = job; ps.x = x; ps.y = y; ps.n_eval = 0; ps.n_pass = 0;
+    ps.sel = -1; ps.cs0 = ps.cs1 = ps.cs2 = 1.f; ps.ncc = -1.f;
+    ps.depth = depth0; ps.dzI = dzI0; ps.dzJ = dzJ0;
+    R.opti = true; R.converged = false; R.viewRemoved = false; R.step_was_normal = false;
+    R.iter = 0; R.need = PASS_DEPTH; R.ctx = CTX_CTOR; R.oldncc = -1.f; R.need_vs = false; R.count_color = false;
+    /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
+    if (x - 2 < 0 || y - 2 < 0 || x + 2 > job->w - 1 || y + 2 > job->h - 1) return false;
+    load_job_constants(ps, job);
+#ifdef MI_USE_VC
+    g_vc[L::patch(lane)][slot][VC_GIDX] = __int_as_float(-1);
+#endif
+    fill_rays<LPV>(job, x, y, rays, pl);
+    /* raw master colours */
+    const DevView* RV = views + job->ref_view;
+    const DevLevel& RL = RV->lv[job->scale];
+    const uint32_t* rimg = RV->img + RL.tex_off;
+    float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;       /* LPV = 16: my sample's raw master colour */
+    for (int i = pl; i < MI_NS; i += 4 * LPV) {
+        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
         const uint32_t t = rimg[(size_t)(y + dj) * RL.w + (x + di)];
         raw0 = s_lut[t & 255u]; raw1 = s_lut[(t >> 8) & 255u]; raw2 = s_lut[(t >> 16) & 255u];
         if (LPV == 1) { mcol[3 * i] = raw0; mcol[3 * i + 1] = raw1; mcol[3 * i + 2] = raw2; }
@@ -749,7 +777,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         mm = 0.f;
         for (int k = 0; k < 3 * MI_NS; ++k) mm += mcol[k];
         mm /= 3.f * (float)MI_NS;
-        if (mm < 0.01f || mm > 0.99f) return;
+        if (mm < 0.01f || mm > 0.99f) return false;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int i = pl; i < MI_NS; i += 4 * LPV) { mcol[3 * i] /= mm; mcol[3 * i + 1] /= mm; mcol[3 * i + 2] /= mm; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -765,7 +793,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         /* one sample per lane (lanes 0..24): wave-wide DPP reductions instead of 3 x 75 LDS reads */
         const bool mine = pl < MI_NS;
         mm = L::wave_sum(mine ? (raw0 + raw1 + raw2) : 0.f) / (3.f * (float)MI_NS);
-        if (mm < 0.01f || mm > 0.99f) return;
+        if (mm < 0.01f || mm > 0.99f) return false;
         const float im = fast_rcp(mm);
         raw0 *= im; raw1 *= im; raw2 *= im;
         if (mine) { mcol[3 * pl] = raw0; mcol[3 * pl + 1] = raw1; mcol[3 * pl + 2] = raw2; }
@@ -780,8 +808,8 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     ps.xbar0 = x0; ps.xbar1 = x1; ps.xbar2 = x2;
     ps.sqrDevX = sd;
     /* computePatchPoints */
-    if (!set_state(ps, rays, depth0, dzI0, dzJ0)) return;
-    if (!(ps.mfp > 0.f)) { err |= 1u; return; }      /* reference throws std::out_of_range here */
+    if (!set_state(ps, rays, depth0, dzI0, dzJ0)) return false;
+    if (!(ps.mfp > 0.f)) { err |= 1u; return false; }      /* reference throws std::out_of_range here */
 
     /* --- LocalViewSelection ctor (local_view_selection.cc:19-54) */
     ps.avail = job->n_global >= 32 ? 0xFFFFFFFFu : ((1u << job->n_global) - 1u);
@@ -797,133 +825,144 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     }
     const float inv_mm = 1.f / mm;
     ps.cs0 = ps.cs1 = ps.cs2 = inv_mm;
-    /* LocalViewSelection::performVS runs at exactly one place (top of the loop below): in the ctor when
+    /* LocalViewSelection::performVS runs at exactly one place (top of run_turn): in the ctor when
      * fewer than K views were propagated (:56-62), and after replaceViews (:149-160) */
-    bool need_vs = __popc(L::view_ballot(ps.sel >= 0, lane)) != st.K;
-    const bool propagated_all = !need_vs;
-    /*
-     * doAutoOptimization (patch_optimization.cc:170-242) as a pass-driven state machine.  Each turn of the
-     * loop runs ONE fused pass at the current state (colour sums + the Gauss-Newton sums the NEXT step
-     * needs), then finishes the decision of the step that led here, then takes the next step.
-     */
-    enum { CTX_CTOR, CTX_FIRST4, CTX_STEP, CTX_REPLACED, CTX_REPASS };
-    bool opti = true, converged = false, viewRemoved = false, step_was_normal = false;
-    int iter = 0, need = PASS_DEPTH, ctx = CTX_CTOR;
-    bool count_color = propagated_all;   /* samples of views picked by the view selection are already cached there */
-    float oldncc = -1.f;
+    R.need_vs = __popc(L::view_ballot(ps.sel >= 0, lane)) != st.K;
+    R.count_color = !R.need_vs;   /* samples of views picked by the view selection are already cached there */
+    return true;
+}
+
+/*
+ * One turn of doAutoOptimization (patch_optimization.cc:170-242) as a pass-driven state machine: run ONE
+ * fused pass at the current state (colour sums + the Gauss-Newton sums the NEXT step needs), finish the
+ * decision of the step that led here, take the next step.  Returns false when the optimisation is over.
+ */
+template <int LPV>
+__device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const DevView* views, int lane) {
+    typedef Lay<LPV> L;
+    PatchState& ps = R.ps;
+    const float* s_lut = g_lut;
+    float* rays = g_rays[L::patch(lane)];
+    float* mcol = g_mcol[L::patch(lane)];
+    const int slot = L::vslot(lane), sub = L::sub(lane);
     const bool active = slot < st.K;               /* view slots 0..K-1 carry a view once the selection succeeded */
 #ifdef MI_USE_VC
     float* vc = g_vc[L::patch(lane)][slot];
 #else
     float* vc = nullptr;
 #endif
-    TSTAMP(10);
-    for (;;) {
-        /* the sums of a pass are consumed within the same turn: declared here so that nothing of them is
-         * live across the back edge (they are 44 registers) */
-        ColorSums S; GNSums gn;
-        S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
-        if (need_vs) {
-            need_vs = false;
-            if (!local_view_selection<LPV>(ps, st, views, lane)) { opti = false; break; }
-        }
-        bool okv;
-        TSTAMP(20 + need);
-        if (need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
-        else if (need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
-        else if (need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
-        else okv = run_pass<PASS_COLOR, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, count_color, sub);
-        TSTAMP(30);
-        /* ---- finish what led to this pass */
-        if (ctx == CTX_CTOR || ctx == CTX_REPLACED) {
-            /* computeColorScale() at the end of the ctor (:77) / after replaceViews (:231) */
-            if (!color_scale_step<LPV>(ps, st, S, okv, lane)) { opti = false; break; }
-        } else if (ctx == CTX_STEP) {
-            if (step_was_normal) {
-                /* optimizeDepthAndNormal is followed by computeColorScale on the new state (:197-199) */
-                if (!color_scale_step<LPV>(ps, st, S, okv, lane)) { opti = false; break; }
-            }
-            /* convergence / view replacement (:207-239) */
-            const float dn = fabsf(ps.ncc - oldncc);
-            const bool moving = active && dn > st.minRefineDiff;
-            const bool replace = active && (ps.ncc < st.acceptNCC || (iter == 14 && dn > st.minRefineDiff));
-            const unsigned rmask = L::view_ballot(replace, lane);
-            const bool conv = L::view_ballot(moving, lane) == 0;
-            if (rmask) {
-                viewRemoved = true;
-                if (replace) ps.sel = -1;              /* available[] is already false for selected views */
-                need_vs = true;
-                ++iter;
-                need = PASS_COLOR; ctx = CTX_REPLACED; count_color = false;   /* cached / VS-evaluated samples */
-                continue;
-            }
-            if (conv) { converged = true; break; }
-            ++iter;
-        }
-        /* ---- loop condition of the main loop (:185-186) */
-        if (iter >= 4 && iter >= st.maxIterations) break;
-        /* ---- take the step of iteration `iter` from the sums of this pass */
-        const bool first4 = iter < 4;
-        const bool want_normal = !first4 && (iter % 5 == 4 || viewRemoved);
-        const bool have_normal = need == PASS_NORMAL, have_depth = need == PASS_DEPTH || need == PASS_DEPTH_FIXED;
-        if (want_normal ? !have_normal : !have_depth) {
-            need = want_normal ? PASS_NORMAL : PASS_DEPTH_FIXED; ctx = CTX_REPASS; count_color = false; continue;
-        }
-        TSTAMP(31);
-        if (L::view_ballot(!okv, lane)) { opti = false; break; }       /* fastColAndDeriv failed (:277-280,:321-324) */
-        if (active) ps.n_eval++;                                       /* this pass stood in for fastColAndDeriv */
-        oldncc = ps.ncc;
-        bool step_ok = false;
-        if (want_normal) {
-            const double m0 = L::patch_sum(gn.A00), m1 = L::patch_sum(gn.A01), m2 = L::patch_sum(gn.A02);
-            const double m4 = L::patch_sum(gn.A11), m5 = L::patch_sum(gn.A12), m8 = L::patch_sum(gn.A22);
-            const double b0 = L::patch_sum(gn.B0), b1 = L::patch_sum(gn.B1), b2 = L::patch_sum(gn.B2);
-            const double m3 = m1, m6 = m2, m7 = m5;
-            /* libs/math/matrix_tools.h:392-399 (determinant), :462-476 (inverse) */
-            const double det = m0 * m4 * m8 + m1 * m5 * m6 + m2 * m3 * m7 - m2 * m4 * m6 - m1 * m3 * m8 - m0 * m5 * m7;
-            if (det == 0.0 || !(det == det)) { opti = false; break; }
-            const double i0 = m4 * m8 - m5 * m7, i1 = m2 * m7 - m1 * m8, i2 = m1 * m5 - m2 * m4;
-            const double i3 = m5 * m6 - m3 * m8, i4 = m0 * m8 - m2 * m6, i5 = m2 * m3 - m0 * m5;
-            const double i6 = m3 * m7 - m4 * m6, i7 = m1 * m6 - m0 * m7, i8 = m0 * m4 - m1 * m3;
-            const float X0 = (float)((i0 * b0 + i1 * b1 + i2 * b2) / det);
-            const float X1 = (float)((i3 * b0 + i4 * b1 + i5 * b2) / det);
-            const float X2 = (float)((i6 * b0 + i7 * b1 + i8 * b2) / det);
-            step_ok = set_state(ps, rays, ps.depth + X0, ps.dzI + X1, ps.dzJ + X2);
-            viewRemoved = false;
-            step_was_normal = true;
-        } else {
-            /* optimizeDepthOnly (:265-299) from the colour-scale independent sums */
-            float num = 0.f, den = 0.f;
-            if (active && okv && need == PASS_DEPTH_FIXED) { num = gn.num; den = gn.den; }
-            else if (active && okv) {
-                num = ps.cs0 * (gn.dr0 - (ps.cs0 - gn.c00) * gn.dn0) + ps.cs1 * (gn.dr1 - (ps.cs1 - gn.c01) * gn.dn1)
-                    + ps.cs2 * (gn.dr2 - (ps.cs2 - gn.c02) * gn.dn2);
-                den = ps.cs0 * ps.cs0 * gn.dd0 + ps.cs1 * ps.cs1 * gn.dd1 + ps.cs2 * ps.cs2 * gn.dd2;
-            }
-            num = L::patch_sum(num); den = L::patch_sum(den);
-            if (den > 0.f) step_ok = set_state(ps, rays, ps.depth + fast_div(num, den), ps.dzI, ps.dzJ);
-            else step_ok = first4;                     /* the first four iterations tolerate denom <= 0 (:177-180) */
-            step_was_normal = false;
-        }
-        if (!step_ok) { opti = false; break; }
-        /* the colour scale only changes right after a normal step (and in the ctor): every other pass can
-         * bake it in, which leaves 7 instead of 21 values to reduce across the view slot */
-        if (first4) {
-            ++iter;
-            need = (iter >= 4 && iter % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED;
-            ctx = CTX_FIRST4;
-            count_color = (iter == 4);                 /* the reference first asks for NCCs when the main loop starts */
-        } else {
-            /* after a normal step computeColorScale follows: that pass must carry per-channel colour sums */
-            need = step_was_normal ? PASS_DEPTH : (((iter + 1) % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED);
-            ctx = CTX_STEP;
-            count_color = true;
-        }
+    /* the sums of a pass are consumed within the same turn */
+    ColorSums S; GNSums gn;
+    S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
+    if (R.need_vs) {
+        R.need_vs = false;
+        if (!local_view_selection<LPV>(ps, st, views, lane)) { R.opti = false; return false; }
     }
-    (void)opti;
-    TSTAMP(40);
+    bool okv;
+    TSTAMP(20 + R.need);
+    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, R.count_color, sub);
+    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, R.count_color, sub);
+    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, R.count_color, sub);
+    else okv = run_pass<PASS_COLOR, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, R.count_color, sub);
+    TSTAMP(30);
+    /* ---- finish what led to this pass */
+    if (R.ctx == CTX_CTOR || R.ctx == CTX_REPLACED) {
+        /* computeColorScale() at the end of the ctor (:77) / after replaceViews (:231) */
+        if (!color_scale_step<LPV>(ps, st, S, okv, lane)) { R.opti = false; return false; }
+    } else if (R.ctx == CTX_STEP) {
+        if (R.step_was_normal) {
+            /* optimizeDepthAndNormal is followed by computeColorScale on the new state (:197-199) */
+            if (!color_scale_step<LPV>(ps, st, S, okv, lane)) { R.opti = false; return false; }
+        }
+        /* convergence / view replacement (:207-239) */
+        const float dn = fabsf(ps.ncc - R.oldncc);
+        const bool moving = active && dn > st.minRefineDiff;
+        const bool replace = active && (ps.ncc < st.acceptNCC || (R.iter == 14 && dn > st.minRefineDiff));
+        const unsigned rmask = L::view_ballot(replace, lane);
+        const bool conv = L::view_ballot(moving, lane) == 0;
+        if (rmask) {
+            R.viewRemoved = true;
+            if (replace) ps.sel = -1;              /* available[] is already false for selected views */
+            R.need_vs = true;
+            ++R.iter;
+            R.need = PASS_COLOR; R.ctx = CTX_REPLACED; R.count_color = false;   /* cached / VS-evaluated samples */
+            return true;
+        }
+        if (conv) { R.converged = true; return false; }
+        ++R.iter;
+    }
+    /* ---- loop condition of the main loop (:185-186) */
+    if (R.iter >= 4 && R.iter >= st.maxIterations) return false;
+    /* ---- take the step of iteration `iter` from the sums of this pass */
+    const bool first4 = R.iter < 4;
+    const bool want_normal = !first4 && (R.iter % 5 == 4 || R.viewRemoved);
+    const bool have_normal = R.need == PASS_NORMAL, have_depth = R.need == PASS_DEPTH || R.need == PASS_DEPTH_FIXED;
+    if (want_normal ? !have_normal : !have_depth) {
+        R.need = want_normal ? PASS_NORMAL : PASS_DEPTH_FIXED; R.ctx = CTX_REPASS; R.count_color = false;
+        return true;
+    }
+    TSTAMP(31);
+    if (L::view_ballot(!okv, lane)) { R.opti = false; return false; }       /* fastColAndDeriv failed (:277-280,:321-324) */
+    if (active) ps.n_eval++;                                                /* this pass stood in for fastColAndDeriv */
+    R.oldncc = ps.ncc;
+    bool step_ok = false;
+    if (want_normal) {
+        const double m0 = L::patch_sum(gn.A00), m1 = L::patch_sum(gn.A01), m2 = L::patch_sum(gn.A02);
+        const double m4 = L::patch_sum(gn.A11), m5 = L::patch_sum(gn.A12), m8 = L::patch_sum(gn.A22);
+        const double b0 = L::patch_sum(gn.B0), b1 = L::patch_sum(gn.B1), b2 = L::patch_sum(gn.B2);
+        const double m3 = m1, m6 = m2, m7 = m5;
+        /* libs/math/matrix_tools.h:392-399 (determinant), :462-476 (inverse) */
+        const double det = m0 * m4 * m8 + m1 * m5 * m6 + m2 * m3 * m7 - m2 * m4 * m6 - m1 * m3 * m8 - m0 * m5 * m7;
+        if (det == 0.0 || !(det == det)) { R.opti = false; return false; }
+        const double i0 = m4 * m8 - m5 * m7, i1 = m2 * m7 - m1 * m8, i2 = m1 * m5 - m2 * m4;
+        const double i3 = m5 * m6 - m3 * m8, i4 = m0 * m8 - m2 * m6, i5 = m2 * m3 - m0 * m5;
+        const double i6 = m3 * m7 - m4 * m6, i7 = m1 * m6 - m0 * m7, i8 = m0 * m4 - m1 * m3;
+        const float X0 = (float)((i0 * b0 + i1 * b1 + i2 * b2) / det);
+        const float X1 = (float)((i3 * b0 + i4 * b1 + i5 * b2) / det);
+        const float X2 = (float)((i6 * b0 + i7 * b1 + i8 * b2) / det);
+        step_ok = set_state(ps, rays, ps.depth + X0, ps.dzI + X1, ps.dzJ + X2);
+        R.viewRemoved = false;
+        R.step_was_normal = true;
+    } else {
+        /* optimizeDepthOnly (:265-299) from the colour-scale independent sums */
+        float num = 0.f, den = 0.f;
+        if (active && okv && R.need == PASS_DEPTH_FIXED) { num = gn.num; den = gn.den; }
+        else if (active && okv) {
+            num = ps.cs0 * (gn.dr0 - (ps.cs0 - gn.c00) * gn.dn0) + ps.cs1 * (gn.dr1 - (ps.cs1 - gn.c01) * gn.dn1)
+                + ps.cs2 * (gn.dr2 - (ps.cs2 - gn.c02) * gn.dn2);
+            den = ps.cs0 * ps.cs0 * gn.dd0 + ps.cs1 * ps.cs1 * gn.dd1 + ps.cs2 * ps.cs2 * gn.dd2;
+        }
+        num = L::patch_sum(num); den = L::patch_sum(den);
+        if (den > 0.f) step_ok = set_state(ps, rays, ps.depth + fast_div(num, den), ps.dzI, ps.dzJ);
+        else step_ok = first4;                     /* the first four iterations tolerate denom <= 0 (:177-180) */
+        R.step_was_normal = false;
+    }
+    if (!step_ok) { R.opti = false; return false; }
+    /* the colour scale only changes right after a normal step (and in the ctor): every other pass can
+     * bake it in, which leaves 7 instead of 21 values to reduce across the view slot */
+    if (first4) {
+        ++R.iter;
+        R.need = (R.iter >= 4 && R.iter % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED;
+        R.ctx = CTX_FIRST4;
+        R.count_color = (R.iter == 4);             /* the reference first asks for NCCs when the main loop starts */
+    } else {
+        /* after a normal step computeColorScale follows: that pass must carry per-channel colour sums */
+        R.need = R.step_was_normal ? PASS_DEPTH : (((R.iter + 1) % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED);
+        R.ctx = CTX_STEP;
+        R.count_color = true;
+    }
+    return true;
+}
+
+template <int LPV>
+__device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane, PatchResult& res,
+                                        unsigned& n_eval, unsigned& n_pass) {
+    typedef Lay<LPV> L;
+    PatchState& ps = R.ps;
+    const float* rays = g_rays[L::patch(lane)];
     n_eval += ps.n_eval; n_pass += ps.n_pass;
-    res.iters = iter;
+    res.conf = 0.f; res.nx = res.ny = res.nz = 0.f;
+    res.iters = R.iter;
     res.depth = ps.depth; res.dzI = ps.dzI; res.dzJ = ps.dzJ;
     /* local view ids, ascending (std::set order) */
     int s[4];
@@ -943,36 +982,46 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         for (int k = 0; k < 4; ++k) packed |= (t[k] < 0 ? MI_VIEW_NONE : (unsigned)t[k]) << (8 * k);
         res.views = packed;
     }
-    if (!converged) return;
+    if (!R.converged) return;
     /* --- computeConfidence (patch_optimization.cc:114-142): NCCs summed in ascending view order */
-    {
-        float c[4];
-        const int ni = __float_as_int(ps.ncc);
-        c[0] = __int_as_float(L::template from_view<0>(ni)); c[1] = __int_as_float(L::template from_view<1>(ni));
-        c[2] = __int_as_float(L::template from_view<2>(ni)); c[3] = __int_as_float(L::template from_view<3>(ni));
-        float mean = 0.f; int cnt = 0;
-        unsigned used = 0;
+    float c[4];
+    const int ni = __float_as_int(ps.ncc);
+    c[0] = __int_as_float(L::template from_view<0>(ni)); c[1] = __int_as_float(L::template from_view<1>(ni));
+    c[2] = __int_as_float(L::template from_view<2>(ni)); c[3] = __int_as_float(L::template from_view<3>(ni));
+    float mean = 0.f; int cnt = 0;
+    unsigned used = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int bi = -1;
+    for (int r = 0; r < 4; ++r) {
+        int bi = -1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (s[k] >= 0 && !((used >> k) & 1u) && (bi < 0 || s[k] < s[bi])) bi = k;
-            if (bi >= 0) { used |= 1u << bi; mean += c[bi]; ++cnt; }
-        }
-        mean /= (float)cnt;
-        const float score = (mean - st.acceptNCC) / (1.f - st.acceptNCC);
-        /* getPatchNormal (patch_sampler.cc:242-256): samples 14,10 (right,left) and 2,22 (top,bottom) */
-        const float tr = ps.depth + 2.f * ps.dzI, tl = ps.depth - 2.f * ps.dzI;
-        const float tt = ps.depth - 2.f * ps.dzJ, tb = ps.depth + 2.f * ps.dzJ;
-        const float ax = tr * rays[42] - tl * rays[30], ay = tr * rays[43] - tl * rays[31], az = tr * rays[44] - tl * rays[32];
-        const float bx = tt * rays[6] - tb * rays[66], by = tt * rays[7] - tb * rays[67], bz = tt * rays[8] - tb * rays[68];
-        float nx, ny, nz;
-        unit_cross(ax, ay, az, bx, by, bz, nx, ny, nz);
-        res.nx = nx; res.ny = ny; res.nz = nz;
-        const float dotP = -(nx * rays[36] + ny * rays[37] + nz * rays[38]);   /* viewRayScaled(midx, midy) = ray 12 */
-        res.conf = (dotP < 0.2f) ? 0.f : score;
+        for (int k = 0; k < 4; ++k)
+            if (s[k] >= 0 && !((used >> k) & 1u) && (bi < 0 || s[k] < s[bi])) bi = k;
+        if (bi >= 0) { used |= 1u << bi; mean += c[bi]; ++cnt; }
     }
+    mean /= (float)cnt;
+    const float score = (mean - st.acceptNCC) / (1.f - st.acceptNCC);
+    /* getPatchNormal (patch_sampler.cc:242-256): samples 14,10 (right,left) and 2,22 (top,bottom) */
+    const float tr = ps.depth + 2.f * ps.dzI, tl = ps.depth - 2.f * ps.dzI;
+    const float tt = ps.depth - 2.f * ps.dzJ, tb = ps.depth + 2.f * ps.dzJ;
+    const float ax = tr * rays[42] - tl * rays[30], ay = tr * rays[43] - tl * rays[31], az = tr * rays[44] - tl * rays[32];
+    const float bx = tt * rays[6] - tb * rays[66], by = tt * rays[7] - tb * rays[67], bz = tt * rays[8] - tb * rays[68];
+    float nx, ny, nz;
+    unit_cross(ax, ay, az, bx, by, bz, nx, ny, nz);
+    res.nx = nx; res.ny = ny; res.nz = nz;
+    const float dotP = -(nx * rays[36] + ny * rays[37] + nz * rays[38]);   /* viewRayScaled(midx, midy) = ray 12 */
+    res.conf = (dotP < 0.2f) ? 0.f : score;
+}
+
+template <int LPV>
+__device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
+                               float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane,
+                               PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err) {
+    Run R;
+    TSTAMP(10);
+    if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err))
+        while (run_turn<LPV>(R, st, views, lane)) { }
+    TSTAMP(40);
+    run_end<LPV>(R, st, lane, res, n_eval, n_pass);
 }
 
 /* ------------------------------------------------------------------------- */
