@@ -37,6 +37,16 @@
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 u32x2_a4 __attribute__((aligned(4)));      /* gfx950 global loads only need dword alignment */
+/* Pointers that are themselves loaded from memory (DevView::img, DevJob maps) have no provable address
+ * space, so hipcc emits flat_load for them -- which also ticks the LDS counter and serialises with the
+ * table lookups.  These typedefs pin them to the global address space (global_load). */
+typedef const __attribute__((address_space(1))) u32x2_a4* gtex2_t;
+typedef const __attribute__((address_space(1))) uint32_t* gtex_t;
+typedef const __attribute__((address_space(1))) float* gf32_t;
+typedef const __attribute__((address_space(1))) int32_t* gi32_t;
+#define GF(p) (*(gf32_t)(p))          /* global-address-space loads of map elements */
+#define GI(p) (*(gi32_t)(p))
+#define GU(p) (*(gtex_t)(p))
 
 #ifdef MI_TIMING
 /* development aid: wave 0 / lane 0 logs shader clock stamps into counters->tstamp[] */
@@ -336,7 +346,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         const float fx = uc - (float)left, fy = vc - (float)top;
         /* the two texels of a row are 8 contiguous bytes (dword aligned): one dwordx2 gather per row */
         const uint32_t* r0 = nv.img + (size_t)top * nv.w + left;
-        const u32x2 ra = *(const u32x2_a4*)r0, rb = *(const u32x2_a4*)(r0 + nv.w);
+        const u32x2 ra = *(gtex2_t)(r0), rb = *(gtex2_t)(r0 + nv.w);
         const uint32_t t00 = ra.x, t10 = ra.y, t01 = rb.x, t11 = rb.y;
         float n[3], dr[3];
 #pragma unroll
@@ -765,7 +775,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;       /* LPV = 16: my sample's raw master colour */
     for (int i = pl; i < MI_NS; i += 4 * LPV) {
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
-        const uint32_t t = rimg[(size_t)(y + dj) * RL.w + (x + di)];
+        const uint32_t t = GU(rimg + (size_t)(y + dj) * RL.w + (x + di));
         raw0 = s_lut[t & 255u]; raw1 = s_lut[(t >> 8) & 255u]; raw2 = s_lut[(t >> 16) & 255u];
         if (LPV == 1) { mcol[3 * i] = raw0; mcol[3 * i + 1] = raw1; mcol[3 * i + 2] = raw2; }
     }
@@ -1047,7 +1057,7 @@ struct OptArgs {
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
  */
 template <int LPV>
-__global__ __launch_bounds__(WAVE, 2) void k_optimize(OptArgs a) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_optimize(OptArgs a) {
     typedef Lay<LPV> L;
     const int lane = threadIdx.x;
 #ifdef MI_TIMING
@@ -1078,7 +1088,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_optimize(OptArgs a) {
         const bool explicit_hyp = a.hyp != nullptr;
         const int W = job->w;
         const int pix = y * W + x;
-        float best = explicit_hyp ? 0.f : job->conf[pix];
+        float best = explicit_hyp ? 0.f : GF(job->conf + pix);
         const float own = best;
         unsigned tried = 0;
         for (int t = 0; t < 4; ++t) {
@@ -1093,15 +1103,15 @@ __global__ __launch_bounds__(WAVE, 2) void k_optimize(OptArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if ((tried >> k) & 1u) continue;
-                    const float c = job->conf[nb[k]];
-                    const bool use = job->upd[nb[k]] == a.round - 1 && (own < c - 0.05f || own == 0.f);
+                    const float c = GF(job->conf + nb[k]);
+                    const bool use = GI(job->upd + nb[k]) == a.round - 1 && (own < c - 0.05f || own == 0.f);
                     if (use && (bi < 0 || c > bc)) { bi = k; bc = c; }
                 }
                 if (bi < 0) break;
                 tried |= 1u << bi;
                 if (best > bc) continue;                           /* dmrecon.cc:371 */
                 const int p = nb[bi];
-                hd = job->depth[p]; hi = job->dz[2 * p]; hj = job->dz[2 * p + 1]; hv = job->views[p];
+                hd = GF(job->depth + p); hi = GF(job->dz + 2 * p); hj = GF(job->dz + 2 * p + 1); hv = GU(job->views + p);
             }
             PatchResult r;
             TSTAMP(3);
