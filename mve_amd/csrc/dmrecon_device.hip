@@ -207,22 +207,25 @@ struct PatchState {
 };
 
 struct NView {                   /* my neighbour view at the selected mip level */
-    float m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11;
-    float ax, ay, cx, cy;
+    float m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11;   /* K.[R|t]: rows 0,1 pre-multiplied by the level's K */
     int w, h;
     const uint32_t* img;
 };
 
 __device__ __forceinline__ void project(const NView& nv, float px, float py, float pz, float& u, float& v) {
-    /* SingleView::worldToScreen, single_view.h:187-195 */
-    float cx_ = nv.m0 * px + nv.m1 * py + nv.m2 * pz + nv.m3;
-    float cy_ = nv.m4 * px + nv.m5 * py + nv.m6 * pz + nv.m7;
-    float cz_ = nv.m8 * px + nv.m9 * py + nv.m10 * pz + nv.m11;
-    float sx = nv.ax * cx_ + nv.cx * cz_;
-    float sy = nv.ay * cy_ + nv.cy * cz_;
+    /* SingleView::worldToScreen (single_view.h:187-195) with K.[R|t] pre-multiplied (rows 0, 1 of NView) */
+    const float sx = nv.m0 * px + nv.m1 * py + nv.m2 * pz + nv.m3;
+    const float sy = nv.m4 * px + nv.m5 * py + nv.m6 * pz + nv.m7;
+    const float cz_ = nv.m8 * px + nv.m9 * py + nv.m10 * pz + nv.m11;
     const float iz = fast_rcp(cz_);
     u = sx * iz - 0.5f;
     v = sy * iz - 0.5f;
+}
+
+/* fold the level's calibration into the first two rows of [R|t]: x' = ax.x + cx.z, y' = ay.y + cy.z */
+__device__ __forceinline__ void premultiply(NView& nv, float ax, float ay, float cx, float cy) {
+    nv.m0 = ax * nv.m0 + cx * nv.m8; nv.m1 = ax * nv.m1 + cx * nv.m9; nv.m2 = ax * nv.m2 + cx * nv.m10; nv.m3 = ax * nv.m3 + cx * nv.m11;
+    nv.m4 = ay * nv.m4 + cy * nv.m8; nv.m5 = ay * nv.m5 + cy * nv.m9; nv.m6 = ay * nv.m6 + cy * nv.m10; nv.m7 = ay * nv.m7 + cy * nv.m11;
 }
 
 /* mip level rule of patch_sampler.cc:72-91 / :353-373.  Returns false if nfp <= 0. */
@@ -242,7 +245,7 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, in
     mm = mm > maxl ? maxl : mm;
     level = mm;
     const DevLevel& L = V->lv[mm];
-    nv.ax = L.ax; nv.ay = L.ay; nv.cx = L.cx; nv.cy = L.cy;
+    premultiply(nv, L.ax, L.ay, L.cx, L.cy);
     nv.w = L.w; nv.h = L.h;
     nv.img = V->img + L.tex_off;
     return true;
@@ -339,9 +342,8 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             gu = u1 - u; gv = v1 - v;
         }
         /* memory-safe even when the sample is outside (result discarded through ok) */
-        float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
-        if (!(uc == uc)) uc = 0.f;
-        if (!(vc == vc)) vc = 0.f;
+        /* (fmaxf/fminf return the non-NaN operand, so a NaN coordinate clamps to 0 as well) */
+        const float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
         const int left = (int)floorf(uc), top = (int)floorf(vc);
         const float fx = uc - (float)left, fy = vc - (float)top;
         /* the two texels of a row are 8 contiguous bytes (dword aligned): one dwordx2 gather per row */
@@ -362,7 +364,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
                 dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) * dnorm;
             }
         }
-        const float wgt = live ? 1.f : 0.f;            /* dead trips contribute nothing */
+        const float wgt = (LPV == 1 || live) ? 1.f : 0.f;   /* dead trips (LPV = 16 only) contribute nothing */
         const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
         if (MODE == PASS_DUMP) {
             dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
@@ -673,7 +675,7 @@ __device__ __forceinline__ bool setup_view_cached(const DevView* __restrict__ vi
     }
     nv.m0 = vc[VC_M + 0]; nv.m1 = vc[VC_M + 1]; nv.m2 = vc[VC_M + 2]; nv.m3 = vc[VC_M + 3];
     nv.m4 = vc[VC_M + 4]; nv.m5 = vc[VC_M + 5]; nv.m6 = vc[VC_M + 6]; nv.m7 = vc[VC_M + 7];
-    nv.ax = vc[VC_AX]; nv.ay = vc[VC_AY]; nv.cx = vc[VC_CX]; nv.cy = vc[VC_CY];
+    premultiply(nv, vc[VC_AX], vc[VC_AY], vc[VC_CX], vc[VC_CY]);
     nv.w = __float_as_int(vc[VC_W]); nv.h = __float_as_int(vc[VC_H]);
     const unsigned long long img = ((unsigned long long)(unsigned)__float_as_int(vc[VC_IMG_HI]) << 32)
                                  | (unsigned long long)(unsigned)__float_as_int(vc[VC_IMG_LO]);

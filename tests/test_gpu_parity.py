@@ -6,7 +6,9 @@ Stated tolerances (the noise floor of the reference against itself
 queue order is median 3.5e-4 / p99 2.3e-3 relative depth, fill IoU 0.9999):
 
   patch level (same hypothesis, same view set)
-      sampled colours abs <= 1e-5, derivatives abs <= 1e-4 * max|deriv|, NCC abs <= 1e-4
+      sampled colours abs <= 3e-5 (a sample position of ~150 px carries ~2 ulp = 3e-5 px of float
+      rounding in either implementation, times a colour gradient of <1 per pixel),
+      derivatives abs <= 1e-4 * max|deriv|, NCC abs <= 1e-4
       full doAutoOptimization: relative depth <= 1e-3 and |conf| <= 5e-3 on >= 99 % of patches,
       identical local view set on >= 98 %
   map level (parallel sweep vs sequential priority queue)
@@ -96,7 +98,7 @@ def test_patch_sampler_vs_reference_vectors(ctx_g1, g1):
         if not okv.any():
             continue
         assert np.abs(e["ncc"][okv] - g1["ev_ncc"][i][okv]).max() <= 1e-4
-        assert np.abs(e["col"][okv] - g1["ev_col"][i][okv]).max() <= 1e-5
+        assert np.abs(e["col"][okv] - g1["ev_col"][i][okv]).max() <= 3e-5
         dref = g1["ev_der"][i][okv]
         assert np.abs(e["deriv"][okv] - dref).max() <= 1e-4 * max(np.abs(dref).max(), 1.0)
         n_checked += int(okv.sum())
