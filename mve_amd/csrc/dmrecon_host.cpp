@@ -780,7 +780,9 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
      * Phase B: the long tail of small rounds is enqueued blind in chunks -- the kernels read the
      *          round's list size from device memory -- with the latency layout (one patch per
      *          wavefront), so a round costs a few tens of microseconds instead of a host round trip. */
-    const unsigned TAIL_THRESHOLD = 12288, TAIL_GRID = 3072, TAIL_CHUNK = 32;
+    unsigned TAIL_THRESHOLD = 12288;
+    if (const char* e = std::getenv("MI_DMRECON_TAIL_THRESHOLD")) TAIL_THRESHOLD = (unsigned)std::atoi(e);
+    const unsigned TAIL_GRID = 3072, TAIL_CHUNK = 32;
     int round = 1;
     const int max_rounds = std::min<int>(MI_MAX_ROUNDS - TAIL_CHUNK - 2, 4 * (max_px > 0 ? (int)std::sqrt((double)max_px) * 4 : 1) + 64);
     DevCounters hc;
