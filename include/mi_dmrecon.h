@@ -175,6 +175,31 @@ int  mi_dmrecon_patch_eval(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, i
                            int32_t x, int32_t y, float depth, float dzI, float dzJ,
                            float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
 
+/* ---- next stage downstream: depth map -> oriented point set ------------------------------- */
+
+/* Options of apps/scene2pset (scene2pset.cc:44-63 AppSettings, :262-356). */
+typedef struct mi_dmrecon_pointset_options {
+    float   dd_factor;        /* 5.0  depth-discontinuity factor of depthmap_triangulate (depthmap.cc:323,372) */
+    float   scale_factor;     /* 2.5  "--scale-factor" (scene2pset.cc:58, :355) */
+    int32_t conf_iterations;  /* 4    depthmap_mesh_confidences(mesh, 4) (scene2pset.cc:329) */
+} mi_dmrecon_pointset_options;
+
+/* The per-view body of apps/scene2pset (scene2pset.cc:262-356) for one depth map: triangulate the depth map
+ * (mve::geom::depthmap_triangulate, libs/mve/depthmap.cc:210-399), compute angle-weighted vertex normals
+ * (TriangleMesh::recalc_normals, libs/mve/mesh.cc:25-160), border-distance confidences
+ * (depthmap_mesh_confidences, depthmap.cc:497-546) and per-vertex scale (scene2pset.cc:343-356), and return the
+ * vertices.  depth: w*h floats (0 = no depth); color: w*h*color_channels bytes (1 or 3 channels) or NULL;
+ * cam: the view's camera (the intrinsics are applied to w x h, i.e. w,h may be a pyramid level).
+ * Outputs (each may be NULL) hold `capacity` entries; a vertex's record is pixel (y*w+x), pos[3] (world),
+ * normal[3], color[3] (0..1), scale, conf.  Order: ascending pixel index (the reference numbers vertices by first
+ * use while scanning 2x2 blocks; as a set the output is the same).  *n_out = number of vertices found (also when
+ * > capacity, in which case only `capacity` are written).  opt == NULL: the defaults above. */
+int  mi_dmrecon_pointset(mi_dmrecon_ctx* ctx, const mi_dmrecon_camera* cam, int32_t w, int32_t h,
+                         const float* depth, const uint8_t* color, int32_t color_channels,
+                         const mi_dmrecon_pointset_options* opt, int32_t capacity,
+                         int32_t* pixel, float* pos, float* normal, float* color_out, float* scale, float* conf,
+                         int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

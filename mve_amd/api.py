@@ -34,7 +34,7 @@ EXPORTS = [
     "mi_dmrecon_set_view", "mi_dmrecon_set_view_async", "mi_dmrecon_sync", "mi_dmrecon_evict_view", "mi_dmrecon_set_features",
     "mi_dmrecon_num_levels", "mi_dmrecon_level_size", "mi_dmrecon_get_level",
     "mi_dmrecon_global_view_selection", "mi_dmrecon_reconstruct",
-    "mi_dmrecon_patch_optimize", "mi_dmrecon_patch_eval",
+    "mi_dmrecon_patch_optimize", "mi_dmrecon_patch_eval", "mi_dmrecon_pointset",
 ]
 
 
@@ -49,6 +49,10 @@ class CSettings(ctypes.Structure):
                 ("maxIterations", ctypes.c_int32), ("nrReconNeighbors", ctypes.c_int32),
                 ("globalVSMax", ctypes.c_int32), ("scale", ctypes.c_int32), ("useColorScale", ctypes.c_int32),
                 ("aabbMin", ctypes.c_float * 3), ("aabbMax", ctypes.c_float * 3)]
+
+
+class CPointsetOptions(ctypes.Structure):
+    _fields_ = [("dd_factor", ctypes.c_float), ("scale_factor", ctypes.c_float), ("conf_iterations", ctypes.c_int32)]
 
 
 class CProgress(ctypes.Structure):
@@ -109,6 +113,9 @@ def load_library() -> ctypes.CDLL:
     L.mi_dmrecon_patch_optimize.argtypes = [vp, ctypes.POINTER(CSettings), i32, i32, vp, vp, vp, vp, vp]
     L.mi_dmrecon_patch_eval.argtypes = [vp, ctypes.POINTER(CSettings), i32, i32, i32, f32, f32, f32,
                                         vp, vp, vp, vp, vp, vp]
+    L.mi_dmrecon_pointset.argtypes = [vp, ctypes.POINTER(CCamera), i32, i32, vp, vp, i32,
+                                      ctypes.POINTER(CPointsetOptions), i32, vp, vp, vp, vp, vp, vp,
+                                      ctypes.POINTER(i32)]
     _lib = L
     return L
 
@@ -388,6 +395,38 @@ class Context:
         if n < 0:
             _raise(n)
         return dict(master=master, ncc=ncc[:n], ok=ok[:n], col=col[:n], deriv=der[:n], level=lvl[:n])
+
+    def pointset(self, cam, depth: np.ndarray, color: Optional[np.ndarray] = None, dd_factor: float = 5.0,
+                 scale_factor: float = 2.5, conf_iterations: int = 4):
+        """apps/scene2pset per-view body (scene2pset.cc:262-356): depth map -> oriented points.
+
+        ``cam`` is a scene_io/synth camera (flen, paspect, ppoint, rot, trans).  Returns a dict of arrays
+        pixel, pos, normal, color, scale, conf in ascending pixel order."""
+        depth = np.ascontiguousarray(depth, np.float32)
+        h, w = depth.shape
+        cc = CCamera()
+        cc.flen = float(cam.flen); cc.paspect = float(cam.paspect)
+        cc.ppoint[:] = [float(v) for v in cam.ppoint]
+        cc.rot[:] = [float(v) for v in np.asarray(cam.rot, np.float32).reshape(9)]
+        cc.trans[:] = [float(v) for v in np.asarray(cam.trans, np.float32).reshape(3)]
+        nch = 0
+        cptr = None
+        if color is not None:
+            color = np.ascontiguousarray(color, np.uint8).reshape(h, w, -1)
+            nch = color.shape[2]
+            cptr = _ptr(color)
+        opt = CPointsetOptions(dd_factor, scale_factor, conf_iterations)
+        cap = int(np.count_nonzero(depth > 0))
+        out = dict(pixel=np.zeros(cap, np.int32), pos=np.zeros((cap, 3), np.float32),
+                   normal=np.zeros((cap, 3), np.float32), color=np.zeros((cap, 3), np.float32),
+                   scale=np.zeros(cap, np.float32), conf=np.zeros(cap, np.float32))
+        n = ctypes.c_int32(0)
+        rc = self._L.mi_dmrecon_pointset(self._h, ctypes.byref(cc), w, h, _ptr(depth), cptr, nch, ctypes.byref(opt),
+                                         cap, _ptr(out["pixel"]), _ptr(out["pos"]), _ptr(out["normal"]),
+                                         _ptr(out["color"]), _ptr(out["scale"]), _ptr(out["conf"]), ctypes.byref(n))
+        if rc < 0:
+            _raise(rc)
+        return {k: v[:n.value] for k, v in out.items()}
 
 
 class DMRecon:

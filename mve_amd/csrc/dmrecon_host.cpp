@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "dmrecon_device.h"
+#include "pointset_device.h"
 #include "dmrecon_types.h"
 
 namespace {
@@ -1007,6 +1008,64 @@ int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int3
     HIP_TRY(hipStreamSynchronize(c->stream));
     dout.release(); diout.release();
     return G;
+}
+
+/* apps/scene2pset per-view body (scene2pset.cc:262-356); kernels in pointset_device.hip */
+int mi_dmrecon_pointset(mi_dmrecon_ctx* c, const mi_dmrecon_camera* cam, int32_t w, int32_t h, const float* depth,
+                        const uint8_t* color, int32_t color_channels, const mi_dmrecon_pointset_options* opt,
+                        int32_t capacity, int32_t* pixel, float* pos, float* normal, float* color_out, float* scale,
+                        float* conf, int32_t* n_out) {
+    if (!c || !cam || !depth || !n_out) return fail(MI_DMRECON_EINVAL, "pointset: null argument");
+    if (w < 2 || h < 2) { *n_out = 0; return w < 0 || h < 0 ? fail(MI_DMRECON_EINVAL, "pointset: bad size") : 0; }
+    if (color && color_channels != 1 && color_channels != 3) return fail(MI_DMRECON_EINVAL, "pointset: 1 or 3 colour channels");
+    if (capacity < 0) return fail(MI_DMRECON_EINVAL, "pointset: negative capacity");
+    if (cam->flen == 0.f) return fail(MI_DMRECON_EINVAL, "pointset: invalid camera");     /* scene2pset.cc:276 */
+    HIP_TRY(hipSetDevice(c->device));
+    PsParams P;
+    P.w = w; P.h = h;
+    float K[9];
+    calibration(*cam, (float)w, (float)h, K, P.inv);
+    for (int i = 0; i < 3; ++i) {                              /* CameraInfo::fill_cam_to_world, camera.cc:83-93 */
+        for (int j = 0; j < 3; ++j) P.ctw[4 * i + j] = cam->rot[3 * j + i];
+        P.ctw[4 * i + 3] = -((cam->rot[i] * cam->trans[0] + cam->rot[3 + i] * cam->trans[1]) + cam->rot[6 + i] * cam->trans[2]);
+    }
+    P.dd_factor = opt ? opt->dd_factor : 5.0f;
+    P.scale_factor = opt ? opt->scale_factor : 2.5f;
+    P.conf_iterations = opt ? opt->conf_iterations : 4;
+    if (P.conf_iterations < 1) return fail(MI_DMRECON_EINVAL, "pointset: conf_iterations < 1");
+    const size_t npix = (size_t)w * h;
+    struct Tmp {                                               /* freed on every return path */
+        DevBuf<float> depth; DevBuf<uint8_t> cells; DevBuf<PsVertex> verts;
+        ~Tmp() { depth.release(); cells.release(); verts.release(); }
+    } tmp;
+    DevBuf<float>& d_depth = tmp.depth; DevBuf<uint8_t>& d_cells = tmp.cells; DevBuf<PsVertex>& d_verts = tmp.verts;
+    if (d_depth.reserve(npix) || d_cells.reserve(npix) || d_verts.reserve(npix)) return fail(MI_DMRECON_EDEVICE, "hipMalloc failed");
+    HIP_TRY(hipMemcpyAsync(d_depth.p, depth, npix * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    mi_ps_launch(c->stream, P, d_depth.p, d_cells.p, d_verts.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<PsVertex> hv(npix);
+    HIP_TRY(hipMemcpyAsync(hv.data(), d_verts.p, npix * sizeof(PsVertex), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int32_t n = 0;
+    const float inv_it = (float)P.conf_iterations;
+    for (size_t i = 0; i < npix; ++i) {
+        PsVertex const& v = hv[i];
+        if (!v.used) continue;
+        if (n < capacity) {
+            if (pixel) pixel[n] = (int32_t)i;
+            if (pos) { pos[3 * n] = v.pos[0]; pos[3 * n + 1] = v.pos[1]; pos[3 * n + 2] = v.pos[2]; }
+            if (normal) { normal[3 * n] = v.nrm[0]; normal[3 * n + 1] = v.nrm[1]; normal[3 * n + 2] = v.nrm[2]; }
+            if (scale) scale[n] = v.scale;
+            if (conf) conf[n] = v.level < 0 ? 1.0f : (float)v.level / inv_it;
+            if (color_out) {                                      /* depthmap.cc:299-307: bytes / 255 */
+                for (int k = 0; k < 3; ++k)
+                    color_out[3 * n + k] = color ? (float)color[i * color_channels + (color_channels == 3 ? k : 0)] / 255.0f : 0.f;
+            }
+        }
+        ++n;
+    }
+    *n_out = n;
+    return 0;
 }
 
 /* development aid (not in the public header): allocate / fetch the MI_TIMING stamp buffer */
