@@ -48,6 +48,19 @@ def algorithmic_bytes(stats, n_maps, scene, cfg):
     return 300.0 * stats["n_eval"] + 75.0 * stats["n_patch"] + 28.0 * stats["n_filled"] + comp * n_maps
 
 
+def measured_traffic():
+    """HBM-side bytes per k_optimize launch from the committed PMC passes (tools/collect_profiles.sh ->
+    tools/summarize_profiles.py -> profiles/*_traffic.json); None when no profile is present.  PMC counters
+    cannot be read from inside the timed run, so this is the latest profiled value of the same command."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")),
+                   key=os.path.getmtime)
+    if not files:
+        return None, None
+    j = json.load(open(files[-1]))
+    return float(j["bytes_per_launch"]), os.path.basename(files[-1])
+
+
 def cpu_baseline(scene, cfg, seconds_hint=20.0):
     """The reference CPU path timed on this box's host cores on a bounded sample of the same workload."""
     cores = os.cpu_count() or 1
@@ -97,6 +110,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="host threads per GPU, each driving its own forked context / HIP stream; steps are "
                          "dealt round-robin (the reference runs its views under an OpenMP loop the same way)")
+    ap.add_argument("--steps-per-call", type=int, default=1,
+                    help="steps (passes over the 20 views) handed to ONE mi_dmrecon_reconstruct batch; the propagation "
+                         "tail costs the same ~600 latency-bound rounds per batch whatever its size")
     args = ap.parse_args()
     rank, world, local_rank = rank_world()
     if world != args.gpus:
@@ -114,7 +130,12 @@ def main():
 
     # one forked context (own HIP stream + scratch, shared resident scene) per host thread; the long,
     # latency-bound tail of one step's propagation overlaps the throughput-bound start of another's
-    n_streams = max(1, min(args.streams, args.steps))
+    spc = max(1, min(args.steps_per_call, args.steps))
+    n_calls = (args.steps + spc - 1) // spc
+    if n_calls * spc != args.steps:
+        raise SystemExit("--steps must be a multiple of --steps-per-call")
+    n_streams = max(1, min(args.streams, n_calls))
+    refs = refs * spc
     ctxs = [ctx] + [ctx.fork() for _ in range(n_streams - 1)]
     outs = [c.alloc_outputs(st, refs, want_normal=False, pinned=True) for c in ctxs]   # reused, page-locked
     for c, o in zip(ctxs, outs):
@@ -132,7 +153,7 @@ def main():
                 for k, v in c.last_stats.items():
                     acc[k] = acc.get(k, 0) + v
 
-    share = [args.steps // n_streams + (1 if i < args.steps % n_streams else 0) for i in range(n_streams)]
+    share = [n_calls // n_streams + (1 if i < n_calls % n_streams else 0) for i in range(n_streams)]
     threads = [threading.Thread(target=worker, args=(c, o, n)) for c, o, n in zip(ctxs, outs, share)]
     coll.barrier()
     t0 = time.perf_counter()
@@ -143,7 +164,7 @@ def main():
     coll.barrier()
     elapsed = coll.max(time.perf_counter() - t0)
     res = last["res"]
-    n_maps_rank = len(refs) * args.steps
+    n_maps_rank = len(refs) * n_calls
     n_maps = int(round(coll.sum(n_maps_rank)))
 
     if rank == 0:
@@ -152,6 +173,7 @@ def main():
         opt_s = acc["ms_opt_kernel"] / 1000.0
         n_launch = max(int(acc["n_launches"]), 1)
         achieved = b_alg / opt_s / 1e9 if opt_s > 0 else 0.0
+        traffic, traffic_src = measured_traffic()
         out = {
             "metric": "depth-maps/sec (1920x1080, 20 views, scale=2)" if args.config == "C3" else "depth-maps/sec (%s)" % args.config,
             "value": n_maps / elapsed, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +187,7 @@ def main():
                        "host_threads_per_gpu": n_streams,
                        "mean_fill": round(fill, 4)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_optimize", "launches": n_launch,
                          "avg_launch_ms": acc["ms_opt_kernel"] / n_launch,
                          "algorithmic_bytes_per_launch": b_alg / n_launch,
