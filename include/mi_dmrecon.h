@@ -97,8 +97,11 @@ typedef struct mi_dmrecon_stats {
     int64_t n_rounds;       /* propagation sweeps */
     int64_t n_launches;     /* launches of the optimisation kernel */
     double  ms_total;       /* wall time of the call, host clock */
-    double  ms_opt_kernel;  /* sum of hipEvent durations of the optimisation kernel */
-    double  ms_sweep_kernels; /* sum of hipEvent durations of the generate/apply kernels */
+    double  ms_opt_kernel;  /* hipEvent durations of the optimisation kernel on the context's stream, summed: every
+                             * launch of the host-visible rounds; in the blind tail every 8th round is bracketed by
+                             * events (an event pair costs ~12 us of queue time per round) and their mean is
+                             * multiplied by the number of tail launches that had work */
+    double  ms_sweep_kernels; /* sum of hipEvent durations of the timed generate/apply kernels */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);

@@ -321,82 +321,100 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     constexpr bool PER_CHANNEL = (MODE == PASS_COLOR || MODE == PASS_DEPTH);
 
     constexpr int NITER = (LPV == 1) ? MI_NS : (MI_NS + LPV - 1) / LPV;
-    constexpr int NITER_UNROLL = (LPV == 1) ? 1 : NITER;
-#pragma unroll NITER_UNROLL
-    for (int it = 0; it < NITER; ++it) {
-        const int iraw = sub + it * LPV;
-        const bool live = iraw < MI_NS;                /* LPV = 16: second trip only for lanes 0..8 */
-        const int i = live ? iraw : (MI_NS - 1);
-        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
-        const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
-        const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;      /* computePatchPoints */
-        const float px = cpx + t * rx, py = cpy + t * ry, pz = cpz + t * rz;
-        float u, v;
-        project(nv, px, py, pz, u, v);
-        /* strict interior test (patch_sampler.cc:116-119, :386-389) */
-        ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
-        float gu = 0.f, gv = 0.f;
-        if (MODE != PASS_COLOR) {
-            float u1, v1;
-            project(nv, px + rx * step, py + ry * step, pz + rz * step, u1, v1);
-            gu = u1 - u; gv = v1 - v;
-        }
-        /* memory-safe even when the sample is outside (result discarded through ok) */
-        /* (fmaxf/fminf return the non-NaN operand, so a NaN coordinate clamps to 0 as well) */
-        const float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
-        const int left = (int)floorf(uc), top = (int)floorf(vc);
-        const float fx = uc - (float)left, fy = vc - (float)top;
-        /* the two texels of a row are 8 contiguous bytes (dword aligned): one dwordx2 gather per row */
-        const uint32_t* r0 = nv.img + (size_t)top * nv.w + left;
-        const u32x2 ra = *(gtex2_t)(r0), rb = *(gtex2_t)(r0 + nv.w);
-        const uint32_t t00 = ra.x, t10 = ra.y, t01 = rb.x, t11 = rb.y;
-        float n[3], dr[3];
+    /* Samples whose texel gathers are in flight together.  The latency layout runs one wavefront per patch with
+     * nothing else to hide a gather behind, so all of a lane's samples (2) are addressed and loaded before the
+     * first one is consumed: one exposed memory latency per pass instead of two.  The throughput layout keeps one
+     * sample in flight (the other wavefronts of the SIMD hide the latency; registers are the scarce resource). */
+    constexpr int NB = (LPV == 1) ? 1 : NITER;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NITER; it0 += NB) {
+        int si[NB]; bool slive[NB];
+        float sfx[NB], sfy[NB], sgu[NB], sgv[NB];
+        u32x2 sra[NB], srb[NB];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float c00 = s_lut[(t00 >> (8 * c)) & 255u], c10 = s_lut[(t10 >> (8 * c)) & 255u];
-            const float c01 = s_lut[(t01 >> (8 * c)) & 255u], c11 = s_lut[(t11 >> (8 * c)) & 255u];
-            /* mvs_tools.cc:119-128 */
-            const float xa = (1.f - fx) * c00 + fx * c10;
-            const float xb = (1.f - fx) * c01 + fx * c11;
-            n[c] = (1.f - fy) * xa + fy * xb;
+        for (int b = 0; b < NB; ++b) {
+            const int iraw = sub + (it0 + b) * LPV;
+            const bool live = iraw < MI_NS;                /* LPV = 16: second trip only for lanes 0..8 */
+            const int i = live ? iraw : (MI_NS - 1);
+            const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+            const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
+            const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;      /* computePatchPoints */
+            const float px = cpx + t * rx, py = cpy + t * ry, pz = cpz + t * rz;
+            float u, v;
+            project(nv, px, py, pz, u, v);
+            /* strict interior test (patch_sampler.cc:116-119, :386-389) */
+            ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
+            float gu = 0.f, gv = 0.f;
             if (MODE != PASS_COLOR) {
-                /* exact directional derivative of the bilinear surface, mvs_tools.cc:131-143; /= stepSize */
-                dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) * dnorm;
+                float u1, v1;
+                project(nv, px + rx * step, py + ry * step, pz + rz * step, u1, v1);
+                gu = u1 - u; gv = v1 - v;
             }
+            /* memory-safe even when the sample is outside (result discarded through ok) */
+            /* (fmaxf/fminf return the non-NaN operand, so a NaN coordinate clamps to 0 as well) */
+            const float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
+            const int left = (int)floorf(uc), top = (int)floorf(vc);
+            /* the two texels of a row are 8 contiguous bytes (dword aligned): one dwordx2 gather per row */
+            const uint32_t* r0 = nv.img + (size_t)top * nv.w + left;
+            sra[b] = *(gtex2_t)(r0); srb[b] = *(gtex2_t)(r0 + nv.w);
+            si[b] = i; slive[b] = live;
+            sfx[b] = uc - (float)left; sfy[b] = vc - (float)top; sgu[b] = gu; sgv[b] = gv;
         }
-        const float wgt = (LPV == 1 || live) ? 1.f : 0.f;   /* dead trips (LPV = 16 only) contribute nothing */
-        const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
-        if (MODE == PASS_DUMP) {
-            dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
-            dump_der[3 * i] = dr[0]; dump_der[3 * i + 1] = dr[1]; dump_der[3 * i + 2] = dr[2];
-        } else {
-            const float a0 = (n[0] - S.s0) * wgt, a1 = (n[1] - S.s1) * wgt, a2 = (n[2] - S.s2) * wgt;
-            S.a0 += a0; S.a1 += a1; S.a2 += a2;
-            if (PER_CHANNEL) {
-                S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
-                S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
-            } else {
-                S.aa0 += a0 * a0 + a1 * a1 + a2 * a2;
-                S.ba0 += (m0 - ps.xbar0) * a0 + (m1 - ps.xbar1) * a1 + (m2 - ps.xbar2) * a2;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = si[b];
+            const bool live = slive[b];
+            const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+            const float fx = sfx[b], fy = sfy[b], gu = sgu[b], gv = sgv[b];
+            const uint32_t t00 = sra[b].x, t10 = sra[b].y, t01 = srb[b].x, t11 = srb[b].y;
+            float n[3], dr[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float c00 = s_lut[(t00 >> (8 * c)) & 255u], c10 = s_lut[(t10 >> (8 * c)) & 255u];
+                const float c01 = s_lut[(t01 >> (8 * c)) & 255u], c11 = s_lut[(t11 >> (8 * c)) & 255u];
+                /* mvs_tools.cc:119-128 */
+                const float xa = (1.f - fx) * c00 + fx * c10;
+                const float xb = (1.f - fx) * c01 + fx * c11;
+                n[c] = (1.f - fy) * xa + fy * xb;
+                if (MODE != PASS_COLOR) {
+                    /* exact directional derivative of the bilinear surface, mvs_tools.cc:131-143; /= stepSize */
+                    dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) * dnorm;
+                }
             }
-            if (MODE == PASS_DEPTH_FIXED) {
-                const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
-                num += wgt * (g0 * (m0 - ps.cs0 * n[0]) + g1 * (m1 - ps.cs1 * n[1]) + g2 * (m2 - ps.cs2 * n[2]));
-                den += wgt * (g0 * g0 + g1 * g1 + g2 * g2);
-            } else if (MODE == PASS_DEPTH) {
-                const float e0 = dr[0] * wgt, e1 = dr[1] * wgt, e2 = dr[2] * wgt;
-                dr0 += e0 * (m0 - ps.cs0 * n[0]); dr1 += e1 * (m1 - ps.cs1 * n[1]); dr2 += e2 * (m2 - ps.cs2 * n[2]);
-                dn0 += e0 * n[0]; dn1 += e1 * n[1]; dn2 += e2 * n[2];
-                dd0 += e0 * dr[0]; dd1 += e1 * dr[1]; dd2 += e2 * dr[2];
-            } else if (MODE == PASS_NORMAL) {
-                const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
-                const float r0_ = m0 - ps.cs0 * n[0], r1_ = m1 - ps.cs1 * n[1], r2_ = m2 - ps.cs2 * n[2];
-                const float gg = (g0 * g0 + g1 * g1 + g2 * g2) * wgt;
-                const float gr = (g0 * r0_ + g1 * r1_ + g2 * r2_) * wgt;
-                const float fi = (float)di, fj = (float)dj;
-                A00 += (acc_t)gg; A01 += (acc_t)(fi * gg); A02 += (acc_t)(fj * gg);
-                A11 += (acc_t)(fi * fi * gg); A12 += (acc_t)(fi * fj * gg); A22 += (acc_t)(fj * fj * gg);
-                B0 += (acc_t)gr; B1 += (acc_t)(fi * gr); B2 += (acc_t)(fj * gr);
+            const float wgt = (LPV == 1 || live) ? 1.f : 0.f;   /* dead trips (LPV = 16 only) contribute nothing */
+            const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
+            if (MODE == PASS_DUMP) {
+                dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
+                dump_der[3 * i] = dr[0]; dump_der[3 * i + 1] = dr[1]; dump_der[3 * i + 2] = dr[2];
+            } else {
+                const float a0 = (n[0] - S.s0) * wgt, a1 = (n[1] - S.s1) * wgt, a2 = (n[2] - S.s2) * wgt;
+                S.a0 += a0; S.a1 += a1; S.a2 += a2;
+                if (PER_CHANNEL) {
+                    S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
+                    S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
+                } else {
+                    S.aa0 += a0 * a0 + a1 * a1 + a2 * a2;
+                    S.ba0 += (m0 - ps.xbar0) * a0 + (m1 - ps.xbar1) * a1 + (m2 - ps.xbar2) * a2;
+                }
+                if (MODE == PASS_DEPTH_FIXED) {
+                    const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
+                    num += wgt * (g0 * (m0 - ps.cs0 * n[0]) + g1 * (m1 - ps.cs1 * n[1]) + g2 * (m2 - ps.cs2 * n[2]));
+                    den += wgt * (g0 * g0 + g1 * g1 + g2 * g2);
+                } else if (MODE == PASS_DEPTH) {
+                    const float e0 = dr[0] * wgt, e1 = dr[1] * wgt, e2 = dr[2] * wgt;
+                    dr0 += e0 * (m0 - ps.cs0 * n[0]); dr1 += e1 * (m1 - ps.cs1 * n[1]); dr2 += e2 * (m2 - ps.cs2 * n[2]);
+                    dn0 += e0 * n[0]; dn1 += e1 * n[1]; dn2 += e2 * n[2];
+                    dd0 += e0 * dr[0]; dd1 += e1 * dr[1]; dd2 += e2 * dr[2];
+                } else if (MODE == PASS_NORMAL) {
+                    const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
+                    const float r0_ = m0 - ps.cs0 * n[0], r1_ = m1 - ps.cs1 * n[1], r2_ = m2 - ps.cs2 * n[2];
+                    const float gg = (g0 * g0 + g1 * g1 + g2 * g2) * wgt;
+                    const float gr = (g0 * r0_ + g1 * r1_ + g2 * r2_) * wgt;
+                    const float fi = (float)di, fj = (float)dj;
+                    A00 += (acc_t)gg; A01 += (acc_t)(fi * gg); A02 += (acc_t)(fj * gg);
+                    A11 += (acc_t)(fi * fi * gg); A12 += (acc_t)(fi * fj * gg); A22 += (acc_t)(fj * fj * gg);
+                    B0 += (acc_t)gr; B1 += (acc_t)(fi * gr); B2 += (acc_t)(fj * gr);
+                }
             }
         }
     }

@@ -749,13 +749,18 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     };
     size_t n_ev = 0;
     std::vector<std::pair<size_t, int> > ev_kind;     /* (start event index, kind) kind 0 = optimise, 1 = sweep */
-    std::vector<unsigned> ev_work;                    /* work-list size of each optimise launch (trace only) */
+    std::vector<unsigned> ev_work;                    /* work-list size of each timed optimise launch */
+    std::vector<char> ev_tail;                        /* ... and whether it belongs to phase B */
     const bool trace = std::getenv("MI_DMRECON_TRACE") != nullptr;
+    /* An event record costs ~6 us of queue time on either side of the kernel it brackets -- more than a tenth of a
+     * tail round.  Phase B therefore times every TAIL_TIMED_EVERY-th round only (all of them when tracing); the
+     * tail launches are uniform (one dependent patch chain each), their mean stands in for the untimed ones. */
+    const unsigned TAIL_TIMED_EVERY = trace ? 1u : 8u;
     auto ev_begin = [&](int kind) { hipEvent_t e = get_event(n_ev); if (e) (void)hipEventRecord(e, c->stream); ev_kind.push_back(std::make_pair(n_ev, kind)); n_ev += 2; };
     auto ev_end = [&]() { hipEvent_t e = get_event(ev_kind.back().first + 1); if (e) (void)hipEventRecord(e, c->stream); };
 
     mark("setup + uploads (async)");
-    int64_t n_launch = 0;
+    int64_t n_launch = 0, n_tail_launch = 0;
     if (c->d_round_work.reserve(MI_MAX_ROUNDS)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(round counters) failed");
     HIP_TRY(hipMemsetAsync(c->d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), c->stream));
     if (!seeds.empty()) {
@@ -763,7 +768,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), c->stream));
-        ev_begin(0); ev_work.push_back((unsigned)seeds.size());
+        ev_begin(0); ev_work.push_back((unsigned)seeds.size()); ev_tail.push_back(0);
         mi_launch_optimize(c->stream, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
                            c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
                            nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0, c->d_counters);
@@ -804,7 +809,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         if (n_work == 0) { done = true; break; }
         if (cancelled()) { was_cancelled = true; break; }
         const bool tail = n_work < TAIL_THRESHOLD;
-        ev_begin(0); ev_work.push_back(n_work);
+        ev_begin(0); ev_work.push_back(n_work); ev_tail.push_back(0);
         if (tail)
             mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters);
@@ -825,13 +830,15 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     DevEntry* wnext = c->d_work2.p;
     while (!done && !was_cancelled && round < max_rounds) {
         const int first = round;
+        const size_t ev_first = ev_work.size();
         for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
+            const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
             mi_launch_expand(c->stream, 64, c->d_jobs.p, wcur, c->d_results.p, c->d_round_work.p + (round - 1), wnext,
                              c->d_round_work.p, round - 1);
-            ev_begin(0); ev_work.push_back(0u);
+            if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
             mi_launch_optimize(c->stream, 16, TAIL_GRID, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wnext, nullptr,
                                c->d_results.p, c->d_round_work.p + round, 0u, 1u, 0xFFFFFFFFu, round, c->d_counters);
-            ev_end();
+            if (timed) ev_end();
             mi_launch_apply(c->stream, 64, c->d_jobs.p, wnext, c->d_results.p, c->d_round_work.p + round, 0u, round,
                             c->d_counters);
             std::swap(wcur, wnext);
@@ -840,10 +847,10 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (hc.error_flags & 1u) return fail(MI_DMRECON_EFOOTPRINT, "Negative pixel footprint");
+        for (size_t q = ev_first; q < ev_work.size(); ++q) ev_work[q] = rw[ev_work[q]];
         for (unsigned k = 0; k < TAIL_CHUNK; ++k) {
-            ev_work[ev_work.size() - TAIL_CHUNK + k] = rw[k];
             if (rw[k] == 0) { done = true; round = first + (int)k; break; }
-            ++n_launch;
+            ++n_launch; ++n_tail_launch;
         }
         for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = rw[TAIL_CHUNK - 1]; }
         if (cancelled()) was_cancelled = true;
@@ -878,12 +885,18 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         stats->n_patch = (int64_t)hc.n_patch; stats->n_eval = (int64_t)hc.n_eval; stats->n_filled = (int64_t)hc.n_filled;
         stats->n_seeds = (int64_t)n_seed_feats; stats->n_seeds_ok = (int64_t)hc.n_seeds_ok;
         stats->n_rounds = round; stats->n_launches = n_launch;
+        double tail_ms = 0.0; int64_t tail_timed = 0;
+        size_t w = 0;
         for (size_t k = 0; k < ev_kind.size(); ++k) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->events[ev_kind[k].first], c->events[ev_kind[k].first + 1]) == hipSuccess) {
-                if (ev_kind[k].second == 0) stats->ms_opt_kernel += ms; else stats->ms_sweep_kernels += ms;
-            }
+            const bool got = hipEventElapsedTime(&ms, c->events[ev_kind[k].first], c->events[ev_kind[k].first + 1]) == hipSuccess;
+            if (ev_kind[k].second != 0) { if (got) stats->ms_sweep_kernels += ms; continue; }
+            if (!ev_tail[w]) { if (got) stats->ms_opt_kernel += ms; }
+            else if (got && ev_work[w] > 0) { tail_ms += ms; ++tail_timed; }
+            ++w;
         }
+        /* phase B: mean of the timed launches x number of launches that had work */
+        if (tail_timed > 0) stats->ms_opt_kernel += tail_ms / (double)tail_timed * (double)n_tail_launch;
         stats->ms_total = now_ms() - t_begin;
     }
     if (trace) {
