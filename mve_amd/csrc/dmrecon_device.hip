@@ -1073,6 +1073,119 @@ struct OptArgs {
 };
 
 /*
+ * Pixel state as the optimisations of round `round` must see it: frozen at the end of round - 1.
+ * VER = false (host-visible rounds: writes happen in a separate k_apply launch): slot 0 is the state.
+ * VER = true (fused tail rounds): the slot with the larger stamp that is older than `round`.
+ */
+struct PixState { const float* depth; const float* dz; const float* conf; const uint32_t* views; int upd; };
+template <bool VER>
+__device__ __forceinline__ PixState pix_state(const DevJob* job, int p, int round) {
+    PixState s;
+    const int s0 = GI(job->upd + p);
+    if (!VER) { s.depth = job->depth; s.dz = job->dz; s.conf = job->conf; s.views = job->views; s.upd = s0; return s; }
+    const int s1 = GI(job->upd1 + p);
+    const bool one = s0 >= round || (s1 < round && s1 > s0);
+    s.depth = one ? job->depth1 : job->depth; s.dz = one ? job->dz1 : job->dz; s.conf = one ? job->conf1 : job->conf;
+    s.views = one ? job->views1 : job->views; s.upd = one ? s1 : s0;
+    return s;
+}
+
+/*
+ * All optimisation attempts of one work-list entry (pixel x, y of `job`), result into a.results[e].
+ * Explicit mode (seeds, parity hook): the one hypothesis given.  Propagate mode: the queue semantics of
+ * dmrecon.cc:365-392 for the hypotheses pulled from the 4-neighbours that were written last round, best
+ * confidence first.  Nothing but `best` and a 4-bit mask is kept in registers across an optimisation (the
+ * candidates are re-read from the frozen state).  Returns true if the pixel state must be overwritten.
+ */
+template <int LPV, bool VER>
+__device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, const DevJob* job, int x, int y, int lane,
+                                              unsigned& n_eval, unsigned& n_pass, unsigned& n_patch, unsigned& err) {
+    typedef Lay<LPV> L;
+    const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
+    if (writer) {
+        DevResult z;
+        z.conf = 0.f; z.depth = 0.f; z.dzI = z.dzJ = 0.f; z.nx = z.ny = z.nz = 0.f;
+        z.views = 0xFFFFFFFFu; z.iters = 0; z.accepted = 0;
+        a.results[e] = z;
+    }
+    const bool explicit_hyp = a.hyp != nullptr;
+    const int W = job->w;
+    const int pix = y * W + x;
+    float best = 0.f;
+    if (!explicit_hyp) { const PixState me = pix_state<VER>(job, pix, a.round); best = GF(me.conf + pix); }
+    const float own = best;
+    unsigned tried = 0;
+    bool accepted = false;
+    for (int t = 0; t < 4; ++t) {
+        float hd, hi, hj; unsigned hv;
+        if (explicit_hyp) {
+            if (t > 0) break;
+            const DevHyp h = a.hyp[e];
+            hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = h.views;
+        } else {
+            const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+            int bi = -1; float bc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((tried >> k) & 1u) continue;
+                const PixState nbs = pix_state<VER>(job, nb[k], a.round);
+                const float c = GF(nbs.conf + nb[k]);
+                const bool use = nbs.upd == a.round - 1 && (own < c - 0.05f || own == 0.f);
+                if (use && (bi < 0 || c > bc)) { bi = k; bc = c; }
+            }
+            if (bi < 0) break;
+            tried |= 1u << bi;
+            if (best > bc) continue;                           /* dmrecon.cc:371 */
+            const int p = nb[bi];
+            const PixState src = pix_state<VER>(job, p, a.round);
+            hd = GF(src.depth + p); hi = GF(src.dz + 2 * p); hj = GF(src.dz + 2 * p + 1); hv = GU(src.views + p);
+        }
+        PatchResult r;
+        TSTAMP(3);
+        optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
+        TSTAMP(4);
+        ++n_patch;
+        const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
+        if (accept) {
+            best = r.conf;
+            accepted = explicit_hyp ? (r.conf > 0.f) : true;
+            if (writer) {
+                DevResult o;
+                o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ;
+                o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.iters = r.iters;
+                o.accepted = accepted ? 1 : 0;
+                a.results[e] = o;
+            }
+        }
+    }
+    return accepted;
+}
+
+/* flush counters: one atomic per wave (per-view counters live in the first lane of each view slot,
+ * the patch counter in the first lane of each patch) */
+template <int LPV>
+__device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, unsigned n_eval, unsigned n_pass,
+                                               unsigned n_patch, unsigned n_filled, unsigned err) {
+    typedef Lay<LPV> L;
+    if (L::sub(lane) != 0) { n_eval = 0; n_pass = 0; }
+    if (L::vslot(lane) != 0 || L::sub(lane) != 0) { n_patch = 0; n_filled = 0; }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_eval += __shfl_down(n_eval, off);
+        n_pass += __shfl_down(n_pass, off);
+        n_patch += __shfl_down(n_patch, off);
+        n_filled += __shfl_down(n_filled, off);
+        err |= __shfl_down(err, off);
+    }
+    if (lane == 0) {
+        if (n_eval) atomicAdd(&counters->n_eval, (unsigned long long)n_eval);
+        if (n_pass) atomicAdd(&counters->n_pass, (unsigned long long)n_pass);
+        if (n_patch) atomicAdd(&counters->n_patch, (unsigned long long)n_patch);
+        if (n_filled) atomicAdd(&counters->n_filled, (unsigned long long)n_filled);
+        if (err) atomicOr(&counters->error_flags, err);
+    }
+}
+
+/*
  * The hot kernel.  LPV = 1: 16 patches per wavefront (throughput); LPV = 16: one patch per
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
  */
@@ -1092,81 +1205,88 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
     for (unsigned e = blockIdx.x * L::PATCHES + L::patch(lane); e < n; e += gridDim.x * L::PATCHES) {
         const DevEntry ent = a.work[e];
-        const DevJob* job = a.jobs + ent.job;
-        const int x = ent.xy & 0xFFFF, y = ent.xy >> 16;
-        const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
-        if (writer) {
-            DevResult z;
-            z.conf = 0.f; z.depth = 0.f; z.dzI = z.dzJ = 0.f; z.nx = z.ny = z.nz = 0.f;
-            z.views = 0xFFFFFFFFu; z.iters = 0; z.accepted = 0;
-            a.results[e] = z;
-        }
-        /* Hypotheses to try.  Explicit mode (seeds, parity hook): the one given.  Propagate mode:
-         * the queue semantics of dmrecon.cc:365-392 for the hypotheses pulled from the 4-neighbours
-         * that were written last round, best confidence first.  Nothing but `best` and a 4-bit mask is kept
-         * in registers across an optimisation (the candidates are re-read from the frozen state). */
-        const bool explicit_hyp = a.hyp != nullptr;
-        const int W = job->w;
-        const int pix = y * W + x;
-        float best = explicit_hyp ? 0.f : GF(job->conf + pix);
-        const float own = best;
-        unsigned tried = 0;
-        for (int t = 0; t < 4; ++t) {
-            float hd, hi, hj; unsigned hv;
-            if (explicit_hyp) {
-                if (t > 0) break;
-                const DevHyp h = a.hyp[e];
-                hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = h.views;
-            } else {
-                const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
-                int bi = -1; float bc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if ((tried >> k) & 1u) continue;
-                    const float c = GF(job->conf + nb[k]);
-                    const bool use = GI(job->upd + nb[k]) == a.round - 1 && (own < c - 0.05f || own == 0.f);
-                    if (use && (bi < 0 || c > bc)) { bi = k; bc = c; }
-                }
-                if (bi < 0) break;
-                tried |= 1u << bi;
-                if (best > bc) continue;                           /* dmrecon.cc:371 */
-                const int p = nb[bi];
-                hd = GF(job->depth + p); hi = GF(job->dz + 2 * p); hj = GF(job->dz + 2 * p + 1); hv = GU(job->views + p);
-            }
-            PatchResult r;
-            TSTAMP(3);
-            optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
-            TSTAMP(4);
-            ++n_patch;
-            const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
-            if (accept) {
-                best = r.conf;
-                if (writer) {
-                    DevResult o;
-                    o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ;
-                    o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.iters = r.iters;
-                    o.accepted = explicit_hyp ? (r.conf > 0.f) : 1;
-                    a.results[e] = o;
-                }
+        process_entry<LPV, false>(a, e, a.jobs + ent.job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err);
+    }
+    flush_counters<LPV>(a.counters, lane, n_eval, n_pass, n_patch, 0u, err);
+}
+
+/*
+ * One fused round of the propagation tail (replaces expand -> optimise -> apply, three dependent launches, by
+ * one): a wavefront takes a candidate = (entry accepted in the previous round, one of its 4-neighbours),
+ * applies the push rule (dmrecon.cc:400-431) against the state frozen at the end of the previous round, claims
+ * the pixel (atomicMax on its mark: each pixel is processed once per round, whoever claims it), appends it to
+ * this round's list, optimises it in the latency layout and writes an accepted result into the pixel's other
+ * state slot (see DevJob).  Which candidate claims a pixel, and the order of the list, depend on timing; the
+ * results do not: every optimisation reads the frozen state only.
+ */
+struct TailArgs {
+    OptArgs o;                    /* o.work / o.results: this round's list and results (written here) */
+    const DevEntry* prev_work;    /* previous round's list, results and entry count */
+    const DevResult* prev_results;
+    unsigned* round_work;         /* [MI_MAX_ROUNDS] entries per round */
+};
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_tail(TailArgs t) {
+    typedef Lay<16> L;
+    const OptArgs& a = t.o;
+    const int lane = threadIdx.x;
+    const unsigned n_prev = t.round_work[a.round - 1];
+    if (n_prev == 0) return;
+    for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
+    __syncthreads();
+    unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;
+    for (unsigned cand = blockIdx.x; cand < 4u * n_prev; cand += gridDim.x) {
+        const unsigned ep = cand >> 2, k = cand & 3u;
+        const DevResult* pr = t.prev_results + ep;
+        if (!pr->accepted) continue;
+        const DevEntry src = t.prev_work[ep];
+        const DevJob* job = a.jobs + src.job;
+        const int W = job->w, H = job->h;
+        const int qx = (src.xy & 0xFFFF) + (k == 0 ? -1 : k == 1 ? 1 : 0), qy = (src.xy >> 16) + (k == 2 ? -1 : k == 3 ? 1 : 0);
+        if (qx < 2 || qy < 2 || qx >= W - 2 || qy >= H - 2) continue;         /* patch_sampler.cc:47-50 */
+        const int q = qy * W + qx;
+        const PixState me = pix_state<true>(job, q, a.round);
+        const float own = GF(me.conf + q), c = pr->conf;
+        if (!(own < c - 0.05f || own == 0.f)) continue;
+        unsigned e = 0xFFFFFFFFu;
+        if (lane == 0) {
+            if (atomicMax(&job->mark[q], a.round) < a.round) {
+                e = atomicAdd(&t.round_work[a.round], 1u);
+                DevEntry o; o.job = src.job; o.xy = qx | (qy << 16);
+                const_cast<DevEntry*>(a.work)[e] = o;
             }
         }
+        e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
+        if (e == 0xFFFFFFFFu) continue;                                        /* another candidate owns the pixel */
+        const bool accepted = process_entry<16, true>(a, e, job, qx, qy, lane, n_eval, n_pass, n_patch, err);
+        if (accepted && lane == 0) {
+            const DevResult r = a.results[e];                                  /* written by this lane */
+            const bool one = me.conf == job->conf1;                            /* slot holding the old state */
+            float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
+            float* cp = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
+            uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
+            dp[q] = r.depth; zp[2 * q] = r.dzI; zp[2 * q + 1] = r.dzJ;
+            np[3 * q] = r.nx; np[3 * q + 1] = r.ny; np[3 * q + 2] = r.nz;
+            cp[q] = r.conf; vp[q] = r.views; up[q] = a.round;
+            if (own <= 0.f) ++n_filled;
+        }
     }
-    /* flush counters: one atomic per wave (per-view counters live in the first lane of each view slot,
-     * the patch counter in the first lane of each patch) */
-    if (L::sub(lane) != 0) { n_eval = 0; n_pass = 0; }
-    if (L::vslot(lane) != 0 || L::sub(lane) != 0) n_patch = 0;
-    for (int off = 32; off > 0; off >>= 1) {
-        n_eval += __shfl_down(n_eval, off);
-        n_pass += __shfl_down(n_pass, off);
-        n_patch += __shfl_down(n_patch, off);
-        err |= __shfl_down(err, off);
-    }
-    if (lane == 0) {
-        if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
-        if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
-        if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
-        if (err) atomicOr(&a.counters->error_flags, err);
-    }
+    flush_counters<16>(a.counters, lane, n_eval, n_pass, n_patch, n_filled, err);
+}
+
+/* Fold the second state slot back into the first where it is the newer one (after the last tail round). */
+struct FlattenArgs {
+    float* depth; float* dz; float* conf; float* normal; uint32_t* views; int32_t* upd;
+    const float* depth1; const float* dz1; const float* conf1; const float* normal1; const uint32_t* views1; const int32_t* upd1;
+    unsigned n;
+};
+__global__ __launch_bounds__(256) void k_flatten(FlattenArgs a) {
+    const unsigned p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.n) return;
+    const int s1 = a.upd1[p];
+    if (s1 <= a.upd[p]) return;
+    a.depth[p] = a.depth1[p]; a.dz[2 * p] = a.dz1[2 * p]; a.dz[2 * p + 1] = a.dz1[2 * p + 1];
+    a.normal[3 * p] = a.normal1[3 * p]; a.normal[3 * p + 1] = a.normal1[3 * p + 1]; a.normal[3 * p + 2] = a.normal1[3 * p + 2];
+    a.conf[p] = a.conf1[p]; a.views[p] = a.views1[p]; a.upd[p] = s1;
 }
 
 /* Parity hook: one hypothesis against every global view; one quad lane per 4 views. */
@@ -1361,47 +1481,6 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
     if (filled && (threadIdx.x & 63) == 0) atomicAdd(&a.counters->n_filled, (unsigned long long)filled);
 }
 
-/* Sparse successor of k_generate for the long tail of small rounds: instead of scanning every pixel,
- * walk the pixels written in round `round` and put their 4-neighbours that satisfy the push rule
- * (dmrecon.cc:400-431, evaluated after all of the round's writes) on the work list of round + 1.
- * A per-pixel atomicMax mark makes each pixel appear once.  The list order depends on atomic order;
- * the results do not (every entry is optimised against the same frozen state). */
-struct ExpandArgs {
-    const DevJob* jobs;
-    const DevEntry* work;
-    const DevResult* results;
-    const unsigned* n_work_ptr;
-    DevEntry* next_work;
-    unsigned* round_work;
-    int round;
-};
-__global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
-    const unsigned n = *a.n_work_ptr;
-    for (unsigned base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
-        const unsigned e = base + threadIdx.x;
-        if (e >= n) continue;
-        if (!a.results[e].accepted) continue;
-        const DevEntry ent = a.work[e];
-        const DevJob* job = a.jobs + ent.job;
-        const int W = job->w, H = job->h;
-        const int x = ent.xy & 0xFFFF, y = ent.xy >> 16;
-        const float c = job->conf[y * W + x];
-        const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int qx = x + dx[k], qy = y + dy[k];
-            if (qx < 2 || qy < 2 || qx >= W - 2 || qy >= H - 2) continue;     /* patch_sampler.cc:47-50 */
-            const int q = qy * W + qx;
-            const float own = job->conf[q];
-            if (!(own < c - 0.05f || own == 0.f)) continue;
-            if (atomicMax(&job->mark[q], a.round + 1) >= a.round + 1) continue;   /* already listed */
-            const unsigned idx = atomicAdd(&a.round_work[a.round + 1], 1u);
-            DevEntry o; o.job = ent.job; o.xy = qx | (qy << 16);
-            a.next_work[idx] = o;
-        }
-    }
-}
-
 /* Seeds (dmrecon.cc:297-330): several features may round to the same pixel; the sequential
  * reference keeps the highest confidence, the earlier feature on ties.  Two phases:
  * vote (64-bit atomicMax of conf | ~index) then write by the winner. */
@@ -1540,12 +1619,27 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
     hipLaunchKernelGGL(k_apply, dim3(grid_blocks), dim3(256), 0, s, a);
 }
 
-void mi_launch_expand(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
-                      const unsigned* n_work_ptr, DevEntry* next_work, unsigned* round_work, int round) {
-    ExpandArgs a;
-    a.jobs = jobs; a.work = work; a.results = results; a.n_work_ptr = n_work_ptr; a.next_work = next_work;
-    a.round_work = round_work; a.round = round;
-    hipLaunchKernelGGL(k_expand, dim3(grid_blocks), dim3(256), 0, s, a);
+void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
+                    const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
+                    DevResult* results, unsigned* round_work, int round, DevCounters* counters) {
+    TailArgs t;
+    t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
+    t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
+    t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
+    t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
+    hipLaunchKernelGGL(k_tail, dim3(grid_blocks), dim3(WAVE), 0, s, t);
+}
+
+void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px) {
+    if (total_px == 0) return;
+    FlattenArgs a;
+    a.depth = maps; a.conf = maps + total_px; a.dz = maps + 2 * total_px; a.normal = maps + 4 * total_px;
+    float* m1 = maps + 7 * total_px;
+    a.depth1 = m1; a.conf1 = m1 + total_px; a.dz1 = m1 + 2 * total_px; a.normal1 = m1 + 4 * total_px;
+    a.views = imaps; a.upd = (int32_t*)(imaps + total_px);
+    a.views1 = imaps + 3 * total_px; a.upd1 = (const int32_t*)(imaps + 4 * total_px);
+    a.n = (unsigned)total_px;
+    hipLaunchKernelGGL(k_flatten, dim3((unsigned)((total_px + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,

@@ -170,6 +170,7 @@ struct mi_dmrecon_ctx {
     DevBuf<DevEntry> d_work2;                /* ping-pong partner of d_work in the tail rounds */
     DevBuf<DevHyp> d_hyp;
     DevBuf<DevResult> d_results;
+    DevBuf<DevResult> d_results2;            /* ping-pong partner of d_results in the tail rounds */
     DevBuf<float> d_maps;                    /* depth | dz | conf | normal per batch */
     DevBuf<uint32_t> d_imaps;                /* views | upd */
     DevBuf<unsigned long long> d_keys;
@@ -402,9 +403,11 @@ DevSettings dev_settings(const mi_dmrecon_settings* st) {
 int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px) {
     total_px = 0;
     for (size_t j = 0; j < jobs.size(); ++j) { jobs[j].pix_off = total_px; total_px += (size_t)jobs[j].w * jobs[j].h; }
-    if (c->d_maps.reserve(total_px * 7)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
-    if (c->d_imaps.reserve(total_px * 3)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
+    /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd, mark + views1, upd1 */
+    if (c->d_maps.reserve(total_px * 14)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
+    if (c->d_imaps.reserve(total_px * 5)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
     float* base = c->d_maps.p;
+    float* base1 = base + 7 * total_px;
     uint32_t* ibase = c->d_imaps.p;
     for (size_t j = 0; j < jobs.size(); ++j) {
         const size_t o = jobs[j].pix_off;
@@ -415,9 +418,16 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
         dj[j].views = ibase + o;
         dj[j].upd = (int32_t*)(ibase + total_px + o);
         dj[j].mark = (int32_t*)(ibase + 2 * total_px + o);
+        dj[j].depth1 = base1 + o;
+        dj[j].conf1 = base1 + total_px + o;
+        dj[j].dz1 = base1 + 2 * total_px + 2 * o;
+        dj[j].normal1 = base1 + 4 * total_px + 3 * o;
+        dj[j].views1 = ibase + 3 * total_px + o;
+        dj[j].upd1 = (int32_t*)(ibase + 4 * total_px + o);
     }
+    /* slot 1 is only ever read where its stamp says so: the stamps (0xFF.. = -1) are all it needs */
     HIP_TRY(hipMemsetAsync(c->d_maps.p, 0, total_px * 7 * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * 3 * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * 5 * sizeof(uint32_t), c->stream));
     return 0;
 }
 
@@ -478,7 +488,7 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
-    c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release();
+    c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release();
     c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
@@ -738,7 +748,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         n_seed_feats += jobs[j].n_seeds;
     }
     const size_t work_cap = std::max(total_px, seeds.size());
-    if (c->d_work.reserve(work_cap) || c->d_work2.reserve(work_cap) || c->d_results.reserve(work_cap) || c->d_hyp.reserve(std::max<size_t>(seeds.size(), 1))
+    if (c->d_work.reserve(work_cap) || c->d_work2.reserve(work_cap) || c->d_results.reserve(work_cap) || c->d_results2.reserve(work_cap) || c->d_hyp.reserve(std::max<size_t>(seeds.size(), 1))
         || c->d_keys.reserve(total_px) || c->d_keyoff.reserve(nj))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(work lists) failed");
     const DevSettings ds = dev_settings(st);
@@ -825,23 +835,25 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         if (tail) { ++round; break; }
     }
     mark("seeds + phase A rounds");
-    /* phase B: round r+1's list is built by k_expand from round r's accepted entries (ping-pong lists) */
-    DevEntry* wcur = c->d_work.p;        /* list of the last executed round (round - 1) */
+    /* phase B: one fused launch per round (k_tail: candidates from the previous round's accepted entries ->
+     * this round's list, optimisations and state writes); lists and results ping-pong */
+    DevEntry* wcur = c->d_work.p;        /* list + results of the last executed round (round - 1) */
     DevEntry* wnext = c->d_work2.p;
+    DevResult* rcur = c->d_results.p;
+    DevResult* rnext = c->d_results2.p;
+    bool ran_tail = false;
     while (!done && !was_cancelled && round < max_rounds) {
         const int first = round;
         const size_t ev_first = ev_work.size();
+        ran_tail = true;
         for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
             const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
-            mi_launch_expand(c->stream, 64, c->d_jobs.p, wcur, c->d_results.p, c->d_round_work.p + (round - 1), wnext,
-                             c->d_round_work.p, round - 1);
             if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
-            mi_launch_optimize(c->stream, 16, TAIL_GRID, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wnext, nullptr,
-                               c->d_results.p, c->d_round_work.p + round, 0u, 1u, 0xFFFFFFFFu, round, c->d_counters);
+            mi_launch_tail(c->stream, TAIL_GRID, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
+                           c->d_round_work.p, round, c->d_counters);
             if (timed) ev_end();
-            mi_launch_apply(c->stream, 64, c->d_jobs.p, wnext, c->d_results.p, c->d_round_work.p + round, 0u, round,
-                            c->d_counters);
             std::swap(wcur, wnext);
+            std::swap(rcur, rnext);
         }
         HIP_TRY(hipMemcpyAsync(rw.data(), c->d_round_work.p + first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
@@ -855,6 +867,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = rw[TAIL_CHUNK - 1]; }
         if (cancelled()) was_cancelled = true;
     }
+    if (ran_tail) mi_launch_flatten(c->stream, c->d_maps.p, c->d_imaps.p, total_px);
     mark("phase B rounds");
     /* ---- results back to the caller's buffers */
     for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_SAVING;

@@ -49,7 +49,17 @@ struct DevJob {
     float* normal;    /* 3 ch */
     uint32_t* views;  /* 4 x 8-bit indices into global_ids, MI_VIEW_NONE padded */
     int32_t* upd;     /* round in which the pixel was last written, -1 = never */
-    int32_t* mark;    /* last round for which the pixel was put on a work list by k_expand, -1 = never */
+    int32_t* mark;    /* last round for which the pixel was claimed by a tail round (k_tail), -1 = never */
+    /* Second slot of the pixel state, used by the fused tail rounds only (k_tail): a write of round r goes to
+     * the slot that does NOT hold the pixel's state as of the end of round r-1, so the optimisations of a round
+     * keep reading the frozen state of the previous round without a separate write-back launch.  The state
+     * of a pixel is the slot with the larger stamp; k_flatten folds slot 1 back into slot 0 at the end. */
+    float* depth1;
+    float* dz1;
+    float* conf1;
+    float* normal1;
+    uint32_t* views1;
+    int32_t* upd1;
 };
 
 /* Settings as the kernels see them. */
