@@ -6,11 +6,14 @@
 #include "dmrecon_types.h"
 
 /* lanes_per_view: 1 = 16 patches per wavefront (throughput), 16 = one patch per wavefront (latency).
- * The launch only acts if min_work <= n < max_work, n = *n_work_ptr (if given) or n_work. */
+ * The launch only acts if min_work <= n < max_work, n = *n_work_ptr (if given) or n_work.
+ * follow_out != null: one optimisation attempt per entry; entries with further candidate hypotheses are appended to
+ * follow_out (count *follow_out_n).  follow_in != null: continue the entries work[follow_in[0 .. *follow_in_n)]. */
 void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
-                        unsigned max_work, int round, DevCounters* counters);
+                        unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in = nullptr,
+                        const unsigned* follow_in_n = nullptr, unsigned* follow_out = nullptr, unsigned* follow_out_n = nullptr);
 extern unsigned long long* mi_debug_tbuf;
 void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                           const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,

@@ -48,6 +48,9 @@ typedef const __attribute__((address_space(1))) int32_t* gi32_t;
 #define GI(p) (*(gi32_t)(p))
 #define GU(p) (*(gtex_t)(p))
 
+#ifdef MI_HIST
+__device__ unsigned long long* g_hist = nullptr;
+#endif
 #ifdef MI_TIMING
 /* development aid: wave 0 / lane 0 logs shader clock stamps into counters->tstamp[] */
 __device__ unsigned long long* g_tbuf;
@@ -321,102 +324,117 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     constexpr bool PER_CHANNEL = (MODE == PASS_COLOR || MODE == PASS_DEPTH);
 
     constexpr int NITER = (LPV == 1) ? MI_NS : (MI_NS + LPV - 1) / LPV;
-    /* Samples whose texel gathers are in flight together.  The latency layout runs one wavefront per patch with
-     * nothing else to hide a gather behind, so all of a lane's samples (2) are addressed and loaded before the
-     * first one is consumed: one exposed memory latency per pass instead of two.  The throughput layout keeps one
-     * sample in flight (the other wavefronts of the SIMD hide the latency; registers are the scarce resource). */
-    constexpr int NB = (LPV == 1) ? 1 : NITER;
-#pragma unroll 1
-    for (int it0 = 0; it0 < NITER; it0 += NB) {
-        int si[NB]; bool slive[NB];
-        float sfx[NB], sfy[NB], sgu[NB], sgv[NB];
-        u32x2 sra[NB], srb[NB];
+    /* A sample is handled in two steps so that texel gathers can be in flight while other samples are consumed:
+     * fetch() = geometry + the two row gathers, consume() = table look-ups, interpolation and the sums.
+     *   latency layout (one wavefront per patch, nothing else to hide a gather behind): both samples of a lane are
+     *   fetched before the first is consumed -- one exposed memory latency per pass instead of two;
+     *   throughput layout: software pipeline of depth 1 -- sample i + 1 is fetched before sample i is consumed. */
+    struct Pre { int i; bool live; float fx, fy, gu, gv; u32x2 ra, rb; };
+    auto fetch = [&](int it) -> Pre {
+        Pre q;
+        const int iraw = sub + it * LPV;
+        q.live = iraw < MI_NS;                         /* LPV = 16: second trip only for lanes 0..8 */
+        const int i = q.live ? iraw : (MI_NS - 1);
+        q.i = i;
+        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
+        const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;      /* computePatchPoints */
+        const float px = cpx + t * rx, py = cpy + t * ry, pz = cpz + t * rz;
+        float u, v;
+        project(nv, px, py, pz, u, v);
+        /* strict interior test (patch_sampler.cc:116-119, :386-389) */
+        ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
+        q.gu = 0.f; q.gv = 0.f;
+        if (MODE != PASS_COLOR) {
+            float u1, v1;
+            project(nv, px + rx * step, py + ry * step, pz + rz * step, u1, v1);
+            q.gu = u1 - u; q.gv = v1 - v;
+        }
+        /* memory-safe even when the sample is outside (result discarded through ok) */
+        /* (fmaxf/fminf return the non-NaN operand, so a NaN coordinate clamps to 0 as well) */
+        const float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
+        const int left = (int)floorf(uc), top = (int)floorf(vc);
+        q.fx = uc - (float)left; q.fy = vc - (float)top;
+        const uint32_t* r0 = nv.img + (size_t)top * nv.w + left;
+        /* the two texels of a row are 8 contiguous bytes (dword aligned): one dwordx2 gather per row */
+        q.ra = *(gtex2_t)(r0); q.rb = *(gtex2_t)(r0 + nv.w);
+        return q;
+    };
+    auto consume = [&](const Pre& q) {
+        const int i = q.i;
+        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const float fx = q.fx, fy = q.fy, gu = q.gu, gv = q.gv;
+        const uint32_t t00 = q.ra.x, t10 = q.ra.y, t01 = q.rb.x, t11 = q.rb.y;
+        float n[3], dr[3];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int iraw = sub + (it0 + b) * LPV;
-            const bool live = iraw < MI_NS;                /* LPV = 16: second trip only for lanes 0..8 */
-            const int i = live ? iraw : (MI_NS - 1);
-            const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
-            const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
-            const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;      /* computePatchPoints */
-            const float px = cpx + t * rx, py = cpy + t * ry, pz = cpz + t * rz;
-            float u, v;
-            project(nv, px, py, pz, u, v);
-            /* strict interior test (patch_sampler.cc:116-119, :386-389) */
-            ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
-            float gu = 0.f, gv = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float c00 = s_lut[(t00 >> (8 * c)) & 255u], c10 = s_lut[(t10 >> (8 * c)) & 255u];
+            const float c01 = s_lut[(t01 >> (8 * c)) & 255u], c11 = s_lut[(t11 >> (8 * c)) & 255u];
+            /* mvs_tools.cc:119-128 */
+            const float xa = (1.f - fx) * c00 + fx * c10;
+            const float xb = (1.f - fx) * c01 + fx * c11;
+            n[c] = (1.f - fy) * xa + fy * xb;
             if (MODE != PASS_COLOR) {
-                float u1, v1;
-                project(nv, px + rx * step, py + ry * step, pz + rz * step, u1, v1);
-                gu = u1 - u; gv = v1 - v;
+                /* exact directional derivative of the bilinear surface, mvs_tools.cc:131-143; /= stepSize */
+                dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) * dnorm;
             }
-            /* memory-safe even when the sample is outside (result discarded through ok) */
-            /* (fmaxf/fminf return the non-NaN operand, so a NaN coordinate clamps to 0 as well) */
-            const float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
-            const int left = (int)floorf(uc), top = (int)floorf(vc);
-            /* the two texels of a row are 8 contiguous bytes (dword aligned): one dwordx2 gather per row */
-            const uint32_t* r0 = nv.img + (size_t)top * nv.w + left;
-            sra[b] = *(gtex2_t)(r0); srb[b] = *(gtex2_t)(r0 + nv.w);
-            si[b] = i; slive[b] = live;
-            sfx[b] = uc - (float)left; sfy[b] = vc - (float)top; sgu[b] = gu; sgv[b] = gv;
         }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = si[b];
-            const bool live = slive[b];
-            const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
-            const float fx = sfx[b], fy = sfy[b], gu = sgu[b], gv = sgv[b];
-            const uint32_t t00 = sra[b].x, t10 = sra[b].y, t01 = srb[b].x, t11 = srb[b].y;
-            float n[3], dr[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float c00 = s_lut[(t00 >> (8 * c)) & 255u], c10 = s_lut[(t10 >> (8 * c)) & 255u];
-                const float c01 = s_lut[(t01 >> (8 * c)) & 255u], c11 = s_lut[(t11 >> (8 * c)) & 255u];
-                /* mvs_tools.cc:119-128 */
-                const float xa = (1.f - fx) * c00 + fx * c10;
-                const float xb = (1.f - fx) * c01 + fx * c11;
-                n[c] = (1.f - fy) * xa + fy * xb;
-                if (MODE != PASS_COLOR) {
-                    /* exact directional derivative of the bilinear surface, mvs_tools.cc:131-143; /= stepSize */
-                    dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) * dnorm;
-                }
-            }
-            const float wgt = (LPV == 1 || live) ? 1.f : 0.f;   /* dead trips (LPV = 16 only) contribute nothing */
-            const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
-            if (MODE == PASS_DUMP) {
-                dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
-                dump_der[3 * i] = dr[0]; dump_der[3 * i + 1] = dr[1]; dump_der[3 * i + 2] = dr[2];
+        const float wgt = (LPV == 1 || q.live) ? 1.f : 0.f;   /* dead trips (LPV = 16 only) contribute nothing */
+        const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
+        if (MODE == PASS_DUMP) {
+            dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
+            dump_der[3 * i] = dr[0]; dump_der[3 * i + 1] = dr[1]; dump_der[3 * i + 2] = dr[2];
+        } else {
+            const float a0 = (n[0] - S.s0) * wgt, a1 = (n[1] - S.s1) * wgt, a2 = (n[2] - S.s2) * wgt;
+            S.a0 += a0; S.a1 += a1; S.a2 += a2;
+            if (PER_CHANNEL) {
+                S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
+                S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
             } else {
-                const float a0 = (n[0] - S.s0) * wgt, a1 = (n[1] - S.s1) * wgt, a2 = (n[2] - S.s2) * wgt;
-                S.a0 += a0; S.a1 += a1; S.a2 += a2;
-                if (PER_CHANNEL) {
-                    S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
-                    S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
-                } else {
-                    S.aa0 += a0 * a0 + a1 * a1 + a2 * a2;
-                    S.ba0 += (m0 - ps.xbar0) * a0 + (m1 - ps.xbar1) * a1 + (m2 - ps.xbar2) * a2;
-                }
-                if (MODE == PASS_DEPTH_FIXED) {
-                    const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
-                    num += wgt * (g0 * (m0 - ps.cs0 * n[0]) + g1 * (m1 - ps.cs1 * n[1]) + g2 * (m2 - ps.cs2 * n[2]));
-                    den += wgt * (g0 * g0 + g1 * g1 + g2 * g2);
-                } else if (MODE == PASS_DEPTH) {
-                    const float e0 = dr[0] * wgt, e1 = dr[1] * wgt, e2 = dr[2] * wgt;
-                    dr0 += e0 * (m0 - ps.cs0 * n[0]); dr1 += e1 * (m1 - ps.cs1 * n[1]); dr2 += e2 * (m2 - ps.cs2 * n[2]);
-                    dn0 += e0 * n[0]; dn1 += e1 * n[1]; dn2 += e2 * n[2];
-                    dd0 += e0 * dr[0]; dd1 += e1 * dr[1]; dd2 += e2 * dr[2];
-                } else if (MODE == PASS_NORMAL) {
-                    const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
-                    const float r0_ = m0 - ps.cs0 * n[0], r1_ = m1 - ps.cs1 * n[1], r2_ = m2 - ps.cs2 * n[2];
-                    const float gg = (g0 * g0 + g1 * g1 + g2 * g2) * wgt;
-                    const float gr = (g0 * r0_ + g1 * r1_ + g2 * r2_) * wgt;
-                    const float fi = (float)di, fj = (float)dj;
-                    A00 += (acc_t)gg; A01 += (acc_t)(fi * gg); A02 += (acc_t)(fj * gg);
-                    A11 += (acc_t)(fi * fi * gg); A12 += (acc_t)(fi * fj * gg); A22 += (acc_t)(fj * fj * gg);
-                    B0 += (acc_t)gr; B1 += (acc_t)(fi * gr); B2 += (acc_t)(fj * gr);
-                }
+                S.aa0 += a0 * a0 + a1 * a1 + a2 * a2;
+                S.ba0 += (m0 - ps.xbar0) * a0 + (m1 - ps.xbar1) * a1 + (m2 - ps.xbar2) * a2;
+            }
+            if (MODE == PASS_DEPTH_FIXED) {
+                const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
+                num += wgt * (g0 * (m0 - ps.cs0 * n[0]) + g1 * (m1 - ps.cs1 * n[1]) + g2 * (m2 - ps.cs2 * n[2]));
+                den += wgt * (g0 * g0 + g1 * g1 + g2 * g2);
+            } else if (MODE == PASS_DEPTH) {
+                const float e0 = dr[0] * wgt, e1 = dr[1] * wgt, e2 = dr[2] * wgt;
+                dr0 += e0 * (m0 - ps.cs0 * n[0]); dr1 += e1 * (m1 - ps.cs1 * n[1]); dr2 += e2 * (m2 - ps.cs2 * n[2]);
+                dn0 += e0 * n[0]; dn1 += e1 * n[1]; dn2 += e2 * n[2];
+                dd0 += e0 * dr[0]; dd1 += e1 * dr[1]; dd2 += e2 * dr[2];
+            } else if (MODE == PASS_NORMAL) {
+                const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
+                const float r0_ = m0 - ps.cs0 * n[0], r1_ = m1 - ps.cs1 * n[1], r2_ = m2 - ps.cs2 * n[2];
+                const float gg = (g0 * g0 + g1 * g1 + g2 * g2) * wgt;
+                const float gr = (g0 * r0_ + g1 * r1_ + g2 * r2_) * wgt;
+                const float fi = (float)di, fj = (float)dj;
+                A00 += (acc_t)gg; A01 += (acc_t)(fi * gg); A02 += (acc_t)(fj * gg);
+                A11 += (acc_t)(fi * fi * gg); A12 += (acc_t)(fi * fj * gg); A22 += (acc_t)(fj * fj * gg);
+                B0 += (acc_t)gr; B1 += (acc_t)(fi * gr); B2 += (acc_t)(fj * gr);
             }
         }
+    };
+    if (LPV == 1) {
+#ifndef MI_NO_PIPELINE
+        Pre cur = fetch(0);
+#pragma unroll 1
+        for (int it = 0; it < NITER; ++it) {
+            Pre nxt = cur;
+            if (it + 1 < NITER) nxt = fetch(it + 1);
+            consume(cur);
+            cur = nxt;
+        }
+#else
+#pragma unroll 1
+        for (int it = 0; it < NITER; ++it) consume(fetch(it));
+#endif
+    } else {
+        Pre q[NITER];
+#pragma unroll
+        for (int b = 0; b < NITER; ++b) q[b] = fetch(b);
+#pragma unroll
+        for (int b = 0; b < NITER; ++b) consume(q[b]);
     }
     if (MODE != PASS_DUMP) {
         S.a0 = L::view_sum(S.a0); S.a1 = L::view_sum(S.a1); S.a2 = L::view_sum(S.a2);
@@ -884,6 +902,20 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     /* the sums of a pass are consumed within the same turn */
     ColorSums S; GNSums gn;
     S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
+#ifdef MI_HIST
+    if (LPV == 1 && g_hist) {
+        /* diagnostic: how often does a wavefront run a view selection / more than one pass variant in a turn? */
+        const int first = __ffsll((long long)__ballot(true)) - 1;
+        const int nvs = __ballot(R.need_vs) != 0;
+        const int nm = (__ballot(R.need == PASS_DEPTH) != 0) + (__ballot(R.need == PASS_DEPTH_FIXED) != 0)
+                     + (__ballot(R.need == PASS_NORMAL) != 0) + (__ballot(R.need == PASS_COLOR) != 0);
+        if (lane == first) {
+            atomicAdd(&g_hist[40], 1ull); atomicAdd(&g_hist[41], (unsigned long long)nvs); atomicAdd(&g_hist[44 + nm], 1ull);
+            atomicAdd(&g_hist[42], (unsigned long long)__popcll(__ballot(R.need_vs)) / 4ull);
+            atomicAdd(&g_hist[43], (unsigned long long)__popcll(__ballot(true)) / 4ull);
+        }
+    }
+#endif
     if (R.need_vs) {
         R.need_vs = false;
         if (!local_view_selection<LPV>(ps, st, views, lane)) { R.opti = false; return false; }
@@ -1048,8 +1080,21 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
                                PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err) {
     Run R;
     TSTAMP(10);
+#ifdef MI_HIST
+    /* diagnostic build: turns per patch vs turns per wavefront (lane divergence of the throughput layout) */
+    unsigned turns = 0;
+    if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err))
+        do { ++turns; } while (run_turn<LPV>(R, st, views, lane));
+    if (LPV == 1 && g_hist) {
+        unsigned mx = turns;
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+        if ((lane & 3) == 0) { atomicAdd(&g_hist[min(turns, 31u)], 1ull); atomicAdd(&g_hist[32], (unsigned long long)turns); }
+        if (lane == __ffsll(__ballot(true)) - 1) { atomicAdd(&g_hist[33], (unsigned long long)mx); atomicAdd(&g_hist[34], 1ull); }
+    }
+#else
     if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err))
         while (run_turn<LPV>(R, st, views, lane)) { }
+#endif
     TSTAMP(40);
     run_end<LPV>(R, st, lane, res, n_eval, n_pass);
 }
@@ -1070,6 +1115,14 @@ struct OptArgs {
     int round;
     DevCounters* counters;
     unsigned long long* tbuf;     /* MI_TIMING builds only */
+    /* One attempt per launch (throughput layout, host-visible rounds): an entry whose pixel has several candidate
+     * hypotheses runs them in successive launches over compacted follow-up lists, so that wavefronts stay full
+     * (16 patches) instead of idling 15 quads while one entry tries its second neighbour. */
+    int max_attempts;             /* 4 = all attempts of an entry back to back; 1 = one, then hand over to follow_out */
+    const unsigned* follow_in;    /* entry indices to continue (their state is in results[]), or null = first attempt */
+    const unsigned* follow_in_n;
+    unsigned* follow_out;         /* entries that still have untried candidates after this launch */
+    unsigned* follow_out_n;
 };
 
 /*
@@ -1099,23 +1152,30 @@ __device__ __forceinline__ PixState pix_state(const DevJob* job, int p, int roun
  */
 template <int LPV, bool VER>
 __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, const DevJob* job, int x, int y, int lane,
-                                              unsigned& n_eval, unsigned& n_pass, unsigned& n_patch, unsigned& err) {
+                                              unsigned& n_eval, unsigned& n_pass, unsigned& n_patch, unsigned& err, bool& more) {
     typedef Lay<LPV> L;
     const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
-    if (writer) {
-        DevResult z;
-        z.conf = 0.f; z.depth = 0.f; z.dzI = z.dzJ = 0.f; z.nx = z.ny = z.nz = 0.f;
-        z.views = 0xFFFFFFFFu; z.iters = 0; z.accepted = 0;
-        a.results[e] = z;
-    }
     const bool explicit_hyp = a.hyp != nullptr;
+    const bool resume = a.follow_in != nullptr;
     const int W = job->w;
     const int pix = y * W + x;
-    float best = 0.f;
-    if (!explicit_hyp) { const PixState me = pix_state<VER>(job, pix, a.round); best = GF(me.conf + pix); }
-    const float own = best;
+    float own = 0.f;
+    if (!explicit_hyp) { const PixState me = pix_state<VER>(job, pix, a.round); own = GF(me.conf + pix); }
+    float best = own;
     unsigned tried = 0;
     bool accepted = false;
+    if (resume) {
+        const DevResult prev = a.results[e];
+        tried = prev.tried; accepted = prev.accepted != 0;
+        if (accepted) best = prev.conf;
+    } else if (writer) {
+        DevResult z;
+        z.conf = 0.f; z.depth = 0.f; z.dzI = z.dzJ = 0.f; z.nx = z.ny = z.nz = 0.f;
+        z.views = 0xFFFFFFFFu; z.iters = 0; z.accepted = 0; z.tried = 0;
+        a.results[e] = z;
+    }
+    more = false;
+    int attempts = 0;
     for (int t = 0; t < 4; ++t) {
         float hd, hi, hj; unsigned hv;
         if (explicit_hyp) {
@@ -1134,6 +1194,12 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
                 if (use && (bi < 0 || c > bc)) { bi = k; bc = c; }
             }
             if (bi < 0) break;
+            if (attempts >= a.max_attempts) {
+                /* continued by the next launch -- unless the pop-time test (dmrecon.cc:371) would skip this candidate,
+                 * and with it every remaining one (they come in descending confidence) */
+                more = !(best > bc);
+                break;
+            }
             tried |= 1u << bi;
             if (best > bc) continue;                           /* dmrecon.cc:371 */
             const int p = nb[bi];
@@ -1144,7 +1210,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
         TSTAMP(3);
         optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
         TSTAMP(4);
-        ++n_patch;
+        ++n_patch; ++attempts;
         const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
         if (accept) {
             best = r.conf;
@@ -1153,11 +1219,12 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
                 DevResult o;
                 o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ;
                 o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.iters = r.iters;
-                o.accepted = accepted ? 1 : 0;
+                o.accepted = accepted ? 1 : 0; o.tried = tried;
                 a.results[e] = o;
             }
         }
     }
+    if (more && writer) a.results[e].tried = tried;
     return accepted;
 }
 
@@ -1197,15 +1264,32 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     if (threadIdx.x == 0 && blockIdx.x == 0) { g_tbuf = a.tbuf; g_tcnt = 0; }
 #endif
     TSTAMP(1);
-    const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
+#ifdef MI_HIST
+    if (threadIdx.x == 0) g_hist = a.tbuf;
+#endif
+    const unsigned n = a.follow_in ? *a.follow_in_n : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
     if (n < a.min_work || n >= a.max_work) return;
     for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
     __syncthreads();
     TSTAMP(2);
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
-    for (unsigned e = blockIdx.x * L::PATCHES + L::patch(lane); e < n; e += gridDim.x * L::PATCHES) {
+    for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < n; i += gridDim.x * L::PATCHES) {
+        const unsigned e = a.follow_in ? a.follow_in[i] : i;
         const DevEntry ent = a.work[e];
-        process_entry<LPV, false>(a, e, a.jobs + ent.job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err);
+        bool more;
+        process_entry<LPV, false>(a, e, a.jobs + ent.job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
+        if (a.follow_out) {
+            /* wave-aggregated append of the entries that still have candidates (one atomic per wavefront) */
+            const bool mine = more && L::vslot(lane) == 0 && L::sub(lane) == 0;
+            const unsigned long long m = __ballot(mine);
+            if (m) {
+                const int leader = __ffsll((long long)__ballot(true)) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(a.follow_out_n, (unsigned)__popcll(m));
+                base = (unsigned)__shfl((int)base, leader);
+                if (mine) a.follow_out[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = e;
+            }
+        }
     }
     flush_counters<LPV>(a.counters, lane, n_eval, n_pass, n_patch, 0u, err);
 }
@@ -1257,7 +1341,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         }
         e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
         if (e == 0xFFFFFFFFu) continue;                                        /* another candidate owns the pixel */
-        const bool accepted = process_entry<16, true>(a, e, job, qx, qy, lane, n_eval, n_pass, n_patch, err);
+        bool more;
+        const bool accepted = process_entry<16, true>(a, e, job, qx, qy, lane, n_eval, n_pass, n_patch, err, more);
         if (accepted && lane == 0) {
             const DevResult r = a.results[e];                                  /* written by this lane */
             const bool one = me.conf == job->conf1;                            /* slot holding the old state */
@@ -1582,12 +1667,15 @@ unsigned long long* mi_debug_tbuf = nullptr;   /* set by MI_TIMING probes */
 void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
-                        unsigned max_work, int round, DevCounters* counters) {
+                        unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
+                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n) {
     if (grid_blocks == 0) return;
     OptArgs a;
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
     a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
+    a.max_attempts = follow_out ? 1 : 4; a.follow_in = follow_in; a.follow_in_n = follow_in_n;
+    a.follow_out = follow_out; a.follow_out_n = follow_out_n;
     if (lanes_per_view == 16)
         hipLaunchKernelGGL(k_optimize<16>, dim3(grid_blocks), dim3(WAVE), 0, s, a);
     else
@@ -1626,6 +1714,7 @@ void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, con
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
+    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
     hipLaunchKernelGGL(k_tail, dim3(grid_blocks), dim3(WAVE), 0, s, t);
 }

@@ -179,6 +179,8 @@ struct mi_dmrecon_ctx {
     DevBuf<uint8_t> d_stage2;
     int stage_flip = 0;
     DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
+    DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
+    DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
     std::vector<hipEvent_t> events;
 };
 
@@ -488,7 +490,7 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
-    c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release();
+    c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release(); c->d_follow.release(); c->d_follow_cnt.release();
     c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
@@ -771,8 +773,10 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
 
     mark("setup + uploads (async)");
     int64_t n_launch = 0, n_tail_launch = 0;
-    if (c->d_round_work.reserve(MI_MAX_ROUNDS)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(round counters) failed");
+    if (c->d_round_work.reserve(MI_MAX_ROUNDS) || c->d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->d_follow.reserve(2 * work_cap))
+        return fail(MI_DMRECON_EDEVICE, "hipMalloc(round counters) failed");
     HIP_TRY(hipMemsetAsync(c->d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), c->stream));
     if (!seeds.empty()) {
         HIP_TRY(hipMemcpyAsync(c->d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
@@ -799,6 +803,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     unsigned TAIL_THRESHOLD = 12288;
     if (const char* e = std::getenv("MI_DMRECON_TAIL_THRESHOLD")) TAIL_THRESHOLD = (unsigned)std::atoi(e);
     const unsigned TAIL_GRID = 3072, TAIL_CHUNK = 32;
+    static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
     int round = 1;
     const int max_rounds = std::min<int>(MI_MAX_ROUNDS - TAIL_CHUNK - 2, 4 * (max_px > 0 ? (int)std::sqrt((double)max_px) * 4 : 1) + 64);
     DevCounters hc;
@@ -823,10 +828,25 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         if (tail)
             mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters);
-        else
+        else if (!USE_FOLLOW)
             mi_launch_optimize(c->stream, 1, (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE, c->d_jobs.p, c->sc->d_views.p,
                                c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
                                c->d_counters);
+        else {
+            /* throughput layout: one optimisation attempt per entry and launch; the entries whose pixel has further
+             * candidate hypotheses (about one in five) continue in a follow-up launch over a compacted list (its
+             * size stays on the device), so that the wavefronts of both launches are full */
+            const unsigned waves = (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE;
+            unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
+            unsigned* fa = c->d_follow.p;
+            mi_launch_optimize(c->stream, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+                               c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt);
+            /* the follow-up launch runs all remaining attempts of its entries back to back (third and fourth
+             * attempts are rare: a third launch would cost more in latency than it saves) */
+            mi_launch_optimize(c->stream, 1, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+                               nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr);
+            ++n_launch;
+        }
         ev_end();
         ++n_launch;
         ev_begin(1);

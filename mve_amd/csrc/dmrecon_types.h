@@ -83,6 +83,7 @@ struct DevResult {
     uint32_t views;
     int32_t iters;
     int32_t accepted;        /* propagate mode: 1 if the pixel state must be overwritten */
+    uint32_t tried;          /* propagate mode: neighbours (bit k: left, right, up, down) whose hypothesis has been consumed */
 };
 
 struct DevCounters {
