@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): bench lines + rocprofv3 kernel stats + HBM PMC passes for the C3 bench.
 # Everything lands in gpurun_out/$TAG/; tools/summarize_profiles.py turns it into profiles/<tag>_*.
-# --pmc passes are separate runs with --kernel-trace only (never with sys/runtime/hip traces).
+# --pmc passes are separate runs with --kernel-trace only (never with sys/runtime/hip traces), each under its own
+# timeout: a counter group the hardware cannot collect makes rocprofv3 abort and then hang in its finalisation.
 TAG=${1:-r1}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -10,12 +11,12 @@ python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --streams 1 > $OUT/bench_1thread.json 2> $OUT/bench_1thread.err
 B1="python bench.py --steps 6 --warmup 1 --streams 1 --no-cpu-baseline"
 B3="python bench.py --steps 6 --warmup 1 --streams 3 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s1 -o bench -- $B1 > $OUT/s1.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s3 -o bench -- $B3 > $OUT/s3.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s1 -o bench -- $B1 > $OUT/s1.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s3 -o bench -- $B3 > $OUT/s3.log 2>&1
 BP="python bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline"
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU"; do
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
   D=$OUT/pmc_$(echo $C | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o bench -- $BP > $D.log 2>&1
+  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o bench -- $BP > $D.log 2>&1
 done
 # keep the merge small: drop the per-dispatch traces of the stats runs (the stats CSV is the summary)
 rm -f $OUT/s1/bench_kernel_trace.csv $OUT/s3/bench_kernel_trace.csv
