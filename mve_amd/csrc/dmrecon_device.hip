@@ -19,8 +19,15 @@
  *               pixels x 4 views in lock step.  Per-patch data shared by the quad
  *               (25 master colours, 25 view rays, NCC scratch for view
  *               selection) and the sRGB->linear table live in LDS.
+ *               (A second layout, Lay<16>, spends a whole wavefront on one
+ *               pixel for the latency-bound tail.)  A bulk round is two
+ *               launches: first attempts, then the follow-up list.
  *   k_apply     writes accepted results back to the state maps (Jacobi sweep:
  *               all of a round's optimisations read the previous round's state).
+ *   k_tail      one fused round of the propagation tail: candidates from the
+ *               previous round's accepted pixels, claim, optimisation (Lay<16>),
+ *               write into the pixel's other state slot; k_flatten folds the
+ *               slots at the end.
  *   k_pyramid   byte-exact 4x4 Gaussian half-size pyramid (image_tools.h:619-690).
  *
  * No MFMA: every reduction here is a 75-term dot product per lane.
