@@ -73,13 +73,6 @@ __shared__ float g_lut[256];                                   /* sRGB -> linear
 __shared__ float g_rays[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterViewDirs */
 __shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterColorSamples */
 __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelection ncc[] */
-/* per (patch, view slot): the selected neighbour view as the sampler needs it, so that a pass starts
- * from LDS instead of three dependent global loads (view -> level -> texels) */
-#define VC_WORDS 24
-#ifdef MI_USE_VC
-__shared__ float g_vc[MI_PATCHES_PER_WAVE][4][VC_WORDS];
-#endif
-enum { VC_M = 0, VC_AX = 12, VC_AY, VC_CX, VC_CY, VC_W, VC_H, VC_IMG_LO, VC_IMG_HI, VC_INV0, VC_NLEV, VC_LEVEL, VC_GIDX };
 
 /* ------------------------------------------------------------------------- */
 /* Lane layouts.  A patch is optimised by 4 "view slots" (one per local neighbour view);
@@ -677,70 +670,17 @@ __device__ __forceinline__ bool color_scale_step(PatchState& ps, const DevSettin
     return L::view_ballot(!good, lane) == 0;
 }
 
-/* setup_view through the per-(patch, view slot) LDS record: global memory is touched only when my view
- * or its mip level changed since the last pass.  Same level rule as setup_view. */
-template <int LPV>
-__device__ __forceinline__ bool setup_view_cached(const DevView* __restrict__ views, const PatchState& ps, float* vc,
-                                                  NView& nv, int sub) {
-    const int view_id = ps.job->global_ids[ps.sel];
-    if (__float_as_int(vc[VC_GIDX]) != ps.sel) {
-        const DevView* V = views + view_id;
-        if (sub == 0) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) vc[VC_M + k] = V->w2c[k];
-            vc[VC_INV0] = V->lv[0].inv0;
-            vc[VC_NLEV] = __int_as_float(V->n_levels);
-            vc[VC_LEVEL] = __int_as_float(-1);
-            vc[VC_GIDX] = __int_as_float(ps.sel);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    nv.m8 = vc[VC_M + 8]; nv.m9 = vc[VC_M + 9]; nv.m10 = vc[VC_M + 10]; nv.m11 = vc[VC_M + 11];
-    const float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
-    const float nfp = z * vc[VC_INV0];               /* SingleView::footPrint */
-    if (!(nfp > 0.f)) return false;
-    float ratio = fast_div(nfp, ps.mfp);
-    int mm = 0;
-    while (ratio < 0.5f && mm < MI_MAX_LEVELS) { ++mm; ratio *= 2.f; }
-    const int maxl = __float_as_int(vc[VC_NLEV]) - 1;
-    mm = mm > maxl ? maxl : mm;
-    if (__float_as_int(vc[VC_LEVEL]) != mm) {
-        const DevView* V = views + view_id;
-        const DevLevel& Lv = V->lv[mm];
-        const unsigned long long img = (unsigned long long)(V->img + Lv.tex_off);
-        if (sub == 0) {
-            vc[VC_AX] = Lv.ax; vc[VC_AY] = Lv.ay; vc[VC_CX] = Lv.cx; vc[VC_CY] = Lv.cy;
-            vc[VC_W] = __int_as_float(Lv.w); vc[VC_H] = __int_as_float(Lv.h);
-            vc[VC_IMG_LO] = __int_as_float((int)(img & 0xFFFFFFFFull)); vc[VC_IMG_HI] = __int_as_float((int)(img >> 32));
-            vc[VC_LEVEL] = __int_as_float(mm);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    nv.m0 = vc[VC_M + 0]; nv.m1 = vc[VC_M + 1]; nv.m2 = vc[VC_M + 2]; nv.m3 = vc[VC_M + 3];
-    nv.m4 = vc[VC_M + 4]; nv.m5 = vc[VC_M + 5]; nv.m6 = vc[VC_M + 6]; nv.m7 = vc[VC_M + 7];
-    premultiply(nv, vc[VC_AX], vc[VC_AY], vc[VC_CX], vc[VC_CY]);
-    nv.w = __float_as_int(vc[VC_W]); nv.h = __float_as_int(vc[VC_H]);
-    const unsigned long long img = ((unsigned long long)(unsigned)__float_as_int(vc[VC_IMG_HI]) << 32)
-                                 | (unsigned long long)(unsigned)__float_as_int(vc[VC_IMG_LO]);
-    nv.img = (const uint32_t*)img;
-    return true;
-}
-
 /* One fused pass of my view at the current state; sets ps.ncc (getFastNCC).  Returns success[v]. */
 template <int MODE, int LPV>
 __device__ __forceinline__ bool run_pass(PatchState& ps, const DevView* views, const float* s_lut, const float* rays,
-                                         const float* mcol, float* vc, ColorSums& S, GNSums& gn, bool count_color, int sub) {
+                                         const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int sub) {
     bool okv = true;
     ps.ncc = -1.f;
     if (MODE == PASS_NORMAL) gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
     if (ps.sel >= 0) {
         NView nv;
-#ifdef MI_USE_VC
-        okv = setup_view_cached<LPV>(views, ps, vc, nv, sub)
-#else
         int level_unused;
         okv = setup_view(views, ps.job->global_ids[ps.sel], ps, nv, level_unused)
-#endif
             && sample_pass<MODE, LPV>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
         ps.n_pass++;
         if (okv) {
@@ -753,8 +693,7 @@ __device__ __forceinline__ bool run_pass(PatchState& ps, const DevView* views, c
 
 /*
  * PatchOptimization ctor + doAutoOptimization + computeConfidence for one patch, as three pieces so that
- * an optimisation can be suspended between two turns (k_optimize caps the turns of the bulk rounds and
- * k_resume finishes the stragglers with freshly packed wavefronts):
+ * the turns of a patch are an explicit loop (optimize_patch):
  *   run_begin  PatchSampler / LocalViewSelection / PatchOptimization constructors
  *   run_turn   one turn of doAutoOptimization's pass-driven state machine
  *   run_end    getLocalViewIDs, computeConfidence, getPatchNormal
@@ -809,9 +748,6 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
     if (x - 2 < 0 || y - 2 < 0 || x + 2 > job->w - 1 || y + 2 > job->h - 1) return false;
     load_job_constants(ps, job);
-#ifdef MI_USE_VC
-    g_vc[L::patch(lane)][slot][VC_GIDX] = __int_as_float(-1);
-#endif
     fill_rays<LPV>(job, x, y, rays, pl);
     /* raw master colours */
     const DevView* RV = views + job->ref_view;
@@ -901,11 +837,6 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     float* mcol = g_mcol[L::patch(lane)];
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const bool active = slot < st.K;               /* view slots 0..K-1 carry a view once the selection succeeded */
-#ifdef MI_USE_VC
-    float* vc = g_vc[L::patch(lane)][slot];
-#else
-    float* vc = nullptr;
-#endif
     /* the sums of a pass are consumed within the same turn */
     ColorSums S; GNSums gn;
     S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
@@ -929,10 +860,10 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     }
     bool okv;
     TSTAMP(20 + R.need);
-    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, R.count_color, sub);
-    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, R.count_color, sub);
-    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, R.count_color, sub);
-    else okv = run_pass<PASS_COLOR, LPV>(ps, views, s_lut, rays, mcol, vc, S, gn, R.count_color, sub);
+    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
+    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
+    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
+    else okv = run_pass<PASS_COLOR, LPV>(ps, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
     TSTAMP(30);
     /* ---- finish what led to this pass */
     if (R.ctx == CTX_CTOR || R.ctx == CTX_REPLACED) {
