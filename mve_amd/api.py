@@ -22,7 +22,7 @@ import numpy as np
 from .scene_io import SceneData
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmi_dmrecon.so")
+LIB_PATH = os.environ.get("MI_DMRECON_LIB") or os.path.join(_HERE, "csrc", "libmi_dmrecon.so")   # env: another build of the same ABI
 
 MAX_GLOBAL_VIEWS = 32
 E_INVAL, E_GVS, E_DEVICE, E_CANCELLED, E_FOOTPRINT = -1, -2, -3, -4, -5

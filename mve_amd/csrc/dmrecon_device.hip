@@ -55,6 +55,12 @@ typedef const __attribute__((address_space(1))) int32_t* gi32_t;
 #define GI(p) (*(gi32_t)(p))
 #define GU(p) (*(gtex_t)(p))
 
+/* Wavefronts per SIMD the optimise kernels are compiled for: 3 = 168 VGPRs (a few cold-path spills); 2 (256 VGPRs,
+ * no spills) measured ~10 % slower, 4 spills 88 registers. */
+#ifndef MI_WAVES_PER_SIMD
+#define MI_WAVES_PER_SIMD 3
+#endif
+
 #ifdef MI_HIST
 __device__ unsigned long long* g_hist = nullptr;
 #endif
@@ -1195,7 +1201,7 @@ __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, 
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
  */
 template <int LPV>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_optimize(OptArgs a) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_WAVES_PER_SIMD, MI_WAVES_PER_SIMD))) void k_optimize(OptArgs a) {
     typedef Lay<LPV> L;
     const int lane = threadIdx.x;
 #ifdef MI_TIMING
@@ -1247,7 +1253,7 @@ struct TailArgs {
     const DevResult* prev_results;
     unsigned* round_work;         /* [MI_MAX_ROUNDS] entries per round */
 };
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_tail(TailArgs t) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_WAVES_PER_SIMD, MI_WAVES_PER_SIMD))) void k_tail(TailArgs t) {
     typedef Lay<16> L;
     const OptArgs& a = t.o;
     const int lane = threadIdx.x;
