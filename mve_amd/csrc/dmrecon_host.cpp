@@ -887,6 +887,13 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = rw[TAIL_CHUNK - 1]; }
         if (cancelled()) was_cancelled = true;
     }
+    if (was_cancelled) {
+        /* DMRecon::start() returns before anything is saved when the flag was raised during processQueue
+         * (dmrecon.cc:353, :101-105): the caller's buffers stay untouched */
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_CANCELLED;
+        return fail(MI_DMRECON_ECANCELLED, "cancelled");
+    }
     if (ran_tail) mi_launch_flatten(c->stream, c->d_maps.p, c->d_imaps.p, total_px);
     mark("phase B rounds");
     /* ---- results back to the caller's buffers */

@@ -123,3 +123,35 @@ def test_config5_shape_large_images_async_staging():
     m = map_parity(res[2]["depth"], res[2]["conf"], o["depth"], o["conf"])
     assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 5e-3, m
     a.close(); b.close()
+
+
+def test_c3_cancel_during_propagation(c3):
+    """progress.cancelled raised while the rounds run (dmrecon.cc:353): RECON_CANCELLED, nothing written
+    (dmrecon.cc:101-105) -- also when the flag is first seen inside the blind tail."""
+    import threading
+    import time
+    cfg, scene, ctx, st, res, stats = c3
+    refs = list(range(cfg["params"].n_views))
+    for wait_s in (0.0, 0.03):                       # cancel in the host-visible rounds / in the tail
+        prog = (api.CProgress * len(refs))()
+        out = ctx.alloc_outputs(st, refs, want_normal=False)
+        for o in out:
+            o["depth"].fill(-7.0)
+
+        def canceller():
+            t0 = time.time()
+            while prog[0].status != 3 and time.time() - t0 < 10.0:      # MI_RECON_QUEUE: propagation running
+                pass
+            time.sleep(wait_s)
+            prog[0].cancelled = 1
+
+        th = threading.Thread(target=canceller)
+        th.start()
+        with pytest.raises(InterruptedError):
+            ctx.reconstruct(st, refs, want_normal=False, progress=prog, out=out)
+        th.join()
+        assert all(p.status == 5 for p in prog)                          # RECON_CANCELLED
+        assert all((o["depth"] == -7.0).all() for o in out)              # caller's buffers untouched
+    # the context is still usable and gives the same maps as before
+    again = ctx.reconstruct(st, refs, want_views=True)
+    assert np.array_equal(again[3]["depth"], res[3]["depth"])
