@@ -31,7 +31,9 @@
 
 #include "mve/image.h"
 #include "mve/image_tools.h"
+#include "mve/mesh_io_ply.h"
 #include "mve/view.h"
+#include "util/file_system.h"
 #include "util/string_utils.h"
 #include "mi_dmrecon.h"
 
@@ -234,6 +236,24 @@ DMRecon::start()
     progress.status = RECON_SAVING;
     progress.filled = (std::size_t)stats.n_filled;
     mve::View::Ptr view = scene->get_views()[settings.refViewNr];
+    if (settings.writePlyFile) {
+        /* SingleView::saveReconAsPly (single_view.cc:122-138) through MVE's own exporters: the triangulated
+         * depth map with confidences and the colours of the scaled image, plus the .xf camera file */
+        std::string fname("mvs-");                                   /* SingleView::createFileName, single_view.h:144-151 */
+        fname += util::string::get_filled(view->get_id(), 4);
+        fname += "-L";
+        fname += util::string::get((float)settings.scale);
+        if (!settings.quiet)
+            std::cout << "Saving ply file as " << settings.plyPath << "/" << fname << ".ply" << std::endl;
+        if (settings.plyPath.empty()) throw std::invalid_argument("Empty path");
+        if (!util::fs::dir_exists(settings.plyPath.c_str())) util::fs::mkdir(settings.plyPath.c_str());
+        mve::ByteImage::Ptr color = mve::ByteImage::create(width, height, 3);
+        rc = mi_dmrecon_get_level(ctx, ref, settings.scale, color->get_data_pointer(), nullptr, nullptr);
+        if (rc != 0) raise_from(rc);
+        mve::geom::save_ply_view(util::fs::join_path(settings.plyPath, fname + ".ply"), view->get_camera(),
+            depthImg, confImg, color);
+        mve::geom::save_xf_file(util::fs::join_path(settings.plyPath, fname + ".xf"), view->get_camera());
+    }
     std::string name("depth-L");
     name += util::string::get(settings.scale);
     view->set_image(depthImg, name);
@@ -255,9 +275,6 @@ DMRecon::start()
         name += util::string::get(settings.scale);
         view->set_image(undist, name);
     }
-    if (settings.writePlyFile && !settings.quiet)
-        std::cout << "Note: --writeply is not provided by the MI355X build (the PLY export of "
-                     "libs/dmrecon/single_view.cc:122-138 is downstream of the depth-map path)." << std::endl;
     progress.status = RECON_IDLE;
     if (!settings.quiet) {
         float percent = (float)progress.filled / (float)(width * height);

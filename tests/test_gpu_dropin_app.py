@@ -47,8 +47,8 @@ def test_unmodified_apps_dmrecon_on_the_gpu_library(tmp_path, g1, g1_scene, g1b,
     # --- single master view at scale 1 of the odd-sized scene: undist-L1 is written too (:135-140)
     sdir2 = str(tmp_path / "g1b")
     scene_io.write_scene(sdir2, g1b_scene)
-    out = subprocess.run([APP, "-s1", "-m2", "--keep-conf", "--force", "--progress=silent", sdir2],
-                         capture_output=True, text=True, timeout=600)
+    out = subprocess.run([APP, "-s1", "-m2", "--keep-conf", "--force", "--progress=silent", "--writeply",
+                          "--plydest=ply-out", sdir2], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     vd2 = scene_io.view_dir(sdir2, 2)
     assert np.array_equal(scene_io.read_png(os.path.join(vd2, "undist-L1.png")), g1b["s1v2_undist"])
@@ -56,3 +56,10 @@ def test_unmodified_apps_dmrecon_on_the_gpu_library(tmp_path, g1, g1_scene, g1b,
     c = scene_io.read_mvei(os.path.join(vd2, "conf-L1.mvei"))[:, :, 0]
     m = map_parity(d, c, g1b["s1v2_depth"], g1b["s1v2_conf"])
     assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
+    # --writeply (dmrecon.cc:107-116, single_view.cc:122-138): the triangulated depth map through MVE's own exporter
+    ply = os.path.join(sdir2, "ply-out", "mvs-0002-L1.ply")
+    assert os.path.exists(ply) and os.path.exists(ply[:-4] + ".xf")
+    header = open(ply, "rb").read(2000).split(b"end_header")[0].decode()
+    from oracle.pset_oracle import pointset_from_depthmap
+    expect = pointset_from_depthmap(d, None, g1b_scene.cameras[2])
+    assert "element vertex %d" % len(expect["pixel"]) in header and "confidence" in header
