@@ -18,7 +18,10 @@ extern unsigned long long* mi_debug_tbuf;
 void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                           const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
                           float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
-void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_pixels, DevEntry* work,
+/* k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile count */
+#define MI_GEN_TILE_W 64
+#define MI_GEN_TILE_H 32
+void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
                         unsigned* round_work, int round);
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                      const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
@@ -32,6 +35,8 @@ void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
                            const unsigned* key_off);
+/* dst: w*h records of 16 bytes (texels (x,y) (x+1,y) (x,y+1) (x+1,y+1), edge-clamped) */
+void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h);
 void mi_launch_pack_rgba(hipStream_t s, const uint8_t* src, uint32_t* dst, int n, int channels);
 void mi_launch_unpack_rgb(hipStream_t s, const uint32_t* src, uint8_t* dst, int n);
 void mi_launch_pyramid(hipStream_t s, const uint32_t* src, uint32_t* dst, int iw, int ih, int ow, int oh,

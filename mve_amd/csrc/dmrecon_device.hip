@@ -48,6 +48,8 @@ typedef u32x2 u32x2_a4 __attribute__((aligned(4)));      /* gfx950 global loads 
  * space, so hipcc emits flat_load for them -- which also ticks the LDS counter and serialises with the
  * table lookups.  These typedefs pin them to the global address space (global_load). */
 typedef const __attribute__((address_space(1))) u32x2_a4* gtex2_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gtex4_t;
 typedef const __attribute__((address_space(1))) uint32_t* gtex_t;
 typedef const __attribute__((address_space(1))) float* gf32_t;
 typedef const __attribute__((address_space(1))) int32_t* gi32_t;
@@ -256,7 +258,7 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, in
     const DevLevel& L = V->lv[mm];
     premultiply(nv, L.ax, L.ay, L.cx, L.cy);
     nv.w = L.w; nv.h = L.h;
-    nv.img = V->img + L.tex_off;
+    nv.img = V->quad + 4 * (size_t)L.tex_off;      /* 16-byte footprint records of this level */
     return true;
 }
 
@@ -329,13 +331,13 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     /* per-channel colour sums are only needed when computeColorScale may follow this pass */
     constexpr bool PER_CHANNEL = (MODE == PASS_COLOR || MODE == PASS_DEPTH);
 
-    constexpr int NITER = (LPV == 1) ? MI_NS : (MI_NS + LPV - 1) / LPV;
+    constexpr int NITER = (MI_NS + LPV - 1) / LPV;
     /* A sample is handled in two steps so that texel gathers can be in flight while other samples are consumed:
      * fetch() = geometry + the two row gathers, consume() = table look-ups, interpolation and the sums.
      *   latency layout (one wavefront per patch, nothing else to hide a gather behind): both samples of a lane are
      *   fetched before the first is consumed -- one exposed memory latency per pass instead of two;
      *   throughput layout: software pipeline of depth 1 -- sample i + 1 is fetched before sample i is consumed. */
-    struct Pre { int i; bool live; float fx, fy, gu, gv; u32x2 ra, rb; };
+    struct Pre { int i; bool live; float fx, fy, gu, gv; u32x4 t; };
     auto fetch = [&](int it) -> Pre {
         Pre q;
         const int iraw = sub + it * LPV;
@@ -362,15 +364,17 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         const int left = (int)floorf(uc), top = (int)floorf(vc);
         q.fx = uc - (float)left; q.fy = vc - (float)top;
         const uint32_t* r0 = nv.img + (size_t)top * nv.w + left;
-        /* the two texels of a row are 8 contiguous bytes (dword aligned): one dwordx2 gather per row */
-        q.ra = *(gtex2_t)(r0); q.rb = *(gtex2_t)(r0 + nv.w);
+        /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
+         * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
+         * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1. */
+        q.t = *(gtex4_t)(nv.img + 4 * ((size_t)top * nv.w + left));
         return q;
     };
     auto consume = [&](const Pre& q) {
         const int i = q.i;
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
         const float fx = q.fx, fy = q.fy, gu = q.gu, gv = q.gv;
-        const uint32_t t00 = q.ra.x, t10 = q.ra.y, t01 = q.rb.x, t11 = q.rb.y;
+        const uint32_t t00 = q.t.x, t10 = q.t.y, t01 = q.t.z, t11 = q.t.w;
         float n[3], dr[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -385,7 +389,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
                 dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) * dnorm;
             }
         }
-        const float wgt = (LPV == 1 || q.live) ? 1.f : 0.f;   /* dead trips (LPV = 16 only) contribute nothing */
+        const float wgt = (LPV == 1 || q.live) ? 1.f : 0.f;   /* dead trips (LPV > 1 only) contribute nothing */
         const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
         if (MODE == PASS_DUMP) {
             dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
@@ -421,8 +425,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             }
         }
     };
-    if (LPV == 1) {
-#ifndef MI_NO_PIPELINE
+    if (LPV != 16) {
         Pre cur = fetch(0);
 #pragma unroll 1
         for (int it = 0; it < NITER; ++it) {
@@ -431,10 +434,6 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             consume(cur);
             cur = nxt;
         }
-#else
-#pragma unroll 1
-        for (int it = 0; it < NITER; ++it) consume(fetch(it));
-#endif
     } else {
         Pre q[NITER];
 #pragma unroll
@@ -764,12 +763,12 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
         const uint32_t t = GU(rimg + (size_t)(y + dj) * RL.w + (x + di));
         raw0 = s_lut[t & 255u]; raw1 = s_lut[(t >> 8) & 255u]; raw2 = s_lut[(t >> 16) & 255u];
-        if (LPV == 1) { mcol[3 * i] = raw0; mcol[3 * i + 1] = raw1; mcol[3 * i + 2] = raw2; }
+        if (LPV != 16) { mcol[3 * i] = raw0; mcol[3 * i + 1] = raw1; mcol[3 * i + 2] = raw2; }
     }
     /* computeMasterSamples (patch_sampler.cc:297-345) */
     float mm, x0, x1, x2, sd;
-    if (LPV == 1) {
-        /* every lane of the quad redundantly, in the reference's summation order */
+    if (LPV != 16) {
+        /* every lane of the patch redundantly, in the reference's summation order */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         mm = 0.f;
         for (int k = 0; k < 3 * MI_NS; ++k) mm += mcol[k];
@@ -1405,7 +1404,6 @@ struct SweepArgs {
     DevEntry* work;
     unsigned* round_work;  /* [round] = size of the work list of that round (zeroed before the call) */
     int round;
-    int max_pixels;       /* max over jobs of w*h */
 };
 
 /* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull.
@@ -1413,34 +1411,40 @@ struct SweepArgs {
  * prefix so that the global work-list counter sees ONE atomic per 2048 pixels (a per-wave atomic on a
  * single word costs ~10 ns each and dominated this kernel at 40 000 waves). */
 #define GEN_PER_THREAD 8
+/* A workgroup scans a MI_GEN_TILE_W x MI_GEN_TILE_H pixel tile; a wavefront takes a 64 x 8 strip of it as eight
+ * 8 x 8 sub-tiles (one per trip, lane = pixel of the sub-tile).  The ballot-compacted entries therefore come out
+ * sub-tile by sub-tile: the 16 consecutive entries that form a wavefront of k_optimize<1> lie within a few pixels
+ * of each other, their sample windows overlap in every neighbour view, and the texel gathers of a wavefront touch
+ * a fraction of the cache lines that 16 hits strung along an image row do (the propagation front crosses a row at
+ * isolated pixels).  The order of the list has no influence on the results. */
 __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
     __shared__ unsigned s_wave_cnt[4];
     __shared__ unsigned s_base;
     const DevJob* job = a.jobs + blockIdx.y;
-    const int W = job->w, H = job->h, npx = W * H;
+    const int W = job->w, H = job->h;
+    const int tiles_x = (W + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, tiles_y = (H + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tx0 = ((int)blockIdx.x % tiles_x) * MI_GEN_TILE_W, ty0 = ((int)blockIdx.x / tiles_x) * MI_GEN_TILE_H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int first = blockIdx.x * (256 * GEN_PER_THREAD);
-    if (first >= npx) return;
-    unsigned hits = 0;                       /* bit t = pixel first + t*256 + threadIdx.x is a hit */
+    const int lx = lane & 7, ly = lane >> 3;
+    unsigned hits = 0;                       /* bit t = my pixel of sub-tile t is a hit */
     unsigned before[GEN_PER_THREAD];         /* hits of lower lanes of my wave in trip t */
     unsigned wave_total = 0;
 #pragma unroll
     for (int t = 0; t < GEN_PER_THREAD; ++t) {
-        const int pix = first + t * 256 + threadIdx.x;
+        const int x = tx0 + t * 8 + lx, y = ty0 + wave * 8 + ly;
         bool any = false;
-        if (pix < npx) {
-            const int y = pix / W, x = pix - y * W;
-            /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
-            if (x >= 2 && y >= 2 && x < W - 2 && y < H - 2) {
-                const float own = job->conf[pix];
-                const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+        /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
+        if (x >= 2 && y >= 2 && x < W - 2 && y < H - 2) {
+            const int pix = y * W + x;
+            const float own = job->conf[pix];
+            const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (job->upd[nb[k]] == a.round - 1) {
-                        const float c = job->conf[nb[k]];
-                        if (own < c - 0.05f || own == 0.f) any = true;
-                    }
-            }
+            for (int k = 0; k < 4; ++k)
+                if (job->upd[nb[k]] == a.round - 1) {
+                    const float c = job->conf[nb[k]];
+                    if (own < c - 0.05f || own == 0.f) any = true;
+                }
         }
         const unsigned long long m = __ballot(any);
         before[t] = wave_total + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
@@ -1459,9 +1463,7 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
 #pragma unroll
     for (int t = 0; t < GEN_PER_THREAD; ++t)
         if ((hits >> t) & 1u) {
-            const int pix = first + t * 256 + threadIdx.x;
-            const int y = pix / W, x = pix - y * W;
-            DevEntry e; e.job = blockIdx.y; e.xy = x | (y << 16);
+            DevEntry e; e.job = blockIdx.y; e.xy = (tx0 + t * 8 + lx) | ((ty0 + wave * 8 + ly) << 16);
             a.work[off + before[t]] = e;
         }
 }
@@ -1635,11 +1637,11 @@ void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views
     hipLaunchKernelGGL(k_patch_eval, dim3(1), dim3(WAVE), 0, s, a);
 }
 
-void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_pixels, DevEntry* work,
+void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
                         unsigned* round_work, int round) {
     SweepArgs a;
-    a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round; a.max_pixels = max_pixels;
-    hipLaunchKernelGGL(k_generate, dim3((max_pixels + 256 * GEN_PER_THREAD - 1) / (256 * GEN_PER_THREAD), n_jobs), dim3(256), 0, s, a);
+    a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round;
+    hipLaunchKernelGGL(k_generate, dim3(max_tiles, n_jobs), dim3(256), 0, s, a);
 }
 
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
@@ -1686,6 +1688,21 @@ void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* wo
     hipLaunchKernelGGL(k_apply_seeds, dim3((n_work + 255) / 256), dim3(256), 0, s, a);
     a.phase = 1;
     hipLaunchKernelGGL(k_apply_seeds, dim3((n_work + 255) / 256), dim3(256), 0, s, a);
+}
+
+/* RGBA8 level -> 16-byte footprint records (DevView::quad): one lane per texel, neighbours edge-clamped. */
+__global__ __launch_bounds__(256) void k_quadify(const uint32_t* __restrict__ src, u32x4* __restrict__ dst, int w, int h) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    const int x1 = x + 1 < w ? x + 1 : x, y1 = y + 1 < h ? y + 1 : y;
+    u32x4 o;
+    o.x = src[y * w + x]; o.y = src[y * w + x1]; o.z = src[y1 * w + x]; o.w = src[y1 * w + x1];
+    dst[i] = o;
+}
+
+void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h) {
+    hipLaunchKernelGGL(k_quadify, dim3((w * h + 255) / 256), dim3(256), 0, s, src, (u32x4*)dst, w, h);
 }
 
 void mi_launch_pack_rgba(hipStream_t s, const uint8_t* src, uint32_t* dst, int n, int channels) {

@@ -79,8 +79,8 @@ struct HostView {
     float cam_pos[3];
     float w2c[16];
     std::vector<HostLevel> levels;
-    uint32_t* d_img = nullptr;
-    size_t n_texels = 0;
+    uint32_t* d_img = nullptr;               /* RGBA8 levels | footprint records (DevView::img / ::quad) */
+    size_t n_texels = 0, quad_off = 0;       /* texels over all levels; offset (in dwords) of the records */
 
     V3 pos() const { return mk(cam_pos[0], cam_pos[1], cam_pos[2]); }
     /* SingleView::pointInFrustum, single_view.cc:106-119 */
@@ -199,6 +199,7 @@ int sync_views(mi_dmrecon_ctx* c) {
         std::memcpy(d.w2c, v.w2c, sizeof(d.w2c));
         d.n_levels = (int)v.levels.size();
         d.img = v.d_img;
+        d.quad = v.d_img ? v.d_img + v.quad_off : nullptr;
         for (int l = 0; l < d.n_levels; ++l) {
             HostLevel const& L = v.levels[l];
             d.lv[l].ax = L.proj[0]; d.lv[l].ay = L.proj[4]; d.lv[l].cx = L.proj[2]; d.lv[l].cy = L.proj[5];
@@ -560,7 +561,9 @@ static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_ca
         off += (size_t)cw * ch;
     }
     v.n_texels = off;
-    HIP_TRY(hipMalloc((void**)&v.d_img, off * sizeof(uint32_t)));
+    /* RGBA8 levels, then (16-byte aligned) the same levels as 2x2 footprint records: 4 + 16 bytes per texel */
+    v.quad_off = (off + 3) & ~(size_t)3;
+    HIP_TRY(hipMalloc((void**)&v.d_img, (v.quad_off + 4 * off) * sizeof(uint32_t)));
     /* ensureImages, image_pyramid.cc:55-95: upload, strip alpha / expand grey, then the Gaussian levels */
     const size_t nbytes = (size_t)width * height * channels;
     /* two device staging buffers used alternately: the copy of view i+1 (from pinned memory) can start
@@ -576,6 +579,10 @@ static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_ca
     for (size_t l = 1; l < v.levels.size(); ++l) {
         HostLevel const& a = v.levels[l - 1]; HostLevel const& b = v.levels[l];
         mi_launch_pyramid(c->stream, v.d_img + a.tex_off, v.d_img + b.tex_off, a.w, a.h, b.w, b.h, w1, w2, w3);
+    }
+    for (size_t l = 0; l < v.levels.size(); ++l) {
+        HostLevel const& a = v.levels[l];
+        mi_launch_quadify(c->stream, v.d_img + a.tex_off, v.d_img + v.quad_off + 4 * (size_t)a.tex_off, a.w, a.h);
     }
     HIP_TRY(hipGetLastError());
     if (!async) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -732,8 +739,12 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     if (rc) return rc;
     const int nj = (int)jobs.size();
     std::vector<DevJob> dj(nj);
-    int max_px = 0;
-    for (int j = 0; j < nj; ++j) { fill_job(c, st, jobs[j], dj[j]); max_px = std::max(max_px, jobs[j].w * jobs[j].h); }
+    int max_px = 0, max_tiles = 0;
+    for (int j = 0; j < nj; ++j) {
+        fill_job(c, st, jobs[j], dj[j]);
+        max_px = std::max(max_px, jobs[j].w * jobs[j].h);
+        max_tiles = std::max(max_tiles, ((jobs[j].w + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W) * ((jobs[j].h + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H));
+    }
     size_t total_px = 0;
     rc = alloc_maps(c, jobs, dj, total_px);
     if (rc) return rc;
@@ -804,6 +815,8 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     if (const char* e = std::getenv("MI_DMRECON_TAIL_THRESHOLD")) TAIL_THRESHOLD = (unsigned)std::atoi(e);
     const unsigned TAIL_GRID = 3072, TAIL_CHUNK = 32;
     static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
+    const int BULK_LPV = 1;
+    const unsigned BULK_PPW = (unsigned)MI_PATCHES_PER_WAVE;
     int round = 1;
     const int max_rounds = std::min<int>(MI_MAX_ROUNDS - TAIL_CHUNK - 2, 4 * (max_px > 0 ? (int)std::sqrt((double)max_px) * 4 : 1) + 64);
     DevCounters hc;
@@ -813,7 +826,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     /* phase A */
     for (; round < max_rounds && !done; ++round) {
         ev_begin(1);
-        mi_launch_generate(c->stream, c->d_jobs.p, nj, max_px, c->d_work.p, c->d_round_work.p, round);
+        mi_launch_generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round);
         ev_end();
         unsigned n_work = 0;
         HIP_TRY(hipMemcpyAsync(&n_work, c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
@@ -829,21 +842,21 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters);
         else if (!USE_FOLLOW)
-            mi_launch_optimize(c->stream, 1, (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE, c->d_jobs.p, c->sc->d_views.p,
+            mi_launch_optimize(c->stream, BULK_LPV, (n_work + BULK_PPW - 1) / BULK_PPW, c->d_jobs.p, c->sc->d_views.p,
                                c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
                                c->d_counters);
         else {
             /* throughput layout: one optimisation attempt per entry and launch; the entries whose pixel has further
              * candidate hypotheses (about one in five) continue in a follow-up launch over a compacted list (its
              * size stays on the device), so that the wavefronts of both launches are full */
-            const unsigned waves = (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE;
+            const unsigned waves = (n_work + BULK_PPW - 1) / BULK_PPW;
             unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
             unsigned* fa = c->d_follow.p;
-            mi_launch_optimize(c->stream, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+            mi_launch_optimize(c->stream, BULK_LPV, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
                                c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt);
             /* the follow-up launch runs all remaining attempts of its entries back to back (third and fourth
              * attempts are rare: a third launch would cost more in latency than it saves) */
-            mi_launch_optimize(c->stream, 1, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+            mi_launch_optimize(c->stream, BULK_LPV, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr);
             ++n_launch;
         }
@@ -1002,7 +1015,8 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     /* MI_DMRECON_HOOK_LPV=16 runs the hook through the latency layout (tests cover both layouts) */
     const char* lpv_env = std::getenv("MI_DMRECON_HOOK_LPV");
     const int lpv = (lpv_env && std::atoi(lpv_env) == 16) ? 16 : 1;
-    mi_launch_optimize(c->stream, lpv, lpv == 16 ? (unsigned)n : ((unsigned)n + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
+    const unsigned ppw = lpv == 16 ? 1u : (unsigned)MI_PATCHES_PER_WAVE;
+    mi_launch_optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw,
                        c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
                        c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters);
     HIP_TRY(hipGetLastError());

@@ -29,6 +29,8 @@ struct DevView {
     float w2c[12];           /* rows of [R|t] */
     int32_t n_levels;
     const uint32_t* img;     /* all levels back to back, RGBA8 (A unused), row-major */
+    const uint32_t* quad;    /* same levels as 16-byte records: record (x, y) = texels (x,y) (x+1,y) (x,y+1) (x+1,y+1),
+                              * edge-clamped -- the whole bilinear footprint of a sample in ONE aligned gather */
     DevLevel lv[MI_MAX_LEVELS];
 };
 

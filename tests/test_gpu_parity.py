@@ -139,11 +139,13 @@ def test_patch_optimization_vs_oracle_many(ctx_g1, g1_scene):
         assert (np.abs(go[ok, 4:7] - oo[ok, 4:7]).max(1) <= 1e-3).mean() >= 0.98   # normals
 
 
-def test_latency_layout_matches_throughput_layout(ctx_g1, g1, monkeypatch):
-    # the tail rounds run one patch per wavefront (16 lanes per view); same maths, different lane layout
+@pytest.mark.parametrize("lpv", ["16"])
+def test_lane_layouts_agree(ctx_g1, g1, monkeypatch, lpv):
+    # the tail rounds run one patch per wavefront (16 lanes per view): same maths as the 16-patch throughput
+    # layout, different lane layout and summation order
     st = api.Settings(refViewNr=0)
     a, al = ctx_g1.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
-    monkeypatch.setenv("MI_DMRECON_HOOK_LPV", "16")
+    monkeypatch.setenv("MI_DMRECON_HOOK_LPV", lpv)
     b, bl = ctx_g1.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
     assert np.array_equal(a[:, 0] > 0, b[:, 0] > 0)
     ok = a[:, 0] > 0
