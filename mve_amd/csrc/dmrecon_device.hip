@@ -333,12 +333,12 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
 
     constexpr int NITER = (MI_NS + LPV - 1) / LPV;
     /* A sample is handled in two steps so that texel gathers can be in flight while other samples are consumed:
-     * fetch() = geometry + the two row gathers, consume() = table look-ups, interpolation and the sums.
+     * geom()/fetch() = geometry + the footprint gather, consume() = table look-ups, interpolation and the sums.
      *   latency layout (one wavefront per patch, nothing else to hide a gather behind): both samples of a lane are
      *   fetched before the first is consumed -- one exposed memory latency per pass instead of two;
-     *   throughput layout: software pipeline of depth 1 -- sample i + 1 is fetched before sample i is consumed. */
+     *   throughput layout: a whole row of the 5 x 5 window per gather round (see below). */
     struct Pre { int i; bool live; float fx, fy, gu, gv; u32x4 t; };
-    auto fetch = [&](int it) -> Pre {
+    auto geom = [&](int it, float depth, bool first) -> Pre {      /* first: interior test + the gather itself */
         Pre q;
         const int iraw = sub + it * LPV;
         q.live = iraw < MI_NS;                         /* LPV = 16: second trip only for lanes 0..8 */
@@ -346,12 +346,12 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         q.i = i;
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
         const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
-        const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;      /* computePatchPoints */
+        const float t = depth + (float)di * ps.dzI + (float)dj * ps.dzJ;         /* computePatchPoints */
         const float px = cpx + t * rx, py = cpy + t * ry, pz = cpz + t * rz;
         float u, v;
         project(nv, px, py, pz, u, v);
         /* strict interior test (patch_sampler.cc:116-119, :386-389) */
-        ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
+        if (first) ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
         q.gu = 0.f; q.gv = 0.f;
         if (MODE != PASS_COLOR) {
             float u1, v1;
@@ -367,9 +367,10 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
          * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
          * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1. */
-        q.t = *(gtex4_t)(nv.img + 4 * ((size_t)top * nv.w + left));
+        if (first) q.t = *(gtex4_t)(nv.img + 4 * ((size_t)top * nv.w + left));
         return q;
     };
+    auto fetch = [&](int it) -> Pre { return geom(it, ps.depth, true); };
     auto consume = [&](const Pre& q) {
         const int i = q.i;
         const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
@@ -425,7 +426,22 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             }
         }
     };
-    if (LPV != 16) {
+    if (LPV == 1) {
+        /* a row of the 5 x 5 window per gather round: its five footprint records are neighbours in memory (1-2
+         * cache lines fetched once, five gathers in flight); only the texels stay in registers, the geometry of a
+         * sample is computed again when it is consumed (the opaque copy of the depth keeps the compiler from
+         * holding it across the gathers instead) */
+#pragma unroll 1
+        for (int row = 0; row < 5; ++row) {
+            u32x4 tx[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) tx[k] = geom(row * 5 + k, ps.depth, true).t;
+            float depth2 = ps.depth;
+            asm volatile("" : "+v"(depth2));
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { Pre q = geom(row * 5 + k, depth2, false); q.t = tx[k]; consume(q); }
+        }
+    } else if (LPV != 16) {
         Pre cur = fetch(0);
 #pragma unroll 1
         for (int it = 0; it < NITER; ++it) {
