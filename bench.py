@@ -14,6 +14,10 @@ torch.distributed (RCCL) only provides the barrier and the max-over-ranks of the
 import argparse
 import json
 import os
+
+# one hardware queue per host thread / HIP stream (the ROCm default of 4 makes streams share queues, and a tail
+# launch then waits behind another stream's bulk kernel); must be set before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import shutil
 import subprocess
 import sys
@@ -107,7 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=6,
                     help="host threads per GPU, each driving its own forked context / HIP stream; steps are "
                          "dealt round-robin (the reference runs its views under an OpenMP loop the same way)")
     ap.add_argument("--steps-per-call", type=int, default=1,

@@ -38,6 +38,11 @@
 
 namespace {
 
+/* One hardware queue per forked context / host thread: with the ROCm default of 4, streams share queues and the
+ * tail launches of one context wait behind another context's bulk kernels.  Only effective if this library is
+ * loaded before the HIP runtime initialises; never overrides the user's setting. */
+struct HwQueueDefault { HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_hw_queue_default;
+
 thread_local std::string g_err;
 
 int fail(int code, const char* fmt, ...) {

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --streams 1 > $OUT/bench_1thread.json 2> $OUT/bench_1thread.err
 B1="python bench.py --steps 6 --warmup 1 --streams 1 --no-cpu-baseline"
-B3="python bench.py --steps 6 --warmup 1 --streams 3 --no-cpu-baseline"
+B3="python bench.py --steps 12 --warmup 1 --streams 6 --no-cpu-baseline"
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s1 -o bench -- $B1 > $OUT/s1.log 2>&1
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s3 -o bench -- $B3 > $OUT/s3.log 2>&1
 BP="python bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline"

@@ -18,7 +18,7 @@ for n in ("1thread", "default"):
 for s in ("s1", "s3"):
     f = os.path.join(src, s, "bench_kernel_stats.csv")
     if os.path.exists(f):
-        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, "1thread" if s == "s1" else "3threads")))
+        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, "1thread" if s == "s1" else "6threads")))
 
 
 def short(name):
