@@ -205,7 +205,11 @@ def main():
                          "avg_launch_ms": acc["ms_opt_kernel"] / n_launch,
                          "algorithmic_bytes_per_launch": b_alg / n_launch,
                          "n_eval": int(acc["n_eval"]), "n_patch": int(acc["n_patch"]), "n_filled": int(acc["n_filled"]),
-                         "kernel_time_share": opt_s / elapsed if elapsed > 0 else None},
+                         "kernel_time_share": opt_s / elapsed if elapsed > 0 else None,
+                         # the launches of the host threads' streams overlap on the GPU, so each launch's own duration
+                         # (above, as the contract asks) stretches; the same bytes over the wall time of the region:
+                         "aggregate_achieved": b_alg / elapsed / 1e9 if elapsed > 0 else None,
+                         "aggregate_frac": b_alg / elapsed / 1e9 / HBM_PEAK_GBS if elapsed > 0 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cfg)
