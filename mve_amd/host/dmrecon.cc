@@ -18,7 +18,12 @@
  */
 #include "dmrecon/dmrecon.h"
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <cstdlib>
 #include <ctime>
 #include <iostream>
@@ -51,39 +56,178 @@ namespace {
     }
 }
 
-/* One resident copy of a scene per GPU + one forked context per (GPU, host thread). */
+/* One request of a host thread: reconstruct one reference view into caller-owned maps. */
+struct Request {
+    mi_dmrecon_settings st;
+    int32_t ref = 0;
+    mi_dmrecon_maps maps;
+    mi_dmrecon_progress* prog = nullptr;       /* the requesting thread's POD (relayed to its mvs::Progress) */
+    int rc = 0;
+    std::string err;
+    bool done = false;
+};
+
+/*
+ * One GPU: the resident scene (parent context), a few forked contexts ("executors", one HIP stream each) and a queue
+ * of requests.  MVE's driver runs one mvs::DMRecon per OpenMP thread (apps/dmrecon/dmrecon.cc:285-318); the library
+ * is fastest when it gets many reference views per call (one set of launches, one ~600-round latency tail per batch
+ * instead of per view).  So the threads' requests are batched: a thread that finds a free executor takes ALL requests
+ * pending at that moment (same settings) into one mi_dmrecon_reconstruct call; the others wait for their result.
+ * Under load (more OpenMP threads than executors) batches form by themselves; a lone request runs immediately.
+ */
+class Slot
+{
+public:
+    int device = 0;
+    mi_dmrecon_ctx* parent = nullptr;
+    std::mutex parent_mu;                      /* the parent context serves short queries (level size, level image) */
+
+    ~Slot() { release(); }
+
+    void release()
+    {
+        for (std::size_t i = 0; i < executors.size(); ++i) mi_dmrecon_ctx_destroy(executors[i]);
+        executors.clear(); idle.clear();
+        if (parent) mi_dmrecon_ctx_destroy(parent);
+        parent = nullptr;
+    }
+
+    void submit(Request& r)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        pending.push_back(&r);
+        for (;;) {
+            if (r.done) return;
+            /* only a thread whose own request is still queued turns executor (one whose request is in flight in
+             * another batch just waits for it) */
+            if (std::find(pending.begin(), pending.end(), &r) != pending.end()
+                && (!idle.empty() || executors.size() < max_executors())) {
+                mi_dmrecon_ctx* ex = nullptr;
+                if (!idle.empty()) { ex = idle.back(); idle.pop_back(); }
+                else {
+                    int rc = mi_dmrecon_ctx_fork(parent, &ex);
+                    if (rc != 0) { fail_all(rc); continue; }
+                    executors.push_back(ex);
+                }
+                /* everything pending with the settings of the oldest request, up to max_batch() views */
+                std::vector<Request*> batch;
+                mi_dmrecon_settings const key = pending.front()->st;
+                for (std::deque<Request*>::iterator it = pending.begin(); it != pending.end() && batch.size() < max_batch();) {
+                    if (same_settings((*it)->st, key)) { batch.push_back(*it); it = pending.erase(it); } else ++it;
+                }
+                lk.unlock();
+                execute(ex, batch);
+                lk.lock();
+                idle.push_back(ex);
+                for (std::size_t i = 0; i < batch.size(); ++i) batch[i]->done = true;
+                cv.notify_all();
+                continue;
+            }
+            cv.wait(lk);
+        }
+    }
+
+private:
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Request*> pending;
+    std::vector<mi_dmrecon_ctx*> executors, idle;
+
+    static std::size_t env_or(char const* name, std::size_t dflt)
+    {
+        char const* e = std::getenv(name);
+        int v = e ? std::atoi(e) : 0;
+        return v > 0 ? (std::size_t)v : dflt;
+    }
+    static std::size_t max_executors() { static std::size_t v = env_or("MI_DMRECON_EXECUTORS", 4); return v; }
+    static std::size_t max_batch() { static std::size_t v = env_or("MI_DMRECON_MAX_BATCH", 128); return v; }
+
+    static bool same_settings(mi_dmrecon_settings const& a, mi_dmrecon_settings const& b)
+    {
+        return a.filterWidth == b.filterWidth && a.minNCC == b.minNCC && a.minParallax == b.minParallax
+            && a.acceptNCC == b.acceptNCC && a.minRefineDiff == b.minRefineDiff && a.maxIterations == b.maxIterations
+            && a.nrReconNeighbors == b.nrReconNeighbors && a.globalVSMax == b.globalVSMax && a.scale == b.scale
+            && a.useColorScale == b.useColorScale
+            && std::equal(a.aabbMin, a.aabbMin + 3, b.aabbMin) && std::equal(a.aabbMax, a.aabbMax + 3, b.aabbMax);
+    }
+
+    void fail_all(int rc)                      /* mu held */
+    {
+        std::string msg = mi_dmrecon_last_error();
+        for (std::deque<Request*>::iterator it = pending.begin(); it != pending.end(); ++it) {
+            (*it)->rc = rc; (*it)->err = msg; (*it)->done = true;
+        }
+        pending.clear();
+        cv.notify_all();
+    }
+
+    static void execute(mi_dmrecon_ctx* ex, std::vector<Request*> const& batch)
+    {
+        std::size_t const n = batch.size();
+        std::vector<int32_t> refs(n), status(n, 0);
+        std::vector<mi_dmrecon_maps> maps(n);
+        std::vector<mi_dmrecon_progress> prog(n);
+        for (std::size_t i = 0; i < n; ++i) { refs[i] = batch[i]->ref; maps[i] = batch[i]->maps; prog[i] = *batch[i]->prog; }
+        /* progress / cancellation relay between the batch's array and the requesting threads' PODs.  The library
+         * cancels a call as a whole: a view cancelled while batched with others cancels those as well. */
+        std::atomic<bool> running(true);
+        std::thread relay([&]() {
+            while (running.load()) {
+                for (std::size_t i = 0; i < n; ++i) {
+                    if (batch[i]->prog->cancelled) prog[i].cancelled = 1;
+                    batch[i]->prog->status = prog[i].status;
+                    batch[i]->prog->filled = prog[i].filled;
+                    batch[i]->prog->queueSize = prog[i].queueSize;
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+        });
+        mi_dmrecon_stats stats;
+        int rc = mi_dmrecon_reconstruct(ex, &batch[0]->st, (int32_t)n, refs.data(), maps.data(), prog.data(), status.data(), &stats);
+        std::string msg = rc != 0 ? mi_dmrecon_last_error() : "";
+        running.store(false);
+        relay.join();
+        for (std::size_t i = 0; i < n; ++i) {
+            Request& q = *batch[i];
+            q.prog->status = prog[i].status;
+            if (rc != 0) { q.rc = rc; q.err = msg; }
+            else if (status[i] != 0) {         /* this view's planning failed, the others ran (mi_dmrecon.h) */
+                q.rc = status[i];
+                q.err = status[i] == MI_DMRECON_EGVS ? "Global View Selection failed" : "reconstruction failed";
+            }
+        }
+    }
+};
+
+/* One Slot per GPU named in MI_DMRECON_DEVICES (default: all), one resident copy of the scene on each; host threads
+ * are dealt round-robin over the slots. */
 class Registry
 {
 public:
     static Registry& get() { static Registry r; return r; }
 
-    mi_dmrecon_ctx* context_for(mve::Scene::Ptr scene, std::string const& embedding)
+    Slot* slot_for(mve::Scene::Ptr scene, std::string const& embedding)
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (devices.empty()) init_devices();
+        if (slots.empty()) init_devices();
         if (scene.get() != cached_scene || embedding != cached_embedding) {
             /* like ImagePyramidCache: first scene/embedding wins; a different one re-uploads */
-            release_all();
+            for (std::size_t i = 0; i < slots.size(); ++i) slots[i]->release();
+            per_thread.clear();
             cached_scene = scene.get();
             cached_embedding = embedding;
         }
         std::thread::id me = std::this_thread::get_id();
-        std::map<std::thread::id, mi_dmrecon_ctx*>::iterator it = per_thread.find(me);
-        if (it != per_thread.end()) return it->second;
-        std::size_t slot = next_slot++ % devices.size();
-        if (parents[slot] == nullptr) upload(slot, scene, embedding);
-        mi_dmrecon_ctx* c = nullptr;
-        int rc = mi_dmrecon_ctx_fork(parents[slot], &c);
-        if (rc != 0) raise_from(rc);
-        per_thread[me] = c;
-        return c;
+        std::map<std::thread::id, std::size_t>::iterator it = per_thread.find(me);
+        std::size_t idx = it != per_thread.end() ? it->second : (per_thread[me] = next_slot++ % slots.size());
+        if (slots[idx]->parent == nullptr) upload(*slots[idx], scene, embedding);
+        return slots[idx].get();
     }
 
 private:
     std::mutex mu;
-    std::vector<int> devices;
-    std::vector<mi_dmrecon_ctx*> parents;
-    std::map<std::thread::id, mi_dmrecon_ctx*> per_thread;
+    std::vector<std::unique_ptr<Slot> > slots;
+    std::map<std::thread::id, std::size_t> per_thread;
     std::size_t next_slot = 0;
     void* cached_scene = nullptr;
     std::string cached_embedding;
@@ -92,6 +236,7 @@ private:
     {
         int n = mi_dmrecon_device_count();
         if (n <= 0) throw std::runtime_error("mvs::DMRecon (MI355X build): no HIP device available; there is no CPU path");
+        std::vector<int> devices;
         char const* env = std::getenv("MI_DMRECON_DEVICES");
         if (env && *env) {
             std::stringstream ss(env);
@@ -102,22 +247,17 @@ private:
             }
         }
         if (devices.empty()) for (int d = 0; d < n; ++d) devices.push_back(d);
-        parents.assign(devices.size(), nullptr);
-    }
-
-    void release_all()
-    {
-        for (std::map<std::thread::id, mi_dmrecon_ctx*>::iterator it = per_thread.begin(); it != per_thread.end(); ++it)
-            mi_dmrecon_ctx_destroy(it->second);
-        per_thread.clear();
-        for (std::size_t i = 0; i < parents.size(); ++i) { if (parents[i]) mi_dmrecon_ctx_destroy(parents[i]); parents[i] = nullptr; }
+        for (std::size_t i = 0; i < devices.size(); ++i) {
+            slots.push_back(std::unique_ptr<Slot>(new Slot()));
+            slots.back()->device = devices[i];
+        }
     }
 
     /* SingleView::create for every usable view (dmrecon.cc:62-71) + ensureImages (image_pyramid.cc:55-95) */
-    void upload(std::size_t slot, mve::Scene::Ptr scene, std::string const& embedding)
+    void upload(Slot& slot, mve::Scene::Ptr scene, std::string const& embedding)
     {
         mi_dmrecon_ctx* c = nullptr;
-        int rc = mi_dmrecon_ctx_create(devices[slot], &c);
+        int rc = mi_dmrecon_ctx_create(slot.device, &c);
         if (rc != 0) raise_from(rc);
         mve::Scene::ViewList const& views(scene->get_views());
         for (std::size_t i = 0; i < views.size(); ++i) {
@@ -147,14 +287,14 @@ private:
         if (ids.empty()) ids.push_back(0);
         rc = mi_dmrecon_set_features(c, (int32_t)feats.size(), pos.data(), off.data(), ids.data());
         if (rc != 0) { mi_dmrecon_ctx_destroy(c); raise_from(rc); }
-        parents[slot] = c;
+        slot.parent = c;
     }
 };
 
 }  // namespace
 
 DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
-    : scene(_scene), settings(_settings), ctx(nullptr), width(0), height(0)
+    : scene(_scene), settings(_settings), slot(nullptr), width(0), height(0)
 {
     mve::Scene::ViewList const& mve_views(scene->get_views());
     if (settings.refViewNr >= mve_views.size())
@@ -173,10 +313,14 @@ DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
         || !ref->has_image(settings.imageEmbedding, mve::IMAGE_TYPE_UINT8))
         throw std::invalid_argument("Invalid master view");
 
-    this->ctx = Registry::get().context_for(scene, settings.imageEmbedding);
+    Slot* slot = Registry::get().slot_for(scene, settings.imageEmbedding);
+    this->slot = slot;
     int32_t w = 0, h = 0;
-    if (mi_dmrecon_level_size(ctx, (int32_t)settings.refViewNr, settings.scale, &w, &h) != 0)
-        throw std::invalid_argument("Invalid master view");
+    {
+        std::lock_guard<std::mutex> lock(slot->parent_mu);
+        if (mi_dmrecon_level_size(slot->parent, (int32_t)settings.refViewNr, settings.scale, &w, &h) != 0)
+            throw std::invalid_argument("Invalid master view");
+    }
     this->width = w;
     this->height = h;
     if (!settings.quiet)
@@ -225,16 +369,30 @@ DMRecon::start()
         }
     });
     int32_t ref = (int32_t)settings.refViewNr;
-    int32_t status = 0;
-    mi_dmrecon_stats stats;
-    int rc = mi_dmrecon_reconstruct(ctx, &st, 1, &ref, &maps, &mp, &status, &stats);
+    Slot* sl = static_cast<Slot*>(this->slot);
+    Request req;
+    req.st = st; req.ref = ref; req.maps = maps; req.prog = &mp;
+    sl->submit(req);                            /* returns when the batch this view ended up in has finished */
+    int rc = req.rc;
     running.store(false);
     relay.join();
     if (rc == MI_DMRECON_ECANCELLED) { progress.status = RECON_CANCELLED; return; }
-    if (rc != 0) { progress.status = RECON_IDLE; raise_from(rc); }
+    if (rc != 0) {
+        progress.status = RECON_IDLE;
+        switch (rc) {
+            case MI_DMRECON_EINVAL: throw std::invalid_argument(req.err);
+            case MI_DMRECON_EFOOTPRINT: throw std::out_of_range(req.err);
+            default: throw std::runtime_error(req.err);
+        }
+    }
 
     progress.status = RECON_SAVING;
-    progress.filled = (std::size_t)stats.n_filled;
+    {
+        std::size_t filled = 0;                 /* per view (the library's counters are per call = per batch) */
+        float const* d = depthImg->get_data_pointer();
+        for (int i = 0; i < width * height; ++i) filled += d[i] > 0.0f ? 1 : 0;
+        progress.filled = filled;
+    }
     mve::View::Ptr view = scene->get_views()[settings.refViewNr];
     if (settings.writePlyFile) {
         /* SingleView::saveReconAsPly (single_view.cc:122-138) through MVE's own exporters: the triangulated
@@ -248,7 +406,10 @@ DMRecon::start()
         if (settings.plyPath.empty()) throw std::invalid_argument("Empty path");
         if (!util::fs::dir_exists(settings.plyPath.c_str())) util::fs::mkdir(settings.plyPath.c_str());
         mve::ByteImage::Ptr color = mve::ByteImage::create(width, height, 3);
-        rc = mi_dmrecon_get_level(ctx, ref, settings.scale, color->get_data_pointer(), nullptr, nullptr);
+        {
+            std::lock_guard<std::mutex> lock(sl->parent_mu);
+            rc = mi_dmrecon_get_level(sl->parent, ref, settings.scale, color->get_data_pointer(), nullptr, nullptr);
+        }
         if (rc != 0) raise_from(rc);
         mve::geom::save_ply_view(util::fs::join_path(settings.plyPath, fname + ".ply"), view->get_camera(),
             depthImg, confImg, color);
@@ -269,7 +430,10 @@ DMRecon::start()
     }
     if (settings.scale != 0) {
         mve::ByteImage::Ptr undist = mve::ByteImage::create(width, height, 3);
-        rc = mi_dmrecon_get_level(ctx, ref, settings.scale, undist->get_data_pointer(), nullptr, nullptr);
+        {
+            std::lock_guard<std::mutex> lock(sl->parent_mu);
+            rc = mi_dmrecon_get_level(sl->parent, ref, settings.scale, undist->get_data_pointer(), nullptr, nullptr);
+        }
         if (rc != 0) raise_from(rc);
         name = "undist-L";
         name += util::string::get(settings.scale);

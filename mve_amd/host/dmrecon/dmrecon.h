@@ -37,7 +37,7 @@ private:
     mve::Scene::Ptr scene;
     Settings settings;
     Progress progress;
-    mi_dmrecon_ctx* ctx;     /* this host thread's forked context on its GPU (owned by the shim's registry) */
+    void* slot;              /* the GPU slot (resident scene + batching executors) this instance submits to */
     int width, height;
 };
 
