@@ -69,7 +69,37 @@ def main():
     d[holes] = 0
     d[:, :3] = 0; d[50:, 70:] = 0
     run_case(sc1, 1, d.astype(np.float32), None, "stress_96x64", work)
+    scene2pset_case(sc1, g1, work)
     shutil.rmtree(work)
+
+
+def scene2pset_case(sc1, g1, work):
+    """The unmodified apps/scene2pset (oracle/_ref/scene2pset_ref) with -F0 on scene G1 holding two depth maps: the
+    reference's own map of view 0 and a synthetic one (holes, a step) on view 3.  One OpenMP thread: the reference
+    appends views in completion order.  Fixture: the parsed vertices + the sha256 of the PLY file."""
+    import hashlib
+    from mve_amd.scene2pset import read_ply_points
+    sdir = os.path.join(work, "s2p")
+    write_scene(sdir, sc1)
+    h, w = g1["s0v0_depth"].shape
+    rng = np.random.RandomState(5)
+    ys, xs = np.mgrid[0:h, 0:w]
+    d3 = (9.5 + 0.004 * xs + 0.3 * np.cos(ys / 9.0)).astype(np.float32)
+    d3[40:80, 50:110] += 0.8
+    d3[rng.rand(h, w) < 0.08] = 0
+    d3[:, :4] = 0
+    write_mvei(os.path.join(view_dir(sdir, 0), "depth-L0.mvei"), g1["s0v0_depth"].astype(np.float32)[:, :, None])
+    write_mvei(os.path.join(view_dir(sdir, 3), "depth-L0.mvei"), d3[:, :, None])
+    ply = os.path.join(work, "s2p.ply")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "scene2pset_ref"), "-F0", sdir, ply], check=True, env=env,
+                   stdout=subprocess.DEVNULL)
+    ref = read_ply_points(ply)
+    sha = hashlib.sha256(open(ply, "rb").read()).hexdigest()
+    n0 = int(np.load(os.path.join(OUT, "pset_g1_v0_s0.npz"))["ref_pixel"].shape[0])
+    np.savez_compressed(os.path.join(OUT, "scene2pset_g1_F0.npz"), depth_v3=d3, n_view0=np.int32(n0), sha256=np.array(sha),
+                        **{"ref_" + k: v for k, v in ref.items()})
+    print("scene2pset -F0: %d points (view 0: %d), sha256 %s" % (len(ref["pos"]), n0, sha[:16]))
 
 
 if __name__ == "__main__":
