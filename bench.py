@@ -52,6 +52,21 @@ def algorithmic_bytes(stats, n_maps, scene, cfg):
     return 300.0 * stats["n_eval"] + 75.0 * stats["n_patch"] + 28.0 * stats["n_filled"] + comp * n_maps
 
 
+def plan_calls(steps, streams, steps_per_call=0):
+    """How the K timed steps are issued: `spc` steps (spc x 20 reference views) per library call, the calls dealt
+    over the host threads.  Larger batches amortise the ~600-round latency tail of a call (measured, 60 steps on 6
+    threads: 852 depth-maps/s with 1 step per call, 948 with 5; 10 steps: 588 vs 827; 5 steps: 490 vs 612)."""
+    steps = max(1, int(steps))
+    if steps_per_call and steps_per_call > 0:
+        spc = min(int(steps_per_call), steps)
+        if steps % spc:
+            raise SystemExit("--steps must be a multiple of --steps-per-call")
+    else:
+        spc = max(d for d in range(1, 6) if steps % d == 0)
+    n_calls = steps // spc
+    return spc, n_calls, max(1, min(int(streams), n_calls))
+
+
 def measured_traffic():
     """HBM-side bytes per k_optimize launch from the committed PMC passes (tools/collect_profiles.sh ->
     tools/summarize_profiles.py -> profiles/*_traffic.json); None when no profile is present.  PMC counters
@@ -114,9 +129,10 @@ def main():
     ap.add_argument("--streams", type=int, default=6,
                     help="host threads per GPU, each driving its own forked context / HIP stream; steps are "
                          "dealt round-robin (the reference runs its views under an OpenMP loop the same way)")
-    ap.add_argument("--steps-per-call", type=int, default=1,
+    ap.add_argument("--steps-per-call", type=int, default=0,
                     help="steps (passes over the 20 views) handed to ONE mi_dmrecon_reconstruct batch; the propagation "
-                         "tail costs the same ~600 latency-bound rounds per batch whatever its size")
+                         "tail costs the same ~600 latency-bound rounds per batch whatever its size.  0 = the largest "
+                         "divisor of --steps that is <= 5")
     args = ap.parse_args()
     rank, world, local_rank = rank_world()
     if world != args.gpus:
@@ -134,11 +150,7 @@ def main():
 
     # one forked context (own HIP stream + scratch, shared resident scene) per host thread; the long,
     # latency-bound tail of one step's propagation overlaps the throughput-bound start of another's
-    spc = max(1, min(args.steps_per_call, args.steps))
-    n_calls = (args.steps + spc - 1) // spc
-    if n_calls * spc != args.steps:
-        raise SystemExit("--steps must be a multiple of --steps-per-call")
-    n_streams = max(1, min(args.streams, n_calls))
+    spc, n_calls, n_streams = plan_calls(args.steps, args.streams, args.steps_per_call)
     refs = refs * spc
     ctxs = [ctx] + [ctx.fork() for _ in range(n_streams - 1)]
     outs = [c.alloc_outputs(st, refs, want_normal=False, pinned=True) for c in ctxs]   # reused, page-locked
@@ -197,7 +209,7 @@ def main():
                                    % (args.config, p.n_views, p.width, p.height, cfg["scale"], res[0]["depth"].shape[1],
                                       res[0]["depth"].shape[0], cfg["local_neighbors"], p.n_views),
                        "sharding": "reference views are independent; each rank reconstructs all views of its scene replica per step, no collective",
-                       "host_threads_per_gpu": n_streams,
+                       "host_threads_per_gpu": n_streams, "steps_per_call": spc,
                        "mean_fill": round(fill, 4)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

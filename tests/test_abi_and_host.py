@@ -91,3 +91,20 @@ def test_oracle_is_not_reachable_from_the_product():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "liboracle" not in txt and "dmrecon_oracle" not in txt and "from oracle" not in txt \
                     and "import oracle" not in txt, "%s references the oracle" % f
+
+
+def test_bench_call_plan():
+    """bench.py: how K timed steps become library calls (pure host logic)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for steps in range(1, 130):
+        spc, calls, threads = b.plan_calls(steps, 6)
+        assert spc * calls == steps and 1 <= spc <= 5 and 1 <= threads <= min(6, calls)
+    assert b.plan_calls(60, 6) == (5, 12, 6) and b.plan_calls(5, 6) == (5, 1, 1) and b.plan_calls(7, 6) == (1, 7, 6)
+    assert b.plan_calls(12, 3, 1) == (1, 12, 3) and b.plan_calls(60, 6, 4) == (4, 15, 6)
+    with pytest.raises(SystemExit):
+        b.plan_calls(10, 6, 4)

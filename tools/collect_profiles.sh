@@ -8,12 +8,12 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python bench.py --streams 1 > $OUT/bench_1thread.json 2> $OUT/bench_1thread.err
-B1="python bench.py --steps 6 --warmup 1 --streams 1 --no-cpu-baseline"
-B3="python bench.py --steps 12 --warmup 1 --streams 6 --no-cpu-baseline"
+python bench.py --streams 1 --steps-per-call 1 > $OUT/bench_1thread.json 2> $OUT/bench_1thread.err
+B1="python bench.py --steps 6 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline"
+B3="python bench.py --steps 12 --warmup 1 --streams 6 --steps-per-call 1 --no-cpu-baseline"
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s1 -o bench -- $B1 > $OUT/s1.log 2>&1
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s3 -o bench -- $B3 > $OUT/s3.log 2>&1
-BP="python bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline"
+BP="python bench.py --steps 2 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
   D=$OUT/pmc_$(echo $C | tr ' ' '+')
   timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o bench -- $BP > $D.log 2>&1

@@ -3,7 +3,7 @@
 # every run under its own timeout: an over-subscribed group makes rocprofv3 abort and then hang in finalisation)
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_mem; mkdir -p $OUT; : > $OUT/summary.txt
-BP="python bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline"
+BP="python bench.py --steps 1 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline"
 i=0
 for C in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
          "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 label=$1; streams=$2; shift 2
-rm -rf /tmp/tr; env "$@" X=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python bench.py --steps 6 --warmup 1 --streams $streams --no-cpu-baseline > /tmp/tr.log 2>&1
+rm -rf /tmp/tr; env "$@" X=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python bench.py --steps 6 --warmup 1 --streams $streams --steps-per-call 1 --no-cpu-baseline > /tmp/tr.log 2>&1
 python - "$label" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open('/tmp/tr/t_kernel_trace.csv')))
