@@ -217,6 +217,9 @@ def main():
                          "avg_launch_ms": acc["ms_opt_kernel"] / n_launch,
                          "algorithmic_bytes_per_launch": b_alg / n_launch,
                          "n_eval": int(acc["n_eval"]), "n_patch": int(acc["n_patch"]), "n_filled": int(acc["n_filled"]),
+                         "n_pass": int(acc.get("n_pass", 0)),
+                         "ms_bulk": acc.get("ms_bulk_kernel"), "ms_tail": acc.get("ms_tail_kernel"),
+                         "n_bulk_launches": int(acc.get("n_bulk_launches", 0)), "n_tail_launches": int(acc.get("n_tail_launches", 0)),
                          "kernel_time_share": opt_s / elapsed if elapsed > 0 else None,
                          # the launches of the host threads' streams overlap on the GPU, so each launch's own duration
                          # (above, as the contract asks) stretches; the same bytes over the wall time of the region:

@@ -102,6 +102,14 @@ typedef struct mi_dmrecon_stats {
                              * events (an event pair costs ~12 us of queue time per round) and their mean is
                              * multiplied by the number of tail launches that had work */
     double  ms_sweep_kernels; /* sum of hipEvent durations of the timed generate/apply kernels */
+    /* the two halves of ms_opt_kernel, with their launch counts */
+    double  ms_bulk_kernel; /* host-visible rounds (throughput layout; seeds; the hand-over round) */
+    double  ms_tail_kernel; /* blind tail rounds (latency layout), extrapolated as described above */
+    int64_t n_bulk_launches;
+    int64_t n_tail_launches;
+    int64_t n_pass;         /* fused sampling passes actually run (each gathers the 100 texels of one patch-view
+                             * once; a pass can stand for two of the reference's evaluations, see n_eval) */
+    int64_t truncated;      /* 1 if the propagation ran out of round counters (the call fails with EDEVICE) */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);
@@ -158,7 +166,12 @@ int  mi_dmrecon_global_view_selection(mi_dmrecon_ctx* ctx, const mi_dmrecon_sett
 /* DMRecon::start() for n_refs reference views at once (dmrecon.cc:89-172: analyzeFeatures,
  * globalViewSelection, processFeatures, processQueue).  The views are independent; batching
  * them fills the GPU.  maps[i] / progress[i] belong to ref_views[i]; progress may be NULL.
- * status_out[i] (may be NULL) receives the per-view error code (e.g. MI_DMRECON_EGVS). */
+ * Views end individually, as mvs::DMRecon instances do: status_out[i] (may be NULL) receives the view's own
+ * outcome -- 0, MI_DMRECON_EGVS, MI_DMRECON_EFOOTPRINT (patch_sampler.cc:78-82 throws for that view only) or
+ * MI_DMRECON_ECANCELLED (progress[i].cancelled was set, before or during the run: dmrecon.cc:101-105,353) -- and
+ * the maps of a view that did not finish are left untouched.  progress[i].filled counts that view's pixels.
+ * Return value: 0 if at least one view finished; with a single view (or when every view failed) the failing
+ * view's own code. */
 int  mi_dmrecon_reconstruct(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t n_refs,
                             const int32_t* ref_views, mi_dmrecon_maps* maps,
                             mi_dmrecon_progress* progress, int32_t* status_out, mi_dmrecon_stats* stats);

@@ -69,7 +69,10 @@ class CStats(ctypes.Structure):
     _fields_ = [("n_patch", ctypes.c_int64), ("n_eval", ctypes.c_int64), ("n_filled", ctypes.c_int64),
                 ("n_seeds", ctypes.c_int64), ("n_seeds_ok", ctypes.c_int64), ("n_rounds", ctypes.c_int64),
                 ("n_launches", ctypes.c_int64), ("ms_total", ctypes.c_double),
-                ("ms_opt_kernel", ctypes.c_double), ("ms_sweep_kernels", ctypes.c_double)]
+                ("ms_opt_kernel", ctypes.c_double), ("ms_sweep_kernels", ctypes.c_double),
+                ("ms_bulk_kernel", ctypes.c_double), ("ms_tail_kernel", ctypes.c_double),
+                ("n_bulk_launches", ctypes.c_int64), ("n_tail_launches", ctypes.c_int64),
+                ("n_pass", ctypes.c_int64), ("truncated", ctypes.c_int64)]
 
 
 _lib = None

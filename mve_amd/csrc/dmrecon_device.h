@@ -13,7 +13,8 @@ void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks,
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in = nullptr,
-                        const unsigned* follow_in_n = nullptr, unsigned* follow_out = nullptr, unsigned* follow_out_n = nullptr);
+                        const unsigned* follow_in_n = nullptr, unsigned* follow_out = nullptr, unsigned* follow_out_n = nullptr,
+                        bool windows = false);
 extern unsigned long long* mi_debug_tbuf;
 void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                           const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
@@ -26,11 +27,12 @@ void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_t
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                      const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
 /* one fused tail round: candidates from (prev_work, prev_results, round_work[round - 1]) -> this round's list,
- * results and pixel-state writes (second state slot, see DevJob) */
+ * results and pixel-state writes (second state slot, see DevJob); cand: MI_CAND_BYTES x 4 x cand_cap bytes */
 void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                     const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
-                    DevResult* results, unsigned* round_work, int round, DevCounters* counters);
-/* maps: [slot 0: depth | conf | dz x2 | normal x3][slot 1: same], imaps: [views | upd | mark][views1 | upd1], per batch */
+                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, DevCand* cand,
+                    unsigned cand_cap, bool windows);
+/* maps: [slot 0: depth | conf | dz x2 | normal x3][slot 1: same], imaps: [views | upd | mark][views1 | upd1][arrive], per batch */
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px);
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,

@@ -50,6 +50,8 @@ typedef u32x2 u32x2_a4 __attribute__((aligned(4)));      /* gfx950 global loads 
 typedef const __attribute__((address_space(1))) u32x2_a4* gtex2_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u32x4* gtex4_t;
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+typedef const __attribute__((address_space(1))) u32x4_a4* gtex4u_t;   /* dword-aligned 16-byte load */
 typedef const __attribute__((address_space(1))) uint32_t* gtex_t;
 typedef const __attribute__((address_space(1))) float* gf32_t;
 typedef const __attribute__((address_space(1))) int32_t* gi32_t;
@@ -81,6 +83,21 @@ __shared__ float g_lut[256];                                   /* sRGB -> linear
 __shared__ float g_rays[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterViewDirs */
 __shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterColorSamples */
 __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelection ncc[] */
+
+/* Texel windows.  The 25 samples of a (patch, neighbour view) pair fall into a small box of the view's mip level
+ * (the level rule keeps the sample spacing in (1, 2] texels: at most 10 x 10 texels), and the box hardly moves
+ * between the ~6 passes of a patch.  A view slot therefore stages the box ONCE from HBM (whole rows, contiguous
+ * loads) into its own LDS region and every pass samples LDS; only when the window leaves the box (or does not
+ * fit one) is it staged again / sampled by scattered global gathers.
+ *   Lay<1>  one lane = one view slot: MI_WIN1_W x MI_WIN1_H texels per lane
+ *   Lay<16> a 16-lane row = one view slot: 16 x 16 texels, one row per lane */
+#define MI_WIN1_W 10
+#define MI_WIN1_H 10
+#define MI_WIN16_W 16
+#define MI_WIN16_H 16
+#define MI_NOBOX (-0x40000000)
+__shared__ uint32_t g_win1[WAVE][MI_WIN1_W * MI_WIN1_H];
+__shared__ __attribute__((aligned(16))) uint32_t g_win16[4][MI_WIN16_W * MI_WIN16_H];
 
 /* ------------------------------------------------------------------------- */
 /* Lane layouts.  A patch is optimised by 4 "view slots" (one per local neighbour view);
@@ -142,6 +159,9 @@ template <> struct Lay<1> {
         const unsigned long long b = __ballot(p);
         return (unsigned)(b >> (lane & ~3)) & 0xFu;
     }
+    /* texel window of my view slot */
+    static constexpr int WW = MI_WIN1_W, WH = MI_WIN1_H;
+    __device__ static __forceinline__ uint32_t* win(int lane) { return g_win1[lane]; }
 };
 
 template <> struct Lay<16> {
@@ -192,6 +212,8 @@ template <> struct Lay<16> {
         const unsigned long long b = __ballot(p);
         return (unsigned)((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull));
     }
+    static constexpr int WW = MI_WIN16_W, WH = MI_WIN16_H;
+    __device__ static __forceinline__ uint32_t* win(int lane) { return g_win16[lane >> 4]; }
 };
 
 /* ------------------------------------------------------------------------- */
@@ -220,7 +242,9 @@ struct PatchState {
 struct NView {                   /* my neighbour view at the selected mip level */
     float m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11;   /* K.[R|t]: rows 0,1 pre-multiplied by the level's K */
     int w, h;
-    const uint32_t* img;
+    const uint32_t* img;         /* 16-byte footprint records of the level (DevView::quad) */
+    const uint32_t* win;         /* LDS texel window of my view slot, or null: sample by global gathers */
+    int bx, by;                  /* texel coordinates of the window's origin */
 };
 
 __device__ __forceinline__ void project(const NView& nv, float px, float py, float pz, float& u, float& v) {
@@ -239,27 +263,83 @@ __device__ __forceinline__ void premultiply(NView& nv, float ax, float ay, float
     nv.m4 = ay * nv.m4 + cy * nv.m8; nv.m5 = ay * nv.m5 + cy * nv.m9; nv.m6 = ay * nv.m6 + cy * nv.m10; nv.m7 = ay * nv.m7 + cy * nv.m11;
 }
 
-/* mip level rule of patch_sampler.cc:72-91 / :353-373.  Returns false if nfp <= 0. */
+/* mip level rule of patch_sampler.cc:72-91 / :353-373 from the view-space depth z of the centre patch point.
+ * Returns -1 if nfp <= 0. */
+__device__ __forceinline__ int mip_level(float z, float inv0, float mfp, int maxl) {
+    const float nfp = z * inv0;                  /* SingleView::footPrint */
+    if (!(nfp > 0.f)) return -1;
+    float ratio = nfp / mfp;
+    int mm = 0;
+    while (ratio < 0.5f && mm < MI_MAX_LEVELS) { ++mm; ratio *= 2.f; }
+    return mm > maxl ? maxl : mm;                /* clampLevel with minLevel 0 (dmrecon.cc:240) */
+}
+
+/* One-shot set-up of a view (view selection candidates, parity hook): three dependent loads, no window. */
 __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, int view_id, const PatchState& ps,
                                            NView& nv, int& level) {
     const DevView* V = views + view_id;
     nv.m0 = V->w2c[0]; nv.m1 = V->w2c[1]; nv.m2 = V->w2c[2]; nv.m3 = V->w2c[3];
     nv.m4 = V->w2c[4]; nv.m5 = V->w2c[5]; nv.m6 = V->w2c[6]; nv.m7 = V->w2c[7];
     nv.m8 = V->w2c[8]; nv.m9 = V->w2c[9]; nv.m10 = V->w2c[10]; nv.m11 = V->w2c[11];
-    float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
-    float nfp = z * V->lv[0].inv0;               /* SingleView::footPrint */
-    if (!(nfp > 0.f)) return false;
-    float ratio = nfp / ps.mfp;
-    int mm = 0;
-    while (ratio < 0.5f && mm < MI_MAX_LEVELS) { ++mm; ratio *= 2.f; }
-    int maxl = V->n_levels - 1;                  /* clampLevel with minLevel 0 (dmrecon.cc:240) */
-    mm = mm > maxl ? maxl : mm;
+    const float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
+    const int mm = mip_level(z, V->lv[0].inv0, ps.mfp, V->n_levels - 1);
+    if (mm < 0) return false;
     level = mm;
     const DevLevel& L = V->lv[mm];
     premultiply(nv, L.ax, L.ay, L.cx, L.cy);
     nv.w = L.w; nv.h = L.h;
     nv.img = V->quad + 4 * (size_t)L.tex_off;      /* 16-byte footprint records of this level */
+    nv.win = nullptr; nv.bx = 0; nv.by = 0;
     return true;
+}
+
+/*
+ * A view slot's selected view, kept across the passes of a patch: the per-pass set-up of the reference
+ * (worldToScreen matrices, mip level, patch_sampler.cc:72-91) costs three dependent memory accesses
+ * (global_ids[sel] -> DevView -> DevLevel) when done from scratch, which is most of a pass's latency in the tail.
+ * Cached here, a pass re-evaluates the level rule in registers and touches memory only when the view or its
+ * level changed, or when the texel window has to be staged again.
+ */
+struct ViewC {
+    int sel;                     /* PatchState::sel this cache belongs to (-2 = empty) */
+    int lvl;                     /* mip level the matrices / window belong to (-1 = none) */
+    const DevView* V;
+    float inv0; int maxl;
+    NView nv;                    /* rows 8..11 valid once sel is set; rows 0..7, w, h, img per level */
+    const uint32_t* lin;         /* RGBA8 texels of the level (DevView::img), the window's source */
+};
+
+__device__ __forceinline__ void viewc_reset(ViewC& vc) {
+    vc.sel = -2; vc.lvl = -1; vc.V = nullptr; vc.inv0 = 0.f; vc.maxl = 0; vc.lin = nullptr;
+    vc.nv.win = nullptr; vc.nv.bx = MI_NOBOX; vc.nv.by = MI_NOBOX; vc.nv.w = 0; vc.nv.h = 0; vc.nv.img = nullptr;
+    vc.nv.m0 = vc.nv.m1 = vc.nv.m2 = vc.nv.m3 = vc.nv.m4 = vc.nv.m5 = vc.nv.m6 = vc.nv.m7 = 0.f;
+    vc.nv.m8 = vc.nv.m9 = vc.nv.m10 = vc.nv.m11 = 0.f;
+}
+
+/* Stage the WW x WH texel box at (bx, by) of the level into my view slot's LDS window (rows clamped to the image;
+ * columns past the row end read the next row -- never sampled, the interior test excludes them). */
+template <int LPV>
+__device__ __forceinline__ void stage_window(const uint32_t* lin, int w, int h, int bx, int by, uint32_t* win, int sub) {
+    typedef Lay<LPV> L;
+    if (LPV == 1) {
+#pragma unroll
+        for (int r = 0; r < L::WH; ++r) {
+            const int y = min(by + r, h - 1);
+            const uint32_t* src = lin + (size_t)y * w + bx;
+            const u32x4 a = *(gtex4u_t)(src);
+            const u32x4 b = *(gtex4u_t)(src + 4);
+            const u32x2 c = *(gtex2_t)(src + 8);
+            uint32_t* d = win + r * L::WW;
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w; d[8] = c.x; d[9] = c.y;
+        }
+    } else {
+        /* one row of 16 texels per lane of the view slot */
+        const int y = min(by + sub, h - 1);
+        const uint32_t* src = lin + (size_t)y * w + bx;
+        const u32x4 a = *(gtex4u_t)(src), b = *(gtex4u_t)(src + 4), c = *(gtex4u_t)(src + 8), d4 = *(gtex4u_t)(src + 12);
+        u32x4* d = (u32x4*)(win + sub * L::WW);
+        d[0] = a; d[1] = b; d[2] = c; d[3] = d4;
+    }
 }
 
 struct ColorSums {               /* shifted one-pass sums of the colours of one view at one state */
@@ -301,11 +381,15 @@ struct GNSums {
  * mvs_tools.cc:97-145); one fused pass here gathers them once.
  * Returns PatchSampler::success[v]; sums are complete (reduced over the view slot) on return.
  */
-template <int MODE, int LPV>
+template <int MODE, int LPV, bool WIN>
 __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& nv, const float* __restrict__ s_lut,
                                             const float* __restrict__ rays, const float* __restrict__ mcol,
-                                            ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub) {
+                                            ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub,
+                                            bool& fits) {
+    /* WIN: the texels come from the view slot's LDS window (nv.win, staged by view_prepare); `fits` returns whether
+     * every footprint lay inside it -- if not, the sums are void and the caller repeats the pass with gathers. */
     typedef Lay<LPV> L;
+    fits = true;
     const float cpx = ps.jcx, cpy = ps.jcy, cpz = ps.jcz;
     float step = 0.f, dnorm = 0.f;
     bool ok = true;
@@ -363,7 +447,15 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         const float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
         const int left = (int)floorf(uc), top = (int)floorf(vc);
         q.fx = uc - (float)left; q.fy = vc - (float)top;
-        const uint32_t* r0 = nv.img + (size_t)top * nv.w + left;
+        if (WIN) {
+            /* the 2 x 2 footprint from the LDS window: two ds_read2_b32 */
+            int ox = left - nv.bx, oy = top - nv.by;
+            if ((unsigned)ox > (unsigned)(L::WW - 2) || (unsigned)oy > (unsigned)(L::WH - 2)) fits = false;
+            ox = min(max(ox, 0), L::WW - 2); oy = min(max(oy, 0), L::WH - 2);      /* stay inside my window in any case */
+            const uint32_t* wp = nv.win + (oy * L::WW + ox);
+            q.t.x = wp[0]; q.t.y = wp[1]; q.t.z = wp[L::WW]; q.t.w = wp[L::WW + 1];
+            return q;
+        }
         /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
          * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
          * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1. */
@@ -426,7 +518,14 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             }
         }
     };
-    if (LPV == 1) {
+    if (WIN && LPV != 16) {
+        /* texels in LDS: nothing to prefetch by hand, the compiler interleaves the reads of a row's samples */
+#pragma unroll 1
+        for (int row = 0; row < NITER; row += 5) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) if (row + k < NITER) { Pre q = geom(row + k, ps.depth, true); consume(q); }
+        }
+    } else if (LPV == 1) {
         /* a row of the 5 x 5 window per gather round: its five footprint records are neighbours in memory (1-2
          * cache lines fetched once, five gathers in flight); only the texels stay in registers, the geometry of a
          * sample is computed again when it is consumed (the opaque copy of the depth keeps the compiler from
@@ -498,7 +597,8 @@ __device__ __forceinline__ float eval_color(PatchState& ps, const DevView* views
     ok = false;
     if (gidx < 0) return -1.f;
     if (!setup_view(views, ps.job->global_ids[gidx], ps, nv, level)) return -1.f;
-    ok = sample_pass<PASS_COLOR, LPV>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
+    bool fits_unused;
+    ok = sample_pass<PASS_COLOR, LPV, false>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub, fits_unused);
     ps.n_pass++;
     if (!ok) return -1.f;
     if (count) ps.n_eval++;
@@ -691,18 +791,97 @@ __device__ __forceinline__ bool color_scale_step(PatchState& ps, const DevSettin
     return L::view_ballot(!good, lane) == 0;
 }
 
+/*
+ * Brings my view slot's cache up to the current patch state: view identity, mip level (patch_sampler.cc:72-91),
+ * and -- WIN -- the LDS texel window.  Returns false where the reference's sampling of this view fails before
+ * any texel is read (non-positive footprint; a corner of the 5 x 5 window outside the image, :116-119).
+ */
+template <int LPV, bool WIN>
+__device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, const DevView* __restrict__ views,
+                                             const float* __restrict__ rays, int lane, int sub) {
+    typedef Lay<LPV> L;
+    if (vc.sel != ps.sel) {
+        vc.sel = ps.sel;
+        const DevView* V = views + ps.job->global_ids[ps.sel];
+        vc.V = V;
+        vc.nv.m8 = V->w2c[8]; vc.nv.m9 = V->w2c[9]; vc.nv.m10 = V->w2c[10]; vc.nv.m11 = V->w2c[11];
+        vc.inv0 = V->lv[0].inv0; vc.maxl = V->n_levels - 1;
+        vc.lvl = -1;
+    }
+    NView& nv = vc.nv;
+    const float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
+    const int mm = mip_level(z, vc.inv0, ps.mfp, vc.maxl);
+    if (mm < 0) return false;
+    if (mm != vc.lvl) {
+        vc.lvl = mm;
+        const DevView* V = vc.V;
+        nv.m0 = V->w2c[0]; nv.m1 = V->w2c[1]; nv.m2 = V->w2c[2]; nv.m3 = V->w2c[3];
+        nv.m4 = V->w2c[4]; nv.m5 = V->w2c[5]; nv.m6 = V->w2c[6]; nv.m7 = V->w2c[7];
+        const DevLevel& Lv = V->lv[mm];
+        premultiply(nv, Lv.ax, Lv.ay, Lv.cx, Lv.cy);
+        nv.w = Lv.w; nv.h = Lv.h;
+        nv.img = V->quad + 4 * (size_t)Lv.tex_off;
+        vc.lin = V->img + Lv.tex_off;
+        nv.bx = MI_NOBOX; nv.by = MI_NOBOX;
+    }
+    nv.win = nullptr;
+    if (!WIN) return true;
+    /* bounding box of the window's footprints from its four corner samples (the patch is a planar quad up to the
+     * curvature of the unit rays over 5 pixels; sample_pass checks every footprint against the box anyway) */
+    int lmin = 0x7fffffff, lmax = -0x7fffffff, tmin = 0x7fffffff, tmax = -0x7fffffff;
+    const float wlim = (float)(nv.w - 1), hlim = (float)(nv.h - 1);
+    bool inside_image = true;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = (c & 1 ? 4 : 0) + (c & 2 ? 20 : 0);
+        const int di = (c & 1) ? 2 : -2, dj = (c & 2) ? 2 : -2;
+        const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
+        const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;
+        float u, v;
+        project(nv, ps.jcx + t * rx, ps.jcy + t * ry, ps.jcz + t * rz, u, v);
+        inside_image = inside_image && (u > 0.f && u < wlim && v > 0.f && v < hlim);
+        const int left = (int)floorf(fminf(fmaxf(u, 0.f), wlim - 0.5f)), top = (int)floorf(fminf(fmaxf(v, 0.f), hlim - 0.5f));
+        lmin = min(lmin, left); lmax = max(lmax, left); tmin = min(tmin, top); tmax = max(tmax, top);
+    }
+    if (!inside_image) return false;            /* the pass fails on that corner sample, whatever the others do */
+    const bool inside = nv.bx != MI_NOBOX && lmin >= nv.bx && lmax + 1 <= nv.bx + L::WW - 1
+                     && tmin >= nv.by && tmax + 1 <= nv.by + L::WH - 1;
+    bool have = inside;
+    if (!inside && lmax - lmin <= L::WW - 2 && tmax - tmin <= L::WH - 2) {
+        /* centre the box on the window, keep it inside the image where the image is large enough */
+        int bx = lmin - (L::WW - 2 - (lmax - lmin)) / 2, by = tmin - (L::WH - 2 - (tmax - tmin)) / 2;
+        bx = max(0, min(bx, nv.w - L::WW)); by = max(0, min(by, nv.h - L::WH));
+        nv.bx = bx; nv.by = by;
+        stage_window<LPV>(vc.lin, nv.w, nv.h, bx, by, L::win(lane), sub);
+        have = true;
+    }
+    if (LPV != 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   /* rows staged by the other lanes of my slot */
+    if (have) nv.win = L::win(lane);
+    return true;
+}
+
 /* One fused pass of my view at the current state; sets ps.ncc (getFastNCC).  Returns success[v]. */
-template <int MODE, int LPV>
-__device__ __forceinline__ bool run_pass(PatchState& ps, const DevView* views, const float* s_lut, const float* rays,
-                                         const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int sub) {
+template <int MODE, int LPV, bool WIN>
+__device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevView* views, const float* s_lut, const float* rays,
+                                         const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int lane, int sub) {
+    typedef Lay<LPV> L;
     bool okv = true;
     ps.ncc = -1.f;
     if (MODE == PASS_NORMAL) gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
+    /* the throughput layout without windows has no registers to spare for the cache: set the view up per pass */
+    if (!WIN && LPV == 1) viewc_reset(vc);
     if (ps.sel >= 0) {
-        NView nv;
-        int level_unused;
-        okv = setup_view(views, ps.job->global_ids[ps.sel], ps, nv, level_unused)
-            && sample_pass<MODE, LPV>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
+        okv = view_prepare<LPV, WIN>(ps, vc, views, rays, lane, sub);
+        if (okv) {
+            bool done = false, fits;
+            if (WIN && vc.nv.win) {
+                okv = sample_pass<MODE, LPV, true>(ps, vc.nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub, fits);
+                fits = L::view_all(fits);
+                done = fits || !okv;          /* a failed pass is a failed pass, whatever it read */
+                if (!done) { vc.nv.bx = MI_NOBOX; okv = true; }
+            }
+            if (!done) okv = sample_pass<MODE, LPV, false>(ps, vc.nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub, fits);
+        }
         ps.n_pass++;
         if (okv) {
             ps.ncc = ncc_from_sums(ps, S);
@@ -724,6 +903,7 @@ enum { CTX_CTOR, CTX_FIRST4, CTX_STEP, CTX_REPLACED, CTX_REPASS };
 
 struct Run {
     PatchState ps;
+    ViewC vc;                    /* my view slot's view, level and texel window */
     bool opti, converged, viewRemoved, step_was_normal, need_vs, count_color;
     int iter, need, ctx;
     float oldncc;                /* per view slot: getFastNCC before the step (:189-192) */
@@ -764,6 +944,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     ps.job = job; ps.x = x; ps.y = y; ps.n_eval = 0; ps.n_pass = 0;
     ps.sel = -1; ps.cs0 = ps.cs1 = ps.cs2 = 1.f; ps.ncc = -1.f;
     ps.depth = depth0; ps.dzI = dzI0; ps.dzJ = dzJ0;
+    viewc_reset(R.vc);
     R.opti = true; R.converged = false; R.viewRemoved = false; R.step_was_normal = false;
     R.iter = 0; R.need = PASS_DEPTH; R.ctx = CTX_CTOR; R.oldncc = -1.f; R.need_vs = false; R.count_color = false;
     /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
@@ -821,7 +1002,11 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     ps.sqrDevX = sd;
     /* computePatchPoints */
     if (!set_state(ps, rays, depth0, dzI0, dzJ0)) return false;
-    if (!(ps.mfp > 0.f)) { err |= 1u; return false; }      /* reference throws std::out_of_range here */
+    if (!(ps.mfp > 0.f)) {                                 /* reference throws std::out_of_range here: the VIEW fails */
+        err |= 1u;
+        atomicOr(const_cast<int32_t*>(&job->flags), (int)MI_JOB_EFOOTPRINT);
+        return false;
+    }
 
     /* --- LocalViewSelection ctor (local_view_selection.cc:19-54) */
     ps.avail = job->n_global >= 32 ? 0xFFFFFFFFu : ((1u << job->n_global) - 1u);
@@ -849,7 +1034,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
  * fused pass at the current state (colour sums + the Gauss-Newton sums the NEXT step needs), finish the
  * decision of the step that led here, take the next step.  Returns false when the optimisation is over.
  */
-template <int LPV>
+template <int LPV, bool WIN>
 __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const DevView* views, int lane) {
     typedef Lay<LPV> L;
     PatchState& ps = R.ps;
@@ -881,10 +1066,10 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     }
     bool okv;
     TSTAMP(20 + R.need);
-    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
-    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
-    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
-    else okv = run_pass<PASS_COLOR, LPV>(ps, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
+    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV, WIN>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, lane, sub);
+    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV, WIN>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, lane, sub);
+    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV, WIN>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, lane, sub);
+    else okv = run_pass<PASS_COLOR, LPV, WIN>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, lane, sub);
     TSTAMP(30);
     /* ---- finish what led to this pass */
     if (R.ctx == CTX_CTOR || R.ctx == CTX_REPLACED) {
@@ -1033,7 +1218,7 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
     res.conf = (dotP < 0.2f) ? 0.f : score;
 }
 
-template <int LPV>
+template <int LPV, bool WIN>
 __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
                                float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane,
                                PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err) {
@@ -1043,7 +1228,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     /* diagnostic build: turns per patch vs turns per wavefront (lane divergence of the throughput layout) */
     unsigned turns = 0;
     if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err))
-        do { ++turns; } while (run_turn<LPV>(R, st, views, lane));
+        do { ++turns; } while (run_turn<LPV, WIN>(R, st, views, lane));
     if (LPV == 1 && g_hist) {
         unsigned mx = turns;
         for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
@@ -1052,7 +1237,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     }
 #else
     if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err))
-        while (run_turn<LPV>(R, st, views, lane)) { }
+        while (run_turn<LPV, WIN>(R, st, views, lane)) { }
 #endif
     TSTAMP(40);
     run_end<LPV>(R, st, lane, res, n_eval, n_pass);
@@ -1085,31 +1270,14 @@ struct OptArgs {
 };
 
 /*
- * Pixel state as the optimisations of round `round` must see it: frozen at the end of round - 1.
- * VER = false (host-visible rounds: writes happen in a separate k_apply launch): slot 0 is the state.
- * VER = true (fused tail rounds): the slot with the larger stamp that is older than `round`.
- */
-struct PixState { const float* depth; const float* dz; const float* conf; const uint32_t* views; int upd; };
-template <bool VER>
-__device__ __forceinline__ PixState pix_state(const DevJob* job, int p, int round) {
-    PixState s;
-    const int s0 = GI(job->upd + p);
-    if (!VER) { s.depth = job->depth; s.dz = job->dz; s.conf = job->conf; s.views = job->views; s.upd = s0; return s; }
-    const int s1 = GI(job->upd1 + p);
-    const bool one = s0 >= round || (s1 < round && s1 > s0);
-    s.depth = one ? job->depth1 : job->depth; s.dz = one ? job->dz1 : job->dz; s.conf = one ? job->conf1 : job->conf;
-    s.views = one ? job->views1 : job->views; s.upd = one ? s1 : s0;
-    return s;
-}
-
-/*
- * All optimisation attempts of one work-list entry (pixel x, y of `job`), result into a.results[e].
- * Explicit mode (seeds, parity hook): the one hypothesis given.  Propagate mode: the queue semantics of
+ * All optimisation attempts of one work-list entry (pixel x, y of `job`) of a host-visible round, result into
+ * a.results[e].  Explicit mode (seeds, parity hook): the one hypothesis given.  Propagate mode: the queue semantics of
  * dmrecon.cc:365-392 for the hypotheses pulled from the 4-neighbours that were written last round, best
  * confidence first.  Nothing but `best` and a 4-bit mask is kept in registers across an optimisation (the
- * candidates are re-read from the frozen state).  Returns true if the pixel state must be overwritten.
+ * candidates are re-read from the state, which a host-visible round does not write -- k_apply does).
+ * Returns true if the pixel state must be overwritten.
  */
-template <int LPV, bool VER>
+template <int LPV, bool WIN>
 __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, const DevJob* job, int x, int y, int lane,
                                               unsigned& n_eval, unsigned& n_pass, unsigned& n_patch, unsigned& err, bool& more) {
     typedef Lay<LPV> L;
@@ -1119,7 +1287,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
     const int W = job->w;
     const int pix = y * W + x;
     float own = 0.f;
-    if (!explicit_hyp) { const PixState me = pix_state<VER>(job, pix, a.round); own = GF(me.conf + pix); }
+    if (!explicit_hyp) own = GF(job->conf + pix);
     float best = own;
     unsigned tried = 0;
     bool accepted = false;
@@ -1147,9 +1315,8 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if ((tried >> k) & 1u) continue;
-                const PixState nbs = pix_state<VER>(job, nb[k], a.round);
-                const float c = GF(nbs.conf + nb[k]);
-                const bool use = nbs.upd == a.round - 1 && (own < c - 0.05f || own == 0.f);
+                const float c = GF(job->conf + nb[k]);
+                const bool use = GI(job->upd + nb[k]) == a.round - 1 && (own < c - 0.05f || own == 0.f);
                 if (use && (bi < 0 || c > bc)) { bi = k; bc = c; }
             }
             if (bi < 0) break;
@@ -1162,12 +1329,11 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
             tried |= 1u << bi;
             if (best > bc) continue;                           /* dmrecon.cc:371 */
             const int p = nb[bi];
-            const PixState src = pix_state<VER>(job, p, a.round);
-            hd = GF(src.depth + p); hi = GF(src.dz + 2 * p); hj = GF(src.dz + 2 * p + 1); hv = GU(src.views + p);
+            hd = GF(job->depth + p); hi = GF(job->dz + 2 * p); hj = GF(job->dz + 2 * p + 1); hv = GU(job->views + p);
         }
         PatchResult r;
         TSTAMP(3);
-        optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
+        optimize_patch<LPV, WIN>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
         TSTAMP(4);
         ++n_patch; ++attempts;
         const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
@@ -1214,9 +1380,11 @@ __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, 
 /*
  * The hot kernel.  LPV = 1: 16 patches per wavefront (throughput); LPV = 16: one patch per
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
+ * WIN: neighbour-view texels staged through per-view-slot LDS windows (the wavefronts per SIMD follow from
+ * the LDS footprint then: 25.6 KB of windows per wavefront in the throughput layout).
  */
-template <int LPV>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_WAVES_PER_SIMD, MI_WAVES_PER_SIMD))) void k_optimize(OptArgs a) {
+template <int LPV, bool WIN>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && LPV == 1) ? 1 : (LPV == 16 ? 2 : MI_WAVES_PER_SIMD)), ((WIN && LPV == 1) ? 2 : (LPV == 16 ? 2 : MI_WAVES_PER_SIMD))))) void k_optimize(OptArgs a) {
     typedef Lay<LPV> L;
     const int lane = threadIdx.x;
 #ifdef MI_TIMING
@@ -1235,8 +1403,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_WAVES_P
     for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < n; i += gridDim.x * L::PATCHES) {
         const unsigned e = a.follow_in ? a.follow_in[i] : i;
         const DevEntry ent = a.work[e];
-        bool more;
-        process_entry<LPV, false>(a, e, a.jobs + ent.job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
+        bool more = false;
+        const DevJob* job = a.jobs + ent.job;
+        if (GI(&job->flags) != 0) {
+            /* the view failed (footprint exception) or was cancelled: nothing of it is touched any more */
+            if (L::vslot(lane) == 0 && L::sub(lane) == 0) a.results[e].accepted = 0;
+        } else
+            process_entry<LPV, WIN>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
         if (a.follow_out) {
             /* wave-aggregated append of the entries that still have candidates (one atomic per wavefront) */
             const bool mine = more && L::vslot(lane) == 0 && L::sub(lane) == 0;
@@ -1254,67 +1427,166 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_WAVES_P
 }
 
 /*
- * One fused round of the propagation tail (replaces expand -> optimise -> apply, three dependent launches, by
- * one): a wavefront takes a candidate = (entry accepted in the previous round, one of its 4-neighbours),
- * applies the push rule (dmrecon.cc:400-431) against the state frozen at the end of the previous round, claims
- * the pixel (atomicMax on its mark: each pixel is processed once per round, whoever claims it), appends it to
- * this round's list, optimises it in the latency layout and writes an accepted result into the pixel's other
- * state slot (see DevJob).  Which candidate claims a pixel, and the order of the list, depend on timing; the
- * results do not: every optimisation reads the frozen state only.
+ * One fused round of the propagation tail (replaces generate -> optimise -> apply, three dependent launches, by one).
+ *
+ * Unit of work = a CANDIDATE: (pixel p accepted in the previous round, one of its 4-neighbours q).  If the push
+ * rule (dmrecon.cc:400-431) holds against the state frozen at the end of the previous round, ONE wavefront
+ * optimises q from p's result (latency layout) -- every candidate of q at the same time, on its own wavefront.
+ * The reference would try q's candidates one after the other, best source confidence first, skipping a candidate
+ * once q has got a confidence above its source's (pop-time test, dmrecon.cc:371) and accepting a result only if
+ * it beats the best so far (:391).  The optimisations themselves do not depend on each other (they all read the
+ * frozen state), so they run speculatively in parallel and the sequential rule is applied afterwards by the last
+ * of q's candidates to finish (per-pixel arrival counter; results of the others through DevCand records):
+ * same results, but a round is as long as ONE patch optimisation instead of up to four in a row.
+ *
+ * The resolver writes an accepted result into the pixel's other state slot (see DevJob) and appends q to this
+ * round's list.  Which wavefront resolves, and the order of the list, depend on timing; the results do not.
  */
+struct DevCand {                  /* result of one speculative attempt (MI_CAND_BYTES) */
+    float conf, depth, dzI, dzJ, nx, ny, nz;
+    uint32_t views;
+    int32_t iters;
+    uint32_t n_eval, n_pass;
+    uint32_t pad;
+};
+static_assert(sizeof(DevCand) == MI_CAND_BYTES, "DevCand size");
 struct TailArgs {
     OptArgs o;                    /* o.work / o.results: this round's list and results (written here) */
     const DevEntry* prev_work;    /* previous round's list, results and entry count */
     const DevResult* prev_results;
-    unsigned* round_work;         /* [MI_MAX_ROUNDS] entries per round */
+    unsigned* round_work;         /* [MI_MAX_ROUNDS] accepted entries per round */
+    DevCand* cand;                /* [4 * cand_cap] attempt results of this round, indexed 4 * source entry + direction */
+    unsigned cand_cap;            /* the previous round's list must not be longer (else: error flag 2, round not run) */
 };
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_WAVES_PER_SIMD, MI_WAVES_PER_SIMD))) void k_tail(TailArgs t) {
+
+/* state of pixel p as the optimisations of round `round` must see it (frozen at the end of round - 1):
+ * the slot with the larger stamp that is older than `round`.  Both slots are loaded at once (one latency). */
+struct Frozen { float conf; int upd; bool one; };
+__device__ __forceinline__ Frozen frozen_state(const DevJob* job, int p, int round) {
+    const int s0 = GI(job->upd + p), s1 = GI(job->upd1 + p);
+    const float c0 = GF(job->conf + p), c1 = GF(job->conf1 + p);
+    Frozen f;
+    f.one = s0 >= round || (s1 < round && s1 > s0);
+    f.conf = f.one ? c1 : c0; f.upd = f.one ? s1 : s0;
+    return f;
+}
+
+template <bool WIN>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tail(TailArgs t) {
     typedef Lay<16> L;
     const OptArgs& a = t.o;
     const int lane = threadIdx.x;
     const unsigned n_prev = t.round_work[a.round - 1];
-    if (n_prev == 0) return;
+    if (blockIdx.x >= 4u * n_prev) return;
+    if (n_prev > t.cand_cap) { if (lane == 0 && blockIdx.x == 0) atomicOr(&a.counters->error_flags, 2u); return; }
     for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
     __syncthreads();
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;
     for (unsigned cand = blockIdx.x; cand < 4u * n_prev; cand += gridDim.x) {
         const unsigned ep = cand >> 2, k = cand & 3u;
-        const DevResult* pr = t.prev_results + ep;
-        if (!pr->accepted) continue;
+        const DevResult pr = t.prev_results[ep];
         const DevEntry src = t.prev_work[ep];
+        if (!pr.accepted) continue;
         const DevJob* job = a.jobs + src.job;
+        if (GI(&job->flags) != 0) continue;                                    /* failed / cancelled view */
         const int W = job->w, H = job->h;
         const int qx = (src.xy & 0xFFFF) + (k == 0 ? -1 : k == 1 ? 1 : 0), qy = (src.xy >> 16) + (k == 2 ? -1 : k == 3 ? 1 : 0);
         if (qx < 2 || qy < 2 || qx >= W - 2 || qy >= H - 2) continue;         /* patch_sampler.cc:47-50 */
         const int q = qy * W + qx;
-        const PixState me = pix_state<true>(job, q, a.round);
-        const float own = GF(me.conf + q), c = pr->conf;
-        if (!(own < c - 0.05f || own == 0.f)) continue;
-        unsigned e = 0xFFFFFFFFu;
-        if (lane == 0) {
-            if (atomicMax(&job->mark[q], a.round) < a.round) {
-                e = atomicAdd(&t.round_work[a.round], 1u);
-                DevEntry o; o.job = src.job; o.xy = qx | (qy << 16);
-                const_cast<DevEntry*>(a.work)[e] = o;
+        /* frozen state of q and of its four neighbours, all loads in flight together */
+        const int nb[4] = {q - 1, q + 1, q - W, q + W};
+        const Frozen me = frozen_state(job, q, a.round);
+        Frozen nf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nf[j] = frozen_state(job, nb[j], a.round);
+        const float own = me.conf;
+        if (!(own < pr.conf - 0.05f || own == 0.f)) continue;
+        /* q's candidates of this round: neighbours written last round for which the push rule holds */
+        unsigned elig = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (nf[j].upd == a.round - 1 && (own < nf[j].conf - 0.05f || own == 0.f)) elig |= 1u << j;
+        const int n_cand = __popc(elig);
+        const int mine = (int)(k ^ 1u);                                        /* my source seen from q */
+        /* speculative attempt from my source's result */
+        PatchResult r;
+        unsigned ce = 0, cp = 0;
+        optimize_patch<16, WIN>(job, a.st, a.views, qx, qy, pr.depth, pr.dzI, pr.dzJ, pr.views, lane, r, ce, cp, err);
+        /* counters of optimize_patch are per view slot (row leaders): bring them to lane 0 */
+        ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
+                      + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
+        cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
+                      + __builtin_amdgcn_readlane((int)cp, 32) + __builtin_amdgcn_readlane((int)cp, 48));
+        bool resolver = true;
+        if (n_cand > 1) {
+            int old = 0;
+            if (lane == 0) {
+                DevCand o;
+                o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ; o.nx = r.nx; o.ny = r.ny; o.nz = r.nz;
+                o.views = r.views; o.iters = r.iters; o.n_eval = ce; o.n_pass = cp; o.pad = 0;
+                t.cand[cand] = o;
+                __threadfence();                                               /* release: the record before the count */
+                old = atomicAdd(&job->arrive[q], 1);
+            }
+            old = __builtin_amdgcn_readfirstlane(old);
+            resolver = old == n_cand - 1;
+            if (resolver) {
+                if (lane == 0) job->arrive[q] = 0;                             /* every candidate has arrived: ready for the next round */
+                __threadfence();                                               /* acquire: the other candidates' records */
             }
         }
-        e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
-        if (e == 0xFFFFFFFFu) continue;                                        /* another candidate owns the pixel */
-        bool more;
-        const bool accepted = process_entry<16, true>(a, e, job, qx, qy, lane, n_eval, n_pass, n_patch, err, more);
+        if (!resolver) continue;
+        /* the reference's sequential rule over q's candidates, descending source confidence (ties: lowest direction) */
+        float best = own;
+        bool accepted = false;
+        PatchResult fin = r;
+        unsigned done = 0;
+        for (int s = 0; s < n_cand; ++s) {
+            int bi = -1; float bc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (((elig >> j) & 1u) && !((done >> j) & 1u) && (bi < 0 || nf[j].conf > bc)) { bi = j; bc = nf[j].conf; }
+            done |= 1u << bi;
+            if (best > bc) break;                                              /* dmrecon.cc:371 (and every later one) */
+            PatchResult c = r; unsigned xe = ce, xp = cp;
+            if (bi != mine) {
+                const unsigned oc = 4u * (unsigned)GI(job->mark + nb[bi]) + (unsigned)(bi ^ 1);
+                const DevCand o = t.cand[oc];
+                c.conf = o.conf; c.depth = o.depth; c.dzI = o.dzI; c.dzJ = o.dzJ; c.nx = o.nx; c.ny = o.ny; c.nz = o.nz;
+                c.views = o.views; c.iters = o.iters; xe = o.n_eval; xp = o.n_pass;
+            }
+            if (lane == 0) { n_eval += xe; n_pass += xp; ++n_patch; }          /* attempts the reference would have made */
+            if (c.conf > 0.f && best < c.conf) { best = c.conf; accepted = true; fin = c; }   /* dmrecon.cc:378,391 */
+        }
         if (accepted && lane == 0) {
-            const DevResult r = a.results[e];                                  /* written by this lane */
-            const bool one = me.conf == job->conf1;                            /* slot holding the old state */
+            const unsigned e = atomicAdd(&t.round_work[a.round], 1u);
+            DevEntry we; we.job = src.job; we.xy = qx | (qy << 16);
+            const_cast<DevEntry*>(a.work)[e] = we;
+            DevResult o;
+            o.conf = fin.conf; o.depth = fin.depth; o.dzI = fin.dzI; o.dzJ = fin.dzJ;
+            o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.iters = fin.iters;
+            o.accepted = 1; o.tried = done;
+            a.results[e] = o;
+            job->mark[q] = (int)e;                                             /* where next round's resolvers find my attempts */
+            const bool one = me.one;                                           /* slot holding the old state */
             float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
-            float* cp = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
+            float* cq = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
             uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
-            dp[q] = r.depth; zp[2 * q] = r.dzI; zp[2 * q + 1] = r.dzJ;
-            np[3 * q] = r.nx; np[3 * q + 1] = r.ny; np[3 * q + 2] = r.nz;
-            cp[q] = r.conf; vp[q] = r.views; up[q] = a.round;
-            if (own <= 0.f) ++n_filled;
+            dp[q] = fin.depth; zp[2 * q] = fin.dzI; zp[2 * q + 1] = fin.dzJ;
+            np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
+            cq[q] = fin.conf; vp[q] = fin.views; up[q] = a.round;
+            if (own <= 0.f) { ++n_filled; atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u); }
         }
     }
-    flush_counters<16>(a.counters, lane, n_eval, n_pass, n_patch, n_filled, err);
+    /* n_eval / n_pass / n_patch / n_filled were kept by lane 0 only */
+    if (lane == 0) {
+        if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
+        if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
+        if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
+        if (n_filled) atomicAdd(&a.counters->n_filled, (unsigned long long)n_filled);
+    }
+    for (int off = 32; off > 0; off >>= 1) err |= __shfl_down(err, off);
+    if (lane == 0 && err) atomicOr(&a.counters->error_flags, err);
 }
 
 /* Fold the second state slot back into the first where it is the newer one (after the last tail round). */
@@ -1405,8 +1677,9 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
         const float ncc = eval_color<1>(ps, a.views, g, s_lut, s_rays, s_mcol, S, okc, true, 0);
         a.ncc[g] = ncc;
         NView nv; int level = -1; GNSums gn;
+        bool fits_unused;
         bool okd = setup_view(a.views, job->global_ids[g], ps, nv, level)
-            && sample_pass<PASS_DUMP, 1>(ps, nv, s_lut, s_rays, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0);
+            && sample_pass<PASS_DUMP, 1, false>(ps, nv, s_lut, s_rays, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0, fits_unused);
         a.ok[g] = okd ? 1 : 0;
         a.level[g] = level;
     }
@@ -1437,6 +1710,7 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
     __shared__ unsigned s_wave_cnt[4];
     __shared__ unsigned s_base;
     const DevJob* job = a.jobs + blockIdx.y;
+    if (job->flags != 0) return;                 /* failed / cancelled view */
     const int W = job->w, H = job->h;
     const int tiles_x = (W + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, tiles_y = (H + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
     if ((int)blockIdx.x >= tiles_x * tiles_y) return;
@@ -1513,17 +1787,29 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
     for (unsigned base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
         const unsigned e = base + threadIdx.x;
         bool newly = false;
+        int myjob = -1;
         if (e < n) {
             const DevResult r = a.results[e];
             if (r.accepted) {
                 const DevEntry ent = a.work[e];
                 const DevJob* job = a.jobs + ent.job;
+                myjob = ent.job;
                 const int pix = (ent.xy >> 16) * job->w + (ent.xy & 0xFFFF);
                 newly = job->conf[pix] <= 0.f;
                 write_pixel(job, pix, r, a.round);
+                job->mark[pix] = (int)e;          /* entry index: where a following tail round finds this pixel's attempts */
             }
         }
         filled += (unsigned)__popcll(__ballot(newly));
+        /* Progress::filled per view: one atomic per (wavefront, job) */
+        unsigned long long todo = __ballot(newly);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lj = __shfl(myjob, leader);
+            const unsigned long long same = __ballot(newly && myjob == lj);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(const_cast<uint32_t*>(&a.jobs[lj].n_filled), (unsigned)__popcll(same));
+            todo &= ~same;
+        }
     }
     if (filled && (threadIdx.x & 63) == 0) atomicAdd(&a.counters->n_filled, (unsigned long long)filled);
 }
@@ -1548,6 +1834,7 @@ __global__ __launch_bounds__(256) void k_apply_seeds(ApplyArgs a) {
             } else if (*slot == key) {
                 newly = job->conf[pix] <= 0.f;
                 write_pixel(job, pix, r, a.round);
+                if (newly) atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u);
             }
         }
     }
@@ -1630,7 +1917,7 @@ void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks,
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n) {
+                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows) {
     if (grid_blocks == 0) return;
     OptArgs a;
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
@@ -1638,10 +1925,13 @@ void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks,
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
     a.max_attempts = follow_out ? 1 : 4; a.follow_in = follow_in; a.follow_in_n = follow_in_n;
     a.follow_out = follow_out; a.follow_out_n = follow_out_n;
-    if (lanes_per_view == 16)
-        hipLaunchKernelGGL(k_optimize<16>, dim3(grid_blocks), dim3(WAVE), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_optimize<1>, dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    if (lanes_per_view == 16) {
+        if (windows) hipLaunchKernelGGL((k_optimize<16, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_optimize<16, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    } else {
+        if (windows) hipLaunchKernelGGL((k_optimize<1, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_optimize<1, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    }
 }
 
 void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
@@ -1671,14 +1961,17 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
 
 void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                     const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
-                    DevResult* results, unsigned* round_work, int round, DevCounters* counters) {
+                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, DevCand* cand,
+                    unsigned cand_cap, bool windows) {
     TailArgs t;
+    t.cand = cand; t.cand_cap = cand_cap;
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
-    hipLaunchKernelGGL(k_tail, dim3(grid_blocks), dim3(WAVE), 0, s, t);
+    if (windows) hipLaunchKernelGGL(k_tail<true>, dim3(grid_blocks), dim3(WAVE), 0, s, t);
+    else hipLaunchKernelGGL(k_tail<false>, dim3(grid_blocks), dim3(WAVE), 0, s, t);
 }
 
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px) {

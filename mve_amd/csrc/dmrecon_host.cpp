@@ -133,6 +133,14 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+/* rounds of the propagation tail enqueued per read-back (even: the list buffers ping-pong per round) */
+#define MI_TAIL_CHUNK 32
+/* MI_DMRECON_WIN default: LDS texel windows in both lane layouts */
+#ifndef MI_WIN_DEFAULT
+#define MI_WIN_DEFAULT 3
+#endif
+struct TailPoll { unsigned rw[MI_TAIL_CHUNK]; DevCounters hc; };
+
 struct JobHost {          /* host-side plan of one reference view */
     int ref_view = -1;
     int status = MI_DMRECON_OK;
@@ -186,6 +194,12 @@ struct mi_dmrecon_ctx {
     DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
     DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
     DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
+    DevBuf<uint8_t> d_cand;                  /* tail rounds: DevCand attempt records, 4 per source entry */
+    TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    uint8_t* h_dyn = nullptr;                /* pinned: two read-backs of the job table (its flags / n_filled words are polled) */
+    size_t h_dyn_cap = 0;
+    std::vector<int32_t> h_jobdyn;           /* staging of the flag words written to dead jobs */
     std::vector<hipEvent_t> events;
 };
 
@@ -411,9 +425,9 @@ DevSettings dev_settings(const mi_dmrecon_settings* st) {
 int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px) {
     total_px = 0;
     for (size_t j = 0; j < jobs.size(); ++j) { jobs[j].pix_off = total_px; total_px += (size_t)jobs[j].w * jobs[j].h; }
-    /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd, mark + views1, upd1 */
+    /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd, mark + views1, upd1 + arrive */
     if (c->d_maps.reserve(total_px * 14)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
-    if (c->d_imaps.reserve(total_px * 5)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
+    if (c->d_imaps.reserve(total_px * 6)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
     float* base = c->d_maps.p;
     float* base1 = base + 7 * total_px;
     uint32_t* ibase = c->d_imaps.p;
@@ -432,10 +446,12 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
         dj[j].normal1 = base1 + 4 * total_px + 3 * o;
         dj[j].views1 = ibase + 3 * total_px + o;
         dj[j].upd1 = (int32_t*)(ibase + 4 * total_px + o);
+        dj[j].arrive = (int32_t*)(ibase + 5 * total_px + o);
     }
     /* slot 1 is only ever read where its stamp says so: the stamps (0xFF.. = -1) are all it needs */
     HIP_TRY(hipMemsetAsync(c->d_maps.p, 0, total_px * 7 * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * 5 * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_imaps.p + 5 * total_px, 0, total_px * sizeof(uint32_t), c->stream));
     return 0;
 }
 
@@ -498,6 +514,10 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
     c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release(); c->d_follow.release(); c->d_follow_cnt.release();
     c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release();
+    c->d_cand.release();
+    if (c->h_poll) (void)hipHostFree(c->h_poll);
+    if (c->h_dyn) (void)hipHostFree(c->h_dyn);
+    for (int k = 0; k < 2; ++k) if (c->poll_ev[k]) (void)hipEventDestroy(c->poll_ev[k]);
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
     delete c;                                 /* the scene store goes with its last owner */
@@ -697,47 +717,50 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
-    auto cancelled = [&]() {
-        if (!progress) return false;
-        for (int i = 0; i < n_refs; ++i) if (progress[i].cancelled) return true;
-        return false;
-    };
-    for (int i = 0; progress && i < n_refs; ++i) {
-        progress[i].start_time = (uint64_t)std::time(nullptr);
-        progress[i].status = MI_RECON_GLOBALVS;
+    /* outcome per reference view (status_out): a view whose planning fails, whose footprint turns non-positive or
+     * that is cancelled ends alone, the others of the call go on (apps/dmrecon/dmrecon.cc:314-317) */
+    std::vector<int> view_rc(n_refs, 0);
+    for (int i = 0; i < n_refs; ++i) {
+        if (progress) progress[i].start_time = (uint64_t)std::time(nullptr);
+        if (progress && progress[i].cancelled) { view_rc[i] = MI_DMRECON_ECANCELLED; progress[i].status = MI_RECON_CANCELLED; }   /* dmrecon.cc:101-105 */
+        else if (progress) progress[i].status = MI_RECON_GLOBALVS;
     }
     /* ---- host planning: global view selection and seeds, one plan per reference view */
     std::vector<JobHost> plans(n_refs);
     std::vector<int> job_of(n_refs, -1);
-    std::vector<int> plan_rc(n_refs, 0);
     std::vector<std::string> plan_err(n_refs);
     const int n_threads = std::max(1, std::min(std::min(n_refs, omp_get_num_procs()), 32));
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
     for (int i = 0; i < n_refs; ++i) {
+        if (view_rc[i]) continue;
         plans[i].ref_view = ref_views[i];
         int r = plan_global_views(c, st, ref_views[i], plans[i].global);
         if (r == 0 && plans[i].global.empty()) r = fail(MI_DMRECON_EGVS, "Global View Selection failed");
-        plan_rc[i] = r;
+        view_rc[i] = r;
         if (r) plan_err[i] = g_err;
     }
     mark("global view selection");
     std::vector<JobHost> jobs;
+    std::vector<int> ref_of_job;
     for (int i = 0; i < n_refs; ++i) {
-        if (status_out) status_out[i] = plan_rc[i];
-        if (plan_rc[i]) {
-            if (n_refs == 1) { g_err = plan_err[i]; return plan_rc[i]; }
+        if (status_out) status_out[i] = view_rc[i];
+        if (view_rc[i]) {
+            if (n_refs == 1) { g_err = view_rc[i] == MI_DMRECON_ECANCELLED ? "cancelled" : plan_err[i]; return view_rc[i]; }
             continue;
         }
         HostLevel const& L = c->sc->views[ref_views[i]].levels[st->scale];
         plans[i].w = L.w; plans[i].h = L.h;
         job_of[i] = (int)jobs.size();
+        ref_of_job.push_back(i);
         jobs.push_back(plans[i]);
     }
-    if (jobs.empty()) return fail(MI_DMRECON_EGVS, "Global View Selection failed for every reference view");
-    for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_FEATURES;
+    if (jobs.empty()) {
+        for (int i = 0; i < n_refs; ++i) if (view_rc[i] != MI_DMRECON_ECANCELLED) return fail(MI_DMRECON_EGVS, "Global View Selection failed for every reference view");
+        return fail(MI_DMRECON_ECANCELLED, "cancelled");
+    }
+    for (int i = 0; progress && i < n_refs; ++i) if (view_rc[i] == 0) progress[i].status = MI_RECON_FEATURES;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
     for (int j = 0; j < (int)jobs.size(); ++j) plan_seeds(c, st, jobs[j], j);
-    if (cancelled()) { for (int i = 0; i < n_refs; ++i) progress[i].status = MI_RECON_CANCELLED; return fail(MI_DMRECON_ECANCELLED, "cancelled"); }
 
     mark("seed planning");
     rc = sync_views(c);
@@ -809,117 +832,208 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                               c->d_keys.p, c->d_keyoff.p);
         ev_end();
     }
-    for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_QUEUE;
+    for (int i = 0; progress && i < n_refs; ++i) if (view_rc[i] == 0) progress[i].status = MI_RECON_QUEUE;
     /* ---- propagation sweeps (replace DMRecon::processQueue, dmrecon.cc:333-434).
      * Phase A: while the work list is large, one host-visible round at a time with the throughput
      *          layout (16 patches per wavefront), grid sized to the list.
      * Phase B: the long tail of small rounds is enqueued blind in chunks -- the kernels read the
      *          round's list size from device memory -- with the latency layout (one patch per
-     *          wavefront), so a round costs a few tens of microseconds instead of a host round trip. */
+     *          wavefront, every candidate hypothesis of a pixel on its own wavefront), two chunks in flight. */
     unsigned TAIL_THRESHOLD = 12288;
     if (const char* e = std::getenv("MI_DMRECON_TAIL_THRESHOLD")) TAIL_THRESHOLD = (unsigned)std::atoi(e);
-    const unsigned TAIL_GRID = 3072, TAIL_CHUNK = 32;
+    const unsigned TAIL_GRID = 4096, TAIL_CHUNK = MI_TAIL_CHUNK;
     static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
-    const int BULK_LPV = 1;
-    const unsigned BULK_PPW = (unsigned)MI_PATCHES_PER_WAVE;
+    /* texel windows in LDS: bit 0 = latency layout (tail rounds), bit 1 = throughput layout (bulk rounds) */
+    const int USE_WIN = [] { const char* e = std::getenv("MI_DMRECON_WIN"); return e ? std::atoi(e) : MI_WIN_DEFAULT; }();
+    const bool WIN_TAIL = (USE_WIN & 1) != 0, WIN_BULK = (USE_WIN & 2) != 0;
+    /* diagnostic: MI_DMRECON_BULK_LPV=16 runs the host-visible rounds in the latency layout too (sequential attempts
+     * per entry) -- the bit-exact reference for the speculative tail rounds, see tests/test_gpu_parity.py */
+    const int BULK_LPV = [] { const char* e = std::getenv("MI_DMRECON_BULK_LPV"); return (e && std::atoi(e) == 16) ? 16 : 1; }();
+    const unsigned BULK_PPW = BULK_LPV == 16 ? 1u : (unsigned)MI_PATCHES_PER_WAVE;
+    const size_t cand_cap = std::min<size_t>(work_cap, 1u << 18);
+    if (c->d_cand.reserve(4 * cand_cap * MI_CAND_BYTES)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(attempt records) failed");
+    if (!c->h_poll) {
+        if (hipHostMalloc((void**)&c->h_poll, 2 * sizeof(TailPoll), hipHostMallocDefault) != hipSuccess)
+            return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(poll buffer) failed");
+        for (int k = 0; k < 2; ++k) if (hipEventCreateWithFlags(&c->poll_ev[k], hipEventDisableTiming) != hipSuccess)
+            return fail(MI_DMRECON_EDEVICE, "hipEventCreate failed");
+    }
+    if (c->h_jobdyn.size() < 2 * (size_t)nj) c->h_jobdyn.resize(2 * (size_t)nj);
+    if (c->h_dyn_cap < 2 * (size_t)nj * sizeof(DevJob)) {
+        if (c->h_dyn) (void)hipHostFree(c->h_dyn);
+        c->h_dyn = nullptr; c->h_dyn_cap = 0;
+        const size_t want = 2 * ((size_t)nj + 16) * sizeof(DevJob);
+        if (hipHostMalloc((void**)&c->h_dyn, want, hipHostMallocDefault) != hipSuccess)
+            return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(job poll buffer) failed");
+        c->h_dyn_cap = want;
+    }
+    auto dyn_of = [&](int slot) -> DevJob* { return (DevJob*)c->h_dyn + (size_t)slot * nj; };
+    bool first_phase_a = true, ran_tail = false;
     int round = 1;
-    const int max_rounds = std::min<int>(MI_MAX_ROUNDS - TAIL_CHUNK - 2, 4 * (max_px > 0 ? (int)std::sqrt((double)max_px) * 4 : 1) + 64);
+    const int max_rounds = MI_MAX_ROUNDS - 2 * (int)TAIL_CHUNK - 2;
     DevCounters hc;
     std::memset(&hc, 0, sizeof(hc));
-    bool was_cancelled = false, done = false;
-    std::vector<unsigned> rw(TAIL_CHUNK);
-    /* phase A */
-    for (; round < max_rounds && !done; ++round) {
-        ev_begin(1);
-        mi_launch_generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round);
-        ev_end();
-        unsigned n_work = 0;
-        HIP_TRY(hipMemcpyAsync(&n_work, c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (hc.error_flags & 1u) return fail(MI_DMRECON_EFOOTPRINT, "Negative pixel footprint");
-        for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = n_work; }
-        if (n_work == 0) { done = true; break; }
-        if (cancelled()) { was_cancelled = true; break; }
-        const bool tail = n_work < TAIL_THRESHOLD;
-        ev_begin(0); ev_work.push_back(n_work); ev_tail.push_back(0);
-        if (tail)
-            mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
-                               nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters);
-        else if (!USE_FOLLOW)
-            mi_launch_optimize(c->stream, BULK_LPV, (n_work + BULK_PPW - 1) / BULK_PPW, c->d_jobs.p, c->sc->d_views.p,
-                               c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
-                               c->d_counters);
-        else {
-            /* throughput layout: one optimisation attempt per entry and launch; the entries whose pixel has further
-             * candidate hypotheses (about one in five) continue in a follow-up launch over a compacted list (its
-             * size stays on the device), so that the wavefronts of both launches are full */
-            const unsigned waves = (n_work + BULK_PPW - 1) / BULK_PPW;
-            unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
-            unsigned* fa = c->d_follow.p;
-            mi_launch_optimize(c->stream, BULK_LPV, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
-                               c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt);
-            /* the follow-up launch runs all remaining attempts of its entries back to back (third and fourth
-             * attempts are rare: a third launch would cost more in latency than it saves) */
-            mi_launch_optimize(c->stream, BULK_LPV, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
-                               nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr);
+    bool done = false, truncated = false;
+    int n_alive = 0;
+    for (int j = 0; j < nj; ++j) if (view_rc[ref_of_job[j]] == 0) ++n_alive;
+
+    /* The per-view outcome of a failed / cancelled view (the reference: an exception or a cancel ends THAT
+     * DMRecon, apps/dmrecon/dmrecon.cc:314-317, dmrecon.cc:353,101-105): the job is marked dead on the device, its
+     * entries are skipped from then on, nothing of it is written back.  Called between rounds / chunks. */
+    auto poll_views = [&](const DevJob* dyn /* read-back of the job table */, unsigned queue_size) -> int {
+        for (int j = 0; j < nj; ++j) {
+            const int i = ref_of_job[j];
+            if (view_rc[i] != 0) continue;
+            int why = 0;
+            if ((uint32_t)dyn[j].flags & MI_JOB_EFOOTPRINT) why = MI_DMRECON_EFOOTPRINT;
+            else if (progress && progress[i].cancelled) why = MI_DMRECON_ECANCELLED;
+            if (progress) { progress[i].filled = dyn[j].n_filled; progress[i].queueSize = queue_size; }
+            if (!why) continue;
+            view_rc[i] = why; --n_alive;
+            if (progress && why == MI_DMRECON_ECANCELLED) progress[i].status = MI_RECON_CANCELLED;
+            const int32_t dead = (int32_t)((uint32_t)dyn[j].flags | MI_JOB_DEAD);
+            c->h_jobdyn[2 * j] = dead;      /* stays valid until the copy has run: the vector is not resized below */
+            if (hipMemcpyAsync((char*)(c->d_jobs.p + j) + offsetof(DevJob, flags), &c->h_jobdyn[2 * j], sizeof(int32_t),
+                               hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+        }
+        return 0;
+    };
+    auto read_dyn = [&](DevJob* dst) -> hipError_t {        /* the job table (a few KB) with its flags / n_filled words */
+        return hipMemcpyAsync(dst, c->d_jobs.p, (size_t)nj * sizeof(DevJob), hipMemcpyDeviceToHost, c->stream);
+    };
+
+    while (!done && n_alive > 0) {
+        /* ---- phase A */
+        bool to_tail = false;
+        for (; round < max_rounds && !done && n_alive > 0; ++round) {
+            ev_begin(1);
+            mi_launch_generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round);
+            ev_end();
+            TailPoll& P = c->h_poll[0];
+            HIP_TRY(hipMemcpyAsync(&P.rw[0], c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(read_dyn(dyn_of(0)));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const unsigned n_work = P.rw[0];
+            hc = P.hc;
+            if (poll_views(dyn_of(0), n_work)) return fail(MI_DMRECON_EDEVICE, "hipMemcpyAsync(job flags) failed");
+            if (n_work == 0) { done = true; break; }
+            if (n_alive == 0) break;
+            const bool tail = n_work < TAIL_THRESHOLD;
+            ev_begin(0); ev_work.push_back(n_work); ev_tail.push_back(0);
+            if (tail)
+                mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+                                   nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters,
+                                   nullptr, nullptr, nullptr, nullptr, WIN_TAIL);
+            else if (!USE_FOLLOW || BULK_LPV == 16)
+                mi_launch_optimize(c->stream, BULK_LPV, BULK_LPV == 16 ? std::min(n_work, 16384u) : (n_work + BULK_PPW - 1) / BULK_PPW,
+                                   c->d_jobs.p, c->sc->d_views.p,
+                                   c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
+                                   c->d_counters, nullptr, nullptr, nullptr, nullptr, BULK_LPV == 16 ? WIN_TAIL : WIN_BULK);
+            else {
+                /* throughput layout: one optimisation attempt per entry and launch; the entries whose pixel has further
+                 * candidate hypotheses (about one in five) continue in a follow-up launch over a compacted list (its
+                 * size stays on the device), so that the wavefronts of both launches are full */
+                const unsigned waves = (n_work + BULK_PPW - 1) / BULK_PPW;
+                unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
+                unsigned* fa = c->d_follow.p;
+                mi_launch_optimize(c->stream, BULK_LPV, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+                                   c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt, WIN_BULK);
+                /* the follow-up launch runs all remaining attempts of its entries back to back (third and fourth
+                 * attempts are rare: a third launch would cost more in latency than it saves) */
+                mi_launch_optimize(c->stream, BULK_LPV, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+                                   nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr, WIN_BULK);
+                ++n_launch;
+            }
+            ev_end();
             ++n_launch;
+            ev_begin(1);
+            mi_launch_apply(c->stream, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
+            ev_end();
+            if (tail) { ++round; to_tail = true; break; }
         }
-        ev_end();
-        ++n_launch;
-        ev_begin(1);
-        mi_launch_apply(c->stream, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
-        ev_end();
-        if (tail) { ++round; break; }
-    }
-    mark("seeds + phase A rounds");
-    /* phase B: one fused launch per round (k_tail: candidates from the previous round's accepted entries ->
-     * this round's list, optimisations and state writes); lists and results ping-pong */
-    DevEntry* wcur = c->d_work.p;        /* list + results of the last executed round (round - 1) */
-    DevEntry* wnext = c->d_work2.p;
-    DevResult* rcur = c->d_results.p;
-    DevResult* rnext = c->d_results2.p;
-    bool ran_tail = false;
-    while (!done && !was_cancelled && round < max_rounds) {
-        const int first = round;
-        const size_t ev_first = ev_work.size();
+        if (first_phase_a) { mark("seeds + phase A rounds"); first_phase_a = false; }
+        if (done || n_alive == 0) break;
+        if (!to_tail) { truncated = true; break; }            /* round counters exhausted */
+        /* ---- phase B: one fused launch per round (k_tail: candidates from the previous round's accepted entries ->
+         * this round's list, optimisations and state writes); lists and results ping-pong.  A chunk of rounds is
+         * enqueued blind and its counters are read back while the NEXT chunk already runs (empty rounds are
+         * microsecond no-ops), so the GPU never waits for the host inside the tail. */
+        DevEntry* wcur = c->d_work.p;        /* list + results of the last executed round (round - 1) */
+        DevEntry* wnext = c->d_work2.p;
+        DevResult* rcur = c->d_results.p;
+        DevResult* rnext = c->d_results2.p;
+        struct ChunkInfo { int first; size_t ev_first, ev_last; };
+        ChunkInfo info[2];
+        auto enqueue_chunk = [&](int slot) -> int {
+            info[slot].first = round; info[slot].ev_first = ev_work.size();
+            for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
+                const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
+                if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
+                mi_launch_tail(c->stream, TAIL_GRID, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
+                               c->d_round_work.p, round, c->d_counters, (DevCand*)c->d_cand.p, (unsigned)cand_cap, WIN_TAIL);
+                if (timed) ev_end();
+                std::swap(wcur, wnext);
+                std::swap(rcur, rnext);
+            }
+            info[slot].ev_last = ev_work.size();
+            TailPoll& P = c->h_poll[slot];
+            if (hipMemcpyAsync(P.rw, c->d_round_work.p + info[slot].first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+            if (hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+            if (read_dyn(dyn_of(slot)) != hipSuccess) return -1;
+            if (hipEventRecord(c->poll_ev[slot], c->stream) != hipSuccess) return -1;
+            return 0;
+        };
         ran_tail = true;
-        for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
-            const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
-            if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
-            mi_launch_tail(c->stream, TAIL_GRID, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
-                           c->d_round_work.p, round, c->d_counters);
-            if (timed) ev_end();
-            std::swap(wcur, wnext);
-            std::swap(rcur, rnext);
+        int slot = 0;
+        bool overflow = false;
+        if (enqueue_chunk(0)) return fail(MI_DMRECON_EDEVICE, "enqueue of tail rounds failed");
+        for (;;) {
+            const bool more_room = round + (int)TAIL_CHUNK < MI_MAX_ROUNDS - 1;
+            if (more_room && enqueue_chunk(slot ^ 1)) return fail(MI_DMRECON_EDEVICE, "enqueue of tail rounds failed");
+            HIP_TRY(hipEventSynchronize(c->poll_ev[slot]));
+            TailPoll& P = c->h_poll[slot];
+            hc = P.hc;
+            for (size_t q = info[slot].ev_first; q < info[slot].ev_last; ++q) ev_work[q] = P.rw[ev_work[q]];
+            int end_round = -1;
+            for (unsigned k = 0; k < TAIL_CHUNK; ++k) {
+                if (P.rw[k] == 0) { end_round = info[slot].first + (int)k; break; }
+                ++n_launch; ++n_tail_launch;
+            }
+            if (poll_views(dyn_of(slot), P.rw[TAIL_CHUNK - 1])) return fail(MI_DMRECON_EDEVICE, "hipMemcpyAsync(job flags) failed");
+            if (end_round >= 0) {
+                /* an empty round: the propagation is over -- or (flag 2) that round's source list did not fit the
+                 * attempt buffer and must be run as a host-visible round */
+                overflow = (hc.error_flags & 2u) != 0;
+                if (more_room) HIP_TRY(hipEventSynchronize(c->poll_ev[slot ^ 1]));     /* the chunk in flight is all no-ops */
+                round = end_round;
+                if (!overflow) done = true;
+                break;
+            }
+            if (n_alive == 0) break;
+            if (!more_room) { truncated = true; break; }
+            slot ^= 1;
         }
-        HIP_TRY(hipMemcpyAsync(rw.data(), c->d_round_work.p + first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (hc.error_flags & 1u) return fail(MI_DMRECON_EFOOTPRINT, "Negative pixel footprint");
-        for (size_t q = ev_first; q < ev_work.size(); ++q) ev_work[q] = rw[ev_work[q]];
-        for (unsigned k = 0; k < TAIL_CHUNK; ++k) {
-            if (rw[k] == 0) { done = true; round = first + (int)k; break; }
-            ++n_launch; ++n_tail_launch;
+        mi_launch_flatten(c->stream, c->d_maps.p, c->d_imaps.p, total_px);
+        if (overflow) {
+            HIP_TRY(hipMemsetAsync((char*)c->d_counters + offsetof(DevCounters, error_flags), 0, sizeof(unsigned), c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_round_work.p + round, 0, (MI_MAX_ROUNDS - round) * sizeof(unsigned), c->stream));
         }
-        for (int i = 0; progress && i < n_refs; ++i) { progress[i].filled = hc.n_filled / (uint64_t)nj; progress[i].queueSize = rw[TAIL_CHUNK - 1]; }
-        if (cancelled()) was_cancelled = true;
+        if (truncated) break;
     }
-    if (was_cancelled) {
-        /* DMRecon::start() returns before anything is saved when the flag was raised during processQueue
-         * (dmrecon.cc:353, :101-105): the caller's buffers stay untouched */
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_CANCELLED;
-        return fail(MI_DMRECON_ECANCELLED, "cancelled");
-    }
-    if (ran_tail) mi_launch_flatten(c->stream, c->d_maps.p, c->d_imaps.p, total_px);
+    (void)ran_tail;
     mark("phase B rounds");
     /* ---- results back to the caller's buffers */
-    for (int i = 0; progress && i < n_refs; ++i) progress[i].status = MI_RECON_SAVING;
+    int n_ok = 0, first_rc = 0;
+    for (int i = 0; i < n_refs; ++i) {
+        if (status_out) status_out[i] = view_rc[i];
+        if (view_rc[i] == 0) { ++n_ok; if (progress) progress[i].status = MI_RECON_SAVING; }
+        else if (!first_rc) first_rc = view_rc[i];
+    }
     std::vector<uint32_t> packed;
     for (int i = 0; i < n_refs; ++i) {
         const int j = job_of[i];
-        if (j < 0) continue;
+        if (j < 0 || view_rc[i] != 0) continue;
         const size_t np = (size_t)jobs[j].w * jobs[j].h;
         mi_dmrecon_maps& m = maps[i];
         if (m.depth) HIP_TRY(hipMemcpyAsync(m.depth, dj[j].depth, np * 4, hipMemcpyDeviceToHost, c->stream));
@@ -940,21 +1054,26 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     HIP_TRY(hipStreamSynchronize(c->stream));
     mark("download");
     if (stats) {
-        stats->n_patch = (int64_t)hc.n_patch; stats->n_eval = (int64_t)hc.n_eval; stats->n_filled = (int64_t)hc.n_filled;
+        stats->n_patch = (int64_t)hc.n_patch; stats->n_eval = (int64_t)hc.n_eval; stats->n_pass = (int64_t)hc.n_pass;
+        stats->n_filled = (int64_t)hc.n_filled;
         stats->n_seeds = (int64_t)n_seed_feats; stats->n_seeds_ok = (int64_t)hc.n_seeds_ok;
-        stats->n_rounds = round; stats->n_launches = n_launch;
+        stats->n_rounds = round; stats->n_launches = n_launch; stats->truncated = truncated ? 1 : 0;
         double tail_ms = 0.0; int64_t tail_timed = 0;
         size_t w = 0;
         for (size_t k = 0; k < ev_kind.size(); ++k) {
             float ms = 0.f;
             const bool got = hipEventElapsedTime(&ms, c->events[ev_kind[k].first], c->events[ev_kind[k].first + 1]) == hipSuccess;
             if (ev_kind[k].second != 0) { if (got) stats->ms_sweep_kernels += ms; continue; }
-            if (!ev_tail[w]) { if (got) stats->ms_opt_kernel += ms; }
+            if (!ev_tail[w]) { if (got) { stats->ms_opt_kernel += ms; stats->ms_bulk_kernel += ms; ++stats->n_bulk_launches; } }
             else if (got && ev_work[w] > 0) { tail_ms += ms; ++tail_timed; }
             ++w;
         }
         /* phase B: mean of the timed launches x number of launches that had work */
-        if (tail_timed > 0) stats->ms_opt_kernel += tail_ms / (double)tail_timed * (double)n_tail_launch;
+        if (tail_timed > 0) {
+            stats->ms_tail_kernel = tail_ms / (double)tail_timed * (double)n_tail_launch;
+            stats->ms_opt_kernel += stats->ms_tail_kernel;
+        }
+        stats->n_tail_launches = n_tail_launch;
         stats->ms_total = now_ms() - t_begin;
     }
     if (trace) {
@@ -968,7 +1087,18 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         }
         fprintf(stderr, "[mi_dmrecon] total %.2f ms host wall\n", now_ms() - t_begin);
     }
-    for (int i = 0; progress && i < n_refs; ++i) { progress[i].status = MI_RECON_IDLE; }
+    for (int i = 0; progress && i < n_refs; ++i) if (view_rc[i] == 0) progress[i].status = MI_RECON_IDLE;
+    if (truncated) return fail(MI_DMRECON_EDEVICE, "propagation did not finish within %d rounds", MI_MAX_ROUNDS);
+    if (n_ok == 0) {
+        /* every view of the call failed: report the first one's reason (a single-view call behaves like
+         * DMRecon::start(): the exception / the cancellation is the call's outcome) */
+        switch (first_rc) {
+            case MI_DMRECON_ECANCELLED: return fail(first_rc, "cancelled");
+            case MI_DMRECON_EFOOTPRINT: return fail(first_rc, "Negative pixel footprint");
+            case MI_DMRECON_EGVS: return fail(first_rc, "Global View Selection failed");
+            default: return fail(first_rc ? first_rc : MI_DMRECON_EDEVICE, "reconstruction failed");
+        }
+    }
     return 0;
 }
 
@@ -1021,9 +1151,14 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     const char* lpv_env = std::getenv("MI_DMRECON_HOOK_LPV");
     const int lpv = (lpv_env && std::atoi(lpv_env) == 16) ? 16 : 1;
     const unsigned ppw = lpv == 16 ? 1u : (unsigned)MI_PATCHES_PER_WAVE;
+    /* MI_DMRECON_WIN (bit 0: latency layout, bit 1: throughput layout) selects the texel-window kernels here too */
+    const char* win_env = std::getenv("MI_DMRECON_WIN");
+    const int win_bits = win_env ? std::atoi(win_env) : MI_WIN_DEFAULT;
+    const bool windows = (win_bits & (lpv == 16 ? 1 : 2)) != 0;
     mi_launch_optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw,
                        c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
-                       c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters);
+                       c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
+                       nullptr, nullptr, nullptr, nullptr, windows);
     HIP_TRY(hipGetLastError());
     std::vector<DevResult> res(n);
     HIP_TRY(hipMemcpyAsync(res.data(), c->d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));

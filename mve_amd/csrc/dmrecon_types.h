@@ -36,6 +36,9 @@ struct DevView {
 
 /* One reference view being reconstructed (one mvs::DMRecon instance). */
 struct DevJob {
+    /* the two words the device writes and the host polls (copied back as a strided 8-byte column) */
+    int32_t flags;                      /* MI_JOB_* */
+    uint32_t n_filled;                  /* pixels that went from confidence 0 to > 0 (Progress::filled) */
     int32_t ref_view, scale, w, h;
     float inv_a, inv_c, inv_b, inv_d;   /* invproj at `scale`: x' = inv_a*x + inv_c, y' = inv_b*y + inv_d */
     float rot_t[9];                     /* R^T (camera -> world rotation) */
@@ -51,7 +54,8 @@ struct DevJob {
     float* normal;    /* 3 ch */
     uint32_t* views;  /* 4 x 8-bit indices into global_ids, MI_VIEW_NONE padded */
     int32_t* upd;     /* round in which the pixel was last written, -1 = never */
-    int32_t* mark;    /* last round for which the pixel was claimed by a tail round (k_tail), -1 = never */
+    int32_t* mark;    /* index of the pixel's entry in the work list of the round that last accepted it (k_apply, k_tail) */
+    int32_t* arrive;  /* tail rounds: how many of the pixel's candidate attempts of the current round have finished (0 between rounds) */
     /* Second slot of the pixel state, used by the fused tail rounds only (k_tail): a write of round r goes to
      * the slot that does NOT hold the pixel's state as of the end of round r-1, so the optimisations of a round
      * keep reading the frozen state of the previous round without a separate write-back launch.  The state
@@ -63,6 +67,9 @@ struct DevJob {
     uint32_t* views1;
     int32_t* upd1;
 };
+
+#define MI_JOB_EFOOTPRINT 1u   /* device: non-positive master footprint in this view (patch_sampler.cc:78-82 throws) */
+#define MI_JOB_DEAD       2u   /* host: the view failed or was cancelled -- its entries are skipped from now on */
 
 /* Settings as the kernels see them. */
 struct DevSettings {
@@ -88,9 +95,13 @@ struct DevResult {
     uint32_t tried;          /* propagate mode: neighbours (bit k: left, right, up, down) whose hypothesis has been consumed */
 };
 
+struct DevCand;              /* tail rounds: result of one speculative attempt (dmrecon_device.hip) */
+#define MI_CAND_BYTES 48
+
 struct DevCounters {
     unsigned long long n_patch, n_eval, n_pass, n_filled, n_seeds_ok;
-    unsigned int error_flags;  /* bit0: non-positive master footprint (patch_sampler.cc:78-82) */
+    unsigned int error_flags;  /* bit0: non-positive master footprint (patch_sampler.cc:78-82); bit1: a tail round's
+                                * source list exceeded the attempt buffer (the round did not run) */
     unsigned int pad;
 };
 

@@ -169,7 +169,7 @@ private:
         std::vector<mi_dmrecon_progress> prog(n);
         for (std::size_t i = 0; i < n; ++i) { refs[i] = batch[i]->ref; maps[i] = batch[i]->maps; prog[i] = *batch[i]->prog; }
         /* progress / cancellation relay between the batch's array and the requesting threads' PODs.  The library
-         * cancels a call as a whole: a view cancelled while batched with others cancels those as well. */
+         * ends views individually (status[i]): a view cancelled while batched with others does not touch those. */
         std::atomic<bool> running(true);
         std::thread relay([&]() {
             while (running.load()) {
@@ -190,11 +190,12 @@ private:
         for (std::size_t i = 0; i < n; ++i) {
             Request& q = *batch[i];
             q.prog->status = prog[i].status;
-            if (rc != 0) { q.rc = rc; q.err = msg; }
-            else if (status[i] != 0) {         /* this view's planning failed, the others ran (mi_dmrecon.h) */
+            if (status[i] != 0) {              /* this view's own outcome; the others ran (mi_dmrecon.h) */
                 q.rc = status[i];
-                q.err = status[i] == MI_DMRECON_EGVS ? "Global View Selection failed" : "reconstruction failed";
-            }
+                q.err = status[i] == MI_DMRECON_EGVS ? "Global View Selection failed"
+                      : status[i] == MI_DMRECON_EFOOTPRINT ? "Negative pixel footprint"
+                      : status[i] == MI_DMRECON_ECANCELLED ? "cancelled" : "reconstruction failed";
+            } else if (rc != 0) { q.rc = rc; q.err = msg; }
         }
     }
 };

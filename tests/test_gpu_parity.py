@@ -157,6 +157,91 @@ def test_lane_layouts_agree(ctx_g1, g1, monkeypatch, lpv):
     assert (np.abs(b[okr, 1] - ref[okr, 1]) / ref[okr, 1] <= 1e-3).mean() >= 0.99
 
 
+@pytest.mark.parametrize("lpv", ["1", "16"])
+def test_texel_windows_are_bit_identical_to_gathers(gpu_ctx, g1, g1_scene, g1b_scene, monkeypatch, lpv):
+    """Sampling from the LDS texel windows reads the very texels the scattered gathers read and sums them in the
+    same order: every output of every patch must be bit-identical, in both lane layouts, also at scale 1 where
+    the mip level of a view flips between patches (Q4)."""
+    monkeypatch.setenv("MI_DMRECON_HOOK_LPV", lpv)
+    rng = np.random.RandomState(5)
+    for scene, scale, (w, h), d0 in ((g1_scene, 0, (160, 120), 10.0), (g1b_scene, 1, (161, 121), 10.0)):
+        gpu_ctx.load_scene(scene)
+        n = 1500
+        xy = np.stack([rng.randint(0, w, n), rng.randint(0, h, n)], 1)
+        hyp = np.stack([d0 + rng.uniform(-0.6, 0.6, n), rng.uniform(-2e-2, 2e-2, n), rng.uniform(-2e-2, 2e-2, n)], 1)
+        st = api.Settings(refViewNr=1, scale=scale)
+        monkeypatch.setenv("MI_DMRECON_WIN", "0")
+        a, al = gpu_ctx.patch_optimize(st, 1, xy, hyp)
+        monkeypatch.setenv("MI_DMRECON_WIN", "3")
+        b, bl = gpu_ctx.patch_optimize(st, 1, xy, hyp)
+        assert (a[:, 0] > 0).sum() > 200
+        assert np.array_equal(a, b) and np.array_equal(al, bl)
+
+
+def test_maps_with_and_without_texel_windows(gpu_ctx, g1_scene, monkeypatch):
+    gpu_ctx.load_scene(g1_scene)
+    monkeypatch.setenv("MI_DMRECON_WIN", "0")
+    a = gpu_ctx.reconstruct(api.Settings(), [0, 1, 2, 3, 4], want_views=True)
+    monkeypatch.setenv("MI_DMRECON_WIN", "3")
+    b = gpu_ctx.reconstruct(api.Settings(), [0, 1, 2, 3, 4], want_views=True)
+    for x, y in zip(a, b):
+        for k in ("depth", "conf", "dz", "normal", "views"):
+            assert np.array_equal(x[k], y[k]), k
+
+
+def test_speculative_tail_equals_sequential_attempts(gpu_ctx, g1_scene, monkeypatch):
+    """The tail rounds run a pixel's candidate hypotheses in parallel and apply the reference's sequential rule
+    (pop-time skip dmrecon.cc:371, accept-if-better :391) afterwards.  Host-visible rounds in the same lane layout
+    run them one after the other: the maps must be bit-identical."""
+    gpu_ctx.load_scene(g1_scene)
+    st = api.Settings()
+    monkeypatch.setenv("MI_DMRECON_BULK_LPV", "16")
+    monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "0")               # never enter the tail
+    seq = gpu_ctx.reconstruct(st, [0, 1, 2, 3, 4], want_views=True)
+    n_seq = dict(gpu_ctx.last_stats)
+    monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "1000000000")      # tail rounds from the first round on
+    spec = gpu_ctx.reconstruct(st, [0, 1, 2, 3, 4], want_views=True)
+    n_spec = dict(gpu_ctx.last_stats)
+    assert n_spec["n_tail_launches"] > 20 and n_seq["n_tail_launches"] == 0
+    for a, b in zip(seq, spec):
+        for k in ("depth", "conf", "dz", "normal", "views"):
+            assert np.array_equal(a[k], b[k]), k
+    # the device counts the attempts the reference's rule would have made, not the speculative extras
+    assert n_seq["n_patch"] == n_spec["n_patch"] and n_seq["n_eval"] == n_spec["n_eval"]
+
+
+def test_views_end_individually_in_a_batch(gpu_ctx, g1_scene):
+    """A cancelled view or a view whose footprint turns non-positive (patch_sampler.cc:78-82 throws) ends alone;
+    the other views of the call finish, with the maps they get without it (apps/dmrecon/dmrecon.cc:314-317)."""
+    from mve_amd.scene_io import Camera, SceneData
+    gpu_ctx.load_scene(g1_scene)
+    st = api.Settings()
+    base = gpu_ctx.reconstruct(st, [0, 1, 2, 3, 4])
+    # (a) view 2 cancelled before the start
+    prog = (api.CProgress * 5)()
+    prog[2].cancelled = 1
+    out = gpu_ctx.alloc_outputs(st, [0, 1, 2, 3, 4])
+    out[2]["depth"].fill(-7.0)
+    res = gpu_ctx.reconstruct(st, [0, 1, 2, 3, 4], progress=prog, out=out)
+    assert [r["status"] for r in res] == [0, 0, api.E_CANCELLED, 0, 0]
+    assert prog[2].status == 5 and all(prog[i].status == 0 for i in (0, 1, 3, 4))
+    assert (res[2]["depth"] == -7.0).all()
+    for i in (0, 1, 3, 4):
+        assert np.array_equal(res[i]["depth"], base[i]["depth"]) and np.array_equal(res[i]["conf"], base[i]["conf"])
+        assert prog[i].filled == int((res[i]["conf"] > 0).sum())          # Progress::filled is per view
+    # (b) a mirrored camera (negative focal length): its footprint is negative, the reference throws for that view
+    cams = list(g1_scene.cameras)
+    c = cams[4]
+    cams[4] = Camera(flen=-c.flen, paspect=c.paspect, ppoint=c.ppoint, rot=c.rot, trans=c.trans)
+    gpu_ctx.load_scene(SceneData(cams, g1_scene.images, g1_scene.features))
+    res = gpu_ctx.reconstruct(st, [0, 4, 1])
+    assert [r["status"] for r in res] == [0, api.E_FOOTPRINT, 0]
+    assert (res[0]["conf"] > 0).mean() > 0.3 and (res[2]["conf"] > 0).mean() > 0.3
+    with pytest.raises(IndexError, match="Negative pixel footprint"):      # alone it is the call's outcome
+        gpu_ctx.reconstruct(st, [4])
+    gpu_ctx.load_scene(g1_scene)
+
+
 def test_maps_vs_reference_scale0(ctx_g1, g1):
     r = ctx_g1.reconstruct(api.Settings(refViewNr=0), [0])[0]
     assert_map_parity(map_parity(r["depth"], r["conf"], g1["s0v0_depth"], g1["s0v0_conf"]))
