@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 from mve_amd import api  # noqa: E402
-from mve_amd.dist import Collective, rank_world  # noqa: E402
+from mve_amd.dist import Collective, rank_views, rank_world, shard_views  # noqa: E402
 from mve_amd.synth import CONFIGS, make_scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guide: 8.0 TB/s; 6.29 TB/s measured copy)
@@ -80,20 +80,22 @@ def measured_traffic():
     return float(j["bytes_per_launch"]), os.path.basename(files[-1])
 
 
-def cpu_baseline(scene, cfg, seconds_hint=20.0):
-    """The reference CPU path timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(scene, cfg, gpu_maps=None):
+    """The reference CPU path timed on this box's host cores on a bounded sample of the same workload.
+    With gpu_maps (the HIP path's depth / conf maps of the same views) the reference's own output -- which this
+    leg produces anyway -- is read back and diffed: the `parity` object of the JSON line."""
     cores = os.cpu_count() or 1
     ref_exe = os.path.join(ROOT, "oracle", "_ref", "dmrecon_ref_fast")
     p, s, k = cfg["params"], cfg["scale"], cfg["local_neighbors"]
     if os.path.exists(ref_exe):
-        from mve_amd.scene_io import write_scene
+        from mve_amd.scene_io import read_mvei, view_dir, write_scene
         n_sample = max(1, min(cores, p.n_views))
         work = tempfile.mkdtemp(prefix="bench_ref_")
         try:
             sdir = os.path.join(work, "scene")
             write_scene(sdir, scene)
             env = dict(os.environ, OMP_NUM_THREADS=str(cores))
-            cmd = [ref_exe, "-s%d" % s, "--local-neighbors=%d" % k, "--force", "--progress=silent",
+            cmd = [ref_exe, "-s%d" % s, "--local-neighbors=%d" % k, "--force", "--progress=silent", "--keep-conf",
                    "--list-view=0-%d" % (n_sample - 1), sdir]
             t0 = time.time()
             out = subprocess.run(cmd, check=True, env=env, capture_output=True, text=True).stdout
@@ -103,64 +105,67 @@ def cpu_baseline(scene, cfg, seconds_hint=20.0):
                 if ln.startswith("Reconstruction took"):
                     app_ms = float(ln.split()[2].rstrip("ms.").rstrip("ms"))
             t = (app_ms / 1000.0) if app_ms else wall
-            return {"value": n_sample / t, "unit": "depth-maps/s", "cores": min(cores, n_sample), "kind": "reference",
+            base = {"value": n_sample / t, "unit": "depth-maps/s", "cores": min(cores, n_sample), "kind": "reference",
                     "sample": "unmodified apps/dmrecon (oracle/_ref/dmrecon_ref_fast: -O3 -march=x86-64-v3 "
                               "-funsafe-math-optimizations, OpenMP over views) on views 0-%d of the same scene at scale %d; "
                               "time = the app's own 'Reconstruction took' (%.1f s, includes its PNG decode + pyramid); "
                               "%d host cores available, one thread per view" % (n_sample - 1, s, t, cores)}
+            parity = None
+            if gpu_maps is not None:
+                parity = map_parity_all(
+                    gpu_maps[:n_sample],
+                    [(read_mvei(os.path.join(view_dir(sdir, v), "depth-L%d.mvei" % s)),
+                      read_mvei(os.path.join(view_dir(sdir, v), "conf-L%d.mvei" % s))) for v in range(n_sample)],
+                    "the reference's own depth-L%d / conf-L%d of views 0-%d (the cpu_baseline run), this run" % (s, s, n_sample - 1))
+            return base, parity
         finally:
             shutil.rmtree(work, ignore_errors=True)
     from oracle import oracle as orc
     S = orc.OracleScene(scene)
     t0 = time.time()
-    S.reconstruct(orc.make_settings(ref_view=0, scale=s, local_neighbors=k))
+    o = S.reconstruct(orc.make_settings(ref_view=0, scale=s, local_neighbors=k))
     t = time.time() - t0
+    parity = None
+    if gpu_maps is not None:
+        parity = map_parity_all(gpu_maps[:1], [(o["depth"], o["conf"])], "oracle restatement, view 0, this run")
     return {"value": 1.0 / t, "unit": "depth-maps/s", "cores": 1, "kind": "port",
-            "sample": "oracle/dmrecon_oracle.cc restatement, view 0 only, single thread (%.1f s)" % t}
+            "sample": "oracle/dmrecon_oracle.cc restatement, view 0 only, single thread (%.1f s)" % t}, parity
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=6,
-                    help="host threads per GPU, each driving its own forked context / HIP stream; steps are "
-                         "dealt round-robin (the reference runs its views under an OpenMP loop the same way)")
-    ap.add_argument("--steps-per-call", type=int, default=0,
-                    help="steps (passes over the 20 views) handed to ONE mi_dmrecon_reconstruct batch; the propagation "
-                         "tail costs the same ~600 latency-bound rounds per batch whatever its size.  0 = the largest "
-                         "divisor of --steps that is <= 5")
-    args = ap.parse_args()
-    rank, world, local_rank = rank_world()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    cfg = CONFIGS[args.config]
-    p = cfg["params"]
-    coll = Collective("nccl", local_rank)
+def map_parity_all(gpu, ref, against):
+    """Worst case over the views of the map-level parity metrics (tests/test_gpu_parity.py states the bounds:
+    IoU >= 0.98, relative depth median <= 1e-3 / p99 <= 5e-3, confidence p99 <= 5e-3)."""
+    iou, med, p99, cp99, n = [], [], [], [], 0
+    for (gd, gc), (rd, rc) in zip(gpu, ref):
+        rd = np.asarray(rd, np.float32).reshape(gd.shape)
+        rc = np.asarray(rc, np.float32).reshape(gc.shape)
+        ma, mb = gd > 0, rd > 0
+        both = ma & mb
+        iou.append(float(both.sum()) / max(int((ma | mb).sum()), 1))
+        rel = np.abs(gd[both] - rd[both]) / rd[both]
+        med.append(float(np.median(rel))); p99.append(float(np.percentile(rel, 99)))
+        cp99.append(float(np.percentile(np.abs(gc[both] - rc[both]), 99)))
+        n += 1
+    ok = min(iou) >= 0.98 and max(med) <= 1e-3 and max(p99) <= 5e-3 and max(cp99) <= 5e-3
+    return {"against": against, "views": n, "min_fill_iou": min(iou), "max_rel_depth_median": max(med),
+            "max_rel_depth_p99": max(p99), "max_conf_abs_p99": max(cp99),
+            "bounds": {"fill_iou": 0.98, "rel_depth_median": 1e-3, "rel_depth_p99": 5e-3, "conf_abs_p99": 5e-3},
+            "within_bounds": bool(ok)}
 
-    scene = make_scene(p)                                   # synthetic, deterministic, identical on every rank
-    ctx = api.Context(local_rank)
-    ctx.load_scene(scene)                                   # upload + device pyramid: inputs resident in HBM
-    st = api.Settings(scale=cfg["scale"], nrReconNeighbors=cfg["local_neighbors"])
-    refs = list(range(p.n_views))
 
-    # one forked context (own HIP stream + scratch, shared resident scene) per host thread; the long,
-    # latency-bound tail of one step's propagation overlaps the throughput-bound start of another's
-    spc, n_calls, n_streams = plan_calls(args.steps, args.streams, args.steps_per_call)
-    refs = refs * spc
-    ctxs = [ctx] + [ctx.fork() for _ in range(n_streams - 1)]
+def timed_region(coll, ctxs, st, refs, n_calls, warmup):
+    """W untimed warm-up calls per host thread, then exactly n_calls library calls of `refs` dealt over the host
+    threads (one forked context / HIP stream each), bracketed by barrier + synchronise on both sides; returns
+    (max-over-ranks elapsed seconds, summed stats, the maps of the last call)."""
+    import threading
+    n_streams = len(ctxs)
     outs = [c.alloc_outputs(st, refs, want_normal=False, pinned=True) for c in ctxs]   # reused, page-locked
     t_call = 0.0
-    for c, o in zip(ctxs, outs):
-        for _ in range(max(args.warmup, 1 if c is not ctx else 0)):
+    for i, (c, o) in enumerate(zip(ctxs, outs)):
+        for _ in range(max(warmup, 1 if i else 0)):
             tw = time.perf_counter()
             c.reconstruct(st, refs, want_normal=False, out=o)
             t_call = time.perf_counter() - tw
-    import threading
     acc, last = {}, {}
     lock = threading.Lock()
 
@@ -173,7 +178,8 @@ def main():
         for _ in range(n):
             r = c.reconstruct(st, refs, want_normal=False, out=o)   # synchronous: returns with the maps on the host
             with lock:
-                last["res"] = r
+                last["res"] = [(m["depth"].copy(), m["conf"].copy()) for m in r] if "res" not in last else last["res"]
+                last["shape"] = r[0]["depth"].shape
                 for k, v in c.last_stats.items():
                     acc[k] = acc.get(k, 0) + v
 
@@ -188,27 +194,96 @@ def main():
         t.join()
     coll.barrier()
     elapsed = coll.max(time.perf_counter() - t0)
-    res = last["res"]
-    n_maps_rank = len(refs) * n_calls
+    return elapsed, acc, last
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1 only.  weak (default): every rank reconstructs all views of its own scene replica per "
+                         "step.  strong (BASELINE config 4): ONE scene, its reference views dealt round-robin over the "
+                         "ranks (mve_amd.dist.shard_views), value = views x steps / slowest rank.  The weak line also "
+                         "carries the strong-mode figure of the same run as `strong_scaling`.")
+    ap.add_argument("--streams", type=int, default=6,
+                    help="host threads per GPU, each driving its own forked context / HIP stream; steps are "
+                         "dealt round-robin (the reference runs its views under an OpenMP loop the same way)")
+    ap.add_argument("--steps-per-call", type=int, default=0,
+                    help="steps (passes over the rank's reference views) handed to ONE mi_dmrecon_reconstruct batch. "
+                         "0 = the largest divisor of --steps that is <= 5")
+    args = ap.parse_args()
+    rank, world, local_rank = rank_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    cfg = CONFIGS[args.config]
+    p = cfg["params"]
+    coll = Collective("nccl", local_rank)
+
+    scene = make_scene(p)                                   # synthetic, deterministic, identical on every rank
+    ctx = api.Context(local_rank)
+    ctx.load_scene(scene)                                   # upload + device pyramid: inputs resident in HBM
+    st = api.Settings(scale=cfg["scale"], nrReconNeighbors=cfg["local_neighbors"])
+    all_views = list(range(p.n_views))
+
+    # one forked context (own HIP stream + scratch, shared resident scene) per host thread; the
+    # latency-bound tail of one call's propagation overlaps the throughput-bound start of another's
+    spc, n_calls, n_streams = plan_calls(args.steps, args.streams, args.steps_per_call)
+    ctxs = [ctx] + [ctx.fork() for _ in range(n_streams - 1)]
+
+    def run_mode(mode):
+        mine = rank_views(all_views, rank, world, mode)
+        if not mine:                                        # more ranks than views: this rank only keeps the barriers
+            coll.barrier(); coll.barrier()
+            return coll.max(0.0), {}, {}, 0
+        el, acc, last = timed_region(coll, ctxs, st, mine * spc, n_calls, args.warmup)
+        return el, acc, last, len(mine) * spc * n_calls
+
+    elapsed, acc, last, n_maps_rank = run_mode(args.scaling if world > 1 else "weak")
     n_maps = int(round(coll.sum(n_maps_rank)))
+    strong = None
+    if world > 1 and args.scaling == "weak":
+        s_el, _, _, s_rank = run_mode("strong")
+        s_maps = int(round(coll.sum(s_rank)))
+        strong = {"value": s_maps / s_el, "unit": "depth-maps/s", "ms_per_step": 1000.0 * s_el / args.steps,
+                  "views_per_rank": [len(shard_views(all_views, r, world)) for r in range(world)],
+                  "note": "BASELINE config 4: the %d reference views of ONE scene dealt round-robin over the %d ranks, "
+                          "same steps / warm-up / call plan; depth maps of all ranks / slowest rank" % (p.n_views, world)}
 
     if rank == 0:
-        fill = float(np.mean([(r["conf"] > 0).mean() for r in res]))
+        res = last["res"]
+        shape = last["shape"]
+        fill = float(np.mean([(c > 0).mean() for _, c in res]))
         b_alg = algorithmic_bytes(acc, n_maps_rank, scene, cfg)
         opt_s = acc["ms_opt_kernel"] / 1000.0
         n_launch = max(int(acc["n_launches"]), 1)
         achieved = b_alg / opt_s / 1e9 if opt_s > 0 else 0.0
         traffic, traffic_src = measured_traffic()
+        # the two kernels behind `achieved`, each with its own share of the algorithmic bytes
+        bulk_stats = {"n_eval": acc.get("n_eval_bulk", 0), "n_patch": acc.get("n_patch_bulk", 0), "n_filled": acc.get("n_filled_bulk", 0)}
+        b_bulk = algorithmic_bytes(bulk_stats, n_maps_rank, scene, cfg)        # the compulsory bytes go with the bulk rounds
+        b_tail = b_alg - b_bulk
+        ms_bulk, ms_tail = acc.get("ms_bulk_kernel", 0.0), acc.get("ms_tail_kernel", 0.0)
+        nb, nt = max(int(acc.get("n_bulk_launches", 0)), 1), max(int(acc.get("n_tail_launches", 0)), 1)
+        sharding = ("reference views are independent; each rank reconstructs all views of its scene replica per step, no collective"
+                    if (world == 1 or args.scaling == "weak") else
+                    "ONE scene: its reference views are dealt round-robin over the ranks (shard_views), every rank holds the "
+                    "whole scene resident, no collective")
         out = {
             "metric": "depth-maps/sec (1920x1080, 20 views, scale=2)" if args.config == "C3" else "depth-maps/sec (%s)" % args.config,
             "value": n_maps / elapsed, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-view %dx%d synthetic height-field scene, scale=%d (%dx%d depth maps), "
                                    "%d local neighbours, 2000 features; one step = all %d reference views"
-                                   % (args.config, p.n_views, p.width, p.height, cfg["scale"], res[0]["depth"].shape[1],
-                                      res[0]["depth"].shape[0], cfg["local_neighbors"], p.n_views),
-                       "sharding": "reference views are independent; each rank reconstructs all views of its scene replica per step, no collective",
+                                   % (args.config, p.n_views, p.width, p.height, cfg["scale"], shape[1],
+                                      shape[0], cfg["local_neighbors"], p.n_views),
+                       "sharding": sharding,
                        "host_threads_per_gpu": n_streams, "steps_per_call": spc,
                        "mean_fill": round(fill, 4)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -218,16 +293,31 @@ def main():
                          "algorithmic_bytes_per_launch": b_alg / n_launch,
                          "n_eval": int(acc["n_eval"]), "n_patch": int(acc["n_patch"]), "n_filled": int(acc["n_filled"]),
                          "n_pass": int(acc.get("n_pass", 0)),
-                         "ms_bulk": acc.get("ms_bulk_kernel"), "ms_tail": acc.get("ms_tail_kernel"),
-                         "n_bulk_launches": int(acc.get("n_bulk_launches", 0)), "n_tail_launches": int(acc.get("n_tail_launches", 0)),
+                         "n_window_stages": int(acc.get("n_stage", 0)), "n_gather_passes": int(acc.get("n_gather_pass", 0)),
+                         # bytes the sampling passes actually requested (one pass gathers a patch-view's 100 texels once,
+                         # RGBA8, where the reference evaluates -- and n_eval counts -- it up to twice)
+                         "gathered_bytes_per_launch": 400.0 * acc.get("n_pass", 0) / n_launch,
+                         "per_kernel": {
+                             "k_optimize<1> (host-visible rounds)": {
+                                 "launches": nb, "avg_launch_ms": ms_bulk / nb, "algorithmic_bytes_per_launch": b_bulk / nb,
+                                 "achieved": (b_bulk / (ms_bulk / 1e3) / 1e9) if ms_bulk > 0 else None,
+                                 "frac": (b_bulk / (ms_bulk / 1e3) / 1e9 / HBM_PEAK_GBS) if ms_bulk > 0 else None},
+                             "k_tail (blind tail rounds)": {
+                                 "launches": nt, "avg_launch_ms": ms_tail / nt, "algorithmic_bytes_per_launch": b_tail / nt,
+                                 "achieved": (b_tail / (ms_tail / 1e3) / 1e9) if ms_tail > 0 else None,
+                                 "frac": (b_tail / (ms_tail / 1e3) / 1e9 / HBM_PEAK_GBS) if ms_tail > 0 else None}},
                          "kernel_time_share": opt_s / elapsed if elapsed > 0 else None,
                          # the launches of the host threads' streams overlap on the GPU, so each launch's own duration
                          # (above, as the contract asks) stretches; the same bytes over the wall time of the region:
                          "aggregate_achieved": b_alg / elapsed / 1e9 if elapsed > 0 else None,
                          "aggregate_frac": b_alg / elapsed / 1e9 / HBM_PEAK_GBS if elapsed > 0 else None},
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cfg)
+            out["cpu_baseline"], parity = cpu_baseline(scene, cfg, gpu_maps=res[:p.n_views])
+            if parity is not None:
+                out["parity"] = parity
         print(json.dumps(out))
     coll.barrier()
     for c in ctxs[1:]:

@@ -110,6 +110,9 @@ typedef struct mi_dmrecon_stats {
     int64_t n_pass;         /* fused sampling passes actually run (each gathers the 100 texels of one patch-view
                              * once; a pass can stand for two of the reference's evaluations, see n_eval) */
     int64_t truncated;      /* 1 if the propagation ran out of round counters (the call fails with EDEVICE) */
+    int64_t n_eval_bulk, n_patch_bulk, n_filled_bulk;   /* the share of n_eval / n_patch / n_filled of the host-visible rounds */
+    int64_t n_stage;        /* texel windows staged into LDS (a patch-view needs one unless its window moves out of the box) */
+    int64_t n_gather_pass;  /* passes of the window kernels that sampled by global gathers after all (window larger than a box) */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);

@@ -72,7 +72,9 @@ class CStats(ctypes.Structure):
                 ("ms_opt_kernel", ctypes.c_double), ("ms_sweep_kernels", ctypes.c_double),
                 ("ms_bulk_kernel", ctypes.c_double), ("ms_tail_kernel", ctypes.c_double),
                 ("n_bulk_launches", ctypes.c_int64), ("n_tail_launches", ctypes.c_int64),
-                ("n_pass", ctypes.c_int64), ("truncated", ctypes.c_int64)]
+                ("n_pass", ctypes.c_int64), ("truncated", ctypes.c_int64),
+                ("n_eval_bulk", ctypes.c_int64), ("n_patch_bulk", ctypes.c_int64), ("n_filled_bulk", ctypes.c_int64),
+                ("n_stage", ctypes.c_int64), ("n_gather_pass", ctypes.c_int64)]
 
 
 _lib = None

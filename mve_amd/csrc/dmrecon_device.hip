@@ -91,13 +91,17 @@ __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelec
  * fit one) is it staged again / sampled by scattered global gathers.
  *   Lay<1>  one lane = one view slot: MI_WIN1_W x MI_WIN1_H texels per lane
  *   Lay<16> a 16-lane row = one view slot: 16 x 16 texels, one row per lane */
+#ifndef MI_WIN1_W
 #define MI_WIN1_W 10
 #define MI_WIN1_H 10
+#endif
+/* dwords between the windows of neighbouring lanes: odd, so that 32 lanes reading the same window position hit 32 banks */
+#define MI_WIN1_STRIDE ((MI_WIN1_W * MI_WIN1_H) | 1)
 #define MI_WIN16_W 16
 #define MI_WIN16_H 16
 #define MI_NOBOX (-0x40000000)
-__shared__ uint32_t g_win1[WAVE][MI_WIN1_W * MI_WIN1_H];
-__shared__ __attribute__((aligned(16))) uint32_t g_win16[4][MI_WIN16_W * MI_WIN16_H];
+__shared__ uint32_t g_win1[WAVE][MI_WIN1_STRIDE];
+__shared__ __attribute__((aligned(16))) uint32_t g_win16[4][4][MI_WIN16_W * MI_WIN16_H];   /* [wavefront][view slot] */
 
 /* ------------------------------------------------------------------------- */
 /* Lane layouts.  A patch is optimised by 4 "view slots" (one per local neighbour view);
@@ -168,7 +172,8 @@ template <> struct Lay<16> {
     static constexpr int PATCHES = 1;
     __device__ static __forceinline__ int vslot(int lane) { return lane >> 4; }
     __device__ static __forceinline__ int sub(int lane) { return lane & 15; }
-    __device__ static __forceinline__ int patch(int) { return 0; }
+    /* LDS slot of the patch = the wavefront's index in its workgroup (k_tail runs four wavefronts per workgroup) */
+    __device__ static __forceinline__ int patch(int) { return (int)(threadIdx.x >> 6); }
     __device__ static __forceinline__ float view_sum(float v) {      /* all 16 lanes of the row get the sum */
         v = fadd_i(v, dpp_xor1(__float_as_int(v)));
         v = fadd_i(v, dpp_xor2(__float_as_int(v)));
@@ -213,7 +218,7 @@ template <> struct Lay<16> {
         return (unsigned)((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull));
     }
     static constexpr int WW = MI_WIN16_W, WH = MI_WIN16_H;
-    __device__ static __forceinline__ uint32_t* win(int lane) { return g_win16[lane >> 4]; }
+    __device__ static __forceinline__ uint32_t* win(int lane) { return g_win16[threadIdx.x >> 6][lane >> 4]; }
 };
 
 /* ------------------------------------------------------------------------- */
@@ -237,6 +242,7 @@ struct PatchState {
     float ncc;                   /* getFastNCC(my view) at the current state */
     /* counters (flushed at kernel end) */
     unsigned n_eval, n_pass;
+    DevCounters* counters;       /* window diagnostics are added directly (one atomic per wavefront and event) */
 };
 
 struct NView {                   /* my neighbour view at the selected mip level */
@@ -326,11 +332,17 @@ __device__ __forceinline__ void stage_window(const uint32_t* lin, int w, int h, 
         for (int r = 0; r < L::WH; ++r) {
             const int y = min(by + r, h - 1);
             const uint32_t* src = lin + (size_t)y * w + bx;
-            const u32x4 a = *(gtex4u_t)(src);
-            const u32x4 b = *(gtex4u_t)(src + 4);
-            const u32x2 c = *(gtex2_t)(src + 8);
             uint32_t* d = win + r * L::WW;
-            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w; d[8] = c.x; d[9] = c.y;
+#pragma unroll
+            for (int c0 = 0; c0 < L::WW; c0 += 4) {
+                if (c0 + 4 <= L::WW) {
+                    const u32x4 a = *(gtex4u_t)(src + c0);
+                    d[c0] = a.x; d[c0 + 1] = a.y; d[c0 + 2] = a.z; d[c0 + 3] = a.w;
+                } else {
+                    const u32x2 c = *(gtex2_t)(src + c0);
+                    d[c0] = c.x; d[c0 + 1] = c.y;
+                }
+            }
         }
     } else {
         /* one row of 16 texels per lane of the view slot */
@@ -553,8 +565,10 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         Pre q[NITER];
 #pragma unroll
         for (int b = 0; b < NITER; ++b) q[b] = fetch(b);
+        TSTAMP(60);
 #pragma unroll
         for (int b = 0; b < NITER; ++b) consume(q[b]);
+        TSTAMP(61);
     }
     if (MODE != PASS_DUMP) {
         S.a0 = L::view_sum(S.a0); S.a1 = L::view_sum(S.a1); S.a2 = L::view_sum(S.a2);
@@ -577,6 +591,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         gn.A11 = (double)L::view_sum(A11); gn.A12 = (double)L::view_sum(A12); gn.A22 = (double)L::view_sum(A22);
         gn.B0 = (double)L::view_sum(B0); gn.B1 = (double)L::view_sum(B1); gn.B2 = (double)L::view_sum(B2);
     }
+    TSTAMP(62);
     return L::view_all(ok);
 }
 
@@ -854,6 +869,10 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
         nv.bx = bx; nv.by = by;
         stage_window<LPV>(vc.lin, nv.w, nv.h, bx, by, L::win(lane), sub);
         have = true;
+        if (sub == 0) {
+            const unsigned long long m = __ballot(true);
+            if (lane == __ffsll((long long)m) - 1) atomicAdd(&ps.counters->n_stage, (unsigned long long)__popcll(m));
+        }
     }
     if (LPV != 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   /* rows staged by the other lanes of my slot */
     if (have) nv.win = L::win(lane);
@@ -871,7 +890,9 @@ __device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevVie
     /* the throughput layout without windows has no registers to spare for the cache: set the view up per pass */
     if (!WIN && LPV == 1) viewc_reset(vc);
     if (ps.sel >= 0) {
+        TSTAMP(50);
         okv = view_prepare<LPV, WIN>(ps, vc, views, rays, lane, sub);
+        TSTAMP(51);
         if (okv) {
             bool done = false, fits;
             if (WIN && vc.nv.win) {
@@ -880,7 +901,13 @@ __device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevVie
                 done = fits || !okv;          /* a failed pass is a failed pass, whatever it read */
                 if (!done) { vc.nv.bx = MI_NOBOX; okv = true; }
             }
-            if (!done) okv = sample_pass<MODE, LPV, false>(ps, vc.nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub, fits);
+            if (!done) {
+                if (WIN && sub == 0) {           /* a pass the windows could not serve */
+                    const unsigned long long m = __ballot(true);
+                    if (lane == __ffsll((long long)m) - 1) atomicAdd(&ps.counters->n_gather_pass, (unsigned long long)__popcll(m));
+                }
+                okv = sample_pass<MODE, LPV, false>(ps, vc.nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub, fits);
+            }
         }
         ps.n_pass++;
         if (okv) {
@@ -933,7 +960,8 @@ __device__ __forceinline__ void load_job_constants(PatchState& ps, const DevJob*
 /* Returns false if the optimisation is over before it started (the result keeps confidence 0). */
 template <int LPV>
 __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
-                                          float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane, unsigned& err) {
+                                          float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane, unsigned& err,
+                                          DevCounters* counters) {
     typedef Lay<LPV> L;
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
@@ -941,7 +969,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     float* mcol = g_mcol[L::patch(lane)];
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const int pl = slot * LPV + sub;                 /* lane index inside the patch */
-    ps.job = job; ps.x = x; ps.y = y; ps.n_eval = 0; ps.n_pass = 0;
+    ps.job = job; ps.x = x; ps.y = y; ps.n_eval = 0; ps.n_pass = 0; ps.counters = counters;
     ps.sel = -1; ps.cs0 = ps.cs1 = ps.cs2 = 1.f; ps.ncc = -1.f;
     ps.depth = depth0; ps.dzI = dzI0; ps.dzJ = dzJ0;
     viewc_reset(R.vc);
@@ -1008,6 +1036,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
         return false;
     }
 
+    TSTAMP(11);
     /* --- LocalViewSelection ctor (local_view_selection.cc:19-54) */
     ps.avail = job->n_global >= 32 ? 0xFFFFFFFFu : ((1u << job->n_global) - 1u);
     {
@@ -1157,6 +1186,7 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
         R.ctx = CTX_STEP;
         R.count_color = true;
     }
+    TSTAMP(32);
     return true;
 }
 
@@ -1216,18 +1246,19 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
     res.nx = nx; res.ny = ny; res.nz = nz;
     const float dotP = -(nx * rays[36] + ny * rays[37] + nz * rays[38]);   /* viewRayScaled(midx, midy) = ray 12 */
     res.conf = (dotP < 0.2f) ? 0.f : score;
+    TSTAMP(41);
 }
 
 template <int LPV, bool WIN>
 __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
                                float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane,
-                               PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err) {
+                               PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err, DevCounters* counters) {
     Run R;
     TSTAMP(10);
 #ifdef MI_HIST
     /* diagnostic build: turns per patch vs turns per wavefront (lane divergence of the throughput layout) */
     unsigned turns = 0;
-    if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err))
+    if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
         do { ++turns; } while (run_turn<LPV, WIN>(R, st, views, lane));
     if (LPV == 1 && g_hist) {
         unsigned mx = turns;
@@ -1236,7 +1267,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
         if (lane == __ffsll(__ballot(true)) - 1) { atomicAdd(&g_hist[33], (unsigned long long)mx); atomicAdd(&g_hist[34], 1ull); }
     }
 #else
-    if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err))
+    if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
         while (run_turn<LPV, WIN>(R, st, views, lane)) { }
 #endif
     TSTAMP(40);
@@ -1333,7 +1364,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
         }
         PatchResult r;
         TSTAMP(3);
-        optimize_patch<LPV, WIN>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err);
+        optimize_patch<LPV, WIN>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters);
         TSTAMP(4);
         ++n_patch; ++attempts;
         const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
@@ -1429,34 +1460,27 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && L
 /*
  * One fused round of the propagation tail (replaces generate -> optimise -> apply, three dependent launches, by one).
  *
- * Unit of work = a CANDIDATE: (pixel p accepted in the previous round, one of its 4-neighbours q).  If the push
- * rule (dmrecon.cc:400-431) holds against the state frozen at the end of the previous round, ONE wavefront
- * optimises q from p's result (latency layout) -- every candidate of q at the same time, on its own wavefront.
- * The reference would try q's candidates one after the other, best source confidence first, skipping a candidate
- * once q has got a confidence above its source's (pop-time test, dmrecon.cc:371) and accepting a result only if
- * it beats the best so far (:391).  The optimisations themselves do not depend on each other (they all read the
- * frozen state), so they run speculatively in parallel and the sequential rule is applied afterwards by the last
- * of q's candidates to finish (per-pixel arrival counter; results of the others through DevCand records):
- * same results, but a round is as long as ONE patch optimisation instead of up to four in a row.
+ * A CANDIDATE is (pixel p accepted in the previous round, one of its 4-neighbours q) for which the push rule
+ * (dmrecon.cc:400-431) holds against the state frozen at the end of the previous round.  The reference would try
+ * q's candidates one after the other, best source confidence first, skipping a candidate once q has got a
+ * confidence above its source's (pop-time test, dmrecon.cc:371) and accepting a result only if it beats the best
+ * so far (:391).  The optimisations themselves do not depend on each other (they all read the frozen state), so
+ * they run speculatively at the same time -- one WAVEFRONT each (latency layout), the up to four wavefronts of a
+ * workgroup -- and the sequential rule is applied afterwards from their results in LDS: same maps, but a round
+ * is as long as ONE patch optimisation instead of up to four in a row.
  *
- * The resolver writes an accepted result into the pixel's other state slot (see DevJob) and appends q to this
- * round's list.  Which wavefront resolves, and the order of the list, depend on timing; the results do not.
+ * Work distribution without claims or atomics: a workgroup is started for every (p, direction); it goes on only
+ * if p is q's BEST source (highest confidence, lowest direction on ties) -- exactly one of q's candidates is.
+ * Its wavefront w takes q's w-th best source; wavefronts without a source end at once.  The first wavefront
+ * resolves, writes an accepted result into the pixel's other state slot (see DevJob) and appends q to this
+ * round's list.  The order of the list depends on timing; the results do not.
  */
-struct DevCand {                  /* result of one speculative attempt (MI_CAND_BYTES) */
-    float conf, depth, dzI, dzJ, nx, ny, nz;
-    uint32_t views;
-    int32_t iters;
-    uint32_t n_eval, n_pass;
-    uint32_t pad;
-};
-static_assert(sizeof(DevCand) == MI_CAND_BYTES, "DevCand size");
+#define MI_TAIL_WAVES 4
 struct TailArgs {
     OptArgs o;                    /* o.work / o.results: this round's list and results (written here) */
     const DevEntry* prev_work;    /* previous round's list, results and entry count */
     const DevResult* prev_results;
     unsigned* round_work;         /* [MI_MAX_ROUNDS] accepted entries per round */
-    DevCand* cand;                /* [4 * cand_cap] attempt results of this round, indexed 4 * source entry + direction */
-    unsigned cand_cap;            /* the previous round's list must not be longer (else: error flag 2, round not run) */
 };
 
 /* state of pixel p as the optimisations of round `round` must see it (frozen at the end of round - 1):
@@ -1471,15 +1495,19 @@ __device__ __forceinline__ Frozen frozen_state(const DevJob* job, int p, int rou
     return f;
 }
 
+struct TailRes { PatchResult r; unsigned n_eval, n_pass; };
+__shared__ TailRes g_tail_res[MI_TAIL_WAVES];
+
 template <bool WIN>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tail(TailArgs t) {
-    typedef Lay<16> L;
+__global__ __launch_bounds__(MI_TAIL_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tail(TailArgs t) {
     const OptArgs& a = t.o;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const unsigned n_prev = t.round_work[a.round - 1];
     if (blockIdx.x >= 4u * n_prev) return;
-    if (n_prev > t.cand_cap) { if (lane == 0 && blockIdx.x == 0) atomicOr(&a.counters->error_flags, 2u); return; }
-    for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
+    /* one candidate per workgroup (the usual case): wavefronts without a source can end; otherwise the workgroup
+     * strides over the candidates and all its wavefronts stay for the barriers */
+    const bool single = 4u * n_prev <= gridDim.x;
+    for (int i = threadIdx.x; i < 256; i += MI_TAIL_WAVES * WAVE) g_lut[i] = a.lut[i];
     __syncthreads();
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;
     for (unsigned cand = blockIdx.x; cand < 4u * n_prev; cand += gridDim.x) {
@@ -1501,85 +1529,91 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         for (int j = 0; j < 4; ++j) nf[j] = frozen_state(job, nb[j], a.round);
         const float own = me.conf;
         if (!(own < pr.conf - 0.05f || own == 0.f)) continue;
-        /* q's candidates of this round: neighbours written last round for which the push rule holds */
+        /* q's candidates of this round: neighbours written last round for which the push rule holds, in the
+         * reference's order of trial: descending source confidence, lowest direction first on ties */
         unsigned elig = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (nf[j].upd == a.round - 1 && (own < nf[j].conf - 0.05f || own == 0.f)) elig |= 1u << j;
-        const int n_cand = __popc(elig);
-        const int mine = (int)(k ^ 1u);                                        /* my source seen from q */
-        /* speculative attempt from my source's result */
-        PatchResult r;
-        unsigned ce = 0, cp = 0;
-        optimize_patch<16, WIN>(job, a.st, a.views, qx, qy, pr.depth, pr.dzI, pr.dzJ, pr.views, lane, r, ce, cp, err);
-        /* counters of optimize_patch are per view slot (row leaders): bring them to lane 0 */
-        ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
-                      + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
-        cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
-                      + __builtin_amdgcn_readlane((int)cp, 32) + __builtin_amdgcn_readlane((int)cp, 48));
-        bool resolver = true;
-        if (n_cand > 1) {
-            int old = 0;
-            if (lane == 0) {
-                DevCand o;
-                o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ; o.nx = r.nx; o.ny = r.ny; o.nz = r.nz;
-                o.views = r.views; o.iters = r.iters; o.n_eval = ce; o.n_pass = cp; o.pad = 0;
-                t.cand[cand] = o;
-                __threadfence();                                               /* release: the record before the count */
-                old = atomicAdd(&job->arrive[q], 1);
-            }
-            old = __builtin_amdgcn_readfirstlane(old);
-            resolver = old == n_cand - 1;
-            if (resolver) {
-                if (lane == 0) job->arrive[q] = 0;                             /* every candidate has arrived: ready for the next round */
-                __threadfence();                                               /* acquire: the other candidates' records */
-            }
-        }
-        if (!resolver) continue;
-        /* the reference's sequential rule over q's candidates, descending source confidence (ties: lowest direction) */
-        float best = own;
-        bool accepted = false;
-        PatchResult fin = r;
-        unsigned done = 0;
-        for (int s = 0; s < n_cand; ++s) {
-            int bi = -1; float bc = 0.f;
+        /* (registers only: a dynamically indexed private array would be placed in LDS) */
+        unsigned order = 0; int n_cand = 0;                                    /* 2 bits per rank: the direction */
+        {
+            unsigned left = elig;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (((elig >> j) & 1u) && !((done >> j) & 1u) && (bi < 0 || nf[j].conf > bc)) { bi = j; bc = nf[j].conf; }
-            done |= 1u << bi;
-            if (best > bc) break;                                              /* dmrecon.cc:371 (and every later one) */
-            PatchResult c = r; unsigned xe = ce, xp = cp;
-            if (bi != mine) {
-                const unsigned oc = 4u * (unsigned)GI(job->mark + nb[bi]) + (unsigned)(bi ^ 1);
-                const DevCand o = t.cand[oc];
-                c.conf = o.conf; c.depth = o.depth; c.dzI = o.dzI; c.dzJ = o.dzJ; c.nx = o.nx; c.ny = o.ny; c.nz = o.nz;
-                c.views = o.views; c.iters = o.iters; xe = o.n_eval; xp = o.n_pass;
+            for (int s = 0; s < 4; ++s) {
+                int bi = -1; float bc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (((left >> j) & 1u) && (bi < 0 || nf[j].conf > bc)) { bi = j; bc = nf[j].conf; }
+                if (bi >= 0) { order |= (unsigned)bi << (2 * s); ++n_cand; left &= ~(1u << bi); }
             }
-            if (lane == 0) { n_eval += xe; n_pass += xp; ++n_patch; }          /* attempts the reference would have made */
-            if (c.conf > 0.f && best < c.conf) { best = c.conf; accepted = true; fin = c; }   /* dmrecon.cc:378,391 */
         }
-        if (accepted && lane == 0) {
-            const unsigned e = atomicAdd(&t.round_work[a.round], 1u);
-            DevEntry we; we.job = src.job; we.xy = qx | (qy << 16);
-            const_cast<DevEntry*>(a.work)[e] = we;
-            DevResult o;
-            o.conf = fin.conf; o.depth = fin.depth; o.dzI = fin.dzI; o.dzJ = fin.dzJ;
-            o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.iters = fin.iters;
-            o.accepted = 1; o.tried = done;
-            a.results[e] = o;
-            job->mark[q] = (int)e;                                             /* where next round's resolvers find my attempts */
-            const bool one = me.one;                                           /* slot holding the old state */
-            float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
-            float* cq = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
-            uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
-            dp[q] = fin.depth; zp[2 * q] = fin.dzI; zp[2 * q + 1] = fin.dzJ;
-            np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
-            cq[q] = fin.conf; vp[q] = fin.views; up[q] = a.round;
-            if (own <= 0.f) { ++n_filled; atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u); }
+        auto dir_of = [&](int s) -> int { return (int)((order >> (2 * s)) & 3u); };
+        auto conf_of = [&](int j) -> float { return j == 0 ? nf[0].conf : j == 1 ? nf[1].conf : j == 2 ? nf[2].conf : nf[3].conf; };
+        const int mine = (int)(k ^ 1u);                                        /* my source seen from q */
+        if (n_cand == 0 || dir_of(0) != mine) continue;                        /* the workgroup of q's best source does q */
+        const bool active = wave < n_cand;
+        if (!active && single) return;
+        if (active) {
+            /* my source's result = the hypothesis (wavefront 0: the previous round's record; the others read their
+             * source's frozen state) */
+            float hd = pr.depth, hi = pr.dzI, hj = pr.dzJ; unsigned hv = pr.views;
+            if (wave > 0) {
+                const int j = dir_of(wave);
+                const int p = j == 0 ? nb[0] : j == 1 ? nb[1] : j == 2 ? nb[2] : nb[3];
+                const bool one = j == 0 ? nf[0].one : j == 1 ? nf[1].one : j == 2 ? nf[2].one : nf[3].one;
+                hd = GF((one ? job->depth1 : job->depth) + p);
+                hi = GF((one ? job->dz1 : job->dz) + 2 * p); hj = GF((one ? job->dz1 : job->dz) + 2 * p + 1);
+                hv = GU((one ? job->views1 : job->views) + p);
+            }
+            PatchResult r;
+            unsigned ce = 0, cp = 0;
+            optimize_patch<16, WIN>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
+            /* counters of optimize_patch are per view slot (row leaders): bring them to lane 0 */
+            ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
+                          + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
+            cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
+                          + __builtin_amdgcn_readlane((int)cp, 32) + __builtin_amdgcn_readlane((int)cp, 48));
+            if (lane == 0) { g_tail_res[wave].r = r; g_tail_res[wave].n_eval = ce; g_tail_res[wave].n_pass = cp; }
         }
+        if (n_cand > 1 || !single) __syncthreads();
+        if (wave == 0) {
+            /* the reference's sequential rule over q's candidates */
+            float best = own;
+            bool accepted = false;
+            PatchResult fin = g_tail_res[0].r;
+            unsigned done = 0;
+            for (int s = 0; s < n_cand; ++s) {
+                const float bc = conf_of(dir_of(s));
+                if (best > bc) break;                                          /* dmrecon.cc:371 (and every later one) */
+                done |= 1u << dir_of(s);
+                const PatchResult c = g_tail_res[s].r;
+                if (lane == 0) { n_eval += g_tail_res[s].n_eval; n_pass += g_tail_res[s].n_pass; ++n_patch; }   /* attempts the reference makes */
+                if (c.conf > 0.f && best < c.conf) { best = c.conf; accepted = true; fin = c; }   /* dmrecon.cc:378,391 */
+            }
+            if (accepted && lane == 0) {
+                const unsigned e = atomicAdd(&t.round_work[a.round], 1u);
+                DevEntry we; we.job = src.job; we.xy = qx | (qy << 16);
+                const_cast<DevEntry*>(a.work)[e] = we;
+                DevResult o;
+                o.conf = fin.conf; o.depth = fin.depth; o.dzI = fin.dzI; o.dzJ = fin.dzJ;
+                o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.iters = fin.iters;
+                o.accepted = 1; o.tried = done;
+                a.results[e] = o;
+                const bool one = me.one;                                       /* slot holding the old state */
+                float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
+                float* cq = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
+                uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
+                dp[q] = fin.depth; zp[2 * q] = fin.dzI; zp[2 * q + 1] = fin.dzJ;
+                np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
+                cq[q] = fin.conf; vp[q] = fin.views; up[q] = a.round;
+                if (own <= 0.f) { ++n_filled; atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u); }
+            }
+        }
+        if (!single) __syncthreads();                                          /* g_tail_res is reused by the next candidate */
     }
-    /* n_eval / n_pass / n_patch / n_filled were kept by lane 0 only */
-    if (lane == 0) {
+    /* n_eval / n_pass / n_patch / n_filled were kept by lane 0 of wavefront 0 only */
+    if (threadIdx.x == 0) {
         if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
         if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
         if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
@@ -1620,7 +1654,7 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     __syncthreads();
     /* reuse optimize_patch's setup by replicating its prologue on quad 0 only */
     const DevJob* job = a.job;
-    PatchState ps; ps.job = job; ps.x = a.x; ps.y = a.y; ps.n_eval = ps.n_pass = 0; ps.sel = -1;
+    PatchState ps; ps.job = job; ps.x = a.x; ps.y = a.y; ps.n_eval = ps.n_pass = 0; ps.sel = -1; ps.counters = nullptr;
     ps.jcx = job->cam_pos[0]; ps.jcy = job->cam_pos[1]; ps.jcz = job->cam_pos[2];
     ps.jz0 = job->w2c_z[0]; ps.jz1 = job->w2c_z[1]; ps.jz2 = job->w2c_z[2]; ps.jz3 = job->w2c_z[3];
     ps.jinv0 = job->inv0_s;
@@ -1797,7 +1831,6 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
                 const int pix = (ent.xy >> 16) * job->w + (ent.xy & 0xFFFF);
                 newly = job->conf[pix] <= 0.f;
                 write_pixel(job, pix, r, a.round);
-                job->mark[pix] = (int)e;          /* entry index: where a following tail round finds this pixel's attempts */
             }
         }
         filled += (unsigned)__popcll(__ballot(newly));
@@ -1961,17 +1994,15 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
 
 void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                     const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
-                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, DevCand* cand,
-                    unsigned cand_cap, bool windows) {
+                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows) {
     TailArgs t;
-    t.cand = cand; t.cand_cap = cand_cap;
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
-    if (windows) hipLaunchKernelGGL(k_tail<true>, dim3(grid_blocks), dim3(WAVE), 0, s, t);
-    else hipLaunchKernelGGL(k_tail<false>, dim3(grid_blocks), dim3(WAVE), 0, s, t);
+    if (windows) hipLaunchKernelGGL(k_tail<true>, dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
+    else hipLaunchKernelGGL(k_tail<false>, dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
 }
 
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px) {
@@ -1981,7 +2012,7 @@ void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total
     float* m1 = maps + 7 * total_px;
     a.depth1 = m1; a.conf1 = m1 + total_px; a.dz1 = m1 + 2 * total_px; a.normal1 = m1 + 4 * total_px;
     a.views = imaps; a.upd = (int32_t*)(imaps + total_px);
-    a.views1 = imaps + 3 * total_px; a.upd1 = (const int32_t*)(imaps + 4 * total_px);
+    a.views1 = imaps + 2 * total_px; a.upd1 = (const int32_t*)(imaps + 3 * total_px);
     a.n = (unsigned)total_px;
     hipLaunchKernelGGL(k_flatten, dim3((unsigned)((total_px + 255) / 256)), dim3(256), 0, s, a);
 }

@@ -194,7 +194,6 @@ struct mi_dmrecon_ctx {
     DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
     DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
     DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
-    DevBuf<uint8_t> d_cand;                  /* tail rounds: DevCand attempt records, 4 per source entry */
     TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     uint8_t* h_dyn = nullptr;                /* pinned: two read-backs of the job table (its flags / n_filled words are polled) */
@@ -425,9 +424,9 @@ DevSettings dev_settings(const mi_dmrecon_settings* st) {
 int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px) {
     total_px = 0;
     for (size_t j = 0; j < jobs.size(); ++j) { jobs[j].pix_off = total_px; total_px += (size_t)jobs[j].w * jobs[j].h; }
-    /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd, mark + views1, upd1 + arrive */
+    /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd + views1, upd1 */
     if (c->d_maps.reserve(total_px * 14)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
-    if (c->d_imaps.reserve(total_px * 6)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
+    if (c->d_imaps.reserve(total_px * 4)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
     float* base = c->d_maps.p;
     float* base1 = base + 7 * total_px;
     uint32_t* ibase = c->d_imaps.p;
@@ -439,19 +438,16 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
         dj[j].normal = base + 4 * total_px + 3 * o;
         dj[j].views = ibase + o;
         dj[j].upd = (int32_t*)(ibase + total_px + o);
-        dj[j].mark = (int32_t*)(ibase + 2 * total_px + o);
         dj[j].depth1 = base1 + o;
         dj[j].conf1 = base1 + total_px + o;
         dj[j].dz1 = base1 + 2 * total_px + 2 * o;
         dj[j].normal1 = base1 + 4 * total_px + 3 * o;
-        dj[j].views1 = ibase + 3 * total_px + o;
-        dj[j].upd1 = (int32_t*)(ibase + 4 * total_px + o);
-        dj[j].arrive = (int32_t*)(ibase + 5 * total_px + o);
+        dj[j].views1 = ibase + 2 * total_px + o;
+        dj[j].upd1 = (int32_t*)(ibase + 3 * total_px + o);
     }
     /* slot 1 is only ever read where its stamp says so: the stamps (0xFF.. = -1) are all it needs */
     HIP_TRY(hipMemsetAsync(c->d_maps.p, 0, total_px * 7 * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * 5 * sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_imaps.p + 5 * total_px, 0, total_px * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * 4 * sizeof(uint32_t), c->stream));
     return 0;
 }
 
@@ -514,7 +510,6 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
     c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release(); c->d_follow.release(); c->d_follow_cnt.release();
     c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release();
-    c->d_cand.release();
     if (c->h_poll) (void)hipHostFree(c->h_poll);
     if (c->h_dyn) (void)hipHostFree(c->h_dyn);
     for (int k = 0; k < 2; ++k) if (c->poll_ev[k]) (void)hipEventDestroy(c->poll_ev[k]);
@@ -850,10 +845,8 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
      * per entry) -- the bit-exact reference for the speculative tail rounds, see tests/test_gpu_parity.py */
     const int BULK_LPV = [] { const char* e = std::getenv("MI_DMRECON_BULK_LPV"); return (e && std::atoi(e) == 16) ? 16 : 1; }();
     const unsigned BULK_PPW = BULK_LPV == 16 ? 1u : (unsigned)MI_PATCHES_PER_WAVE;
-    const size_t cand_cap = std::min<size_t>(work_cap, 1u << 18);
-    if (c->d_cand.reserve(4 * cand_cap * MI_CAND_BYTES)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(attempt records) failed");
     if (!c->h_poll) {
-        if (hipHostMalloc((void**)&c->h_poll, 2 * sizeof(TailPoll), hipHostMallocDefault) != hipSuccess)
+        if (hipHostMalloc((void**)&c->h_poll, 3 * sizeof(TailPoll), hipHostMallocDefault) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(poll buffer) failed");
         for (int k = 0; k < 2; ++k) if (hipEventCreateWithFlags(&c->poll_ev[k], hipEventDisableTiming) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipEventCreate failed");
@@ -868,7 +861,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         c->h_dyn_cap = want;
     }
     auto dyn_of = [&](int slot) -> DevJob* { return (DevJob*)c->h_dyn + (size_t)slot * nj; };
-    bool first_phase_a = true, ran_tail = false;
+    bool first_phase_a = true, ran_tail = false, have_handover = false;
     int round = 1;
     const int max_rounds = MI_MAX_ROUNDS - 2 * (int)TAIL_CHUNK - 2;
     DevCounters hc;
@@ -950,7 +943,12 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             ev_begin(1);
             mi_launch_apply(c->stream, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
             ev_end();
-            if (tail) { ++round; to_tail = true; break; }
+            if (tail) {
+                /* counters as of the end of the host-visible rounds (slot 2 of the poll buffer; read after the call) */
+                HIP_TRY(hipMemcpyAsync(&c->h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+                have_handover = true;
+                ++round; to_tail = true; break;
+            }
         }
         if (first_phase_a) { mark("seeds + phase A rounds"); first_phase_a = false; }
         if (done || n_alive == 0) break;
@@ -971,7 +969,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                 const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
                 if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
                 mi_launch_tail(c->stream, TAIL_GRID, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
-                               c->d_round_work.p, round, c->d_counters, (DevCand*)c->d_cand.p, (unsigned)cand_cap, WIN_TAIL);
+                               c->d_round_work.p, round, c->d_counters, WIN_TAIL);
                 if (timed) ev_end();
                 std::swap(wcur, wnext);
                 std::swap(rcur, rnext);
@@ -986,7 +984,6 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         };
         ran_tail = true;
         int slot = 0;
-        bool overflow = false;
         if (enqueue_chunk(0)) return fail(MI_DMRECON_EDEVICE, "enqueue of tail rounds failed");
         for (;;) {
             const bool more_room = round + (int)TAIL_CHUNK < MI_MAX_ROUNDS - 1;
@@ -1002,12 +999,10 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             }
             if (poll_views(dyn_of(slot), P.rw[TAIL_CHUNK - 1])) return fail(MI_DMRECON_EDEVICE, "hipMemcpyAsync(job flags) failed");
             if (end_round >= 0) {
-                /* an empty round: the propagation is over -- or (flag 2) that round's source list did not fit the
-                 * attempt buffer and must be run as a host-visible round */
-                overflow = (hc.error_flags & 2u) != 0;
+                /* an empty round: the propagation is over */
                 if (more_room) HIP_TRY(hipEventSynchronize(c->poll_ev[slot ^ 1]));     /* the chunk in flight is all no-ops */
                 round = end_round;
-                if (!overflow) done = true;
+                done = true;
                 break;
             }
             if (n_alive == 0) break;
@@ -1015,10 +1010,6 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             slot ^= 1;
         }
         mi_launch_flatten(c->stream, c->d_maps.p, c->d_imaps.p, total_px);
-        if (overflow) {
-            HIP_TRY(hipMemsetAsync((char*)c->d_counters + offsetof(DevCounters, error_flags), 0, sizeof(unsigned), c->stream));
-            HIP_TRY(hipMemsetAsync(c->d_round_work.p + round, 0, (MI_MAX_ROUNDS - round) * sizeof(unsigned), c->stream));
-        }
         if (truncated) break;
     }
     (void)ran_tail;
@@ -1058,6 +1049,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         stats->n_filled = (int64_t)hc.n_filled;
         stats->n_seeds = (int64_t)n_seed_feats; stats->n_seeds_ok = (int64_t)hc.n_seeds_ok;
         stats->n_rounds = round; stats->n_launches = n_launch; stats->truncated = truncated ? 1 : 0;
+        stats->n_stage = (int64_t)hc.n_stage; stats->n_gather_pass = (int64_t)hc.n_gather_pass;
         double tail_ms = 0.0; int64_t tail_timed = 0;
         size_t w = 0;
         for (size_t k = 0; k < ev_kind.size(); ++k) {
@@ -1074,6 +1066,8 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             stats->ms_opt_kernel += stats->ms_tail_kernel;
         }
         stats->n_tail_launches = n_tail_launch;
+        const DevCounters& ho = have_handover ? c->h_poll[2].hc : hc;      /* the stream has been synchronised above */
+        stats->n_eval_bulk = (int64_t)ho.n_eval; stats->n_patch_bulk = (int64_t)ho.n_patch; stats->n_filled_bulk = (int64_t)ho.n_filled;
         stats->ms_total = now_ms() - t_begin;
     }
     if (trace) {

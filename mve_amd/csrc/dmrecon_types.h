@@ -54,8 +54,6 @@ struct DevJob {
     float* normal;    /* 3 ch */
     uint32_t* views;  /* 4 x 8-bit indices into global_ids, MI_VIEW_NONE padded */
     int32_t* upd;     /* round in which the pixel was last written, -1 = never */
-    int32_t* mark;    /* index of the pixel's entry in the work list of the round that last accepted it (k_apply, k_tail) */
-    int32_t* arrive;  /* tail rounds: how many of the pixel's candidate attempts of the current round have finished (0 between rounds) */
     /* Second slot of the pixel state, used by the fused tail rounds only (k_tail): a write of round r goes to
      * the slot that does NOT hold the pixel's state as of the end of round r-1, so the optimisations of a round
      * keep reading the frozen state of the previous round without a separate write-back launch.  The state
@@ -95,13 +93,11 @@ struct DevResult {
     uint32_t tried;          /* propagate mode: neighbours (bit k: left, right, up, down) whose hypothesis has been consumed */
 };
 
-struct DevCand;              /* tail rounds: result of one speculative attempt (dmrecon_device.hip) */
-#define MI_CAND_BYTES 48
-
 struct DevCounters {
     unsigned long long n_patch, n_eval, n_pass, n_filled, n_seeds_ok;
-    unsigned int error_flags;  /* bit0: non-positive master footprint (patch_sampler.cc:78-82); bit1: a tail round's
-                                * source list exceeded the attempt buffer (the round did not run) */
+    unsigned long long n_stage;        /* texel windows staged into LDS (per patch-view; speculative attempts included) */
+    unsigned long long n_gather_pass;  /* passes of window kernels that had to sample by global gathers */
+    unsigned int error_flags;  /* bit0: non-positive master footprint (patch_sampler.cc:78-82) */
     unsigned int pad;
 };
 

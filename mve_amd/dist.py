@@ -22,6 +22,18 @@ def shard_views(view_ids: Sequence[int], rank: int, world: int) -> List[int]:
     return [v for i, v in enumerate(view_ids) if i % world == rank]
 
 
+def rank_views(view_ids: Sequence[int], rank: int, world: int, scaling: str) -> List[int]:
+    """The reference views rank `rank` reconstructs per step.
+    weak: all of them, of its own scene replica (per-GPU work fixed as N grows);
+    strong (BASELINE config 4): its share of ONE scene (total work fixed) -- apps/dmrecon/dmrecon.cc:285-318
+    deals the views of one scene over its workers the same way."""
+    if scaling == "weak" or world <= 1:
+        return list(view_ids)
+    if scaling != "strong":
+        raise ValueError("scaling must be 'weak' or 'strong'")
+    return shard_views(view_ids, rank, world)
+
+
 class Collective:
     """Barrier + max-reduce; a no-op for a single process (no torch import at N = 1)."""
 

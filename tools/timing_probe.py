@@ -18,15 +18,16 @@ loc = r["views"][ys[sel], xs[sel]]
 L.mi_dmrecon_debug_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.mi_dmrecon_debug_timing(None, 0)
 buf = np.zeros(500, np.uint64)
-for lpv in (16, 1):
+for lpv, win in ((16, 0), (16, 1), (1, 0), (1, 2)):
     os.environ["MI_DMRECON_HOOK_LPV"] = str(lpv)
+    os.environ["MI_DMRECON_WIN"] = str(win)
     for rep in range(3):
         L.mi_dmrecon_debug_timing(ctypes.c_void_p(buf.ctypes.data), 500)
         out, _ = ctx.patch_optimize(st, 0, xy[:1] if lpv == 16 else xy[:16], hyp[:1] if lpv == 16 else hyp[:16], loc[:1] if lpv == 16 else loc[:16])
     L.mi_dmrecon_debug_timing(ctypes.c_void_p(buf.ctypes.data), 500)
     ids, ts = buf[0::2], buf[1::2]
     n = int((ts > 0).sum())
-    print("lpv", lpv, "iters", out[0, 7], "stamps", n)
+    print("lpv", lpv, "win", win, "iters", out[0, 7], "stamps", n)
     prev = None
     line = []
     for i in range(n):
@@ -34,3 +35,8 @@ for lpv in (16, 1):
         line.append("%d:+%d" % (ids[i], dd))
     print(" ".join(line))
     print("total cycles", int(ts[n - 1] - ts[0]))
+    # cycles spent in the interval that ENDS at each stamp id, summed over the patch
+    agg = {}
+    for i in range(1, n):
+        agg[int(ids[i])] = agg.get(int(ids[i]), 0) + int(ts[i] - ts[i - 1])
+    print("by closing stamp:", " ".join("%d=%d" % kv for kv in sorted(agg.items())))
