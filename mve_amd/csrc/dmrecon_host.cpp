@@ -156,8 +156,22 @@ struct JobHost {          /* host-side plan of one reference view */
 
 /* What mve::Scene + ImagePyramidCache are to the reference: the views (pyramids resident in HBM),
  * the bundle features and the lookup table.  Shared, read-only, by a context and its forks. */
+/* What analyzeFeatures (dmrecon.cc:178-208) and benefitFromView (global_view_selection.cc:62-101) compute from the
+ * scene alone -- not from the reference view or the settings: which view sees which feature, the feature's depth
+ * in each view (-> footPrint) and the parallax between two views at a feature.  Built once per scene (like the image
+ * pyramids) so that the global view selection of a reference view is table look-ups plus its greedy loop; the float
+ * operations behind every entry are the ones the per-view code performs, so the selection is bit-identical. */
+struct SceneGeom {
+    bool built = false, has_plx = false;
+    size_t nv = 0, nf = 0;
+    std::vector<uint8_t> sees;               /* [v * nf + f]: v references f and f is inside v's frustum */
+    std::vector<float> zcam;                 /* [v * nf + f]: (worldToCam_v . f).z */
+    std::vector<float> plx;                  /* [(v1 * nv + v2) * nf + f]: parallax in degrees where both see f */
+};
+
 struct SceneStore {
     int device = 0;
+    SceneGeom geom;                          /* guarded by mu; dropped with views_dirty / set_features */
     std::mutex mu;                           /* guards the lazy upload of the DevView table */
     std::vector<HostView> views;
     std::vector<Feature> features;
@@ -256,6 +270,140 @@ inline float parallax(V3 const& p, HostView const& v1, HostView const& v2) {   /
     return std::acos(dp) * 180.f / kPi;
 }
 
+/* Builds SceneStore::geom (see SceneGeom).  Called with the scene mutex held. */
+void build_scene_geom(SceneStore& sc) {
+    SceneGeom& g = sc.geom;
+    const size_t nv = sc.views.size(), nf = sc.features.size();
+    g.nv = nv; g.nf = nf; g.built = true;
+    g.sees.assign(nv * nf, 0);
+    g.zcam.assign(nv * nf, 0.f);
+    /* unit directions camera -> feature (parallax(), mvs_tools.h:46-56), only needed while building */
+    std::vector<V3> dir(nv * nf);
+    const int nt = std::max(1, std::min(omp_get_num_procs(), 32));
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (long f = 0; f < (long)nf; ++f) {
+        Feature const& ft = sc.features[f];
+        const V3 p = mk(ft.pos[0], ft.pos[1], ft.pos[2]);
+        for (int j = ft.ref_begin; j < ft.ref_end; ++j) {
+            const int v = sc.feat_refs[j];
+            if (v < 0 || v >= (int)nv || !sc.views[v].valid) continue;
+            if (!sc.views[v].pointInFrustum(p)) continue;                  /* dmrecon.cc:190,203 */
+            g.sees[(size_t)v * nf + f] = 1;
+            g.zcam[(size_t)v * nf + f] = xform(sc.views[v].w2c, p)[2];     /* SingleView::footPrint's depth */
+            dir[(size_t)v * nf + f] = normalized(sub(p, sc.views[v].pos()));
+        }
+    }
+    g.has_plx = nv * nv * nf <= ((size_t)1 << 26);                         /* 256 MB of floats at most */
+    if (!g.has_plx) { g.plx.clear(); return; }
+    g.plx.assign(nv * nv * nf, 0.f);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+    for (long v1 = 0; v1 < (long)nv; ++v1)
+        for (size_t v2 = (size_t)v1 + 1; v2 < nv; ++v2)
+            for (size_t f = 0; f < nf; ++f) {
+                if (!g.sees[(size_t)v1 * nf + f] || !g.sees[v2 * nf + f]) continue;
+                float dp = std::max(std::min(dot3(dir[(size_t)v1 * nf + f].v, dir[v2 * nf + f].v), 1.f), -1.f);
+                const float a = std::acos(dp) * 180.f / kPi;
+                g.plx[((size_t)v1 * nv + v2) * nf + f] = a;               /* dot3 is symmetric in its arguments, */
+                g.plx[(v2 * nv + (size_t)v1) * nf + f] = a;               /* bit for bit                         */
+            }
+}
+
+/* plan_global_views from the scene tables: the same selection, without a single acos or projection per call */
+int plan_global_views_tables(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref, std::vector<int>& global) {
+    SceneGeom const& g = c->sc->geom;
+    const size_t nv = g.nv, nf = g.nf;
+    HostView const& R = c->sc->views[ref];
+    const bool no_box = st->aabbMin[0] == -std::numeric_limits<float>::max() && st->aabbMax[0] == std::numeric_limits<float>::max()
+                     && st->aabbMin[1] == -std::numeric_limits<float>::max() && st->aabbMax[1] == std::numeric_limits<float>::max()
+                     && st->aabbMin[2] == -std::numeric_limits<float>::max() && st->aabbMax[2] == std::numeric_limits<float>::max();
+    /* features attached to the reference view (dmrecon.cc:185-196) */
+    std::vector<int> feat;
+    feat.reserve(nf);
+    const uint8_t* sees_ref = &g.sees[(size_t)ref * nf];
+    for (size_t f = 0; f < nf; ++f) {
+        if (!sees_ref[f]) continue;
+        if (!no_box) {
+            Feature const& ft = c->sc->features[f];
+            if (!in_box(mk(ft.pos[0], ft.pos[1], ft.pos[2]), st->aabbMin, st->aabbMax)) continue;
+        }
+        feat.push_back((int)f);
+    }
+    /* per view: the attached features it sees too (dmrecon.cc:198-206), as global feature indices */
+    std::vector<std::vector<int> > featInd(nv);
+    for (size_t v = 0; v < nv; ++v) {
+        if ((int)v == ref || !c->sc->views[v].valid) continue;
+        const uint8_t* sv = &g.sees[v * nf];
+        for (size_t l = 0; l < feat.size(); ++l) if (sv[feat[l]]) featInd[v].push_back(feat[l]);
+    }
+    const float minP = st->minParallax;
+    /* the part of benefitFromView's score that does not depend on the selected set (:76-89) */
+    std::vector<std::vector<float> > base(nv);
+    const float inv_m = R.levels[st->scale].invproj[0];
+    for (size_t i = 0; i < nv; ++i) {
+        if ((int)i == ref || !c->sc->views[i].valid) continue;
+        const float inv_n = c->sc->views[i].levels[0].invproj[0];
+        const float* plx_ri = &g.plx[((size_t)ref * nv + i) * nf];
+        base[i].resize(featInd[i].size());
+        for (size_t k = 0; k < featInd[i].size(); ++k) {
+            const size_t f = featInd[i][k];
+            float score = 1.f;
+            const float plx = plx_ri[f];
+            if (plx < minP) score *= (plx / 10.f) * (plx / 10.f);
+            const float mfp = g.zcam[(size_t)ref * nf + f] * inv_m;
+            const float nfp = g.zcam[i * nf + f] * inv_n;
+            float ratio = mfp / nfp;
+            if (ratio > 2.) ratio = 2. / ratio;
+            else if (ratio > 1.) ratio = 1.;
+            score *= ratio;
+            base[i][k] = score;
+        }
+    }
+    std::vector<char> available(nv, 1);                                     /* global_view_selection.cc:23-30 */
+    available[ref] = 0;
+    for (size_t i = 0; i < nv; ++i) if (!c->sc->views[i].valid) available[i] = 0;
+    std::vector<int> selected;          /* kept sorted ascending = std::set order */
+    std::vector<std::vector<std::vector<float> > > pen(nv);
+    bool foundOne = true;
+    while (foundOne && selected.size() < (size_t)st->globalVSMax) {
+        float maxBenefit = 0.f; size_t maxView = 0; foundOne = false;
+        for (size_t i = 0; i < nv; ++i) {
+            if (!available[i]) continue;
+            float benefit = 0;
+            const size_t nk = featInd[i].size();
+            const float* b = base[i].data();
+            const size_t ns = selected.size();
+            for (size_t k = 0; k < nk; ++k) {
+                float score = b[k];
+                for (size_t q = 0; q < ns; ++q) score *= pen[selected[q]][i][k];
+                benefit += score;
+            }
+            if (benefit > maxBenefit) { maxBenefit = benefit; maxView = i; foundOne = true; }
+        }
+        if (foundOne) {
+            selected.insert(std::upper_bound(selected.begin(), selected.end(), (int)maxView), (int)maxView);
+            available[maxView] = 0;
+            if (selected.size() < (size_t)st->globalVSMax) {
+                pen[maxView].resize(nv);
+                const uint8_t* sm = &g.sees[maxView * nf];
+                for (size_t i = 0; i < nv; ++i) {
+                    if (!available[i]) continue;
+                    std::vector<float>& pv = pen[maxView][i];
+                    pv.assign(featInd[i].size(), 1.f);
+                    const float* pl = &g.plx[(maxView * nv + i) * nf];
+                    for (size_t k = 0; k < featInd[i].size(); ++k) {
+                        const size_t f = featInd[i][k];
+                        if (!sm[f]) continue;
+                        const float plx = pl[f];
+                        if (plx < minP) pv[k] = (plx / 10.f) * (plx / 10.f);
+                    }
+                }
+            }
+        }
+    }
+    global = selected;
+    return 0;
+}
+
 /* analyzeFeatures + GlobalViewSelection::performVS for one reference view; fills `global`.
  * Same arithmetic, operation order and tie-breaking as the reference (dmrecon.cc:178-208,
  * global_view_selection.cc:33-101), so the greedy arg-max sees the same floats.  What differs is
@@ -269,6 +417,17 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
     HostView const& R = c->sc->views[ref];
     if (!R.valid) return fail(MI_DMRECON_EINVAL, "Invalid master view");
     if ((size_t)st->scale >= R.levels.size()) return fail(MI_DMRECON_EINVAL, "scale %d beyond pyramid of view %d", st->scale, ref);
+    {
+        /* the scene tables (built on first use after the scene changed; MI_DMRECON_GVS_TABLES=0: always the direct path) */
+        static const bool use_tables = [] { const char* e = std::getenv("MI_DMRECON_GVS_TABLES"); return e ? std::atoi(e) != 0 : true; }();
+        if (use_tables) {
+            {
+                std::lock_guard<std::mutex> lock(c->sc->mu);
+                if (!c->sc->geom.built) build_scene_geom(*c->sc);
+            }
+            if (c->sc->geom.has_plx) return plan_global_views_tables(c, st, ref, global);
+        }
+    }
     /* features attached to the reference view (dmrecon.cc:185-196), local index = position in `feat` */
     std::vector<int> feat;
     for (size_t i = 0; i < c->sc->features.size(); ++i) {
@@ -408,6 +567,10 @@ void fill_job(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost const& j
     std::memcpy(d.cam_pos, R.cam_pos, sizeof(d.cam_pos));
     d.w2c_z[0] = R.w2c[8]; d.w2c_z[1] = R.w2c[9]; d.w2c_z[2] = R.w2c[10]; d.w2c_z[3] = R.w2c[11];
     d.inv0_s = L.invproj[0];
+    /* fault injection for tests: MI_DMRECON_INJECT_FOOTPRINT=<view id> gives that reference view a negative pixel
+     * footprint, the condition under which PatchSampler throws std::out_of_range (patch_sampler.cc:78-82) -- with
+     * valid cameras it cannot be reached from outside */
+    if (const char* e = std::getenv("MI_DMRECON_INJECT_FOOTPRINT")) if (std::atoi(e) == jh.ref_view) d.inv0_s = -d.inv0_s;
     d.n_global = (int)jh.global.size();
     for (size_t g = 0; g < jh.global.size(); ++g) d.global_ids[g] = jh.global[g];
 }
@@ -607,6 +770,7 @@ static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_ca
     HIP_TRY(hipGetLastError());
     if (!async) HIP_TRY(hipStreamSynchronize(c->stream));
     c->sc->views_dirty = true;
+    c->sc->geom.built = false;
     return 0;
 }
 
@@ -633,6 +797,7 @@ int mi_dmrecon_evict_view(mi_dmrecon_ctx* c, int32_t view_id) {
     if (v.d_img) { (void)hipFree(v.d_img); v.d_img = nullptr; }
     v.valid = false; v.levels.clear();
     c->sc->views_dirty = true;
+    c->sc->geom.built = false;
     return 0;
 }
 
@@ -645,6 +810,7 @@ int mi_dmrecon_set_features(mi_dmrecon_ctx* c, int32_t n, const float* pos, cons
         f.ref_begin = off[i]; f.ref_end = off[i + 1];
     }
     c->sc->feat_refs.assign(ids, ids + (n ? off[n] : 0));
+    c->sc->geom.built = false;
     return 0;
 }
 
@@ -837,6 +1003,11 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     unsigned TAIL_THRESHOLD = 12288;
     if (const char* e = std::getenv("MI_DMRECON_TAIL_THRESHOLD")) TAIL_THRESHOLD = (unsigned)std::atoi(e);
     const unsigned TAIL_GRID = 4096, TAIL_CHUNK = MI_TAIL_CHUNK;
+    /* Workgroups of a blind tail round: one per candidate (4 per entry of the previous round's list) lets the
+     * wavefronts without a source end at once; the list sizes are only known with a chunk's delay, so the grid is
+     * twice what the last known size asks for (a shorter grid strides, correct but with idle wavefronts). */
+    unsigned tail_known = TAIL_THRESHOLD;
+    auto tail_grid = [&]() -> unsigned { return std::min(65536u, std::max(1024u, 8u * tail_known)); };
     static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
     /* texel windows in LDS: bit 0 = latency layout (tail rounds), bit 1 = throughput layout (bulk rounds) */
     const int USE_WIN = [] { const char* e = std::getenv("MI_DMRECON_WIN"); return e ? std::atoi(e) : MI_WIN_DEFAULT; }();
@@ -944,6 +1115,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             mi_launch_apply(c->stream, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
             ev_end();
             if (tail) {
+                tail_known = n_work;
                 /* counters as of the end of the host-visible rounds (slot 2 of the poll buffer; read after the call) */
                 HIP_TRY(hipMemcpyAsync(&c->h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
                 have_handover = true;
@@ -968,7 +1140,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
                 const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
                 if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
-                mi_launch_tail(c->stream, TAIL_GRID, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
+                mi_launch_tail(c->stream, tail_grid(), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
                                c->d_round_work.p, round, c->d_counters, WIN_TAIL);
                 if (timed) ev_end();
                 std::swap(wcur, wnext);
@@ -993,10 +1165,13 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             hc = P.hc;
             for (size_t q = info[slot].ev_first; q < info[slot].ev_last; ++q) ev_work[q] = P.rw[ev_work[q]];
             int end_round = -1;
+            unsigned chunk_max = 0;
             for (unsigned k = 0; k < TAIL_CHUNK; ++k) {
                 if (P.rw[k] == 0) { end_round = info[slot].first + (int)k; break; }
                 ++n_launch; ++n_tail_launch;
+                if (k >= TAIL_CHUNK / 2) chunk_max = std::max(chunk_max, P.rw[k]);
             }
+            if (chunk_max) tail_known = chunk_max;
             if (poll_views(dyn_of(slot), P.rw[TAIL_CHUNK - 1])) return fail(MI_DMRECON_EDEVICE, "hipMemcpyAsync(job flags) failed");
             if (end_round >= 0) {
                 /* an empty round: the propagation is over */

@@ -48,6 +48,20 @@ def test_c3_invariants_and_accuracy(c3):
     assert 1.0 < stats["n_patch"] / stats["n_filled"] < 2.5
 
 
+def test_c3_global_view_selection_vs_oracle(c3):
+    """The table-driven global view selection (scene-level parallax / visibility tables) picks exactly the
+    reference's views for all 20 reference views of the full-size scene."""
+    from oracle import oracle as orc
+    cfg, scene, ctx, st, res, stats = c3
+    S = orc.OracleScene(scene)
+    for ref in range(cfg["params"].n_views):
+        mine = ctx.global_view_selection(api.Settings(refViewNr=ref, scale=cfg["scale"]), ref)
+        assert mine == S.global_vs(orc.make_settings(ref_view=ref, scale=cfg["scale"])), ref
+    for ref in (0, 11):
+        stn = api.Settings(refViewNr=ref, scale=cfg["scale"], globalVSMax=5)
+        assert ctx.global_view_selection(stn, ref) == S.global_vs(orc.make_settings(ref_view=ref, scale=cfg["scale"], global_max=5))
+
+
 def test_c3_deterministic(c3):
     cfg, scene, ctx, st, res, stats = c3
     refs = list(range(cfg["params"].n_views))
