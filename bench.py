@@ -147,7 +147,8 @@ def map_parity_all(gpu, ref, against):
         cp99.append(float(np.percentile(np.abs(gc[both] - rc[both]), 99)))
         n += 1
     ok = min(iou) >= 0.98 and max(med) <= 1e-3 and max(p99) <= 5e-3 and max(cp99) <= 5e-3
-    return {"against": against, "views": n, "min_fill_iou": min(iou), "max_rel_depth_median": max(med),
+    return {"against": against, "views": n, "min_fill_iou": min(iou), "fill_iou_per_view": [round(v, 4) for v in iou],
+            "max_rel_depth_median": max(med),
             "max_rel_depth_p99": max(p99), "max_conf_abs_p99": max(cp99),
             "bounds": {"fill_iou": 0.98, "rel_depth_median": 1e-3, "rel_depth_p99": 5e-3, "conf_abs_p99": 5e-3},
             "within_bounds": bool(ok)}
@@ -156,40 +157,46 @@ def map_parity_all(gpu, ref, against):
 def timed_region(coll, ctxs, st, refs, n_calls, warmup):
     """W untimed warm-up calls per host thread, then exactly n_calls library calls of `refs` dealt over the host
     threads (one forked context / HIP stream each), bracketed by barrier + synchronise on both sides; returns
-    (max-over-ranks elapsed seconds, summed stats, the maps of the last call)."""
+    (max-over-ranks elapsed seconds, summed stats, the maps of the first timed call).
+    The host threads live across warm-up and timed region, as the threads of a long-running process do: thread
+    creation -- and with it the creation of each thread's OpenMP team inside the library (~10 ms) -- is not part of
+    a step."""
     import threading
     n_streams = len(ctxs)
     outs = [c.alloc_outputs(st, refs, want_normal=False, pinned=True) for c in ctxs]   # reused, page-locked
-    t_call = 0.0
-    for i, (c, o) in enumerate(zip(ctxs, outs)):
-        for _ in range(max(warmup, 1 if i else 0)):
+    share = [n_calls // n_streams + (1 if i < n_calls % n_streams else 0) for i in range(n_streams)]
+    acc, last, t_calls = {}, {}, [0.0] * n_streams
+    lock = threading.Lock()
+    warmed, go = threading.Barrier(n_streams + 1), threading.Barrier(n_streams + 1)
+
+    def worker(i, c, o, n):
+        for _ in range(max(warmup, 1)):
             tw = time.perf_counter()
             c.reconstruct(st, refs, want_normal=False, out=o)
-            t_call = time.perf_counter() - tw
-    acc, last = {}, {}
-    lock = threading.Lock()
-
-    def worker(c, o, n, delay):
+            t_calls[i] = time.perf_counter() - tw
+        warmed.wait()
+        go.wait()
         # phase offset between the host threads (inside the timed region): the throughput-bound rounds of one
         # stream then coincide with the latency-bound tail of another from the first step on, as they do in the
         # steady state of a long run anyway
-        if delay > 0:
-            time.sleep(delay)
+        if i:
+            time.sleep(i * max(t_calls) / n_streams)
         for _ in range(n):
             r = c.reconstruct(st, refs, want_normal=False, out=o)   # synchronous: returns with the maps on the host
             with lock:
-                last["res"] = [(m["depth"].copy(), m["conf"].copy()) for m in r] if "res" not in last else last["res"]
-                last["shape"] = r[0]["depth"].shape
+                if "res" not in last:
+                    last["res"] = [(m["depth"].copy(), m["conf"].copy()) for m in r]
+                    last["shape"] = r[0]["depth"].shape
                 for k, v in c.last_stats.items():
                     acc[k] = acc.get(k, 0) + v
 
-    share = [n_calls // n_streams + (1 if i < n_calls % n_streams else 0) for i in range(n_streams)]
-    threads = [threading.Thread(target=worker, args=(c, o, n, i * t_call / n_streams))
-               for i, (c, o, n) in enumerate(zip(ctxs, outs, share))]
-    coll.barrier()
-    t0 = time.perf_counter()
+    threads = [threading.Thread(target=worker, args=(i, c, o, n)) for i, (c, o, n) in enumerate(zip(ctxs, outs, share))]
     for t in threads:
         t.start()
+    warmed.wait()
+    coll.barrier()
+    t0 = time.perf_counter()
+    go.wait()
     for t in threads:
         t.join()
     coll.barrier()
@@ -318,12 +325,14 @@ def main():
             out["cpu_baseline"], parity = cpu_baseline(scene, cfg, gpu_maps=res[:p.n_views])
             if parity is not None:
                 out["parity"] = parity
-        print(json.dumps(out))
     coll.barrier()
     for c in ctxs[1:]:
         c.close()
     ctx.close()
     coll.close()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)          # the one JSON line, last on stdout (RCCL prints its banner there too)
 
 
 if __name__ == "__main__":

@@ -113,6 +113,8 @@ typedef struct mi_dmrecon_stats {
     int64_t n_eval_bulk, n_patch_bulk, n_filled_bulk;   /* the share of n_eval / n_patch / n_filled of the host-visible rounds */
     int64_t n_stage;        /* texel windows staged into LDS (a patch-view needs one unless its window moves out of the box) */
     int64_t n_gather_pass;  /* passes of the window kernels that sampled by global gathers after all (window larger than a box) */
+    int64_t n_view_replaced; /* local views dropped by replaceViews (patch_optimization.cc:218-228; speculative attempts included) */
+    int64_t n_iter14;        /* ... of which only by the iteration-14 rule (still moving at iterationCount == 14) */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);

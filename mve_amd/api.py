@@ -74,7 +74,8 @@ class CStats(ctypes.Structure):
                 ("n_bulk_launches", ctypes.c_int64), ("n_tail_launches", ctypes.c_int64),
                 ("n_pass", ctypes.c_int64), ("truncated", ctypes.c_int64),
                 ("n_eval_bulk", ctypes.c_int64), ("n_patch_bulk", ctypes.c_int64), ("n_filled_bulk", ctypes.c_int64),
-                ("n_stage", ctypes.c_int64), ("n_gather_pass", ctypes.c_int64)]
+                ("n_stage", ctypes.c_int64), ("n_gather_pass", ctypes.c_int64),
+                ("n_view_replaced", ctypes.c_int64), ("n_iter14", ctypes.c_int64)]
 
 
 _lib = None

@@ -27,10 +27,12 @@ void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_t
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                      const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
 /* one fused tail round: candidates from (prev_work, prev_results, round_work[round - 1]) -> this round's list,
- * results and pixel-state writes (second state slot, see DevJob); workgroups of four wavefronts */
+ * results and pixel-state writes (second state slot, see DevJob).  speculative: workgroups of four wavefronts, a
+ * pixel's candidate hypotheses tried at the same time; else one wavefront per pixel tries them in turn */
 void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                     const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
-                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows);
+                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows,
+                    bool speculative);
 /* maps: [slot 0: depth | conf | dz x2 | normal x3][slot 1: same], imaps: [views | upd][views1 | upd1], per batch */
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px);
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,

@@ -101,7 +101,9 @@ __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelec
 #define MI_WIN16_H 16
 #define MI_NOBOX (-0x40000000)
 __shared__ uint32_t g_win1[WAVE][MI_WIN1_STRIDE];
-__shared__ __attribute__((aligned(16))) uint32_t g_win16[4][4][MI_WIN16_W * MI_WIN16_H];   /* [wavefront][view slot] */
+/* latency layout: [wavefront of the workgroup][view slot][16 x 16], dynamic LDS sized at launch (4 KB per wavefront) */
+extern __shared__ __attribute__((aligned(16))) uint32_t g_win16[];
+#define MI_WIN16_BYTES_PER_WAVE (4 * MI_WIN16_W * MI_WIN16_H * 4)
 
 /* ------------------------------------------------------------------------- */
 /* Lane layouts.  A patch is optimised by 4 "view slots" (one per local neighbour view);
@@ -218,7 +220,9 @@ template <> struct Lay<16> {
         return (unsigned)((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull));
     }
     static constexpr int WW = MI_WIN16_W, WH = MI_WIN16_H;
-    __device__ static __forceinline__ uint32_t* win(int lane) { return g_win16[threadIdx.x >> 6][lane >> 4]; }
+    __device__ static __forceinline__ uint32_t* win(int lane) {
+        return g_win16 + (((threadIdx.x >> 6) * 4 + (lane >> 4)) * (MI_WIN16_W * MI_WIN16_H));
+    }
 };
 
 /* ------------------------------------------------------------------------- */
@@ -1115,7 +1119,13 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
         const bool replace = active && (ps.ncc < st.acceptNCC || (R.iter == 14 && dn > st.minRefineDiff));
         const unsigned rmask = L::view_ballot(replace, lane);
         const bool conv = L::view_ballot(moving, lane) == 0;
+        const unsigned r14 = L::view_ballot(replace && !(ps.ncc < st.acceptNCC), lane);
         if (rmask) {
+            if (slot == 0 && sub == 0) {
+                /* diagnostics (rare events): views replaced, and how many of them by the iteration-14 rule alone */
+                atomicAdd(&ps.counters->n_view_replaced, (unsigned long long)__popc(rmask));
+                if (r14) atomicAdd(&ps.counters->n_iter14, (unsigned long long)__popc(r14));
+            }
             R.viewRemoved = true;
             if (replace) ps.sel = -1;              /* available[] is already false for selected views */
             R.need_vs = true;
@@ -1498,8 +1508,8 @@ __device__ __forceinline__ Frozen frozen_state(const DevJob* job, int p, int rou
 struct TailRes { PatchResult r; unsigned n_eval, n_pass; };
 __shared__ TailRes g_tail_res[MI_TAIL_WAVES];
 
-template <bool WIN>
-__global__ __launch_bounds__(MI_TAIL_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tail(TailArgs t) {
+template <bool WIN, bool SPEC>
+__global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((amdgpu_waves_per_eu((SPEC ? 2 : MI_WAVES_PER_SIMD), (SPEC ? 2 : MI_WAVES_PER_SIMD)))) void k_tail(TailArgs t) {
     const OptArgs& a = t.o;
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const unsigned n_prev = t.round_work[a.round - 1];
@@ -1507,7 +1517,7 @@ __global__ __launch_bounds__(MI_TAIL_WAVES * WAVE) __attribute__((amdgpu_waves_p
     /* one candidate per workgroup (the usual case): wavefronts without a source can end; otherwise the workgroup
      * strides over the candidates and all its wavefronts stay for the barriers */
     const bool single = 4u * n_prev <= gridDim.x;
-    for (int i = threadIdx.x; i < 256; i += MI_TAIL_WAVES * WAVE) g_lut[i] = a.lut[i];
+    for (int i = threadIdx.x; i < 256; i += (SPEC ? MI_TAIL_WAVES : 1) * WAVE) g_lut[i] = a.lut[i];
     __syncthreads();
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;
     for (unsigned cand = blockIdx.x; cand < 4u * n_prev; cand += gridDim.x) {
@@ -1552,45 +1562,69 @@ __global__ __launch_bounds__(MI_TAIL_WAVES * WAVE) __attribute__((amdgpu_waves_p
         auto conf_of = [&](int j) -> float { return j == 0 ? nf[0].conf : j == 1 ? nf[1].conf : j == 2 ? nf[2].conf : nf[3].conf; };
         const int mine = (int)(k ^ 1u);                                        /* my source seen from q */
         if (n_cand == 0 || dir_of(0) != mine) continue;                        /* the workgroup of q's best source does q */
-        const bool active = wave < n_cand;
-        if (!active && single) return;
-        if (active) {
-            /* my source's result = the hypothesis (wavefront 0: the previous round's record; the others read their
-             * source's frozen state) */
-            float hd = pr.depth, hi = pr.dzI, hj = pr.dzJ; unsigned hv = pr.views;
-            if (wave > 0) {
-                const int j = dir_of(wave);
+        /* hypothesis of q's rank-s candidate = its source's result (rank 0: the previous round's record in hand;
+         * the others: their source's frozen state) */
+        auto hypothesis = [&](int s, float& hd, float& hi, float& hj, unsigned& hv) {
+            hd = pr.depth; hi = pr.dzI; hj = pr.dzJ; hv = pr.views;
+            if (s > 0) {
+                const int j = dir_of(s);
                 const int p = j == 0 ? nb[0] : j == 1 ? nb[1] : j == 2 ? nb[2] : nb[3];
                 const bool one = j == 0 ? nf[0].one : j == 1 ? nf[1].one : j == 2 ? nf[2].one : nf[3].one;
                 hd = GF((one ? job->depth1 : job->depth) + p);
                 hi = GF((one ? job->dz1 : job->dz) + 2 * p); hj = GF((one ? job->dz1 : job->dz) + 2 * p + 1);
                 hv = GU((one ? job->views1 : job->views) + p);
             }
-            PatchResult r;
-            unsigned ce = 0, cp = 0;
+        };
+        auto attempt = [&](int s, PatchResult& r, unsigned& ce, unsigned& cp) {
+            float hd, hi, hj; unsigned hv;
+            hypothesis(s, hd, hi, hj, hv);
+            ce = 0; cp = 0;
             optimize_patch<16, WIN>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
             /* counters of optimize_patch are per view slot (row leaders): bring them to lane 0 */
             ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
                           + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
             cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
                           + __builtin_amdgcn_readlane((int)cp, 32) + __builtin_amdgcn_readlane((int)cp, 48));
-            if (lane == 0) { g_tail_res[wave].r = r; g_tail_res[wave].n_eval = ce; g_tail_res[wave].n_pass = cp; }
-        }
-        if (n_cand > 1 || !single) __syncthreads();
-        if (wave == 0) {
-            /* the reference's sequential rule over q's candidates */
-            float best = own;
-            bool accepted = false;
-            PatchResult fin = g_tail_res[0].r;
-            unsigned done = 0;
+        };
+        float best = own;
+        bool accepted = false;
+        PatchResult fin;
+        fin.conf = 0.f; fin.depth = fin.dzI = fin.dzJ = fin.nx = fin.ny = fin.nz = 0.f; fin.views = 0xFFFFFFFFu; fin.iters = 0;
+        unsigned done = 0;
+        if (SPEC) {
+            const bool active = wave < n_cand;
+            if (!active && single) return;
+            if (active) {
+                PatchResult r; unsigned ce, cp;
+                attempt(wave, r, ce, cp);
+                if (lane == 0) { g_tail_res[wave].r = r; g_tail_res[wave].n_eval = ce; g_tail_res[wave].n_pass = cp; }
+            }
+            if (n_cand > 1 || !single) __syncthreads();
+            if (wave == 0) {
+                /* the reference's sequential rule over q's candidates */
+                for (int s = 0; s < n_cand; ++s) {
+                    const float bc = conf_of(dir_of(s));
+                    if (best > bc) break;                                      /* dmrecon.cc:371 (and every later one) */
+                    done |= 1u << dir_of(s);
+                    const PatchResult c = g_tail_res[s].r;
+                    if (lane == 0) { n_eval += g_tail_res[s].n_eval; n_pass += g_tail_res[s].n_pass; ++n_patch; }   /* attempts the reference makes */
+                    if (c.conf > 0.f && best < c.conf) { best = c.conf; accepted = true; fin = c; }   /* dmrecon.cc:378,391 */
+                }
+            }
+        } else {
+            /* one wavefront, the candidates one after the other exactly as the reference pops them: nothing
+             * speculative -- the form for rounds large enough to fill the GPU anyway */
             for (int s = 0; s < n_cand; ++s) {
                 const float bc = conf_of(dir_of(s));
                 if (best > bc) break;                                          /* dmrecon.cc:371 (and every later one) */
                 done |= 1u << dir_of(s);
-                const PatchResult c = g_tail_res[s].r;
-                if (lane == 0) { n_eval += g_tail_res[s].n_eval; n_pass += g_tail_res[s].n_pass; ++n_patch; }   /* attempts the reference makes */
-                if (c.conf > 0.f && best < c.conf) { best = c.conf; accepted = true; fin = c; }   /* dmrecon.cc:378,391 */
+                PatchResult c; unsigned ce, cp;
+                attempt(s, c, ce, cp);
+                if (lane == 0) { n_eval += ce; n_pass += cp; ++n_patch; }
+                if (c.conf > 0.f && best < c.conf) { best = c.conf; accepted = true; fin = c; }       /* dmrecon.cc:378,391 */
             }
+        }
+        if (wave == 0) {
             if (accepted && lane == 0) {
                 const unsigned e = atomicAdd(&t.round_work[a.round], 1u);
                 DevEntry we; we.job = src.job; we.xy = qx | (qy << 16);
@@ -1610,7 +1644,7 @@ __global__ __launch_bounds__(MI_TAIL_WAVES * WAVE) __attribute__((amdgpu_waves_p
                 if (own <= 0.f) { ++n_filled; atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u); }
             }
         }
-        if (!single) __syncthreads();                                          /* g_tail_res is reused by the next candidate */
+        if (SPEC && !single) __syncthreads();                                  /* g_tail_res is reused by the next candidate */
     }
     /* n_eval / n_pass / n_patch / n_filled were kept by lane 0 of wavefront 0 only */
     if (threadIdx.x == 0) {
@@ -1959,7 +1993,7 @@ void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks,
     a.max_attempts = follow_out ? 1 : 4; a.follow_in = follow_in; a.follow_in_n = follow_in_n;
     a.follow_out = follow_out; a.follow_out_n = follow_out_n;
     if (lanes_per_view == 16) {
-        if (windows) hipLaunchKernelGGL((k_optimize<16, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        if (windows) hipLaunchKernelGGL((k_optimize<16, true>), dim3(grid_blocks), dim3(WAVE), MI_WIN16_BYTES_PER_WAVE, s, a);
         else hipLaunchKernelGGL((k_optimize<16, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
     } else {
         if (windows) hipLaunchKernelGGL((k_optimize<1, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
@@ -1994,15 +2028,21 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
 
 void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                     const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
-                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows) {
+                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows,
+                    bool speculative) {
     TailArgs t;
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
-    if (windows) hipLaunchKernelGGL(k_tail<true>, dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
-    else hipLaunchKernelGGL(k_tail<false>, dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
+    if (speculative) {
+        if (windows) hipLaunchKernelGGL((k_tail<true, true>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), MI_TAIL_WAVES * MI_WIN16_BYTES_PER_WAVE, s, t);
+        else hipLaunchKernelGGL((k_tail<false, true>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
+    } else {
+        if (windows) hipLaunchKernelGGL((k_tail<true, false>), dim3(grid_blocks), dim3(WAVE), MI_WIN16_BYTES_PER_WAVE, s, t);
+        else hipLaunchKernelGGL((k_tail<false, false>), dim3(grid_blocks), dim3(WAVE), 0, s, t);
+    }
 }
 
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px) {

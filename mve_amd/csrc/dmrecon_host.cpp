@@ -1008,6 +1008,10 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
      * twice what the last known size asks for (a shorter grid strides, correct but with idle wavefronts). */
     unsigned tail_known = TAIL_THRESHOLD;
     auto tail_grid = [&]() -> unsigned { return std::min(65536u, std::max(1024u, 8u * tail_known)); };
+    /* Rounds up to this many entries try a pixel's candidate hypotheses at the same time (four wavefronts per
+     * pixel: the round is one patch optimisation long instead of up to four); larger rounds fill the GPU anyway
+     * and run them in turn on one wavefront, which wastes nothing.  MI_DMRECON_SPECULATE=<entries> (0 = never). */
+    static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 1024u; }();
     static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
     /* texel windows in LDS: bit 0 = latency layout (tail rounds), bit 1 = throughput layout (bulk rounds) */
     const int USE_WIN = [] { const char* e = std::getenv("MI_DMRECON_WIN"); return e ? std::atoi(e) : MI_WIN_DEFAULT; }();
@@ -1141,7 +1145,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                 const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
                 if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
                 mi_launch_tail(c->stream, tail_grid(), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
-                               c->d_round_work.p, round, c->d_counters, WIN_TAIL);
+                               c->d_round_work.p, round, c->d_counters, WIN_TAIL, tail_known <= SPEC_MAX);
                 if (timed) ev_end();
                 std::swap(wcur, wnext);
                 std::swap(rcur, rnext);
@@ -1225,6 +1229,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         stats->n_seeds = (int64_t)n_seed_feats; stats->n_seeds_ok = (int64_t)hc.n_seeds_ok;
         stats->n_rounds = round; stats->n_launches = n_launch; stats->truncated = truncated ? 1 : 0;
         stats->n_stage = (int64_t)hc.n_stage; stats->n_gather_pass = (int64_t)hc.n_gather_pass;
+        stats->n_view_replaced = (int64_t)hc.n_view_replaced; stats->n_iter14 = (int64_t)hc.n_iter14;
         double tail_ms = 0.0; int64_t tail_timed = 0;
         size_t w = 0;
         for (size_t k = 0; k < ev_kind.size(); ++k) {

@@ -214,3 +214,141 @@ CONFIGS = {
     "C5": dict(params=SynthParams(n_views=100, width=4032, height=3024, ring=(0.4, 1.6)), scale=3,
                local_neighbors=4),
 }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A deliberately difficult small scene for the parity fixtures (tests/golden/make_golden_hard.py): what the smooth,
+# fully visible height field above never exercises -- a depth step, a foreground occluder, a textureless band and
+# a view with little overlap.  Rendered in numpy (small images only).
+
+@dataclass
+class HardParams:
+    n_views: int = 9
+    width: int = 208
+    height: int = 156
+    n_features: int = 500
+    seed: int = 11
+    distance: float = 10.0
+    flen: float = 1.0
+    step_x: float = 1.0          # the background jumps back by step_dz for x > step_x
+    step_dz: float = 0.8
+    plate: Tuple[float, float, float, float, float] = (-2.2, -0.2, -1.4, 0.6, -1.5)   # x0, x1, y0, y1, z: occluder
+    band: Tuple[float, float] = (1.3, 1.9)                                          # y range without texture
+
+
+def _hard_texture(seed, x, y, lo=40.0, hi=215.0):
+    rng = np.random.RandomState(seed)
+    f = np.exp(rng.uniform(np.log(0.3), np.log(10.0), 20))
+    th = rng.uniform(0, 2 * np.pi, 20)
+    ph = rng.uniform(0, 2 * np.pi, (20, 3))
+    amp = f ** -0.35
+    a = (2 * np.pi * f * np.cos(th))[:, None] * x.reshape(1, -1) + (2 * np.pi * f * np.sin(th))[:, None] * y.reshape(1, -1)
+    v = np.einsum("w,wpc->pc", amp, np.sin(a[:, :, None] + ph[:, None, :])) / (2.2 * np.sqrt(0.5 * np.sum(amp ** 2)))
+    return (0.5 * (lo + hi) + 0.5 * (hi - lo) * np.clip(v, -1, 1)).reshape(x.shape + (3,))
+
+
+def _hard_bg(hp: HardParams, x, y):
+    return 0.25 * np.sin(1.3 * x + 0.4) * np.sin(1.9 * y - 0.3)
+
+
+def hard_cameras(hp: HardParams) -> List[Camera]:
+    rng = np.random.RandomState(hp.seed)
+    cams = []
+    for i in range(hp.n_views):
+        a = 2 * np.pi * i / (hp.n_views - 1)
+        r = rng.uniform(0.7, 1.1)
+        c = np.array([r * np.cos(a), r * np.sin(a), -hp.distance + 0.4 * rng.uniform(-1, 1)])
+        rot = _rodrigues(rng.normal(size=3), np.deg2rad(1.5) * rng.uniform(-1, 1))
+        if i == hp.n_views - 1:
+            # the low-overlap view: far to the side, turned back towards the scene only part of the way
+            c = np.array([5.5, 0.4, -hp.distance + 0.3])
+            rot = _rodrigues(np.array([0.0, 1.0, 0.0]), np.deg2rad(-12.0))
+        rot32 = rot.astype(np.float32)
+        trans32 = (-(rot32.astype(np.float64) @ c)).astype(np.float32)
+        cams.append(Camera(flen=hp.flen, paspect=1.0, ppoint=(0.5, 0.5), rot=[float(v) for v in rot32.reshape(-1)],
+                           trans=[float(v) for v in trans32]))
+    return cams
+
+
+def hard_trace(hp: HardParams, cam: Camera, w: int, h: int, xs=None, ys=None):
+    """First surface hit of the pixel-centre rays: (t along the z_cam = 1 ray, surface id 0 = background left of the
+    step, 1 = right of it, 2 = the step's wall, 3 = occluder plate, world x, y, z)."""
+    rays = pixel_rays(cam, w, h, xs, ys)
+    c = cam.position()
+    shp = rays.shape[:-1]
+    best_t = np.full(shp, np.inf)
+    sid = np.full(shp, -1, np.int32)
+
+    def bg(dz, keep):
+        t = (0.0 + dz - c[2]) / rays[..., 2]
+        for _ in range(14):
+            x, y = c[0] + t * rays[..., 0], c[1] + t * rays[..., 1]
+            t = (_hard_bg(hp, x, y) + dz - c[2]) / rays[..., 2]
+        x = c[0] + t * rays[..., 0]
+        return t, keep(x)
+    for k, (dz, keep) in enumerate(((0.0, lambda x: x <= hp.step_x), (hp.step_dz, lambda x: x > hp.step_x))):
+        t, ok = bg(dz, keep)
+        take = ok & (t > 0) & (t < best_t)
+        best_t = np.where(take, t, best_t); sid = np.where(take, k, sid)
+    # wall of the step: plane x = step_x between the two background sheets
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tw = (hp.step_x - c[0]) / rays[..., 0]
+    yw, zw = c[1] + tw * rays[..., 1], c[2] + tw * rays[..., 2]
+    z0 = _hard_bg(hp, np.full(shp, hp.step_x), yw)
+    take = np.isfinite(tw) & (tw > 0) & (zw >= z0) & (zw <= z0 + hp.step_dz) & (tw < best_t)
+    best_t = np.where(take, tw, best_t); sid = np.where(take, 2, sid)
+    # occluder plate
+    x0, x1, y0, y1, zp = hp.plate
+    tp = (zp - c[2]) / rays[..., 2]
+    xp, yp = c[0] + tp * rays[..., 0], c[1] + tp * rays[..., 1]
+    take = (tp > 0) & (xp >= x0) & (xp <= x1) & (yp >= y0) & (yp <= y1) & (tp < best_t)
+    best_t = np.where(take, tp, best_t); sid = np.where(take, 3, sid)
+    X = c[0] + best_t * rays[..., 0]; Y = c[1] + best_t * rays[..., 1]; Z = c[2] + best_t * rays[..., 2]
+    return best_t, sid, X, Y, Z, rays
+
+
+def hard_render(hp: HardParams, cam: Camera, w: int, h: int):
+    t, sid, X, Y, Z, rays = hard_trace(hp, cam, w, h)
+    img = np.full((h, w, 3), 128.0)
+    for k, seed in ((0, 7), (1, 7), (3, 23)):
+        m = sid == k
+        if m.any():
+            img[m] = _hard_texture(seed, X[m], Y[m])
+    m = sid == 2
+    if m.any():
+        img[m] = _hard_texture(31, Y[m], 3.0 * Z[m])
+    band = ((sid == 0) | (sid == 1)) & (Y >= hp.band[0]) & (Y <= hp.band[1])
+    img[band] = 128.0
+    img[sid < 0] = 0.0
+    depth = np.where(sid >= 0, t * np.linalg.norm(rays, axis=-1), 0.0)           # radial distance (quirk Q1)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8), depth.astype(np.float32), sid
+
+
+def make_hard_scene(hp: HardParams = HardParams()) -> SceneData:
+    cams = hard_cameras(hp)
+    imgs, depths = [], []
+    for cm in cams:
+        im, d, _ = hard_render(hp, cm, hp.width, hp.height)
+        imgs.append(im); depths.append(d)
+    rng = np.random.RandomState(hp.seed + 1)
+    half_w = 0.5 * hp.distance / hp.flen * 1.25
+    half_h = half_w * hp.height / hp.width
+    xy = np.stack([rng.uniform(-half_w, half_w + 3.0, hp.n_features), rng.uniform(-half_h, half_h, hp.n_features)], 1)
+    z = _hard_bg(hp, xy[:, 0], xy[:, 1]) + np.where(xy[:, 0] > hp.step_x, hp.step_dz, 0.0)
+    x0, x1, y0, y1, zp = hp.plate
+    on_plate = (xy[:, 0] >= x0) & (xy[:, 0] <= x1) & (xy[:, 1] >= y0) & (xy[:, 1] <= y1) & (rng.uniform(size=len(z)) < 0.7)
+    z = np.where(on_plate, zp, z)
+    pts32 = np.concatenate([xy, z[:, None]], 1).astype(np.float32)
+    feats = []
+    for i in range(hp.n_features):
+        ids = []
+        for v, cm in enumerate(cams):
+            u, vv, zc = project(cm, hp.width, hp.height, pts32[i:i + 1].astype(np.float64))
+            if zc[0] <= 0 or u[0] < 1 or vv[0] < 1 or u[0] > hp.width - 2 or vv[0] > hp.height - 2:
+                continue
+            d = float(np.linalg.norm(pts32[i].astype(np.float64) - cm.position()))
+            if abs(depths[v][int(round(vv[0])), int(round(u[0]))] - d) < 0.05:      # not occluded in this view
+                ids.append(v)
+        if len(ids) >= 2:
+            feats.append(Feature([float(v) for v in pts32[i]], ids))
+    return SceneData(cams, imgs, feats)

@@ -44,6 +44,16 @@ def g2():
 
 
 @pytest.fixture(scope="session")
+def h1():
+    return dict(np.load(os.path.join(GOLDEN, "h1_hard_9views_208x156.npz")))
+
+
+@pytest.fixture(scope="session")
+def h1_scene(h1):
+    return scene_from_golden(h1)
+
+
+@pytest.fixture(scope="session")
 def g1_scene(g1):
     return scene_from_golden(g1)
 

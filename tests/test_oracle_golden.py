@@ -85,3 +85,29 @@ def test_patch_sampler_vs_reference_classes(g1, g1_scene):
         assert np.array_equal(e["deriv"][okv], g1["ev_der"][i][okv])
         n_checked += int(okv.sum())
     assert n_checked > 50
+
+
+def test_hard_scene_maps_bit_exact(h1, h1_scene):
+    """Scene H1 (depth step, occluder, textureless band, a low-overlap view): the restatement reproduces the
+    reference's maps bit for bit also where views get replaced, samplings fail and regions stay empty."""
+    S = orc.OracleScene(h1_scene)
+    for v in (0, 8):
+        r = S.reconstruct(orc.make_settings(ref_view=v, scale=0))
+        assert np.array_equal(r["depth"], h1["s0v%d_depth" % v]), v
+        assert np.array_equal(r["conf"], h1["s0v%d_conf" % v]), v
+        assert np.array_equal(r["dz"], h1["s0v%d_dz" % v]), v
+    assert 0.15 < (h1["s0v8_depth"] > 0).mean() < 0.35 and 0.6 < (h1["s0v0_depth"] > 0).mean() < 0.9
+
+
+def test_hard_scene_patch_vectors_exact(h1, h1_scene):
+    S = orc.OracleScene(h1_scene)
+    assert S.global_vs(orc.make_settings(ref_view=0)) == list(h1["gvs"])
+    out, loc = S.patch_optimize(orc.make_settings(ref_view=0), h1["seeds_xy"], h1["seeds_hyp"], h1["seeds_local"])
+    ref, ref_loc = h1["opt"], h1["opt_local"]
+    assert np.array_equal(out[:, 0] > 0, ref[:, 0] > 0)
+    ok = ref[:, 0] > 0
+    assert ok.sum() >= 100 and (~ok).sum() >= 100           # both outcomes are well represented
+    assert np.array_equal(out[ok, :7], ref[ok, :7]) and np.array_equal(loc[ok], ref_loc[ok])
+    n = len(ref)
+    changed = ok[n // 2:] & (ref_loc[n // 2:] != h1["seeds_local"][n // 2:]).any(1)
+    assert changed.sum() >= 3                                # propagated sets the reference had to re-select
