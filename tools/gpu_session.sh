@@ -1,8 +1,6 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun).  One round-2 measurement session: GPU tests, then bench lines
-# (MI_DMRECON_WIN: 0 = gathers only, 1 = texel windows in the latency layout / tail, 3 = both layouts),
-# a round trace and rocprofv3 kernel stats.  Output: gpurun_out/$TAG/.
-TAG=${1:-s3}
+# Runs ON THE GPU BOX (through gpurun).  One round-2 measurement session.  Output: gpurun_out/$TAG/.
+TAG=${1:-s4}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -20,27 +18,22 @@ except Exception as e:
     print('  (no json)', e)
 PY
 }
-echo "== pytest"; timeout -s KILL 900 python -m pytest tests -m gpu -q --maxfail=6 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -12 $OUT/pytest.log | cut -c1-220
+echo "== pytest"; timeout -s KILL 900 python -m pytest tests -m gpu -q -s --maxfail=6 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "^H1|passed|failed|Error" $OUT/pytest.log | cut -c1-400 | tail -20
 B1="python bench.py --steps 6 --warmup 2 --streams 1 --steps-per-call 1 --no-cpu-baseline"
 for W in 0 1; do
   echo "== bench 1 stream WIN=$W"
   MI_DMRECON_WIN=$W timeout -s KILL 240 $B1 > $OUT/bench1_win$W.json 2> $OUT/bench1_win$W.err; show $OUT/bench1_win$W.json; tail -3 $OUT/bench1_win$W.err
 done
-for T in 4096 30000; do
-  echo "== bench 1 stream WIN=1 tail threshold $T"
-  MI_DMRECON_TAIL_THRESHOLD=$T MI_DMRECON_WIN=1 timeout -s KILL 240 $B1 > $OUT/bench1_win1_t$T.json 2> $OUT/bench1_win1_t$T.err; show $OUT/bench1_win1_t$T.json
+echo "== bench 1 stream WIN=0 no speculation"
+MI_DMRECON_SPECULATE=0 MI_DMRECON_WIN=0 timeout -s KILL 240 $B1 > $OUT/bench1_win0_nospec.json 2> $OUT/bench1_win0_nospec.err; show $OUT/bench1_win0_nospec.json
+for W in 0 1; do
+  for S in 0 1024; do
+    echo "== bench default (6 threads, 5 steps per call) WIN=$W SPECULATE=$S"
+    MI_DMRECON_SPECULATE=$S MI_DMRECON_WIN=$W timeout -s KILL 300 python bench.py --steps 30 --warmup 2 --no-cpu-baseline > $OUT/benchd_win${W}_s$S.json 2> $OUT/benchd_win${W}_s$S.err; show $OUT/benchd_win${W}_s$S.json
+  done
 done
-echo "== bench default (6 threads, 5 steps per call) WIN=1, with cpu baseline + parity"
-MI_DMRECON_WIN=1 timeout -s KILL 400 python bench.py --steps 30 --warmup 2 > $OUT/benchd_win1.json 2> $OUT/benchd_win1.err; show $OUT/benchd_win1.json; tail -3 $OUT/benchd_win1.err
-echo "== bench default WIN=0"
-MI_DMRECON_WIN=0 timeout -s KILL 300 python bench.py --steps 30 --warmup 2 --no-cpu-baseline > $OUT/benchd_win0.json 2> $OUT/benchd_win0.err; show $OUT/benchd_win0.json
-echo "== strong-scaling path with one rank (MI_FORCE_DIST)"
-MI_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MI_DMRECON_WIN=1 timeout -s KILL 300 python bench.py --steps 10 --warmup 2 --scaling strong --no-cpu-baseline > $OUT/bench_strong1.json 2> $OUT/bench_strong1.err; show $OUT/bench_strong1.json; tail -2 $OUT/bench_strong1.err
-echo "== trace WIN=1"
-MI_DMRECON_WIN=1 MI_DMRECON_TRACE=1 timeout -s KILL 240 python bench.py --steps 1 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline > /dev/null 2> $OUT/trace_win1.txt
-grep "phase" $OUT/trace_win1.txt | tail -6; grep "optimise launch" $OUT/trace_win1.txt | tail -n +620 | awk 'NR%40==1'
-echo "== rocprofv3 kernel stats WIN=1"
-MI_DMRECON_WIN=1 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_win1 -o bench -- $B1 > $OUT/ks_win1.log 2>&1
-find $OUT/ks_win1 -name "*kernel_stats.csv" | head -1 | xargs -r head -8
-find $OUT/ks_win1 -name "*_kernel_trace.csv" -delete
+echo "== trace WIN=0"
+MI_DMRECON_WIN=0 MI_DMRECON_TRACE=1 timeout -s KILL 240 python bench.py --steps 2 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline > /dev/null 2> $OUT/trace_win0.txt
+grep "phase" $OUT/trace_win0.txt | tail -6
+echo "== parity probe (fast reference)"; timeout -s KILL 400 python tools/parity_probe.py fast > $OUT/parity_probe_fast.txt 2>&1; cat $OUT/parity_probe_fast.txt | cut -c1-200
 du -sh $OUT
