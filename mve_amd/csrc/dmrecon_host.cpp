@@ -135,9 +135,10 @@ struct DevBuf {
 
 /* rounds of the propagation tail enqueued per read-back (even: the list buffers ping-pong per round) */
 #define MI_TAIL_CHUNK 32
-/* MI_DMRECON_WIN default: LDS texel windows in both lane layouts */
+/* MI_DMRECON_WIN default: no LDS texel windows (measured, DESIGN.md section 5: bit 0, the latency layout, costs 8 %
+ * single-stream and gains 10 % only against a 6-stream run without them; bit 1, the throughput layout, is 2x slower) */
 #ifndef MI_WIN_DEFAULT
-#define MI_WIN_DEFAULT 3
+#define MI_WIN_DEFAULT 0
 #endif
 struct TailPoll { unsigned rw[MI_TAIL_CHUNK]; DevCounters hc; };
 
@@ -1011,7 +1012,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     /* Rounds up to this many entries try a pixel's candidate hypotheses at the same time (four wavefronts per
      * pixel: the round is one patch optimisation long instead of up to four); larger rounds fill the GPU anyway
      * and run them in turn on one wavefront, which wastes nothing.  MI_DMRECON_SPECULATE=<entries> (0 = never). */
-    static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 1024u; }();
+    static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 256u; }();
     static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
     /* texel windows in LDS: bit 0 = latency layout (tail rounds), bit 1 = throughput layout (bulk rounds) */
     const int USE_WIN = [] { const char* e = std::getenv("MI_DMRECON_WIN"); return e ? std::atoi(e) : MI_WIN_DEFAULT; }();

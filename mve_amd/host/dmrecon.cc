@@ -200,40 +200,56 @@ private:
     }
 };
 
-/* One Slot per GPU named in MI_DMRECON_DEVICES (default: all), one resident copy of the scene on each; host threads
- * are dealt round-robin over the slots. */
+/*
+ * The scene as the GPUs hold it: one Slot per GPU named in MI_DMRECON_DEVICES (default: all), one resident copy of
+ * the scene on each.  A generation belongs to one (scene, embedding) pair and OWNS a reference to the mve::Scene,
+ * so a freed scene's address cannot come back as a "cached" key; every mvs::DMRecon holds its generation by
+ * shared_ptr, so a change of scene never destroys contexts that still have requests in flight -- the old
+ * generation goes when its last DMRecon does (the reference: ImagePyramidCache hands out shared_ptrs,
+ * image_pyramid.cc:98-132).
+ */
+struct Generation {
+    mve::Scene::Ptr scene;
+    std::string embedding;
+    std::vector<std::unique_ptr<Slot> > slots;
+    std::once_flag uploaded;
+    std::exception_ptr upload_error;
+    std::atomic<std::size_t> next_slot{0};
+};
+
 class Registry
 {
 public:
     static Registry& get() { static Registry r; return r; }
 
-    Slot* slot_for(mve::Scene::Ptr scene, std::string const& embedding)
+    /* the generation of (scene, embedding), with every GPU's copy resident; the caller keeps the pointer */
+    std::shared_ptr<Generation> generation_for(mve::Scene::Ptr scene, std::string const& embedding)
     {
-        std::lock_guard<std::mutex> lock(mu);
-        if (slots.empty()) init_devices();
-        if (scene.get() != cached_scene || embedding != cached_embedding) {
-            /* like ImagePyramidCache: first scene/embedding wins; a different one re-uploads */
-            for (std::size_t i = 0; i < slots.size(); ++i) slots[i]->release();
-            per_thread.clear();
-            cached_scene = scene.get();
-            cached_embedding = embedding;
+        std::shared_ptr<Generation> g;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!current || current->scene != scene || current->embedding != embedding) {
+                /* like ImagePyramidCache: one scene/embedding at a time; a different one re-uploads */
+                current = std::make_shared<Generation>();
+                current->scene = scene;
+                current->embedding = embedding;
+                init_devices(*current);
+            }
+            g = current;
         }
-        std::thread::id me = std::this_thread::get_id();
-        std::map<std::thread::id, std::size_t>::iterator it = per_thread.find(me);
-        std::size_t idx = it != per_thread.end() ? it->second : (per_thread[me] = next_slot++ % slots.size());
-        if (slots[idx]->parent == nullptr) upload(*slots[idx], scene, embedding);
-        return slots[idx].get();
+        /* outside the registry lock: the first caller stages the scene, the others of this generation wait for it */
+        std::call_once(g->uploaded, [&]() {
+            try { upload(*g); } catch (...) { g->upload_error = std::current_exception(); }
+        });
+        if (g->upload_error) std::rethrow_exception(g->upload_error);
+        return g;
     }
 
 private:
     std::mutex mu;
-    std::vector<std::unique_ptr<Slot> > slots;
-    std::map<std::thread::id, std::size_t> per_thread;
-    std::size_t next_slot = 0;
-    void* cached_scene = nullptr;
-    std::string cached_embedding;
+    std::shared_ptr<Generation> current;
 
-    void init_devices()
+    static void init_devices(Generation& g)
     {
         int n = mi_dmrecon_device_count();
         if (n <= 0) throw std::runtime_error("mvs::DMRecon (MI355X build): no HIP device available; there is no CPU path");
@@ -249,35 +265,65 @@ private:
         }
         if (devices.empty()) for (int d = 0; d < n; ++d) devices.push_back(d);
         for (std::size_t i = 0; i < devices.size(); ++i) {
-            slots.push_back(std::unique_ptr<Slot>(new Slot()));
-            slots.back()->device = devices[i];
+            g.slots.push_back(std::unique_ptr<Slot>(new Slot()));
+            g.slots.back()->device = devices[i];
         }
     }
 
-    /* SingleView::create for every usable view (dmrecon.cc:62-71) + ensureImages (image_pyramid.cc:55-95) */
-    void upload(Slot& slot, mve::Scene::Ptr scene, std::string const& embedding)
+    /*
+     * SingleView::create for every usable view (dmrecon.cc:62-71) + ensureImages (image_pyramid.cc:55-95), for all
+     * GPUs at once.  The reference decodes and down-samples under one global mutex (image_pyramid.cc:102); here the
+     * views are decoded ONCE, by several host threads in parallel, and each decoded image is handed to every GPU's
+     * asynchronous staging path (mi_dmrecon_set_view_async: copy + RGBA pack + pyramid kernels are only enqueued),
+     * so the uploads of the GPUs and the decoding of the next views overlap.
+     */
+    static void upload(Generation& g)
     {
-        mi_dmrecon_ctx* c = nullptr;
-        int rc = mi_dmrecon_ctx_create(slot.device, &c);
-        if (rc != 0) raise_from(rc);
-        mve::Scene::ViewList const& views(scene->get_views());
+        std::size_t const ns = g.slots.size();
+        std::vector<mi_dmrecon_ctx*> ctxs(ns, nullptr);
+        std::vector<std::unique_ptr<std::mutex> > ctx_mu;
+        for (std::size_t s = 0; s < ns; ++s) {
+            ctx_mu.push_back(std::unique_ptr<std::mutex>(new std::mutex()));
+            int rc = mi_dmrecon_ctx_create(g.slots[s]->device, &ctxs[s]);
+            if (rc != 0) { for (std::size_t k = 0; k < s; ++k) mi_dmrecon_ctx_destroy(ctxs[k]); raise_from(rc); }
+        }
+        mve::Scene::ViewList const& views(g.scene->get_views());
+        /* images stay alive until the copies enqueued from them have run (mi_dmrecon_sync below) */
+        std::vector<mve::ByteImage::Ptr> keep(views.size());
+        int failed_rc = 0;
+        std::string failed_msg;
+        int const n_threads = (int)std::max<std::size_t>(1, std::min<std::size_t>(env_threads(), views.size()));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
         for (std::size_t i = 0; i < views.size(); ++i) {
             if (views[i] == nullptr || !views[i]->is_camera_valid()
-                || !views[i]->has_image(embedding, mve::IMAGE_TYPE_UINT8))
+                || !views[i]->has_image(g.embedding, mve::IMAGE_TYPE_UINT8))
                 continue;
-            mve::ByteImage::Ptr img = views[i]->get_byte_image(embedding);
+            mve::ByteImage::Ptr img = views[i]->get_byte_image(g.embedding);      /* decode: per view, no shared state */
             if (img == nullptr) continue;
+            keep[i] = img;
             mve::CameraInfo const& cam = views[i]->get_camera();
             mi_dmrecon_camera mc;
             mc.flen = cam.flen; mc.paspect = cam.paspect;
             mc.ppoint[0] = cam.ppoint[0]; mc.ppoint[1] = cam.ppoint[1];
             for (int k = 0; k < 9; ++k) mc.rot[k] = cam.rot[k];
             for (int k = 0; k < 3; ++k) mc.trans[k] = cam.trans[k];
-            rc = mi_dmrecon_set_view(c, (int32_t)i, &mc, img->width(), img->height(), img->channels(), img->get_data_pointer());
+            for (std::size_t s = 0; s < ns; ++s) {
+                std::lock_guard<std::mutex> lock(*ctx_mu[s]);                     /* a context is not thread-safe */
+                int rc = mi_dmrecon_set_view_async(ctxs[s], (int32_t)i, &mc, img->width(), img->height(), img->channels(),
+                                                   img->get_data_pointer());
+                if (rc != 0) {
+#pragma omp critical(mi_dmrecon_upload_error)
+                    if (failed_rc == 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
+                }
+            }
             views[i]->cache_cleanup();
-            if (rc != 0) { mi_dmrecon_ctx_destroy(c); raise_from(rc); }
         }
-        mve::Bundle::Features const& feats = scene->get_bundle()->get_features();
+        for (std::size_t s = 0; s < ns && failed_rc == 0; ++s) {
+            int rc = mi_dmrecon_sync(ctxs[s]);
+            if (rc != 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
+        }
+        keep.clear();
+        mve::Bundle::Features const& feats = g.scene->get_bundle()->get_features();
         std::vector<float> pos(feats.size() * 3);
         std::vector<int32_t> off(feats.size() + 1, 0), ids;
         for (std::size_t i = 0; i < feats.size(); ++i) {
@@ -286,16 +332,38 @@ private:
             off[i + 1] = (int32_t)ids.size();
         }
         if (ids.empty()) ids.push_back(0);
-        rc = mi_dmrecon_set_features(c, (int32_t)feats.size(), pos.data(), off.data(), ids.data());
-        if (rc != 0) { mi_dmrecon_ctx_destroy(c); raise_from(rc); }
-        slot.parent = c;
+        for (std::size_t s = 0; s < ns && failed_rc == 0; ++s) {
+            int rc = mi_dmrecon_set_features(ctxs[s], (int32_t)feats.size(), pos.data(), off.data(), ids.data());
+            if (rc != 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
+        }
+        if (failed_rc != 0) {
+            for (std::size_t s = 0; s < ns; ++s) mi_dmrecon_ctx_destroy(ctxs[s]);
+            switch (failed_rc) {
+                case MI_DMRECON_EINVAL: throw std::invalid_argument(failed_msg);
+                default: throw std::runtime_error(failed_msg);
+            }
+        }
+        for (std::size_t s = 0; s < ns; ++s) g.slots[s]->parent = ctxs[s];
     }
+
+    static std::size_t env_threads()
+    {
+        char const* e = std::getenv("MI_DMRECON_DECODE_THREADS");
+        int v = e ? std::atoi(e) : 0;
+        return v > 0 ? (std::size_t)v : 16;
+    }
+};
+
+/* what a DMRecon instance keeps: its generation (alive as long as the instance) and its GPU of that generation */
+struct Attachment {
+    std::shared_ptr<Generation> gen;
+    Slot* slot = nullptr;
 };
 
 }  // namespace
 
 DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
-    : scene(_scene), settings(_settings), slot(nullptr), width(0), height(0)
+    : scene(_scene), settings(_settings), slot(), width(0), height(0)
 {
     mve::Scene::ViewList const& mve_views(scene->get_views());
     if (settings.refViewNr >= mve_views.size())
@@ -314,8 +382,13 @@ DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
         || !ref->has_image(settings.imageEmbedding, mve::IMAGE_TYPE_UINT8))
         throw std::invalid_argument("Invalid master view");
 
-    Slot* slot = Registry::get().slot_for(scene, settings.imageEmbedding);
-    this->slot = slot;
+    /* requests are dealt round-robin over the GPUs of the generation (schedule(dynamic,1) over views, apps/dmrecon/
+     * dmrecon.cc:285, hands consecutive views to whichever thread is free: any static thread -> GPU map would do) */
+    std::shared_ptr<Attachment> att = std::make_shared<Attachment>();
+    att->gen = Registry::get().generation_for(scene, settings.imageEmbedding);
+    att->slot = att->gen->slots[att->gen->next_slot++ % att->gen->slots.size()].get();
+    this->slot = att;
+    Slot* slot = att->slot;
     int32_t w = 0, h = 0;
     {
         std::lock_guard<std::mutex> lock(slot->parent_mu);
@@ -370,7 +443,7 @@ DMRecon::start()
         }
     });
     int32_t ref = (int32_t)settings.refViewNr;
-    Slot* sl = static_cast<Slot*>(this->slot);
+    Slot* sl = std::static_pointer_cast<Attachment>(this->slot)->slot;
     Request req;
     req.st = st; req.ref = ref; req.maps = maps; req.prog = &mp;
     sl->submit(req);                            /* returns when the batch this view ended up in has finished */

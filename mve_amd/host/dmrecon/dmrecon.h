@@ -7,6 +7,7 @@
 /* the reference header pulls these in and its callers rely on that (fancy_progress_printer.cc uses
  * std::cout without including <iostream> itself) */
 #include <fstream>
+#include <memory>
 #include <iostream>
 #include <queue>
 #include <string>
@@ -37,7 +38,7 @@ private:
     mve::Scene::Ptr scene;
     Settings settings;
     Progress progress;
-    void* slot;              /* the GPU slot (resident scene + batching executors) this instance submits to */
+    std::shared_ptr<void> slot;   /* the resident scene's generation and the GPU slot of it this instance submits to */
     int width, height;
 };
 

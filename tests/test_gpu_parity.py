@@ -391,17 +391,19 @@ def test_hard_scene_patch_vectors_vs_reference(gpu_ctx, h1, h1_scene):
 
 
 def test_hard_scene_maps_vs_reference(gpu_ctx, h1, h1_scene):
-    """Map-level parity where the propagation meets discontinuities and empty regions.  The parallel sweep and the
-    sequential queue disagree most exactly there (which neighbour reaches a pixel first decides its local views), so
-    the fill-mask bound is the looser 0.95 here; depth / confidence bounds are the usual ones."""
+    """Map-level parity where the propagation meets discontinuities and empty regions.  Which neighbour reaches a
+    pixel first decides its local view set, and at the depth step / the occluder's edge that decides the result:
+    the reference algorithm against ITSELF with the queue popped worst-first (tests/test_oracle_golden.py::
+    test_order_sensitivity_floor_on_hard_scene) gives IoU 0.9947, relative depth p99 1.6e-2, confidence p99 0.091 on
+    view 0.  The bounds here are that floor x ~2 in the tails; medians as everywhere else."""
     gpu_ctx.load_scene(h1_scene)
     res = gpu_ctx.reconstruct(api.Settings(), [0, 8], want_views=True)
     stats = dict(gpu_ctx.last_stats)
     for v, r in zip((0, 8), res):
         m = map_parity(r["depth"], r["conf"], h1["s0v%d_depth" % v], h1["s0v%d_conf" % v])
         print("H1 view %d:" % v, m)
-        assert m["iou"] >= 0.95 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
-        assert m["conf_med"] <= 1e-3 and m["conf_p99"] <= 1e-2, m
+        assert m["iou"] >= 0.985 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 3e-2, m
+        assert m["conf_med"] <= 2e-3 and m["conf_p99"] <= 0.15, m
         # the occluder's silhouette and the empty part of the low-overlap view are where the reference has them
         empty_ref = h1["s0v%d_depth" % v] == 0
         assert ((r["depth"] == 0) & empty_ref).sum() >= 0.9 * empty_ref.sum()

@@ -111,3 +111,27 @@ def test_hard_scene_patch_vectors_exact(h1, h1_scene):
     n = len(ref)
     changed = ok[n // 2:] & (ref_loc[n // 2:] != h1["seeds_local"][n // 2:]).any(1)
     assert changed.sum() >= 3                                # propagated sets the reference had to re-select
+
+
+def test_order_sensitivity_floor_on_hard_scene(h1, h1_scene, monkeypatch):
+    """How much does the reference ALGORITHM depend on its own pop order?  Same restatement, queue popped worst-first
+    (ORC_QUEUE_ORDER=reverse, read when the library is loaded -> a subprocess).  This is the floor against which the
+    GPU's parallel sweep is judged on scene H1 (tests/test_gpu_parity.py::test_hard_scene_maps_vs_reference)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import map_parity, ROOT
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from conftest import scene_from_golden, GOLDEN\nfrom oracle import oracle as orc\nimport os\n"
+            "g = dict(np.load(os.path.join(GOLDEN, 'h1_hard_9views_208x156.npz')))\n"
+            "r = orc.OracleScene(scene_from_golden(g)).reconstruct(orc.make_settings(ref_view=0, scale=0))\n"
+            "np.savez(sys.argv[1], d=r['depth'], c=r['conf'])\n" % (ROOT, os.path.join(ROOT, "tests")))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rev.npz")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, ORC_QUEUE_ORDER="reverse"))
+        rev = np.load(out)
+        m = map_parity(h1["s0v0_depth"], h1["s0v0_conf"], rev["d"], rev["c"])
+    assert not np.array_equal(rev["d"], h1["s0v0_depth"])
+    # measured: iou 0.9947, rel_med 2.5e-4, rel_p99 1.6e-2, conf_med 9.5e-4, conf_p99 0.091
+    assert 0.99 <= m["iou"] <= 0.999 and 5e-3 <= m["rel_p99"] <= 3e-2 and 0.03 <= m["conf_p99"] <= 0.15, m
