@@ -1415,6 +1415,7 @@ int mi_dmrecon_pointset(mi_dmrecon_ctx* c, const mi_dmrecon_camera* cam, int32_t
     P.scale_factor = opt ? opt->scale_factor : 2.5f;
     P.conf_iterations = opt ? opt->conf_iterations : 4;
     if (P.conf_iterations < 1) return fail(MI_DMRECON_EINVAL, "pointset: conf_iterations < 1");
+    if (P.conf_iterations > 127) return fail(MI_DMRECON_EINVAL, "pointset: conf_iterations > 127 (border distances are kept in 8 bits)");
     const size_t npix = (size_t)w * h;
     struct Tmp {                                               /* freed on every return path */
         DevBuf<float> depth; DevBuf<uint8_t> cells; DevBuf<PsVertex> verts;
