@@ -67,17 +67,20 @@ def plan_calls(steps, streams, steps_per_call=0):
     return spc, n_calls, max(1, min(int(streams), n_calls))
 
 
-def measured_traffic():
-    """HBM-side bytes per k_optimize launch from the committed PMC passes (tools/collect_profiles.sh ->
-    tools/summarize_profiles.py -> profiles/*_traffic.json); None when no profile is present.  PMC counters
-    cannot be read from inside the timed run, so this is the latest profiled value of the same command."""
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")),
-                   key=os.path.getmtime)
-    if not files:
-        return None, None
-    j = json.load(open(files[-1]))
-    return float(j["bytes_per_launch"]), os.path.basename(files[-1])
+def measured_traffic(n_streams, spc):
+    """HBM-side bytes per STEP of the two optimise kernel families from the committed PMC passes of this round
+    (tools/collect_profiles.sh -> tools/summarize_profiles.py -> profiles/r2_traffic.json), at the call plan that
+    matches this run; ({}, None) when no profile is present.  PMC counters cannot be read from inside the timed run,
+    so this is the latest profiled value of the same command; FETCH_SIZE is already corrected (x2, calibrated)."""
+    f = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    if not os.path.exists(f):
+        return {}, None
+    j = json.load(open(f))
+    want = "1 host thread" if (n_streams == 1 and spc == 1) else "default"
+    for plan, fams in j.get("plans", {}).items():
+        if plan.startswith(want):
+            return fams, "profiles/r2_traffic.json (%s; %s)" % (plan, j.get("correction", ""))
+    return {}, None
 
 
 def cpu_baseline(scene, cfg, gpu_maps=None):
@@ -274,7 +277,14 @@ def main():
         opt_s = acc["ms_opt_kernel"] / 1000.0
         n_launch = max(int(acc["n_launches"]), 1)
         achieved = b_alg / opt_s / 1e9 if opt_s > 0 else 0.0
-        traffic, traffic_src = measured_traffic()
+        fams, traffic_src = measured_traffic(n_streams, spc)
+        steps_rank = max(n_maps_rank // p.n_views, 1)
+
+        def fam_bytes(name):                                  # measured HBM-side bytes of a family over this run
+            v = fams.get(name)
+            return None if v is None else (v["read_bytes_per_step"] + v["written_bytes_per_step"]) * steps_rank
+        t_bulk, t_tail = fam_bytes("k_optimize<1> (host-visible rounds)"), fam_bytes("k_tail (blind tail rounds)")
+        traffic = None if t_bulk is None or t_tail is None else (t_bulk + t_tail) / n_launch
         # the two kernels behind `achieved`, each with its own share of the algorithmic bytes
         bulk_stats = {"n_eval": acc.get("n_eval_bulk", 0), "n_patch": acc.get("n_patch_bulk", 0), "n_filled": acc.get("n_filled_bulk", 0)}
         b_bulk = algorithmic_bytes(bulk_stats, n_maps_rank, scene, cfg)        # the compulsory bytes go with the bulk rounds
@@ -303,6 +313,7 @@ def main():
                          "kernel": "k_optimize<1> + k_tail (patch optimisation, both lane layouts)", "launches": n_launch,
                          "avg_launch_ms": acc["ms_opt_kernel"] / n_launch,
                          "algorithmic_bytes_per_launch": b_alg / n_launch,
+                         "traffic_over_algorithmic": None if traffic is None else traffic * n_launch / b_alg,
                          "n_eval": int(acc["n_eval"]), "n_patch": int(acc["n_patch"]), "n_filled": int(acc["n_filled"]),
                          "n_pass": int(acc.get("n_pass", 0)),
                          "n_window_stages": int(acc.get("n_stage", 0)), "n_gather_passes": int(acc.get("n_gather_pass", 0)),
@@ -312,12 +323,24 @@ def main():
                          "per_kernel": {
                              "k_optimize<1> (host-visible rounds)": {
                                  "launches": nb, "avg_launch_ms": ms_bulk / nb, "algorithmic_bytes_per_launch": b_bulk / nb,
+                                 "traffic": None if t_bulk is None else t_bulk / nb,
+                                 "traffic_over_algorithmic": None if t_bulk is None else t_bulk / b_bulk,
                                  "achieved": (b_bulk / (ms_bulk / 1e3) / 1e9) if ms_bulk > 0 else None,
                                  "frac": (b_bulk / (ms_bulk / 1e3) / 1e9 / HBM_PEAK_GBS) if ms_bulk > 0 else None},
                              "k_tail (blind tail rounds)": {
                                  "launches": nt, "avg_launch_ms": ms_tail / nt, "algorithmic_bytes_per_launch": b_tail / nt,
+                                 "traffic": None if t_tail is None else t_tail / nt,
+                                 "traffic_over_algorithmic": None if t_tail is None else t_tail / b_tail,
                                  "achieved": (b_tail / (ms_tail / 1e3) / 1e9) if ms_tail > 0 else None,
                                  "frac": (b_tail / (ms_tail / 1e3) / 1e9 / HBM_PEAK_GBS) if ms_tail > 0 else None}},
+                         # the secondary roofs SURVEY 8d names (the real limiters are on-chip):
+                         # fp32 VALU with SURVEY's algorithmic flop counts (3.6 kflop per derivative evaluation, 1.6 kflop
+                         # per colour evaluation, mix 19.9 : 11.9), and the L2 with the bytes the passes request from it
+                         "secondary_roofs": {
+                             "valu_fp32": {"algorithmic_flop": 2.85e3 * acc["n_eval"], "achieved": 2.85e3 * acc["n_eval"] / opt_s / 1e12 if opt_s > 0 else None,
+                                           "peak": 157.3, "unit": "TFLOP/s", "frac": 2.85e3 * acc["n_eval"] / opt_s / 1e12 / 157.3 if opt_s > 0 else None},
+                             "l2": {"requested_bytes": 400.0 * acc.get("n_pass", 0), "achieved": 400.0 * acc.get("n_pass", 0) / opt_s / 1e9 if opt_s > 0 else None,
+                                    "peak": 34500.0, "unit": "GB/s", "frac": 400.0 * acc.get("n_pass", 0) / opt_s / 1e9 / 34500.0 if opt_s > 0 else None}},
                          "kernel_time_share": opt_s / elapsed if elapsed > 0 else None,
                          # the launches of the host threads' streams overlap on the GPU, so each launch's own duration
                          # (above, as the contract asks) stretches; the same bytes over the wall time of the region:

@@ -1,5 +1,10 @@
 """Turns gpurun_out/<tag>/ (written by tools/collect_profiles.sh on the GPU box) into the committed summaries
-under profiles/: kernel stats CSVs (rocprofv3 --kernel-trace --stats), bench JSON lines and a PMC table."""
+under profiles/: kernel stats CSVs (rocprofv3 --kernel-trace --stats), bench JSON lines, a PMC table and the
+HBM-side traffic per step that bench.py reports as `roofline.traffic`.
+
+Counter units (profiles/r2_pmc_calibration.md, tools/pmc_calib.sh): FETCH_SIZE is reported in KB of 64 B per
+fabric read request, but every request moves 128 B -- for coalesced streams AND for scattered 16-byte gathers (one
+request per record) -- so read bytes = FETCH_SIZE x 1024 x 2.  WRITE_SIZE is exact as reported (x 1024)."""
 import csv
 import collections
 import glob
@@ -8,9 +13,13 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
+FETCH_CORR = 2.0
+# steps (passes over the 20 views) behind each PMC run of tools/collect_profiles.sh, warm-up calls included
+STEPS = {"pmc": 3,      # --steps 2 --warmup 1 --streams 1 --steps-per-call 1: three calls of one step
+         "pmcd": 20}    # --steps 10 --warmup 1 (5 steps per call, 2 threads): 2 warm-up + 2 timed calls of five steps
 for n in ("1thread", "default"):
     f = os.path.join(src, "bench_%s.json" % n)
     if os.path.exists(f) and os.path.getsize(f):
@@ -25,25 +34,37 @@ def short(name):
     return name.split("(")[0].replace("void ", "")
 
 
-acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-regs = {}
-for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-    if not os.path.isdir(d):
-        continue
-    f = os.path.join(d, "bench_counter_collection.csv")
-    if not os.path.exists(f):
-        continue
-    for row in csv.DictReader(open(f)):
-        k = short(row["Kernel_Name"])
-        a = acc[k][row["Counter_Name"]]
-        a[0] += float(row["Counter_Value"]); a[1] += 1
-        regs[k] = (row["VGPR_Count"], row["Accum_VGPR_Count"], row["SGPR_Count"], row["LDS_Block_Size"], row["Scratch_Size"])
-lines = ["# %s — PMC counters of the C3 bench (rocprofv3 --pmc, one counter group per run; see tools/collect_profiles.sh)" % tag, "",
-         "Per launch averages over `python bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline` (3 reconstructions",
-         "of the 20-view scene).  FETCH_SIZE / WRITE_SIZE are reported in KB and shown here in MB; no x2 correction is",
-         "applied (the guide's doubling concerns 16 B/lane streams, these kernels gather 4-8 B per lane).", "",
-         "| kernel | launches | FETCH MB | WRITE MB | L2 hit % | VALU-active % of wave cycles | wave-cycles/VALU inst | wait-any % | L1 accesses | L1->L2 read req | L1 pending-stall % of L1 busy | VGPR/AGPR/SGPR | LDS B | scratch B |",
-         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+def family(k):
+    if k.startswith("k_tail"):
+        return "k_tail (blind tail rounds)"
+    if k.startswith("k_optimize"):
+        return "k_optimize<1> (host-visible rounds)"
+    return None
+
+
+def collect(prefix):
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    regs = {}
+    for d in sorted(glob.glob(os.path.join(src, prefix + "_*"))):
+        f = os.path.join(d, "bench_counter_collection.csv")
+        if not os.path.isdir(d) or not os.path.exists(f):
+            continue
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            a = acc[k][row["Counter_Name"]]
+            a[0] += float(row["Counter_Value"]); a[1] += 1
+            regs[k] = (row["VGPR_Count"], row["Accum_VGPR_Count"], row["SGPR_Count"], row["LDS_Block_Size"], row["Scratch_Size"])
+    return acc, regs
+
+
+acc, regs = collect("pmc")
+lines = ["# %s -- PMC counters of the C3 bench (rocprofv3 --pmc, one counter group per run; tools/collect_profiles.sh)" % tag, "",
+         "Per launch averages over `python bench.py --steps 2 --warmup 1 --streams 1 --steps-per-call 1` (3 reconstructions",
+         "of the 20-view scene).  FETCH MB = FETCH_SIZE x 1024 x 2 (every fabric read request moves 128 B, the counter tallies",
+         "64 B: calibrated on known byte counts in this kernel's own access pattern, profiles/r2_pmc_calibration.md);",
+         "WRITE MB = WRITE_SIZE x 1024 (exact).  k_tail averages include the empty rounds enqueued blind.", "",
+         "| kernel | launches | FETCH MB | WRITE MB | L2 hit % | VALU-active % of wave cycles | wave-cycles/VALU inst | wait-any % | LDS-active % | LDS bank-conflict % of LDS-active | L1 accesses | L1->L2 read req | L1 pending-stall % of L1 busy | VGPR/AGPR/SGPR | LDS B | scratch B |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for k in sorted(acc, key=lambda k: -acc[k].get("FETCH_SIZE", [0, 0])[0]):
     c = acc[k]
     if k.startswith("__amd"):
@@ -52,30 +73,41 @@ for k in sorted(acc, key=lambda k: -acc[k].get("FETCH_SIZE", [0, 0])[0]):
         return c[n][0] / c[n][1] if n in c and c[n][1] else None
     n = max(v[1] for v in c.values())
     hit, miss = avg("TCC_HIT_sum"), avg("TCC_MISS_sum")
-    busy, act = avg("SQ_BUSY_CYCLES"), avg("SQ_ACTIVE_INST_VALU")
-    wc, valu, wany = avg("SQ_WAVE_CYCLES"), avg("SQ_INSTS_VALU"), avg("SQ_WAIT_INST_ANY")
+    act = avg("SQ_ACTIVE_INST_VALU")
+    wc, valu, wany = avg("SQ_WAVE_CYCLES"), avg("SQ_INSTS_VALU"), avg("SQ_WAIT_ANY")
+    lds_a, lds_c = avg("SQ_ACTIVE_INST_LDS"), avg("SQ_LDS_BANK_CONFLICT")
     f = lambda v, s=1.0, fmt="%.3f": "-" if v is None else fmt % (v * s)
     l1a, l1r, l1p, l1g = avg("TCP_TOTAL_CACHE_ACCESSES_sum"), avg("TCP_TCC_READ_REQ_sum"), avg("TCP_PENDING_STALL_CYCLES_sum"), avg("TCP_GATE_EN1_sum")
-    lines.append("| `%s` | %d | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
-        k, n, f(avg("FETCH_SIZE"), 1 / 1024), f(avg("WRITE_SIZE"), 1 / 1024),
+    lines.append("| `%s` | %d | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
+        k, n, f(avg("FETCH_SIZE"), FETCH_CORR / 1024), f(avg("WRITE_SIZE"), 1 / 1024),
         "-" if hit is None or hit + miss == 0 else "%.1f" % (100 * hit / (hit + miss)),
         "-" if not wc or act is None else "%.1f" % (100 * act / wc),
         "-" if not valu or wc is None else "%.2f" % (wc / valu),
         "-" if not wc or wany is None else "%.1f" % (100 * wany / wc),
+        "-" if not wc or lds_a is None else "%.1f" % (100 * lds_a / wc),
+        "-" if not lds_a or lds_c is None else "%.1f" % (100 * lds_c / lds_a),
         "-" if l1a is None else "%.3g" % l1a, "-" if l1r is None else "%.3g" % l1r,
         "-" if not l1g or l1p is None else "%.1f" % (100 * l1p / l1g),
         "/".join(regs[k][:3]), regs[k][3], regs[k][4]))
-# HBM-side traffic of the optimise kernels per launch (all layouts pooled, like bench.py's `achieved`)
-tb, tl = 0.0, 0
-for k in acc:
-    if (k.startswith("k_optimize") or k == "k_tail") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
-        tb += (acc[k]["FETCH_SIZE"][0] + acc[k]["WRITE_SIZE"][0]) * 1024.0
-        tl += acc[k]["FETCH_SIZE"][1]
-if tl:
-    json.dump({"kernel": "k_optimize", "bytes_per_launch": tb / tl, "launches": tl,
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/%s_pmc.md" % tag},
-              open(os.path.join(dst, "%s_traffic.json" % tag), "w"))
-    lines += ["", "optimise kernels (k_optimize<1>, k_optimize<16>, k_tail pooled, as bench.py counts launches): %.2f MB of HBM-side traffic per launch over %d launches" % (tb / tl / 1e6, tl)]
+
+# HBM-side bytes per STEP of the two optimise kernel families, at both call plans (bench.py divides by ITS launch
+# counts: rocprofv3 also sees the empty tail rounds that the host enqueues blind)
+traffic = {"correction": "read bytes = FETCH_SIZE x 1024 x 2 (128-byte requests tallied at 64 B; calibrated, profiles/r2_pmc_calibration.md); "
+                         "written bytes = WRITE_SIZE x 1024", "plans": {}}
+for prefix, plan in (("pmc", "1 host thread, 1 step per call"), ("pmcd", "default: 6 host threads, 5 steps per call")):
+    a, _ = (acc, regs) if prefix == "pmc" else collect("pmcd")
+    fam = collections.defaultdict(lambda: [0.0, 0.0])
+    for k in a:
+        fm = family(k)
+        if fm and "FETCH_SIZE" in a[k] and "WRITE_SIZE" in a[k]:
+            fam[fm][0] += a[k]["FETCH_SIZE"][0] * 1024.0 * FETCH_CORR
+            fam[fm][1] += a[k]["WRITE_SIZE"][0] * 1024.0
+    if fam:
+        traffic["plans"][plan] = {fm: {"read_bytes_per_step": v[0] / STEPS[prefix], "written_bytes_per_step": v[1] / STEPS[prefix]} for fm, v in fam.items()}
+        lines += ["", "HBM-side traffic per step (20 depth maps), %s:" % plan] + [
+            "  %s: %.1f MB read + %.1f MB written" % (fm, v[0] / STEPS[prefix] / 1e6, v[1] / STEPS[prefix] / 1e6) for fm, v in sorted(fam.items())]
+if traffic["plans"]:
+    json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 for n in ("1thread", "default"):
     f = os.path.join(src, "bench_%s.json" % n)
     if os.path.exists(f) and os.path.getsize(f):
