@@ -284,17 +284,18 @@ __device__ __forceinline__ int mip_level(float z, float inv0, float mfp, int max
     return mm > maxl ? maxl : mm;                /* clampLevel with minLevel 0 (dmrecon.cc:240) */
 }
 
-/* One-shot set-up of a view (view selection candidates, parity hook): three dependent loads, no window. */
-__device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, int view_id, const PatchState& ps,
+/* One-shot set-up of a view (view selection candidates, parity hook): two dependent loads (the job's record of the
+ * view, then the level), no window. */
+__device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, const DevJobView& J, const PatchState& ps,
                                            NView& nv, int& level) {
-    const DevView* V = views + view_id;
-    nv.m0 = V->w2c[0]; nv.m1 = V->w2c[1]; nv.m2 = V->w2c[2]; nv.m3 = V->w2c[3];
-    nv.m4 = V->w2c[4]; nv.m5 = V->w2c[5]; nv.m6 = V->w2c[6]; nv.m7 = V->w2c[7];
-    nv.m8 = V->w2c[8]; nv.m9 = V->w2c[9]; nv.m10 = V->w2c[10]; nv.m11 = V->w2c[11];
+    nv.m0 = J.w2c[0]; nv.m1 = J.w2c[1]; nv.m2 = J.w2c[2]; nv.m3 = J.w2c[3];
+    nv.m4 = J.w2c[4]; nv.m5 = J.w2c[5]; nv.m6 = J.w2c[6]; nv.m7 = J.w2c[7];
+    nv.m8 = J.w2c[8]; nv.m9 = J.w2c[9]; nv.m10 = J.w2c[10]; nv.m11 = J.w2c[11];
     const float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
-    const int mm = mip_level(z, V->lv[0].inv0, ps.mfp, V->n_levels - 1);
+    const int mm = mip_level(z, J.inv0, ps.mfp, J.maxl);
     if (mm < 0) return false;
     level = mm;
+    const DevView* V = views + J.view;
     const DevLevel& L = V->lv[mm];
     premultiply(nv, L.ax, L.ay, L.cx, L.cy);
     nv.w = L.w; nv.h = L.h;
@@ -313,7 +314,7 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, in
 struct ViewC {
     int sel;                     /* PatchState::sel this cache belongs to (-2 = empty) */
     int lvl;                     /* mip level the matrices / window belong to (-1 = none) */
-    const DevView* V;
+    const DevJobView* V;
     float inv0; int maxl;
     NView nv;                    /* rows 8..11 valid once sel is set; rows 0..7, w, h, img per level */
     const uint32_t* lin;         /* RGBA8 texels of the level (DevView::img), the window's source */
@@ -615,7 +616,7 @@ __device__ __forceinline__ float eval_color(PatchState& ps, const DevView* views
     NView nv; int level; GNSums gn;
     ok = false;
     if (gidx < 0) return -1.f;
-    if (!setup_view(views, ps.job->global_ids[gidx], ps, nv, level)) return -1.f;
+    if (!setup_view(views, ps.job->gv[gidx], ps, nv, level)) return -1.f;
     bool fits_unused;
     ok = sample_pass<PASS_COLOR, LPV, false>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub, fits_unused);
     ps.n_pass++;
@@ -723,10 +724,10 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
         float best = 0.f; int bestg = -1;
         for (int g = slot; g < G; g += QUAD) {
             if (!((ps.avail >> g) & 1u)) continue;
-            const DevView* V = views + J->global_ids[g];
+            const DevJobView* V = &J->gv[g];
             float score = s_ncc[g];
             const float z = V->w2c[8] * ps.p0x + V->w2c[9] * ps.p0y + V->w2c[10] * ps.p0z + V->w2c[11];
-            const float nfp = z * V->lv[0].inv0;
+            const float nfp = z * V->inv0;
             if (ps.mfp / nfp < 0.5f) score *= 0.01f;
             float vx, vy, vz;
             unit_dir(V->cam_pos, ps.p0x, ps.p0y, ps.p0z, vx, vy, vz);
@@ -737,7 +738,7 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (sl[k] < 0) continue;
-                const DevView* U = views + J->global_ids[sl[k]];
+                const DevJobView* U = &J->gv[sl[k]];
                 float sx, sy, sz;
                 unit_dir(U->cam_pos, ps.p0x, ps.p0y, ps.p0z, sx, sy, sz);
                 dp = fminf(fmaxf(sx * vx + sy * vy + sz * vz, -1.f), 1.f);
@@ -821,10 +822,10 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
     typedef Lay<LPV> L;
     if (vc.sel != ps.sel) {
         vc.sel = ps.sel;
-        const DevView* V = views + ps.job->global_ids[ps.sel];
+        const DevJobView* V = &ps.job->gv[ps.sel];
         vc.V = V;
         vc.nv.m8 = V->w2c[8]; vc.nv.m9 = V->w2c[9]; vc.nv.m10 = V->w2c[10]; vc.nv.m11 = V->w2c[11];
-        vc.inv0 = V->lv[0].inv0; vc.maxl = V->n_levels - 1;
+        vc.inv0 = V->inv0; vc.maxl = V->maxl;
         vc.lvl = -1;
     }
     NView& nv = vc.nv;
@@ -833,14 +834,15 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
     if (mm < 0) return false;
     if (mm != vc.lvl) {
         vc.lvl = mm;
-        const DevView* V = vc.V;
+        const DevJobView* V = vc.V;
         nv.m0 = V->w2c[0]; nv.m1 = V->w2c[1]; nv.m2 = V->w2c[2]; nv.m3 = V->w2c[3];
         nv.m4 = V->w2c[4]; nv.m5 = V->w2c[5]; nv.m6 = V->w2c[6]; nv.m7 = V->w2c[7];
-        const DevLevel& Lv = V->lv[mm];
+        const DevView* DV = views + V->view;
+        const DevLevel& Lv = DV->lv[mm];
         premultiply(nv, Lv.ax, Lv.ay, Lv.cx, Lv.cy);
         nv.w = Lv.w; nv.h = Lv.h;
-        nv.img = V->quad + 4 * (size_t)Lv.tex_off;
-        vc.lin = V->img + Lv.tex_off;
+        nv.img = DV->quad + 4 * (size_t)Lv.tex_off;
+        vc.lin = DV->img + Lv.tex_off;
         nv.bx = MI_NOBOX; nv.by = MI_NOBOX;
     }
     nv.win = nullptr;
@@ -1746,7 +1748,7 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
         a.ncc[g] = ncc;
         NView nv; int level = -1; GNSums gn;
         bool fits_unused;
-        bool okd = setup_view(a.views, job->global_ids[g], ps, nv, level)
+        bool okd = setup_view(a.views, job->gv[g], ps, nv, level)
             && sample_pass<PASS_DUMP, 1, false>(ps, nv, s_lut, s_rays, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0, fits_unused);
         a.ok[g] = okd ? 1 : 0;
         a.level[g] = level;

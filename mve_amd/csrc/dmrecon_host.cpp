@@ -573,7 +573,16 @@ void fill_job(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost const& j
      * valid cameras it cannot be reached from outside */
     if (const char* e = std::getenv("MI_DMRECON_INJECT_FOOTPRINT")) if (std::atoi(e) == jh.ref_view) d.inv0_s = -d.inv0_s;
     d.n_global = (int)jh.global.size();
-    for (size_t g = 0; g < jh.global.size(); ++g) d.global_ids[g] = jh.global[g];
+    for (size_t g = 0; g < jh.global.size(); ++g) {
+        d.global_ids[g] = jh.global[g];
+        HostView const& N = c->sc->views[jh.global[g]];
+        DevJobView& J = d.gv[g];
+        std::memcpy(J.w2c, N.w2c, sizeof(J.w2c));
+        J.inv0 = N.levels[0].invproj[0];
+        J.maxl = (int)N.levels.size() - 1;
+        J.view = jh.global[g];
+        std::memcpy(J.cam_pos, N.cam_pos, sizeof(J.cam_pos));
+    }
 }
 
 DevSettings dev_settings(const mi_dmrecon_settings* st) {

@@ -34,6 +34,17 @@ struct DevView {
     DevLevel lv[MI_MAX_LEVELS];
 };
 
+/* A global neighbour view as a job sees it: everything a sampling pass needs before it knows the mip level, in one
+ * record indexed by the view's position in the job's global list (no global_ids -> DevView indirection). */
+struct DevJobView {
+    float w2c[12];           /* rows of [R|t] */
+    float inv0;              /* invproj[0] of level 0 (SingleView::footPrint) */
+    int32_t maxl;            /* number of pyramid levels - 1 */
+    int32_t view;            /* index into the DevView table (levels, texels) */
+    float cam_pos[3];
+    int32_t pad[2];
+};
+
 /* One reference view being reconstructed (one mvs::DMRecon instance). */
 struct DevJob {
     /* the two words the device writes and the host polls (copied back as a strided 8-byte column) */
@@ -47,6 +58,7 @@ struct DevJob {
     float inv0_s;                       /* footPrintScaled factor */
     int32_t n_global;
     int32_t global_ids[MI_MAX_GLOBAL];  /* ascending view ids (GlobalViewSelection result) */
+    DevJobView gv[MI_MAX_GLOBAL];       /* ... and what the sampler needs of each of them */
     /* per-pixel state maps (device), zero = unfilled (single_view.cc:78-81) */
     float* depth;
     float* dz;        /* 2 ch */
