@@ -555,7 +555,16 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             float depth2 = ps.depth;
             asm volatile("" : "+v"(depth2));
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { Pre q = geom(row * 5 + k, depth2, false); q.t = tx[k]; consume(q); }
+            for (int k = 0; k < 5; ++k) {
+                Pre q = geom(row * 5 + k, depth2, false); q.t = tx[k]; consume(q);
+#ifdef MI_EXPERIMENT_EXTRA_GEOM
+                /* sensitivity probe: one more (useless) geometry evaluation per sample = +45 VALU instructions, +3 LDS reads */
+                float depth3 = ps.depth;
+                asm volatile("" : "+v"(depth3));
+                Pre q3 = geom(row * 5 + k, depth3, false);
+                asm volatile("" :: "v"(q3.fx), "v"(q3.fy), "v"(q3.gu), "v"(q3.gv));
+#endif
+            }
         }
     } else if (LPV != 16) {
         Pre cur = fetch(0);
