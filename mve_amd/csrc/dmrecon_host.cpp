@@ -1021,7 +1021,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     /* Rounds up to this many entries try a pixel's candidate hypotheses at the same time (four wavefronts per
      * pixel: the round is one patch optimisation long instead of up to four); larger rounds fill the GPU anyway
      * and run them in turn on one wavefront, which wastes nothing.  MI_DMRECON_SPECULATE=<entries> (0 = never). */
-    static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 256u; }();
+    static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 1024u; }();
     static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
     /* texel windows in LDS: bit 0 = latency layout (tail rounds), bit 1 = throughput layout (bulk rounds) */
     const int USE_WIN = [] { const char* e = std::getenv("MI_DMRECON_WIN"); return e ? std::atoi(e) : MI_WIN_DEFAULT; }();
