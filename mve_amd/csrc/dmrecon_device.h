@@ -14,7 +14,7 @@ void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in = nullptr,
                         const unsigned* follow_in_n = nullptr, unsigned* follow_out = nullptr, unsigned* follow_out_n = nullptr,
-                        bool windows = false);
+                        bool windows = false, bool self = false);
 extern unsigned long long* mi_debug_tbuf;
 void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                           const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
@@ -22,8 +22,9 @@ void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views
 /* k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile count */
 #define MI_GEN_TILE_W 64
 #define MI_GEN_TILE_H 32
+/* self: the work list = the pixels written in round - 1 themselves (the seeds' own queue entries), not their neighbours */
 void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
-                        unsigned* round_work, int round);
+                        unsigned* round_work, int round, bool self = false);
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                      const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
 /* one fused tail round: candidates from (prev_work, prev_results, round_work[round - 1]) -> this round's list,

@@ -1314,6 +1314,9 @@ struct OptArgs {
     /* One attempt per launch (throughput layout, host-visible rounds): an entry whose pixel has several candidate
      * hypotheses runs them in successive launches over compacted follow-up lists, so that wavefronts stay full
      * (16 patches) instead of idling 15 quads while one entry tries its second neighbour. */
+    int self;                     /* 1: an entry's one candidate is the pixel's OWN state (a seed popped from the queue is
+                                   * re-optimised from its converged result and only propagates if that strictly raises its
+                                   * confidence, dmrecon.cc:320-329,365-398) */
     int max_attempts;             /* 4 = all attempts of an entry back to back; 1 = one, then hand over to follow_out */
     const unsigned* follow_in;    /* entry indices to continue (their state is in results[]), or null = first attempt */
     const unsigned* follow_in_n;
@@ -1361,6 +1364,10 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
             if (t > 0) break;
             const DevHyp h = a.hyp[e];
             hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = h.views;
+        } else if (a.self) {
+            if (t > 0) break;
+            /* pop-time test confImg > seed.confidence (:371) cannot hold: the entry IS the pixel's state */
+            hd = GF(job->depth + pix); hi = GF(job->dz + 2 * pix); hj = GF(job->dz + 2 * pix + 1); hv = GU(job->views + pix);
         } else {
             const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
             int bi = -1; float bc = 0.f;
@@ -1772,6 +1779,7 @@ struct SweepArgs {
     DevEntry* work;
     unsigned* round_work;  /* [round] = size of the work list of that round (zeroed before the call) */
     int round;
+    int self;              /* 1: the pixels written last round THEMSELVES (the seeds' own queue entries, dmrecon.cc:320-329) */
 };
 
 /* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull.
@@ -1806,14 +1814,17 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
         /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
         if (x >= 2 && y >= 2 && x < W - 2 && y < H - 2) {
             const int pix = y * W + x;
-            const float own = job->conf[pix];
-            const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+            if (a.self) any = job->upd[pix] == a.round - 1;
+            else {
+                const float own = job->conf[pix];
+                const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (job->upd[nb[k]] == a.round - 1) {
-                    const float c = job->conf[nb[k]];
-                    if (own < c - 0.05f || own == 0.f) any = true;
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (job->upd[nb[k]] == a.round - 1) {
+                        const float c = job->conf[nb[k]];
+                        if (own < c - 0.05f || own == 0.f) any = true;
+                    }
+            }
         }
         const unsigned long long m = __ballot(any);
         before[t] = wave_total + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
@@ -1995,9 +2006,10 @@ void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks,
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows) {
+                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows, bool self) {
     if (grid_blocks == 0) return;
     OptArgs a;
+    a.self = self ? 1 : 0;
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
     a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
@@ -2022,9 +2034,9 @@ void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views
 }
 
 void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
-                        unsigned* round_work, int round) {
+                        unsigned* round_work, int round, bool self) {
     SweepArgs a;
-    a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round;
+    a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round; a.self = self ? 1 : 0;
     hipLaunchKernelGGL(k_generate, dim3(max_tiles, n_jobs), dim3(256), 0, s, a);
 }
 
@@ -2045,6 +2057,7 @@ void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, con
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
+    t.o.self = 0;
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
     if (speculative) {

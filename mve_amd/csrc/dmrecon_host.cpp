@@ -1084,8 +1084,11 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         /* ---- phase A */
         bool to_tail = false;
         for (; round < max_rounds && !done && n_alive > 0; ++round) {
+            /* round 1: the seeds' own queue entries -- a seed is re-optimised from its converged result and propagates
+             * (from round 2 on) only if that strictly raised its confidence (dmrecon.cc:320-329,365-398) */
+            const bool self = round == 1;
             ev_begin(1);
-            mi_launch_generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round);
+            mi_launch_generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round, self);
             ev_end();
             TailPoll& P = c->h_poll[0];
             HIP_TRY(hipMemcpyAsync(&P.rw[0], c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
@@ -1102,12 +1105,12 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             if (tail)
                 mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                    nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters,
-                                   nullptr, nullptr, nullptr, nullptr, WIN_TAIL);
-            else if (!USE_FOLLOW || BULK_LPV == 16)
+                                   nullptr, nullptr, nullptr, nullptr, WIN_TAIL, self);
+            else if (!USE_FOLLOW || BULK_LPV == 16 || self)
                 mi_launch_optimize(c->stream, BULK_LPV, BULK_LPV == 16 ? std::min(n_work, 16384u) : (n_work + BULK_PPW - 1) / BULK_PPW,
                                    c->d_jobs.p, c->sc->d_views.p,
                                    c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
-                                   c->d_counters, nullptr, nullptr, nullptr, nullptr, BULK_LPV == 16 ? WIN_TAIL : WIN_BULK);
+                                   c->d_counters, nullptr, nullptr, nullptr, nullptr, BULK_LPV == 16 ? WIN_TAIL : WIN_BULK, self);
             else {
                 /* throughput layout: one optimisation attempt per entry and launch; the entries whose pixel has further
                  * candidate hypotheses (about one in five) continue in a follow-up launch over a compacted list (its

@@ -1,6 +1,12 @@
 /* mvs::DMRecon -- same public surface as libs/dmrecon/dmrecon.h:40-68 (constructor, getRefViewNr,
  * getProgress x2, start); the private part talks to libmi_dmrecon.so instead of owning the
- * reference's priority queue. */
+ * reference's priority queue.
+ *
+ * Interface attribution: the names, field order and default values mirrored here are those of MVE's
+ * libs/dmrecon public headers, Copyright (C) 2015 Simon Fuhrmann, Ronny Klowsky, TU Darmstadt, distributed under
+ * the BSD 3-Clause license (LICENSE.txt of simonfuhrmann/mve).  Only the declarations a caller compiles against
+ * are mirrored; the implementation behind them is this repository's.
+ */
 #ifndef MI_DMRECON_SHIM_DMRECON_H
 #define MI_DMRECON_SHIM_DMRECON_H
 

@@ -1,5 +1,11 @@
 /* mvs::Settings -- field-for-field the public struct of libs/dmrecon/settings.h:22-52 (same names,
- * types and defaults: callers assign these fields directly, apps/dmrecon/dmrecon.cc:166-222). */
+ * types and defaults: callers assign these fields directly, apps/dmrecon/dmrecon.cc:166-222).
+ *
+ * Interface attribution: the names, field order and default values mirrored here are those of MVE's
+ * libs/dmrecon public headers, Copyright (C) 2015 Simon Fuhrmann, Ronny Klowsky, TU Darmstadt, distributed under
+ * the BSD 3-Clause license (LICENSE.txt of simonfuhrmann/mve).  Only the declarations a caller compiles against
+ * are mirrored; the implementation behind them is this repository's.
+ */
 #ifndef MI_DMRECON_SHIM_SETTINGS_H
 #define MI_DMRECON_SHIM_SETTINGS_H
 
