@@ -51,7 +51,8 @@ typedef struct mi_dmrecon_camera {
 /* POD mirror of the algorithmic fields of mvs::Settings (libs/dmrecon/settings.h:22-52).
  * refViewNr is passed per call; imageEmbedding / ply / keep* flags stay in the host shim. */
 typedef struct mi_dmrecon_settings {
-    int32_t filterWidth;        /* 5 (the only width the reference's hard-coded centre sample 12 is right for) */
+    int32_t filterWidth;        /* 3, 5 or 7 (apps/dmrecon --filter-width; default 5, the only width for which the
+                                 * reference's hard-coded derivative sample 12 is the centre, patch_sampler.cc:96) */
     float   minNCC;             /* 0.3 */
     float   minParallax;        /* 10 */
     float   acceptNCC;          /* 0.6 */
@@ -191,7 +192,7 @@ int  mi_dmrecon_patch_optimize(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* s
 
 /* Patch-level evaluation hook (PatchSampler::getFastNCC + fastColAndDeriv, patch_sampler.cc:64-163)
  * of ONE hypothesis against every global view g (order of mi_dmrecon_global_view_selection):
- * master[5] = ok, masterMeanCol, normal; ncc[g]; ok[g]; level[g]; col/deriv [g][25][3]. */
+ * master[5] = ok, masterMeanCol, normal; ncc[g]; ok[g]; level[g]; col/deriv [g][filterWidth^2][3]. */
 int  mi_dmrecon_patch_eval(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t ref_view,
                            int32_t x, int32_t y, float depth, float dzI, float dzJ,
                            float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);

@@ -392,8 +392,9 @@ class Context:
         master = np.zeros(5, np.float32)
         ncc = np.zeros(g, np.float32)
         ok = np.zeros(g, np.int32)
-        col = np.zeros((g, 25, 3), np.float32)
-        der = np.zeros((g, 25, 3), np.float32)
+        ns = int(st.filterWidth) ** 2
+        col = np.zeros((g, ns, 3), np.float32)
+        der = np.zeros((g, ns, 3), np.float32)
         lvl = np.zeros(g, np.int32)
         cs = st.to_c()
         n = self._L.mi_dmrecon_patch_eval(self._h, ctypes.byref(cs), ref_view, x, y, depth, dzi, dzj,

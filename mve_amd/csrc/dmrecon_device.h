@@ -5,35 +5,47 @@
 #include <hip/hip_runtime.h>
 #include "dmrecon_types.h"
 
-/* lanes_per_view: 1 = 16 patches per wavefront (throughput), 16 = one patch per wavefront (latency).
- * The launch only acts if min_work <= n < max_work, n = *n_work_ptr (if given) or n_work.
- * follow_out != null: one optimisation attempt per entry; entries with further candidate hypotheses are appended to
- * follow_out (count *follow_out_n).  follow_in != null: continue the entries work[follow_in[0 .. *follow_in_n)]. */
-void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
-                        const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
-                        DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
-                        unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in = nullptr,
-                        const unsigned* follow_in_n = nullptr, unsigned* follow_out = nullptr, unsigned* follow_out_n = nullptr,
-                        bool windows = false, bool self = false);
+/*
+ * The kernels that depend on the filter width (mvs::Settings::filterWidth: 3, 5 or 7 -> 9 / 25 / 49 samples per
+ * patch) are compiled once per width (dmrecon_device.hip with -DMI_FW=...); mi_device_api() returns the launchers
+ * of a width, or null.
+ *
+ * optimize -- lanes_per_view: 1 = 16 patches per wavefront (throughput), 16 = one patch per wavefront (latency).
+ *   The launch only acts if min_work <= n < max_work, n = *n_work_ptr (if given) or n_work.
+ *   follow_out != null: one optimisation attempt per entry; entries with further candidate hypotheses are appended to
+ *   follow_out (count *follow_out_n).  follow_in != null: continue the entries work[follow_in[0 .. *follow_in_n)].
+ *   windows: sample the neighbour views through LDS texel windows; self: an entry's candidate is its own pixel's state.
+ * generate -- k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile
+ *   count; self: the work list = the pixels written in round - 1 themselves (the seeds' own queue entries).
+ * tail -- one fused tail round: candidates from (prev_work, prev_results, round_work[round - 1]) -> this round's list,
+ *   results and pixel-state writes (second state slot, see DevJob).  speculative: workgroups of four wavefronts, a
+ *   pixel's candidate hypotheses tried at the same time; else one wavefront per pixel tries them in turn.
+ */
+struct MiDeviceApi {
+    int filter_width;
+    void (*optimize)(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
+                     const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
+                     DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
+                     unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
+                     const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows, bool self);
+    void (*patch_eval)(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
+                       const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
+                       float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
+    void (*generate)(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
+                     unsigned* round_work, int round, bool self);
+    void (*tail)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
+                 const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
+                 DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows,
+                 bool speculative);
+};
+const MiDeviceApi* mi_device_api(int filter_width);
 extern unsigned long long* mi_debug_tbuf;
-void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
-                          const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
-                          float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
-/* k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile count */
+
+/* ---- kernels that do not depend on the filter width (defined once, in the width-5 object) ---- */
 #define MI_GEN_TILE_W 64
 #define MI_GEN_TILE_H 32
-/* self: the work list = the pixels written in round - 1 themselves (the seeds' own queue entries), not their neighbours */
-void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
-                        unsigned* round_work, int round, bool self = false);
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                      const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
-/* one fused tail round: candidates from (prev_work, prev_results, round_work[round - 1]) -> this round's list,
- * results and pixel-state writes (second state slot, see DevJob).  speculative: workgroups of four wavefronts, a
- * pixel's candidate hypotheses tried at the same time; else one wavefront per pixel tries them in turn */
-void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
-                    const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
-                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows,
-                    bool speculative);
 /* maps: [slot 0: depth | conf | dz x2 | normal x3][slot 1: same], imaps: [views | upd][views1 | upd1], per batch */
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px);
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,

@@ -42,6 +42,28 @@
 #define QUAD 4
 #define WAVE 64
 
+/* This file is compiled once per supported filter width (mvs::Settings::filterWidth, apps/dmrecon --filter-width):
+ * -DMI_FW=3 / 5 / 7.  Everything that depends on it lives in a namespace of its own; the host picks the table of
+ * launchers (MiDeviceApi, dmrecon_device.h) that belongs to the call's settings. */
+#ifndef MI_FW
+#define MI_FW 5
+#endif
+#define MI_HALF (MI_FW / 2)             /* PatchSampler::offset */
+#define MI_NS (MI_FW * MI_FW)           /* PatchSampler::nrSamples */
+#define MI_MID (MI_NS / 2)              /* the centre sample, patchPoints[nrSamples / 2] */
+/* Q3: fastColAndDeriv measures its derivative step at patchPoints[12] whatever the filter width (patch_sampler.cc:96);
+ * that is the centre only for width 5.  Width 7: sample 12 = row 1, column 5, kept.  Width 3 has no sample 12 -- the
+ * reference reads past the end of the vector there (undefined behaviour); the centre is used instead. */
+#define MI_STEP_SAMPLE (MI_NS > 12 ? 12 : MI_MID)
+#define MI_CAT2(a, b) a##b
+#define MI_CAT(a, b) MI_CAT2(a, b)
+#define MI_FWNS MI_CAT(mi_fw, MI_FW)
+/* wavefronts per SIMD the bulk kernels aim for: width 7 needs 18.8 KB of rays / master colours per wavefront in LDS,
+ * which caps the occupancy anyway -- let the compiler use the registers */
+#define MI_BULK_WAVES (MI_FW == 7 ? 1 : MI_WAVES_PER_SIMD)
+
+namespace MI_FWNS {
+
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 u32x2_a4 __attribute__((aligned(4)));      /* gfx950 global loads only need dword alignment */
 /* Pointers that are themselves loaded from memory (DevView::img, DevJob maps) have no provable address
@@ -411,10 +433,17 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     float step = 0.f, dnorm = 0.f;
     bool ok = true;
     if (MODE != PASS_COLOR) {
-        /* derivative step size from the centre sample (patch_sampler.cc:93-100; sample 12 hard-coded there) */
-        float rx = rays[36], ry = rays[37], rz = rays[38];
+        /* derivative step size (patch_sampler.cc:93-100): the centre point advanced by its unit ray against
+         * patchPoints[12] -- hard-coded there; the centre itself only for filter width 5 (MI_STEP_SAMPLE) */
+        float rx = rays[3 * MI_MID], ry = rays[3 * MI_MID + 1], rz = rays[3 * MI_MID + 2];
         float u0, v0, u1, v1;
-        project(nv, ps.p0x, ps.p0y, ps.p0z, u0, v0);
+        if (MI_STEP_SAMPLE == MI_MID)
+            project(nv, ps.p0x, ps.p0y, ps.p0z, u0, v0);
+        else {
+            constexpr int sj = MI_STEP_SAMPLE / MI_FW - MI_HALF, si = MI_STEP_SAMPLE - (MI_STEP_SAMPLE / MI_FW) * MI_FW - MI_HALF;
+            const float ts = ps.depth + (float)si * ps.dzI + (float)sj * ps.dzJ;
+            project(nv, cpx + ts * rays[3 * MI_STEP_SAMPLE], cpy + ts * rays[3 * MI_STEP_SAMPLE + 1], cpz + ts * rays[3 * MI_STEP_SAMPLE + 2], u0, v0);
+        }
         project(nv, ps.p0x + rx, ps.p0y + ry, ps.p0z + rz, u1, v1);
         float du = u1 - u0, dv = v1 - v0;
         dnorm = fast_sqrt(du * du + dv * dv);          /* deriv /= stepSize  ==  deriv * dnorm */
@@ -445,7 +474,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         q.live = iraw < MI_NS;                         /* LPV = 16: second trip only for lanes 0..8 */
         const int i = q.live ? iraw : (MI_NS - 1);
         q.i = i;
-        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
         const float t = depth + (float)di * ps.dzI + (float)dj * ps.dzJ;         /* computePatchPoints */
         const float px = cpx + t * rx, py = cpy + t * ry, pz = cpz + t * rz;
@@ -482,7 +511,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     auto fetch = [&](int it) -> Pre { return geom(it, ps.depth, true); };
     auto consume = [&](const Pre& q) {
         const int i = q.i;
-        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const float fx = q.fx, fy = q.fy, gu = q.gu, gv = q.gv;
         const uint32_t t00 = q.t.x, t10 = q.t.y, t01 = q.t.z, t11 = q.t.w;
         float n[3], dr[3];
@@ -538,30 +567,30 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     if (WIN && LPV != 16) {
         /* texels in LDS: nothing to prefetch by hand, the compiler interleaves the reads of a row's samples */
 #pragma unroll 1
-        for (int row = 0; row < NITER; row += 5) {
+        for (int row = 0; row < NITER; row += MI_FW) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) if (row + k < NITER) { Pre q = geom(row + k, ps.depth, true); consume(q); }
+            for (int k = 0; k < MI_FW; ++k) if (row + k < NITER) { Pre q = geom(row + k, ps.depth, true); consume(q); }
         }
     } else if (LPV == 1) {
-        /* a row of the 5 x 5 window per gather round: its five footprint records are neighbours in memory (1-2
+        /* a row of the window per gather round (5 x 5: its five footprint records are neighbours in memory, 1-2
          * cache lines fetched once, five gathers in flight); only the texels stay in registers, the geometry of a
          * sample is computed again when it is consumed (the opaque copy of the depth keeps the compiler from
          * holding it across the gathers instead) */
 #pragma unroll 1
-        for (int row = 0; row < 5; ++row) {
-            u32x4 tx[5];
+        for (int row = 0; row < MI_FW; ++row) {
+            u32x4 tx[MI_FW];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) tx[k] = geom(row * 5 + k, ps.depth, true).t;
+            for (int k = 0; k < MI_FW; ++k) tx[k] = geom(row * MI_FW + k, ps.depth, true).t;
             float depth2 = ps.depth;
             asm volatile("" : "+v"(depth2));
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                Pre q = geom(row * 5 + k, depth2, false); q.t = tx[k]; consume(q);
+            for (int k = 0; k < MI_FW; ++k) {
+                Pre q = geom(row * MI_FW + k, depth2, false); q.t = tx[k]; consume(q);
 #ifdef MI_EXPERIMENT_EXTRA_GEOM
                 /* sensitivity probe: one more (useless) geometry evaluation per sample = +45 VALU instructions, +3 LDS reads */
                 float depth3 = ps.depth;
                 asm volatile("" : "+v"(depth3));
-                Pre q3 = geom(row * 5 + k, depth3, false);
+                Pre q3 = geom(row * MI_FW + k, depth3, false);
                 asm volatile("" :: "v"(q3.fx), "v"(q3.fy), "v"(q3.gu), "v"(q3.gv));
 #endif
             }
@@ -638,11 +667,11 @@ __device__ __forceinline__ float eval_color(PatchState& ps, const DevView* views
 __device__ __forceinline__ bool set_state(PatchState& ps, const float* rays, float depth, float dzI, float dzJ) {
     ps.depth = depth; ps.dzI = dzI; ps.dzJ = dzJ;
     /* tmpDepth is linear in (i, j): its minimum over the window is at a corner */
-    const float a = 2.f * fabsf(dzI) + 2.f * fabsf(dzJ);
+    const float a = (float)MI_HALF * fabsf(dzI) + (float)MI_HALF * fabsf(dzJ);
     bool ok = (depth - a) > 0.f && depth == depth && a == a;
-    ps.p0x = ps.jcx + depth * rays[36];
-    ps.p0y = ps.jcy + depth * rays[37];
-    ps.p0z = ps.jcz + depth * rays[38];
+    ps.p0x = ps.jcx + depth * rays[3 * MI_MID];
+    ps.p0y = ps.jcy + depth * rays[3 * MI_MID + 1];
+    ps.p0z = ps.jcz + depth * rays[3 * MI_MID + 2];
     const float z = ps.jz0 * ps.p0x + ps.jz1 * ps.p0y + ps.jz2 * ps.p0z + ps.jz3;
     ps.mfp = z * ps.jinv0;                            /* footPrintScaled */
     return ok;
@@ -863,8 +892,8 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
     bool inside_image = true;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int i = (c & 1 ? 4 : 0) + (c & 2 ? 20 : 0);
-        const int di = (c & 1) ? 2 : -2, dj = (c & 2) ? 2 : -2;
+        const int i = (c & 1 ? MI_FW - 1 : 0) + (c & 2 ? MI_NS - MI_FW : 0);
+        const int di = (c & 1) ? MI_HALF : -MI_HALF, dj = (c & 2) ? MI_HALF : -MI_HALF;
         const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
         const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;
         float u, v;
@@ -955,7 +984,7 @@ struct Run {
 template <int LPV>
 __device__ __forceinline__ void fill_rays(const DevJob* job, int x, int y, float* rays, int pl) {
     for (int i = pl; i < MI_NS; i += 4 * LPV) {
-        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const float fx = (float)(x + di) + 0.5f, fy = (float)(y + dj) + 0.5f;
         float rx = job->inv_a * fx + job->inv_c, ry = job->inv_b * fy + job->inv_d, rz = 1.f;
         const float inrm = fast_rsqrt(rx * rx + ry * ry + rz * rz);
@@ -991,7 +1020,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     R.opti = true; R.converged = false; R.viewRemoved = false; R.step_was_normal = false;
     R.iter = 0; R.need = PASS_DEPTH; R.ctx = CTX_CTOR; R.oldncc = -1.f; R.need_vs = false; R.count_color = false;
     /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
-    if (x - 2 < 0 || y - 2 < 0 || x + 2 > job->w - 1 || y + 2 > job->h - 1) return false;
+    if (x - MI_HALF < 0 || y - MI_HALF < 0 || x + MI_HALF > job->w - 1 || y + MI_HALF > job->h - 1) return false;
     load_job_constants(ps, job);
     fill_rays<LPV>(job, x, y, rays, pl);
     /* raw master colours */
@@ -1000,7 +1029,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     const uint32_t* rimg = RV->img + RL.tex_off;
     float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;       /* LPV = 16: my sample's raw master colour */
     for (int i = pl; i < MI_NS; i += 4 * LPV) {
-        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const uint32_t t = GU(rimg + (size_t)(y + dj) * RL.w + (x + di));
         raw0 = s_lut[t & 255u]; raw1 = s_lut[(t >> 8) & 255u]; raw2 = s_lut[(t >> 16) & 255u];
         if (LPV != 16) { mcol[3 * i] = raw0; mcol[3 * i + 1] = raw1; mcol[3 * i + 2] = raw2; }
@@ -1258,14 +1287,16 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
     mean /= (float)cnt;
     const float score = (mean - st.acceptNCC) / (1.f - st.acceptNCC);
     /* getPatchNormal (patch_sampler.cc:242-256): samples 14,10 (right,left) and 2,22 (top,bottom) */
-    const float tr = ps.depth + 2.f * ps.dzI, tl = ps.depth - 2.f * ps.dzI;
-    const float tt = ps.depth - 2.f * ps.dzJ, tb = ps.depth + 2.f * ps.dzJ;
-    const float ax = tr * rays[42] - tl * rays[30], ay = tr * rays[43] - tl * rays[31], az = tr * rays[44] - tl * rays[32];
-    const float bx = tt * rays[6] - tb * rays[66], by = tt * rays[7] - tb * rays[67], bz = tt * rays[8] - tb * rays[68];
+    /* right / left = the centre row's ends, top / bottom = the centre column's ends */
+    constexpr int iR = 3 * (MI_MID + MI_HALF), iL = 3 * (MI_MID - MI_HALF), iT = 3 * MI_HALF, iB = 3 * (MI_NS - 1 - MI_HALF);
+    const float tr = ps.depth + (float)MI_HALF * ps.dzI, tl = ps.depth - (float)MI_HALF * ps.dzI;
+    const float tt = ps.depth - (float)MI_HALF * ps.dzJ, tb = ps.depth + (float)MI_HALF * ps.dzJ;
+    const float ax = tr * rays[iR] - tl * rays[iL], ay = tr * rays[iR + 1] - tl * rays[iL + 1], az = tr * rays[iR + 2] - tl * rays[iL + 2];
+    const float bx = tt * rays[iT] - tb * rays[iB], by = tt * rays[iT + 1] - tb * rays[iB + 1], bz = tt * rays[iT + 2] - tb * rays[iB + 2];
     float nx, ny, nz;
     unit_cross(ax, ay, az, bx, by, bz, nx, ny, nz);
     res.nx = nx; res.ny = ny; res.nz = nz;
-    const float dotP = -(nx * rays[36] + ny * rays[37] + nz * rays[38]);   /* viewRayScaled(midx, midy) = ray 12 */
+    const float dotP = -(nx * rays[3 * MI_MID] + ny * rays[3 * MI_MID + 1] + nz * rays[3 * MI_MID + 2]);   /* viewRayScaled(midx, midy) */
     res.conf = (dotP < 0.2f) ? 0.f : score;
     TSTAMP(41);
 }
@@ -1443,7 +1474,7 @@ __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, 
  * the LDS footprint then: 25.6 KB of windows per wavefront in the throughput layout).
  */
 template <int LPV, bool WIN>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && LPV == 1) ? 1 : (LPV == 16 ? 2 : MI_WAVES_PER_SIMD)), ((WIN && LPV == 1) ? 2 : (LPV == 16 ? 2 : MI_WAVES_PER_SIMD))))) void k_optimize(OptArgs a) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && LPV == 1) ? 1 : (LPV == 16 ? 2 : MI_BULK_WAVES)), ((WIN && LPV == 1) ? 2 : (LPV == 16 ? 2 : MI_WAVES_PER_SIMD))))) void k_optimize(OptArgs a) {
     typedef Lay<LPV> L;
     const int lane = threadIdx.x;
 #ifdef MI_TIMING
@@ -1527,7 +1558,7 @@ struct TailRes { PatchResult r; unsigned n_eval, n_pass; };
 __shared__ TailRes g_tail_res[MI_TAIL_WAVES];
 
 template <bool WIN, bool SPEC>
-__global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((amdgpu_waves_per_eu((SPEC ? 2 : MI_WAVES_PER_SIMD), (SPEC ? 2 : MI_WAVES_PER_SIMD)))) void k_tail(TailArgs t) {
+__global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((amdgpu_waves_per_eu((SPEC ? 2 : (MI_FW == 7 ? 2 : MI_WAVES_PER_SIMD)), (SPEC ? 2 : MI_WAVES_PER_SIMD)))) void k_tail(TailArgs t) {
     const OptArgs& a = t.o;
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const unsigned n_prev = t.round_work[a.round - 1];
@@ -1547,7 +1578,7 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
         if (GI(&job->flags) != 0) continue;                                    /* failed / cancelled view */
         const int W = job->w, H = job->h;
         const int qx = (src.xy & 0xFFFF) + (k == 0 ? -1 : k == 1 ? 1 : 0), qy = (src.xy >> 16) + (k == 2 ? -1 : k == 3 ? 1 : 0);
-        if (qx < 2 || qy < 2 || qx >= W - 2 || qy >= H - 2) continue;         /* patch_sampler.cc:47-50 */
+        if (qx < MI_HALF || qy < MI_HALF || qx >= W - MI_HALF || qy >= H - MI_HALF) continue;   /* patch_sampler.cc:47-50 */
         const int q = qy * W + qx;
         /* frozen state of q and of its four neighbours, all loads in flight together */
         const int nb[4] = {q - 1, q + 1, q - W, q + W};
@@ -1711,12 +1742,12 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     ps.jz0 = job->w2c_z[0]; ps.jz1 = job->w2c_z[1]; ps.jz2 = job->w2c_z[2]; ps.jz3 = job->w2c_z[3];
     ps.jinv0 = job->inv0_s;
     if (lane == 0) for (int k = 0; k < 5; ++k) a.master[k] = 0.f;
-    if (a.x - 2 < 0 || a.y - 2 < 0 || a.x + 2 > job->w - 1 || a.y + 2 > job->h - 1) return;
+    if (a.x - MI_HALF < 0 || a.y - MI_HALF < 0 || a.x + MI_HALF > job->w - 1 || a.y + MI_HALF > job->h - 1) return;
     const DevView* RV = a.views + job->ref_view;
     const DevLevel& RL = RV->lv[job->scale];
     const uint32_t* rimg = RV->img + RL.tex_off;
     for (int i = lane; i < MI_NS; i += WAVE) {
-        const int dj = i / 5 - 2, di = i - (i / 5) * 5 - 2;
+        const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const float fx = (float)(a.x + di) + 0.5f, fy = (float)(a.y + dj) + 0.5f;
         float rx = job->inv_a * fx + job->inv_c, ry = job->inv_b * fy + job->inv_d, rz = 1.f;
         const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
@@ -1748,11 +1779,12 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     if (!set_state(ps, s_rays, a.depth, a.dzI, a.dzJ)) return;
     if (lane == 0) {
         a.master[0] = 1.f; a.master[1] = mm;
-        const float tr = ps.depth + 2.f * ps.dzI, tl = ps.depth - 2.f * ps.dzI;
-        const float tt = ps.depth - 2.f * ps.dzJ, tb = ps.depth + 2.f * ps.dzJ;
+        constexpr int iR = 3 * (MI_MID + MI_HALF), iL = 3 * (MI_MID - MI_HALF), iT = 3 * MI_HALF, iB = 3 * (MI_NS - 1 - MI_HALF);
+        const float tr = ps.depth + (float)MI_HALF * ps.dzI, tl = ps.depth - (float)MI_HALF * ps.dzI;
+        const float tt = ps.depth - (float)MI_HALF * ps.dzJ, tb = ps.depth + (float)MI_HALF * ps.dzJ;
         const float* rays = s_rays;
-        const float ax = tr * rays[42] - tl * rays[30], ay = tr * rays[43] - tl * rays[31], az = tr * rays[44] - tl * rays[32];
-        const float bx = tt * rays[6] - tb * rays[66], by = tt * rays[7] - tb * rays[67], bz = tt * rays[8] - tb * rays[68];
+        const float ax = tr * rays[iR] - tl * rays[iL], ay = tr * rays[iR + 1] - tl * rays[iL + 1], az = tr * rays[iR + 2] - tl * rays[iL + 2];
+        const float bx = tt * rays[iT] - tb * rays[iB], by = tt * rays[iT + 1] - tb * rays[iB + 1], bz = tt * rays[iT + 2] - tb * rays[iB + 2];
         float nx, ny, nz;
         unit_cross(ax, ay, az, bx, by, bz, nx, ny, nz);
         a.master[2] = nx; a.master[3] = ny; a.master[4] = nz;
@@ -1812,7 +1844,7 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
         const int x = tx0 + t * 8 + lx, y = ty0 + wave * 8 + ly;
         bool any = false;
         /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
-        if (x >= 2 && y >= 2 && x < W - 2 && y < H - 2) {
+        if (x >= MI_HALF && y >= MI_HALF && x < W - MI_HALF && y < H - MI_HALF) {
             const int pix = y * W + x;
             if (a.self) any = job->upd[pix] == a.round - 1;
             else {
@@ -1997,12 +2029,29 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint32_t* __restrict__ sr
     dst[(size_t)y * ow + x] = (b0 & 255u) | ((b1 & 255u) << 8) | ((b2 & 255u) << 16) | 0xFF000000u;
 }
 
+/* RGBA8 level -> 16-byte footprint records (DevView::quad): one lane per texel, neighbours edge-clamped. */
+__global__ __launch_bounds__(256) void k_quadify(const uint32_t* __restrict__ src, u32x4* __restrict__ dst, int w, int h) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    const int x1 = x + 1 < w ? x + 1 : x, y1 = y + 1 < h ? y + 1 : y;
+    u32x4 o;
+    o.x = src[y * w + x]; o.y = src[y * w + x1]; o.z = src[y1 * w + x]; o.w = src[y1 * w + x1];
+    dst[i] = o;
+}
+
+
+}  /* namespace MI_FWNS */
+using namespace MI_FWNS;
+
 /* ------------------------------------------------------------------------- */
 /* Host-callable launchers (declared in dmrecon_device.h).                     */
 
+#if MI_FW == 5
 unsigned long long* mi_debug_tbuf = nullptr;   /* set by MI_TIMING probes */
+#endif
 
-void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
+static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
@@ -2024,7 +2073,7 @@ void mi_launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks,
     }
 }
 
-void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
+static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                           const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
                           float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level) {
     EvalArgs a;
@@ -2033,13 +2082,14 @@ void mi_launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views
     hipLaunchKernelGGL(k_patch_eval, dim3(1), dim3(WAVE), 0, s, a);
 }
 
-void mi_launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
+static void launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
                         unsigned* round_work, int round, bool self) {
     SweepArgs a;
     a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round; a.self = self ? 1 : 0;
     hipLaunchKernelGGL(k_generate, dim3(max_tiles, n_jobs), dim3(256), 0, s, a);
 }
 
+#if MI_FW == 5
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                      const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters) {
     if (grid_blocks == 0) return;
@@ -2049,7 +2099,9 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
     hipLaunchKernelGGL(k_apply, dim3(grid_blocks), dim3(256), 0, s, a);
 }
 
-void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
+#endif
+
+static void launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                     const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
                     DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows,
                     bool speculative) {
@@ -2069,6 +2121,7 @@ void mi_launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, con
     }
 }
 
+#if MI_FW == 5
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px) {
     if (total_px == 0) return;
     FlattenArgs a;
@@ -2094,17 +2147,6 @@ void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* wo
     hipLaunchKernelGGL(k_apply_seeds, dim3((n_work + 255) / 256), dim3(256), 0, s, a);
 }
 
-/* RGBA8 level -> 16-byte footprint records (DevView::quad): one lane per texel, neighbours edge-clamped. */
-__global__ __launch_bounds__(256) void k_quadify(const uint32_t* __restrict__ src, u32x4* __restrict__ dst, int w, int h) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= w * h) return;
-    const int y = i / w, x = i - y * w;
-    const int x1 = x + 1 < w ? x + 1 : x, y1 = y + 1 < h ? y + 1 : y;
-    u32x4 o;
-    o.x = src[y * w + x]; o.y = src[y * w + x1]; o.z = src[y1 * w + x]; o.w = src[y1 * w + x1];
-    dst[i] = o;
-}
-
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h) {
     hipLaunchKernelGGL(k_quadify, dim3((w * h + 255) / 256), dim3(256), 0, s, src, (u32x4*)dst, w, h);
 }
@@ -2119,3 +2161,9 @@ void mi_launch_pyramid(hipStream_t s, const uint32_t* src, uint32_t* dst, int iw
                        float w1, float w2, float w3) {
     hipLaunchKernelGGL(k_pyramid, dim3((ow + 63) / 64, (oh + 3) / 4), dim3(256), 0, s, src, dst, iw, ih, ow, oh, w1, w2, w3);
 }
+#endif
+
+/* the launchers of this filter width (dmrecon_device.h: mi_device_api); host side only */
+#if !defined(__HIP_DEVICE_COMPILE__)
+extern const MiDeviceApi MI_CAT(mi_device_api_fw, MI_FW) = {MI_FW, launch_optimize, launch_patch_eval, launch_generate, launch_tail};
+#endif

@@ -246,10 +246,25 @@ int sync_views(mi_dmrecon_ctx* c) {
     return 0;
 }
 
+}  // namespace
+
+/* the launchers of the kernels compiled for a filter width (dmrecon_device.hip, one object per width) */
+extern const MiDeviceApi mi_device_api_fw3, mi_device_api_fw5, mi_device_api_fw7;
+const MiDeviceApi* mi_device_api(int filter_width) {
+    switch (filter_width) {
+        case 3: return &mi_device_api_fw3;
+        case 5: return &mi_device_api_fw5;
+        case 7: return &mi_device_api_fw7;
+        default: return nullptr;
+    }
+}
+
+namespace {
+
 int check_settings(const mi_dmrecon_settings* st) {
     if (!st) return fail(MI_DMRECON_EINVAL, "null settings");
     if (st->scale < 0) return fail(MI_DMRECON_EINVAL, "Invalid scale factor");            /* dmrecon.cc:41-42 */
-    if (st->filterWidth != 5) return fail(MI_DMRECON_EINVAL, "filterWidth %d unsupported (only 5)", st->filterWidth);
+    if (!mi_device_api(st->filterWidth)) return fail(MI_DMRECON_EINVAL, "filterWidth %d unsupported (3, 5 or 7)", st->filterWidth);
     if (st->nrReconNeighbors < 1 || st->nrReconNeighbors > MI_DMRECON_MAX_LOCAL_VIEWS)
         return fail(MI_DMRECON_EINVAL, "nrReconNeighbors must be in 1..%d", MI_DMRECON_MAX_LOCAL_VIEWS);
     if (st->globalVSMax < 1 || st->globalVSMax > MI_DMRECON_MAX_GLOBAL_VIEWS)
@@ -886,6 +901,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     if (!c || !ref_views || !maps || n_refs <= 0) return fail(MI_DMRECON_EINVAL, "null argument");
     int rc = check_settings(st);
     if (rc) return rc;
+    const MiDeviceApi& D = *mi_device_api(st->filterWidth);
     HIP_TRY(hipSetDevice(c->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
     /* outcome per reference view (status_out): a view whose planning fails, whose footprint turns non-positive or
@@ -993,9 +1009,10 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         HIP_TRY(hipMemcpyAsync(c->d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), c->stream));
         ev_begin(0); ev_work.push_back((unsigned)seeds.size()); ev_tail.push_back(0);
-        mi_launch_optimize(c->stream, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
+        D.optimize(c->stream, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
                            c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
-                           nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0, c->d_counters);
+                           nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0, c->d_counters,
+                           nullptr, nullptr, nullptr, nullptr, false, false);
         ev_end();
         ++n_launch;
         ev_begin(1);
@@ -1084,11 +1101,15 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         /* ---- phase A */
         bool to_tail = false;
         for (; round < max_rounds && !done && n_alive > 0; ++round) {
-            /* round 1: the seeds' own queue entries -- a seed is re-optimised from its converged result and propagates
-             * (from round 2 on) only if that strictly raised its confidence (dmrecon.cc:320-329,365-398) */
-            const bool self = round == 1;
+            /* MI_DMRECON_SEED_REOPT=1: round 1 = the seeds' own queue entries -- the reference pushes a seed's OWN pixel,
+             * re-optimises it from its converged result when popped and lets it propagate only if that strictly raised
+             * its confidence (dmrecon.cc:320-329,365-398).  Default off: every seed propagates at once.  Measured on C3
+             * (DESIGN.md section 2): no parity gain (fill IoU / depth p99 against the reference unchanged), one more
+             * bulk round per call and sparser early fronts: +8 % bulk kernel time. */
+            static const bool SEED_REOPT = [] { const char* e = std::getenv("MI_DMRECON_SEED_REOPT"); return e && std::atoi(e) != 0; }();
+            const bool self = SEED_REOPT && round == 1;
             ev_begin(1);
-            mi_launch_generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round, self);
+            D.generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round, self);
             ev_end();
             TailPoll& P = c->h_poll[0];
             HIP_TRY(hipMemcpyAsync(&P.rw[0], c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
@@ -1103,11 +1124,11 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             const bool tail = n_work < TAIL_THRESHOLD;
             ev_begin(0); ev_work.push_back(n_work); ev_tail.push_back(0);
             if (tail)
-                mi_launch_optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+                D.optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                    nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters,
                                    nullptr, nullptr, nullptr, nullptr, WIN_TAIL, self);
             else if (!USE_FOLLOW || BULK_LPV == 16 || self)
-                mi_launch_optimize(c->stream, BULK_LPV, BULK_LPV == 16 ? std::min(n_work, 16384u) : (n_work + BULK_PPW - 1) / BULK_PPW,
+                D.optimize(c->stream, BULK_LPV, BULK_LPV == 16 ? std::min(n_work, 16384u) : (n_work + BULK_PPW - 1) / BULK_PPW,
                                    c->d_jobs.p, c->sc->d_views.p,
                                    c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
                                    c->d_counters, nullptr, nullptr, nullptr, nullptr, BULK_LPV == 16 ? WIN_TAIL : WIN_BULK, self);
@@ -1118,12 +1139,12 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                 const unsigned waves = (n_work + BULK_PPW - 1) / BULK_PPW;
                 unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
                 unsigned* fa = c->d_follow.p;
-                mi_launch_optimize(c->stream, BULK_LPV, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
-                                   c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt, WIN_BULK);
+                D.optimize(c->stream, BULK_LPV, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+                                   c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt, WIN_BULK, false);
                 /* the follow-up launch runs all remaining attempts of its entries back to back (third and fourth
                  * attempts are rare: a third launch would cost more in latency than it saves) */
-                mi_launch_optimize(c->stream, BULK_LPV, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
-                                   nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr, WIN_BULK);
+                D.optimize(c->stream, BULK_LPV, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+                                   nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr, WIN_BULK, false);
                 ++n_launch;
             }
             ev_end();
@@ -1157,7 +1178,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
                 const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
                 if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
-                mi_launch_tail(c->stream, tail_grid(), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
+                D.tail(c->stream, tail_grid(), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
                                c->d_round_work.p, round, c->d_counters, WIN_TAIL, tail_known <= SPEC_MAX);
                 if (timed) ev_end();
                 std::swap(wcur, wnext);
@@ -1294,6 +1315,7 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     if (!c || !xy || !hyp || !out || !out_local || n < 0) return fail(MI_DMRECON_EINVAL, "null argument");
     int rc = check_settings(st);
     if (rc) return rc;
+    const MiDeviceApi& D = *mi_device_api(st->filterWidth);
     HIP_TRY(hipSetDevice(c->device));
     JobHost jh; jh.ref_view = ref_view;
     rc = plan_global_views(c, st, ref_view, jh.global);
@@ -1342,10 +1364,10 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     const char* win_env = std::getenv("MI_DMRECON_WIN");
     const int win_bits = win_env ? std::atoi(win_env) : MI_WIN_DEFAULT;
     const bool windows = (win_bits & (lpv == 16 ? 1 : 2)) != 0;
-    mi_launch_optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw,
+    D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw,
                        c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
                        c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
-                       nullptr, nullptr, nullptr, nullptr, windows);
+                       nullptr, nullptr, nullptr, nullptr, windows, false);
     HIP_TRY(hipGetLastError());
     std::vector<DevResult> res(n);
     HIP_TRY(hipMemcpyAsync(res.data(), c->d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
@@ -1368,6 +1390,7 @@ int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int3
     if (!c || !master || !ncc || !ok || !col || !deriv || !level) return fail(MI_DMRECON_EINVAL, "null argument");
     int rc = check_settings(st);
     if (rc) return rc;
+    const MiDeviceApi& D = *mi_device_api(st->filterWidth);
     HIP_TRY(hipSetDevice(c->device));
     JobHost jh; jh.ref_view = ref_view;
     rc = plan_global_views(c, st, ref_view, jh.global);
@@ -1383,20 +1406,21 @@ int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int3
     rc = alloc_maps(c, jobs, dj, total_px);
     if (rc) return rc;
     const int G = (int)jh.global.size();
-    const size_t nfl = 5 + G + 2 * (size_t)G * 75;
+    const size_t NS3 = 3 * (size_t)st->filterWidth * st->filterWidth;       /* floats per view: fw x fw samples, 3 channels */
+    const size_t nfl = 5 + G + 2 * (size_t)G * NS3;
     DevBuf<float> dout; DevBuf<int32_t> diout;
     if (dout.reserve(nfl) || diout.reserve(2 * G) || c->d_jobs.reserve(1)) return fail(MI_DMRECON_EDEVICE, "hipMalloc failed");
     HIP_TRY(hipMemsetAsync(dout.p, 0, nfl * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(diout.p, 0, 2 * G * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
-    float* d_master = dout.p; float* d_ncc = dout.p + 5; float* d_col = d_ncc + G; float* d_der = d_col + (size_t)G * 75;
-    mi_launch_patch_eval(c->stream, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), x, y, depth, dzI, dzJ,
+    float* d_master = dout.p; float* d_ncc = dout.p + 5; float* d_col = d_ncc + G; float* d_der = d_col + (size_t)G * NS3;
+    D.patch_eval(c->stream, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), x, y, depth, dzI, dzJ,
                          d_master, d_ncc, diout.p, d_col, d_der, diout.p + G);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(master, d_master, 5 * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(ncc, d_ncc, G * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(col, d_col, (size_t)G * 75 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(deriv, d_der, (size_t)G * 75 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(col, d_col, (size_t)G * NS3 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(deriv, d_der, (size_t)G * NS3 * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(ok, diout.p, G * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(level, diout.p + G, G * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

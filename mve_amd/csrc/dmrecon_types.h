@@ -9,7 +9,7 @@
 
 #define MI_MAX_LEVELS 16
 #define MI_MAX_GLOBAL 32
-#define MI_NS 25            /* filterWidth^2 samples per patch */
+#define MI_MAX_FW 7         /* filter widths 3, 5, 7: the device code is compiled once per width (dmrecon_device.hip) */
 #define MI_PATCHES_PER_WAVE 16
 #define MI_VIEW_NONE 0xFFu
 #define MI_MAX_ROUNDS 8192      /* per-round work counters kept on the device */

@@ -160,8 +160,9 @@ class OracleScene:
         master = np.zeros(5, np.float32)
         ncc = np.zeros(g, np.float32)
         ok = np.zeros(g, np.int32)
-        col = np.zeros((g, 25, 3), np.float32)
-        der = np.zeros((g, 25, 3), np.float32)
+        ns = int(st.filterWidth) ** 2
+        col = np.zeros((g, ns, 3), np.float32)
+        der = np.zeros((g, ns, 3), np.float32)
         lvl = np.zeros(g, np.int32)
         n = lib().orc_patch_eval(self.h, ctypes.byref(st), x, y, depth, dzi, dzj, _ptr(master), _ptr(ncc), _ptr(ok),
                                  _ptr(col), _ptr(der), _ptr(lvl))
@@ -200,7 +201,7 @@ def run_reference_app(scene_dir: str, scale: int, local_neighbors: int = 4, mast
 
 
 def run_reference_patch_driver(scene_dir: str, ref_view: int, scale: int, local_neighbors: int, mode: str,
-                               seeds: Sequence[Sequence[float]]) -> List[List[str]]:
+                               seeds: Sequence[Sequence[float]], filter_width: int = 5) -> List[List[str]]:
     exe = os.path.join(REF_DIR, "ref_patch_driver")
     with tempfile.TemporaryDirectory() as td:
         sp, op = os.path.join(td, "seeds.txt"), os.path.join(td, "out.txt")
@@ -210,6 +211,6 @@ def run_reference_patch_driver(scene_dir: str, ref_view: int, scale: int, local_
                 loc = [int(v) for v in s[5:] if int(v) >= 0]
                 f.write("%d %d %.9g %.9g %.9g %d %s\n" % (x, y, d, dzi, dzj, len(loc), " ".join(map(str, loc))))
         subprocess.run([exe, scene_dir, str(ref_view), str(scale), str(local_neighbors), mode, sp, op],
-                       check=True, stdout=subprocess.DEVNULL)
+                       check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, REF_FILTER_WIDTH=str(filter_width)))
         with open(op) as f:
             return [ln.split() for ln in f if ln.strip()]

@@ -16,6 +16,7 @@
  *                    colour / derivative samples of fastColAndDeriv
  *   MODE = opt    -> per seed: result of doAutoOptimization + computeConfidence
  * SEEDS: text, one hypothesis per line: x y depth dzI dzJ nlocal [ids...]
+ * Environment: REF_FILTER_WIDTH = mvs::Settings::filterWidth (default 5).
  */
 #include <cstdio>
 #include <cstdlib>
@@ -48,6 +49,7 @@ int main (int argc, char** argv)
     st.scale = std::atoi(argv[3]);
     st.nrReconNeighbors = std::atoi(argv[4]);
     st.quiet = true;
+    if (char const* fw = std::getenv("REF_FILTER_WIDTH")) st.filterWidth = std::atoi(fw);   /* apps/dmrecon --filter-width */
     std::string mode = argv[5];
 
     mve::Scene::Ptr scene = mve::Scene::create(scene_path);

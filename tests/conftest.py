@@ -44,6 +44,11 @@ def g2():
 
 
 @pytest.fixture(scope="session")
+def g1_fw():
+    return dict(np.load(os.path.join(GOLDEN, "g1_filter_widths.npz")))
+
+
+@pytest.fixture(scope="session")
 def h1():
     return dict(np.load(os.path.join(GOLDEN, "h1_hard_9views_208x156.npz")))
 

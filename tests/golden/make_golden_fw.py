@@ -1,0 +1,67 @@
+"""Generates tests/golden/g1_filter_widths.npz from the REAL reference (oracle/_ref): scene G1 reconstructed with
+apps/dmrecon --filter-width=3 and =7 (reference view 0, scale 0), and the patch-level results of G1's 48 hypotheses
+from the reference's own PatchOptimization with those widths.  Run in the authoring container only:
+
+    python tests/golden/make_golden_fw.py
+
+Width 7 keeps quirk Q3 (the derivative step is measured at patchPoints[12], row 1 / column 5 of the 7 x 7 window).
+With width 3 the reference reads patchPoints[12] past the end of a 9-element vector (undefined behaviour; in this
+build it lands in the neighbouring heap block, deterministically); neither the oracle nor the HIP path can restate
+that, both use the centre sample -- the step only scales a finite difference that is divided out again
+(patch_sampler.cc:100-131), so the results agree to rounding, not bit for bit.
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import scene_from_golden  # noqa: E402
+from mve_amd.scene_io import read_mvei, write_scene  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    g1 = dict(np.load(os.path.join(OUT, "g1_5views_160x120.npz")))
+    sc = scene_from_golden(g1)
+    work = tempfile.mkdtemp(prefix="golden_fw_")
+    sdir = os.path.join(work, "g1")
+    write_scene(sdir, sc)
+    n = len(g1["seeds_xy"])
+    seeds = []
+    for i in range(n):
+        s = [int(g1["seeds_xy"][i, 0]), int(g1["seeds_xy"][i, 1])] + [float(v) for v in g1["seeds_hyp"][i]]
+        s += [int(v) for v in g1["seeds_local"][i] if v >= 0]
+        seeds.append(s)
+    g = {}
+    for fw in (3, 7):
+        dst, _ = orc.run_reference_app(sdir, 0, local_neighbors=4, master=0, flavour="strict", extra=["--filter-width=%d" % fw])
+        vd = os.path.join(dst, "views", "view_0000.mve")
+        g["fw%d_depth" % fw] = read_mvei(os.path.join(vd, "depth-L0.mvei"))[:, :, 0]
+        g["fw%d_conf" % fw] = read_mvei(os.path.join(vd, "conf-L0.mvei"))[:, :, 0]
+        g["fw%d_dz" % fw] = read_mvei(os.path.join(vd, "dz-L0.mvei"))
+        shutil.rmtree(os.path.dirname(dst))
+        lines = orc.run_reference_patch_driver(sdir, 0, 0, 4, "opt", seeds, filter_width=fw)
+        opt = np.zeros((n, 8), np.float32)
+        loc = np.full((n, 4), -1, np.int32)
+        for ln in lines[1:]:
+            i = int(ln[1])
+            opt[i, :7] = [np.float32(v) for v in ln[2:9]]
+            nl = int(ln[9])
+            loc[i, :nl] = [int(v) for v in ln[10:10 + nl]]
+        g["fw%d_opt" % fw], g["fw%d_opt_local" % fw] = opt, loc
+        print("filter width %d: filled %d, patches ok %d of %d" % (fw, int((g["fw%d_depth" % fw] > 0).sum()), int((opt[:, 0] > 0).sum()), n))
+    np.savez_compressed(os.path.join(OUT, "g1_filter_widths.npz"), **g)
+    shutil.rmtree(work)
+    print("g1_filter_widths.npz", os.path.getsize(os.path.join(OUT, "g1_filter_widths.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -340,7 +340,9 @@ def test_edge_cases(gpu_ctx, g1_scene):
     with pytest.raises(ValueError):
         gpu_ctx.reconstruct(api.Settings(scale=12), [0])
     with pytest.raises(ValueError):
-        gpu_ctx.reconstruct(api.Settings(filterWidth=7), [0])
+        gpu_ctx.reconstruct(api.Settings(filterWidth=4), [0])
+    with pytest.raises(ValueError):
+        gpu_ctx.reconstruct(api.Settings(filterWidth=9), [0])
     with pytest.raises(ValueError):
         gpu_ctx.reconstruct(api.Settings(nrReconNeighbors=5), [0])
     # an AABB that excludes every feature -> no global views
@@ -410,3 +412,52 @@ def test_hard_scene_maps_vs_reference(gpu_ctx, h1, h1_scene):
     # the paths the smooth scenes never take were taken
     print("H1 stats:", {k: stats[k] for k in ("n_patch", "n_eval", "n_view_replaced", "n_iter14", "n_filled")})
     assert stats["n_view_replaced"] > 50 and stats["n_iter14"] >= 1
+
+
+# ---- apps/dmrecon --filter-width: 3 x 3 and 7 x 7 windows ---------------------------------------------------
+
+@pytest.mark.parametrize("fw", [3, 7])
+def test_filter_widths_vs_reference(gpu_ctx, g1, g1_fw, g1_scene, fw, monkeypatch):
+    """mvs::Settings::filterWidth 3 and 7 (the kernels are compiled once per width): maps against the reference's own
+    output of `dmrecon --filter-width=N`, patch results against its PatchOptimization class and against the oracle,
+    in both lane layouts.  (Width 3: the reference's derivative step reads out of bounds, see tests/golden/
+    make_golden_fw.py -- its patch results carry that noise, so the patch-level check is against the oracle there.)"""
+    from oracle import oracle as orc
+    gpu_ctx.load_scene(g1_scene)
+    st = api.Settings(refViewNr=0, filterWidth=fw)
+    r = gpu_ctx.reconstruct(st, [0])[0]
+    m = map_parity(r["depth"], r["conf"], g1_fw["fw%d_depth" % fw], g1_fw["fw%d_conf" % fw])
+    print("filter width %d maps:" % fw, m)
+    assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_med"] <= 1e-3, m
+    assert m["conf_p99"] <= (2e-2 if fw == 3 else 5e-3), m
+    half = fw // 2                                                           # the border that is never filled (Q11)
+    assert (r["depth"][:half] == 0).all() and (r["depth"][-half:] == 0).all() and (r["depth"][:, :half] == 0).all()
+    S = orc.OracleScene(g1_scene)
+    rng = np.random.RandomState(21)
+    n = 300
+    xy = np.stack([rng.randint(0, 160, n), rng.randint(0, 120, n)], 1)
+    hyp = np.stack([10.0 + rng.uniform(-0.4, 0.4, n), rng.uniform(-5e-3, 5e-3, n), rng.uniform(-5e-3, 5e-3, n)], 1)
+    oo, ol = S.patch_optimize(orc.make_settings(ref_view=0, filterWidth=fw), xy, hyp)
+    for lpv in ("1", "16"):
+        monkeypatch.setenv("MI_DMRECON_HOOK_LPV", lpv)
+        go, gl = gpu_ctx.patch_optimize(st, 0, xy, hyp)
+        assert ((go[:, 0] > 0) == (oo[:, 0] > 0)).mean() >= 0.97
+        ok = (go[:, 0] > 0) & (oo[:, 0] > 0)
+        assert ok.sum() > 40
+        assert (np.abs(go[ok, 1] - oo[ok, 1]) / oo[ok, 1] <= 1e-3).mean() >= 0.99
+        assert (np.abs(go[ok, 0] - oo[ok, 0]) <= 5e-3).mean() >= 0.98
+        assert (gl[ok] == ol[ok]).all(1).mean() >= 0.98
+        if fw == 7:
+            g2, g2l = gpu_ctx.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
+            ref = g1_fw["fw7_opt"]
+            both = (g2[:, 0] > 0) & (ref[:, 0] > 0)
+            assert both.sum() >= 15 and ((g2[:, 0] > 0) == (ref[:, 0] > 0)).mean() >= 0.95
+            assert (np.abs(g2[both, 1] - ref[both, 1]) / ref[both, 1] <= 1e-3).all()
+    # the evaluation hook returns fw * fw samples per view
+    e = gpu_ctx.patch_eval(st, 0, 80, 60, 10.0)
+    o = S.patch_eval(orc.make_settings(ref_view=0, filterWidth=fw), 80, 60, 10.0)
+    assert e["col"].shape[1] == fw * fw and np.array_equal(e["ok"], o["ok"])
+    okv = e["ok"] > 0
+    assert np.abs(e["col"][okv] - o["col"][okv]).max() <= 3e-5 and np.abs(e["ncc"][okv] - o["ncc"][okv]).max() <= 1e-4
+    dref = o["deriv"][okv]
+    assert np.abs(e["deriv"][okv] - dref).max() <= 1e-4 * max(np.abs(dref).max(), 1.0)
