@@ -1566,8 +1566,14 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
     /* one candidate per workgroup (the usual case): wavefronts without a source can end; otherwise the workgroup
      * strides over the candidates and all its wavefronts stay for the barriers */
     const bool single = 4u * n_prev <= gridDim.x;
-    for (int i = threadIdx.x; i < 256; i += (SPEC ? MI_TAIL_WAVES : 1) * WAVE) g_lut[i] = a.lut[i];
-    __syncthreads();
+    /* the sRGB table: three workgroups in four end at the candidate tests below and never sample -- with one candidate
+     * per workgroup a wavefront stages the table itself (every wavefront the same 256 values) just before its first
+     * patch, instead of all of them waiting on a load and a barrier up front */
+    bool lut_ready = !single;
+    if (!single) {
+        for (int i = threadIdx.x; i < 256; i += (SPEC ? MI_TAIL_WAVES : 1) * WAVE) g_lut[i] = a.lut[i];
+        __syncthreads();
+    }
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;
     for (unsigned cand = blockIdx.x; cand < 4u * n_prev; cand += gridDim.x) {
         const unsigned ep = cand >> 2, k = cand & 3u;
@@ -1627,6 +1633,11 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
         auto attempt = [&](int s, PatchResult& r, unsigned& ce, unsigned& cp) {
             float hd, hi, hj; unsigned hv;
             hypothesis(s, hd, hi, hj, hv);
+            if (!lut_ready) {
+                for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                lut_ready = true;
+            }
             ce = 0; cp = 0;
             optimize_patch<16, WIN>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
             /* counters of optimize_patch are per view slot (row leaders): bring them to lane 0 */
