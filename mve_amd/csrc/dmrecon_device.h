@@ -16,7 +16,9 @@
  *   follow_out (count *follow_out_n).  follow_in != null: continue the entries work[follow_in[0 .. *follow_in_n)].
  *   windows: sample the neighbour views through LDS texel windows; self: an entry's candidate is its own pixel's state.
  * generate -- k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile
- *   count; self: the work list = the pixels written in round - 1 themselves (the seeds' own queue entries).
+ *   count; self: the work list = the pixels written in round - 1 themselves (the seeds' own queue entries);
+ *   band_tiles_x/y > 0: list ordered (tile row, job, tile column) -- with optimize's xcd_chunks every XCD then works
+ *   on one horizontal band of all reference views.
  * tail -- one fused tail round: candidates from (prev_work, prev_results, round_work[round - 1]) -> this round's list,
  *   results and pixel-state writes (second state slot, see DevJob).  speculative: workgroups of four wavefronts, a
  *   pixel's candidate hypotheses tried at the same time; else one wavefront per pixel tries them in turn.
@@ -27,12 +29,13 @@ struct MiDeviceApi {
                      const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                      DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                      unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                     const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows, bool self);
+                     const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows, bool self,
+                     bool xcd_chunks);
     void (*patch_eval)(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                        const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
                        float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
     void (*generate)(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
-                     unsigned* round_work, int round, bool self);
+                     unsigned* round_work, int round, bool self, int band_tiles_x, int band_tiles_y);
     void (*tail)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                  const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
                  DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows,

@@ -275,6 +275,7 @@ struct NView {                   /* my neighbour view at the selected mip level 
     float m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11;   /* K.[R|t]: rows 0,1 pre-multiplied by the level's K */
     int w, h;
     const uint32_t* img;         /* 16-byte footprint records of the level (DevView::quad) */
+    const uint32_t* lin;         /* RGBA8 texels of the level (DevView::img): MI_GATHER_ROWS experiment, window source */
     const uint32_t* win;         /* LDS texel window of my view slot, or null: sample by global gathers */
     int bx, by;                  /* texel coordinates of the window's origin */
 };
@@ -322,6 +323,7 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, co
     premultiply(nv, L.ax, L.ay, L.cx, L.cy);
     nv.w = L.w; nv.h = L.h;
     nv.img = V->quad + 4 * (size_t)L.tex_off;      /* 16-byte footprint records of this level */
+    nv.lin = V->img + L.tex_off;
     nv.win = nullptr; nv.bx = 0; nv.by = 0;
     return true;
 }
@@ -344,7 +346,7 @@ struct ViewC {
 
 __device__ __forceinline__ void viewc_reset(ViewC& vc) {
     vc.sel = -2; vc.lvl = -1; vc.V = nullptr; vc.inv0 = 0.f; vc.maxl = 0; vc.lin = nullptr;
-    vc.nv.win = nullptr; vc.nv.bx = MI_NOBOX; vc.nv.by = MI_NOBOX; vc.nv.w = 0; vc.nv.h = 0; vc.nv.img = nullptr;
+    vc.nv.win = nullptr; vc.nv.bx = MI_NOBOX; vc.nv.by = MI_NOBOX; vc.nv.w = 0; vc.nv.h = 0; vc.nv.img = nullptr; vc.nv.lin = nullptr;
     vc.nv.m0 = vc.nv.m1 = vc.nv.m2 = vc.nv.m3 = vc.nv.m4 = vc.nv.m5 = vc.nv.m6 = vc.nv.m7 = 0.f;
     vc.nv.m8 = vc.nv.m9 = vc.nv.m10 = vc.nv.m11 = 0.f;
 }
@@ -505,7 +507,17 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
          * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
          * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1. */
+#ifdef MI_GATHER_ROWS
+        /* experiment: the footprint as two 8-byte row gathers from the plain RGBA8 level (4 B per texel resident
+         * instead of 20: the sampled levels of 20 views are 52 MB instead of 207 MB) */
+        if (first) {
+            const uint32_t* r0 = nv.lin + (size_t)top * nv.w + left;
+            const u32x2 a = *(gtex2_t)r0, b = *(gtex2_t)(r0 + nv.w);
+            q.t.x = a.x; q.t.y = a.y; q.t.z = b.x; q.t.w = b.y;
+        }
+#else
         if (first) q.t = *(gtex4_t)(nv.img + 4 * ((size_t)top * nv.w + left));
+#endif
         return q;
     };
     auto fetch = [&](int it) -> Pre { return geom(it, ps.depth, true); };
@@ -881,6 +893,7 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
         nv.w = Lv.w; nv.h = Lv.h;
         nv.img = DV->quad + 4 * (size_t)Lv.tex_off;
         vc.lin = DV->img + Lv.tex_off;
+        nv.lin = vc.lin;
         nv.bx = MI_NOBOX; nv.by = MI_NOBOX;
     }
     nv.win = nullptr;
@@ -1345,6 +1358,8 @@ struct OptArgs {
     /* One attempt per launch (throughput layout, host-visible rounds): an entry whose pixel has several candidate
      * hypotheses runs them in successive launches over compacted follow-up lists, so that wavefronts stay full
      * (16 patches) instead of idling 15 quads while one entry tries its second neighbour. */
+    int xcd_chunks;               /* 1: workgroup b takes the (b % 8)-th eighth of the list (workgroups go round-robin over the 8
+                                   * XCDs, each with its own L2): an XCD then works on one contiguous stretch of the list */
     int self;                     /* 1: an entry's one candidate is the pixel's OWN state (a seed popped from the queue is
                                    * re-optimised from its converged result and only propagates if that strictly raises its
                                    * confidence, dmrecon.cc:320-329,365-398) */
@@ -1490,7 +1505,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && L
     __syncthreads();
     TSTAMP(2);
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
-    for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < n; i += gridDim.x * L::PATCHES) {
+    unsigned bid = blockIdx.x;
+    if (a.xcd_chunks && (gridDim.x & 7u) == 0u) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (unsigned i = bid * L::PATCHES + L::patch(lane); i < n; i += gridDim.x * L::PATCHES) {
         const unsigned e = a.follow_in ? a.follow_in[i] : i;
         const DevEntry ent = a.work[e];
         bool more = false;
@@ -1823,6 +1840,10 @@ struct SweepArgs {
     unsigned* round_work;  /* [round] = size of the work list of that round (zeroed before the call) */
     int round;
     int self;              /* 1: the pixels written last round THEMSELVES (the seeds' own queue entries, dmrecon.cc:320-329) */
+    int band_major;        /* > 0: 1-D grid ordered (tile row, job, tile column), band_major = widest job's tile columns:
+                            * the work list then runs through the image top to bottom ACROSS the jobs, and a contiguous
+                            * eighth of it is one horizontal band of every reference view (see k_optimize's xcd_chunks) */
+    int n_jobs;
 };
 
 /* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull.
@@ -1839,12 +1860,23 @@ struct SweepArgs {
 __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
     __shared__ unsigned s_wave_cnt[4];
     __shared__ unsigned s_base;
-    const DevJob* job = a.jobs + blockIdx.y;
+    int jobi = blockIdx.y, tcol = -1, trow = -1;
+    if (a.band_major > 0) {
+        const int per_row = a.n_jobs * a.band_major;
+        trow = (int)blockIdx.x / per_row;
+        const int rem = (int)blockIdx.x - trow * per_row;
+        jobi = rem / a.band_major; tcol = rem - jobi * a.band_major;
+    }
+    const DevJob* job = a.jobs + jobi;
     if (job->flags != 0) return;                 /* failed / cancelled view */
     const int W = job->w, H = job->h;
     const int tiles_x = (W + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, tiles_y = (H + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
-    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-    const int tx0 = ((int)blockIdx.x % tiles_x) * MI_GEN_TILE_W, ty0 = ((int)blockIdx.x / tiles_x) * MI_GEN_TILE_H;
+    if (a.band_major > 0) { if (tcol >= tiles_x || trow >= tiles_y) return; }
+    else {
+        if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+        tcol = (int)blockIdx.x % tiles_x; trow = (int)blockIdx.x / tiles_x;
+    }
+    const int tx0 = tcol * MI_GEN_TILE_W, ty0 = trow * MI_GEN_TILE_H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = lane & 7, ly = lane >> 3;
     unsigned hits = 0;                       /* bit t = my pixel of sub-tile t is a hit */
@@ -1886,7 +1918,7 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
 #pragma unroll
     for (int t = 0; t < GEN_PER_THREAD; ++t)
         if ((hits >> t) & 1u) {
-            DevEntry e; e.job = blockIdx.y; e.xy = (tx0 + t * 8 + lx) | ((ty0 + wave * 8 + ly) << 16);
+            DevEntry e; e.job = jobi; e.xy = (tx0 + t * 8 + lx) | ((ty0 + wave * 8 + ly) << 16);
             a.work[off + before[t]] = e;
         }
 }
@@ -2066,10 +2098,13 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows, bool self) {
+                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows, bool self,
+                        bool xcd_chunks) {
     if (grid_blocks == 0) return;
     OptArgs a;
     a.self = self ? 1 : 0;
+    a.xcd_chunks = xcd_chunks ? 1 : 0;
+    if (xcd_chunks) grid_blocks = (grid_blocks + 7u) & ~7u;
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
     a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
@@ -2094,10 +2129,12 @@ static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* v
 }
 
 static void launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
-                        unsigned* round_work, int round, bool self) {
+                        unsigned* round_work, int round, bool self, int band_tiles_x, int band_tiles_y) {
     SweepArgs a;
     a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round; a.self = self ? 1 : 0;
-    hipLaunchKernelGGL(k_generate, dim3(max_tiles, n_jobs), dim3(256), 0, s, a);
+    a.band_major = band_tiles_x; a.n_jobs = n_jobs;
+    if (band_tiles_x > 0) hipLaunchKernelGGL(k_generate, dim3((unsigned)(band_tiles_x * band_tiles_y * n_jobs)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_generate, dim3(max_tiles, n_jobs), dim3(256), 0, s, a);
 }
 
 #if MI_FW == 5
@@ -2120,7 +2157,7 @@ static void launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs,
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.self = 0;
+    t.o.self = 0; t.o.xcd_chunks = 0;
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
     if (speculative) {

@@ -959,12 +959,15 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     if (rc) return rc;
     const int nj = (int)jobs.size();
     std::vector<DevJob> dj(nj);
-    int max_px = 0, max_tiles = 0;
+    int max_px = 0, max_tiles = 0, max_tiles_x = 0, max_tiles_y = 0;
     for (int j = 0; j < nj; ++j) {
         fill_job(c, st, jobs[j], dj[j]);
         max_px = std::max(max_px, jobs[j].w * jobs[j].h);
-        max_tiles = std::max(max_tiles, ((jobs[j].w + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W) * ((jobs[j].h + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H));
+        const int tx = (jobs[j].w + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, ty = (jobs[j].h + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
+        max_tiles = std::max(max_tiles, tx * ty); max_tiles_x = std::max(max_tiles_x, tx); max_tiles_y = std::max(max_tiles_y, ty);
     }
+    /* MI_DMRECON_BANDS=1 (experiment): work lists ordered by image band across the jobs, one band per XCD */
+    static const bool BANDS = [] { const char* e = std::getenv("MI_DMRECON_BANDS"); return e && std::atoi(e) != 0; }();
     size_t total_px = 0;
     rc = alloc_maps(c, jobs, dj, total_px);
     if (rc) return rc;
@@ -1017,7 +1020,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         D.optimize(c->stream, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
                            c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
                            nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0, c->d_counters,
-                           nullptr, nullptr, nullptr, nullptr, false, false);
+                           nullptr, nullptr, nullptr, nullptr, false, false, false);
         ev_end();
         ++n_launch;
         ev_begin(1);
@@ -1114,7 +1117,8 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             static const bool SEED_REOPT = [] { const char* e = std::getenv("MI_DMRECON_SEED_REOPT"); return e && std::atoi(e) != 0; }();
             const bool self = SEED_REOPT && round == 1;
             ev_begin(1);
-            D.generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round, self);
+            D.generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round, self,
+                       BANDS ? max_tiles_x : 0, BANDS ? max_tiles_y : 0);
             ev_end();
             TailPoll& P = c->h_poll[0];
             HIP_TRY(hipMemcpyAsync(&P.rw[0], c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
@@ -1131,12 +1135,12 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             if (tail)
                 D.optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                    nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters,
-                                   nullptr, nullptr, nullptr, nullptr, WIN_TAIL, self);
+                                   nullptr, nullptr, nullptr, nullptr, WIN_TAIL, self, false);
             else if (!USE_FOLLOW || BULK_LPV == 16 || self)
                 D.optimize(c->stream, BULK_LPV, BULK_LPV == 16 ? std::min(n_work, 16384u) : (n_work + BULK_PPW - 1) / BULK_PPW,
                                    c->d_jobs.p, c->sc->d_views.p,
                                    c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
-                                   c->d_counters, nullptr, nullptr, nullptr, nullptr, BULK_LPV == 16 ? WIN_TAIL : WIN_BULK, self);
+                                   c->d_counters, nullptr, nullptr, nullptr, nullptr, BULK_LPV == 16 ? WIN_TAIL : WIN_BULK, self, BANDS && BULK_LPV != 16);
             else {
                 /* throughput layout: one optimisation attempt per entry and launch; the entries whose pixel has further
                  * candidate hypotheses (about one in five) continue in a follow-up launch over a compacted list (its
@@ -1145,11 +1149,11 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                 unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
                 unsigned* fa = c->d_follow.p;
                 D.optimize(c->stream, BULK_LPV, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
-                                   c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt, WIN_BULK, false);
+                                   c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt, WIN_BULK, false, BANDS);
                 /* the follow-up launch runs all remaining attempts of its entries back to back (third and fourth
                  * attempts are rare: a third launch would cost more in latency than it saves) */
                 D.optimize(c->stream, BULK_LPV, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
-                                   nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr, WIN_BULK, false);
+                                   nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr, WIN_BULK, false, false);
                 ++n_launch;
             }
             ev_end();
@@ -1372,7 +1376,7 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw,
                        c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
                        c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
-                       nullptr, nullptr, nullptr, nullptr, windows, false);
+                       nullptr, nullptr, nullptr, nullptr, windows, false, false);
     HIP_TRY(hipGetLastError());
     std::vector<DevResult> res(n);
     HIP_TRY(hipMemcpyAsync(res.data(), c->d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
