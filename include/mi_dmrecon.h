@@ -116,6 +116,9 @@ typedef struct mi_dmrecon_stats {
     int64_t n_gather_pass;  /* passes of the window kernels that sampled by global gathers after all (window larger than a box) */
     int64_t n_view_replaced; /* local views dropped by replaceViews (patch_optimization.cc:218-228; speculative attempts included) */
     int64_t n_iter14;        /* ... of which only by the iteration-14 rule (still moving at iterationCount == 14) */
+    int64_t gvs_on_device;   /* 1 if the global view selection of this call ran on the GPU (gvs_device.hip) */
+    double  ms_plan_gvs;     /* host clock: global view selection of all reference views of the call */
+    double  ms_plan_seeds;   /* host clock: feature seeds of all reference views (dmrecon.cc:232-258) */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);

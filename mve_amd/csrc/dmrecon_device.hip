@@ -588,11 +588,28 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
          * cache lines fetched once, five gathers in flight); only the texels stay in registers, the geometry of a
          * sample is computed again when it is consumed (the opaque copy of the depth keeps the compiler from
          * holding it across the gathers instead) */
+#ifdef MI_ROW_PREFETCH
+        /* experiment: the gathers of row r + 1 are issued before row r is consumed (a second set of texel registers) */
+        u32x4 nx[MI_FW];
+#pragma unroll
+        for (int k = 0; k < MI_FW; ++k) nx[k] = geom(k, ps.depth, true).t;
+#endif
 #pragma unroll 1
         for (int row = 0; row < MI_FW; ++row) {
             u32x4 tx[MI_FW];
+#ifdef MI_ROW_PREFETCH
+#pragma unroll
+            for (int k = 0; k < MI_FW; ++k) tx[k] = nx[k];
+            if (row + 1 < MI_FW) {
+                float depth1 = ps.depth;
+                asm volatile("" : "+v"(depth1));
+#pragma unroll
+                for (int k = 0; k < MI_FW; ++k) nx[k] = geom((row + 1) * MI_FW + k, depth1, true).t;
+            }
+#else
 #pragma unroll
             for (int k = 0; k < MI_FW; ++k) tx[k] = geom(row * MI_FW + k, ps.depth, true).t;
+#endif
             float depth2 = ps.depth;
             asm volatile("" : "+v"(depth2));
 #pragma unroll

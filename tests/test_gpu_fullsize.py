@@ -62,6 +62,20 @@ def test_c3_global_view_selection_vs_oracle(c3):
         assert ctx.global_view_selection(stn, ref) == S.global_vs(orc.make_settings(ref_view=ref, scale=cfg["scale"], global_max=5))
 
 
+def test_c3_view_selection_on_device(c3, monkeypatch):
+    """gvs_device.hip agrees with the host loop -- which the test above pins to the oracle -- for every reference view
+    of the full-size scene (the fixture's 20-view call is below the size from which the device is the default)."""
+    cfg, scene, ctx, st, res, stats = c3
+    assert stats["gvs_on_device"] == 0
+    for ref in range(cfg["params"].n_views):
+        for gmax in (20, 4):
+            s = api.Settings(refViewNr=ref, scale=cfg["scale"], globalVSMax=gmax)
+            monkeypatch.setenv("MI_DMRECON_GVS_DEVICE", "0")
+            host = ctx.global_view_selection(s, ref)
+            monkeypatch.setenv("MI_DMRECON_GVS_DEVICE", "1")
+            assert ctx.global_view_selection(s, ref) == host, (ref, gmax)
+
+
 def test_c3_deterministic(c3):
     cfg, scene, ctx, st, res, stats = c3
     refs = list(range(cfg["params"].n_views))

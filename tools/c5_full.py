@@ -35,6 +35,11 @@ out = a.alloc_outputs(st, refs, want_normal=False, pinned=True)
 a.reconstruct(st, refs, want_normal=False, out=out)                       # warm-up (builds the scene tables too)
 t0 = time.time(); res = a.reconstruct(st, refs, want_normal=False, out=out); t_one = time.time() - t0
 stats = dict(a.last_stats)
+os.environ["MI_DMRECON_GVS_DEVICE"] = "0"                                  # the same call with the view selection on the host
+a.reconstruct(st, refs, want_normal=False, out=out)
+t0 = time.time(); a.reconstruct(st, refs, want_normal=False, out=out); t_one_host = time.time() - t0
+stats_host = dict(a.last_stats)
+del os.environ["MI_DMRECON_GVS_DEVICE"]
 fill = float(np.mean([(r["conf"] > 0).mean() for r in res]))
 # two host threads, half the views each
 f = a.fork()
@@ -68,6 +73,9 @@ print(json.dumps({
     "hbm_used_before_after_upload": [m0, m1], "hbm_scene_bytes": (m1 - m0) if (m0 is not None and m1 is not None) else None,
     "one_call_all_views": {"seconds": t_one, "depth_maps_per_s": p.n_views / t_one, "n_rounds": stats["n_rounds"],
                            "ms_bulk_kernel": stats["ms_bulk_kernel"], "ms_tail_kernel": stats["ms_tail_kernel"],
-                           "n_patch": stats["n_patch"], "n_eval": stats["n_eval"], "n_filled": stats["n_filled"]},
+                           "n_patch": stats["n_patch"], "n_eval": stats["n_eval"], "n_filled": stats["n_filled"],
+                           "gvs_on_device": stats["gvs_on_device"], "ms_plan_gvs": stats["ms_plan_gvs"], "ms_plan_seeds": stats["ms_plan_seeds"]},
+    "one_call_view_selection_on_host": {"seconds": t_one_host, "depth_maps_per_s": p.n_views / t_one_host,
+                                        "ms_plan_gvs": stats_host["ms_plan_gvs"], "ms_plan_seeds": stats_host["ms_plan_seeds"]},
     "two_threads_half_each": {"seconds": t_two, "depth_maps_per_s": p.n_views / t_two},
     "mean_fill": fill, "median_abs_depth_error_views_first_mid_last": errs, "parity_view2_vs_oracle": par}))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun).  Round-2 measurement session.  Output: gpurun_out/$TAG/.
-TAG=${1:-s11}
+TAG=${1:-s12}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -17,22 +17,35 @@ except Exception as e:
     print('  (no json)', e)
 PY
 }
-echo "== maps with and without band ordering are identical"
-python - <<'PY'
-import os, numpy as np
+echo "== view selection on the device: tests"
+timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -q --maxfail=4 -k "view_selection or c3_inv or batch_equals" 2>&1 | tail -5
+echo "== view selection: host vs device time, C3 and C5 geometry (small images, same cameras / features)"
+python - <<'PY' 2>&1 | tail -12
+import os, time, numpy as np
 from mve_amd import api
-from mve_amd.synth import SynthParams, make_scene
-sc = make_scene(SynthParams(n_views=8, width=640, height=360, n_features=800))
-ctx = api.Context(0); ctx.load_scene(sc)
-a = ctx.reconstruct(api.Settings(), list(range(8)))
-print("gvs ok", ctx.global_view_selection(api.Settings(refViewNr=3)))
+from mve_amd.synth import CONFIGS, SynthParams, make_scene
+for name, w, h in (("C3", 480, 270), ("C5", 504, 378)):
+    cfg = CONFIGS[name]; p = SynthParams(**{**cfg["params"].__dict__, "width": w, "height": h})
+    sc = make_scene(p); ctx = api.Context(0); ctx.load_scene(sc)
+    st = api.Settings(scale=0, nrReconNeighbors=cfg["local_neighbors"]); refs = list(range(p.n_views))
+    for mode in ("0", "1"):
+        os.environ["MI_DMRECON_GVS_DEVICE"] = mode
+        ts = []
+        for k in range(4):
+            ctx.reconstruct(st, refs, want_normal=False); s = ctx.last_stats
+            ts.append((s["ms_plan_gvs"], s["ms_plan_seeds"], s["ms_total"]))
+        print(name, p.n_views, "views", p.n_features, "features; device" if mode == "1" else "features; host  ", "gvs/seeds/total ms:", ["%.2f/%.2f/%.1f" % t for t in ts])
+    sel = {}
+    for mode in ("0", "1"):
+        os.environ["MI_DMRECON_GVS_DEVICE"] = mode
+        sel[mode] = [ctx.global_view_selection(api.Settings(refViewNr=r), r) for r in refs]
+    print(name, "identical selections:", sel["0"] == sel["1"])
 PY
 B1="python bench.py --steps 8 --warmup 2 --streams 1 --steps-per-call 1 --no-cpu-baseline"
 BD="python bench.py --steps 30 --warmup 2 --no-cpu-baseline"
-for V in base rows; do for BN in 0 1; do
-  L=$PWD/mve_amd/csrc/libmi_dmrecon.so; [ $V = rows ] && L=$PWD/build/libmi_dmrecon_rows.so
-  echo "== $V bands=$BN: 1 stream"; MI_DMRECON_LIB=$L MI_DMRECON_BANDS=$BN timeout -s KILL 240 $B1 > $OUT/b1_${V}_$BN.json 2> $OUT/b1_${V}_$BN.err; show $OUT/b1_${V}_$BN.json; tail -1 $OUT/b1_${V}_$BN.err | cut -c1-200
-  echo "== $V bands=$BN: default"; MI_DMRECON_LIB=$L MI_DMRECON_BANDS=$BN timeout -s KILL 300 $BD > $OUT/bd_${V}_$BN.json 2> $OUT/bd_${V}_$BN.err; show $OUT/bd_${V}_$BN.json
-done; done
-echo "== pytest with bands"; MI_DMRECON_BANDS=1 timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -q --maxfail=4 2>&1 | tail -3
-echo "== pytest rows"; MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_rows.so timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --maxfail=4 2>&1 | tail -3
+for G in 0 1; do
+  echo "== gvs_device=$G: 1 stream"; MI_DMRECON_GVS_DEVICE=$G timeout -s KILL 240 $B1 > $OUT/b1_$G.json 2> $OUT/b1_$G.err; show $OUT/b1_$G.json; tail -1 $OUT/b1_$G.err | cut -c1-200
+  echo "== gvs_device=$G: default"; MI_DMRECON_GVS_DEVICE=$G timeout -s KILL 300 $BD > $OUT/bd_$G.json 2> $OUT/bd_$G.err; show $OUT/bd_$G.json
+done
+echo "== C5 full"; timeout -s KILL 500 python tools/c5_full.py > $OUT/c5_full.json 2> $OUT/c5_full.err; python -c "
+import json; d=json.load(open('$OUT/c5_full.json')); print(d['one_call_all_views']); print(d['one_call_view_selection_on_host']); print(d['parity_view2_vs_oracle'])"
