@@ -22,7 +22,15 @@
  * tail -- one fused tail round: candidates from (prev_work, prev_results, round_work[round - 1]) -> this round's list,
  *   results and pixel-state writes (second state slot, see DevJob).  speculative: workgroups of four wavefronts, a
  *   pixel's candidate hypotheses tried at the same time; else one wavefront per pixel tries them in turn.
+ * tail_persist -- the rounds first .. first + n_rounds - 1 of the tail in one launch (k_tail_persist: tickets instead of
+ *   one grid per round; same results as n_rounds speculative `tail` launches).  work0 / results0 hold the list of
+ *   round first - 1; the lists alternate between the two buffer pairs from there.  round_head / round_done:
+ *   [MI_MAX_ROUNDS] zeroed counters.  spin_limit_ms: how long a workgroup waits for a round before it gives up
+ *   (error flag bit 2).  team_off != null: the TEAM form -- eight teams (job % 8), one per XCD, each with its own lists
+ *   (at team_off[x] of the buffers, dealt out by mi_launch_team_split) and counters (index round * MI_TEAMS + team,
+ *   arrays of MI_MAX_ROUNDS * MI_TEAMS words).
  */
+#define MI_TEAMS 8
 struct MiDeviceApi {
     int filter_width;
     void (*optimize)(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
@@ -40,6 +48,10 @@ struct MiDeviceApi {
                  const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
                  DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows,
                  bool speculative);
+    void (*tail_persist)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
+                         const DevSettings& st, DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
+                         unsigned* round_work, unsigned* round_head, unsigned* round_done, const unsigned* team_off,
+                         int first, int n_rounds, DevCounters* counters, unsigned spin_limit_ms);
 };
 const MiDeviceApi* mi_device_api(int filter_width);
 extern unsigned long long* mi_debug_tbuf;
@@ -51,6 +63,11 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
                      const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
 /* maps: [slot 0: depth | conf | dz x2 | normal x3][slot 1: same], imaps: [views | upd][views1 | upd1], per batch */
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px);
+/* accepted entries of (work, results, *n_ptr) -> per-team lists (team = job % MI_TEAMS) at team_off[x], counts in team_count[x] */
+void mi_launch_team_split(hipStream_t s, const DevEntry* work, const DevResult* results, const unsigned* n_ptr, DevEntry* owork,
+                          DevResult* oresults, unsigned* team_count, const unsigned* team_off);
+/* ORs 1 << HW_REG_XCC_ID of every workgroup of a 1024-workgroup grid into *mask */
+void mi_launch_xcc_probe(hipStream_t s, unsigned* mask);
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
                            const unsigned* key_off);

@@ -1751,6 +1751,262 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
     if (lane == 0 && err) atomicOr(&a.counters->error_flags, err);
 }
 
+/*
+ * k_tail_persist: up to n_rounds tail rounds in ONE launch -- the same rounds, candidates, rules and writes as k_tail
+ * (speculative form), without a kernel boundary between two rounds.  The boundary is what a small round pays most for:
+ * dispatch, the drain of the previous grid, and every record of the chain entry -> job -> pixel states cold again.
+ *
+ * Work distribution: a TICKET is one accepted entry p of the previous round (round_head[r] hands them out); the
+ * workgroup that draws it looks at p's four neighbours q at the same time (wavefront k = direction k), runs every
+ * candidate hypothesis of the q's whose best source is p -- the same speculative attempts as k_tail, spread over its
+ * four wavefronts -- resolves them by the reference's sequential rule and writes.  round_done[r] counts finished
+ * tickets; a round is over when it reaches the size of the previous list, and only then is this round's list final.
+ *
+ * No grid barrier and no co-residency assumption: nothing ever waits for a workgroup that has not started -- only for
+ * tickets that were drawn, and a drawn ticket is being processed by a running workgroup.  One resident workgroup is
+ * enough to finish the launch; a workgroup that starts late finds the tickets of the old rounds gone and joins the
+ * current one.  (A grid barrier would deadlock two such launches from two host threads against each other.)
+ *
+ * Memory: everything one workgroup writes and another reads in the same launch -- lists, results, the pixel states
+ * and their stamps, the three per-round counters -- goes through agent-scope atomic loads and stores (sc1: served by
+ * the memory side, coherent across the eight XCD-local L2s) instead of cache-wide release / acquire fences, which on
+ * this GPU write back and invalidate a whole L2 each time.  A ticket's stores are waited for (vmcnt) before its
+ * round_done increment is issued.  Images, cameras and the job records are read-only here and are read normally.
+ * A waiting workgroup gives up after spin_limit (error flag bit 2; the host fails the call) rather than hang the GPU.
+ *
+ * TEAM form: the reference views of a call never interact, so the jobs are dealt out to eight TEAMS, one per XCD (job j
+ * -> team j % 8), each with its own lists and round counters, and a workgroup serves the team of the XCD it finds
+ * itself on (HW_REG_XCC_ID, read at run time -- no assumption about where the dispatcher puts a workgroup).  All
+ * hand-offs of a team then stay inside one L2: plain stores (write-through from the CU's L1, the line stays in the L2)
+ * and sc1 loads (bypass the reader's L1, served by that L2) -- a third of the latency of the memory-side round trip the
+ * one-team form pays per hop -- and eight sequences of rounds advance independently, each at its own pace.  The
+ * counters remain agent-scope atomics (sharded per team).  A team's rounds are numbered like the call's, so stamps and
+ * results are those of one launch per round.
+ */
+struct PersistArgs {
+    OptArgs o;
+    DevEntry* work[2];            /* [0]: the list of round first - 1 and of every second round after it; [1]: its partner */
+    DevResult* results[2];
+    unsigned* round_work;         /* [MI_MAX_ROUNDS (x MI_TEAMS)] accepted entries per round (and team: index round * MI_TEAMS + team) */
+    unsigned* round_head;         /* ... tickets drawn */
+    unsigned* round_done;         /* ... tickets finished */
+    unsigned team_off[MI_TEAMS];  /* TEAM: where a team's lists start in work[] / results[] */
+    int first, n_rounds;
+    unsigned long long spin_limit;   /* wall_clock64 ticks (100 MHz) a workgroup waits for a round to complete */
+};
+
+typedef __attribute__((address_space(1))) int* gi32w_t;
+__device__ __forceinline__ int cld(const int* p) { return __hip_atomic_load((gi32_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned cldu(const unsigned* p) { return (unsigned)cld((const int*)p); }
+__device__ __forceinline__ float cldf(const float* p) { return __int_as_float(cld((const int*)p)); }
+__device__ __forceinline__ void cst(int* p, int v) { __hip_atomic_store((gi32w_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cstu(unsigned* p, unsigned v) { cst((int*)p, (int)v); }
+__device__ __forceinline__ void cstf(float* p, float v) { cst((int*)p, __float_as_int(v)); }
+
+__device__ __forceinline__ Frozen frozen_state_c(const DevJob* job, int p, int round) {
+    const int s0 = cld(job->upd + p), s1 = cld(job->upd1 + p);
+    const float c0 = cldf(job->conf + p), c1 = cldf(job->conf1 + p);
+    Frozen f;
+    f.one = s0 >= round || (s1 < round && s1 > s0);
+    f.conf = f.one ? c1 : c0; f.upd = f.one ? s1 : s0;
+    return f;
+}
+
+struct PTask {                    /* neighbour q of the ticket's pixel in direction k, as wavefront k found it */
+    int alive;                    /* p is q's best source: this workgroup does q */
+    int n_cand;
+    unsigned order;               /* 2 bits per rank: direction (seen from q) of the rank's source */
+    int me_one;                   /* slot holding q's frozen state */
+    float own;
+    float nconf[4];               /* frozen confidence of q's four neighbours */
+    int none[4];                  /* ... and the slot it is in */
+};
+__shared__ PTask g_ptask[MI_TAIL_WAVES];
+__shared__ TailRes g_pres[MI_TAIL_WAVES * 4];
+__shared__ unsigned g_pticket, g_pnprev;
+__shared__ int g_pabort;
+
+/* a store another workgroup of the launch will read: write-through to the memory side (one team = any XCD), or plain =
+ * stays in this XCD's L2, where the reader's sc1 load finds it (TEAM: reader and writer share the XCD) */
+template <bool TEAM> __device__ __forceinline__ void pst(int* p, int v) { if (TEAM) *p = v; else cst(p, v); }
+template <bool TEAM> __device__ __forceinline__ void pstu(unsigned* p, unsigned v) { pst<TEAM>((int*)p, (int)v); }
+template <bool TEAM> __device__ __forceinline__ void pstf(float* p, float v) { pst<TEAM>((int*)p, __float_as_int(v)); }
+
+template <bool WIN, bool TEAM>
+__global__ __launch_bounds__(MI_TAIL_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tail_persist(PersistArgs t) {
+    const OptArgs& a = t.o;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    /* my team = the XCD I run on: s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits) */
+    const int team = TEAM ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (MI_TEAMS - 1)) : 0;
+    constexpr int NT = TEAM ? MI_TEAMS : 1;
+    const unsigned off = TEAM ? t.team_off[team] : 0u;
+    for (int i = threadIdx.x; i < 256; i += MI_TAIL_WAVES * WAVE) g_lut[i] = a.lut[i];
+    if (threadIdx.x == 0) { g_pnprev = cldu(&t.round_work[(t.first - 1) * NT + team]); g_pabort = 0; }
+    __syncthreads();
+    unsigned n_prev = g_pnprev;
+    unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;
+    for (int kr = 0; kr < t.n_rounds && n_prev != 0; ++kr) {
+        const int round = t.first + kr;
+        const DevEntry* pw = t.work[kr & 1] + off; const DevResult* prs = t.results[kr & 1] + off;
+        DevEntry* ow = t.work[(kr & 1) ^ 1] + off; DevResult* ors = t.results[(kr & 1) ^ 1] + off;
+        const int ri = round * NT + team;                                      /* my team's counters of this round */
+        for (;;) {
+            if (threadIdx.x == 0) g_pticket = atomicAdd(&t.round_head[ri], 1u);
+            __syncthreads();
+            const unsigned tk = g_pticket;
+            if (tk >= n_prev) break;
+            /* the ticket: entry tk of the previous round and its result (every lane the same words: one request each) */
+            DevEntry src; src.job = cld(&pw[tk].job); src.xy = cld(&pw[tk].xy);
+            DevResult pr;
+            pr.conf = cldf(&prs[tk].conf); pr.depth = cldf(&prs[tk].depth); pr.dzI = cldf(&prs[tk].dzI); pr.dzJ = cldf(&prs[tk].dzJ);
+            pr.views = cldu(&prs[tk].views); pr.accepted = cld(&prs[tk].accepted);
+            const DevJob* job = a.jobs + src.job;
+            const bool live = pr.accepted != 0 && cld(&job->flags) == 0;                 /* failed / cancelled view */
+            const int W = job->w, H = job->h;
+            const int px = src.xy & 0xFFFF, py = src.xy >> 16;
+            {
+                /* wavefront k: neighbour q in direction k, its frozen state and its neighbours', q's candidates in the
+                 * reference's order of trial (descending source confidence, lowest direction first on ties) */
+                const int k = wave;
+                const int qx = px + (k == 0 ? -1 : k == 1 ? 1 : 0), qy = py + (k == 2 ? -1 : k == 3 ? 1 : 0);
+                PTask T;
+                T.alive = 0; T.n_cand = 0; T.order = 0; T.me_one = 0; T.own = 0.f;
+                const bool inside = !(qx < MI_HALF || qy < MI_HALF || qx >= W - MI_HALF || qy >= H - MI_HALF);   /* patch_sampler.cc:47-50 */
+                if (live && inside) {
+                    const int q = qy * W + qx;
+                    const int nb[4] = {q - 1, q + 1, q - W, q + W};
+                    const Frozen me = frozen_state_c(job, q, round);
+                    Frozen nf[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nf[j] = frozen_state_c(job, nb[j], round);
+                    const float own = me.conf;
+                    T.own = own; T.me_one = me.one ? 1 : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { T.nconf[j] = nf[j].conf; T.none[j] = nf[j].one ? 1 : 0; }
+                    if (own < pr.conf - 0.05f || own == 0.f) {
+                        unsigned elig = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (nf[j].upd == round - 1 && (own < nf[j].conf - 0.05f || own == 0.f)) elig |= 1u << j;
+                        unsigned left = elig;
+#pragma unroll
+                        for (int sr = 0; sr < 4; ++sr) {
+                            int bi = -1; float bc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (((left >> j) & 1u) && (bi < 0 || nf[j].conf > bc)) { bi = j; bc = nf[j].conf; }
+                            if (bi >= 0) { T.order |= (unsigned)bi << (2 * sr); ++T.n_cand; left &= ~(1u << bi); }
+                        }
+                        T.alive = (T.n_cand > 0 && (int)(T.order & 3u) == (k ^ 1)) ? 1 : 0;   /* the best source's workgroup does q */
+                    }
+                }
+                if (lane == 0) g_ptask[wave] = T;
+            }
+            __syncthreads();
+            /* the attempts of the ticket's live q's, one wavefront each, four at a time */
+            int total = 0;
+#pragma unroll
+            for (int k = 0; k < MI_TAIL_WAVES; ++k) total += g_ptask[k].alive ? g_ptask[k].n_cand : 0;
+            for (int base = 0; base < total; base += MI_TAIL_WAVES) {
+                const int my = base + wave;
+                if (my >= total) continue;
+                int tq = 0, sr = my;
+#pragma unroll
+                for (int k = 0; k < MI_TAIL_WAVES; ++k) {
+                    const int nk = g_ptask[k].alive ? g_ptask[k].n_cand : 0;
+                    if (tq == k && sr >= nk) { sr -= nk; tq = k + 1; }
+                }
+                const int qx = px + (tq == 0 ? -1 : tq == 1 ? 1 : 0), qy = py + (tq == 2 ? -1 : tq == 3 ? 1 : 0);
+                /* hypothesis of q's rank-sr candidate = its source's result (rank 0: the ticket's record; the others:
+                 * their source's frozen state) */
+                float hd = pr.depth, hi = pr.dzI, hj = pr.dzJ; unsigned hv = pr.views;
+                if (sr > 0) {
+                    const int j = (int)((g_ptask[tq].order >> (2 * sr)) & 3u);
+                    const int q = qy * W + qx;
+                    const int p = j == 0 ? q - 1 : j == 1 ? q + 1 : j == 2 ? q - W : q + W;
+                    const bool one = g_ptask[tq].none[j] != 0;
+                    hd = cldf((one ? job->depth1 : job->depth) + p);
+                    hi = cldf((one ? job->dz1 : job->dz) + 2 * p); hj = cldf((one ? job->dz1 : job->dz) + 2 * p + 1);
+                    hv = cldu((one ? job->views1 : job->views) + p);
+                }
+                PatchResult r; unsigned ce = 0, cp = 0;
+                optimize_patch<16, WIN>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
+                ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
+                              + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
+                cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
+                              + __builtin_amdgcn_readlane((int)cp, 32) + __builtin_amdgcn_readlane((int)cp, 48));
+                if (lane == 0) { TailRes& o = g_pres[tq * 4 + sr]; o.r = r; o.n_eval = ce; o.n_pass = cp; }
+            }
+            __syncthreads();
+            /* wavefront k resolves q_k by the reference's sequential rule and writes */
+            if (g_ptask[wave].alive) {
+                const PTask& T = g_ptask[wave];
+                const int k = wave;
+                const int qx = px + (k == 0 ? -1 : k == 1 ? 1 : 0), qy = py + (k == 2 ? -1 : k == 3 ? 1 : 0);
+                const int q = qy * W + qx;
+                float best = T.own;
+                bool accepted = false;
+                PatchResult fin;
+                fin.conf = 0.f; fin.depth = fin.dzI = fin.dzJ = fin.nx = fin.ny = fin.nz = 0.f; fin.views = 0xFFFFFFFFu; fin.iters = 0;
+                unsigned done = 0;
+                for (int sr = 0; sr < T.n_cand; ++sr) {
+                    const int j = (int)((T.order >> (2 * sr)) & 3u);
+                    const float bc = T.nconf[j];
+                    if (best > bc) break;                                      /* dmrecon.cc:371 (and every later one) */
+                    done |= 1u << j;
+                    const TailRes& c = g_pres[k * 4 + sr];
+                    if (lane == 0) { n_eval += c.n_eval; n_pass += c.n_pass; ++n_patch; }   /* attempts the reference makes */
+                    if (c.r.conf > 0.f && best < c.r.conf) { best = c.r.conf; accepted = true; fin = c.r; }   /* dmrecon.cc:378,391 */
+                }
+                if (accepted && lane == 0) {
+                    const unsigned e = atomicAdd(&t.round_work[ri], 1u);
+                    pst<TEAM>(&ow[e].job, src.job); pst<TEAM>(&ow[e].xy, qx | (qy << 16));
+                    DevResult* o = ors + e;
+                    pstf<TEAM>(&o->conf, fin.conf); pstf<TEAM>(&o->depth, fin.depth); pstf<TEAM>(&o->dzI, fin.dzI); pstf<TEAM>(&o->dzJ, fin.dzJ);
+                    pstf<TEAM>(&o->nx, fin.nx); pstf<TEAM>(&o->ny, fin.ny); pstf<TEAM>(&o->nz, fin.nz); pstu<TEAM>(&o->views, fin.views);
+                    pst<TEAM>(&o->iters, fin.iters); pst<TEAM>(&o->accepted, 1); pstu<TEAM>(&o->tried, done);
+                    const bool one = T.me_one != 0;                            /* slot holding the old state */
+                    float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
+                    float* cq = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
+                    uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
+                    pstf<TEAM>(dp + q, fin.depth); pstf<TEAM>(zp + 2 * q, fin.dzI); pstf<TEAM>(zp + 2 * q + 1, fin.dzJ);
+                    pstf<TEAM>(np + 3 * q, fin.nx); pstf<TEAM>(np + 3 * q + 1, fin.ny); pstf<TEAM>(np + 3 * q + 2, fin.nz);
+                    pstf<TEAM>(cq + q, fin.conf); pstu<TEAM>(vp + q, fin.views); pst<TEAM>(up + q, round);
+                    if (T.own <= 0.f) { ++n_filled; atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u); }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               /* my stores have landed before the ticket counts as done */
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(&t.round_done[ri], 1u);
+        }
+        /* the round is over when every drawn ticket is done; then its list is final */
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            unsigned spins = 0;
+            while (cldu(&t.round_done[ri]) < n_prev) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((++spins & 15u) == 0 && ((cldu(&a.counters->error_flags) & 4u) || wall_clock64() - t0 > t.spin_limit)) {
+                    atomicOr(&a.counters->error_flags, 4u);
+                    g_pabort = 1;
+                    break;
+                }
+            }
+            g_pnprev = cldu(&t.round_work[ri]);
+        }
+        __syncthreads();
+        if (g_pabort) break;
+        n_prev = g_pnprev;
+    }
+    if (lane == 0) {
+        if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
+        if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
+        if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
+        if (n_filled) atomicAdd(&a.counters->n_filled, (unsigned long long)n_filled);
+    }
+    for (int off = 32; off > 0; off >>= 1) err |= __shfl_down(err, off);
+    if (lane == 0 && err) atomicOr(&a.counters->error_flags, err);
+}
+
 /* Fold the second state slot back into the first where it is the newer one (after the last tail round). */
 struct FlattenArgs {
     float* depth; float* dz; float* conf; float* normal; uint32_t* views; int32_t* upd;
@@ -2186,7 +2442,58 @@ static void launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs,
     }
 }
 
+static void launch_tail_persist(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
+                                const DevSettings& st, DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
+                                unsigned* round_work, unsigned* round_head, unsigned* round_done, const unsigned* team_off,
+                                int first, int n_rounds, DevCounters* counters, unsigned spin_limit_ms) {
+    PersistArgs t;
+    t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = nullptr; t.o.hyp = nullptr; t.o.results = nullptr;
+    t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = first;
+    t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
+    t.o.self = 0; t.o.xcd_chunks = 0;
+    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
+    t.work[0] = work0; t.work[1] = work1; t.results[0] = results0; t.results[1] = results1;
+    t.round_work = round_work; t.round_head = round_head; t.round_done = round_done;
+    for (int x = 0; x < MI_TEAMS; ++x) t.team_off[x] = team_off ? team_off[x] : 0u;
+    t.first = first; t.n_rounds = n_rounds;
+    t.spin_limit = (unsigned long long)spin_limit_ms * 100000ull;            /* wall_clock64: 100 MHz */
+    if (team_off) hipLaunchKernelGGL((k_tail_persist<false, true>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
+    else hipLaunchKernelGGL((k_tail_persist<false, false>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
+}
+
 #if MI_FW == 5
+/* The accepted entries of a round's list (all jobs mixed) dealt out to the eight teams of k_tail_persist's TEAM form:
+ * team = job % MI_TEAMS, team x's list at team_off[x] of the output buffers, its length in team_count[x]. */
+struct SplitArgs {
+    const DevEntry* work; const DevResult* results; const unsigned* n_ptr;
+    DevEntry* owork; DevResult* oresults; unsigned* team_count;
+    unsigned team_off[MI_TEAMS];
+};
+__global__ __launch_bounds__(256) void k_team_split(SplitArgs a) {
+    const unsigned n = *a.n_ptr;
+    for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const DevResult r = a.results[e];
+        if (!r.accepted) continue;
+        const DevEntry w = a.work[e];
+        const int x = w.job & (MI_TEAMS - 1);
+        const unsigned i = a.team_off[x] + atomicAdd(&a.team_count[x], 1u);
+        a.owork[i] = w; a.oresults[i] = r;
+    }
+}
+void mi_launch_team_split(hipStream_t s, const DevEntry* work, const DevResult* results, const unsigned* n_ptr, DevEntry* owork,
+                          DevResult* oresults, unsigned* team_count, const unsigned* team_off) {
+    SplitArgs a;
+    a.work = work; a.results = results; a.n_ptr = n_ptr; a.owork = owork; a.oresults = oresults; a.team_count = team_count;
+    for (int x = 0; x < MI_TEAMS; ++x) a.team_off[x] = team_off[x];
+    hipLaunchKernelGGL(k_team_split, dim3(64), dim3(256), 0, s, a);
+}
+
+/* Which XCDs do the workgroups of a launch land on?  One bit per HW_REG_XCC_ID seen by a 1024-workgroup grid. */
+__global__ __launch_bounds__(WAVE) void k_xcc_probe(unsigned* mask) {
+    if (threadIdx.x == 0) atomicOr(mask, 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15));
+}
+void mi_launch_xcc_probe(hipStream_t s, unsigned* mask) { hipLaunchKernelGGL(k_xcc_probe, dim3(1024), dim3(WAVE), 0, s, mask); }
+
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px) {
     if (total_px == 0) return;
     FlattenArgs a;
@@ -2230,5 +2537,5 @@ void mi_launch_pyramid(hipStream_t s, const uint32_t* src, uint32_t* dst, int iw
 
 /* the launchers of this filter width (dmrecon_device.h: mi_device_api); host side only */
 #if !defined(__HIP_DEVICE_COMPILE__)
-extern const MiDeviceApi MI_CAT(mi_device_api_fw, MI_FW) = {MI_FW, launch_optimize, launch_patch_eval, launch_generate, launch_tail};
+extern const MiDeviceApi MI_CAT(mi_device_api_fw, MI_FW) = {MI_FW, launch_optimize, launch_patch_eval, launch_generate, launch_tail, launch_tail_persist};
 #endif

@@ -19,6 +19,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -141,7 +142,18 @@ struct DevBuf {
 #ifndef MI_WIN_DEFAULT
 #define MI_WIN_DEFAULT 0
 #endif
-struct TailPoll { unsigned rw[MI_TAIL_CHUNK]; DevCounters hc; };
+struct TailPoll { unsigned rw[MI_TAIL_CHUNK]; DevCounters hc; unsigned tw[MI_TAIL_CHUNK * MI_TEAMS]; };
+/* reconstruct calls in progress per device, all contexts of the process (MI_DMRECON_TAIL_PERSIST=-1: only a call that
+ * has the GPU to itself runs its small tail rounds in persistent launches; overlapping calls fill each other's gaps
+ * with one launch per round, and spinning workgroups would only take wavefront slots from them) */
+#define MI_MAX_DEVICES 64
+std::atomic<int> g_active_calls[MI_MAX_DEVICES];
+struct ActiveCall {
+    int dev;
+    explicit ActiveCall(int d) : dev(d >= 0 && d < MI_MAX_DEVICES ? d : -1) { if (dev >= 0) g_active_calls[dev].fetch_add(1); }
+    ~ActiveCall() { if (dev >= 0) g_active_calls[dev].fetch_sub(1); }
+    bool alone() const { return dev < 0 || g_active_calls[dev].load() <= 1; }
+};
 
 struct JobHost {          /* host-side plan of one reference view */
     int ref_view = -1;
@@ -213,6 +225,9 @@ struct mi_dmrecon_ctx {
     DevBuf<uint8_t> d_stage2;
     int stage_flip = 0;
     DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
+    DevBuf<unsigned> d_round_tickets;        /* [3][MI_MAX_ROUNDS][MI_TEAMS] k_tail_persist: entries per team round | tickets drawn | finished */
+    DevBuf<unsigned> d_xcc;                  /* one word: probe of the XCDs a grid lands on */
+    int xcc_mask = -1;                       /* its result (-1: not probed yet) */
     DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
     DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
     TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
@@ -802,7 +817,7 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
     c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release(); c->d_follow.release(); c->d_follow_cnt.release();
-    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release();
+    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release(); c->d_round_tickets.release(); c->d_xcc.release();
     if (c->h_poll) (void)hipHostFree(c->h_poll);
     if (c->h_dyn) (void)hipHostFree(c->h_dyn);
     for (int k = 0; k < 2; ++k) if (c->poll_ev[k]) (void)hipEventDestroy(c->poll_ev[k]);
@@ -1016,6 +1031,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     if (rc) return rc;
     const MiDeviceApi& D = *mi_device_api(st->filterWidth);
     HIP_TRY(hipSetDevice(c->device));
+    const ActiveCall active_call(c->device);
     if (stats) std::memset(stats, 0, sizeof(*stats));
     /* outcome per reference view (status_out): a view whose planning fails, whose footprint turns non-positive or
      * that is cancelled ends alone, the others of the call go on (apps/dmrecon/dmrecon.cc:314-317) */
@@ -1132,10 +1148,11 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     auto ev_end = [&]() { hipEvent_t e = get_event(ev_kind.back().first + 1); if (e) (void)hipEventRecord(e, c->stream); };
 
     mark("setup + uploads (async)");
-    int64_t n_launch = 0, n_tail_launch = 0;
-    if (c->d_round_work.reserve(MI_MAX_ROUNDS) || c->d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->d_follow.reserve(2 * work_cap))
+    int64_t n_launch = 0, n_tail_launch = 0, n_tail_classic = 0, n_tail_rounds_persist = 0;
+    if (c->d_round_work.reserve(MI_MAX_ROUNDS) || c->d_round_tickets.reserve(3 * MI_MAX_ROUNDS * MI_TEAMS) || c->d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->d_follow.reserve(2 * work_cap))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(round counters) failed");
     HIP_TRY(hipMemsetAsync(c->d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_round_tickets.p, 0, 3 * MI_MAX_ROUNDS * MI_TEAMS * sizeof(unsigned), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), c->stream));
     if (!seeds.empty()) {
         HIP_TRY(hipMemcpyAsync(c->d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
@@ -1173,6 +1190,31 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
      * pixel: the round is one patch optimisation long instead of up to four); larger rounds fill the GPU anyway
      * and run them in turn on one wavefront, which wastes nothing.  MI_DMRECON_SPECULATE=<entries> (0 = never). */
     static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 1024u; }();
+    /* Persistent tail launches (k_tail_persist: a chunk of rounds per launch, no kernel boundary between rounds) once
+     * the rounds are down to PERSIST_MAX entries.  MI_DMRECON_TAIL_PERSIST: 0 / unset = one launch per round, 1 = one
+     * team (hand-offs through the memory side), 2 = eight teams, one per XCD (hand-offs inside an L2), -1 = teams
+     * whenever no other reconstruct call is running on this GPU.  Same rounds, same results in every form
+     * (tests/test_gpu_parity.py).  Off by default because it buys nothing: a small round is one
+     * cold patch optimisation long (25-30 us) whichever way it is started -- the boundary between two launches is
+     * only ~1.5 us of it -- and the tickets and counters of the persistent forms cost about what they save.
+     * MI_DMRECON_TAIL_PERSIST_MAX=<entries>, _GRID=<workgroups>, MI_DMRECON_TAIL_SPIN_MS (all read per call). */
+    const int PERSIST_MODE = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PERSIST"); return e ? std::max(-1, std::min(2, std::atoi(e))) : 0; }();
+    const unsigned PERSIST_MAX = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PERSIST_MAX"); return e ? (unsigned)std::atoi(e) : 512u; }();
+    const unsigned PERSIST_SPIN_MS = [] { const char* e = std::getenv("MI_DMRECON_TAIL_SPIN_MS"); return e ? (unsigned)std::atoi(e) : 2000u; }();
+    const unsigned PERSIST_GRID = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PERSIST_GRID"); return e ? (unsigned)std::max(1, std::atoi(e)) : 0u; }();
+    /* the teams' list regions: team x = the jobs j with j % MI_TEAMS == x; a list holds a pixel at most once */
+    unsigned team_off[MI_TEAMS];
+    {
+        size_t acc = 0;
+        for (int x = 0; x < MI_TEAMS; ++x) {
+            team_off[x] = (unsigned)acc;
+            for (int j = x; j < nj; j += MI_TEAMS) acc += (size_t)jobs[j].w * jobs[j].h;
+        }
+    }
+    unsigned* const d_team_work = c->d_round_tickets.p;
+    unsigned* const d_ticket_head = c->d_round_tickets.p + (size_t)MI_MAX_ROUNDS * MI_TEAMS;
+    unsigned* const d_ticket_done = c->d_round_tickets.p + 2 * (size_t)MI_MAX_ROUNDS * MI_TEAMS;
+    bool teams_started = false;
     static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
     /* texel windows in LDS: bit 0 = latency layout (tail rounds), bit 1 = throughput layout (bulk rounds) */
     const int USE_WIN = [] { const char* e = std::getenv("MI_DMRECON_WIN"); return e ? std::atoi(e) : MI_WIN_DEFAULT; }();
@@ -1306,10 +1348,46 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         DevEntry* wnext = c->d_work2.p;
         DevResult* rcur = c->d_results.p;
         DevResult* rnext = c->d_results2.p;
-        struct ChunkInfo { int first; size_t ev_first, ev_last; };
+        struct ChunkInfo { int first; size_t ev_first, ev_last; int mode; };
         ChunkInfo info[2];
         auto enqueue_chunk = [&](int slot) -> int {
             info[slot].first = round; info[slot].ev_first = ev_work.size();
+            int mode = 0;                                  /* 0: one launch per round, 1: persistent, one team, 2: eight teams */
+            if (teams_started) mode = 2;                   /* the lists are the teams' now */
+            else if (!WIN_TAIL && SPEC_MAX > 0 && tail_known <= PERSIST_MAX) {
+                if (PERSIST_MODE > 0) mode = PERSIST_MODE;
+                else if (PERSIST_MODE < 0 && active_call.alone()) mode = 2;
+                if (mode == 2) {
+                    if (c->xcc_mask < 0) {                 /* once per context: do the workgroups of a grid reach all eight XCDs? */
+                        unsigned m = 0;
+                        if (c->d_xcc.reserve(1) || hipMemsetAsync(c->d_xcc.p, 0, sizeof(unsigned), c->stream) != hipSuccess) return -1;
+                        mi_launch_xcc_probe(c->stream, c->d_xcc.p);
+                        if (hipMemcpyAsync(&m, c->d_xcc.p, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess
+                            || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+                        c->xcc_mask = (int)m;
+                    }
+                    if (c->xcc_mask != (1 << MI_TEAMS) - 1) mode = PERSIST_MODE > 0 ? 1 : 0;
+                }
+            }
+            info[slot].mode = mode;
+            if (mode != 0) {
+                /* the whole chunk in one launch; TAIL_CHUNK is even, so the list buffers end where they started */
+                const bool timed = stats != nullptr || trace;
+                if (mode == 2 && !teams_started) {
+                    /* deal the list of the last round out to the teams (into the free buffer pair) */
+                    mi_launch_team_split(c->stream, wcur, rcur, c->d_round_work.p + (round - 1), wnext, rnext,
+                                         d_team_work + (size_t)(round - 1) * MI_TEAMS, team_off);
+                    std::swap(wcur, wnext); std::swap(rcur, rnext);
+                    teams_started = true;
+                }
+                if (timed) { ev_begin(0); ev_work.push_back(0); ev_tail.push_back(2); }
+                const unsigned grid = PERSIST_GRID ? PERSIST_GRID : (mode == 2 ? 512u : std::min(512u, std::max(64u, tail_known)));
+                D.tail_persist(c->stream, grid, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
+                               mode == 2 ? d_team_work : c->d_round_work.p, d_ticket_head, d_ticket_done, mode == 2 ? team_off : nullptr,
+                               round, (int)TAIL_CHUNK, c->d_counters, PERSIST_SPIN_MS);
+                if (timed) ev_end();
+                round += (int)TAIL_CHUNK;
+            } else
             for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
                 const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
                 if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
@@ -1321,7 +1399,9 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             }
             info[slot].ev_last = ev_work.size();
             TailPoll& P = c->h_poll[slot];
-            if (hipMemcpyAsync(P.rw, c->d_round_work.p + info[slot].first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+            if (mode == 2) {
+                if (hipMemcpyAsync(P.tw, d_team_work + (size_t)info[slot].first * MI_TEAMS, TAIL_CHUNK * MI_TEAMS * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+            } else if (hipMemcpyAsync(P.rw, c->d_round_work.p + info[slot].first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
             if (hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
             if (read_dyn(dyn_of(slot)) != hipSuccess) return -1;
             if (hipEventRecord(c->poll_ev[slot], c->stream) != hipSuccess) return -1;
@@ -1336,12 +1416,19 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             HIP_TRY(hipEventSynchronize(c->poll_ev[slot]));
             TailPoll& P = c->h_poll[slot];
             hc = P.hc;
+            if (info[slot].mode == 2)                      /* entries of a round = the sum over the teams */
+                for (unsigned k = 0; k < TAIL_CHUNK; ++k) {
+                    P.rw[k] = 0;
+                    for (int x = 0; x < MI_TEAMS; ++x) P.rw[k] += P.tw[k * MI_TEAMS + x];
+                }
             for (size_t q = info[slot].ev_first; q < info[slot].ev_last; ++q) ev_work[q] = P.rw[ev_work[q]];
             int end_round = -1;
             unsigned chunk_max = 0;
+            if (P.hc.error_flags & 4u) return fail(MI_DMRECON_EDEVICE, "a persistent tail launch gave up waiting for a round (MI_DMRECON_TAIL_SPIN_MS)");
             for (unsigned k = 0; k < TAIL_CHUNK; ++k) {
                 if (P.rw[k] == 0) { end_round = info[slot].first + (int)k; break; }
-                ++n_launch; ++n_tail_launch;
+                if (info[slot].mode == 0) { ++n_launch; ++n_tail_launch; ++n_tail_classic; }
+                else { ++n_tail_rounds_persist; if (k == 0) { ++n_launch; ++n_tail_launch; } }
                 if (k >= TAIL_CHUNK / 2) chunk_max = std::max(chunk_max, P.rw[k]);
             }
             if (chunk_max) tail_known = chunk_max;
@@ -1399,21 +1486,22 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         stats->n_rounds = round; stats->n_launches = n_launch; stats->truncated = truncated ? 1 : 0;
         stats->n_stage = (int64_t)hc.n_stage; stats->n_gather_pass = (int64_t)hc.n_gather_pass;
         stats->n_view_replaced = (int64_t)hc.n_view_replaced; stats->n_iter14 = (int64_t)hc.n_iter14;
-        double tail_ms = 0.0; int64_t tail_timed = 0;
+        double tail_ms = 0.0, tail_persist_ms = 0.0; int64_t tail_timed = 0;
         size_t w = 0;
         for (size_t k = 0; k < ev_kind.size(); ++k) {
             float ms = 0.f;
             const bool got = hipEventElapsedTime(&ms, c->events[ev_kind[k].first], c->events[ev_kind[k].first + 1]) == hipSuccess;
             if (ev_kind[k].second != 0) { if (got) stats->ms_sweep_kernels += ms; continue; }
             if (!ev_tail[w]) { if (got) { stats->ms_opt_kernel += ms; stats->ms_bulk_kernel += ms; ++stats->n_bulk_launches; } }
+            else if (ev_tail[w] == 2) { if (got && ev_work[w] > 0) tail_persist_ms += ms; }
             else if (got && ev_work[w] > 0) { tail_ms += ms; ++tail_timed; }
             ++w;
         }
-        /* phase B: mean of the timed launches x number of launches that had work */
-        if (tail_timed > 0) {
-            stats->ms_tail_kernel = tail_ms / (double)tail_timed * (double)n_tail_launch;
-            stats->ms_opt_kernel += stats->ms_tail_kernel;
-        }
+        /* phase B: mean of the timed launches x number of launches that had work; persistent launches are all timed */
+        if (tail_timed > 0) stats->ms_tail_kernel = tail_ms / (double)tail_timed * (double)n_tail_classic;
+        stats->ms_tail_kernel += tail_persist_ms;
+        stats->ms_opt_kernel += stats->ms_tail_kernel;
+        stats->n_tail_rounds_persistent = n_tail_rounds_persist;
         stats->n_tail_launches = n_tail_launch;
         const DevCounters& ho = have_handover ? c->h_poll[2].hc : hc;      /* the stream has been synchronised above */
         stats->n_eval_bulk = (int64_t)ho.n_eval; stats->n_patch_bulk = (int64_t)ho.n_patch; stats->n_filled_bulk = (int64_t)ho.n_filled;

@@ -18,6 +18,7 @@
 #include "gvs_device.h"
 
 #define GVS_THREADS 1024
+#define GVS_TILE_FLOATS 8192                /* LDS tile of scores: 32 KB */
 
 __device__ __forceinline__ float gvs_penalty(float plx) {                /* (plx / 10)^2, global_view_selection.cc:78,97 */
     const float q = __fdiv_rn(plx, 10.f);
@@ -29,12 +30,12 @@ __global__ __launch_bounds__(GVS_THREADS) void k_gvs(GvsArgs a) {
     __shared__ int s_nfeat, s_nsel, s_found, s_best;
     __shared__ int s_sel[MI_GVS_MAX_OUT];
     __shared__ uint8_t s_avail[1024];
+    __shared__ float s_tile[GVS_TILE_FLOATS + 64];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const GvsScene& S = a.sc;
     const int nv = S.nv, nf = S.nf, ref = a.refs[r].ref;
     int32_t* feat = a.feat + (size_t)r * nf;
     float* base = a.base + (size_t)r * nv * nf;
-    float* score = a.score + (size_t)r * nv * nf;
     float* benefit = a.benefit + (size_t)r * nv;
     const uint8_t* sees_ref = S.sees + (size_t)ref * nf;
 
@@ -85,36 +86,40 @@ __global__ __launch_bounds__(GVS_THREADS) void k_gvs(GvsArgs a) {
     __syncthreads();
 
     /* ---- greedy selection (global_view_selection.cc:33-60) */
+    const int nvp = nv | 1;                                              /* odd row length: the transposed tile writes spread over the banks */
+    const int TL = max(1, min(64, GVS_TILE_FLOATS / nvp));               /* features per tile */
     for (;;) {
         const int nsel = s_nsel;
         if (nsel >= a.globalVSMax || nsel >= MI_GVS_MAX_OUT) break;
-        /* scores of every (available candidate, attached feature it sees) */
-        for (size_t idx = tid; idx < (size_t)nv * nfeat; idx += GVS_THREADS) {
-            const int i = (int)(idx / nfeat), l = (int)(idx - (size_t)i * nfeat);
-            if (!s_avail[i]) continue;
-            const int f = feat[l];
-            if (!S.sees[(size_t)i * nf + f]) { score[(size_t)l * nv + i] = 0.f; continue; }   /* x + 0 = x: same sum as skipping */
-            float sc = base[(size_t)i * nf + l];
-            for (int q = 0; q < nsel; ++q) {
-                const int sv = s_sel[q];
-                if (!S.sees[(size_t)sv * nf + f]) continue;                             /* :93 */
-                const float plx = S.plx[((size_t)sv * nv + i) * nf + f];
-                if (plx < a.minParallax) sc = __fmul_rn(sc, gvs_penalty(plx));         /* :96-98; otherwise x 1 */
+        /* The scores of a tile of features for every candidate, by all threads, into LDS; then thread i adds candidate
+         * i's column to its running benefit, feature after feature.  Nothing but the tile leaves the registers. */
+        float b = 0.f;                                                   /* benefit of candidate `tid` */
+        for (int l0 = 0; l0 < nfeat; l0 += TL) {
+            const int tl = min(TL, nfeat - l0);
+            for (int idx = tid; idx < nv * tl; idx += GVS_THREADS) {
+                const int i = idx / tl, lt = idx - i * tl, l = l0 + lt;
+                if (!s_avail[i]) continue;
+                const int f = feat[l];
+                float sc = 0.f;                                          /* a feature the candidate does not see adds +0: x + 0 = x */
+                if (S.sees[(size_t)i * nf + f]) {
+                    sc = base[(size_t)i * nf + l];
+                    for (int q = 0; q < nsel; ++q) {
+                        const int sv = s_sel[q];
+                        if (!S.sees[(size_t)sv * nf + f]) continue;                     /* :93 */
+                        const float plx = S.plx[((size_t)sv * nv + i) * nf + f];
+                        if (plx < a.minParallax) sc = __fmul_rn(sc, gvs_penalty(plx)); /* :96-98; otherwise x 1 */
+                    }
+                }
+                s_tile[lt * nvp + i] = sc;
             }
-            score[(size_t)l * nv + i] = sc;
-        }
-        __threadfence_block();
-        __syncthreads();
-        /* benefit of a candidate: its scores added up in ascending feature order, by one thread */
-        for (int i = tid; i < nv; i += GVS_THREADS) {
-            float b = 0.f;
-            if (s_avail[i]) {
-                const float* sci = score + i;                            /* [feature][view]: neighbouring threads, neighbouring words */
+            __syncthreads();
+            if (tid < nv && s_avail[tid]) {
 #pragma unroll 8
-                for (int l = 0; l < nfeat; ++l) b = __fadd_rn(b, sci[(size_t)l * nv]);
+                for (int lt = 0; lt < tl; ++lt) b = __fadd_rn(b, s_tile[lt * nvp + tid]);
             }
-            benefit[i] = b;
+            __syncthreads();
         }
+        if (tid < nv) benefit[tid] = b;
         __threadfence_block();
         __syncthreads();
         if (tid == 0) {

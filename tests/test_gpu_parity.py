@@ -124,6 +124,8 @@ def test_device_view_selection_equals_host_and_reference(gpu_ctx, g1, g1_scene, 
     monkeypatch.setenv("MI_DMRECON_GVS_DEVICE", "1")
     with pytest.raises(ValueError):
         gpu_ctx.global_view_selection(api.Settings(refViewNr=99))
+    monkeypatch.delenv("MI_DMRECON_GVS_DEVICE")
+    gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
 
 
 def test_patch_sampler_vs_reference_vectors(ctx_g1, g1):
@@ -260,6 +262,39 @@ def test_speculative_tail_equals_sequential_attempts(gpu_ctx, g1_scene, monkeypa
             assert np.array_equal(a[k], b[k]), k
     # the device counts the attempts the reference's rule would have made, not the speculative extras
     assert n_seq["n_patch"] == n_spec["n_patch"] and n_seq["n_eval"] == n_spec["n_eval"]
+
+
+@pytest.mark.parametrize("mode,grid", [("1", "0"), ("1", "3"), ("2", "0"), ("2", "8")])
+def test_persistent_tail_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, monkeypatch, mode, grid):
+    """k_tail_persist (a chunk of tail rounds per launch, tickets instead of one grid per round) writes exactly what
+    one launch per round writes: same candidates, same speculative attempts, same sequential rule.  Mode 1: one team,
+    hand-offs through the memory side; mode 2: a team per XCD (job % 8), hand-offs inside its L2.  Forced on for every
+    tail chunk (MI_DMRECON_TAIL_PERSIST_MAX), with the default grid and with a tiny one, so that a workgroup draws
+    many tickets per round and late workgroups find rounds already over.  Nine / five reference views per call:
+    several jobs per team and teams without a job."""
+    for scene, refs in ((g1_scene, [0, 1, 2, 3, 4]), (h1_scene, list(range(9)))):
+        gpu_ctx.load_scene(scene)
+        monkeypatch.setenv("MI_DMRECON_TAIL_PERSIST", "0")
+        ref = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
+        s0 = dict(gpu_ctx.last_stats)
+        assert s0["n_tail_rounds_persistent"] == 0
+        monkeypatch.setenv("MI_DMRECON_TAIL_PERSIST", mode)
+        monkeypatch.setenv("MI_DMRECON_TAIL_PERSIST_MAX", "1000000")
+        if grid != "0":
+            monkeypatch.setenv("MI_DMRECON_TAIL_PERSIST_GRID", grid)
+        for rep in range(2):
+            got = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
+            s1 = dict(gpu_ctx.last_stats)
+            assert s1["n_tail_rounds_persistent"] > 10 and s1["n_rounds"] == s0["n_rounds"]
+            for k in ("n_patch", "n_eval", "n_filled"):
+                assert s1[k] == s0[k], k
+            for a, b in zip(got, ref):
+                for k in ("depth", "conf", "dz", "normal", "views"):
+                    assert np.array_equal(a[k], b[k]), (k, rep)
+        monkeypatch.delenv("MI_DMRECON_TAIL_PERSIST_MAX")
+        monkeypatch.delenv("MI_DMRECON_TAIL_PERSIST_GRID", raising=False)
+    monkeypatch.delenv("MI_DMRECON_TAIL_PERSIST")
+    gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
 
 
 def test_views_end_individually_in_a_batch(gpu_ctx, g1_scene, monkeypatch):
