@@ -119,6 +119,8 @@ typedef struct mi_dmrecon_stats {
     int64_t gvs_on_device;   /* 1 if the global view selection of this call ran on the GPU (gvs_device.hip) */
     double  ms_plan_gvs;     /* host clock: global view selection of all reference views of the call */
     double  ms_plan_seeds;   /* host clock: feature seeds of all reference views (dmrecon.cc:232-258) */
+    double  ms_wait_bulk_token; /* host clock: time this call waited for other calls' bulk rounds on the same GPU before
+                              * its own (calls on one GPU take turns with the throughput half) */
     int64_t n_tail_rounds_persistent; /* tail rounds that ran inside persistent launches (a chunk of rounds per launch;
                               * n_tail_launches counts such a launch once, ms_tail_kernel holds its measured time) */
 } mi_dmrecon_stats;

@@ -148,6 +148,15 @@ struct TailPoll { unsigned rw[MI_TAIL_CHUNK]; DevCounters hc; unsigned tw[MI_TAI
  * with one launch per round, and spinning workgroups would only take wavefront slots from them) */
 #define MI_MAX_DEVICES 64
 std::atomic<int> g_active_calls[MI_MAX_DEVICES];
+/* The BULK TOKEN of a device (MI_DMRECON_BULK_TOKEN=1; off by default).  A call has two very different halves: the
+ * seeds and the host-visible rounds (phase A) are throughput work -- every launch fills the GPU by itself -- and the
+ * tail (phase B) is ~600 dependent rounds of a few workgroups each.  With the token, calls that run at the same time on
+ * one GPU (several host threads, each with a forked context) take turns with phase A and run their tails next to
+ * whoever holds it.  Measured with six host threads: the bulk kernels then run at the speed
+ * they have alone (3.5 instead of 4.2-5.0 ms per 100-view launch) and the token is the saturated resource, but the
+ * depth-maps/s are the same to slightly lower (705-716 against 703-757 without): the GPU was not short of bulk work
+ * before, it is short of everything the co-running tails take from it. */
+std::mutex g_bulk_token[MI_MAX_DEVICES];
 struct ActiveCall {
     int dev;
     explicit ActiveCall(int d) : dev(d >= 0 && d < MI_MAX_DEVICES ? d : -1) { if (dev >= 0) g_active_calls[dev].fetch_add(1); }
@@ -209,6 +218,8 @@ struct SceneStore {
 struct mi_dmrecon_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_hi = nullptr;         /* highest priority the device offers: the tail rounds (phase B) */
+    hipEvent_t xs_ev = nullptr;              /* orders the two streams at the phase boundaries */
     std::shared_ptr<SceneStore> sc;
     DevCounters* d_counters = nullptr;
     DevBuf<DevJob> d_jobs;
@@ -785,6 +796,31 @@ void mi_dmrecon_settings_default(mi_dmrecon_settings* s) {          /* libs/dmre
     }
 }
 
+/* The context's two streams: the normal one and one of the highest priority the device offers (tail rounds).  A
+ * device without stream priorities gets no second stream; the tail then stays on the first. */
+static int create_streams(mi_dmrecon_ctx* c) {
+    /* MI_DMRECON_RESERVE_CUS=<n> (read when a context is created): the context's main stream -- the bulk rounds, tens of
+     * thousands of workgroups per launch -- is created with a CU mask that leaves n compute units out, so that the
+     * latency-bound tail rounds of OTHER calls on the same GPU (priority stream, unmasked) always find idle CUs instead
+     * of queueing for wavefront slots.  A throughput knob for several concurrent calls; a lone call only loses the CUs. */
+    int reserve = 0;
+    if (const char* e = std::getenv("MI_DMRECON_RESERVE_CUS")) reserve = std::max(0, std::atoi(e));
+    hipDeviceProp_t prop;
+    if (reserve > 0 && hipGetDeviceProperties(&prop, c->device) == hipSuccess && reserve < prop.multiProcessorCount) {
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
+        for (int i = 0; i < reserve; ++i) mask[i / 32] &= ~(1u << (i % 32));
+        if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) c->stream = nullptr;
+    }
+    if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least
+        && hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, greatest) == hipSuccess) {
+        if (hipEventCreateWithFlags(&c->xs_ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->stream_hi); c->stream_hi = nullptr; }
+    } else c->stream_hi = nullptr;
+    return 0;
+}
+
 int mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out) {
     if (!out) return fail(MI_DMRECON_EINVAL, "null out pointer");
     int n = mi_dmrecon_device_count();
@@ -795,7 +831,7 @@ int mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out) {
     c->device = device;
     c->sc = std::make_shared<SceneStore>();
     c->sc->device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (int rc = create_streams(c)) return rc;
     /* sRGB -> linear table: the formula documented at mvs_tools.cc:22-29 evaluated in double and
      * rounded to float reproduces the literal table at :30-93 bit for bit (tests/test_host_logic.py). */
     float lut[256];
@@ -822,6 +858,8 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     if (c->h_dyn) (void)hipHostFree(c->h_dyn);
     for (int k = 0; k < 2; ++k) if (c->poll_ev[k]) (void)hipEventDestroy(c->poll_ev[k]);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->stream_hi) { (void)hipStreamSynchronize(c->stream_hi); (void)hipStreamDestroy(c->stream_hi); }
+    if (c->xs_ev) (void)hipEventDestroy(c->xs_ev);
     (void)hipStreamDestroy(c->stream);
     delete c;                                 /* the scene store goes with its last owner */
 }
@@ -832,7 +870,7 @@ int mi_dmrecon_ctx_fork(mi_dmrecon_ctx* parent, mi_dmrecon_ctx** out) {
     mi_dmrecon_ctx* c = new mi_dmrecon_ctx;
     c->device = parent->device;
     c->sc = parent->sc;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (int rc = create_streams(c)) return rc;
     HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(DevCounters)));
     *out = c;
     return 0;
@@ -1032,6 +1070,10 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     const MiDeviceApi& D = *mi_device_api(st->filterWidth);
     HIP_TRY(hipSetDevice(c->device));
     const ActiveCall active_call(c->device);
+    if (c->stream_hi) {                      /* a call that failed inside its tail may have left work on the priority stream */
+        HIP_TRY(hipEventRecord(c->xs_ev, c->stream_hi));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->xs_ev, 0));
+    }
     if (stats) std::memset(stats, 0, sizeof(*stats));
     /* outcome per reference view (status_out): a view whose planning fails, whose footprint turns non-positive or
      * that is cancelled ends alone, the others of the call go on (apps/dmrecon/dmrecon.cc:314-317) */
@@ -1144,30 +1186,39 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
      * tail round.  Phase B therefore times every TAIL_TIMED_EVERY-th round only (all of them when tracing); the
      * tail launches are uniform (one dependent patch chain each), their mean stands in for the untimed ones. */
     const unsigned TAIL_TIMED_EVERY = trace ? 1u : 8u;
-    auto ev_begin = [&](int kind) { hipEvent_t e = get_event(n_ev); if (e) (void)hipEventRecord(e, c->stream); ev_kind.push_back(std::make_pair(n_ev, kind)); n_ev += 2; };
-    auto ev_end = [&]() { hipEvent_t e = get_event(ev_kind.back().first + 1); if (e) (void)hipEventRecord(e, c->stream); };
+    hipStream_t S = c->stream;                         /* the stream the rounds are enqueued on: c->stream, or the high-priority one in phase B */
+    auto ev_begin = [&](int kind) { hipEvent_t e = get_event(n_ev); if (e) (void)hipEventRecord(e, S); ev_kind.push_back(std::make_pair(n_ev, kind)); n_ev += 2; };
+    auto ev_end = [&]() { hipEvent_t e = get_event(ev_kind.back().first + 1); if (e) (void)hipEventRecord(e, S); };
 
     mark("setup + uploads (async)");
     int64_t n_launch = 0, n_tail_launch = 0, n_tail_classic = 0, n_tail_rounds_persist = 0;
     if (c->d_round_work.reserve(MI_MAX_ROUNDS) || c->d_round_tickets.reserve(3 * MI_MAX_ROUNDS * MI_TEAMS) || c->d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->d_follow.reserve(2 * work_cap))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(round counters) failed");
-    HIP_TRY(hipMemsetAsync(c->d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_round_tickets.p, 0, 3 * MI_MAX_ROUNDS * MI_TEAMS * sizeof(unsigned), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
+    HIP_TRY(hipMemsetAsync(c->d_round_tickets.p, 0, 3 * MI_MAX_ROUNDS * MI_TEAMS * sizeof(unsigned), S));
+    HIP_TRY(hipMemsetAsync(c->d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), S));
+    static const bool USE_BULK_TOKEN = [] { const char* e = std::getenv("MI_DMRECON_BULK_TOKEN"); return e ? std::atoi(e) != 0 : false; }();
+    std::unique_lock<std::mutex> bulk_token;
+    if (USE_BULK_TOKEN && c->device >= 0 && c->device < MI_MAX_DEVICES) {
+        const double t_wait = now_ms();
+        bulk_token = std::unique_lock<std::mutex>(g_bulk_token[c->device]);
+        if (stats) stats->ms_wait_bulk_token = now_ms() - t_wait;
+        mark("wait for the bulk token");
+    }
     if (!seeds.empty()) {
-        HIP_TRY(hipMemcpyAsync(c->d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, S));
+        HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, S));
+        HIP_TRY(hipMemcpyAsync(c->d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
+        HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), S));
         ev_begin(0); ev_work.push_back((unsigned)seeds.size()); ev_tail.push_back(0);
-        D.optimize(c->stream, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
+        D.optimize(S, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
                            c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
                            nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0, c->d_counters,
                            nullptr, nullptr, nullptr, nullptr, false, false, false);
         ev_end();
         ++n_launch;
         ev_begin(1);
-        mi_launch_apply_seeds(c->stream, c->d_jobs.p, c->d_work.p, c->d_results.p, (unsigned)seeds.size(), c->d_counters,
+        mi_launch_apply_seeds(S, c->d_jobs.p, c->d_work.p, c->d_results.p, (unsigned)seeds.size(), c->d_counters,
                               c->d_keys.p, c->d_keyoff.p);
         ev_end();
     }
@@ -1198,6 +1249,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
      * cold patch optimisation long (25-30 us) whichever way it is started -- the boundary between two launches is
      * only ~1.5 us of it -- and the tickets and counters of the persistent forms cost about what they save.
      * MI_DMRECON_TAIL_PERSIST_MAX=<entries>, _GRID=<workgroups>, MI_DMRECON_TAIL_SPIN_MS (all read per call). */
+    static const bool TAIL_PRIORITY = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PRIORITY"); return e ? std::atoi(e) != 0 : false; }();
     const int PERSIST_MODE = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PERSIST"); return e ? std::max(-1, std::min(2, std::atoi(e))) : 0; }();
     const unsigned PERSIST_MAX = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PERSIST_MAX"); return e ? (unsigned)std::atoi(e) : 512u; }();
     const unsigned PERSIST_SPIN_MS = [] { const char* e = std::getenv("MI_DMRECON_TAIL_SPIN_MS"); return e ? (unsigned)std::atoi(e) : 2000u; }();
@@ -1265,12 +1317,12 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             const int32_t dead = (int32_t)((uint32_t)dyn[j].flags | MI_JOB_DEAD);
             c->h_jobdyn[2 * j] = dead;      /* stays valid until the copy has run: the vector is not resized below */
             if (hipMemcpyAsync((char*)(c->d_jobs.p + j) + offsetof(DevJob, flags), &c->h_jobdyn[2 * j], sizeof(int32_t),
-                               hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+                               hipMemcpyHostToDevice, S) != hipSuccess) return -1;
         }
         return 0;
     };
     auto read_dyn = [&](DevJob* dst) -> hipError_t {        /* the job table (a few KB) with its flags / n_filled words */
-        return hipMemcpyAsync(dst, c->d_jobs.p, (size_t)nj * sizeof(DevJob), hipMemcpyDeviceToHost, c->stream);
+        return hipMemcpyAsync(dst, c->d_jobs.p, (size_t)nj * sizeof(DevJob), hipMemcpyDeviceToHost, S);
     };
 
     while (!done && n_alive > 0) {
@@ -1285,14 +1337,14 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             static const bool SEED_REOPT = [] { const char* e = std::getenv("MI_DMRECON_SEED_REOPT"); return e && std::atoi(e) != 0; }();
             const bool self = SEED_REOPT && round == 1;
             ev_begin(1);
-            D.generate(c->stream, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round, self,
+            D.generate(S, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round, self,
                        BANDS ? max_tiles_x : 0, BANDS ? max_tiles_y : 0);
             ev_end();
             TailPoll& P = c->h_poll[0];
-            HIP_TRY(hipMemcpyAsync(&P.rw[0], c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(&P.rw[0], c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
+            HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
             HIP_TRY(read_dyn(dyn_of(0)));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipStreamSynchronize(S));
             const unsigned n_work = P.rw[0];
             hc = P.hc;
             if (poll_views(dyn_of(0), n_work)) return fail(MI_DMRECON_EDEVICE, "hipMemcpyAsync(job flags) failed");
@@ -1301,11 +1353,11 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             const bool tail = n_work < TAIL_THRESHOLD;
             ev_begin(0); ev_work.push_back(n_work); ev_tail.push_back(0);
             if (tail)
-                D.optimize(c->stream, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+                D.optimize(S, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                    nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters,
                                    nullptr, nullptr, nullptr, nullptr, WIN_TAIL, self, false);
             else if (!USE_FOLLOW || BULK_LPV == 16 || self)
-                D.optimize(c->stream, BULK_LPV, BULK_LPV == 16 ? std::min(n_work, 16384u) : (n_work + BULK_PPW - 1) / BULK_PPW,
+                D.optimize(S, BULK_LPV, BULK_LPV == 16 ? std::min(n_work, 16384u) : (n_work + BULK_PPW - 1) / BULK_PPW,
                                    c->d_jobs.p, c->sc->d_views.p,
                                    c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
                                    c->d_counters, nullptr, nullptr, nullptr, nullptr, BULK_LPV == 16 ? WIN_TAIL : WIN_BULK, self, BANDS && BULK_LPV != 16);
@@ -1316,27 +1368,28 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                 const unsigned waves = (n_work + BULK_PPW - 1) / BULK_PPW;
                 unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
                 unsigned* fa = c->d_follow.p;
-                D.optimize(c->stream, BULK_LPV, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+                D.optimize(S, BULK_LPV, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
                                    c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt, WIN_BULK, false, BANDS);
                 /* the follow-up launch runs all remaining attempts of its entries back to back (third and fourth
                  * attempts are rare: a third launch would cost more in latency than it saves) */
-                D.optimize(c->stream, BULK_LPV, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+                D.optimize(S, BULK_LPV, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                    nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr, WIN_BULK, false, false);
                 ++n_launch;
             }
             ev_end();
             ++n_launch;
             ev_begin(1);
-            mi_launch_apply(c->stream, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
+            mi_launch_apply(S, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
             ev_end();
             if (tail) {
                 tail_known = n_work;
                 /* counters as of the end of the host-visible rounds (slot 2 of the poll buffer; read after the call) */
-                HIP_TRY(hipMemcpyAsync(&c->h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipMemcpyAsync(&c->h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
                 have_handover = true;
                 ++round; to_tail = true; break;
             }
         }
+        if (bulk_token.owns_lock()) bulk_token.unlock();       /* the next call's bulk rounds run while this one's tail does */
         if (first_phase_a) { mark("seeds + phase A rounds"); first_phase_a = false; }
         if (done || n_alive == 0) break;
         if (!to_tail) { truncated = true; break; }            /* round counters exhausted */
@@ -1344,6 +1397,16 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
          * this round's list, optimisations and state writes); lists and results ping-pong.  A chunk of rounds is
          * enqueued blind and its counters are read back while the NEXT chunk already runs (empty rounds are
          * microsecond no-ops), so the GPU never waits for the host inside the tail. */
+        /* MI_DMRECON_TAIL_PRIORITY=1: the tail rounds go to the context's high-priority stream -- each is a handful of
+         * latency-bound workgroups, and next to the bulk kernels of other calls on the same GPU they queue behind tens
+         * of thousands of bulk workgroups for every one of their ~600 dependent rounds.  Off by default: measured +6 %
+         * depth-maps/s with six host threads in most runs, but one run in five collapsed to a third of the rate with
+         * every kernel running alone (queues of two priorities apparently not scheduled side by side). */
+        if (c->stream_hi && TAIL_PRIORITY) {
+            HIP_TRY(hipEventRecord(c->xs_ev, c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream_hi, c->xs_ev, 0));
+            S = c->stream_hi;
+        }
         DevEntry* wcur = c->d_work.p;        /* list + results of the last executed round (round - 1) */
         DevEntry* wnext = c->d_work2.p;
         DevResult* rcur = c->d_results.p;
@@ -1360,10 +1423,10 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                 if (mode == 2) {
                     if (c->xcc_mask < 0) {                 /* once per context: do the workgroups of a grid reach all eight XCDs? */
                         unsigned m = 0;
-                        if (c->d_xcc.reserve(1) || hipMemsetAsync(c->d_xcc.p, 0, sizeof(unsigned), c->stream) != hipSuccess) return -1;
-                        mi_launch_xcc_probe(c->stream, c->d_xcc.p);
-                        if (hipMemcpyAsync(&m, c->d_xcc.p, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess
-                            || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+                        if (c->d_xcc.reserve(1) || hipMemsetAsync(c->d_xcc.p, 0, sizeof(unsigned), S) != hipSuccess) return -1;
+                        mi_launch_xcc_probe(S, c->d_xcc.p);
+                        if (hipMemcpyAsync(&m, c->d_xcc.p, sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
+                            || hipStreamSynchronize(S) != hipSuccess) return -1;
                         c->xcc_mask = (int)m;
                     }
                     if (c->xcc_mask != (1 << MI_TEAMS) - 1) mode = PERSIST_MODE > 0 ? 1 : 0;
@@ -1375,14 +1438,14 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                 const bool timed = stats != nullptr || trace;
                 if (mode == 2 && !teams_started) {
                     /* deal the list of the last round out to the teams (into the free buffer pair) */
-                    mi_launch_team_split(c->stream, wcur, rcur, c->d_round_work.p + (round - 1), wnext, rnext,
+                    mi_launch_team_split(S, wcur, rcur, c->d_round_work.p + (round - 1), wnext, rnext,
                                          d_team_work + (size_t)(round - 1) * MI_TEAMS, team_off);
                     std::swap(wcur, wnext); std::swap(rcur, rnext);
                     teams_started = true;
                 }
                 if (timed) { ev_begin(0); ev_work.push_back(0); ev_tail.push_back(2); }
                 const unsigned grid = PERSIST_GRID ? PERSIST_GRID : (mode == 2 ? 512u : std::min(512u, std::max(64u, tail_known)));
-                D.tail_persist(c->stream, grid, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
+                D.tail_persist(S, grid, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
                                mode == 2 ? d_team_work : c->d_round_work.p, d_ticket_head, d_ticket_done, mode == 2 ? team_off : nullptr,
                                round, (int)TAIL_CHUNK, c->d_counters, PERSIST_SPIN_MS);
                 if (timed) ev_end();
@@ -1391,7 +1454,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
                 const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
                 if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
-                D.tail(c->stream, tail_grid(), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
+                D.tail(S, tail_grid(), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
                                c->d_round_work.p, round, c->d_counters, WIN_TAIL, tail_known <= SPEC_MAX);
                 if (timed) ev_end();
                 std::swap(wcur, wnext);
@@ -1400,11 +1463,11 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             info[slot].ev_last = ev_work.size();
             TailPoll& P = c->h_poll[slot];
             if (mode == 2) {
-                if (hipMemcpyAsync(P.tw, d_team_work + (size_t)info[slot].first * MI_TEAMS, TAIL_CHUNK * MI_TEAMS * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
-            } else if (hipMemcpyAsync(P.rw, c->d_round_work.p + info[slot].first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
-            if (hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+                if (hipMemcpyAsync(P.tw, d_team_work + (size_t)info[slot].first * MI_TEAMS, TAIL_CHUNK * MI_TEAMS * sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess) return -1;
+            } else if (hipMemcpyAsync(P.rw, c->d_round_work.p + info[slot].first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess) return -1;
+            if (hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S) != hipSuccess) return -1;
             if (read_dyn(dyn_of(slot)) != hipSuccess) return -1;
-            if (hipEventRecord(c->poll_ev[slot], c->stream) != hipSuccess) return -1;
+            if (hipEventRecord(c->poll_ev[slot], S) != hipSuccess) return -1;
             return 0;
         };
         ran_tail = true;
@@ -1444,7 +1507,12 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
             if (!more_room) { truncated = true; break; }
             slot ^= 1;
         }
-        mi_launch_flatten(c->stream, c->d_maps.p, c->d_imaps.p, total_px);
+        mi_launch_flatten(S, c->d_maps.p, c->d_imaps.p, total_px);
+        if (S != c->stream) {                                  /* the rest of the call is ordered behind the tail again */
+            HIP_TRY(hipEventRecord(c->xs_ev, S));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->xs_ev, 0));
+            S = c->stream;
+        }
         if (truncated) break;
     }
     (void)ran_tail;

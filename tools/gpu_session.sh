@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun).  Round-2 measurement session.  Output: gpurun_out/$TAG/.
-TAG=${1:-s14}
+TAG=${1:-s23}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -17,26 +17,17 @@ except Exception as e:
     print('  (no json)', e)
 PY
 }
-echo "== persistent tail + device view selection: equality tests first (short spin limit: a hang must not take the box)"
-MI_DMRECON_TAIL_SPIN_MS=200 timeout -s KILL 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "persistent_tail or device_view" 2>&1 | tail -8
-B1="python bench.py --steps 8 --warmup 2 --streams 1 --steps-per-call 1 --no-cpu-baseline"
-BD="python bench.py --steps 30 --warmup 2 --no-cpu-baseline"
-L0=$PWD/mve_amd/csrc/libmi_dmrecon.so
-run1() { N=$1; shift
-  echo "== $N: 1 stream"; env "$@" timeout -s KILL 240 $B1 > $OUT/b1_$N.json 2> $OUT/b1_$N.err; show $OUT/b1_$N.json; tail -1 $OUT/b1_$N.err | cut -c1-200
-}
+BD="python bench.py --warmup 2 --no-cpu-baseline --steps 30"
 rund() { N=$1; shift
-  echo "== $N: default"; env "$@" timeout -s KILL 300 $BD > $OUT/bd_$N.json 2> $OUT/bd_$N.err; show $OUT/bd_$N.json
+  env "$@" timeout -s KILL 300 $BD $EXTRA > $OUT/bd_$N.json 2> $OUT/bd_$N.err; echo -n "$N "; show $OUT/bd_$N.json | cut -c1-150
 }
-run1 classic MI_DMRECON_TAIL_PERSIST=0
-run1 team_auto MI_DMRECON_TAIL_SPIN_MS=500
-run1 team_1024 MI_DMRECON_TAIL_SPIN_MS=500 MI_DMRECON_TAIL_PERSIST_MAX=1024
-run1 team_2048 MI_DMRECON_TAIL_SPIN_MS=500 MI_DMRECON_TAIL_PERSIST_MAX=2048
-run1 team_g256 MI_DMRECON_TAIL_SPIN_MS=500 MI_DMRECON_TAIL_PERSIST_GRID=256
-run1 oneteam MI_DMRECON_TAIL_PERSIST=1 MI_DMRECON_TAIL_SPIN_MS=500
-rund auto MI_DMRECON_TAIL_SPIN_MS=500
-rund team_always MI_DMRECON_TAIL_PERSIST=2 MI_DMRECON_TAIL_SPIN_MS=500
-rund team_always_g128 MI_DMRECON_TAIL_PERSIST=2 MI_DMRECON_TAIL_SPIN_MS=500 MI_DMRECON_TAIL_PERSIST_GRID=128
-echo "== trace of one call (auto)"
-MI_DMRECON_TRACE=1 timeout -s KILL 200 python bench.py --steps 1 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline 2>&1 | grep -E "phase|launch " > $OUT/trace_team.txt; grep phase $OUT/trace_team.txt | tail -6; grep launch $OUT/trace_team.txt | tail -40 | head -34
-echo "== pytest parity + fullsize"; MI_DMRECON_TAIL_SPIN_MS=500 timeout -s KILL 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -q --maxfail=4 2>&1 | tail -6
+for REP in 1 2 3; do
+  EXTRA="" rund base_$REP
+  EXTRA="" rund bulkprio_$REP MI_DMRECON_TAIL_PRIORITY=-1
+  EXTRA="" rund thr4096_$REP MI_DMRECON_TAIL_THRESHOLD=4096
+done
+EXTRA="" rund bulkprio_notoken MI_DMRECON_TAIL_PRIORITY=-1 MI_DMRECON_BULK_TOKEN=0
+EXTRA="" rund thr2048 MI_DMRECON_TAIL_THRESHOLD=2048
+EXTRA="" rund thr32768 MI_DMRECON_TAIL_THRESHOLD=32768
+EXTRA="" rund gvsdev MI_DMRECON_GVS_DEVICE=1
+EXTRA="--streams 3" rund gvsdev_t3 MI_DMRECON_GVS_DEVICE=1
