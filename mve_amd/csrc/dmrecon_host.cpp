@@ -247,7 +247,7 @@ struct mi_dmrecon_ctx {
     size_t h_dyn_cap = 0;
     std::vector<int32_t> h_jobdyn;           /* staging of the flag words written to dead jobs */
     DevBuf<int32_t> d_gvs_feat, d_gvs_out;   /* scratch and result of the device view selection */
-    DevBuf<float> d_gvs_base, d_gvs_score, d_gvs_benefit;
+    DevBuf<float> d_gvs_base, d_gvs_benefit;
     DevBuf<GvsRef> d_gvs_refs;
     std::vector<hipEvent_t> events;
 };
@@ -525,7 +525,7 @@ int plan_global_views_device(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
     const size_t m = hr.size();
     if (m == 0) return 0;
     if (c->d_gvs_refs.reserve(m) || c->d_gvs_feat.reserve(m * nf) || c->d_gvs_base.reserve(m * nv * nf)
-        || c->d_gvs_score.reserve(m * nv * nf) || c->d_gvs_benefit.reserve(m * nv) || c->d_gvs_out.reserve(m * (MI_GVS_MAX_OUT + 1)))
+        || c->d_gvs_benefit.reserve(m * nv) || c->d_gvs_out.reserve(m * (MI_GVS_MAX_OUT + 1)))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(view selection scratch) failed");
     GvsArgs a;
     a.sc.nv = (int)nv; a.sc.nf = (int)nf;
@@ -537,7 +537,7 @@ int plan_global_views_device(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
         a.aabb_min[k] = st->aabbMin[k]; a.aabb_max[k] = st->aabbMax[k];
         if (st->aabbMin[k] != -std::numeric_limits<float>::max() || st->aabbMax[k] != std::numeric_limits<float>::max()) a.use_box = 1;
     }
-    a.feat = c->d_gvs_feat.p; a.base = c->d_gvs_base.p; a.score = c->d_gvs_score.p; a.benefit = c->d_gvs_benefit.p;
+    a.feat = c->d_gvs_feat.p; a.base = c->d_gvs_base.p; a.benefit = c->d_gvs_benefit.p;
     a.out_ids = c->d_gvs_out.p; a.out_n = c->d_gvs_out.p + m * MI_GVS_MAX_OUT;
     HIP_TRY(hipMemcpyAsync(c->d_gvs_refs.p, hr.data(), m * sizeof(GvsRef), hipMemcpyHostToDevice, c->stream));
     mi_gvs_launch(c->stream, a, (int)m);
@@ -854,6 +854,7 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
     c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release(); c->d_follow.release(); c->d_follow_cnt.release();
     c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release(); c->d_round_tickets.release(); c->d_xcc.release();
+    c->d_gvs_feat.release(); c->d_gvs_out.release(); c->d_gvs_base.release(); c->d_gvs_benefit.release(); c->d_gvs_refs.release();
     if (c->h_poll) (void)hipHostFree(c->h_poll);
     if (c->h_dyn) (void)hipHostFree(c->h_dyn);
     for (int k = 0; k < 2; ++k) if (c->poll_ev[k]) (void)hipEventDestroy(c->poll_ev[k]);

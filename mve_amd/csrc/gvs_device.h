@@ -32,7 +32,6 @@ struct GvsArgs {
     /* scratch, per reference view (blockIdx.x): */
     int32_t* feat;                 /* [n_refs][nf] attached features, ascending */
     float* base;                   /* [n_refs][nv][nf] indexed by position in feat */
-    float* score;                  /* [n_refs][nf][nv] by position in feat, view fastest */
     float* benefit;                /* [n_refs][nv] */
     /* output */
     int32_t* out_ids;              /* [n_refs][MI_GVS_MAX_OUT] ascending */

@@ -9,6 +9,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --streams 1 --steps-per-call 1 --steps 20 --no-cpu-baseline > $OUT/bench_1thread.json 2> $OUT/bench_1thread.err
+# one host thread, the default five steps (100 reference views) per call: what the size of a launch does to the bulk kernel
+python bench.py --streams 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_1thread_5steps.json 2> $OUT/bench_1thread_5steps.err
 B1="python bench.py --steps 6 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline"
 B3="python bench.py --steps 30 --warmup 1 --no-cpu-baseline"
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s1 -o bench -- $B1 > $OUT/s1.log 2>&1
@@ -29,4 +31,4 @@ done
 rm -f $OUT/s1/bench_kernel_trace.csv $OUT/s3/bench_kernel_trace.csv
 find $OUT -name "*_kernel_trace.csv" -path "*pmc*" -delete
 du -sh $OUT
-cat $OUT/bench_default.json $OUT/bench_1thread.json | cut -c1-600
+cat $OUT/bench_default.json $OUT/bench_1thread.json $OUT/bench_1thread_5steps.json | cut -c1-600
