@@ -65,8 +65,10 @@ def test_c3_global_view_selection_vs_oracle(c3):
 def test_c3_view_selection_on_device(c3, monkeypatch):
     """gvs_device.hip agrees with the host loop -- which the test above pins to the oracle -- for every reference view
     of the full-size scene (the fixture's 20-view call is below the size from which the device is the default)."""
+    import os
     cfg, scene, ctx, st, res, stats = c3
-    assert stats["gvs_on_device"] == 0
+    if "MI_DMRECON_GVS_DEVICE" not in os.environ:                      # (the suite is also run with the switch forced)
+        assert stats["gvs_on_device"] == 0
     for ref in range(cfg["params"].n_views):
         for gmax in (20, 4):
             s = api.Settings(refViewNr=ref, scale=cfg["scale"], globalVSMax=gmax)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun).  Final evidence session of round 2: all GPU tests, smoke, then the profile collection.
-TAG=${1:-s24}
+# Runs ON THE GPU BOX (through gpurun).  The GPU test suite under every opt-in mode of the library.
+TAG=${1:-s26}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-echo "== pytest -m gpu"; timeout -s KILL 1200 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | tail -6
-echo "== smoke"; timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-echo "== profiles"; timeout -s KILL 1500 bash tools/collect_profiles.sh r2 2>&1 | tail -12
+for M in "MI_DMRECON_TAIL_PERSIST=2 MI_DMRECON_TAIL_SPIN_MS=500" "MI_DMRECON_TAIL_PERSIST=1 MI_DMRECON_TAIL_SPIN_MS=500" "MI_DMRECON_GVS_DEVICE=1" "MI_DMRECON_BULK_TOKEN=1 MI_DMRECON_TAIL_PRIORITY=1" "MI_DMRECON_RESERVE_CUS=32" "MI_DMRECON_GVS_TABLES=0"; do
+  echo "== $M"; env $M timeout -s KILL 900 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | tail -4
+done
