@@ -28,6 +28,41 @@ def test_library_exports_every_declared_symbol():
     assert sorted(api.EXPORTS) == names
 
 
+def header_struct(name):
+    """[(ctype, field)] of a typedef struct in include/mi_dmrecon.h, arrays as 'type[n]'."""
+    src = open(os.path.join(ROOT, "include", "mi_dmrecon.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(?:volatile )?(?:const )?([A-Za-z0-9_]+\s*\*?)\s*(.*)", decl)
+        ctype = m.group(1).replace(" ", "")
+        for f in m.group(2).split(","):
+            f = f.strip()
+            arr = re.match(r"([A-Za-z0-9_]+)\[(\d+)\]", f)
+            out.append((ctype + ("[%s]" % arr.group(2) if arr else ""), arr.group(1) if arr else f.lstrip("*").strip()))
+    return out
+
+
+def test_ctypes_mirrors_match_the_header_field_for_field():
+    """mve_amd/api.py restates the structs of include/mi_dmrecon.h for ctypes: same fields, same order, same types
+    (a field added on one side only shifts everything behind it silently)."""
+    C = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float,
+         "double": ctypes.c_double}
+    for cname, mirror in (("mi_dmrecon_settings", api.CSettings), ("mi_dmrecon_stats", api.CStats)):
+        want = header_struct(cname)
+        got = mirror._fields_
+        assert [f for _, f in want] == [f for f, _ in got], cname
+        for (ct, f), (_, gt) in zip(want, got):
+            arr = re.match(r"(\w+)\[(\d+)\]", ct)
+            expect = C[arr.group(1)] * int(arr.group(2)) if arr else C[ct]
+            assert ctypes.sizeof(gt) == ctypes.sizeof(expect) and gt._type_ == expect._type_, (cname, f)
+    assert ctypes.sizeof(api.CStats) == 8 * len(api.CStats._fields_)
+
+
 def test_settings_defaults_match_reference():
     # libs/dmrecon/settings.h:25-51
     L = api.load_library()
