@@ -1569,6 +1569,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && L
  * round's list.  The order of the list depends on timing; the results do not.
  */
 #define MI_TAIL_WAVES 4
+/* wavefronts per SIMD the speculative tail kernel is compiled for: 2 = 222 VGPRs, no spills (experiment: 3 = 168, so
+ * that a tail wavefront displaces one bulk wavefront of another call instead of two) */
+#ifndef MI_TAIL_SPEC_WAVES
+#define MI_TAIL_SPEC_WAVES 2
+#endif
 struct TailArgs {
     OptArgs o;                    /* o.work / o.results: this round's list and results (written here) */
     const DevEntry* prev_work;    /* previous round's list, results and entry count */
@@ -1592,7 +1597,7 @@ struct TailRes { PatchResult r; unsigned n_eval, n_pass; };
 __shared__ TailRes g_tail_res[MI_TAIL_WAVES];
 
 template <bool WIN, bool SPEC>
-__global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((amdgpu_waves_per_eu((SPEC ? 2 : (MI_FW == 7 ? 2 : MI_WAVES_PER_SIMD)), (SPEC ? 2 : MI_WAVES_PER_SIMD)))) void k_tail(TailArgs t) {
+__global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((amdgpu_waves_per_eu((SPEC ? MI_TAIL_SPEC_WAVES : (MI_FW == 7 ? 2 : MI_WAVES_PER_SIMD)), (SPEC ? MI_TAIL_SPEC_WAVES : MI_WAVES_PER_SIMD)))) void k_tail(TailArgs t) {
     const OptArgs& a = t.o;
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const unsigned n_prev = t.round_work[a.round - 1];

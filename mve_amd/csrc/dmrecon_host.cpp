@@ -813,6 +813,9 @@ static int create_streams(mi_dmrecon_ctx* c) {
         if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) c->stream = nullptr;
     }
     if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    /* the second stream: the highest priority the device offers (MI_DMRECON_TAIL_PRIORITY=1 runs the tail rounds on it).
+     * A stream confined to a few CUs was tried for the same purpose (hipExtStreamCreateWithCUMask, 16-128 CUs): the
+     * kernels of ALL streams of the process then ran one at a time, 304-655 against 725-746 depth-maps/s. */
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least
         && hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, greatest) == hipSuccess) {

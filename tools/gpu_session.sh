@@ -1,9 +1,35 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun).  The GPU test suite under every opt-in mode of the library.
-TAG=${1:-s26}
+# Runs ON THE GPU BOX (through gpurun).  Round-2 measurement session.  Output: gpurun_out/$TAG/.
+TAG=${1:-s27}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-for M in "MI_DMRECON_TAIL_PERSIST=2 MI_DMRECON_TAIL_SPIN_MS=500" "MI_DMRECON_TAIL_PERSIST=1 MI_DMRECON_TAIL_SPIN_MS=500" "MI_DMRECON_GVS_DEVICE=1" "MI_DMRECON_BULK_TOKEN=1 MI_DMRECON_TAIL_PRIORITY=1" "MI_DMRECON_RESERVE_CUS=32" "MI_DMRECON_GVS_TABLES=0"; do
-  echo "== $M"; env $M timeout -s KILL 900 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | tail -4
+show() { python - "$1" <<'PY'
+import sys, json
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d['roofline']
+    n = d['steps']
+    line = '  value %.1f maps/s  ms/step %.2f  frac %.4f' % (d['value'], d['ms_per_step'], r['frac'])
+    if 'per_kernel' in r:
+        line += ' | ' + ' | '.join('%s: %.0f x %.4f = %.2f ms' % (k[:10], v['launches']/n, v['avg_launch_ms'], v['launches']*v['avg_launch_ms']/n) for k, v in r['per_kernel'].items())
+    print(line)
+except Exception as e:
+    print('  (no json)', e)
+PY
+}
+BD="python bench.py --warmup 2 --no-cpu-baseline --steps 30"
+rund() { N=$1; shift
+  env "$@" timeout -s KILL 300 $BD $EXTRA > $OUT/bd_$N.json 2> $OUT/bd_$N.err; echo -n "$N "; show $OUT/bd_$N.json | cut -c1-170
+}
+for REP in 1 2 3; do
+  EXTRA="" rund base_$REP
+  EXTRA="" rund tcus64_$REP MI_DMRECON_TAIL_CUS=64
+  EXTRA="" rund tcus32_$REP MI_DMRECON_TAIL_CUS=32
+  EXTRA="" rund tw3_$REP MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_tw3.so
 done
+EXTRA="" rund tcus128 MI_DMRECON_TAIL_CUS=128
+EXTRA="" rund tcus16 MI_DMRECON_TAIL_CUS=16
+EXTRA="--streams 2" rund base_t2
+EXTRA="--streams 2" rund tcus64_t2 MI_DMRECON_TAIL_CUS=64
+EXTRA="--streams 2" rund tw3_t2 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_tw3.so
+EXTRA="--streams 1 --steps-per-call 1 --steps 8" rund tw3_1 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_tw3.so
