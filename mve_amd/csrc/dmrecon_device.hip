@@ -105,6 +105,16 @@ __shared__ float g_lut[256];                                   /* sRGB -> linear
 __shared__ float g_rays[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterViewDirs */
 __shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterColorSamples */
 __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelection ncc[] */
+/* the same for the latency layout: one patch per wavefront, at most MI_LAT_SLOTS wavefronts per workgroup.  Separate
+ * (smaller) arrays because a kernel's LDS is what it references: the tail kernels then ask for 4 KB instead of 12.8 KB,
+ * and a CU filled with bulk workgroups of another call (12 x 12.6 KB of 160 KB) has that much to spare */
+#define MI_LAT_SLOTS 4
+__shared__ float g_rays_lat[MI_LAT_SLOTS][3 * MI_NS];
+__shared__ float g_mcol_lat[MI_LAT_SLOTS][3 * MI_NS];
+__shared__ float g_ncc_lat[MI_LAT_SLOTS][MI_MAX_GLOBAL];
+template <int LPV> __device__ __forceinline__ float* lds_rays(int patch) { return LPV == 16 ? g_rays_lat[patch] : g_rays[patch]; }
+template <int LPV> __device__ __forceinline__ float* lds_mcol(int patch) { return LPV == 16 ? g_mcol_lat[patch] : g_mcol[patch]; }
+template <int LPV> __device__ __forceinline__ float* lds_ncc(int patch) { return LPV == 16 ? g_ncc_lat[patch] : g_ncc[patch]; }
 
 /* Texel windows.  The 25 samples of a (patch, neighbour view) pair fall into a small box of the view's mip level
  * (the level rule keeps the sample spacing in (1, 2] texels: at most 10 x 10 texels), and the box hardly moves
@@ -757,9 +767,9 @@ template <int LPV>
 __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSettings& st, const DevView* views, int lane) {
     typedef Lay<LPV> L;
     const float* s_lut = g_lut;
-    const float* rays = g_rays[L::patch(lane)];
-    const float* mcol = g_mcol[L::patch(lane)];
-    float* s_ncc = g_ncc[L::patch(lane)];
+    const float* rays = lds_rays<LPV>(L::patch(lane));
+    const float* mcol = lds_mcol<LPV>(L::patch(lane));
+    float* s_ncc = lds_ncc<LPV>(L::patch(lane));
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const int K = st.K;
     unsigned selmask = L::view_ballot(ps.sel >= 0, lane);
@@ -1039,8 +1049,8 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     typedef Lay<LPV> L;
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
-    float* rays = g_rays[L::patch(lane)];
-    float* mcol = g_mcol[L::patch(lane)];
+    float* rays = lds_rays<LPV>(L::patch(lane));
+    float* mcol = lds_mcol<LPV>(L::patch(lane));
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const int pl = slot * LPV + sub;                 /* lane index inside the patch */
     ps.job = job; ps.x = x; ps.y = y; ps.n_eval = 0; ps.n_pass = 0; ps.counters = counters;
@@ -1142,8 +1152,8 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     typedef Lay<LPV> L;
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
-    float* rays = g_rays[L::patch(lane)];
-    float* mcol = g_mcol[L::patch(lane)];
+    float* rays = lds_rays<LPV>(L::patch(lane));
+    float* mcol = lds_mcol<LPV>(L::patch(lane));
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const bool active = slot < st.K;               /* view slots 0..K-1 carry a view once the selection succeeded */
     /* the sums of a pass are consumed within the same turn */
@@ -1275,7 +1285,7 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
                                         unsigned& n_eval, unsigned& n_pass) {
     typedef Lay<LPV> L;
     PatchState& ps = R.ps;
-    const float* rays = g_rays[L::patch(lane)];
+    const float* rays = lds_rays<LPV>(L::patch(lane));
     n_eval += ps.n_eval; n_pass += ps.n_pass;
     res.conf = 0.f; res.nx = res.ny = res.nz = 0.f;
     res.iters = R.iter;
@@ -1569,6 +1579,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && L
  * round's list.  The order of the list depends on timing; the results do not.
  */
 #define MI_TAIL_WAVES 4
+static_assert(MI_TAIL_WAVES <= MI_LAT_SLOTS, "the latency layout's LDS holds one patch per wavefront of a tail workgroup");
 /* wavefronts per SIMD the speculative tail kernel is compiled for: 2 = 222 VGPRs, no spills (experiment: 3 = 168, so
  * that a tail wavefront displaces one bulk wavefront of another call instead of two) */
 #ifndef MI_TAIL_SPEC_WAVES

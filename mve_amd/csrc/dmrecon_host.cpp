@@ -162,6 +162,7 @@ struct ActiveCall {
     explicit ActiveCall(int d) : dev(d >= 0 && d < MI_MAX_DEVICES ? d : -1) { if (dev >= 0) g_active_calls[dev].fetch_add(1); }
     ~ActiveCall() { if (dev >= 0) g_active_calls[dev].fetch_sub(1); }
     bool alone() const { return dev < 0 || g_active_calls[dev].load() <= 1; }
+    int count() const { return dev < 0 ? 1 : g_active_calls[dev].load(); }
 };
 
 struct JobHost {          /* host-side plan of one reference view */
@@ -1271,6 +1272,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     unsigned* const d_ticket_head = c->d_round_tickets.p + (size_t)MI_MAX_ROUNDS * MI_TEAMS;
     unsigned* const d_ticket_done = c->d_round_tickets.p + 2 * (size_t)MI_MAX_ROUNDS * MI_TEAMS;
     bool teams_started = false;
+    static const bool SPEC_SHARED = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE_SHARED"); return e && std::atoi(e) != 0; }();
     static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
     /* texel windows in LDS: bit 0 = latency layout (tail rounds), bit 1 = throughput layout (bulk rounds) */
     const int USE_WIN = [] { const char* e = std::getenv("MI_DMRECON_WIN"); return e ? std::atoi(e) : MI_WIN_DEFAULT; }();
@@ -1454,15 +1456,22 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                                round, (int)TAIL_CHUNK, c->d_counters, PERSIST_SPIN_MS);
                 if (timed) ev_end();
                 round += (int)TAIL_CHUNK;
-            } else
+            } else {
+            /* Speculative attempts (workgroups of four wavefronts) buy latency -- for a call that has the GPU to itself
+             * or shares it with one other.  Next to the bulk rounds of several other calls the small form (one
+             * wavefront per workgroup, 168 registers, 4 KB of LDS) is placed without draining a CU first and takes
+             * less from them: measured 768-777 against 718-731 depth-maps/s with six host threads, 707 against 742
+             * with two.  MI_DMRECON_SPECULATE_SHARED=1: speculative regardless. */
+            const bool speculative = tail_known <= SPEC_MAX && (SPEC_SHARED || active_call.count() <= 2);
             for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
                 const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
                 if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
                 D.tail(S, tail_grid(), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
-                               c->d_round_work.p, round, c->d_counters, WIN_TAIL, tail_known <= SPEC_MAX);
+                               c->d_round_work.p, round, c->d_counters, WIN_TAIL, speculative);
                 if (timed) ev_end();
                 std::swap(wcur, wnext);
                 std::swap(rcur, rnext);
+            }
             }
             info[slot].ev_last = ev_work.size();
             TailPoll& P = c->h_poll[slot];

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun).  Round-2 measurement session.  Output: gpurun_out/$TAG/.
-TAG=${1:-s27}
+TAG=${1:-s29}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -21,15 +21,13 @@ BD="python bench.py --warmup 2 --no-cpu-baseline --steps 30"
 rund() { N=$1; shift
   env "$@" timeout -s KILL 300 $BD $EXTRA > $OUT/bd_$N.json 2> $OUT/bd_$N.err; echo -n "$N "; show $OUT/bd_$N.json | cut -c1-170
 }
+echo "== quick tests"; timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -3
 for REP in 1 2 3; do
-  EXTRA="" rund base_$REP
-  EXTRA="" rund tcus64_$REP MI_DMRECON_TAIL_CUS=64
-  EXTRA="" rund tcus32_$REP MI_DMRECON_TAIL_CUS=32
-  EXTRA="" rund tw3_$REP MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_tw3.so
+  EXTRA="" rund spec_$REP MI_DMRECON_SPECULATE_SHARED=1
+  EXTRA="" rund auto_$REP
 done
-EXTRA="" rund tcus128 MI_DMRECON_TAIL_CUS=128
-EXTRA="" rund tcus16 MI_DMRECON_TAIL_CUS=16
-EXTRA="--streams 2" rund base_t2
-EXTRA="--streams 2" rund tcus64_t2 MI_DMRECON_TAIL_CUS=64
-EXTRA="--streams 2" rund tw3_t2 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_tw3.so
-EXTRA="--streams 1 --steps-per-call 1 --steps 8" rund tw3_1 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_tw3.so
+EXTRA="--streams 2" rund auto_t2
+EXTRA="--streams 3" rund auto_t3
+EXTRA="--streams 4" rund auto_t4
+EXTRA="--streams 8 --steps 40" rund auto_t8
+EXTRA="--streams 1 --steps-per-call 1 --steps 10" rund auto_1
