@@ -121,6 +121,9 @@ typedef struct mi_dmrecon_stats {
     double  ms_plan_seeds;   /* host clock: feature seeds of all reference views (dmrecon.cc:232-258) */
     double  ms_wait_bulk_token; /* host clock: time this call waited for other calls' bulk rounds on the same GPU before
                               * its own (calls on one GPU take turns with the throughput half) */
+    int64_t n_merged_calls;  /* calls this execution served (concurrent calls on one scene with equal settings are merged
+                              * into one batch; the call that ran it carries the statistics) */
+    int64_t merged_into_other_call; /* 1: this call's views were reconstructed in another call's batch (all other fields 0) */
     int64_t n_tail_rounds_persistent; /* tail rounds that ran inside persistent launches (a chunk of rounds per launch;
                               * n_tail_launches counts such a launch once, ms_tail_kernel holds its measured time) */
 } mi_dmrecon_stats;

@@ -77,7 +77,8 @@ class CStats(ctypes.Structure):
                 ("n_stage", ctypes.c_int64), ("n_gather_pass", ctypes.c_int64),
                 ("n_view_replaced", ctypes.c_int64), ("n_iter14", ctypes.c_int64),
                 ("gvs_on_device", ctypes.c_int64), ("ms_plan_gvs", ctypes.c_double), ("ms_plan_seeds", ctypes.c_double),
-                ("ms_wait_bulk_token", ctypes.c_double), ("n_tail_rounds_persistent", ctypes.c_int64)]
+                ("ms_wait_bulk_token", ctypes.c_double), ("n_merged_calls", ctypes.c_int64),
+                ("merged_into_other_call", ctypes.c_int64), ("n_tail_rounds_persistent", ctypes.c_int64)]
 
 
 _lib = None

@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -194,8 +196,23 @@ struct SceneGeom {
     std::vector<float> plx;                  /* [(v1 * nv + v2) * nf + f]: parallax in degrees where both see f */
 };
 
+/* A reconstruct call waiting to be merged with others on the same scene (see mi_dmrecon_reconstruct) */
+struct MergeReq {
+    const mi_dmrecon_settings* st; int32_t n; const int32_t* refs; mi_dmrecon_maps* maps; int32_t* status; mi_dmrecon_stats* stats;
+    int rc = 0; std::string err; bool done = false; bool taken = false;
+};
+struct MergeQueue {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<MergeReq*> pending;          /* requests not yet part of a running batch */
+    int running = 0;                         /* batches being executed */
+    bool gathering = false;                  /* a leader is waiting a moment for more requests before it starts */
+    bool seen_company = false;               /* some call of this scene has met another one: worth a short wait for more */
+};
+
 struct SceneStore {
     int device = 0;
+    MergeQueue merge;
     SceneGeom geom;                          /* guarded by mu; dropped with views_dirty / set_features */
     std::mutex mu;                           /* guards the lazy upload of the DevView table */
     std::vector<HostView> views;
@@ -1057,9 +1074,9 @@ int mi_dmrecon_global_view_selection(mi_dmrecon_ctx* c, const mi_dmrecon_setting
     return 0;
 }
 
-int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views,
-                           mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out,
-                           mi_dmrecon_stats* stats) {
+static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views,
+                             mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out,
+                             mi_dmrecon_stats* stats) {
     const double t_begin = now_ms();
     double t_mark = t_begin;
     const bool trace_phases = std::getenv("MI_DMRECON_TRACE") != nullptr;
@@ -1612,6 +1629,111 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         }
     }
     return 0;
+}
+
+/*
+ * The entry point.  Calls that arrive at the same time on contexts of one scene (several host threads, each with a
+ * forked context) and ask for the same settings are MERGED into one batch: the reference views of a batch are
+ * independent jobs, so every caller gets exactly the maps its own call would have produced, but the batch pays the
+ * ~600 latency-bound tail rounds once and its bulk launches are large (one thread with 400 views per call reaches
+ * 905 depth-maps/s where six threads with 100 each reach 740-830).  This is what the shim does
+ * for mvs::DMRecon::start(); here for callers of the C ABI.
+ *   - A call that finds fewer than MI_DMRECON_MERGE_RUNNING (2) batches running becomes a LEADER: it takes every
+ *     request pending at that moment (after a wait of MI_DMRECON_MERGE_WINDOW_US = 150 us for more, only if calls of
+ *     this scene have met before), runs them as one batch on its own context and hands the results out.  The other
+ *     calls wait; whoever is still pending when a batch ends becomes the next leader.  A lone caller never waits.
+ *   - Per-view statuses go to their callers; a caller all of whose views failed gets the first failure as its return
+ *     code, as from its own call.  The statistics go to the leader (n_merged_calls = calls served); the other
+ *     callers get zeros with merged_into_other_call = 1, so that sums over calls stay right.
+ *   - Calls with a progress array (cancellation, status polling) are never merged.  MI_DMRECON_MERGE_CALLS=0: off.
+ */
+int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views,
+                           mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out,
+                           mi_dmrecon_stats* stats) {
+    /* (read per call: tests switch them) */
+    const bool MERGE = [] { const char* e = std::getenv("MI_DMRECON_MERGE_CALLS"); return e ? std::atoi(e) != 0 : true; }();
+    const int MAX_RUNNING = [] { const char* e = std::getenv("MI_DMRECON_MERGE_RUNNING"); return e ? std::max(1, std::atoi(e)) : 2; }();
+    const int WINDOW_US = [] { const char* e = std::getenv("MI_DMRECON_MERGE_WINDOW_US"); return e ? std::max(0, std::atoi(e)) : 150; }();
+    if (!MERGE || progress || !c || !st || !ref_views || !maps || n_refs <= 0)
+        return reconstruct_batch(c, st, n_refs, ref_views, maps, progress, status_out, stats);
+    MergeQueue& Q = c->sc->merge;
+    MergeReq me;
+    me.st = st; me.n = n_refs; me.refs = ref_views; me.maps = maps; me.status = status_out; me.stats = stats;
+    std::vector<MergeReq*> batch;
+    {
+        std::unique_lock<std::mutex> lock(Q.mu);
+        Q.pending.push_back(&me);
+        if (Q.pending.size() > 1 || Q.running > 0) Q.seen_company = true;
+        /* wait until my request has been served by another leader, or I can lead */
+        Q.cv.wait(lock, [&] { return me.done || (!me.taken && Q.running < MAX_RUNNING && !Q.gathering); });
+        if (me.done) { if (me.rc) g_err = me.err; return me.rc; }
+        ++Q.running;
+        me.taken = true;
+        Q.pending.erase(std::find(Q.pending.begin(), Q.pending.end(), &me));
+        batch.push_back(&me);
+        if (Q.seen_company && WINDOW_US > 0) {              /* others are probably on their way: let them join me */
+            Q.gathering = true;                              /* (nobody else starts to lead meanwhile) */
+            lock.unlock();
+            std::this_thread::sleep_for(std::chrono::microseconds(WINDOW_US));
+            lock.lock();
+            Q.gathering = false;
+        }
+        /* take every pending request with my settings, in arrival order */
+        for (size_t i = 0; i < Q.pending.size();) {
+            MergeReq* r = Q.pending[i];
+            if (std::memcmp(r->st, st, sizeof(*st)) == 0) { r->taken = true; batch.push_back(r); Q.pending.erase(Q.pending.begin() + i); }
+            else ++i;
+        }
+    }
+    Q.cv.notify_all();                                       /* requests with other settings may lead now */
+    int rc = 0;
+    if (batch.size() == 1) {
+        rc = reconstruct_batch(c, st, n_refs, ref_views, maps, nullptr, status_out, stats);
+        if (stats) stats->n_merged_calls = 1;
+    } else {
+        size_t total = 0;
+        for (MergeReq* r : batch) total += (size_t)r->n;
+        std::vector<int32_t> refs; refs.reserve(total);
+        std::vector<mi_dmrecon_maps> mm; mm.reserve(total);
+        std::vector<int32_t> status(total, 0);
+        for (MergeReq* r : batch) { refs.insert(refs.end(), r->refs, r->refs + r->n); mm.insert(mm.end(), r->maps, r->maps + r->n); }
+        mi_dmrecon_stats bs;
+        std::memset(&bs, 0, sizeof(bs));
+        const int brc = reconstruct_batch(c, st, (int32_t)total, refs.data(), mm.data(), nullptr, status.data(), &bs);
+        const std::string berr = brc ? g_err : std::string();
+        bs.n_merged_calls = (int64_t)batch.size();
+        /* a failure of the batch as a whole (device error, bad argument) is everybody's; anything else is per view */
+        const bool whole = brc == MI_DMRECON_EDEVICE || brc == MI_DMRECON_EINVAL;
+        size_t off = 0;
+        for (MergeReq* r : batch) {
+            int first = 0, n_ok = 0;
+            for (int i = 0; i < r->n; ++i) {
+                const int sv = whole ? brc : status[off + i];
+                if (r->status) r->status[i] = sv;
+                if (sv == 0) ++n_ok; else if (!first) first = sv;
+            }
+            if (whole) { r->rc = brc; r->err = berr; }
+            else if (n_ok == 0) {
+                r->rc = first;
+                r->err = first == MI_DMRECON_ECANCELLED ? "cancelled" : first == MI_DMRECON_EFOOTPRINT ? "Negative pixel footprint"
+                       : first == MI_DMRECON_EGVS ? "Global View Selection failed" : "reconstruction failed";
+            } else r->rc = 0;
+            if (r->stats) {
+                if (r == &me) *r->stats = bs;
+                else { std::memset(r->stats, 0, sizeof(*r->stats)); r->stats->merged_into_other_call = 1; }
+            }
+            off += (size_t)r->n;
+        }
+        rc = me.rc;
+        if (rc) g_err = me.err;
+    }
+    {
+        std::lock_guard<std::mutex> lock(Q.mu);
+        --Q.running;
+        for (MergeReq* r : batch) if (r != &me) r->done = true;
+    }
+    Q.cv.notify_all();
+    return rc;
 }
 
 int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n,

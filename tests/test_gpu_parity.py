@@ -297,6 +297,66 @@ def test_persistent_tail_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene
     gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
 
 
+def test_concurrent_calls_are_merged_and_keep_their_own_results(gpu_ctx, g1_scene, monkeypatch):
+    """Calls that arrive together on forked contexts of one scene with equal settings run as ONE batch
+    (mi_dmrecon_reconstruct's merge front end): every caller gets the maps, statuses and errors of its own call; the
+    statistics sit with the call that ran the batch; a call with other settings is not mixed in."""
+    import threading
+    gpu_ctx.load_scene(g1_scene)
+    st = api.Settings()
+    st3 = api.Settings(globalVSMax=3)
+    alone = {v: gpu_ctx.reconstruct(st, [v], want_views=True)[0] for v in range(5)}
+    alone3 = gpu_ctx.reconstruct(st3, [1, 2], want_views=True)
+    assert gpu_ctx.last_stats["n_merged_calls"] == 1 and gpu_ctx.last_stats["merged_into_other_call"] == 0
+    monkeypatch.setenv("MI_DMRECON_MERGE_WINDOW_US", "50000")           # the leader waits 50 ms: everybody joins
+    # view 4 gets a non-positive pixel footprint (fault injection): the call that asks for nothing else fails with the
+    # reference's exception, the call that asks for 4 among others gets its other views
+    monkeypatch.setenv("MI_DMRECON_INJECT_FOOTPRINT", "4")
+    plans = [(st, [0, 1]), (st, [2]), (st, [3, 1, 0]), (st, [4]), (st3, [1, 2]), (st, [3, 4])]
+    forks = [gpu_ctx.fork() for _ in plans]
+    go = threading.Barrier(len(plans))
+    out = [None] * len(plans)
+
+    def worker(i):
+        go.wait()
+        try:
+            out[i] = ("ok", forks[i].reconstruct(plans[i][0], plans[i][1], want_views=True), dict(forks[i].last_stats))
+        except Exception as e:                                          # noqa: BLE001 - the exception IS the result
+            out[i] = ("err", e, None)
+
+    for rep in range(2):
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(plans))]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert out[3][0] == "err" and isinstance(out[3][1], IndexError), out[3]    # std::out_of_range, its only view
+        for i in (0, 1, 2, 5):
+            assert out[i][0] == "ok", out[i]
+            for v, r in zip(plans[i][1], out[i][1]):
+                if v == 4:
+                    assert r["status"] == api.E_FOOTPRINT
+                    continue
+                assert r["status"] == 0
+                for k in ("depth", "conf", "dz", "normal", "views"):
+                    assert np.array_equal(r[k], alone[v][k]), (i, v, k)
+        assert out[4][0] == "ok"
+        for a, b in zip(out[4][1], alone3):
+            for k in ("depth", "conf", "views"):
+                assert np.array_equal(a[k], b[k]), k
+        served = sorted(o[2]["n_merged_calls"] for o in out if o[0] == "ok")
+        followers = sum(o[2]["merged_into_other_call"] for o in out if o[0] == "ok")
+        # five calls with equal settings -> one batch: four of them followers (the failing call shows no statistics)
+        assert followers >= 3 and max(served) in (1, 5), (served, followers)
+        assert out[4][2]["n_merged_calls"] <= 1                                   # other settings: its own batch
+    monkeypatch.setenv("MI_DMRECON_MERGE_CALLS", "0")
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(plans))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert all(o[2]["merged_into_other_call"] == 0 for o in out if o[0] == "ok")
+    monkeypatch.delenv("MI_DMRECON_INJECT_FOOTPRINT")
+    for f in forks:
+        f.close()
+
+
 def test_views_end_individually_in_a_batch(gpu_ctx, g1_scene, monkeypatch):
     """A cancelled view or a view whose footprint turns non-positive (patch_sampler.cc:78-82 throws) ends alone;
     the other views of the call finish, with the maps they get without it (apps/dmrecon/dmrecon.cc:314-317)."""
