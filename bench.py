@@ -307,6 +307,10 @@ def main():
                                       shape[0], cfg["local_neighbors"], p.n_views),
                        "sharding": sharding,
                        "host_threads_per_gpu": n_streams, "steps_per_call": spc,
+                       # concurrent calls with equal settings are merged into one batch by the library
+                       # (mi_dmrecon_reconstruct; MI_DMRECON_MERGE_CALLS=0 switches it off): how large the batches were
+                       "library_batches": int(n_calls - acc.get("merged_into_other_call", 0)),
+                       "views_per_library_batch": round(n_maps_rank / max(1, n_calls - acc.get("merged_into_other_call", 0)), 1),
                        "mean_fill": round(fill, 4)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

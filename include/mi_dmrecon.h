@@ -187,7 +187,11 @@ int  mi_dmrecon_global_view_selection(mi_dmrecon_ctx* ctx, const mi_dmrecon_sett
  * MI_DMRECON_ECANCELLED (progress[i].cancelled was set, before or during the run: dmrecon.cc:101-105,353) -- and
  * the maps of a view that did not finish are left untouched.  progress[i].filled counts that view's pixels.
  * Return value: 0 if at least one view finished; with a single view (or when every view failed) the failing
- * view's own code. */
+ * view's own code.
+ * Calls without a progress array that arrive at the same time on contexts of one scene (ctx_fork) with equal
+ * settings are run as ONE batch by one of the callers (the others wait for their maps): results, statuses and return
+ * codes are those of the separate calls, the statistics go to the call that ran the batch (stats.n_merged_calls;
+ * the others get zeros and stats.merged_into_other_call = 1).  MI_DMRECON_MERGE_CALLS=0 switches this off. */
 int  mi_dmrecon_reconstruct(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t n_refs,
                             const int32_t* ref_views, mi_dmrecon_maps* maps,
                             mi_dmrecon_progress* progress, int32_t* status_out, mi_dmrecon_stats* stats);
