@@ -1,20 +1,9 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun).  Merged concurrent calls: tests, then A/B of the default bench.
-TAG=${1:-s34}
+# Runs ON THE GPU BOX (through gpurun).  Final evidence session of round 2: all GPU tests, smoke, then the profile collection.
+TAG=${1:-s35}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-show() { python - "$1" <<'PY'
-import sys, json
-try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d['roofline']
-    n = d['steps']
-    line = '  value %.1f maps/s  ms/step %.2f  frac %.4f' % (d['value'], d['ms_per_step'], r['frac'])
-    if 'per_kernel' in r:
-        line += ' | ' + ' | '.join('%s: %.1f x %.4f = %.2f ms' % (k[:10], v['launches']/n, v['avg_launch_ms'], v['launches']*v['avg_launch_ms']/n) for k, v in r['per_kernel'].items())
-    print(line)
-except Exception as e:
-    print('  (no json)', e)
-PY
-}
-echo "== test"; timeout -s KILL 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "concurrent_calls" 2>&1 | tail -40
+echo "== pytest -m gpu"; timeout -s KILL 1200 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | tail -6
+echo "== smoke"; timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+echo "== profiles"; timeout -s KILL 1500 bash tools/collect_profiles.sh r2 2>&1 | tail -12
