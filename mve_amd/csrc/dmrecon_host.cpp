@@ -207,7 +207,7 @@ struct MergeQueue {
     std::vector<MergeReq*> pending;          /* requests not yet part of a running batch */
     int running = 0;                         /* batches being executed */
     bool gathering = false;                  /* a leader is waiting a moment for more requests before it starts */
-    bool seen_company = false;               /* some call of this scene has met another one: worth a short wait for more */
+    int company_credit = 0;                  /* > 0: calls of this scene have met lately -- worth a short wait for more */
 };
 
 struct SceneStore {
@@ -1640,7 +1640,7 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
  * for mvs::DMRecon::start(); here for callers of the C ABI.
  *   - A call that finds fewer than MI_DMRECON_MERGE_RUNNING (2) batches running becomes a LEADER: it takes every
  *     request pending at that moment (after a wait of MI_DMRECON_MERGE_WINDOW_US = 150 us for more, only if calls of
- *     this scene have met before), runs them as one batch on its own context and hands the results out.  The other
+ *     this scene have met within the last few calls), runs them as one batch on its own context and hands the results out.  The other
  *     calls wait; whoever is still pending when a batch ends becomes the next leader.  A lone caller never waits.
  *   - Per-view statuses go to their callers; a caller all of whose views failed gets the first failure as its return
  *     code, as from its own call.  The statistics go to the leader (n_merged_calls = calls served); the other
@@ -1663,7 +1663,8 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
     {
         std::unique_lock<std::mutex> lock(Q.mu);
         Q.pending.push_back(&me);
-        if (Q.pending.size() > 1 || Q.running > 0) Q.seen_company = true;
+        if (Q.pending.size() > 1 || Q.running > 0) Q.company_credit = 8;   /* company now: expect it for the next few calls */
+        else if (Q.company_credit > 0) --Q.company_credit;                  /* a caller that stays alone stops waiting */
         /* wait until my request has been served by another leader, or I can lead */
         Q.cv.wait(lock, [&] { return me.done || (!me.taken && Q.running < MAX_RUNNING && !Q.gathering); });
         if (me.done) { if (me.rc) g_err = me.err; return me.rc; }
@@ -1671,7 +1672,7 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         me.taken = true;
         Q.pending.erase(std::find(Q.pending.begin(), Q.pending.end(), &me));
         batch.push_back(&me);
-        if (Q.seen_company && WINDOW_US > 0) {              /* others are probably on their way: let them join me */
+        if (Q.company_credit > 0 && WINDOW_US > 0) {              /* others are probably on their way: let them join me */
             Q.gathering = true;                              /* (nobody else starts to lead meanwhile) */
             lock.unlock();
             std::this_thread::sleep_for(std::chrono::microseconds(WINDOW_US));
