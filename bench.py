@@ -226,7 +226,8 @@ def main():
                          "carries the strong-mode figure of the same run as `strong_scaling`.")
     ap.add_argument("--streams", type=int, default=6,
                     help="host threads per GPU, each driving its own forked context / HIP stream; steps are "
-                         "dealt round-robin (the reference runs its views under an OpenMP loop the same way)")
+                         "dealt round-robin (the reference runs its views under an OpenMP loop the same way).  Calls "
+                         "that meet inside the library are merged into one batch (config.views_per_library_batch)")
     ap.add_argument("--steps-per-call", type=int, default=0,
                     help="steps (passes over the rank's reference views) handed to ONE mi_dmrecon_reconstruct batch. "
                          "0 = the largest divisor of --steps that is <= 5")
