@@ -1634,7 +1634,8 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
 /*
  * The entry point.  Calls that arrive at the same time on contexts of one scene (several host threads, each with a
  * forked context) and ask for the same settings are MERGED into one batch: the reference views of a batch are
- * independent jobs, so every caller gets exactly the maps its own call would have produced, but the batch pays the
+ * independent jobs, so every caller gets the maps of its own views (up to what any change of batch composition does:
+ * the round at which a batch changes lane layouts, i.e. rounding -- tests/test_gpu_fullsize.py), but the batch pays the
  * ~600 latency-bound tail rounds once and its bulk launches are large (one thread with 400 views per call reaches
  * 905 depth-maps/s where six threads with 100 each reach 740-830).  This is what the shim does
  * for mvs::DMRecon::start(); here for callers of the C ABI.
