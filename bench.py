@@ -215,7 +215,9 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=240,
+                    help="timed steps (one step = all reference views of the scene once); the default keeps the GPU busy "
+                         "for several seconds so that an outside utilisation sampler sees the run")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -1,16 +1,13 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun).  Merge front end after the adaptive gather window: its test, two default bench lines.
-TAG=${1:-s36}
+# Runs ON THE GPU BOX (through gpurun).  The default bench line as the driver runs it.
+TAG=${1:-s37}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -s KILL 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "concurrent_calls or batch_equals or views_end" 2>&1 | tail -3
-for REP in 1 2; do
-  timeout -s KILL 300 python bench.py --no-cpu-baseline > $OUT/bd_$REP.json 2> $OUT/bd_$REP.err
-  python - $OUT/bd_$REP.json <<'PY'
+T0=$(date +%s.%N); timeout -s KILL 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+echo "wall $(python -c "import time,sys; print(round(time.time()-float(sys.argv[1]),1))" $T0) s"
+python - $OUT/bench_default.json <<'PY'
 import sys, json
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(round(d['value'], 1), 'maps/s', d['config']['library_batches'], 'batches of', d['config']['views_per_library_batch'], 'views; frac', round(d['roofline']['frac'], 4))
+print(round(d['value'], 1), 'maps/s', 'steps', d['steps'], d['config']['library_batches'], 'batches of', d['config']['views_per_library_batch'], 'views; frac', round(d['roofline']['frac'], 4), 'bulk', round(d['roofline']['per_kernel']['k_optimize<1> (host-visible rounds)']['frac'], 4), 'cpu', d['cpu_baseline']['value'], 'parity', d['parity']['within_bounds'])
 PY
-done
-timeout -s KILL 200 python bench.py --no-cpu-baseline --streams 1 --steps-per-call 1 --steps 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('1 thread:', round(d['value'],1))"
