@@ -1,22 +1,8 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun).  Merge policy sweep on the default bench plan.
-TAG=${1:-s38}
+# Runs ON THE GPU BOX (through gpurun).  The measurement / test session of the day; this one: the whole GPU suite and smoke.
+TAG=${1:-s39}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-run() { N=$1; shift
-  env "$@" timeout -s KILL 300 python bench.py --no-cpu-baseline $EXTRA > $OUT/$N.json 2> $OUT/$N.err
-  python - $OUT/$N.json $N <<'PY'
-import sys, json
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[2], round(d['value'], 1), 'maps/s;', d['config']['library_batches'], 'batches of', d['config']['views_per_library_batch'], 'views; bulk frac', round(d['roofline']['per_kernel']['k_optimize<1> (host-visible rounds)']['frac'], 4))
-PY
-}
-EXTRA="" run base_1
-EXTRA="" run run3 MI_DMRECON_MERGE_RUNNING=3
-EXTRA="" run win2000 MI_DMRECON_MERGE_WINDOW_US=2000
-EXTRA="" run run1_win0 MI_DMRECON_MERGE_RUNNING=1 MI_DMRECON_MERGE_WINDOW_US=0
-EXTRA="--streams 12" run t12
-EXTRA="--streams 3" run t3
-EXTRA="" run base_2
-EXTRA="" run nomerge MI_DMRECON_MERGE_CALLS=0
+echo "== pytest -m gpu"; timeout -s KILL 1200 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | tail -5
+echo "== smoke"; timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
