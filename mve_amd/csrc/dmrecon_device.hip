@@ -202,6 +202,63 @@ template <> struct Lay<1> {
     __device__ static __forceinline__ uint32_t* win(int lane) { return g_win1[lane]; }
 };
 
+/* Middle layout: view slot = a quad (6-7 samples per lane with 5 x 5 windows), patch = a 16-lane DPP row, FOUR patches
+ * per wavefront.  A patch is a quarter as long as in Lay<1> and four times as many wavefronts carry a list: for the
+ * late host-visible rounds, whose lists are fewer Lay<1> wavefronts than the GPU has slots (one generation of 150-250 us
+ * each however small they are).  Within a view: quad_perm DPP; across the four views of a row: ds_swizzle (xor 4 / 8
+ * inside 32 lanes; no LDS memory), in the same (v0 + v1) + (v2 + v3) order as the other layouts. */
+__device__ __forceinline__ int swz_xor4(int v) { return __builtin_amdgcn_ds_swizzle(v, (4 << 10) | 0x1F); }
+__device__ __forceinline__ int swz_xor8(int v) { return __builtin_amdgcn_ds_swizzle(v, (8 << 10) | 0x1F); }
+template <> struct Lay<4> {
+    static constexpr int PATCHES = 4;
+    __device__ static __forceinline__ int vslot(int lane) { return (lane >> 2) & 3; }
+    __device__ static __forceinline__ int sub(int lane) { return lane & 3; }
+    __device__ static __forceinline__ int patch(int lane) { return lane >> 4; }
+    __device__ static __forceinline__ float view_sum(float v) {      /* all 4 lanes of the quad get the sum */
+        v = fadd_i(v, dpp_xor1(__float_as_int(v)));
+        v = fadd_i(v, dpp_xor2(__float_as_int(v)));
+        return v;
+    }
+    __device__ static __forceinline__ double view_sum(double v) {
+        v += dmov(v, dpp_xor1);
+        v += dmov(v, dpp_xor2);
+        return v;
+    }
+    __device__ static __forceinline__ bool view_all(bool p) {
+        int v = p ? 1 : 0;
+        v &= dpp_xor1(v); v &= dpp_xor2(v);
+        return v != 0;
+    }
+    /* inputs are uniform within each view's quad */
+    __device__ static __forceinline__ float patch_sum(float v) {
+        v = fadd_i(v, swz_xor4(__float_as_int(v)));
+        v = fadd_i(v, swz_xor8(__float_as_int(v)));
+        return v;
+    }
+    __device__ static __forceinline__ double patch_sum(double v) {
+        v += dmov(v, swz_xor4);
+        v += dmov(v, swz_xor8);
+        return v;
+    }
+    __device__ static __forceinline__ float wave_sum(float v) { return v; }      /* unused in this layout */
+    __device__ static __forceinline__ int patch_or(int v) {
+        v |= dpp_xor1(v); v |= dpp_xor2(v); v |= swz_xor4(v); v |= swz_xor8(v);
+        return v;
+    }
+    /* lane (row, view K, my sub-lane): and_mask keeps bits 0, 1 and 4, or_mask sets the view */
+    template <int K> __device__ static __forceinline__ int from_view(int v) { return __builtin_amdgcn_ds_swizzle(v, ((K << 2) << 5) | 0x13); }
+    __device__ static __forceinline__ int view_xor1(int v) { return swz_xor4(v); }
+    __device__ static __forceinline__ int view_xor2(int v) { return swz_xor8(v); }
+    /* bit k = predicate of view slot k of my patch (taken from the slot's first lane) */
+    __device__ static __forceinline__ unsigned view_ballot(bool p, int lane) {
+        const unsigned r = (unsigned)(__ballot(p) >> (lane & ~15)) & 0xFFFFu;
+        return (r & 1u) | ((r >> 3) & 2u) | ((r >> 6) & 4u) | ((r >> 9) & 8u);
+    }
+    /* (no texel windows in this layout; the members only keep the WIN = true templates well-formed) */
+    static constexpr int WW = MI_WIN1_W, WH = MI_WIN1_H;
+    __device__ static __forceinline__ uint32_t* win(int lane) { return g_win1[lane]; }
+};
+
 template <> struct Lay<16> {
     static constexpr int PATCHES = 1;
     __device__ static __forceinline__ int vslot(int lane) { return lane >> 4; }
@@ -2402,6 +2459,8 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     if (lanes_per_view == 16) {
         if (windows) hipLaunchKernelGGL((k_optimize<16, true>), dim3(grid_blocks), dim3(WAVE), MI_WIN16_BYTES_PER_WAVE, s, a);
         else hipLaunchKernelGGL((k_optimize<16, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    } else if (lanes_per_view == 4) {
+        hipLaunchKernelGGL((k_optimize<4, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);       /* (no windows in this layout) */
     } else {
         if (windows) hipLaunchKernelGGL((k_optimize<1, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
         else hipLaunchKernelGGL((k_optimize<1, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);

@@ -1289,6 +1289,7 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
     unsigned* const d_ticket_head = c->d_round_tickets.p + (size_t)MI_MAX_ROUNDS * MI_TEAMS;
     unsigned* const d_ticket_done = c->d_round_tickets.p + 2 * (size_t)MI_MAX_ROUNDS * MI_TEAMS;
     bool teams_started = false;
+    const unsigned MID_THRESHOLD = [] { const char* e = std::getenv("MI_DMRECON_MID_THRESHOLD"); return e ? (unsigned)std::atoi(e) : 0u; }();
     static const bool SPEC_SHARED = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE_SHARED"); return e && std::atoi(e) != 0; }();
     static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
     /* texel windows in LDS: bit 0 = latency layout (tail rounds), bit 1 = throughput layout (bulk rounds) */
@@ -1388,14 +1389,20 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
                 /* throughput layout: one optimisation attempt per entry and launch; the entries whose pixel has further
                  * candidate hypotheses (about one in five) continue in a follow-up launch over a compacted list (its
                  * size stays on the device), so that the wavefronts of both launches are full */
-                const unsigned waves = (n_work + BULK_PPW - 1) / BULK_PPW;
+                /* MI_DMRECON_MID_THRESHOLD=<entries> (default 0 = off): lists below it run in the middle layout (4 lanes per
+                 * view, 4 patches per wavefront): a list of 14 000-50 000 entries is fewer Lay<1> wavefronts than the GPU
+                 * has slots and costs one 150-250 us generation however small it is */
+                const bool mid = !WIN_BULK && n_work < MID_THRESHOLD;
+                const int lpv = mid ? 4 : BULK_LPV;
+                const unsigned ppw = mid ? 4u : BULK_PPW;
+                const unsigned waves = (n_work + ppw - 1) / ppw;
                 unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
                 unsigned* fa = c->d_follow.p;
-                D.optimize(S, BULK_LPV, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
-                                   c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt, WIN_BULK, false, BANDS);
+                D.optimize(S, lpv, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+                                   c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt, WIN_BULK, false, BANDS && !mid);
                 /* the follow-up launch runs all remaining attempts of its entries back to back (third and fourth
                  * attempts are rare: a third launch would cost more in latency than it saves) */
-                D.optimize(S, BULK_LPV, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+                D.optimize(S, lpv, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
                                    nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr, WIN_BULK, false, false);
                 ++n_launch;
             }
@@ -1786,12 +1793,12 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     /* MI_DMRECON_HOOK_LPV=16 runs the hook through the latency layout (tests cover both layouts) */
     const char* lpv_env = std::getenv("MI_DMRECON_HOOK_LPV");
-    const int lpv = (lpv_env && std::atoi(lpv_env) == 16) ? 16 : 1;
-    const unsigned ppw = lpv == 16 ? 1u : (unsigned)MI_PATCHES_PER_WAVE;
+    const int lpv = (lpv_env && std::atoi(lpv_env) == 16) ? 16 : (lpv_env && std::atoi(lpv_env) == 4) ? 4 : 1;
+    const unsigned ppw = lpv == 16 ? 1u : lpv == 4 ? 4u : (unsigned)MI_PATCHES_PER_WAVE;
     /* MI_DMRECON_WIN (bit 0: latency layout, bit 1: throughput layout) selects the texel-window kernels here too */
     const char* win_env = std::getenv("MI_DMRECON_WIN");
     const int win_bits = win_env ? std::atoi(win_env) : MI_WIN_DEFAULT;
-    const bool windows = (win_bits & (lpv == 16 ? 1 : 2)) != 0;
+    const bool windows = lpv != 4 && (win_bits & (lpv == 16 ? 1 : 2)) != 0;
     D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw,
                        c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
                        c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,

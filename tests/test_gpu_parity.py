@@ -186,10 +186,10 @@ def test_patch_optimization_vs_oracle_many(ctx_g1, g1_scene):
         assert (np.abs(go[ok, 4:7] - oo[ok, 4:7]).max(1) <= 1e-3).mean() >= 0.98   # normals
 
 
-@pytest.mark.parametrize("lpv", ["16"])
+@pytest.mark.parametrize("lpv", ["16", "4"])
 def test_lane_layouts_agree(ctx_g1, g1, monkeypatch, lpv):
-    # the tail rounds run one patch per wavefront (16 lanes per view): same maths as the 16-patch throughput
-    # layout, different lane layout and summation order
+    # the tail rounds run one patch per wavefront (16 lanes per view), the middle layout four (4 lanes per view):
+    # same maths as the 16-patch throughput layout, different lane layout and summation order
     st = api.Settings(refViewNr=0)
     a, al = ctx_g1.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
     monkeypatch.setenv("MI_DMRECON_HOOK_LPV", lpv)
@@ -357,6 +357,23 @@ def test_concurrent_calls_are_merged_and_keep_their_own_results(gpu_ctx, g1_scen
     monkeypatch.delenv("MI_DMRECON_INJECT_FOOTPRINT")
     for f in forks:
         f.close()
+
+
+def test_middle_layout_rounds_agree_with_the_throughput_layout(gpu_ctx, g1_scene, h1_scene, monkeypatch):
+    """MI_DMRECON_MID_THRESHOLD: host-visible rounds with short lists in the middle lane layout -- the same maps up to
+    the summation order (what any change of layout does)."""
+    for scene, refs in ((g1_scene, [0, 1, 2, 3, 4]), (h1_scene, [0, 8])):
+        gpu_ctx.load_scene(scene)
+        monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "64")          # keep the rounds host-visible for long
+        a = gpu_ctx.reconstruct(api.Settings(), refs)
+        monkeypatch.setenv("MI_DMRECON_MID_THRESHOLD", "100000000")    # every one of them in the middle layout
+        b = gpu_ctx.reconstruct(api.Settings(), refs)
+        monkeypatch.delenv("MI_DMRECON_MID_THRESHOLD")
+        monkeypatch.delenv("MI_DMRECON_TAIL_THRESHOLD")
+        for x, y in zip(a, b):
+            m = map_parity(x["depth"], x["conf"], y["depth"], y["conf"])
+            assert m["iou"] >= 0.995 and m["rel_med"] <= 1e-4 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 5e-3, m
+    gpu_ctx.load_scene(g1_scene)
 
 
 def test_views_end_individually_in_a_batch(gpu_ctx, g1_scene, monkeypatch):
