@@ -67,19 +67,27 @@ def plan_calls(steps, streams, steps_per_call=0):
     return spc, n_calls, max(1, min(int(streams), n_calls))
 
 
+TRAFFIC_PROFILES = ("r3_traffic.json", "r2_traffic.json")     # newest first
+
+
 def measured_traffic(n_streams, spc):
-    """HBM-side bytes per STEP of the two optimise kernel families from the committed PMC passes of this round
-    (tools/collect_profiles.sh -> tools/summarize_profiles.py -> profiles/r2_traffic.json), at the call plan that
-    matches this run; ({}, None) when no profile is present.  PMC counters cannot be read from inside the timed run,
-    so this is the latest profiled value of the same command; FETCH_SIZE is already corrected (x2, calibrated)."""
-    f = os.path.join(ROOT, "profiles", "r2_traffic.json")
-    if not os.path.exists(f):
-        return {}, None
-    j = json.load(open(f))
-    want = "1 host thread" if (n_streams == 1 and spc == 1) else "default"
-    for plan, fams in j.get("plans", {}).items():
-        if plan.startswith(want):
-            return fams, "profiles/r2_traffic.json (%s; %s)" % (plan, j.get("correction", ""))
+    """HBM-side bytes per STEP of the optimise kernel families from the committed PMC passes
+    (tools/collect_profiles.sh -> tools/summarize_profiles.py -> profiles/r<N>_traffic.json), at the call plan closest
+    to this run: "1 host thread" profiles for a lone 20-view call, "default" (several host threads, five steps per
+    call) otherwise; ({}, None) when no profile is present.  PMC counters cannot be read from inside the timed run: this
+    is a STORED value of an earlier run of the same workload, labelled as such (`stored_profile`, `profiled_plan`);
+    FETCH_SIZE is already corrected (x2, calibrated)."""
+    for name in TRAFFIC_PROFILES:
+        f = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(f):
+            continue
+        j = json.load(open(f))
+        want = "1 host thread" if (n_streams == 1 and spc == 1) else "default"
+        for plan, fams in j.get("plans", {}).items():
+            if plan.startswith(want):
+                return fams, {"file": "profiles/" + name, "profiled_plan": plan, "stored_profile": True,
+                              "this_run_plan": "%d host thread(s), %d step(s) per call" % (n_streams, spc),
+                              "correction": j.get("correction", "")}
     return {}, None
 
 
@@ -184,11 +192,7 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup):
             t_calls[i] = time.perf_counter() - tw
         warmed.wait()
         go.wait()
-        # phase offset between the host threads (inside the timed region): the throughput-bound rounds of one
-        # stream then coincide with the latency-bound tail of another from the first step on, as they do in the
-        # steady state of a long run anyway
-        if i:
-            time.sleep(i * max(t_calls) / n_streams)
+        # (no phase offsets: every host thread starts at once; calls that meet inside the library are merged)
         for _ in range(n):
             r = c.reconstruct(st, refs, want_normal=False, out=o)   # synchronous: returns with the maps on the host
             with lock:
@@ -212,6 +216,115 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup):
     return elapsed, acc, last
 
 
+def roofline(acc, n_maps, scene, cfg, n_streams, spc, elapsed):
+    """The `roofline` object of a run from its summed call statistics: HBM bound, ALGORITHMIC bytes (SURVEY 8d:
+    300 B per patch-view evaluation + 75 B per patch + 28 B per filled pixel + the compulsory image bytes, counted on
+    the device) over the HIP-event durations of the optimise launches of the timed region."""
+    p = cfg["params"]
+    b_alg = algorithmic_bytes(acc, n_maps, scene, cfg)
+    opt_s = acc["ms_opt_kernel"] / 1000.0
+    n_launch = max(int(acc["n_launches"]), 1)
+    achieved = b_alg / opt_s / 1e9 if opt_s > 0 else 0.0
+    fams, traffic_src = measured_traffic(n_streams, spc)
+    steps_rank = max(n_maps // p.n_views, 1)
+
+    def fam_bytes(name):                                  # stored HBM-side bytes of a family, scaled to this run's steps
+        v = fams.get(name)
+        return None if v is None else (v["read_bytes_per_step"] + v["written_bytes_per_step"]) * steps_rank
+    t_bulk = fam_bytes("k_optimize<1> (host-visible rounds)")
+    t_tail = fam_bytes("k_tail + k_front (tail rounds)") or fam_bytes("k_tail (blind tail rounds)")
+    traffic = None if t_bulk is None or t_tail is None else (t_bulk + t_tail) / n_launch
+    # the kernels behind `achieved`, each with its own share of the algorithmic bytes
+    bulk_stats = {"n_eval": acc.get("n_eval_bulk", 0), "n_patch": acc.get("n_patch_bulk", 0), "n_filled": acc.get("n_filled_bulk", 0)}
+    b_bulk = algorithmic_bytes(bulk_stats, n_maps, scene, cfg)        # the compulsory bytes go with the bulk rounds
+    b_tail = b_alg - b_bulk                                            # tail rounds: k_tail launches + the front kernel
+    ms_bulk, ms_tail, ms_front = acc.get("ms_bulk_kernel", 0.0), acc.get("ms_tail_kernel", 0.0), acc.get("ms_front_kernel", 0.0)
+    nb, nt = max(int(acc.get("n_bulk_launches", 0)), 1), max(int(acc.get("n_tail_launches", 0)), 1)
+    n_pass = acc.get("n_pass", 0)
+    # the same fraction on the sampling passes actually executed: one fused pass gathers a patch-view's 100 texels
+    # once where the reference evaluates -- and n_eval counts -- it up to twice
+    b_pass = b_alg - 300.0 * acc["n_eval"] + 300.0 * n_pass
+    ms_tail_all = ms_tail + ms_front
+
+    def fam(launches, ms, b, t):
+        return {"launches": launches, "avg_launch_ms": ms / max(launches, 1), "algorithmic_bytes_per_launch": b / max(launches, 1),
+                "traffic": None if t is None else t / max(launches, 1),
+                "traffic_over_algorithmic": None if (t is None or b <= 0) else t / b,
+                "achieved": (b / (ms / 1e3) / 1e9) if ms > 0 else None,
+                "frac": (b / (ms / 1e3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else None}
+    per_kernel = {"k_optimize<1> (host-visible rounds)": fam(nb, ms_bulk, b_bulk, t_bulk),
+                  "k_tail + k_front (tail rounds)": dict(
+                      fam(nt + int(acc.get("n_front_launches", 0)), ms_tail_all, b_tail, t_tail),
+                      k_tail_launches=nt, k_tail_ms=ms_tail, k_front_launches=int(acc.get("n_front_launches", 0)),
+                      k_front_ms=ms_front, k_front_rounds_slowest_view=int(acc.get("n_front_rounds_max", 0)),
+                      k_front_attempts=int(acc.get("n_front_attempts", 0)))}
+    bulk_pass_frac = None
+    if ms_bulk > 0 and acc["n_eval"] > 0:
+        # the bulk kernel's share of the executed passes follows its share of the evaluations
+        bulk_pass_frac = (b_bulk - 300.0 * bulk_stats["n_eval"] * (1.0 - n_pass / acc["n_eval"])) / (ms_bulk / 1e3) / 1e9 / HBM_PEAK_GBS
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_on_passes": (b_pass / opt_s / 1e9 / HBM_PEAK_GBS) if opt_s > 0 else None,
+            "bulk_kernel_frac": per_kernel["k_optimize<1> (host-visible rounds)"]["frac"],
+            "bulk_kernel_frac_on_passes": bulk_pass_frac,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "k_optimize<1> + k_tail + k_front (patch optimisation, both lane layouts)", "launches": n_launch,
+            "avg_launch_ms": acc["ms_opt_kernel"] / n_launch,
+            "algorithmic_bytes_per_launch": b_alg / n_launch,
+            "traffic_over_algorithmic": None if traffic is None else traffic * n_launch / b_alg,
+            "n_eval": int(acc["n_eval"]), "n_patch": int(acc["n_patch"]), "n_filled": int(acc["n_filled"]),
+            "n_pass": int(n_pass),
+            # bytes the sampling passes actually requested (RGBA8 footprints: 400 B per pass)
+            "gathered_bytes_per_launch": 400.0 * n_pass / n_launch,
+            "per_kernel": per_kernel,
+            # the secondary roofs SURVEY 8d names (the real limiters are on-chip, DESIGN.md section 5):
+            # fp32 VALU with SURVEY's algorithmic flop counts (3.6 kflop per derivative evaluation, 1.6 kflop
+            # per colour evaluation, mix 19.9 : 11.9), and the L2 with the bytes the passes request from it
+            "secondary_roofs": {
+                "valu_fp32": {"algorithmic_flop": 2.85e3 * acc["n_eval"], "achieved": 2.85e3 * acc["n_eval"] / opt_s / 1e12 if opt_s > 0 else None,
+                              "peak": 157.3, "unit": "TFLOP/s", "frac": 2.85e3 * acc["n_eval"] / opt_s / 1e12 / 157.3 if opt_s > 0 else None},
+                "l2": {"requested_bytes": 400.0 * n_pass, "achieved": 400.0 * n_pass / opt_s / 1e9 if opt_s > 0 else None,
+                       "peak": 34500.0, "unit": "GB/s", "frac": 400.0 * n_pass / opt_s / 1e9 / 34500.0 if opt_s > 0 else None}},
+            "kernel_time_share": opt_s / elapsed if elapsed > 0 else None,
+            # the launches of the host threads' streams overlap on the GPU, so each launch's own duration
+            # (above, as the contract asks) stretches; the same bytes over the wall time of the region:
+            "aggregate_achieved": b_alg / elapsed / 1e9 if elapsed > 0 else None,
+            "aggregate_frac": b_alg / elapsed / 1e9 / HBM_PEAK_GBS if elapsed > 0 else None}
+
+
+def run_one_call(ctx, st, views, scene, cfg, n_timed=10):
+    """What a user of apps/dmrecon gets: ONE library call for the scene's reference views (20 on C3) on one host
+    thread, nothing else on the GPU.  Measured after the timed region, same resident scene: 2 warm-up calls, then
+    n_timed calls; ms per call (median / mean), depth-maps/s, where the time goes, and the roofline of that call."""
+    out = ctx.alloc_outputs(st, views, want_normal=False, pinned=True)
+    for _ in range(2):
+        ctx.reconstruct(st, views, want_normal=False, out=out)
+    ts, acc = [], {}
+    for _ in range(n_timed):
+        t0 = time.perf_counter()
+        ctx.reconstruct(st, views, want_normal=False, out=out)
+        ts.append(time.perf_counter() - t0)
+        for k, v in ctx.last_stats.items():
+            acc[k] = acc.get(k, 0) + v
+    med = float(np.median(ts))
+    roof = roofline(acc, len(views) * n_timed, scene, cfg, 1, 1, float(np.sum(ts)))
+    pk = roof["per_kernel"]
+    return {"what": "one library call = the %d reference views of the scene once, 1 host thread, GPU otherwise idle; "
+                    "median of %d calls after the timed region" % (len(views), n_timed),
+            "ms_per_call": 1000.0 * med, "ms_per_call_mean": 1000.0 * float(np.mean(ts)),
+            "depth_maps_per_s": len(views) / med,
+            "ms_host_planning": (acc.get("ms_plan_gvs", 0.0) + acc.get("ms_plan_seeds", 0.0)) / n_timed,
+            "ms_bulk_kernel": acc.get("ms_bulk_kernel", 0.0) / n_timed,
+            "ms_tail_kernel": acc.get("ms_tail_kernel", 0.0) / n_timed,
+            "ms_front_kernel": acc.get("ms_front_kernel", 0.0) / n_timed,
+            "rounds": int(acc.get("n_rounds", 0) / n_timed), "front_first_round": int(acc.get("front_first_round", 0) / n_timed),
+            "bulk_launches": int(acc.get("n_bulk_launches", 0) / n_timed),
+            "bulk_kernel_avg_launch_ms": pk["k_optimize<1> (host-visible rounds)"]["avg_launch_ms"],
+            "bulk_kernel_frac": roof["bulk_kernel_frac"], "bulk_kernel_frac_on_passes": roof["bulk_kernel_frac_on_passes"],
+            "tail_frac": pk["k_tail + k_front (tail rounds)"]["frac"],
+            "frac": roof["frac"], "frac_on_passes": roof["frac_on_passes"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,6 +334,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-call", action="store_true",
+                    help="skip the `one_call` object (one 20-view library call on one host thread, measured after the timed region)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1 only.  weak (default): every rank reconstructs all views of its own scene replica per "
                          "step.  strong (BASELINE config 4): ONE scene, its reference views dealt round-robin over the "
@@ -272,32 +387,19 @@ def main():
                   "note": "BASELINE config 4: the %d reference views of ONE scene dealt round-robin over the %d ranks, "
                           "same steps / warm-up / call plan; depth maps of all ranks / slowest rank" % (p.n_views, world)}
 
+    one_call = None
+    if rank == 0 and world == 1 and not args.no_one_call:
+        one_call = run_one_call(ctx, st, all_views, scene, cfg)
+
     if rank == 0:
         res = last["res"]
         shape = last["shape"]
         fill = float(np.mean([(c > 0).mean() for _, c in res]))
-        b_alg = algorithmic_bytes(acc, n_maps_rank, scene, cfg)
-        opt_s = acc["ms_opt_kernel"] / 1000.0
-        n_launch = max(int(acc["n_launches"]), 1)
-        achieved = b_alg / opt_s / 1e9 if opt_s > 0 else 0.0
-        fams, traffic_src = measured_traffic(n_streams, spc)
-        steps_rank = max(n_maps_rank // p.n_views, 1)
-
-        def fam_bytes(name):                                  # measured HBM-side bytes of a family over this run
-            v = fams.get(name)
-            return None if v is None else (v["read_bytes_per_step"] + v["written_bytes_per_step"]) * steps_rank
-        t_bulk, t_tail = fam_bytes("k_optimize<1> (host-visible rounds)"), fam_bytes("k_tail (blind tail rounds)")
-        traffic = None if t_bulk is None or t_tail is None else (t_bulk + t_tail) / n_launch
-        # the two kernels behind `achieved`, each with its own share of the algorithmic bytes
-        bulk_stats = {"n_eval": acc.get("n_eval_bulk", 0), "n_patch": acc.get("n_patch_bulk", 0), "n_filled": acc.get("n_filled_bulk", 0)}
-        b_bulk = algorithmic_bytes(bulk_stats, n_maps_rank, scene, cfg)        # the compulsory bytes go with the bulk rounds
-        b_tail = b_alg - b_bulk
-        ms_bulk, ms_tail = acc.get("ms_bulk_kernel", 0.0), acc.get("ms_tail_kernel", 0.0)
-        nb, nt = max(int(acc.get("n_bulk_launches", 0)), 1), max(int(acc.get("n_tail_launches", 0)), 1)
         sharding = ("reference views are independent; each rank reconstructs all views of its scene replica per step, no collective"
                     if (world == 1 or args.scaling == "weak") else
                     "ONE scene: its reference views are dealt round-robin over the ranks (shard_views), every rank holds the "
                     "whole scene resident, no collective")
+        roof = roofline(acc, n_maps_rank, scene, cfg, n_streams, spc, elapsed)
         out = {
             "metric": "depth-maps/sec (1920x1080, 20 views, scale=2)" if args.config == "C3" else "depth-maps/sec (%s)" % args.config,
             "value": n_maps / elapsed, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -315,45 +417,10 @@ def main():
                        "library_batches": int(n_calls - acc.get("merged_into_other_call", 0)),
                        "views_per_library_batch": round(n_maps_rank / max(1, n_calls - acc.get("merged_into_other_call", 0)), 1),
                        "mean_fill": round(fill, 4)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_optimize<1> + k_tail (patch optimisation, both lane layouts)", "launches": n_launch,
-                         "avg_launch_ms": acc["ms_opt_kernel"] / n_launch,
-                         "algorithmic_bytes_per_launch": b_alg / n_launch,
-                         "traffic_over_algorithmic": None if traffic is None else traffic * n_launch / b_alg,
-                         "n_eval": int(acc["n_eval"]), "n_patch": int(acc["n_patch"]), "n_filled": int(acc["n_filled"]),
-                         "n_pass": int(acc.get("n_pass", 0)),
-                         "n_window_stages": int(acc.get("n_stage", 0)), "n_gather_passes": int(acc.get("n_gather_pass", 0)),
-                         # bytes the sampling passes actually requested (one pass gathers a patch-view's 100 texels once,
-                         # RGBA8, where the reference evaluates -- and n_eval counts -- it up to twice)
-                         "gathered_bytes_per_launch": 400.0 * acc.get("n_pass", 0) / n_launch,
-                         "per_kernel": {
-                             "k_optimize<1> (host-visible rounds)": {
-                                 "launches": nb, "avg_launch_ms": ms_bulk / nb, "algorithmic_bytes_per_launch": b_bulk / nb,
-                                 "traffic": None if t_bulk is None else t_bulk / nb,
-                                 "traffic_over_algorithmic": None if t_bulk is None else t_bulk / b_bulk,
-                                 "achieved": (b_bulk / (ms_bulk / 1e3) / 1e9) if ms_bulk > 0 else None,
-                                 "frac": (b_bulk / (ms_bulk / 1e3) / 1e9 / HBM_PEAK_GBS) if ms_bulk > 0 else None},
-                             "k_tail (blind tail rounds)": {
-                                 "launches": nt, "avg_launch_ms": ms_tail / nt, "algorithmic_bytes_per_launch": b_tail / nt,
-                                 "traffic": None if t_tail is None else t_tail / nt,
-                                 "traffic_over_algorithmic": None if t_tail is None else t_tail / b_tail,
-                                 "achieved": (b_tail / (ms_tail / 1e3) / 1e9) if ms_tail > 0 else None,
-                                 "frac": (b_tail / (ms_tail / 1e3) / 1e9 / HBM_PEAK_GBS) if ms_tail > 0 else None}},
-                         # the secondary roofs SURVEY 8d names (the real limiters are on-chip):
-                         # fp32 VALU with SURVEY's algorithmic flop counts (3.6 kflop per derivative evaluation, 1.6 kflop
-                         # per colour evaluation, mix 19.9 : 11.9), and the L2 with the bytes the passes request from it
-                         "secondary_roofs": {
-                             "valu_fp32": {"algorithmic_flop": 2.85e3 * acc["n_eval"], "achieved": 2.85e3 * acc["n_eval"] / opt_s / 1e12 if opt_s > 0 else None,
-                                           "peak": 157.3, "unit": "TFLOP/s", "frac": 2.85e3 * acc["n_eval"] / opt_s / 1e12 / 157.3 if opt_s > 0 else None},
-                             "l2": {"requested_bytes": 400.0 * acc.get("n_pass", 0), "achieved": 400.0 * acc.get("n_pass", 0) / opt_s / 1e9 if opt_s > 0 else None,
-                                    "peak": 34500.0, "unit": "GB/s", "frac": 400.0 * acc.get("n_pass", 0) / opt_s / 1e9 / 34500.0 if opt_s > 0 else None}},
-                         "kernel_time_share": opt_s / elapsed if elapsed > 0 else None,
-                         # the launches of the host threads' streams overlap on the GPU, so each launch's own duration
-                         # (above, as the contract asks) stretches; the same bytes over the wall time of the region:
-                         "aggregate_achieved": b_alg / elapsed / 1e9 if elapsed > 0 else None,
-                         "aggregate_frac": b_alg / elapsed / 1e9 / HBM_PEAK_GBS if elapsed > 0 else None},
+            "roofline": roof,
         }
+        if one_call is not None:
+            out["one_call"] = one_call
         if strong is not None:
             out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:

@@ -98,34 +98,38 @@ typedef struct mi_dmrecon_stats {
     int64_t n_rounds;       /* propagation sweeps */
     int64_t n_launches;     /* launches of the optimisation kernel */
     double  ms_total;       /* wall time of the call, host clock */
-    double  ms_opt_kernel;  /* hipEvent durations of the optimisation kernel on the context's stream, summed: every
-                             * launch of the host-visible rounds; in the blind tail every 8th round is bracketed by
-                             * events (an event pair costs ~12 us of queue time per round) and their mean is
-                             * multiplied by the number of tail launches that had work */
+    double  ms_opt_kernel;  /* hipEvent durations of the optimisation kernels on the context's stream, summed
+                             * (= ms_bulk_kernel + ms_tail_kernel + ms_front_kernel) */
     double  ms_sweep_kernels; /* sum of hipEvent durations of the timed generate/apply kernels */
     /* the two halves of ms_opt_kernel, with their launch counts */
     double  ms_bulk_kernel; /* host-visible rounds (throughput layout; seeds; the hand-over round) */
-    double  ms_tail_kernel; /* blind tail rounds (latency layout), extrapolated as described above */
+    double  ms_tail_kernel; /* blind tail rounds (latency layout, one launch per round): every 8th round is bracketed by
+                             * events (an event pair costs ~12 us of queue time per round) and their mean is multiplied by
+                             * the number of tail launches that had work */
     int64_t n_bulk_launches;
     int64_t n_tail_launches;
     int64_t n_pass;         /* fused sampling passes actually run (each gathers the 100 texels of one patch-view
                              * once; a pass can stand for two of the reference's evaluations, see n_eval) */
     int64_t truncated;      /* 1 if the propagation ran out of round counters (the call fails with EDEVICE) */
     int64_t n_eval_bulk, n_patch_bulk, n_filled_bulk;   /* the share of n_eval / n_patch / n_filled of the host-visible rounds */
-    int64_t n_stage;        /* texel windows staged into LDS (a patch-view needs one unless its window moves out of the box) */
-    int64_t n_gather_pass;  /* passes of the window kernels that sampled by global gathers after all (window larger than a box) */
     int64_t n_view_replaced; /* local views dropped by replaceViews (patch_optimization.cc:218-228; speculative attempts included) */
     int64_t n_iter14;        /* ... of which only by the iteration-14 rule (still moving at iterationCount == 14) */
     int64_t gvs_on_device;   /* 1 if the global view selection of this call ran on the GPU (gvs_device.hip) */
     double  ms_plan_gvs;     /* host clock: global view selection of all reference views of the call */
     double  ms_plan_seeds;   /* host clock: feature seeds of all reference views (dmrecon.cc:232-258) */
-    double  ms_wait_bulk_token; /* host clock: time this call waited for other calls' bulk rounds on the same GPU before
-                              * its own (calls on one GPU take turns with the throughput half) */
     int64_t n_merged_calls;  /* calls this execution served (concurrent calls on one scene with equal settings are merged
                               * into one batch; the call that ran it carries the statistics) */
     int64_t merged_into_other_call; /* 1: this call's views were reconstructed in another call's batch (all other fields 0) */
-    int64_t n_tail_rounds_persistent; /* tail rounds that ran inside persistent launches (a chunk of rounds per launch;
-                              * n_tail_launches counts such a launch once, ms_tail_kernel holds its measured time) */
+    /* the end of the tail in the front kernel (one persistent workgroup per reference view, its own rounds) */
+    double  ms_front_kernel;     /* hipEvent duration of the front launch (= its slowest view) */
+    double  ms_front_view_max;   /* the slowest view's own clock inside that launch */
+    int64_t n_front_launches;    /* 0 or 1 */
+    int64_t front_first_round;   /* the round at which the views went their own ways */
+    int64_t n_front_views;       /* views that still had a front then */
+    int64_t n_front_rounds_max;  /* rounds of the view that needed most (n_rounds = front_first_round + this) */
+    int64_t n_front_rounds_sum;  /* ... summed over the views */
+    int64_t n_front_attempts;    /* patch optimisations run there (speculative ones included) */
+    int64_t n_front_entries;     /* list entries summed over all rounds of all views */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);
@@ -202,9 +206,11 @@ int  mi_dmrecon_reconstruct(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, 
 /* Patch-level entry (parity hook; = constructing mvs::PatchOptimization, doAutoOptimization,
  * computeConfidence -- patch_optimization.cc:21-78,170-242,114-142) for n hypotheses in
  * reference view ref_view: xy[2n]; hyp[3n] = depth,dzI,dzJ; local[4n] view ids (-1 = none, may be NULL).
+ * lanes_per_view: the lane layout to run them in (1 = throughput layout, 16 patches per wavefront; 16 = latency
+ * layout, one patch per wavefront -- the two layouts of the product path, same mathematics).
  * out[8n] = conf, depth, dzI, dzJ, nx, ny, nz, iterationCount; out_local[4n] ascending ids, -1 padded. */
 int  mi_dmrecon_patch_optimize(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n,
-                               const int32_t* xy, const float* hyp, const int32_t* local,
+                               const int32_t* xy, const float* hyp, const int32_t* local, int32_t lanes_per_view,
                                float* out, int32_t* out_local);
 
 /* Patch-level evaluation hook (PatchSampler::getFastNCC + fastColAndDeriv, patch_sampler.cc:64-163)

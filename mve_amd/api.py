@@ -74,11 +74,14 @@ class CStats(ctypes.Structure):
                 ("n_bulk_launches", ctypes.c_int64), ("n_tail_launches", ctypes.c_int64),
                 ("n_pass", ctypes.c_int64), ("truncated", ctypes.c_int64),
                 ("n_eval_bulk", ctypes.c_int64), ("n_patch_bulk", ctypes.c_int64), ("n_filled_bulk", ctypes.c_int64),
-                ("n_stage", ctypes.c_int64), ("n_gather_pass", ctypes.c_int64),
                 ("n_view_replaced", ctypes.c_int64), ("n_iter14", ctypes.c_int64),
                 ("gvs_on_device", ctypes.c_int64), ("ms_plan_gvs", ctypes.c_double), ("ms_plan_seeds", ctypes.c_double),
-                ("ms_wait_bulk_token", ctypes.c_double), ("n_merged_calls", ctypes.c_int64),
-                ("merged_into_other_call", ctypes.c_int64), ("n_tail_rounds_persistent", ctypes.c_int64)]
+                ("n_merged_calls", ctypes.c_int64), ("merged_into_other_call", ctypes.c_int64),
+                ("ms_front_kernel", ctypes.c_double), ("ms_front_view_max", ctypes.c_double),
+                ("n_front_launches", ctypes.c_int64), ("front_first_round", ctypes.c_int64),
+                ("n_front_views", ctypes.c_int64), ("n_front_rounds_max", ctypes.c_int64),
+                ("n_front_rounds_sum", ctypes.c_int64), ("n_front_attempts", ctypes.c_int64),
+                ("n_front_entries", ctypes.c_int64)]
 
 
 _lib = None
@@ -119,14 +122,22 @@ def load_library() -> ctypes.CDLL:
     L.mi_dmrecon_global_view_selection.argtypes = [vp, ctypes.POINTER(CSettings), i32, vp, ctypes.POINTER(i32)]
     L.mi_dmrecon_reconstruct.argtypes = [vp, ctypes.POINTER(CSettings), i32, vp, ctypes.POINTER(CMaps),
                                          ctypes.POINTER(CProgress), vp, ctypes.POINTER(CStats)]
-    L.mi_dmrecon_patch_optimize.argtypes = [vp, ctypes.POINTER(CSettings), i32, i32, vp, vp, vp, vp, vp]
+    L.mi_dmrecon_patch_optimize.argtypes = [vp, ctypes.POINTER(CSettings), i32, i32, vp, vp, vp, i32, vp, vp]
     L.mi_dmrecon_patch_eval.argtypes = [vp, ctypes.POINTER(CSettings), i32, i32, i32, f32, f32, f32,
                                         vp, vp, vp, vp, vp, vp]
     L.mi_dmrecon_pointset.argtypes = [vp, ctypes.POINTER(CCamera), i32, i32, vp, vp, i32,
                                       ctypes.POINTER(CPointsetOptions), i32, vp, vp, vp, vp, vp, vp,
                                       ctypes.POINTER(i32)]
+    L.mi_dmrecon_debug_inject_footprint.argtypes = [ctypes.c_int]          # test hook, not in the public header
+    L.mi_dmrecon_debug_inject_footprint.restype = None
     _lib = L
     return L
+
+
+def debug_inject_footprint(view_id: int) -> None:
+    """Test hook: the reference view `view_id` gets a negative pixel footprint in the calls that follow (-1: none) --
+    the condition under which the reference's PatchSampler throws std::out_of_range (patch_sampler.cc:78-82)."""
+    load_library().mi_dmrecon_debug_inject_footprint(int(view_id))
 
 
 def device_count() -> int:
@@ -376,7 +387,7 @@ class Context:
             out[i]["status"] = int(status[i])
         return out
 
-    def patch_optimize(self, st: Settings, ref_view: int, xy, hyp, local=None):
+    def patch_optimize(self, st: Settings, ref_view: int, xy, hyp, local=None, lanes_per_view: int = 1):
         xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
         n = len(xy)
         hyp = np.ascontiguousarray(hyp, np.float32).reshape(n, 3)
@@ -385,7 +396,7 @@ class Context:
         out_local = np.zeros((n, 4), np.int32)
         cs = st.to_c()
         rc = self._L.mi_dmrecon_patch_optimize(self._h, ctypes.byref(cs), ref_view, n, _ptr(xy), _ptr(hyp),
-                                               _ptr(loc), _ptr(out), _ptr(out_local))
+                                               _ptr(loc), int(lanes_per_view), _ptr(out), _ptr(out_local))
         if rc != 0:
             _raise(rc)
         return out, out_local

@@ -14,44 +14,37 @@
  *   The launch only acts if min_work <= n < max_work, n = *n_work_ptr (if given) or n_work.
  *   follow_out != null: one optimisation attempt per entry; entries with further candidate hypotheses are appended to
  *   follow_out (count *follow_out_n).  follow_in != null: continue the entries work[follow_in[0 .. *follow_in_n)].
- *   windows: sample the neighbour views through LDS texel windows; self: an entry's candidate is its own pixel's state.
- * generate -- k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile
- *   count; self: the work list = the pixels written in round - 1 themselves (the seeds' own queue entries);
- *   band_tiles_x/y > 0: list ordered (tile row, job, tile column) -- with optimize's xcd_chunks every XCD then works
- *   on one horizontal band of all reference views.
+ * generate -- k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile count.
  * tail -- one fused tail round: candidates from (prev_work, prev_results, round_work[round - 1]) -> this round's list,
  *   results and pixel-state writes (second state slot, see DevJob).  speculative: workgroups of four wavefronts, a
  *   pixel's candidate hypotheses tried at the same time; else one wavefront per pixel tries them in turn.
- * tail_persist -- the rounds first .. first + n_rounds - 1 of the tail in one launch (k_tail_persist: tickets instead of
- *   one grid per round; same results as n_rounds speculative `tail` launches).  work0 / results0 hold the list of
- *   round first - 1; the lists alternate between the two buffer pairs from there.  round_head / round_done:
- *   [MI_MAX_ROUNDS] zeroed counters.  spin_limit_ms: how long a workgroup waits for a round before it gives up
- *   (error flag bit 2).  team_off != null: the TEAM form -- eight teams (job % 8), one per XCD, each with its own lists
- *   (at team_off[x] of the buffers, dealt out by mi_launch_team_split) and counters (index round * MI_TEAMS + team,
- *   arrays of MI_MAX_ROUNDS * MI_TEAMS words).
+ * front -- the end of the tail, one persistent workgroup per reference view (k_front): the accepted entries of
+ *   (list, list_results, *list_n) = round first_round - 1 are dealt out to per-view lists (view j's at job_off[j] of
+ *   work0 / results0, its size in job_count[j], zeroed by the caller), then every view runs its own rounds
+ *   first_round, first_round + 1, ... until its front is empty (lists alternate between the two buffer pairs).
+ *   job_stats[4 j ..]: rounds run, attempts run, sum of list sizes, 100 MHz ticks (zeroed by the caller).
+ *   Same maps as one `tail` launch per round.
  */
-#define MI_TEAMS 8
 struct MiDeviceApi {
     int filter_width;
     void (*optimize)(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
                      const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                      DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                      unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                     const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows, bool self,
-                     bool xcd_chunks);
+                     const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n);
     void (*patch_eval)(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                        const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
                        float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
     void (*generate)(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
-                     unsigned* round_work, int round, bool self, int band_tiles_x, int band_tiles_y);
+                     unsigned* round_work, int round);
     void (*tail)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                  const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
-                 DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows,
-                 bool speculative);
-    void (*tail_persist)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
-                         const DevSettings& st, DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
-                         unsigned* round_work, unsigned* round_head, unsigned* round_done, const unsigned* team_off,
-                         int first, int n_rounds, DevCounters* counters, unsigned spin_limit_ms);
+                 DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool speculative);
+    void (*front)(hipStream_t s, int n_jobs, const DevJob* jobs, const DevView* views, const float* lut, const DevSettings& st,
+                  const DevEntry* list, const DevResult* list_results, const unsigned* list_n,
+                  DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
+                  const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
+                  DevCounters* counters);
 };
 const MiDeviceApi* mi_device_api(int filter_width);
 extern unsigned long long* mi_debug_tbuf;
@@ -63,11 +56,6 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
                      const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
 /* maps: [slot 0: depth | conf | dz x2 | normal x3][slot 1: same], imaps: [views | upd][views1 | upd1], per batch */
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px);
-/* accepted entries of (work, results, *n_ptr) -> per-team lists (team = job % MI_TEAMS) at team_off[x], counts in team_count[x] */
-void mi_launch_team_split(hipStream_t s, const DevEntry* work, const DevResult* results, const unsigned* n_ptr, DevEntry* owork,
-                          DevResult* oresults, unsigned* team_count, const unsigned* team_off);
-/* ORs 1 << HW_REG_XCC_ID of every workgroup of a 1024-workgroup grid into *mask */
-void mi_launch_xcc_probe(hipStream_t s, unsigned* mask);
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
                            const unsigned* key_off);

@@ -108,7 +108,7 @@ __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelec
 /* the same for the latency layout: one patch per wavefront, at most MI_LAT_SLOTS wavefronts per workgroup.  Separate
  * (smaller) arrays because a kernel's LDS is what it references: the tail kernels then ask for 4 KB instead of 12.8 KB,
  * and a CU filled with bulk workgroups of another call (12 x 12.6 KB of 160 KB) has that much to spare */
-#define MI_LAT_SLOTS 4
+#define MI_LAT_SLOTS 8
 __shared__ float g_rays_lat[MI_LAT_SLOTS][3 * MI_NS];
 __shared__ float g_mcol_lat[MI_LAT_SLOTS][3 * MI_NS];
 __shared__ float g_ncc_lat[MI_LAT_SLOTS][MI_MAX_GLOBAL];
@@ -116,26 +116,6 @@ template <int LPV> __device__ __forceinline__ float* lds_rays(int patch) { retur
 template <int LPV> __device__ __forceinline__ float* lds_mcol(int patch) { return LPV == 16 ? g_mcol_lat[patch] : g_mcol[patch]; }
 template <int LPV> __device__ __forceinline__ float* lds_ncc(int patch) { return LPV == 16 ? g_ncc_lat[patch] : g_ncc[patch]; }
 
-/* Texel windows.  The 25 samples of a (patch, neighbour view) pair fall into a small box of the view's mip level
- * (the level rule keeps the sample spacing in (1, 2] texels: at most 10 x 10 texels), and the box hardly moves
- * between the ~6 passes of a patch.  A view slot therefore stages the box ONCE from HBM (whole rows, contiguous
- * loads) into its own LDS region and every pass samples LDS; only when the window leaves the box (or does not
- * fit one) is it staged again / sampled by scattered global gathers.
- *   Lay<1>  one lane = one view slot: MI_WIN1_W x MI_WIN1_H texels per lane
- *   Lay<16> a 16-lane row = one view slot: 16 x 16 texels, one row per lane */
-#ifndef MI_WIN1_W
-#define MI_WIN1_W 10
-#define MI_WIN1_H 10
-#endif
-/* dwords between the windows of neighbouring lanes: odd, so that 32 lanes reading the same window position hit 32 banks */
-#define MI_WIN1_STRIDE ((MI_WIN1_W * MI_WIN1_H) | 1)
-#define MI_WIN16_W 16
-#define MI_WIN16_H 16
-#define MI_NOBOX (-0x40000000)
-__shared__ uint32_t g_win1[WAVE][MI_WIN1_STRIDE];
-/* latency layout: [wavefront of the workgroup][view slot][16 x 16], dynamic LDS sized at launch (4 KB per wavefront) */
-extern __shared__ __attribute__((aligned(16))) uint32_t g_win16[];
-#define MI_WIN16_BYTES_PER_WAVE (4 * MI_WIN16_W * MI_WIN16_H * 4)
 
 /* ------------------------------------------------------------------------- */
 /* Lane layouts.  A patch is optimised by 4 "view slots" (one per local neighbour view);
@@ -197,67 +177,8 @@ template <> struct Lay<1> {
         const unsigned long long b = __ballot(p);
         return (unsigned)(b >> (lane & ~3)) & 0xFu;
     }
-    /* texel window of my view slot */
-    static constexpr int WW = MI_WIN1_W, WH = MI_WIN1_H;
-    __device__ static __forceinline__ uint32_t* win(int lane) { return g_win1[lane]; }
 };
 
-/* Middle layout: view slot = a quad (6-7 samples per lane with 5 x 5 windows), patch = a 16-lane DPP row, FOUR patches
- * per wavefront.  A patch is a quarter as long as in Lay<1> and four times as many wavefronts carry a list: for the
- * late host-visible rounds, whose lists are fewer Lay<1> wavefronts than the GPU has slots (one generation of 150-250 us
- * each however small they are).  Within a view: quad_perm DPP; across the four views of a row: ds_swizzle (xor 4 / 8
- * inside 32 lanes; no LDS memory), in the same (v0 + v1) + (v2 + v3) order as the other layouts. */
-__device__ __forceinline__ int swz_xor4(int v) { return __builtin_amdgcn_ds_swizzle(v, (4 << 10) | 0x1F); }
-__device__ __forceinline__ int swz_xor8(int v) { return __builtin_amdgcn_ds_swizzle(v, (8 << 10) | 0x1F); }
-template <> struct Lay<4> {
-    static constexpr int PATCHES = 4;
-    __device__ static __forceinline__ int vslot(int lane) { return (lane >> 2) & 3; }
-    __device__ static __forceinline__ int sub(int lane) { return lane & 3; }
-    __device__ static __forceinline__ int patch(int lane) { return lane >> 4; }
-    __device__ static __forceinline__ float view_sum(float v) {      /* all 4 lanes of the quad get the sum */
-        v = fadd_i(v, dpp_xor1(__float_as_int(v)));
-        v = fadd_i(v, dpp_xor2(__float_as_int(v)));
-        return v;
-    }
-    __device__ static __forceinline__ double view_sum(double v) {
-        v += dmov(v, dpp_xor1);
-        v += dmov(v, dpp_xor2);
-        return v;
-    }
-    __device__ static __forceinline__ bool view_all(bool p) {
-        int v = p ? 1 : 0;
-        v &= dpp_xor1(v); v &= dpp_xor2(v);
-        return v != 0;
-    }
-    /* inputs are uniform within each view's quad */
-    __device__ static __forceinline__ float patch_sum(float v) {
-        v = fadd_i(v, swz_xor4(__float_as_int(v)));
-        v = fadd_i(v, swz_xor8(__float_as_int(v)));
-        return v;
-    }
-    __device__ static __forceinline__ double patch_sum(double v) {
-        v += dmov(v, swz_xor4);
-        v += dmov(v, swz_xor8);
-        return v;
-    }
-    __device__ static __forceinline__ float wave_sum(float v) { return v; }      /* unused in this layout */
-    __device__ static __forceinline__ int patch_or(int v) {
-        v |= dpp_xor1(v); v |= dpp_xor2(v); v |= swz_xor4(v); v |= swz_xor8(v);
-        return v;
-    }
-    /* lane (row, view K, my sub-lane): and_mask keeps bits 0, 1 and 4, or_mask sets the view */
-    template <int K> __device__ static __forceinline__ int from_view(int v) { return __builtin_amdgcn_ds_swizzle(v, ((K << 2) << 5) | 0x13); }
-    __device__ static __forceinline__ int view_xor1(int v) { return swz_xor4(v); }
-    __device__ static __forceinline__ int view_xor2(int v) { return swz_xor8(v); }
-    /* bit k = predicate of view slot k of my patch (taken from the slot's first lane) */
-    __device__ static __forceinline__ unsigned view_ballot(bool p, int lane) {
-        const unsigned r = (unsigned)(__ballot(p) >> (lane & ~15)) & 0xFFFFu;
-        return (r & 1u) | ((r >> 3) & 2u) | ((r >> 6) & 4u) | ((r >> 9) & 8u);
-    }
-    /* (no texel windows in this layout; the members only keep the WIN = true templates well-formed) */
-    static constexpr int WW = MI_WIN1_W, WH = MI_WIN1_H;
-    __device__ static __forceinline__ uint32_t* win(int lane) { return g_win1[lane]; }
-};
 
 template <> struct Lay<16> {
     static constexpr int PATCHES = 1;
@@ -308,10 +229,6 @@ template <> struct Lay<16> {
         const unsigned long long b = __ballot(p);
         return (unsigned)((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull));
     }
-    static constexpr int WW = MI_WIN16_W, WH = MI_WIN16_H;
-    __device__ static __forceinline__ uint32_t* win(int lane) {
-        return g_win16 + (((threadIdx.x >> 6) * 4 + (lane >> 4)) * (MI_WIN16_W * MI_WIN16_H));
-    }
 };
 
 /* ------------------------------------------------------------------------- */
@@ -335,16 +252,13 @@ struct PatchState {
     float ncc;                   /* getFastNCC(my view) at the current state */
     /* counters (flushed at kernel end) */
     unsigned n_eval, n_pass;
-    DevCounters* counters;       /* window diagnostics are added directly (one atomic per wavefront and event) */
+    DevCounters* counters;       /* rare-event diagnostics are added directly (one atomic per event) */
 };
 
 struct NView {                   /* my neighbour view at the selected mip level */
     float m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11;   /* K.[R|t]: rows 0,1 pre-multiplied by the level's K */
     int w, h;
     const uint32_t* img;         /* 16-byte footprint records of the level (DevView::quad) */
-    const uint32_t* lin;         /* RGBA8 texels of the level (DevView::img): MI_GATHER_ROWS experiment, window source */
-    const uint32_t* win;         /* LDS texel window of my view slot, or null: sample by global gathers */
-    int bx, by;                  /* texel coordinates of the window's origin */
 };
 
 __device__ __forceinline__ void project(const NView& nv, float px, float py, float pz, float& u, float& v) {
@@ -390,8 +304,6 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, co
     premultiply(nv, L.ax, L.ay, L.cx, L.cy);
     nv.w = L.w; nv.h = L.h;
     nv.img = V->quad + 4 * (size_t)L.tex_off;      /* 16-byte footprint records of this level */
-    nv.lin = V->img + L.tex_off;
-    nv.win = nullptr; nv.bx = 0; nv.by = 0;
     return true;
 }
 
@@ -400,55 +312,23 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, co
  * (worldToScreen matrices, mip level, patch_sampler.cc:72-91) costs three dependent memory accesses
  * (global_ids[sel] -> DevView -> DevLevel) when done from scratch, which is most of a pass's latency in the tail.
  * Cached here, a pass re-evaluates the level rule in registers and touches memory only when the view or its
- * level changed, or when the texel window has to be staged again.
+ * level changed.
  */
 struct ViewC {
     int sel;                     /* PatchState::sel this cache belongs to (-2 = empty) */
-    int lvl;                     /* mip level the matrices / window belong to (-1 = none) */
+    int lvl;                     /* mip level the matrices belong to (-1 = none) */
     const DevJobView* V;
     float inv0; int maxl;
     NView nv;                    /* rows 8..11 valid once sel is set; rows 0..7, w, h, img per level */
-    const uint32_t* lin;         /* RGBA8 texels of the level (DevView::img), the window's source */
 };
 
 __device__ __forceinline__ void viewc_reset(ViewC& vc) {
-    vc.sel = -2; vc.lvl = -1; vc.V = nullptr; vc.inv0 = 0.f; vc.maxl = 0; vc.lin = nullptr;
-    vc.nv.win = nullptr; vc.nv.bx = MI_NOBOX; vc.nv.by = MI_NOBOX; vc.nv.w = 0; vc.nv.h = 0; vc.nv.img = nullptr; vc.nv.lin = nullptr;
+    vc.sel = -2; vc.lvl = -1; vc.V = nullptr; vc.inv0 = 0.f; vc.maxl = 0;
+    vc.nv.w = 0; vc.nv.h = 0; vc.nv.img = nullptr;
     vc.nv.m0 = vc.nv.m1 = vc.nv.m2 = vc.nv.m3 = vc.nv.m4 = vc.nv.m5 = vc.nv.m6 = vc.nv.m7 = 0.f;
     vc.nv.m8 = vc.nv.m9 = vc.nv.m10 = vc.nv.m11 = 0.f;
 }
 
-/* Stage the WW x WH texel box at (bx, by) of the level into my view slot's LDS window (rows clamped to the image;
- * columns past the row end read the next row -- never sampled, the interior test excludes them). */
-template <int LPV>
-__device__ __forceinline__ void stage_window(const uint32_t* lin, int w, int h, int bx, int by, uint32_t* win, int sub) {
-    typedef Lay<LPV> L;
-    if (LPV == 1) {
-#pragma unroll
-        for (int r = 0; r < L::WH; ++r) {
-            const int y = min(by + r, h - 1);
-            const uint32_t* src = lin + (size_t)y * w + bx;
-            uint32_t* d = win + r * L::WW;
-#pragma unroll
-            for (int c0 = 0; c0 < L::WW; c0 += 4) {
-                if (c0 + 4 <= L::WW) {
-                    const u32x4 a = *(gtex4u_t)(src + c0);
-                    d[c0] = a.x; d[c0 + 1] = a.y; d[c0 + 2] = a.z; d[c0 + 3] = a.w;
-                } else {
-                    const u32x2 c = *(gtex2_t)(src + c0);
-                    d[c0] = c.x; d[c0 + 1] = c.y;
-                }
-            }
-        }
-    } else {
-        /* one row of 16 texels per lane of the view slot */
-        const int y = min(by + sub, h - 1);
-        const uint32_t* src = lin + (size_t)y * w + bx;
-        const u32x4 a = *(gtex4u_t)(src), b = *(gtex4u_t)(src + 4), c = *(gtex4u_t)(src + 8), d4 = *(gtex4u_t)(src + 12);
-        u32x4* d = (u32x4*)(win + sub * L::WW);
-        d[0] = a; d[1] = b; d[2] = c; d[3] = d4;
-    }
-}
 
 struct ColorSums {               /* shifted one-pass sums of the colours of one view at one state */
     float s0, s1, s2;            /* shift (any value near the mean colour; only conditions the sums) */
@@ -489,15 +369,11 @@ struct GNSums {
  * mvs_tools.cc:97-145); one fused pass here gathers them once.
  * Returns PatchSampler::success[v]; sums are complete (reduced over the view slot) on return.
  */
-template <int MODE, int LPV, bool WIN>
+template <int MODE, int LPV>
 __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& nv, const float* __restrict__ s_lut,
                                             const float* __restrict__ rays, const float* __restrict__ mcol,
-                                            ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub,
-                                            bool& fits) {
-    /* WIN: the texels come from the view slot's LDS window (nv.win, staged by view_prepare); `fits` returns whether
-     * every footprint lay inside it -- if not, the sums are void and the caller repeats the pass with gathers. */
+                                            ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub) {
     typedef Lay<LPV> L;
-    fits = true;
     const float cpx = ps.jcx, cpy = ps.jcy, cpz = ps.jcz;
     float step = 0.f, dnorm = 0.f;
     bool ok = true;
@@ -562,29 +438,10 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         const float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
         const int left = (int)floorf(uc), top = (int)floorf(vc);
         q.fx = uc - (float)left; q.fy = vc - (float)top;
-        if (WIN) {
-            /* the 2 x 2 footprint from the LDS window: two ds_read2_b32 */
-            int ox = left - nv.bx, oy = top - nv.by;
-            if ((unsigned)ox > (unsigned)(L::WW - 2) || (unsigned)oy > (unsigned)(L::WH - 2)) fits = false;
-            ox = min(max(ox, 0), L::WW - 2); oy = min(max(oy, 0), L::WH - 2);      /* stay inside my window in any case */
-            const uint32_t* wp = nv.win + (oy * L::WW + ox);
-            q.t.x = wp[0]; q.t.y = wp[1]; q.t.z = wp[L::WW]; q.t.w = wp[L::WW + 1];
-            return q;
-        }
         /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
          * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
          * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1. */
-#ifdef MI_GATHER_ROWS
-        /* experiment: the footprint as two 8-byte row gathers from the plain RGBA8 level (4 B per texel resident
-         * instead of 20: the sampled levels of 20 views are 52 MB instead of 207 MB) */
-        if (first) {
-            const uint32_t* r0 = nv.lin + (size_t)top * nv.w + left;
-            const u32x2 a = *(gtex2_t)r0, b = *(gtex2_t)(r0 + nv.w);
-            q.t.x = a.x; q.t.y = a.y; q.t.z = b.x; q.t.w = b.y;
-        }
-#else
         if (first) q.t = *(gtex4_t)(nv.img + 4 * ((size_t)top * nv.w + left));
-#endif
         return q;
     };
     auto fetch = [&](int it) -> Pre { return geom(it, ps.depth, true); };
@@ -643,62 +500,22 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             }
         }
     };
-    if (WIN && LPV != 16) {
-        /* texels in LDS: nothing to prefetch by hand, the compiler interleaves the reads of a row's samples */
-#pragma unroll 1
-        for (int row = 0; row < NITER; row += MI_FW) {
-#pragma unroll
-            for (int k = 0; k < MI_FW; ++k) if (row + k < NITER) { Pre q = geom(row + k, ps.depth, true); consume(q); }
-        }
-    } else if (LPV == 1) {
+    if (LPV == 1) {
         /* a row of the window per gather round (5 x 5: its five footprint records are neighbours in memory, 1-2
          * cache lines fetched once, five gathers in flight); only the texels stay in registers, the geometry of a
          * sample is computed again when it is consumed (the opaque copy of the depth keeps the compiler from
          * holding it across the gathers instead) */
-#ifdef MI_ROW_PREFETCH
-        /* experiment: the gathers of row r + 1 are issued before row r is consumed (a second set of texel registers) */
-        u32x4 nx[MI_FW];
-#pragma unroll
-        for (int k = 0; k < MI_FW; ++k) nx[k] = geom(k, ps.depth, true).t;
-#endif
 #pragma unroll 1
         for (int row = 0; row < MI_FW; ++row) {
             u32x4 tx[MI_FW];
-#ifdef MI_ROW_PREFETCH
-#pragma unroll
-            for (int k = 0; k < MI_FW; ++k) tx[k] = nx[k];
-            if (row + 1 < MI_FW) {
-                float depth1 = ps.depth;
-                asm volatile("" : "+v"(depth1));
-#pragma unroll
-                for (int k = 0; k < MI_FW; ++k) nx[k] = geom((row + 1) * MI_FW + k, depth1, true).t;
-            }
-#else
 #pragma unroll
             for (int k = 0; k < MI_FW; ++k) tx[k] = geom(row * MI_FW + k, ps.depth, true).t;
-#endif
             float depth2 = ps.depth;
             asm volatile("" : "+v"(depth2));
 #pragma unroll
             for (int k = 0; k < MI_FW; ++k) {
                 Pre q = geom(row * MI_FW + k, depth2, false); q.t = tx[k]; consume(q);
-#ifdef MI_EXPERIMENT_EXTRA_GEOM
-                /* sensitivity probe: one more (useless) geometry evaluation per sample = +45 VALU instructions, +3 LDS reads */
-                float depth3 = ps.depth;
-                asm volatile("" : "+v"(depth3));
-                Pre q3 = geom(row * MI_FW + k, depth3, false);
-                asm volatile("" :: "v"(q3.fx), "v"(q3.fy), "v"(q3.gu), "v"(q3.gv));
-#endif
             }
-        }
-    } else if (LPV != 16) {
-        Pre cur = fetch(0);
-#pragma unroll 1
-        for (int it = 0; it < NITER; ++it) {
-            Pre nxt = cur;
-            if (it + 1 < NITER) nxt = fetch(it + 1);
-            consume(cur);
-            cur = nxt;
         }
     } else {
         Pre q[NITER];
@@ -751,8 +568,7 @@ __device__ __forceinline__ float eval_color(PatchState& ps, const DevView* views
     ok = false;
     if (gidx < 0) return -1.f;
     if (!setup_view(views, ps.job->gv[gidx], ps, nv, level)) return -1.f;
-    bool fits_unused;
-    ok = sample_pass<PASS_COLOR, LPV, false>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub, fits_unused);
+    ok = sample_pass<PASS_COLOR, LPV>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
     ps.n_pass++;
     if (!ok) return -1.f;
     if (count) ps.n_eval++;
@@ -946,14 +762,10 @@ __device__ __forceinline__ bool color_scale_step(PatchState& ps, const DevSettin
 }
 
 /*
- * Brings my view slot's cache up to the current patch state: view identity, mip level (patch_sampler.cc:72-91),
- * and -- WIN -- the LDS texel window.  Returns false where the reference's sampling of this view fails before
- * any texel is read (non-positive footprint; a corner of the 5 x 5 window outside the image, :116-119).
+ * Brings my view slot's cache up to the current patch state: view identity and mip level (patch_sampler.cc:72-91).
+ * Returns false where the reference's sampling of this view fails before any texel is read (non-positive footprint).
  */
-template <int LPV, bool WIN>
-__device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, const DevView* __restrict__ views,
-                                             const float* __restrict__ rays, int lane, int sub) {
-    typedef Lay<LPV> L;
+__device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, const DevView* __restrict__ views) {
     if (vc.sel != ps.sel) {
         vc.sel = ps.sel;
         const DevJobView* V = &ps.job->gv[ps.sel];
@@ -976,80 +788,24 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
         premultiply(nv, Lv.ax, Lv.ay, Lv.cx, Lv.cy);
         nv.w = Lv.w; nv.h = Lv.h;
         nv.img = DV->quad + 4 * (size_t)Lv.tex_off;
-        vc.lin = DV->img + Lv.tex_off;
-        nv.lin = vc.lin;
-        nv.bx = MI_NOBOX; nv.by = MI_NOBOX;
     }
-    nv.win = nullptr;
-    if (!WIN) return true;
-    /* bounding box of the window's footprints from its four corner samples (the patch is a planar quad up to the
-     * curvature of the unit rays over 5 pixels; sample_pass checks every footprint against the box anyway) */
-    int lmin = 0x7fffffff, lmax = -0x7fffffff, tmin = 0x7fffffff, tmax = -0x7fffffff;
-    const float wlim = (float)(nv.w - 1), hlim = (float)(nv.h - 1);
-    bool inside_image = true;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int i = (c & 1 ? MI_FW - 1 : 0) + (c & 2 ? MI_NS - MI_FW : 0);
-        const int di = (c & 1) ? MI_HALF : -MI_HALF, dj = (c & 2) ? MI_HALF : -MI_HALF;
-        const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
-        const float t = ps.depth + (float)di * ps.dzI + (float)dj * ps.dzJ;
-        float u, v;
-        project(nv, ps.jcx + t * rx, ps.jcy + t * ry, ps.jcz + t * rz, u, v);
-        inside_image = inside_image && (u > 0.f && u < wlim && v > 0.f && v < hlim);
-        const int left = (int)floorf(fminf(fmaxf(u, 0.f), wlim - 0.5f)), top = (int)floorf(fminf(fmaxf(v, 0.f), hlim - 0.5f));
-        lmin = min(lmin, left); lmax = max(lmax, left); tmin = min(tmin, top); tmax = max(tmax, top);
-    }
-    if (!inside_image) return false;            /* the pass fails on that corner sample, whatever the others do */
-    const bool inside = nv.bx != MI_NOBOX && lmin >= nv.bx && lmax + 1 <= nv.bx + L::WW - 1
-                     && tmin >= nv.by && tmax + 1 <= nv.by + L::WH - 1;
-    bool have = inside;
-    if (!inside && lmax - lmin <= L::WW - 2 && tmax - tmin <= L::WH - 2) {
-        /* centre the box on the window, keep it inside the image where the image is large enough */
-        int bx = lmin - (L::WW - 2 - (lmax - lmin)) / 2, by = tmin - (L::WH - 2 - (tmax - tmin)) / 2;
-        bx = max(0, min(bx, nv.w - L::WW)); by = max(0, min(by, nv.h - L::WH));
-        nv.bx = bx; nv.by = by;
-        stage_window<LPV>(vc.lin, nv.w, nv.h, bx, by, L::win(lane), sub);
-        have = true;
-        if (sub == 0) {
-            const unsigned long long m = __ballot(true);
-            if (lane == __ffsll((long long)m) - 1) atomicAdd(&ps.counters->n_stage, (unsigned long long)__popcll(m));
-        }
-    }
-    if (LPV != 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   /* rows staged by the other lanes of my slot */
-    if (have) nv.win = L::win(lane);
     return true;
 }
 
 /* One fused pass of my view at the current state; sets ps.ncc (getFastNCC).  Returns success[v]. */
-template <int MODE, int LPV, bool WIN>
+template <int MODE, int LPV>
 __device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevView* views, const float* s_lut, const float* rays,
-                                         const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int lane, int sub) {
-    typedef Lay<LPV> L;
+                                         const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int sub) {
     bool okv = true;
     ps.ncc = -1.f;
     if (MODE == PASS_NORMAL) gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
-    /* the throughput layout without windows has no registers to spare for the cache: set the view up per pass */
-    if (!WIN && LPV == 1) viewc_reset(vc);
+    /* the throughput layout has no registers to spare for the cache: set the view up per pass */
+    if (LPV == 1) viewc_reset(vc);
     if (ps.sel >= 0) {
         TSTAMP(50);
-        okv = view_prepare<LPV, WIN>(ps, vc, views, rays, lane, sub);
+        okv = view_prepare(ps, vc, views);
         TSTAMP(51);
-        if (okv) {
-            bool done = false, fits;
-            if (WIN && vc.nv.win) {
-                okv = sample_pass<MODE, LPV, true>(ps, vc.nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub, fits);
-                fits = L::view_all(fits);
-                done = fits || !okv;          /* a failed pass is a failed pass, whatever it read */
-                if (!done) { vc.nv.bx = MI_NOBOX; okv = true; }
-            }
-            if (!done) {
-                if (WIN && sub == 0) {           /* a pass the windows could not serve */
-                    const unsigned long long m = __ballot(true);
-                    if (lane == __ffsll((long long)m) - 1) atomicAdd(&ps.counters->n_gather_pass, (unsigned long long)__popcll(m));
-                }
-                okv = sample_pass<MODE, LPV, false>(ps, vc.nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub, fits);
-            }
-        }
+        if (okv) okv = sample_pass<MODE, LPV>(ps, vc.nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
         ps.n_pass++;
         if (okv) {
             ps.ncc = ncc_from_sums(ps, S);
@@ -1204,7 +960,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
  * fused pass at the current state (colour sums + the Gauss-Newton sums the NEXT step needs), finish the
  * decision of the step that led here, take the next step.  Returns false when the optimisation is over.
  */
-template <int LPV, bool WIN>
+template <int LPV>
 __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const DevView* views, int lane) {
     typedef Lay<LPV> L;
     PatchState& ps = R.ps;
@@ -1236,10 +992,10 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     }
     bool okv;
     TSTAMP(20 + R.need);
-    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV, WIN>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, lane, sub);
-    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV, WIN>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, lane, sub);
-    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV, WIN>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, lane, sub);
-    else okv = run_pass<PASS_COLOR, LPV, WIN>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, lane, sub);
+    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
+    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
+    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
+    else okv = run_pass<PASS_COLOR, LPV>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
     TSTAMP(30);
     /* ---- finish what led to this pass */
     if (R.ctx == CTX_CTOR || R.ctx == CTX_REPLACED) {
@@ -1398,7 +1154,7 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
     TSTAMP(41);
 }
 
-template <int LPV, bool WIN>
+template <int LPV>
 __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
                                float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane,
                                PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err, DevCounters* counters) {
@@ -1408,7 +1164,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     /* diagnostic build: turns per patch vs turns per wavefront (lane divergence of the throughput layout) */
     unsigned turns = 0;
     if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
-        do { ++turns; } while (run_turn<LPV, WIN>(R, st, views, lane));
+        do { ++turns; } while (run_turn<LPV>(R, st, views, lane));
     if (LPV == 1 && g_hist) {
         unsigned mx = turns;
         for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
@@ -1417,7 +1173,7 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
     }
 #else
     if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
-        while (run_turn<LPV, WIN>(R, st, views, lane)) { }
+        while (run_turn<LPV>(R, st, views, lane)) { }
 #endif
     TSTAMP(40);
     run_end<LPV>(R, st, lane, res, n_eval, n_pass);
@@ -1442,11 +1198,6 @@ struct OptArgs {
     /* One attempt per launch (throughput layout, host-visible rounds): an entry whose pixel has several candidate
      * hypotheses runs them in successive launches over compacted follow-up lists, so that wavefronts stay full
      * (16 patches) instead of idling 15 quads while one entry tries its second neighbour. */
-    int xcd_chunks;               /* 1: workgroup b takes the (b % 8)-th eighth of the list (workgroups go round-robin over the 8
-                                   * XCDs, each with its own L2): an XCD then works on one contiguous stretch of the list */
-    int self;                     /* 1: an entry's one candidate is the pixel's OWN state (a seed popped from the queue is
-                                   * re-optimised from its converged result and only propagates if that strictly raises its
-                                   * confidence, dmrecon.cc:320-329,365-398) */
     int max_attempts;             /* 4 = all attempts of an entry back to back; 1 = one, then hand over to follow_out */
     const unsigned* follow_in;    /* entry indices to continue (their state is in results[]), or null = first attempt */
     const unsigned* follow_in_n;
@@ -1462,7 +1213,7 @@ struct OptArgs {
  * candidates are re-read from the state, which a host-visible round does not write -- k_apply does).
  * Returns true if the pixel state must be overwritten.
  */
-template <int LPV, bool WIN>
+template <int LPV>
 __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, const DevJob* job, int x, int y, int lane,
                                               unsigned& n_eval, unsigned& n_pass, unsigned& n_patch, unsigned& err, bool& more) {
     typedef Lay<LPV> L;
@@ -1494,10 +1245,6 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
             if (t > 0) break;
             const DevHyp h = a.hyp[e];
             hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = h.views;
-        } else if (a.self) {
-            if (t > 0) break;
-            /* pop-time test confImg > seed.confidence (:371) cannot hold: the entry IS the pixel's state */
-            hd = GF(job->depth + pix); hi = GF(job->dz + 2 * pix); hj = GF(job->dz + 2 * pix + 1); hv = GU(job->views + pix);
         } else {
             const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
             int bi = -1; float bc = 0.f;
@@ -1522,7 +1269,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
         }
         PatchResult r;
         TSTAMP(3);
-        optimize_patch<LPV, WIN>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters);
+        optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters);
         TSTAMP(4);
         ++n_patch; ++attempts;
         const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
@@ -1569,11 +1316,9 @@ __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, 
 /*
  * The hot kernel.  LPV = 1: 16 patches per wavefront (throughput); LPV = 16: one patch per
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
- * WIN: neighbour-view texels staged through per-view-slot LDS windows (the wavefronts per SIMD follow from
- * the LDS footprint then: 25.6 KB of windows per wavefront in the throughput layout).
  */
-template <int LPV, bool WIN>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && LPV == 1) ? 1 : (LPV == 16 ? 2 : MI_BULK_WAVES)), ((WIN && LPV == 1) ? 2 : (LPV == 16 ? 2 : MI_WAVES_PER_SIMD))))) void k_optimize(OptArgs a) {
+template <int LPV>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((LPV == 16 ? 2 : MI_BULK_WAVES), (LPV == 16 ? 2 : MI_WAVES_PER_SIMD)))) void k_optimize(OptArgs a) {
     typedef Lay<LPV> L;
     const int lane = threadIdx.x;
 #ifdef MI_TIMING
@@ -1589,9 +1334,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && L
     __syncthreads();
     TSTAMP(2);
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
-    unsigned bid = blockIdx.x;
-    if (a.xcd_chunks && (gridDim.x & 7u) == 0u) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    for (unsigned i = bid * L::PATCHES + L::patch(lane); i < n; i += gridDim.x * L::PATCHES) {
+    for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < n; i += gridDim.x * L::PATCHES) {
         const unsigned e = a.follow_in ? a.follow_in[i] : i;
         const DevEntry ent = a.work[e];
         bool more = false;
@@ -1600,7 +1343,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(((WIN && L
             /* the view failed (footprint exception) or was cancelled: nothing of it is touched any more */
             if (L::vslot(lane) == 0 && L::sub(lane) == 0) a.results[e].accepted = 0;
         } else
-            process_entry<LPV, WIN>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
+            process_entry<LPV>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
         if (a.follow_out) {
             /* wave-aggregated append of the entries that still have candidates (one atomic per wavefront) */
             const bool mine = more && L::vslot(lane) == 0 && L::sub(lane) == 0;
@@ -1664,7 +1407,7 @@ __device__ __forceinline__ Frozen frozen_state(const DevJob* job, int p, int rou
 struct TailRes { PatchResult r; unsigned n_eval, n_pass; };
 __shared__ TailRes g_tail_res[MI_TAIL_WAVES];
 
-template <bool WIN, bool SPEC>
+template <bool SPEC>
 __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((amdgpu_waves_per_eu((SPEC ? MI_TAIL_SPEC_WAVES : (MI_FW == 7 ? 2 : MI_WAVES_PER_SIMD)), (SPEC ? MI_TAIL_SPEC_WAVES : MI_WAVES_PER_SIMD)))) void k_tail(TailArgs t) {
     const OptArgs& a = t.o;
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
@@ -1746,7 +1489,7 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
                 lut_ready = true;
             }
             ce = 0; cp = 0;
-            optimize_patch<16, WIN>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
+            optimize_patch<16>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
             /* counters of optimize_patch are per view slot (row leaders): bring them to lane 0 */
             ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
                           + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
@@ -1824,260 +1567,274 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
     if (lane == 0 && err) atomicOr(&a.counters->error_flags, err);
 }
 
+
+
 /*
- * k_tail_persist: up to n_rounds tail rounds in ONE launch -- the same rounds, candidates, rules and writes as k_tail
- * (speculative form), without a kernel boundary between two rounds.  The boundary is what a small round pays most for:
- * dispatch, the drain of the previous grid, and every record of the chain entry -> job -> pixel states cold again.
+ * k_front: the END of the propagation tail, one persistent workgroup per reference view.
  *
- * Work distribution: a TICKET is one accepted entry p of the previous round (round_head[r] hands them out); the
- * workgroup that draws it looks at p's four neighbours q at the same time (wavefront k = direction k), runs every
- * candidate hypothesis of the q's whose best source is p -- the same speculative attempts as k_tail, spread over its
- * four wavefronts -- resolves them by the reference's sequential rule and writes.  round_done[r] counts finished
- * tickets; a round is over when it reaches the size of the previous list, and only then is this round's list final.
+ * Once the fronts are down to a few pixels per view, a round of k_tail is one cold patch optimisation long: every
+ * launch starts with empty caches and walks the chain previous record -> job -> pixel states -> hypothesis -> master
+ * window -> view records -> level -> texels again (~30 us for five entries, ~500 such rounds per call).  The reference
+ * views of a call never interact (each mvs::DMRecon owns its maps, dmrecon.cc:89-172), so here every view gets ONE
+ * workgroup that stays: it keeps the view's lists to itself (written and read by the same CU: its L1 / the XCD's L2,
+ * ordered by workgroup barriers -- no agent-scope traffic, no tickets, no co-residency assumption), runs its rounds
+ * at its own pace -- no view waits for another view's round -- and ends when its front is empty.  The rounds
+ * themselves are k_tail's: same candidates, same order of trial, same acceptance rule, same two-slot pixel state,
+ * same patch code (optimize_patch<16>), so the maps are bit-identical to one k_tail launch per round
+ * (tests/test_gpu_parity.py::test_front_kernel_equals_one_launch_per_round); only the round NUMBERS (stamps) of a
+ * view now count that view's own rounds.
  *
- * No grid barrier and no co-residency assumption: nothing ever waits for a workgroup that has not started -- only for
- * tickets that were drawn, and a drawn ticket is being processed by a running workgroup.  One resident workgroup is
- * enough to finish the launch; a workgroup that starts late finds the tickets of the old rounds gone and joins the
- * current one.  (A grid barrier would deadlock two such launches from two host threads against each other.)
- *
- * Memory: everything one workgroup writes and another reads in the same launch -- lists, results, the pixel states
- * and their stamps, the three per-round counters -- goes through agent-scope atomic loads and stores (sc1: served by
- * the memory side, coherent across the eight XCD-local L2s) instead of cache-wide release / acquire fences, which on
- * this GPU write back and invalidate a whole L2 each time.  A ticket's stores are waited for (vmcnt) before its
- * round_done increment is issued.  Images, cameras and the job records are read-only here and are read normally.
- * A waiting workgroup gives up after spin_limit (error flag bit 2; the host fails the call) rather than hang the GPU.
- *
- * TEAM form: the reference views of a call never interact, so the jobs are dealt out to eight TEAMS, one per XCD (job j
- * -> team j % 8), each with its own lists and round counters, and a workgroup serves the team of the XCD it finds
- * itself on (HW_REG_XCC_ID, read at run time -- no assumption about where the dispatcher puts a workgroup).  All
- * hand-offs of a team then stay inside one L2: plain stores (write-through from the CU's L1, the line stays in the L2)
- * and sc1 loads (bypass the reader's L1, served by that L2) -- a third of the latency of the memory-side round trip the
- * one-team form pays per hop -- and eight sequences of rounds advance independently, each at its own pace.  The
- * counters remain agent-scope atomics (sharded per team).  A team's rounds are numbered like the call's, so stamps and
- * results are those of one launch per round.
+ * A round of a view:
+ *   1. every (entry of the previous round, direction) pair is looked at by one LANE: frozen state of the neighbour q
+ *      and of q's four neighbours, push rule (dmrecon.cc:400-431), q's candidates in the reference's order of trial;
+ *      the lane of q's best source files q (FQ) -- exactly one lane does;
+ *   2. the attempts (q, rank) run one per WAVEFRONT, taken from an LDS counter: all of them at once when they fit the
+ *      workgroup (speculative, as k_tail<SPEC>), else rank by rank -- a later rank only if the reference's sequential
+ *      rule still asks for it (dmrecon.cc:371);
+ *   3. one lane per q applies that rule to the results (dmrecon.cc:378,391), appends q to the view's next list and
+ *      writes its other state slot.
+ * Rounds with more than MI_FRONT_QCAP candidate pairs are processed in chunks (all chunks read the frozen state).
  */
-struct PersistArgs {
-    OptArgs o;
-    DevEntry* work[2];            /* [0]: the list of round first - 1 and of every second round after it; [1]: its partner */
+#define MI_FRONT_WAVES 8
+#define MI_FRONT_QCAP 128
+static_assert(MI_FRONT_WAVES <= MI_LAT_SLOTS, "the latency layout's LDS holds one patch per wavefront of a front workgroup");
+struct FrontArgs {
+    OptArgs o;                    /* jobs, views, lut, st, counters; o.round = the first round to run */
+    DevEntry* work[2];            /* per-view lists (view j's at job_off[j]); [0] holds the lists of round o.round - 1 */
     DevResult* results[2];
-    unsigned* round_work;         /* [MI_MAX_ROUNDS (x MI_TEAMS)] accepted entries per round (and team: index round * MI_TEAMS + team) */
-    unsigned* round_head;         /* ... tickets drawn */
-    unsigned* round_done;         /* ... tickets finished */
-    unsigned team_off[MI_TEAMS];  /* TEAM: where a team's lists start in work[] / results[] */
-    int first, n_rounds;
-    unsigned long long spin_limit;   /* wall_clock64 ticks (100 MHz) a workgroup waits for a round to complete */
+    const unsigned* job_off;      /* [n_jobs] */
+    const unsigned* job_count;    /* [n_jobs] entries of view j in work[0] */
+    unsigned* job_stats;          /* [n_jobs][4]: rounds run, attempts run, sum of list sizes, 100 MHz ticks */
+    int max_rounds;               /* a view stops here (int32 stamps would last; a guard against an endless front) */
 };
-
-typedef __attribute__((address_space(1))) int* gi32w_t;
-__device__ __forceinline__ int cld(const int* p) { return __hip_atomic_load((gi32_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned cldu(const unsigned* p) { return (unsigned)cld((const int*)p); }
-__device__ __forceinline__ float cldf(const float* p) { return __int_as_float(cld((const int*)p)); }
-__device__ __forceinline__ void cst(int* p, int v) { __hip_atomic_store((gi32w_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cstu(unsigned* p, unsigned v) { cst((int*)p, (int)v); }
-__device__ __forceinline__ void cstf(float* p, float v) { cst((int*)p, __float_as_int(v)); }
-
-__device__ __forceinline__ Frozen frozen_state_c(const DevJob* job, int p, int round) {
-    const int s0 = cld(job->upd + p), s1 = cld(job->upd1 + p);
-    const float c0 = cldf(job->conf + p), c1 = cldf(job->conf1 + p);
-    Frozen f;
-    f.one = s0 >= round || (s1 < round && s1 > s0);
-    f.conf = f.one ? c1 : c0; f.upd = f.one ? s1 : s0;
-    return f;
-}
-
-struct PTask {                    /* neighbour q of the ticket's pixel in direction k, as wavefront k found it */
-    int alive;                    /* p is q's best source: this workgroup does q */
-    int n_cand;
-    unsigned order;               /* 2 bits per rank: direction (seen from q) of the rank's source */
-    int me_one;                   /* slot holding q's frozen state */
-    float own;
-    float nconf[4];               /* frozen confidence of q's four neighbours */
-    int none[4];                  /* ... and the slot it is in */
+struct FQ {                       /* a pixel this round may rewrite */
+    int xy, src;                  /* qx | qy << 16; (unused) index of its best source in the previous list */
+    float own;                    /* its frozen confidence */
+    unsigned info;                /* 0..7: direction of the rank-s source (2 bits each), 8..10: candidates, 11: slot of my frozen
+                                   * state, 12..15: slot of my neighbours' frozen state */
+    float nconf[4];               /* frozen confidence of my four neighbours */
+    float hd, hi, hj; unsigned hv;   /* the rank-0 hypothesis: the best source's result of the previous round */
+    float best; int fin;          /* sequential rule so far: best confidence, rank of the accepted result (-1: none) */
+    unsigned done; int next;      /* directions consumed; next rank to consume (= candidates: finished) */
 };
-__shared__ PTask g_ptask[MI_TAIL_WAVES];
-__shared__ TailRes g_pres[MI_TAIL_WAVES * 4];
-__shared__ unsigned g_pticket, g_pnprev;
-__shared__ int g_pabort;
+struct FR { PatchResult r; unsigned n_eval, n_pass; int ready; };
+__shared__ FQ g_fq[MI_FRONT_QCAP];
+__shared__ FR g_fr[MI_FRONT_QCAP][4];
+__shared__ unsigned g_fatt[MI_FRONT_QCAP * 4];
+__shared__ unsigned g_fcnt[8];    /* 0: FQs, 1: attempts of the pass, 2: attempts taken, 3: entries of the next list, 4: sum of candidates,
+                                   * 5: newly filled pixels of the round */
 
-/* a store another workgroup of the launch will read: write-through to the memory side (one team = any XCD), or plain =
- * stays in this XCD's L2, where the reader's sc1 load finds it (TEAM: reader and writer share the XCD) */
-template <bool TEAM> __device__ __forceinline__ void pst(int* p, int v) { if (TEAM) *p = v; else cst(p, v); }
-template <bool TEAM> __device__ __forceinline__ void pstu(unsigned* p, unsigned v) { pst<TEAM>((int*)p, (int)v); }
-template <bool TEAM> __device__ __forceinline__ void pstf(float* p, float v) { pst<TEAM>((int*)p, __float_as_int(v)); }
-
-template <bool WIN, bool TEAM>
-__global__ __launch_bounds__(MI_TAIL_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tail_persist(PersistArgs t) {
+__global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_front(FrontArgs t) {
     const OptArgs& a = t.o;
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-    /* my team = the XCD I run on: s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits) */
-    const int team = TEAM ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (MI_TEAMS - 1)) : 0;
-    constexpr int NT = TEAM ? MI_TEAMS : 1;
-    const unsigned off = TEAM ? t.team_off[team] : 0u;
-    for (int i = threadIdx.x; i < 256; i += MI_TAIL_WAVES * WAVE) g_lut[i] = a.lut[i];
-    if (threadIdx.x == 0) { g_pnprev = cldu(&t.round_work[(t.first - 1) * NT + team]); g_pabort = 0; }
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int jobi = blockIdx.x;
+    const DevJob* job = a.jobs + jobi;
+    unsigned n_prev = t.job_count[jobi];
+    if (n_prev == 0) return;
+    for (int i = tid; i < 256; i += MI_FRONT_WAVES * WAVE) g_lut[i] = a.lut[i];
+    const unsigned long long t0 = wall_clock64();
+    const unsigned off = t.job_off[jobi];
+    const int W = job->w, H = job->h;
+    unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;   /* per lane; summed at the end */
+    unsigned st_rounds = 0, st_att = 0, st_list = 0;
+    int cur = 0;
+    int round = a.round;
     __syncthreads();
-    unsigned n_prev = g_pnprev;
-    unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;
-    for (int kr = 0; kr < t.n_rounds && n_prev != 0; ++kr) {
-        const int round = t.first + kr;
-        const DevEntry* pw = t.work[kr & 1] + off; const DevResult* prs = t.results[kr & 1] + off;
-        DevEntry* ow = t.work[(kr & 1) ^ 1] + off; DevResult* ors = t.results[(kr & 1) ^ 1] + off;
-        const int ri = round * NT + team;                                      /* my team's counters of this round */
-        for (;;) {
-            if (threadIdx.x == 0) g_pticket = atomicAdd(&t.round_head[ri], 1u);
+    for (; n_prev != 0 && round < t.max_rounds; ++round) {
+        /* a footprint exception (patch_sampler.cc:78-82) or the host's cancel ends the view: one lane looks, all agree */
+        if (tid == 0) g_fcnt[6] = (unsigned)__hip_atomic_load((gi32_t)&job->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (g_fcnt[6] != 0) break;
+        const DevEntry* pw = t.work[cur] + off; const DevResult* prs = t.results[cur] + off;
+        DevEntry* ow = t.work[cur ^ 1] + off; DevResult* ors = t.results[cur ^ 1] + off;
+        if (tid == 0) { g_fcnt[3] = 0; g_fcnt[5] = 0; }
+        ++st_rounds; st_list += n_prev;
+        for (unsigned base = 0; base < 4u * n_prev; base += MI_FRONT_QCAP) {
+            if (tid == 0) { g_fcnt[0] = 0; g_fcnt[1] = 0; g_fcnt[2] = 0; g_fcnt[4] = 0; }
             __syncthreads();
-            const unsigned tk = g_pticket;
-            if (tk >= n_prev) break;
-            /* the ticket: entry tk of the previous round and its result (every lane the same words: one request each) */
-            DevEntry src; src.job = cld(&pw[tk].job); src.xy = cld(&pw[tk].xy);
-            DevResult pr;
-            pr.conf = cldf(&prs[tk].conf); pr.depth = cldf(&prs[tk].depth); pr.dzI = cldf(&prs[tk].dzI); pr.dzJ = cldf(&prs[tk].dzJ);
-            pr.views = cldu(&prs[tk].views); pr.accepted = cld(&prs[tk].accepted);
-            const DevJob* job = a.jobs + src.job;
-            const bool live = pr.accepted != 0 && cld(&job->flags) == 0;                 /* failed / cancelled view */
-            const int W = job->w, H = job->h;
-            const int px = src.xy & 0xFFFF, py = src.xy >> 16;
-            {
-                /* wavefront k: neighbour q in direction k, its frozen state and its neighbours', q's candidates in the
-                 * reference's order of trial (descending source confidence, lowest direction first on ties) */
-                const int k = wave;
-                const int qx = px + (k == 0 ? -1 : k == 1 ? 1 : 0), qy = py + (k == 2 ? -1 : k == 3 ? 1 : 0);
-                PTask T;
-                T.alive = 0; T.n_cand = 0; T.order = 0; T.me_one = 0; T.own = 0.f;
-                const bool inside = !(qx < MI_HALF || qy < MI_HALF || qx >= W - MI_HALF || qy >= H - MI_HALF);   /* patch_sampler.cc:47-50 */
-                if (live && inside) {
+            /* ---- 1. one lane per (entry, direction) */
+            const unsigned cand = base + (unsigned)tid;
+            if (tid < MI_FRONT_QCAP && cand < 4u * n_prev) {
+                const unsigned ep = cand >> 2, k = cand & 3u;
+                const DevResult* pr = prs + ep;
+                const float pconf = GF(&pr->conf);
+                const int sxy = GI(&pw[ep].xy);
+                const int qx = (sxy & 0xFFFF) + (k == 0 ? -1 : k == 1 ? 1 : 0), qy = (sxy >> 16) + (k == 2 ? -1 : k == 3 ? 1 : 0);
+                if (!(qx < MI_HALF || qy < MI_HALF || qx >= W - MI_HALF || qy >= H - MI_HALF)) {   /* patch_sampler.cc:47-50 */
                     const int q = qy * W + qx;
                     const int nb[4] = {q - 1, q + 1, q - W, q + W};
-                    const Frozen me = frozen_state_c(job, q, round);
+                    const Frozen me = frozen_state(job, q, round);
                     Frozen nf[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) nf[j] = frozen_state_c(job, nb[j], round);
+                    for (int j = 0; j < 4; ++j) nf[j] = frozen_state(job, nb[j], round);
                     const float own = me.conf;
-                    T.own = own; T.me_one = me.one ? 1 : 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { T.nconf[j] = nf[j].conf; T.none[j] = nf[j].one ? 1 : 0; }
-                    if (own < pr.conf - 0.05f || own == 0.f) {
+                    if (own < pconf - 0.05f || own == 0.f) {
                         unsigned elig = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (nf[j].upd == round - 1 && (own < nf[j].conf - 0.05f || own == 0.f)) elig |= 1u << j;
+                        unsigned order = 0; int n_cand = 0;
                         unsigned left = elig;
 #pragma unroll
-                        for (int sr = 0; sr < 4; ++sr) {
+                        for (int s = 0; s < 4; ++s) {
                             int bi = -1; float bc = 0.f;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 if (((left >> j) & 1u) && (bi < 0 || nf[j].conf > bc)) { bi = j; bc = nf[j].conf; }
-                            if (bi >= 0) { T.order |= (unsigned)bi << (2 * sr); ++T.n_cand; left &= ~(1u << bi); }
+                            if (bi >= 0) { order |= (unsigned)bi << (2 * s); ++n_cand; left &= ~(1u << bi); }
                         }
-                        T.alive = (T.n_cand > 0 && (int)(T.order & 3u) == (k ^ 1)) ? 1 : 0;   /* the best source's workgroup does q */
+                        if (n_cand > 0 && (int)(order & 3u) == (int)(k ^ 1u)) {        /* I am q's best source: q is mine */
+                            const unsigned qi = atomicAdd(&g_fcnt[0], 1u);
+                            atomicAdd(&g_fcnt[4], (unsigned)n_cand);
+                            FQ Q;
+                            Q.xy = qx | (qy << 16); Q.src = (int)ep; Q.own = own;
+                            Q.info = order | ((unsigned)n_cand << 8) | (me.one ? 1u << 11 : 0u)
+                                   | (nf[0].one ? 1u << 12 : 0u) | (nf[1].one ? 1u << 13 : 0u) | (nf[2].one ? 1u << 14 : 0u) | (nf[3].one ? 1u << 15 : 0u);
+                            Q.nconf[0] = nf[0].conf; Q.nconf[1] = nf[1].conf; Q.nconf[2] = nf[2].conf; Q.nconf[3] = nf[3].conf;
+                            Q.hd = GF(&pr->depth); Q.hi = GF(&pr->dzI); Q.hj = GF(&pr->dzJ); Q.hv = GU(&pr->views);
+                            Q.best = own; Q.fin = -1; Q.done = 0; Q.next = 0;
+                            g_fq[qi] = Q;
+                            g_fr[qi][0].ready = 0; g_fr[qi][1].ready = 0; g_fr[qi][2].ready = 0; g_fr[qi][3].ready = 0;
+                        }
                     }
                 }
-                if (lane == 0) g_ptask[wave] = T;
             }
             __syncthreads();
-            /* the attempts of the ticket's live q's, one wavefront each, four at a time */
-            int total = 0;
-#pragma unroll
-            for (int k = 0; k < MI_TAIL_WAVES; ++k) total += g_ptask[k].alive ? g_ptask[k].n_cand : 0;
-            for (int base = 0; base < total; base += MI_TAIL_WAVES) {
-                const int my = base + wave;
-                if (my >= total) continue;
-                int tq = 0, sr = my;
-#pragma unroll
-                for (int k = 0; k < MI_TAIL_WAVES; ++k) {
-                    const int nk = g_ptask[k].alive ? g_ptask[k].n_cand : 0;
-                    if (tq == k && sr >= nk) { sr -= nk; tq = k + 1; }
-                }
-                const int qx = px + (tq == 0 ? -1 : tq == 1 ? 1 : 0), qy = py + (tq == 2 ? -1 : tq == 3 ? 1 : 0);
-                /* hypothesis of q's rank-sr candidate = its source's result (rank 0: the ticket's record; the others:
-                 * their source's frozen state) */
-                float hd = pr.depth, hi = pr.dzI, hj = pr.dzJ; unsigned hv = pr.views;
-                if (sr > 0) {
-                    const int j = (int)((g_ptask[tq].order >> (2 * sr)) & 3u);
-                    const int q = qy * W + qx;
-                    const int p = j == 0 ? q - 1 : j == 1 ? q + 1 : j == 2 ? q - W : q + W;
-                    const bool one = g_ptask[tq].none[j] != 0;
-                    hd = cldf((one ? job->depth1 : job->depth) + p);
-                    hi = cldf((one ? job->dz1 : job->dz) + 2 * p); hj = cldf((one ? job->dz1 : job->dz) + 2 * p + 1);
-                    hv = cldu((one ? job->views1 : job->views) + p);
-                }
-                PatchResult r; unsigned ce = 0, cp = 0;
-                optimize_patch<16, WIN>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
-                ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
-                              + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
-                cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
-                              + __builtin_amdgcn_readlane((int)cp, 32) + __builtin_amdgcn_readlane((int)cp, 48));
-                if (lane == 0) { TailRes& o = g_pres[tq * 4 + sr]; o.r = r; o.n_eval = ce; o.n_pass = cp; }
+            const unsigned nq = g_fcnt[0];
+            /* the first pass: every attempt at once if they fit the workgroup, else the best candidate of every pixel */
+            const bool all_at_once = g_fcnt[4] <= (unsigned)MI_FRONT_WAVES;
+            if ((unsigned)tid < nq) {
+                const int n_cand = (int)((g_fq[tid].info >> 8) & 7u);
+                const int cnt = all_at_once ? n_cand : 1;
+                const unsigned pos = atomicAdd(&g_fcnt[1], (unsigned)cnt);
+                for (int s = 0; s < cnt; ++s) g_fatt[pos + s] = (unsigned)tid | ((unsigned)s << 16);
             }
-            __syncthreads();
-            /* wavefront k resolves q_k by the reference's sequential rule and writes */
-            if (g_ptask[wave].alive) {
-                const PTask& T = g_ptask[wave];
-                const int k = wave;
-                const int qx = px + (k == 0 ? -1 : k == 1 ? 1 : 0), qy = py + (k == 2 ? -1 : k == 3 ? 1 : 0);
-                const int q = qy * W + qx;
-                float best = T.own;
-                bool accepted = false;
-                PatchResult fin;
-                fin.conf = 0.f; fin.depth = fin.dzI = fin.dzJ = fin.nx = fin.ny = fin.nz = 0.f; fin.views = 0xFFFFFFFFu; fin.iters = 0;
-                unsigned done = 0;
-                for (int sr = 0; sr < T.n_cand; ++sr) {
-                    const int j = (int)((T.order >> (2 * sr)) & 3u);
-                    const float bc = T.nconf[j];
-                    if (best > bc) break;                                      /* dmrecon.cc:371 (and every later one) */
-                    done |= 1u << j;
-                    const TailRes& c = g_pres[k * 4 + sr];
-                    if (lane == 0) { n_eval += c.n_eval; n_pass += c.n_pass; ++n_patch; }   /* attempts the reference makes */
-                    if (c.r.conf > 0.f && best < c.r.conf) { best = c.r.conf; accepted = true; fin = c.r; }   /* dmrecon.cc:378,391 */
+            for (;;) {
+                __syncthreads();
+                const unsigned natt = g_fcnt[1];
+                if (natt == 0) break;
+                /* ---- 2. the attempts of this pass, one per wavefront */
+                for (;;) {
+                    unsigned idx = 0;
+                    if (lane == 0) idx = atomicAdd(&g_fcnt[2], 1u);
+                    idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+                    if (idx >= natt) break;
+                    const unsigned att = g_fatt[idx];
+                    const int qi = (int)(att & 0xFFFFu), s = (int)(att >> 16);
+                    const FQ& Q = g_fq[qi];
+                    const int qx = Q.xy & 0xFFFF, qy = Q.xy >> 16;
+                    float hd = Q.hd, hi = Q.hi, hj = Q.hj; unsigned hv = Q.hv;
+                    if (s > 0) {
+                        /* a later candidate's hypothesis = its source's frozen state */
+                        const int j = (int)((Q.info >> (2 * s)) & 3u);
+                        const int q = qy * W + qx;
+                        const int p = j == 0 ? q - 1 : j == 1 ? q + 1 : j == 2 ? q - W : q + W;
+                        const bool one = ((Q.info >> (12 + j)) & 1u) != 0;
+                        hd = GF((one ? job->depth1 : job->depth) + p);
+                        hi = GF((one ? job->dz1 : job->dz) + 2 * p); hj = GF((one ? job->dz1 : job->dz) + 2 * p + 1);
+                        hv = GU((one ? job->views1 : job->views) + p);
+                    }
+                    PatchResult r; unsigned ce = 0, cp = 0;
+                    optimize_patch<16>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
+                    ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
+                                  + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
+                    cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
+                                  + __builtin_amdgcn_readlane((int)cp, 32) + __builtin_amdgcn_readlane((int)cp, 48));
+                    if (lane == 0) { FR& o = g_fr[qi][s]; o.r = r; o.n_eval = ce; o.n_pass = cp; o.ready = 1; ++st_att; }
                 }
-                if (accepted && lane == 0) {
-                    const unsigned e = atomicAdd(&t.round_work[ri], 1u);
-                    pst<TEAM>(&ow[e].job, src.job); pst<TEAM>(&ow[e].xy, qx | (qy << 16));
-                    DevResult* o = ors + e;
-                    pstf<TEAM>(&o->conf, fin.conf); pstf<TEAM>(&o->depth, fin.depth); pstf<TEAM>(&o->dzI, fin.dzI); pstf<TEAM>(&o->dzJ, fin.dzJ);
-                    pstf<TEAM>(&o->nx, fin.nx); pstf<TEAM>(&o->ny, fin.ny); pstf<TEAM>(&o->nz, fin.nz); pstu<TEAM>(&o->views, fin.views);
-                    pst<TEAM>(&o->iters, fin.iters); pst<TEAM>(&o->accepted, 1); pstu<TEAM>(&o->tried, done);
-                    const bool one = T.me_one != 0;                            /* slot holding the old state */
+                __syncthreads();
+                if (tid == 0) { g_fcnt[1] = 0; g_fcnt[2] = 0; }
+                __syncthreads();
+                /* ---- 3. the reference's sequential rule, one lane per pixel; what it still asks for is the next pass */
+                if ((unsigned)tid < nq) {
+                    FQ& Q = g_fq[tid];
+                    const int n_cand = (int)((Q.info >> 8) & 7u);
+                    int next = Q.next;
+                    if (next < n_cand) {
+                        float best = Q.best; int fin = Q.fin; unsigned done = Q.done;
+                        while (next < n_cand) {
+                            const int j = (int)((Q.info >> (2 * next)) & 3u);
+                            const float bc = Q.nconf[j];
+                            if (best > bc) { next = n_cand; break; }                   /* dmrecon.cc:371 (and every later one) */
+                            const FR& c = g_fr[tid][next];
+                            if (!c.ready) break;
+                            done |= 1u << j;
+                            n_eval += c.n_eval; n_pass += c.n_pass; ++n_patch;         /* attempts the reference makes */
+                            if (c.r.conf > 0.f && best < c.r.conf) { best = c.r.conf; fin = next; }   /* dmrecon.cc:378,391 */
+                            ++next;
+                        }
+                        Q.best = best; Q.fin = fin; Q.done = done; Q.next = next;
+                        if (next < n_cand) g_fatt[atomicAdd(&g_fcnt[1], 1u)] = (unsigned)tid | ((unsigned)next << 16);
+                    }
+                }
+            }
+            /* ---- the accepted pixels: this round's list, the other state slot */
+            if ((unsigned)tid < nq) {
+                const FQ& Q = g_fq[tid];
+                if (Q.fin >= 0) {
+                    const PatchResult fin = g_fr[tid][Q.fin].r;
+                    const int qx = Q.xy & 0xFFFF, qy = Q.xy >> 16, q = qy * W + qx;
+                    const unsigned en = atomicAdd(&g_fcnt[3], 1u);
+                    DevEntry we; we.job = jobi; we.xy = Q.xy;
+                    ow[en] = we;
+                    DevResult o;
+                    o.conf = fin.conf; o.depth = fin.depth; o.dzI = fin.dzI; o.dzJ = fin.dzJ;
+                    o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.iters = fin.iters;
+                    o.accepted = 1; o.tried = Q.done;
+                    ors[en] = o;
+                    const bool one = ((Q.info >> 11) & 1u) != 0;                       /* slot holding the old state */
                     float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
                     float* cq = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
                     uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
-                    pstf<TEAM>(dp + q, fin.depth); pstf<TEAM>(zp + 2 * q, fin.dzI); pstf<TEAM>(zp + 2 * q + 1, fin.dzJ);
-                    pstf<TEAM>(np + 3 * q, fin.nx); pstf<TEAM>(np + 3 * q + 1, fin.ny); pstf<TEAM>(np + 3 * q + 2, fin.nz);
-                    pstf<TEAM>(cq + q, fin.conf); pstu<TEAM>(vp + q, fin.views); pst<TEAM>(up + q, round);
-                    if (T.own <= 0.f) { ++n_filled; atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u); }
+                    dp[q] = fin.depth; zp[2 * q] = fin.dzI; zp[2 * q + 1] = fin.dzJ;
+                    np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
+                    cq[q] = fin.conf; vp[q] = fin.views; up[q] = round;
+                    if (Q.own <= 0.f) { ++n_filled; atomicAdd(&g_fcnt[5], 1u); }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               /* my stores have landed before the ticket counts as done */
             }
             __syncthreads();
-            if (threadIdx.x == 0) atomicAdd(&t.round_done[ri], 1u);
         }
-        /* the round is over when every drawn ticket is done; then its list is final */
-        if (threadIdx.x == 0) {
-            const unsigned long long t0 = wall_clock64();
-            unsigned spins = 0;
-            while (cldu(&t.round_done[ri]) < n_prev) {
-                __builtin_amdgcn_s_sleep(8);
-                if ((++spins & 15u) == 0 && ((cldu(&a.counters->error_flags) & 4u) || wall_clock64() - t0 > t.spin_limit)) {
-                    atomicOr(&a.counters->error_flags, 4u);
-                    g_pabort = 1;
-                    break;
-                }
-            }
-            g_pnprev = cldu(&t.round_work[ri]);
-        }
+        n_prev = g_fcnt[3];
+        if (tid == 0 && g_fcnt[5]) atomicAdd(const_cast<uint32_t*>(&job->n_filled), g_fcnt[5]);   /* Progress::filled */
+        cur ^= 1;
         __syncthreads();
-        if (g_pabort) break;
-        n_prev = g_pnprev;
+    }
+    /* counters: per lane so far */
+    for (int off2 = 32; off2 > 0; off2 >>= 1) {
+        n_eval += __shfl_down(n_eval, off2); n_pass += __shfl_down(n_pass, off2);
+        n_patch += __shfl_down(n_patch, off2); n_filled += __shfl_down(n_filled, off2);
+        err |= __shfl_down(err, off2); st_att += __shfl_down(st_att, off2);
     }
     if (lane == 0) {
         if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
         if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
         if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
         if (n_filled) atomicAdd(&a.counters->n_filled, (unsigned long long)n_filled);
+        if (err) atomicOr(&a.counters->error_flags, err);
+        if (st_att) atomicAdd(&t.job_stats[4 * jobi + 1], st_att);
     }
-    for (int off = 32; off > 0; off >>= 1) err |= __shfl_down(err, off);
-    if (lane == 0 && err) atomicOr(&a.counters->error_flags, err);
+    if (tid == 0) {
+        t.job_stats[4 * jobi] = st_rounds; t.job_stats[4 * jobi + 2] = st_list;
+        t.job_stats[4 * jobi + 3] = (unsigned)(wall_clock64() - t0);
+        if (n_prev != 0 && round >= t.max_rounds) atomicOr(&a.counters->error_flags, 8u);    /* the front did not end */
+    }
+}
+
+/* The accepted entries of the last k_tail round (all views mixed) dealt out to the views' own lists for k_front:
+ * view j's entries at job_off[j] of the output buffers, their number in job_count[j] (zeroed before). */
+struct FrontSplitArgs {
+    const DevEntry* work; const DevResult* results; const unsigned* n_ptr;
+    DevEntry* owork; DevResult* oresults; const unsigned* job_off; unsigned* job_count;
+};
+__global__ __launch_bounds__(256) void k_front_split(FrontSplitArgs a) {
+    const unsigned n = *a.n_ptr;
+    for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const DevResult r = a.results[e];
+        if (!r.accepted) continue;
+        const DevEntry w = a.work[e];
+        const unsigned i = a.job_off[w.job] + atomicAdd(&a.job_count[w.job], 1u);
+        a.owork[i] = w; a.oresults[i] = r;
+    }
 }
 
 /* Fold the second state slot back into the first where it is the newer one (after the last tail round). */
@@ -2169,9 +1926,8 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
         const float ncc = eval_color<1>(ps, a.views, g, s_lut, s_rays, s_mcol, S, okc, true, 0);
         a.ncc[g] = ncc;
         NView nv; int level = -1; GNSums gn;
-        bool fits_unused;
         bool okd = setup_view(a.views, job->gv[g], ps, nv, level)
-            && sample_pass<PASS_DUMP, 1, false>(ps, nv, s_lut, s_rays, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0, fits_unused);
+            && sample_pass<PASS_DUMP, 1>(ps, nv, s_lut, s_rays, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0);
         a.ok[g] = okd ? 1 : 0;
         a.level[g] = level;
     }
@@ -2185,11 +1941,6 @@ struct SweepArgs {
     DevEntry* work;
     unsigned* round_work;  /* [round] = size of the work list of that round (zeroed before the call) */
     int round;
-    int self;              /* 1: the pixels written last round THEMSELVES (the seeds' own queue entries, dmrecon.cc:320-329) */
-    int band_major;        /* > 0: 1-D grid ordered (tile row, job, tile column), band_major = widest job's tile columns:
-                            * the work list then runs through the image top to bottom ACROSS the jobs, and a contiguous
-                            * eighth of it is one horizontal band of every reference view (see k_optimize's xcd_chunks) */
-    int n_jobs;
 };
 
 /* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull.
@@ -2206,22 +1957,13 @@ struct SweepArgs {
 __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
     __shared__ unsigned s_wave_cnt[4];
     __shared__ unsigned s_base;
-    int jobi = blockIdx.y, tcol = -1, trow = -1;
-    if (a.band_major > 0) {
-        const int per_row = a.n_jobs * a.band_major;
-        trow = (int)blockIdx.x / per_row;
-        const int rem = (int)blockIdx.x - trow * per_row;
-        jobi = rem / a.band_major; tcol = rem - jobi * a.band_major;
-    }
+    const int jobi = blockIdx.y;
     const DevJob* job = a.jobs + jobi;
     if (job->flags != 0) return;                 /* failed / cancelled view */
     const int W = job->w, H = job->h;
     const int tiles_x = (W + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, tiles_y = (H + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
-    if (a.band_major > 0) { if (tcol >= tiles_x || trow >= tiles_y) return; }
-    else {
-        if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-        tcol = (int)blockIdx.x % tiles_x; trow = (int)blockIdx.x / tiles_x;
-    }
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tcol = (int)blockIdx.x % tiles_x, trow = (int)blockIdx.x / tiles_x;
     const int tx0 = tcol * MI_GEN_TILE_W, ty0 = trow * MI_GEN_TILE_H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = lane & 7, ly = lane >> 3;
@@ -2235,17 +1977,14 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
         /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
         if (x >= MI_HALF && y >= MI_HALF && x < W - MI_HALF && y < H - MI_HALF) {
             const int pix = y * W + x;
-            if (a.self) any = job->upd[pix] == a.round - 1;
-            else {
-                const float own = job->conf[pix];
-                const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+            const float own = job->conf[pix];
+            const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (job->upd[nb[k]] == a.round - 1) {
-                        const float c = job->conf[nb[k]];
-                        if (own < c - 0.05f || own == 0.f) any = true;
-                    }
-            }
+            for (int k = 0; k < 4; ++k)
+                if (job->upd[nb[k]] == a.round - 1) {
+                    const float c = job->conf[nb[k]];
+                    if (own < c - 0.05f || own == 0.f) any = true;
+                }
         }
         const unsigned long long m = __ballot(any);
         before[t] = wave_total + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
@@ -2444,27 +2183,16 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, bool windows, bool self,
-                        bool xcd_chunks) {
+                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n) {
     if (grid_blocks == 0) return;
     OptArgs a;
-    a.self = self ? 1 : 0;
-    a.xcd_chunks = xcd_chunks ? 1 : 0;
-    if (xcd_chunks) grid_blocks = (grid_blocks + 7u) & ~7u;
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
     a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
     a.max_attempts = follow_out ? 1 : 4; a.follow_in = follow_in; a.follow_in_n = follow_in_n;
     a.follow_out = follow_out; a.follow_out_n = follow_out_n;
-    if (lanes_per_view == 16) {
-        if (windows) hipLaunchKernelGGL((k_optimize<16, true>), dim3(grid_blocks), dim3(WAVE), MI_WIN16_BYTES_PER_WAVE, s, a);
-        else hipLaunchKernelGGL((k_optimize<16, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
-    } else if (lanes_per_view == 4) {
-        hipLaunchKernelGGL((k_optimize<4, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);       /* (no windows in this layout) */
-    } else {
-        if (windows) hipLaunchKernelGGL((k_optimize<1, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_optimize<1, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
-    }
+    if (lanes_per_view == 16) hipLaunchKernelGGL((k_optimize<16>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    else hipLaunchKernelGGL((k_optimize<1>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
 }
 
 static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
@@ -2477,12 +2205,10 @@ static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* v
 }
 
 static void launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
-                        unsigned* round_work, int round, bool self, int band_tiles_x, int band_tiles_y) {
+                        unsigned* round_work, int round) {
     SweepArgs a;
-    a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round; a.self = self ? 1 : 0;
-    a.band_major = band_tiles_x; a.n_jobs = n_jobs;
-    if (band_tiles_x > 0) hipLaunchKernelGGL(k_generate, dim3((unsigned)(band_tiles_x * band_tiles_y * n_jobs)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_generate, dim3(max_tiles, n_jobs), dim3(256), 0, s, a);
+    a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round;
+    hipLaunchKernelGGL(k_generate, dim3(max_tiles, n_jobs), dim3(256), 0, s, a);
 }
 
 #if MI_FW == 5
@@ -2499,76 +2225,38 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
 
 static void launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                     const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
-                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool windows,
-                    bool speculative) {
+                    DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool speculative) {
     TailArgs t;
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.self = 0; t.o.xcd_chunks = 0;
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
-    if (speculative) {
-        if (windows) hipLaunchKernelGGL((k_tail<true, true>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), MI_TAIL_WAVES * MI_WIN16_BYTES_PER_WAVE, s, t);
-        else hipLaunchKernelGGL((k_tail<false, true>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
-    } else {
-        if (windows) hipLaunchKernelGGL((k_tail<true, false>), dim3(grid_blocks), dim3(WAVE), MI_WIN16_BYTES_PER_WAVE, s, t);
-        else hipLaunchKernelGGL((k_tail<false, false>), dim3(grid_blocks), dim3(WAVE), 0, s, t);
-    }
+    if (speculative) hipLaunchKernelGGL((k_tail<true>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
+    else hipLaunchKernelGGL((k_tail<false>), dim3(grid_blocks), dim3(WAVE), 0, s, t);
 }
 
-static void launch_tail_persist(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
-                                const DevSettings& st, DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
-                                unsigned* round_work, unsigned* round_head, unsigned* round_done, const unsigned* team_off,
-                                int first, int n_rounds, DevCounters* counters, unsigned spin_limit_ms) {
-    PersistArgs t;
+static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const DevView* views, const float* lut, const DevSettings& st,
+                         const DevEntry* list, const DevResult* list_results, const unsigned* list_n,
+                         DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
+                         const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
+                         DevCounters* counters) {
+    if (n_jobs <= 0) return;
+    FrontSplitArgs sp;
+    sp.work = list; sp.results = list_results; sp.n_ptr = list_n; sp.owork = work0; sp.oresults = results0;
+    sp.job_off = job_off; sp.job_count = job_count;
+    hipLaunchKernelGGL(k_front_split, dim3(16), dim3(256), 0, s, sp);
+    FrontArgs t;
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = nullptr; t.o.hyp = nullptr; t.o.results = nullptr;
-    t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = first;
+    t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = first_round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.self = 0; t.o.xcd_chunks = 0;
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.work[0] = work0; t.work[1] = work1; t.results[0] = results0; t.results[1] = results1;
-    t.round_work = round_work; t.round_head = round_head; t.round_done = round_done;
-    for (int x = 0; x < MI_TEAMS; ++x) t.team_off[x] = team_off ? team_off[x] : 0u;
-    t.first = first; t.n_rounds = n_rounds;
-    t.spin_limit = (unsigned long long)spin_limit_ms * 100000ull;            /* wall_clock64: 100 MHz */
-    if (team_off) hipLaunchKernelGGL((k_tail_persist<false, true>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
-    else hipLaunchKernelGGL((k_tail_persist<false, false>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
+    t.job_off = job_off; t.job_count = job_count; t.job_stats = job_stats; t.max_rounds = max_rounds;
+    hipLaunchKernelGGL(k_front, dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
 }
 
 #if MI_FW == 5
-/* The accepted entries of a round's list (all jobs mixed) dealt out to the eight teams of k_tail_persist's TEAM form:
- * team = job % MI_TEAMS, team x's list at team_off[x] of the output buffers, its length in team_count[x]. */
-struct SplitArgs {
-    const DevEntry* work; const DevResult* results; const unsigned* n_ptr;
-    DevEntry* owork; DevResult* oresults; unsigned* team_count;
-    unsigned team_off[MI_TEAMS];
-};
-__global__ __launch_bounds__(256) void k_team_split(SplitArgs a) {
-    const unsigned n = *a.n_ptr;
-    for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-        const DevResult r = a.results[e];
-        if (!r.accepted) continue;
-        const DevEntry w = a.work[e];
-        const int x = w.job & (MI_TEAMS - 1);
-        const unsigned i = a.team_off[x] + atomicAdd(&a.team_count[x], 1u);
-        a.owork[i] = w; a.oresults[i] = r;
-    }
-}
-void mi_launch_team_split(hipStream_t s, const DevEntry* work, const DevResult* results, const unsigned* n_ptr, DevEntry* owork,
-                          DevResult* oresults, unsigned* team_count, const unsigned* team_off) {
-    SplitArgs a;
-    a.work = work; a.results = results; a.n_ptr = n_ptr; a.owork = owork; a.oresults = oresults; a.team_count = team_count;
-    for (int x = 0; x < MI_TEAMS; ++x) a.team_off[x] = team_off[x];
-    hipLaunchKernelGGL(k_team_split, dim3(64), dim3(256), 0, s, a);
-}
-
-/* Which XCDs do the workgroups of a launch land on?  One bit per HW_REG_XCC_ID seen by a 1024-workgroup grid. */
-__global__ __launch_bounds__(WAVE) void k_xcc_probe(unsigned* mask) {
-    if (threadIdx.x == 0) atomicOr(mask, 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15));
-}
-void mi_launch_xcc_probe(hipStream_t s, unsigned* mask) { hipLaunchKernelGGL(k_xcc_probe, dim3(1024), dim3(WAVE), 0, s, mask); }
-
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px) {
     if (total_px == 0) return;
     FlattenArgs a;
@@ -2612,5 +2300,5 @@ void mi_launch_pyramid(hipStream_t s, const uint32_t* src, uint32_t* dst, int iw
 
 /* the launchers of this filter width (dmrecon_device.h: mi_device_api); host side only */
 #if !defined(__HIP_DEVICE_COMPILE__)
-extern const MiDeviceApi MI_CAT(mi_device_api_fw, MI_FW) = {MI_FW, launch_optimize, launch_patch_eval, launch_generate, launch_tail, launch_tail_persist};
+extern const MiDeviceApi MI_CAT(mi_device_api_fw, MI_FW) = {MI_FW, launch_optimize, launch_patch_eval, launch_generate, launch_tail, launch_front};
 #endif

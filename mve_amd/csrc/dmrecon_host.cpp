@@ -139,26 +139,17 @@ struct DevBuf {
 
 /* rounds of the propagation tail enqueued per read-back (even: the list buffers ping-pong per round) */
 #define MI_TAIL_CHUNK 32
-/* MI_DMRECON_WIN default: no LDS texel windows (measured, DESIGN.md section 5: bit 0, the latency layout, costs 8 %
- * single-stream and gains 10 % only against a 6-stream run without them; bit 1, the throughput layout, is 2x slower) */
-#ifndef MI_WIN_DEFAULT
-#define MI_WIN_DEFAULT 0
-#endif
-struct TailPoll { unsigned rw[MI_TAIL_CHUNK]; DevCounters hc; unsigned tw[MI_TAIL_CHUNK * MI_TEAMS]; };
-/* reconstruct calls in progress per device, all contexts of the process (MI_DMRECON_TAIL_PERSIST=-1: only a call that
- * has the GPU to itself runs its small tail rounds in persistent launches; overlapping calls fill each other's gaps
- * with one launch per round, and spinning workgroups would only take wavefront slots from them) */
+struct TailPoll { unsigned rw[MI_TAIL_CHUNK]; DevCounters hc; };
+/* reconstruct calls in progress per device, all contexts of the process: a call that shares the GPU with several
+ * others runs its small tail rounds in the one-wavefront form (BatchRun::tail_rounds) */
 #define MI_MAX_DEVICES 64
 std::atomic<int> g_active_calls[MI_MAX_DEVICES];
-/* The BULK TOKEN of a device (MI_DMRECON_BULK_TOKEN=1; off by default).  A call has two very different halves: the
- * seeds and the host-visible rounds (phase A) are throughput work -- every launch fills the GPU by itself -- and the
- * tail (phase B) is ~600 dependent rounds of a few workgroups each.  With the token, calls that run at the same time on
- * one GPU (several host threads, each with a forked context) take turns with phase A and run their tails next to
- * whoever holds it.  Measured with six host threads: the bulk kernels then run at the speed
- * they have alone (3.5 instead of 4.2-5.0 ms per 100-view launch) and the token is the saturated resource, but the
- * depth-maps/s are the same to slightly lower (705-716 against 703-757 without): the GPU was not short of bulk work
- * before, it is short of everything the co-running tails take from it. */
-std::mutex g_bulk_token[MI_MAX_DEVICES];
+std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
+/* MI_DMRECON_FRONT default: entries per reference view (average over the batch) below which the rest of the
+ * propagation goes to the front kernel */
+#ifndef MI_FRONT_DEFAULT
+#define MI_FRONT_DEFAULT 8
+#endif
 struct ActiveCall {
     int dev;
     explicit ActiveCall(int d) : dev(d >= 0 && d < MI_MAX_DEVICES ? d : -1) { if (dev >= 0) g_active_calls[dev].fetch_add(1); }
@@ -199,7 +190,7 @@ struct SceneGeom {
 /* A reconstruct call waiting to be merged with others on the same scene (see mi_dmrecon_reconstruct) */
 struct MergeReq {
     const mi_dmrecon_settings* st; int32_t n; const int32_t* refs; mi_dmrecon_maps* maps; int32_t* status; mi_dmrecon_stats* stats;
-    int rc = 0; std::string err; bool done = false; bool taken = false;
+    int rc = 0; std::string err; bool done = false; bool taken = false; bool served = false;
 };
 struct MergeQueue {
     std::mutex mu;
@@ -236,8 +227,6 @@ struct SceneStore {
 struct mi_dmrecon_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream_hi = nullptr;         /* highest priority the device offers: the tail rounds (phase B) */
-    hipEvent_t xs_ev = nullptr;              /* orders the two streams at the phase boundaries */
     std::shared_ptr<SceneStore> sc;
     DevCounters* d_counters = nullptr;
     DevBuf<DevJob> d_jobs;
@@ -254,14 +243,12 @@ struct mi_dmrecon_ctx {
     DevBuf<uint8_t> d_stage2;
     int stage_flip = 0;
     DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
-    DevBuf<unsigned> d_round_tickets;        /* [3][MI_MAX_ROUNDS][MI_TEAMS] k_tail_persist: entries per team round | tickets drawn | finished */
-    DevBuf<unsigned> d_xcc;                  /* one word: probe of the XCDs a grid lands on */
-    int xcc_mask = -1;                       /* its result (-1: not probed yet) */
+    DevBuf<unsigned> d_front;                /* k_front: [n_jobs] list offsets | [n_jobs] list sizes | [n_jobs][4] per-view statistics */
     DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
     DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
     TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
-    uint8_t* h_dyn = nullptr;                /* pinned: two read-backs of the job table (its flags / n_filled words are polled) */
+    uint8_t* h_dyn = nullptr;                /* pinned: read-backs of the jobs' flags / n_filled words (JobDyn), three slots */
     size_t h_dyn_cap = 0;
     std::vector<int32_t> h_jobdyn;           /* staging of the flag words written to dead jobs */
     DevBuf<int32_t> d_gvs_feat, d_gvs_out;   /* scratch and result of the device view selection */
@@ -344,6 +331,13 @@ void build_scene_geom(SceneStore& sc) {
     SceneGeom& g = sc.geom;
     const size_t nv = sc.views.size(), nf = sc.features.size();
     g.nv = nv; g.nf = nf; g.built = true; g.on_device = false;
+    /* the size guard first: a bundle too large for the parallax table (1000 views x 1M features would need 4 TB) gets
+     * no tables at all -- the direct path (plan_global_views) needs O(features of the reference view) */
+    g.has_plx = nv * nv * nf <= ((size_t)1 << 26);                         /* 256 MB of floats at most */
+    if (!g.has_plx) {
+        std::vector<uint8_t>().swap(g.sees); std::vector<float>().swap(g.zcam); std::vector<float>().swap(g.plx);
+        return;
+    }
     g.sees.assign(nv * nf, 0);
     g.zcam.assign(nv * nf, 0.f);
     /* unit directions camera -> feature (parallax(), mvs_tools.h:46-56), only needed while building */
@@ -362,8 +356,6 @@ void build_scene_geom(SceneStore& sc) {
             dir[(size_t)v * nf + f] = normalized(sub(p, sc.views[v].pos()));
         }
     }
-    g.has_plx = nv * nv * nf <= ((size_t)1 << 26);                         /* 256 MB of floats at most */
-    if (!g.has_plx) { g.plx.clear(); return; }
     g.plx.assign(nv * nv * nf, 0.f);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
     for (long v1 = 0; v1 < (long)nv; ++v1)
@@ -584,7 +576,7 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
     HostView const& R = c->sc->views[ref];
     {
         /* the scene tables (built on first use after the scene changed; MI_DMRECON_GVS_TABLES=0: always the direct path) */
-        static const bool use_tables = [] { const char* e = std::getenv("MI_DMRECON_GVS_TABLES"); return e ? std::atoi(e) != 0 : true; }();
+        const bool use_tables = true;
         if (use_tables) {
             {
                 std::lock_guard<std::mutex> lock(c->sc->mu);
@@ -732,10 +724,10 @@ void fill_job(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost const& j
     std::memcpy(d.cam_pos, R.cam_pos, sizeof(d.cam_pos));
     d.w2c_z[0] = R.w2c[8]; d.w2c_z[1] = R.w2c[9]; d.w2c_z[2] = R.w2c[10]; d.w2c_z[3] = R.w2c[11];
     d.inv0_s = L.invproj[0];
-    /* fault injection for tests: MI_DMRECON_INJECT_FOOTPRINT=<view id> gives that reference view a negative pixel
+    /* fault injection for tests (mi_dmrecon_debug_inject_footprint): the chosen reference view gets a negative pixel
      * footprint, the condition under which PatchSampler throws std::out_of_range (patch_sampler.cc:78-82) -- with
      * valid cameras it cannot be reached from outside */
-    if (const char* e = std::getenv("MI_DMRECON_INJECT_FOOTPRINT")) if (std::atoi(e) == jh.ref_view) d.inv0_s = -d.inv0_s;
+    if (g_inject_footprint.load() == jh.ref_view) d.inv0_s = -d.inv0_s;
     d.n_global = (int)jh.global.size();
     for (size_t g = 0; g < jh.global.size(); ++g) {
         d.global_ids[g] = jh.global[g];
@@ -814,31 +806,8 @@ void mi_dmrecon_settings_default(mi_dmrecon_settings* s) {          /* libs/dmre
     }
 }
 
-/* The context's two streams: the normal one and one of the highest priority the device offers (tail rounds).  A
- * device without stream priorities gets no second stream; the tail then stays on the first. */
 static int create_streams(mi_dmrecon_ctx* c) {
-    /* MI_DMRECON_RESERVE_CUS=<n> (read when a context is created): the context's main stream -- the bulk rounds, tens of
-     * thousands of workgroups per launch -- is created with a CU mask that leaves n compute units out, so that the
-     * latency-bound tail rounds of OTHER calls on the same GPU (priority stream, unmasked) always find idle CUs instead
-     * of queueing for wavefront slots.  A throughput knob for several concurrent calls; a lone call only loses the CUs. */
-    int reserve = 0;
-    if (const char* e = std::getenv("MI_DMRECON_RESERVE_CUS")) reserve = std::max(0, std::atoi(e));
-    hipDeviceProp_t prop;
-    if (reserve > 0 && hipGetDeviceProperties(&prop, c->device) == hipSuccess && reserve < prop.multiProcessorCount) {
-        const int ncu = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
-        for (int i = 0; i < reserve; ++i) mask[i / 32] &= ~(1u << (i % 32));
-        if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) c->stream = nullptr;
-    }
-    if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    /* the second stream: the highest priority the device offers (MI_DMRECON_TAIL_PRIORITY=1 runs the tail rounds on it).
-     * A stream confined to a few CUs was tried for the same purpose (hipExtStreamCreateWithCUMask, 16-128 CUs): the
-     * kernels of ALL streams of the process then ran one at a time, 304-655 against 725-746 depth-maps/s. */
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least
-        && hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, greatest) == hipSuccess) {
-        if (hipEventCreateWithFlags(&c->xs_ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->stream_hi); c->stream_hi = nullptr; }
-    } else c->stream_hi = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     return 0;
 }
 
@@ -874,14 +843,12 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
     c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release(); c->d_follow.release(); c->d_follow_cnt.release();
-    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release(); c->d_round_tickets.release(); c->d_xcc.release();
+    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release(); c->d_front.release();
     c->d_gvs_feat.release(); c->d_gvs_out.release(); c->d_gvs_base.release(); c->d_gvs_benefit.release(); c->d_gvs_refs.release();
     if (c->h_poll) (void)hipHostFree(c->h_poll);
     if (c->h_dyn) (void)hipHostFree(c->h_dyn);
     for (int k = 0; k < 2; ++k) if (c->poll_ev[k]) (void)hipEventDestroy(c->poll_ev[k]);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->stream_hi) { (void)hipStreamSynchronize(c->stream_hi); (void)hipStreamDestroy(c->stream_hi); }
-    if (c->xs_ev) (void)hipEventDestroy(c->xs_ev);
     (void)hipStreamDestroy(c->stream);
     delete c;                                 /* the scene store goes with its last owner */
 }
@@ -1006,7 +973,7 @@ int mi_dmrecon_evict_view(mi_dmrecon_ctx* c, int32_t view_id) {
     return 0;
 }
 
-int mi_dmrecon_set_features(mi_dmrecon_ctx* c, int32_t n, const float* pos, const int32_t* off, const int32_t* ids) {
+static int mi_dmrecon_set_features_impl(mi_dmrecon_ctx* c, int32_t n, const float* pos, const int32_t* off, const int32_t* ids) {
     if (!c || n < 0 || (n > 0 && (!pos || !off || !ids))) return fail(MI_DMRECON_EINVAL, "null argument");
     c->sc->features.resize(n);
     for (int i = 0; i < n; ++i) {
@@ -1053,7 +1020,7 @@ int mi_dmrecon_get_level(mi_dmrecon_ctx* c, int32_t view_id, int32_t level, uint
     return 0;
 }
 
-int mi_dmrecon_global_view_selection(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view,
+static int mi_dmrecon_global_view_selection_impl(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view,
                                      int32_t* ids_out, int32_t* n_out) {
     if (!c || !ids_out || !n_out) return fail(MI_DMRECON_EINVAL, "null argument");
     int rc = check_settings(st);
@@ -1074,41 +1041,95 @@ int mi_dmrecon_global_view_selection(mi_dmrecon_ctx* c, const mi_dmrecon_setting
     return 0;
 }
 
-static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views,
-                             mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out,
-                             mi_dmrecon_stats* stats) {
-    const double t_begin = now_ms();
-    double t_mark = t_begin;
-    const bool trace_phases = std::getenv("MI_DMRECON_TRACE") != nullptr;
-    auto mark = [&](const char* what) {
-        if (!trace_phases) return;
+/* ---- one batch of reference views: what mvs::DMRecon::start() does for each of them (dmrecon.cc:89-172) ---------- */
+namespace {
+
+/* the two words of a DevJob the device writes and the host polls, copied back as a strided 8-byte column */
+struct JobDyn { int32_t flags; uint32_t n_filled; };
+
+/* hipEvent pairs around the timed launches of a call, recorded on the stream the launch goes to */
+struct EventLog {
+    enum { BULK = 0, SWEEP = 1, TAIL = 2, FRONT = 3 };
+    struct Item { size_t first; int kind; unsigned work; bool ok; };
+    mi_dmrecon_ctx* c = nullptr;
+    size_t n_ev = 0;
+    std::vector<Item> items;
+    hipEvent_t get(size_t i) {
+        while (c->events.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; c->events.push_back(e); }
+        return c->events[i];
+    }
+    void begin(hipStream_t S, int kind, unsigned work) {
+        Item it; it.first = n_ev; it.kind = kind; it.work = work;
+        hipEvent_t e0 = get(n_ev), e1 = get(n_ev + 1);
+        it.ok = e0 && e1 && hipEventRecord(e0, S) == hipSuccess;
+        items.push_back(it); n_ev += 2;
+    }
+    void end(hipStream_t S) { Item& it = items.back(); if (it.ok) it.ok = hipEventRecord(c->events[it.first + 1], S) == hipSuccess; }
+    bool ms(const Item& it, float& out) const {
+        return it.ok && hipEventElapsedTime(&out, c->events[it.first], c->events[it.first + 1]) == hipSuccess;
+    }
+};
+
+struct BatchRun {
+    /* the call */
+    mi_dmrecon_ctx* c; const mi_dmrecon_settings* st; int n_refs; const int32_t* ref_views;
+    mi_dmrecon_maps* maps; mi_dmrecon_progress* progress; int32_t* status_out; mi_dmrecon_stats* stats;
+    const MiDeviceApi* D; DevSettings ds; hipStream_t S;
+    bool trace; double t_begin, t_mark;
+    /* the plan: one job per reference view that got through the host planning */
+    std::vector<int> view_rc, job_of, ref_of_job;
+    std::vector<std::string> plan_err;
+    std::vector<JobHost> jobs; std::vector<DevJob> dj;
+    int nj = 0, n_alive = 0, max_tiles = 0;
+    size_t total_px = 0, work_cap = 0, n_seed_feats = 0;
+    std::vector<DevEntry> seeds; std::vector<DevHyp> hyps; std::vector<unsigned> keyoff;
+    /* the rounds */
+    EventLog ev;
+    int round = 1;
+    bool done = false, truncated = false, have_handover = false;
+    unsigned tail_known = 0;
+    DevCounters hc;
+    int64_t n_launch = 0, n_tail_launch = 0, n_tail_timed = 0;
+    /* list + results of the last executed tail round, and their ping-pong partners */
+    DevEntry* wcur = nullptr; DevEntry* wnext = nullptr; DevResult* rcur = nullptr; DevResult* rnext = nullptr;
+    /* the front kernel (phase C) */
+    bool ran_front = false; int front_first_round = 0;
+    std::vector<unsigned> front_stats;
+    const ActiveCall* active_call = nullptr;   /* reconstruct calls in progress on this GPU */
+
+    void mark(const char* what) {
+        if (!trace) return;
         const double t = now_ms();
         fprintf(stderr, "[mi_dmrecon] phase %-22s %8.3f ms\n", what, t - t_mark);
         t_mark = t;
-    };
-    if (!c || !ref_views || !maps || n_refs <= 0) return fail(MI_DMRECON_EINVAL, "null argument");
-    int rc = check_settings(st);
-    if (rc) return rc;
-    const MiDeviceApi& D = *mi_device_api(st->filterWidth);
-    HIP_TRY(hipSetDevice(c->device));
-    const ActiveCall active_call(c->device);
-    if (c->stream_hi) {                      /* a call that failed inside its tail may have left work on the priority stream */
-        HIP_TRY(hipEventRecord(c->xs_ev, c->stream_hi));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->xs_ev, 0));
     }
-    if (stats) std::memset(stats, 0, sizeof(*stats));
-    /* outcome per reference view (status_out): a view whose planning fails, whose footprint turns non-positive or
-     * that is cancelled ends alone, the others of the call go on (apps/dmrecon/dmrecon.cc:314-317) */
-    std::vector<int> view_rc(n_refs, 0);
+    JobDyn* dyn_of(int slot) { return (JobDyn*)c->h_dyn + (size_t)slot * nj; }
+    hipError_t read_dyn(int slot) {
+        return hipMemcpy2DAsync(dyn_of(slot), sizeof(JobDyn), (const char*)c->d_jobs.p + offsetof(DevJob, flags), sizeof(DevJob),
+                                sizeof(JobDyn), (size_t)nj, hipMemcpyDeviceToHost, S);
+    }
+    int plan();
+    int upload();
+    int seed_round();
+    int poll_views(const JobDyn* dyn, unsigned queue_size);
+    int bulk_rounds(bool& to_tail);
+    int tail_rounds(bool& to_front);
+    int front_rounds();
+    int download();
+    void fill_stats();
+    int outcome();
+};
+
+/* ---- host planning: global view selection and seeds, one plan per reference view.
+ * Returns 0 to go on, a negative code when the call is over (g_err set). */
+int BatchRun::plan() {
+    view_rc.assign(n_refs, 0); job_of.assign(n_refs, -1); plan_err.assign(n_refs, std::string());
     for (int i = 0; i < n_refs; ++i) {
         if (progress) progress[i].start_time = (uint64_t)std::time(nullptr);
         if (progress && progress[i].cancelled) { view_rc[i] = MI_DMRECON_ECANCELLED; progress[i].status = MI_RECON_CANCELLED; }   /* dmrecon.cc:101-105 */
         else if (progress) progress[i].status = MI_RECON_GLOBALVS;
     }
-    /* ---- host planning: global view selection and seeds, one plan per reference view */
     std::vector<JobHost> plans(n_refs);
-    std::vector<int> job_of(n_refs, -1);
-    std::vector<std::string> plan_err(n_refs);
     const int n_threads = std::max(1, std::min(std::min(n_refs, omp_get_num_procs()), 64));
     bool gvs_done = false;
     if (gvs_device_wanted(c, n_refs)) {
@@ -1137,14 +1158,9 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
     mark("global view selection");
     const double t_gvs_done = now_ms();
     if (stats) { stats->gvs_on_device = gvs_done ? 1 : 0; stats->ms_plan_gvs = t_gvs_done - t_begin; }
-    std::vector<JobHost> jobs;
-    std::vector<int> ref_of_job;
     for (int i = 0; i < n_refs; ++i) {
         if (status_out) status_out[i] = view_rc[i];
-        if (view_rc[i]) {
-            if (n_refs == 1) { g_err = view_rc[i] == MI_DMRECON_ECANCELLED ? "cancelled" : plan_err[i]; return view_rc[i]; }
-            continue;
-        }
+        if (view_rc[i]) continue;
         HostLevel const& L = c->sc->views[ref_views[i]].levels[st->scale];
         plans[i].w = L.w; plans[i].h = L.h;
         job_of[i] = (int)jobs.size();
@@ -1152,153 +1168,52 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
         jobs.push_back(plans[i]);
     }
     if (jobs.empty()) {
-        for (int i = 0; i < n_refs; ++i) if (view_rc[i] != MI_DMRECON_ECANCELLED) return fail(MI_DMRECON_EGVS, "Global View Selection failed for every reference view");
+        /* no view got through: the first failing view's own code and message (a single-view call behaves like
+         * DMRecon's constructor / start(): the exception is the call's outcome), a cancellation only if all were */
+        for (int i = 0; i < n_refs; ++i)
+            if (view_rc[i] != MI_DMRECON_ECANCELLED) { g_err = plan_err[i].empty() ? "Global View Selection failed" : plan_err[i]; return view_rc[i]; }
         return fail(MI_DMRECON_ECANCELLED, "cancelled");
     }
     for (int i = 0; progress && i < n_refs; ++i) if (view_rc[i] == 0) progress[i].status = MI_RECON_FEATURES;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
     for (int j = 0; j < (int)jobs.size(); ++j) plan_seeds(c, st, jobs[j], j);
-
     mark("seed planning");
     if (stats) stats->ms_plan_seeds = now_ms() - t_gvs_done;
-    rc = sync_views(c);
+    return 0;
+}
+
+/* ---- job table, state maps, seeds and work-list buffers on the device (all copies asynchronous) */
+int BatchRun::upload() {
+    int rc = sync_views(c);
     if (rc) return rc;
-    const int nj = (int)jobs.size();
-    std::vector<DevJob> dj(nj);
-    int max_px = 0, max_tiles = 0, max_tiles_x = 0, max_tiles_y = 0;
+    nj = (int)jobs.size();
+    dj.resize(nj);
     for (int j = 0; j < nj; ++j) {
         fill_job(c, st, jobs[j], dj[j]);
-        max_px = std::max(max_px, jobs[j].w * jobs[j].h);
         const int tx = (jobs[j].w + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, ty = (jobs[j].h + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
-        max_tiles = std::max(max_tiles, tx * ty); max_tiles_x = std::max(max_tiles_x, tx); max_tiles_y = std::max(max_tiles_y, ty);
+        max_tiles = std::max(max_tiles, tx * ty);
     }
-    /* MI_DMRECON_BANDS=1 (experiment): work lists ordered by image band across the jobs, one band per XCD */
-    static const bool BANDS = [] { const char* e = std::getenv("MI_DMRECON_BANDS"); return e && std::atoi(e) != 0; }();
-    size_t total_px = 0;
     rc = alloc_maps(c, jobs, dj, total_px);
     if (rc) return rc;
     if (c->d_jobs.reserve(nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(jobs) failed");
-    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), nj * sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
-    /* seeds of all jobs, concatenated */
-    std::vector<DevEntry> seeds; std::vector<DevHyp> hyps; std::vector<unsigned> keyoff(nj);
-    size_t n_seed_feats = 0;
+    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), nj * sizeof(DevJob), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), S));
+    keyoff.resize(nj);
     for (int j = 0; j < nj; ++j) {
         seeds.insert(seeds.end(), jobs[j].seeds.begin(), jobs[j].seeds.end());
         hyps.insert(hyps.end(), jobs[j].seed_hyp.begin(), jobs[j].seed_hyp.end());
         keyoff[j] = (unsigned)jobs[j].pix_off;
         n_seed_feats += jobs[j].n_seeds;
     }
-    const size_t work_cap = std::max(total_px, seeds.size());
-    if (c->d_work.reserve(work_cap) || c->d_work2.reserve(work_cap) || c->d_results.reserve(work_cap) || c->d_results2.reserve(work_cap) || c->d_hyp.reserve(std::max<size_t>(seeds.size(), 1))
-        || c->d_keys.reserve(total_px) || c->d_keyoff.reserve(nj))
+    work_cap = std::max(total_px, seeds.size());
+    if (c->d_work.reserve(work_cap) || c->d_work2.reserve(work_cap) || c->d_results.reserve(work_cap) || c->d_results2.reserve(work_cap)
+        || c->d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->d_keys.reserve(total_px) || c->d_keyoff.reserve(nj)
+        || c->d_round_work.reserve(MI_MAX_ROUNDS) || c->d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->d_follow.reserve(2 * work_cap)
+        || c->d_front.reserve(6 * (size_t)nj))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(work lists) failed");
-    const DevSettings ds = dev_settings(st);
-    /* events for the kernel timings */
-    auto get_event = [&](size_t i) -> hipEvent_t {
-        while (c->events.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; c->events.push_back(e); }
-        return c->events[i];
-    };
-    size_t n_ev = 0;
-    std::vector<std::pair<size_t, int> > ev_kind;     /* (start event index, kind) kind 0 = optimise, 1 = sweep */
-    std::vector<unsigned> ev_work;                    /* work-list size of each timed optimise launch */
-    std::vector<char> ev_tail;                        /* ... and whether it belongs to phase B */
-    const bool trace = std::getenv("MI_DMRECON_TRACE") != nullptr;
-    /* An event record costs ~6 us of queue time on either side of the kernel it brackets -- more than a tenth of a
-     * tail round.  Phase B therefore times every TAIL_TIMED_EVERY-th round only (all of them when tracing); the
-     * tail launches are uniform (one dependent patch chain each), their mean stands in for the untimed ones. */
-    const unsigned TAIL_TIMED_EVERY = trace ? 1u : 8u;
-    hipStream_t S = c->stream;                         /* the stream the rounds are enqueued on: c->stream, or the high-priority one in phase B */
-    auto ev_begin = [&](int kind) { hipEvent_t e = get_event(n_ev); if (e) (void)hipEventRecord(e, S); ev_kind.push_back(std::make_pair(n_ev, kind)); n_ev += 2; };
-    auto ev_end = [&]() { hipEvent_t e = get_event(ev_kind.back().first + 1); if (e) (void)hipEventRecord(e, S); };
-
-    mark("setup + uploads (async)");
-    int64_t n_launch = 0, n_tail_launch = 0, n_tail_classic = 0, n_tail_rounds_persist = 0;
-    if (c->d_round_work.reserve(MI_MAX_ROUNDS) || c->d_round_tickets.reserve(3 * MI_MAX_ROUNDS * MI_TEAMS) || c->d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->d_follow.reserve(2 * work_cap))
-        return fail(MI_DMRECON_EDEVICE, "hipMalloc(round counters) failed");
     HIP_TRY(hipMemsetAsync(c->d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
-    HIP_TRY(hipMemsetAsync(c->d_round_tickets.p, 0, 3 * MI_MAX_ROUNDS * MI_TEAMS * sizeof(unsigned), S));
     HIP_TRY(hipMemsetAsync(c->d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), S));
-    static const bool USE_BULK_TOKEN = [] { const char* e = std::getenv("MI_DMRECON_BULK_TOKEN"); return e ? std::atoi(e) != 0 : false; }();
-    std::unique_lock<std::mutex> bulk_token;
-    if (USE_BULK_TOKEN && c->device >= 0 && c->device < MI_MAX_DEVICES) {
-        const double t_wait = now_ms();
-        bulk_token = std::unique_lock<std::mutex>(g_bulk_token[c->device]);
-        if (stats) stats->ms_wait_bulk_token = now_ms() - t_wait;
-        mark("wait for the bulk token");
-    }
-    if (!seeds.empty()) {
-        HIP_TRY(hipMemcpyAsync(c->d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, S));
-        HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, S));
-        HIP_TRY(hipMemcpyAsync(c->d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
-        HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), S));
-        ev_begin(0); ev_work.push_back((unsigned)seeds.size()); ev_tail.push_back(0);
-        D.optimize(S, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE,
-                           c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p,
-                           nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0, c->d_counters,
-                           nullptr, nullptr, nullptr, nullptr, false, false, false);
-        ev_end();
-        ++n_launch;
-        ev_begin(1);
-        mi_launch_apply_seeds(S, c->d_jobs.p, c->d_work.p, c->d_results.p, (unsigned)seeds.size(), c->d_counters,
-                              c->d_keys.p, c->d_keyoff.p);
-        ev_end();
-    }
-    for (int i = 0; progress && i < n_refs; ++i) if (view_rc[i] == 0) progress[i].status = MI_RECON_QUEUE;
-    /* ---- propagation sweeps (replace DMRecon::processQueue, dmrecon.cc:333-434).
-     * Phase A: while the work list is large, one host-visible round at a time with the throughput
-     *          layout (16 patches per wavefront), grid sized to the list.
-     * Phase B: the long tail of small rounds is enqueued blind in chunks -- the kernels read the
-     *          round's list size from device memory -- with the latency layout (one patch per
-     *          wavefront, every candidate hypothesis of a pixel on its own wavefront), two chunks in flight. */
-    unsigned TAIL_THRESHOLD = 12288;
-    if (const char* e = std::getenv("MI_DMRECON_TAIL_THRESHOLD")) TAIL_THRESHOLD = (unsigned)std::atoi(e);
-    const unsigned TAIL_GRID = 4096, TAIL_CHUNK = MI_TAIL_CHUNK;
-    /* Workgroups of a blind tail round: one per candidate (4 per entry of the previous round's list) lets the
-     * wavefronts without a source end at once; the list sizes are only known with a chunk's delay, so the grid is
-     * twice what the last known size asks for (a shorter grid strides, correct but with idle wavefronts). */
-    unsigned tail_known = TAIL_THRESHOLD;
-    auto tail_grid = [&]() -> unsigned { return std::min(65536u, std::max(1024u, 8u * tail_known)); };
-    /* Rounds up to this many entries try a pixel's candidate hypotheses at the same time (four wavefronts per
-     * pixel: the round is one patch optimisation long instead of up to four); larger rounds fill the GPU anyway
-     * and run them in turn on one wavefront, which wastes nothing.  MI_DMRECON_SPECULATE=<entries> (0 = never). */
-    static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 1024u; }();
-    /* Persistent tail launches (k_tail_persist: a chunk of rounds per launch, no kernel boundary between rounds) once
-     * the rounds are down to PERSIST_MAX entries.  MI_DMRECON_TAIL_PERSIST: 0 / unset = one launch per round, 1 = one
-     * team (hand-offs through the memory side), 2 = eight teams, one per XCD (hand-offs inside an L2), -1 = teams
-     * whenever no other reconstruct call is running on this GPU.  Same rounds, same results in every form
-     * (tests/test_gpu_parity.py).  Off by default because it buys nothing: a small round is one
-     * cold patch optimisation long (25-30 us) whichever way it is started -- the boundary between two launches is
-     * only ~1.5 us of it -- and the tickets and counters of the persistent forms cost about what they save.
-     * MI_DMRECON_TAIL_PERSIST_MAX=<entries>, _GRID=<workgroups>, MI_DMRECON_TAIL_SPIN_MS (all read per call). */
-    static const bool TAIL_PRIORITY = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PRIORITY"); return e ? std::atoi(e) != 0 : false; }();
-    const int PERSIST_MODE = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PERSIST"); return e ? std::max(-1, std::min(2, std::atoi(e))) : 0; }();
-    const unsigned PERSIST_MAX = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PERSIST_MAX"); return e ? (unsigned)std::atoi(e) : 512u; }();
-    const unsigned PERSIST_SPIN_MS = [] { const char* e = std::getenv("MI_DMRECON_TAIL_SPIN_MS"); return e ? (unsigned)std::atoi(e) : 2000u; }();
-    const unsigned PERSIST_GRID = [] { const char* e = std::getenv("MI_DMRECON_TAIL_PERSIST_GRID"); return e ? (unsigned)std::max(1, std::atoi(e)) : 0u; }();
-    /* the teams' list regions: team x = the jobs j with j % MI_TEAMS == x; a list holds a pixel at most once */
-    unsigned team_off[MI_TEAMS];
-    {
-        size_t acc = 0;
-        for (int x = 0; x < MI_TEAMS; ++x) {
-            team_off[x] = (unsigned)acc;
-            for (int j = x; j < nj; j += MI_TEAMS) acc += (size_t)jobs[j].w * jobs[j].h;
-        }
-    }
-    unsigned* const d_team_work = c->d_round_tickets.p;
-    unsigned* const d_ticket_head = c->d_round_tickets.p + (size_t)MI_MAX_ROUNDS * MI_TEAMS;
-    unsigned* const d_ticket_done = c->d_round_tickets.p + 2 * (size_t)MI_MAX_ROUNDS * MI_TEAMS;
-    bool teams_started = false;
-    const unsigned MID_THRESHOLD = [] { const char* e = std::getenv("MI_DMRECON_MID_THRESHOLD"); return e ? (unsigned)std::atoi(e) : 0u; }();
-    static const bool SPEC_SHARED = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE_SHARED"); return e && std::atoi(e) != 0; }();
-    static const bool USE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW"); return e ? std::atoi(e) != 0 : true; }();
-    /* texel windows in LDS: bit 0 = latency layout (tail rounds), bit 1 = throughput layout (bulk rounds) */
-    const int USE_WIN = [] { const char* e = std::getenv("MI_DMRECON_WIN"); return e ? std::atoi(e) : MI_WIN_DEFAULT; }();
-    const bool WIN_TAIL = (USE_WIN & 1) != 0, WIN_BULK = (USE_WIN & 2) != 0;
-    /* diagnostic: MI_DMRECON_BULK_LPV=16 runs the host-visible rounds in the latency layout too (sequential attempts
-     * per entry) -- the bit-exact reference for the speculative tail rounds, see tests/test_gpu_parity.py */
-    const int BULK_LPV = [] { const char* e = std::getenv("MI_DMRECON_BULK_LPV"); return (e && std::atoi(e) == 16) ? 16 : 1; }();
-    const unsigned BULK_PPW = BULK_LPV == 16 ? 1u : (unsigned)MI_PATCHES_PER_WAVE;
+    HIP_TRY(hipMemcpyAsync(c->d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
     if (!c->h_poll) {
         if (hipHostMalloc((void**)&c->h_poll, 3 * sizeof(TailPoll), hipHostMallocDefault) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(poll buffer) failed");
@@ -1306,275 +1221,256 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
             return fail(MI_DMRECON_EDEVICE, "hipEventCreate failed");
     }
     if (c->h_jobdyn.size() < 2 * (size_t)nj) c->h_jobdyn.resize(2 * (size_t)nj);
-    if (c->h_dyn_cap < 2 * (size_t)nj * sizeof(DevJob)) {
+    if (c->h_dyn_cap < 3 * (size_t)nj * sizeof(JobDyn)) {
         if (c->h_dyn) (void)hipHostFree(c->h_dyn);
         c->h_dyn = nullptr; c->h_dyn_cap = 0;
-        const size_t want = 2 * ((size_t)nj + 16) * sizeof(DevJob);
+        const size_t want = 3 * ((size_t)nj + 64) * sizeof(JobDyn);
         if (hipHostMalloc((void**)&c->h_dyn, want, hipHostMallocDefault) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(job poll buffer) failed");
         c->h_dyn_cap = want;
     }
-    auto dyn_of = [&](int slot) -> DevJob* { return (DevJob*)c->h_dyn + (size_t)slot * nj; };
-    bool first_phase_a = true, ran_tail = false, have_handover = false;
-    int round = 1;
-    const int max_rounds = MI_MAX_ROUNDS - 2 * (int)TAIL_CHUNK - 2;
-    DevCounters hc;
-    std::memset(&hc, 0, sizeof(hc));
-    bool done = false, truncated = false;
-    int n_alive = 0;
-    for (int j = 0; j < nj; ++j) if (view_rc[ref_of_job[j]] == 0) ++n_alive;
+    n_alive = nj;
+    mark("setup + uploads (async)");
+    return 0;
+}
 
-    /* The per-view outcome of a failed / cancelled view (the reference: an exception or a cancel ends THAT
-     * DMRecon, apps/dmrecon/dmrecon.cc:314-317, dmrecon.cc:353,101-105): the job is marked dead on the device, its
-     * entries are skipped from then on, nothing of it is written back.  Called between rounds / chunks. */
-    auto poll_views = [&](const DevJob* dyn /* read-back of the job table */, unsigned queue_size) -> int {
-        for (int j = 0; j < nj; ++j) {
-            const int i = ref_of_job[j];
-            if (view_rc[i] != 0) continue;
-            int why = 0;
-            if ((uint32_t)dyn[j].flags & MI_JOB_EFOOTPRINT) why = MI_DMRECON_EFOOTPRINT;
-            else if (progress && progress[i].cancelled) why = MI_DMRECON_ECANCELLED;
-            if (progress) { progress[i].filled = dyn[j].n_filled; progress[i].queueSize = queue_size; }
-            if (!why) continue;
-            view_rc[i] = why; --n_alive;
-            if (progress && why == MI_DMRECON_ECANCELLED) progress[i].status = MI_RECON_CANCELLED;
-            const int32_t dead = (int32_t)((uint32_t)dyn[j].flags | MI_JOB_DEAD);
-            c->h_jobdyn[2 * j] = dead;      /* stays valid until the copy has run: the vector is not resized below */
-            if (hipMemcpyAsync((char*)(c->d_jobs.p + j) + offsetof(DevJob, flags), &c->h_jobdyn[2 * j], sizeof(int32_t),
-                               hipMemcpyHostToDevice, S) != hipSuccess) return -1;
+/* ---- round 0: DMRecon::processFeatures (dmrecon.cc:243-331), every SfM feature of every view in one launch */
+int BatchRun::seed_round() {
+    if (seeds.empty()) return 0;
+    HIP_TRY(hipMemcpyAsync(c->d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), S));
+    ev.begin(S, EventLog::BULK, (unsigned)seeds.size());
+    D->optimize(S, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE, c->d_jobs.p, c->sc->d_views.p,
+                c->sc->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p, nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0,
+                c->d_counters, nullptr, nullptr, nullptr, nullptr);
+    ev.end(S);
+    ++n_launch;
+    ev.begin(S, EventLog::SWEEP, 0);
+    mi_launch_apply_seeds(S, c->d_jobs.p, c->d_work.p, c->d_results.p, (unsigned)seeds.size(), c->d_counters, c->d_keys.p, c->d_keyoff.p);
+    ev.end(S);
+    return 0;
+}
+
+/* The per-view outcome of a failed / cancelled view (the reference: an exception or a cancel ends THAT DMRecon,
+ * apps/dmrecon/dmrecon.cc:314-317, dmrecon.cc:353,101-105): the job is marked dead on the device, its entries are
+ * skipped from then on, nothing of it is written back.  Called between rounds / chunks with a read-back of the jobs'
+ * flags / n_filled words. */
+int BatchRun::poll_views(const JobDyn* dyn, unsigned queue_size) {
+    for (int j = 0; j < nj; ++j) {
+        const int i = ref_of_job[j];
+        if (view_rc[i] != 0) continue;
+        int why = 0;
+        if ((uint32_t)dyn[j].flags & MI_JOB_EFOOTPRINT) why = MI_DMRECON_EFOOTPRINT;
+        else if (progress && progress[i].cancelled) why = MI_DMRECON_ECANCELLED;
+        if (progress) { progress[i].filled = dyn[j].n_filled; progress[i].queueSize = queue_size; }
+        if (!why) continue;
+        view_rc[i] = why; --n_alive;
+        if (progress && why == MI_DMRECON_ECANCELLED) progress[i].status = MI_RECON_CANCELLED;
+        c->h_jobdyn[2 * j] = (int32_t)((uint32_t)dyn[j].flags | MI_JOB_DEAD);   /* stays valid until the copy has run */
+        if (hipMemcpyAsync((char*)(c->d_jobs.p + j) + offsetof(DevJob, flags), &c->h_jobdyn[2 * j], sizeof(int32_t),
+                           hipMemcpyHostToDevice, S) != hipSuccess)
+            return fail(MI_DMRECON_EDEVICE, "hipMemcpyAsync(job flags) failed");
+    }
+    return 0;
+}
+
+/* ---- phase A: while the work list is large, one host-visible round at a time in the throughput layout (16 patches
+ * per wavefront), grid sized to the list: k_generate -> k_optimize<1> (first attempts, then the follow-up list) ->
+ * k_apply.  The first round below MI_DMRECON_TAIL_THRESHOLD entries runs in the latency layout and hands over. */
+int BatchRun::bulk_rounds(bool& to_tail) {
+    to_tail = false;
+    unsigned TAIL_THRESHOLD = 12288;
+    if (const char* e = std::getenv("MI_DMRECON_TAIL_THRESHOLD")) TAIL_THRESHOLD = (unsigned)std::atoi(e);
+    /* diagnostic: MI_DMRECON_BULK_LPV=16 runs the host-visible rounds in the latency layout too (sequential attempts
+     * per entry) -- the bit-exact reference for the fused tail rounds, see tests/test_gpu_parity.py */
+    const int BULK_LPV = [] { const char* e = std::getenv("MI_DMRECON_BULK_LPV"); return (e && std::atoi(e) == 16) ? 16 : 1; }();
+    const int max_rounds = MI_MAX_ROUNDS - 2 * (int)MI_TAIL_CHUNK - 2;
+    for (; round < max_rounds && n_alive > 0; ++round) {
+        ev.begin(S, EventLog::SWEEP, 0);
+        D->generate(S, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round);
+        ev.end(S);
+        TailPoll& P = c->h_poll[0];
+        HIP_TRY(hipMemcpyAsync(&P.rw[0], c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
+        HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
+        HIP_TRY(read_dyn(0));
+        HIP_TRY(hipStreamSynchronize(S));
+        const unsigned n_work = P.rw[0];
+        hc = P.hc;
+        if (int rc = poll_views(dyn_of(0), n_work)) return rc;
+        if (n_work == 0) { done = true; return 0; }
+        if (n_alive == 0) return 0;
+        const bool tail = n_work < TAIL_THRESHOLD;
+        ev.begin(S, EventLog::BULK, n_work);
+        if (tail || BULK_LPV == 16)
+            D->optimize(S, 16, std::min(n_work, tail ? 4096u : 16384u), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
+                        nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
+        else {
+            /* one optimisation attempt per entry and launch; the entries whose pixel has further candidate hypotheses
+             * (about one in five) continue in a follow-up launch over a compacted list (its size stays on the device),
+             * so that the wavefronts of both launches are full; the follow-up launch runs all remaining attempts of its
+             * entries back to back (third and fourth attempts are rare) */
+            const unsigned waves = (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE;
+            unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
+            D->optimize(S, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr,
+                        n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->d_follow.p, fcnt);
+            D->optimize(S, 1, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+                        c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->d_follow.p, fcnt, nullptr, nullptr);
+            ++n_launch;
         }
+        ev.end(S);
+        ++n_launch;
+        ev.begin(S, EventLog::SWEEP, 0);
+        mi_launch_apply(S, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
+        ev.end(S);
+        if (tail) {
+            tail_known = n_work;
+            /* counters as of the end of the host-visible rounds (slot 2 of the poll buffer; read after the call) */
+            HIP_TRY(hipMemcpyAsync(&c->h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
+            have_handover = true;
+            ++round; to_tail = true;
+            return 0;
+        }
+    }
+    if (n_alive > 0) truncated = true;               /* round counters exhausted */
+    return 0;
+}
+
+/* ---- phase B: one fused launch per round (k_tail: candidates from the previous round's accepted entries -> this
+ * round's list, optimisations and state writes); lists and results ping-pong.  A chunk of rounds is enqueued blind
+ * (the kernels read the round's list size from device memory) and its counters are read back while the NEXT chunk
+ * already runs (empty rounds are microsecond no-ops), so the GPU never waits for the host inside the tail.
+ * Once the lists are down to a few entries per view the rest goes to the front kernel (phase C). */
+int BatchRun::tail_rounds(bool& to_front) {
+    to_front = false;
+    /* Rounds up to this many entries try a pixel's candidate hypotheses at the same time (four wavefronts per pixel:
+     * the round is one patch optimisation long instead of up to four); larger rounds fill the GPU anyway and run
+     * them in turn on one wavefront, which wastes nothing.  MI_DMRECON_SPECULATE=<entries> (0 = never). */
+    static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 1024u; }();
+    /* MI_DMRECON_FRONT=<entries per view> (read per call; 0 = never): hand the rest of the propagation to k_front once
+     * a round's list is down to that many entries per reference view on average. */
+    const unsigned FRONT_PER_VIEW = [] { const char* e = std::getenv("MI_DMRECON_FRONT"); return e ? (unsigned)std::max(0, std::atoi(e)) : (unsigned)MI_FRONT_DEFAULT; }();
+    const unsigned front_max = FRONT_PER_VIEW * (unsigned)nj;
+    const ActiveCall& active = *active_call;
+    wcur = c->d_work.p; wnext = c->d_work2.p; rcur = c->d_results.p; rnext = c->d_results2.p;
+    /* An event record costs ~6 us of queue time on either side of the kernel it brackets -- more than a tenth of a
+     * tail round: every 8th round is timed (all of them when tracing); the tail launches are uniform (one dependent
+     * patch chain each), their mean stands in for the untimed ones. */
+    const unsigned TIMED_EVERY = trace ? 1u : 8u;
+    struct ChunkInfo { int first; size_t ev_first, ev_last; };
+    ChunkInfo info[2];
+    auto enqueue_chunk = [&](int slot) -> int {
+        info[slot].first = round; info[slot].ev_first = ev.items.size();
+        /* workgroups of a blind round: one per candidate (4 per entry of the previous list) lets the wavefronts without
+         * a source end at once; the list sizes are known with a chunk's delay, so the grid is twice what the last
+         * known size asks for (a shorter grid strides, correct but with idle wavefronts) */
+        const unsigned grid = std::min(65536u, std::max(1024u, 8u * tail_known));
+        /* Speculative attempts (workgroups of four wavefronts) buy latency -- for a call that has the GPU to itself or
+         * shares it with one other.  Next to the bulk rounds of several other calls the small form (one wavefront per
+         * workgroup, 168 registers, 7 KB of LDS) is placed without draining a CU first and takes less from them. */
+        const bool speculative = tail_known <= SPEC_MAX && active.count() <= 2;
+        for (unsigned k = 0; k < MI_TAIL_CHUNK; ++k, ++round) {
+            const bool timed = (stats != nullptr || trace) && k % TIMED_EVERY == 0;
+            if (timed) ev.begin(S, EventLog::TAIL, k);            /* k -> entries after the read-back */
+            D->tail(S, grid, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext, c->d_round_work.p, round,
+                    c->d_counters, speculative);
+            if (timed) ev.end(S);
+            std::swap(wcur, wnext); std::swap(rcur, rnext);
+        }
+        info[slot].ev_last = ev.items.size();
+        TailPoll& P = c->h_poll[slot];
+        if (hipMemcpyAsync(P.rw, c->d_round_work.p + info[slot].first, MI_TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
+            || hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S) != hipSuccess
+            || read_dyn(slot) != hipSuccess || hipEventRecord(c->poll_ev[slot], S) != hipSuccess)
+            return fail(MI_DMRECON_EDEVICE, "enqueue of tail rounds failed");
         return 0;
     };
-    auto read_dyn = [&](DevJob* dst) -> hipError_t {        /* the job table (a few KB) with its flags / n_filled words */
-        return hipMemcpyAsync(dst, c->d_jobs.p, (size_t)nj * sizeof(DevJob), hipMemcpyDeviceToHost, S);
-    };
-
-    while (!done && n_alive > 0) {
-        /* ---- phase A */
-        bool to_tail = false;
-        for (; round < max_rounds && !done && n_alive > 0; ++round) {
-            /* MI_DMRECON_SEED_REOPT=1: round 1 = the seeds' own queue entries -- the reference pushes a seed's OWN pixel,
-             * re-optimises it from its converged result when popped and lets it propagate only if that strictly raised
-             * its confidence (dmrecon.cc:320-329,365-398).  Default off: every seed propagates at once.  Measured on C3
-             * (DESIGN.md section 2): no parity gain (fill IoU / depth p99 against the reference unchanged), one more
-             * bulk round per call and sparser early fronts: +8 % bulk kernel time. */
-            static const bool SEED_REOPT = [] { const char* e = std::getenv("MI_DMRECON_SEED_REOPT"); return e && std::atoi(e) != 0; }();
-            const bool self = SEED_REOPT && round == 1;
-            ev_begin(1);
-            D.generate(S, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round, self,
-                       BANDS ? max_tiles_x : 0, BANDS ? max_tiles_y : 0);
-            ev_end();
-            TailPoll& P = c->h_poll[0];
-            HIP_TRY(hipMemcpyAsync(&P.rw[0], c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
-            HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
-            HIP_TRY(read_dyn(dyn_of(0)));
-            HIP_TRY(hipStreamSynchronize(S));
-            const unsigned n_work = P.rw[0];
-            hc = P.hc;
-            if (poll_views(dyn_of(0), n_work)) return fail(MI_DMRECON_EDEVICE, "hipMemcpyAsync(job flags) failed");
-            if (n_work == 0) { done = true; break; }
-            if (n_alive == 0) break;
-            const bool tail = n_work < TAIL_THRESHOLD;
-            ev_begin(0); ev_work.push_back(n_work); ev_tail.push_back(0);
-            if (tail)
-                D.optimize(S, 16, std::min(n_work, TAIL_GRID), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
-                                   nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters,
-                                   nullptr, nullptr, nullptr, nullptr, WIN_TAIL, self, false);
-            else if (!USE_FOLLOW || BULK_LPV == 16 || self)
-                D.optimize(S, BULK_LPV, BULK_LPV == 16 ? std::min(n_work, 16384u) : (n_work + BULK_PPW - 1) / BULK_PPW,
-                                   c->d_jobs.p, c->sc->d_views.p,
-                                   c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round,
-                                   c->d_counters, nullptr, nullptr, nullptr, nullptr, BULK_LPV == 16 ? WIN_TAIL : WIN_BULK, self, BANDS && BULK_LPV != 16);
-            else {
-                /* throughput layout: one optimisation attempt per entry and launch; the entries whose pixel has further
-                 * candidate hypotheses (about one in five) continue in a follow-up launch over a compacted list (its
-                 * size stays on the device), so that the wavefronts of both launches are full */
-                /* MI_DMRECON_MID_THRESHOLD=<entries> (default 0 = off): lists below it run in the middle layout (4 lanes per
-                 * view, 4 patches per wavefront): a list of 14 000-50 000 entries is fewer Lay<1> wavefronts than the GPU
-                 * has slots and costs one 150-250 us generation however small it is */
-                const bool mid = !WIN_BULK && n_work < MID_THRESHOLD;
-                const int lpv = mid ? 4 : BULK_LPV;
-                const unsigned ppw = mid ? 4u : BULK_PPW;
-                const unsigned waves = (n_work + ppw - 1) / ppw;
-                unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
-                unsigned* fa = c->d_follow.p;
-                D.optimize(S, lpv, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
-                                   c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, fa, fcnt, WIN_BULK, false, BANDS && !mid);
-                /* the follow-up launch runs all remaining attempts of its entries back to back (third and fourth
-                 * attempts are rare: a third launch would cost more in latency than it saves) */
-                D.optimize(S, lpv, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
-                                   nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, fa, fcnt, nullptr, nullptr, WIN_BULK, false, false);
-                ++n_launch;
-            }
-            ev_end();
-            ++n_launch;
-            ev_begin(1);
-            mi_launch_apply(S, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
-            ev_end();
-            if (tail) {
-                tail_known = n_work;
-                /* counters as of the end of the host-visible rounds (slot 2 of the poll buffer; read after the call) */
-                HIP_TRY(hipMemcpyAsync(&c->h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
-                have_handover = true;
-                ++round; to_tail = true; break;
-            }
+    int slot = 0;
+    if (int rc = enqueue_chunk(0)) return rc;
+    for (;;) {
+        const bool want_front = front_max > 0 && tail_known <= front_max;
+        const bool more_room = round + (int)MI_TAIL_CHUNK < MI_MAX_ROUNDS - 1;
+        const bool ahead = more_room && !want_front;              /* keep a second chunk in flight */
+        if (ahead) if (int rc = enqueue_chunk(slot ^ 1)) return rc;
+        HIP_TRY(hipEventSynchronize(c->poll_ev[slot]));
+        TailPoll& P = c->h_poll[slot];
+        hc = P.hc;
+        for (size_t q = info[slot].ev_first; q < info[slot].ev_last; ++q) ev.items[q].work = P.rw[ev.items[q].work];
+        int end_round = -1;
+        unsigned chunk_max = 0;
+        for (unsigned k = 0; k < MI_TAIL_CHUNK; ++k) {
+            if (P.rw[k] == 0) { end_round = info[slot].first + (int)k; break; }
+            ++n_launch; ++n_tail_launch;
+            if (k >= MI_TAIL_CHUNK / 2) chunk_max = std::max(chunk_max, P.rw[k]);
         }
-        if (bulk_token.owns_lock()) bulk_token.unlock();       /* the next call's bulk rounds run while this one's tail does */
-        if (first_phase_a) { mark("seeds + phase A rounds"); first_phase_a = false; }
-        if (done || n_alive == 0) break;
-        if (!to_tail) { truncated = true; break; }            /* round counters exhausted */
-        /* ---- phase B: one fused launch per round (k_tail: candidates from the previous round's accepted entries ->
-         * this round's list, optimisations and state writes); lists and results ping-pong.  A chunk of rounds is
-         * enqueued blind and its counters are read back while the NEXT chunk already runs (empty rounds are
-         * microsecond no-ops), so the GPU never waits for the host inside the tail. */
-        /* MI_DMRECON_TAIL_PRIORITY=1: the tail rounds go to the context's high-priority stream -- each is a handful of
-         * latency-bound workgroups, and next to the bulk kernels of other calls on the same GPU they queue behind tens
-         * of thousands of bulk workgroups for every one of their ~600 dependent rounds.  Off by default: measured +6 %
-         * depth-maps/s with six host threads in most runs, but one run in five collapsed to a third of the rate with
-         * every kernel running alone (queues of two priorities apparently not scheduled side by side). */
-        if (c->stream_hi && TAIL_PRIORITY) {
-            HIP_TRY(hipEventRecord(c->xs_ev, c->stream));
-            HIP_TRY(hipStreamWaitEvent(c->stream_hi, c->xs_ev, 0));
-            S = c->stream_hi;
-        }
-        DevEntry* wcur = c->d_work.p;        /* list + results of the last executed round (round - 1) */
-        DevEntry* wnext = c->d_work2.p;
-        DevResult* rcur = c->d_results.p;
-        DevResult* rnext = c->d_results2.p;
-        struct ChunkInfo { int first; size_t ev_first, ev_last; int mode; };
-        ChunkInfo info[2];
-        auto enqueue_chunk = [&](int slot) -> int {
-            info[slot].first = round; info[slot].ev_first = ev_work.size();
-            int mode = 0;                                  /* 0: one launch per round, 1: persistent, one team, 2: eight teams */
-            if (teams_started) mode = 2;                   /* the lists are the teams' now */
-            else if (!WIN_TAIL && SPEC_MAX > 0 && tail_known <= PERSIST_MAX) {
-                if (PERSIST_MODE > 0) mode = PERSIST_MODE;
-                else if (PERSIST_MODE < 0 && active_call.alone()) mode = 2;
-                if (mode == 2) {
-                    if (c->xcc_mask < 0) {                 /* once per context: do the workgroups of a grid reach all eight XCDs? */
-                        unsigned m = 0;
-                        if (c->d_xcc.reserve(1) || hipMemsetAsync(c->d_xcc.p, 0, sizeof(unsigned), S) != hipSuccess) return -1;
-                        mi_launch_xcc_probe(S, c->d_xcc.p);
-                        if (hipMemcpyAsync(&m, c->d_xcc.p, sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
-                            || hipStreamSynchronize(S) != hipSuccess) return -1;
-                        c->xcc_mask = (int)m;
-                    }
-                    if (c->xcc_mask != (1 << MI_TEAMS) - 1) mode = PERSIST_MODE > 0 ? 1 : 0;
-                }
-            }
-            info[slot].mode = mode;
-            if (mode != 0) {
-                /* the whole chunk in one launch; TAIL_CHUNK is even, so the list buffers end where they started */
-                const bool timed = stats != nullptr || trace;
-                if (mode == 2 && !teams_started) {
-                    /* deal the list of the last round out to the teams (into the free buffer pair) */
-                    mi_launch_team_split(S, wcur, rcur, c->d_round_work.p + (round - 1), wnext, rnext,
-                                         d_team_work + (size_t)(round - 1) * MI_TEAMS, team_off);
-                    std::swap(wcur, wnext); std::swap(rcur, rnext);
-                    teams_started = true;
-                }
-                if (timed) { ev_begin(0); ev_work.push_back(0); ev_tail.push_back(2); }
-                const unsigned grid = PERSIST_GRID ? PERSIST_GRID : (mode == 2 ? 512u : std::min(512u, std::max(64u, tail_known)));
-                D.tail_persist(S, grid, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
-                               mode == 2 ? d_team_work : c->d_round_work.p, d_ticket_head, d_ticket_done, mode == 2 ? team_off : nullptr,
-                               round, (int)TAIL_CHUNK, c->d_counters, PERSIST_SPIN_MS);
-                if (timed) ev_end();
-                round += (int)TAIL_CHUNK;
-            } else {
-            /* Speculative attempts (workgroups of four wavefronts) buy latency -- for a call that has the GPU to itself
-             * or shares it with one other.  Next to the bulk rounds of several other calls the small form (one
-             * wavefront per workgroup, 168 registers, 4 KB of LDS) is placed without draining a CU first and takes
-             * less from them: measured 768-777 against 718-731 depth-maps/s with six host threads, 707 against 742
-             * with two.  MI_DMRECON_SPECULATE_SHARED=1: speculative regardless. */
-            const bool speculative = tail_known <= SPEC_MAX && (SPEC_SHARED || active_call.count() <= 2);
-            for (unsigned k = 0; k < TAIL_CHUNK; ++k, ++round) {
-                const bool timed = (stats != nullptr || trace) && k % TAIL_TIMED_EVERY == 0;
-                if (timed) { ev_begin(0); ev_work.push_back(k); ev_tail.push_back(1); }     /* k -> entries after the read-back */
-                D.tail(S, tail_grid(), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext,
-                               c->d_round_work.p, round, c->d_counters, WIN_TAIL, speculative);
-                if (timed) ev_end();
-                std::swap(wcur, wnext);
-                std::swap(rcur, rnext);
-            }
-            }
-            info[slot].ev_last = ev_work.size();
-            TailPoll& P = c->h_poll[slot];
-            if (mode == 2) {
-                if (hipMemcpyAsync(P.tw, d_team_work + (size_t)info[slot].first * MI_TEAMS, TAIL_CHUNK * MI_TEAMS * sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess) return -1;
-            } else if (hipMemcpyAsync(P.rw, c->d_round_work.p + info[slot].first, TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess) return -1;
-            if (hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S) != hipSuccess) return -1;
-            if (read_dyn(dyn_of(slot)) != hipSuccess) return -1;
-            if (hipEventRecord(c->poll_ev[slot], S) != hipSuccess) return -1;
+        if (chunk_max) tail_known = chunk_max;
+        if (int rc = poll_views(dyn_of(slot), P.rw[MI_TAIL_CHUNK - 1])) return rc;
+        if (end_round >= 0) {
+            /* an empty round: the propagation is over */
+            if (ahead) HIP_TRY(hipEventSynchronize(c->poll_ev[slot ^ 1]));     /* the chunk in flight is all no-ops */
+            round = end_round;
+            done = true;
             return 0;
-        };
-        ran_tail = true;
-        int slot = 0;
-        if (enqueue_chunk(0)) return fail(MI_DMRECON_EDEVICE, "enqueue of tail rounds failed");
-        for (;;) {
-            const bool more_room = round + (int)TAIL_CHUNK < MI_MAX_ROUNDS - 1;
-            if (more_room && enqueue_chunk(slot ^ 1)) return fail(MI_DMRECON_EDEVICE, "enqueue of tail rounds failed");
-            HIP_TRY(hipEventSynchronize(c->poll_ev[slot]));
-            TailPoll& P = c->h_poll[slot];
-            hc = P.hc;
-            if (info[slot].mode == 2)                      /* entries of a round = the sum over the teams */
-                for (unsigned k = 0; k < TAIL_CHUNK; ++k) {
-                    P.rw[k] = 0;
-                    for (int x = 0; x < MI_TEAMS; ++x) P.rw[k] += P.tw[k * MI_TEAMS + x];
-                }
-            for (size_t q = info[slot].ev_first; q < info[slot].ev_last; ++q) ev_work[q] = P.rw[ev_work[q]];
-            int end_round = -1;
-            unsigned chunk_max = 0;
-            if (P.hc.error_flags & 4u) return fail(MI_DMRECON_EDEVICE, "a persistent tail launch gave up waiting for a round (MI_DMRECON_TAIL_SPIN_MS)");
-            for (unsigned k = 0; k < TAIL_CHUNK; ++k) {
-                if (P.rw[k] == 0) { end_round = info[slot].first + (int)k; break; }
-                if (info[slot].mode == 0) { ++n_launch; ++n_tail_launch; ++n_tail_classic; }
-                else { ++n_tail_rounds_persist; if (k == 0) { ++n_launch; ++n_tail_launch; } }
-                if (k >= TAIL_CHUNK / 2) chunk_max = std::max(chunk_max, P.rw[k]);
-            }
-            if (chunk_max) tail_known = chunk_max;
-            if (poll_views(dyn_of(slot), P.rw[TAIL_CHUNK - 1])) return fail(MI_DMRECON_EDEVICE, "hipMemcpyAsync(job flags) failed");
-            if (end_round >= 0) {
-                /* an empty round: the propagation is over */
-                if (more_room) HIP_TRY(hipEventSynchronize(c->poll_ev[slot ^ 1]));     /* the chunk in flight is all no-ops */
-                round = end_round;
-                done = true;
-                break;
-            }
-            if (n_alive == 0) break;
-            if (!more_room) { truncated = true; break; }
-            slot ^= 1;
         }
-        mi_launch_flatten(S, c->d_maps.p, c->d_imaps.p, total_px);
-        if (S != c->stream) {                                  /* the rest of the call is ordered behind the tail again */
-            HIP_TRY(hipEventRecord(c->xs_ev, S));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->xs_ev, 0));
-            S = c->stream;
+        if (n_alive == 0) return 0;
+        if (!ahead) {
+            /* nothing is in flight behind this chunk: its last round's list is the current one */
+            if (want_front) { to_front = true; return 0; }
+            truncated = true;                                     /* round counters exhausted */
+            return 0;
         }
-        if (truncated) break;
+        slot ^= 1;
     }
-    (void)ran_tail;
-    mark("phase B rounds");
-    /* ---- results back to the caller's buffers */
-    int n_ok = 0, first_rc = 0;
-    for (int i = 0; i < n_refs; ++i) {
-        if (status_out) status_out[i] = view_rc[i];
-        if (view_rc[i] == 0) { ++n_ok; if (progress) progress[i].status = MI_RECON_SAVING; }
-        else if (!first_rc) first_rc = view_rc[i];
-    }
+}
+
+/* ---- phase C: the rest of the propagation, one persistent workgroup per reference view (k_front, dmrecon_device.hip):
+ * each view runs its own rounds from the list the last tail round left, at its own pace, until its front is empty. */
+int BatchRun::front_rounds() {
+    unsigned* d_off = c->d_front.p; unsigned* d_cnt = d_off + nj; unsigned* d_stats = d_cnt + nj;
+    HIP_TRY(hipMemcpyAsync(d_off, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));   /* a view's list region = its pixel offset */
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * (size_t)nj * sizeof(unsigned) + nj * sizeof(unsigned), S));
+    front_first_round = round;
+    ev.begin(S, EventLog::FRONT, tail_known);
+    D->front(S, nj, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, c->d_round_work.p + (round - 1),
+             wnext, rnext, wcur, rcur, d_off, d_cnt, d_stats, round, 0x7FFFFFF0, c->d_counters);
+    ev.end(S);
+    ++n_launch;
+    front_stats.assign(4 * (size_t)nj, 0u);
+    TailPoll& P = c->h_poll[0];
+    HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
+    HIP_TRY(read_dyn(0));
+    HIP_TRY(hipMemcpyAsync(front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
+    HIP_TRY(hipStreamSynchronize(S));
+    hc = P.hc;
+    ran_front = true;
+    /* n_rounds as one launch per round counts them: up to the first round that accepted nothing (the slowest view's
+     * last round is that one) */
+    unsigned rmax = 0;
+    for (int j = 0; j < nj; ++j) rmax = std::max(rmax, front_stats[4 * j]);
+    if (rmax > 0) round += (int)rmax - 1;
+    if (int rc = poll_views(dyn_of(0), 0)) return rc;
+    if (hc.error_flags & 8u) truncated = true;
+    else done = true;
+    return 0;
+}
+
+/* ---- results back to the caller's buffers (views that did not finish keep their buffers untouched) */
+int BatchRun::download() {
     std::vector<uint32_t> packed;
     for (int i = 0; i < n_refs; ++i) {
         const int j = job_of[i];
         if (j < 0 || view_rc[i] != 0) continue;
+        if (progress) progress[i].status = MI_RECON_SAVING;
         const size_t np = (size_t)jobs[j].w * jobs[j].h;
         mi_dmrecon_maps& m = maps[i];
-        if (m.depth) HIP_TRY(hipMemcpyAsync(m.depth, dj[j].depth, np * 4, hipMemcpyDeviceToHost, c->stream));
-        if (m.conf) HIP_TRY(hipMemcpyAsync(m.conf, dj[j].conf, np * 4, hipMemcpyDeviceToHost, c->stream));
-        if (m.dz) HIP_TRY(hipMemcpyAsync(m.dz, dj[j].dz, np * 8, hipMemcpyDeviceToHost, c->stream));
-        if (m.normal) HIP_TRY(hipMemcpyAsync(m.normal, dj[j].normal, np * 12, hipMemcpyDeviceToHost, c->stream));
+        if (m.depth) HIP_TRY(hipMemcpyAsync(m.depth, dj[j].depth, np * 4, hipMemcpyDeviceToHost, S));
+        if (m.conf) HIP_TRY(hipMemcpyAsync(m.conf, dj[j].conf, np * 4, hipMemcpyDeviceToHost, S));
+        if (m.dz) HIP_TRY(hipMemcpyAsync(m.dz, dj[j].dz, np * 8, hipMemcpyDeviceToHost, S));
+        if (m.normal) HIP_TRY(hipMemcpyAsync(m.normal, dj[j].normal, np * 12, hipMemcpyDeviceToHost, S));
         if (m.views) {
             packed.resize(np);
-            HIP_TRY(hipMemcpyAsync(packed.data(), dj[j].views, np * 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpyAsync(packed.data(), dj[j].views, np * 4, hipMemcpyDeviceToHost, S));
+            HIP_TRY(hipStreamSynchronize(S));
             for (size_t p = 0; p < np; ++p)
                 for (int k = 0; k < 4; ++k) {
                     const unsigned g = (packed[p] >> (8 * k)) & 0xFFu;
@@ -1582,60 +1478,127 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
                 }
         }
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(S));
     mark("download");
+    return 0;
+}
+
+void BatchRun::fill_stats() {
     if (stats) {
         stats->n_patch = (int64_t)hc.n_patch; stats->n_eval = (int64_t)hc.n_eval; stats->n_pass = (int64_t)hc.n_pass;
         stats->n_filled = (int64_t)hc.n_filled;
         stats->n_seeds = (int64_t)n_seed_feats; stats->n_seeds_ok = (int64_t)hc.n_seeds_ok;
         stats->n_rounds = round; stats->n_launches = n_launch; stats->truncated = truncated ? 1 : 0;
-        stats->n_stage = (int64_t)hc.n_stage; stats->n_gather_pass = (int64_t)hc.n_gather_pass;
         stats->n_view_replaced = (int64_t)hc.n_view_replaced; stats->n_iter14 = (int64_t)hc.n_iter14;
-        double tail_ms = 0.0, tail_persist_ms = 0.0; int64_t tail_timed = 0;
-        size_t w = 0;
-        for (size_t k = 0; k < ev_kind.size(); ++k) {
+        double tail_ms = 0.0; int64_t tail_timed = 0;
+        for (const EventLog::Item& it : ev.items) {
             float ms = 0.f;
-            const bool got = hipEventElapsedTime(&ms, c->events[ev_kind[k].first], c->events[ev_kind[k].first + 1]) == hipSuccess;
-            if (ev_kind[k].second != 0) { if (got) stats->ms_sweep_kernels += ms; continue; }
-            if (!ev_tail[w]) { if (got) { stats->ms_opt_kernel += ms; stats->ms_bulk_kernel += ms; ++stats->n_bulk_launches; } }
-            else if (ev_tail[w] == 2) { if (got && ev_work[w] > 0) tail_persist_ms += ms; }
-            else if (got && ev_work[w] > 0) { tail_ms += ms; ++tail_timed; }
-            ++w;
+            if (!ev.ms(it, ms)) continue;
+            switch (it.kind) {
+                case EventLog::SWEEP: stats->ms_sweep_kernels += ms; break;
+                case EventLog::BULK: stats->ms_bulk_kernel += ms; ++stats->n_bulk_launches; break;
+                case EventLog::TAIL: if (it.work > 0) { tail_ms += ms; ++tail_timed; } break;
+                case EventLog::FRONT: stats->ms_front_kernel += ms; break;
+            }
         }
-        /* phase B: mean of the timed launches x number of launches that had work; persistent launches are all timed */
-        if (tail_timed > 0) stats->ms_tail_kernel = tail_ms / (double)tail_timed * (double)n_tail_classic;
-        stats->ms_tail_kernel += tail_persist_ms;
-        stats->ms_opt_kernel += stats->ms_tail_kernel;
-        stats->n_tail_rounds_persistent = n_tail_rounds_persist;
+        /* phase B: mean of the timed launches x number of launches that had work */
+        if (tail_timed > 0) stats->ms_tail_kernel = tail_ms / (double)tail_timed * (double)n_tail_launch;
+        stats->ms_opt_kernel = stats->ms_bulk_kernel + stats->ms_tail_kernel + stats->ms_front_kernel;
         stats->n_tail_launches = n_tail_launch;
-        const DevCounters& ho = have_handover ? c->h_poll[2].hc : hc;      /* the stream has been synchronised above */
+        if (ran_front) {
+            stats->n_front_launches = 1;
+            stats->front_first_round = front_first_round;
+            for (int j = 0; j < nj; ++j) {
+                const unsigned* fs = &front_stats[4 * (size_t)j];
+                if (fs[0]) ++stats->n_front_views;
+                stats->n_front_rounds_max = std::max<int64_t>(stats->n_front_rounds_max, fs[0]);
+                stats->n_front_rounds_sum += fs[0]; stats->n_front_attempts += fs[1]; stats->n_front_entries += fs[2];
+                stats->ms_front_view_max = std::max(stats->ms_front_view_max, fs[3] * 1e-5);   /* 100 MHz ticks */
+            }
+        }
+        const DevCounters& ho = have_handover ? c->h_poll[2].hc : hc;      /* the stream has been synchronised */
         stats->n_eval_bulk = (int64_t)ho.n_eval; stats->n_patch_bulk = (int64_t)ho.n_patch; stats->n_filled_bulk = (int64_t)ho.n_filled;
         stats->ms_total = now_ms() - t_begin;
     }
     if (trace) {
         size_t w = 0;
-        for (size_t k = 0; k < ev_kind.size(); ++k) {
-            if (ev_kind[k].second != 0) continue;
+        for (const EventLog::Item& it : ev.items) {
+            if (it.kind == EventLog::SWEEP) continue;
             float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, c->events[ev_kind[k].first], c->events[ev_kind[k].first + 1]);
-            if (ev_work[w] || ms > 0.02f) fprintf(stderr, "[mi_dmrecon] optimise launch %zu: %u entries, %.3f ms\n", w, ev_work[w], ms);
+            (void)ev.ms(it, ms);
+            if (it.work || ms > 0.02f)
+                fprintf(stderr, "[mi_dmrecon] %s launch %zu: %u entries, %.3f ms\n", it.kind == EventLog::FRONT ? "front" : "optimise", w, it.work, ms);
             ++w;
         }
+        if (ran_front)
+            for (int j = 0; j < nj; ++j) {
+                const unsigned* fs = &front_stats[4 * (size_t)j];
+                fprintf(stderr, "[mi_dmrecon] front view %d: %u rounds, %u attempts, %u entries, %.3f ms\n", jobs[j].ref_view, fs[0], fs[1], fs[2], fs[3] * 1e-5);
+            }
         fprintf(stderr, "[mi_dmrecon] total %.2f ms host wall\n", now_ms() - t_begin);
     }
-    for (int i = 0; progress && i < n_refs; ++i) if (view_rc[i] == 0) progress[i].status = MI_RECON_IDLE;
-    if (truncated) return fail(MI_DMRECON_EDEVICE, "propagation did not finish within %d rounds", MI_MAX_ROUNDS);
-    if (n_ok == 0) {
-        /* every view of the call failed: report the first one's reason (a single-view call behaves like
-         * DMRecon::start(): the exception / the cancellation is the call's outcome) */
-        switch (first_rc) {
-            case MI_DMRECON_ECANCELLED: return fail(first_rc, "cancelled");
-            case MI_DMRECON_EFOOTPRINT: return fail(first_rc, "Negative pixel footprint");
-            case MI_DMRECON_EGVS: return fail(first_rc, "Global View Selection failed");
-            default: return fail(first_rc ? first_rc : MI_DMRECON_EDEVICE, "reconstruction failed");
-        }
+}
+
+/* per-view statuses and the call's return value */
+int BatchRun::outcome() {
+    int n_ok = 0, first_rc = 0, first_i = -1;
+    for (int i = 0; i < n_refs; ++i) {
+        if (status_out) status_out[i] = view_rc[i];
+        if (view_rc[i] == 0) { ++n_ok; if (progress) progress[i].status = MI_RECON_IDLE; }
+        else if (!first_rc || (first_rc == MI_DMRECON_ECANCELLED && view_rc[i] != MI_DMRECON_ECANCELLED)) { first_rc = view_rc[i]; first_i = i; }
     }
-    return 0;
+    if (truncated) return fail(MI_DMRECON_EDEVICE, "propagation did not finish within %d rounds", MI_MAX_ROUNDS);
+    if (n_ok > 0) return 0;
+    /* every view of the call failed: the first failure's own code and message (a single-view call behaves like
+     * DMRecon::start(): the exception / the cancellation is the call's outcome) */
+    switch (first_rc) {
+        case MI_DMRECON_ECANCELLED: return fail(first_rc, "cancelled");
+        case MI_DMRECON_EFOOTPRINT: return fail(first_rc, "Negative pixel footprint");
+        case MI_DMRECON_EGVS: return fail(first_rc, "Global View Selection failed");
+        default:
+            if (first_i >= 0 && !plan_err[first_i].empty()) { g_err = plan_err[first_i]; return first_rc; }
+            return fail(first_rc ? first_rc : MI_DMRECON_EDEVICE, "reconstruction failed");
+    }
+}
+
+}  // namespace
+
+static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views,
+                             mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out,
+                             mi_dmrecon_stats* stats) {
+    if (!c || !ref_views || !maps || n_refs <= 0) return fail(MI_DMRECON_EINVAL, "null argument");
+    int rc = check_settings(st);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const ActiveCall active_call(c->device);
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    BatchRun B;
+    B.c = c; B.st = st; B.n_refs = n_refs; B.ref_views = ref_views; B.maps = maps; B.progress = progress;
+    B.status_out = status_out; B.stats = stats; B.D = mi_device_api(st->filterWidth); B.ds = dev_settings(st); B.S = c->stream;
+    B.trace = std::getenv("MI_DMRECON_TRACE") != nullptr; B.t_begin = B.t_mark = now_ms();
+    B.ev.c = c; B.active_call = &active_call;
+    std::memset(&B.hc, 0, sizeof(B.hc));
+    try {
+        if ((rc = B.plan()) != 0) return rc;
+        if ((rc = B.upload()) != 0) return rc;
+        if ((rc = B.seed_round()) != 0) return rc;
+        for (int i = 0; progress && i < n_refs; ++i) if (B.view_rc[i] == 0) progress[i].status = MI_RECON_QUEUE;
+        /* the propagation sweeps (replace DMRecon::processQueue, dmrecon.cc:333-434) */
+        bool to_tail = false, to_front = false;
+        if ((rc = B.bulk_rounds(to_tail)) != 0) return rc;
+        B.mark("seeds + phase A rounds");
+        if (to_tail) {
+            if ((rc = B.tail_rounds(to_front)) != 0) return rc;
+            B.mark("phase B rounds");
+            if (to_front) { if ((rc = B.front_rounds()) != 0) return rc; B.mark("phase C (front kernel)"); }
+            mi_launch_flatten(B.S, c->d_maps.p, c->d_imaps.p, B.total_px);
+        }
+        if ((rc = B.download()) != 0) return rc;
+        B.fill_stats();
+        return B.outcome();
+    } catch (const std::bad_alloc&) {
+        return fail(MI_DMRECON_EDEVICE, "out of host memory");
+    }
 }
 
 /*
@@ -1655,12 +1618,12 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
  *     callers get zeros with merged_into_other_call = 1, so that sums over calls stay right.
  *   - Calls with a progress array (cancellation, status polling) are never merged.  MI_DMRECON_MERGE_CALLS=0: off.
  */
-int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views,
+static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views,
                            mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out,
                            mi_dmrecon_stats* stats) {
     /* (read per call: tests switch them) */
     const bool MERGE = [] { const char* e = std::getenv("MI_DMRECON_MERGE_CALLS"); return e ? std::atoi(e) != 0 : true; }();
-    const int MAX_RUNNING = [] { const char* e = std::getenv("MI_DMRECON_MERGE_RUNNING"); return e ? std::max(1, std::atoi(e)) : 2; }();
+    const int MAX_RUNNING = 2;                               /* batches of one scene in flight at a time */
     const int WINDOW_US = [] { const char* e = std::getenv("MI_DMRECON_MERGE_WINDOW_US"); return e ? std::max(0, std::atoi(e)) : 150; }();
     if (!MERGE || progress || !c || !st || !ref_views || !maps || n_refs <= 0)
         return reconstruct_batch(c, st, n_refs, ref_views, maps, progress, status_out, stats);
@@ -1695,11 +1658,30 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
         }
     }
     Q.cv.notify_all();                                       /* requests with other settings may lead now */
+    /* whatever happens below (std::bad_alloc included): the batch stops counting as running, and every follower that
+     * has not been handed its result gets an error instead of waiting for ever */
+    struct Release {
+        MergeQueue& Q; std::vector<MergeReq*>& batch; MergeReq* me;
+        ~Release() {
+            {
+                std::lock_guard<std::mutex> lock(Q.mu);
+                --Q.running;
+                for (MergeReq* r : batch) {
+                    if (r == me || r->done) continue;
+                    if (!r->served) { r->rc = MI_DMRECON_EDEVICE; r->err = "the merged batch this call was part of failed"; }
+                    r->done = true;
+                }
+            }
+            Q.cv.notify_all();
+        }
+    } release{Q, batch, &me};
     int rc = 0;
-    if (batch.size() == 1) {
-        rc = reconstruct_batch(c, st, n_refs, ref_views, maps, nullptr, status_out, stats);
-        if (stats) stats->n_merged_calls = 1;
-    } else {
+    try {
+        if (batch.size() == 1) {
+            rc = reconstruct_batch(c, st, n_refs, ref_views, maps, nullptr, status_out, stats);
+            if (stats) stats->n_merged_calls = 1;
+            return rc;
+        }
         size_t total = 0;
         for (MergeReq* r : batch) total += (size_t)r->n;
         std::vector<int32_t> refs; refs.reserve(total);
@@ -1731,22 +1713,20 @@ int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int
                 if (r == &me) *r->stats = bs;
                 else { std::memset(r->stats, 0, sizeof(*r->stats)); r->stats->merged_into_other_call = 1; }
             }
+            r->served = true;
             off += (size_t)r->n;
         }
         rc = me.rc;
         if (rc) g_err = me.err;
+    } catch (const std::bad_alloc&) {
+        rc = fail(MI_DMRECON_EDEVICE, "out of host memory");
     }
-    {
-        std::lock_guard<std::mutex> lock(Q.mu);
-        --Q.running;
-        for (MergeReq* r : batch) if (r != &me) r->done = true;
-    }
-    Q.cv.notify_all();
     return rc;
 }
 
-int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n,
-                              const int32_t* xy, const float* hyp, const int32_t* local, float* out, int32_t* out_local) {
+static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n,
+                              const int32_t* xy, const float* hyp, const int32_t* local, int32_t lanes_per_view,
+                              float* out, int32_t* out_local) {
     if (!c || !xy || !hyp || !out || !out_local || n < 0) return fail(MI_DMRECON_EINVAL, "null argument");
     int rc = check_settings(st);
     if (rc) return rc;
@@ -1791,18 +1771,12 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     HIP_TRY(hipMemcpyAsync(c->d_work.p, ent.data(), n * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hy.data(), n * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
-    /* MI_DMRECON_HOOK_LPV=16 runs the hook through the latency layout (tests cover both layouts) */
-    const char* lpv_env = std::getenv("MI_DMRECON_HOOK_LPV");
-    const int lpv = (lpv_env && std::atoi(lpv_env) == 16) ? 16 : (lpv_env && std::atoi(lpv_env) == 4) ? 4 : 1;
-    const unsigned ppw = lpv == 16 ? 1u : lpv == 4 ? 4u : (unsigned)MI_PATCHES_PER_WAVE;
-    /* MI_DMRECON_WIN (bit 0: latency layout, bit 1: throughput layout) selects the texel-window kernels here too */
-    const char* win_env = std::getenv("MI_DMRECON_WIN");
-    const int win_bits = win_env ? std::atoi(win_env) : MI_WIN_DEFAULT;
-    const bool windows = lpv != 4 && (win_bits & (lpv == 16 ? 1 : 2)) != 0;
-    D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw,
-                       c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), c->d_work.p, c->d_hyp.p,
-                       c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
-                       nullptr, nullptr, nullptr, nullptr, windows, false, false);
+    /* lanes_per_view = 16 runs the hook through the latency layout, anything else through the throughput layout */
+    const int lpv = lanes_per_view == 16 ? 16 : 1;
+    const unsigned ppw = lpv == 16 ? 1u : (unsigned)MI_PATCHES_PER_WAVE;
+    D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st),
+               c->d_work.p, c->d_hyp.p, c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
+               nullptr, nullptr, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     std::vector<DevResult> res(n);
     HIP_TRY(hipMemcpyAsync(res.data(), c->d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
@@ -1819,7 +1793,7 @@ int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, 
     return 0;
 }
 
-int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t x, int32_t y,
+static int mi_dmrecon_patch_eval_impl(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t x, int32_t y,
                           float depth, float dzI, float dzJ, float* master, float* ncc, int32_t* ok, float* col,
                           float* deriv, int32_t* level) {
     if (!c || !master || !ncc || !ok || !col || !deriv || !level) return fail(MI_DMRECON_EINVAL, "null argument");
@@ -1864,7 +1838,7 @@ int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int3
 }
 
 /* apps/scene2pset per-view body (scene2pset.cc:262-356); kernels in pointset_device.hip */
-int mi_dmrecon_pointset(mi_dmrecon_ctx* c, const mi_dmrecon_camera* cam, int32_t w, int32_t h, const float* depth,
+static int mi_dmrecon_pointset_impl(mi_dmrecon_ctx* c, const mi_dmrecon_camera* cam, int32_t w, int32_t h, const float* depth,
                         const uint8_t* color, int32_t color_channels, const mi_dmrecon_pointset_options* opt,
                         int32_t capacity, int32_t* pixel, float* pos, float* normal, float* color_out, float* scale,
                         float* conf, int32_t* n_out) {
@@ -1922,12 +1896,47 @@ int mi_dmrecon_pointset(mi_dmrecon_ctx* c, const mi_dmrecon_camera* cam, int32_t
     return 0;
 }
 
+/* test hook (not in the public header): the reference view with this id gets a negative pixel footprint in the calls
+ * that follow (-1: none), see fill_job */
+void mi_dmrecon_debug_inject_footprint(int view_id) { g_inject_footprint.store(view_id); }
+
 /* development aid (not in the public header): allocate / fetch the MI_TIMING stamp buffer */
 int mi_dmrecon_debug_timing(unsigned long long* out, int n) {
     if (!mi_debug_tbuf) { if (hipMalloc((void**)&mi_debug_tbuf, 500 * sizeof(unsigned long long)) != hipSuccess) return -1; (void)hipMemset(mi_debug_tbuf, 0, 500 * 8); return 0; }
     if (out) (void)hipMemcpy(out, mi_debug_tbuf, std::min(n, 500) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipMemset(mi_debug_tbuf, 0, 500 * 8);
     return 0;
+}
+
+/* ---- the entry points that allocate host memory: no exception crosses the C ABI (std::bad_alloc -> MI_DMRECON_EDEVICE) */
+int mi_dmrecon_global_view_selection(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t* ids_out, int32_t* n_out) {
+    try { return mi_dmrecon_global_view_selection_impl(c, st, ref_view, ids_out, n_out); }
+    catch (const std::bad_alloc&) { return fail(MI_DMRECON_EDEVICE, "out of host memory"); }
+}
+
+int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views, mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out, mi_dmrecon_stats* stats) {
+    try { return mi_dmrecon_reconstruct_impl(c, st, n_refs, ref_views, maps, progress, status_out, stats); }
+    catch (const std::bad_alloc&) { return fail(MI_DMRECON_EDEVICE, "out of host memory"); }
+}
+
+int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n, const int32_t* xy, const float* hyp, const int32_t* local, int32_t lanes_per_view, float* out, int32_t* out_local) {
+    try { return mi_dmrecon_patch_optimize_impl(c, st, ref_view, n, xy, hyp, local, lanes_per_view, out, out_local); }
+    catch (const std::bad_alloc&) { return fail(MI_DMRECON_EDEVICE, "out of host memory"); }
+}
+
+int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t x, int32_t y, float depth, float dzI, float dzJ, float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level) {
+    try { return mi_dmrecon_patch_eval_impl(c, st, ref_view, x, y, depth, dzI, dzJ, master, ncc, ok, col, deriv, level); }
+    catch (const std::bad_alloc&) { return fail(MI_DMRECON_EDEVICE, "out of host memory"); }
+}
+
+int mi_dmrecon_set_features(mi_dmrecon_ctx* c, int32_t n, const float* pos, const int32_t* off, const int32_t* ids) {
+    try { return mi_dmrecon_set_features_impl(c, n, pos, off, ids); }
+    catch (const std::bad_alloc&) { return fail(MI_DMRECON_EDEVICE, "out of host memory"); }
+}
+
+int mi_dmrecon_pointset(mi_dmrecon_ctx* c, const mi_dmrecon_camera* cam, int32_t w, int32_t h, const float* depth, const uint8_t* color, int32_t color_channels, const mi_dmrecon_pointset_options* opt, int32_t capacity, int32_t* pixel, float* pos, float* normal, float* color_out, float* scale, float* conf, int32_t* n_out) {
+    try { return mi_dmrecon_pointset_impl(c, cam, w, h, depth, color, color_channels, opt, capacity, pixel, pos, normal, color_out, scale, conf, n_out); }
+    catch (const std::bad_alloc&) { return fail(MI_DMRECON_EDEVICE, "out of host memory"); }
 }
 
 }  /* extern "C" */

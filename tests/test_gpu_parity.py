@@ -186,14 +186,12 @@ def test_patch_optimization_vs_oracle_many(ctx_g1, g1_scene):
         assert (np.abs(go[ok, 4:7] - oo[ok, 4:7]).max(1) <= 1e-3).mean() >= 0.98   # normals
 
 
-@pytest.mark.parametrize("lpv", ["16", "4"])
-def test_lane_layouts_agree(ctx_g1, g1, monkeypatch, lpv):
-    # the tail rounds run one patch per wavefront (16 lanes per view), the middle layout four (4 lanes per view):
-    # same maths as the 16-patch throughput layout, different lane layout and summation order
+def test_lane_layouts_agree(ctx_g1, g1):
+    # the tail rounds run one patch per wavefront (16 lanes per view): same maths as the 16-patch throughput layout,
+    # different lane layout and summation order
     st = api.Settings(refViewNr=0)
-    a, al = ctx_g1.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
-    monkeypatch.setenv("MI_DMRECON_HOOK_LPV", lpv)
-    b, bl = ctx_g1.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
+    a, al = ctx_g1.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"], lanes_per_view=1)
+    b, bl = ctx_g1.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"], lanes_per_view=16)
     assert np.array_equal(a[:, 0] > 0, b[:, 0] > 0)
     ok = a[:, 0] > 0
     assert np.abs(a[ok, 1] - b[ok, 1]).max() / 10.0 <= 1e-5      # only the summation order differs
@@ -204,51 +202,13 @@ def test_lane_layouts_agree(ctx_g1, g1, monkeypatch, lpv):
     assert (np.abs(b[okr, 1] - ref[okr, 1]) / ref[okr, 1] <= 1e-3).mean() >= 0.99
 
 
-@pytest.mark.parametrize("lpv", ["1", "16"])
-def test_texel_windows_agree_with_gathers(gpu_ctx, g1, g1_scene, g1b_scene, monkeypatch, lpv):
-    """Sampling from the LDS texel windows reads the very texels the scattered gathers read and sums them in the
-    same order: the outputs of every patch must agree to rounding, in both lane layouts, also at scale 1 where
-    the mip level of a view flips between patches (Q4)."""
-    monkeypatch.setenv("MI_DMRECON_HOOK_LPV", lpv)
-    rng = np.random.RandomState(5)
-    for scene, scale, (w, h), d0 in ((g1_scene, 0, (160, 120), 10.0), (g1b_scene, 1, (161, 121), 10.0)):
-        gpu_ctx.load_scene(scene)
-        n = 1500
-        xy = np.stack([rng.randint(0, w, n), rng.randint(0, h, n)], 1)
-        hyp = np.stack([d0 + rng.uniform(-0.6, 0.6, n), rng.uniform(-2e-2, 2e-2, n), rng.uniform(-2e-2, 2e-2, n)], 1)
-        st = api.Settings(refViewNr=1, scale=scale)
-        monkeypatch.setenv("MI_DMRECON_WIN", "0")
-        a, al = gpu_ctx.patch_optimize(st, 1, xy, hyp)
-        monkeypatch.setenv("MI_DMRECON_WIN", "3")
-        b, bl = gpu_ctx.patch_optimize(st, 1, xy, hyp)
-        assert (a[:, 0] > 0).sum() > 200
-        # same texels, same summation order; the two instantiations are contracted into FMAs differently by the
-        # compiler, so the sums differ in their last bits (measured 1e-7) -- and in nothing else
-        same = (a[:, 0] > 0) == (b[:, 0] > 0)
-        assert same.mean() >= 0.998
-        ok = (a[:, 0] > 0) & (b[:, 0] > 0)
-        assert np.array_equal(al[ok], bl[ok]) and (a[ok, 7] == b[ok, 7]).mean() >= 0.995
-        assert np.median(np.abs(a[ok, 1] - b[ok, 1])) / d0 <= 1e-6 and np.percentile(np.abs(a[ok, 0] - b[ok, 0]), 99) <= 1e-4
-
-
-def test_maps_with_and_without_texel_windows(gpu_ctx, g1_scene, monkeypatch):
-    # (a scene of this size runs in the latency layout from the first round on, where windows are bit-identical)
-    gpu_ctx.load_scene(g1_scene)
-    monkeypatch.setenv("MI_DMRECON_WIN", "0")
-    a = gpu_ctx.reconstruct(api.Settings(), [0, 1, 2, 3, 4], want_views=True)
-    monkeypatch.setenv("MI_DMRECON_WIN", "1")
-    b = gpu_ctx.reconstruct(api.Settings(), [0, 1, 2, 3, 4], want_views=True)
-    for x, y in zip(a, b):
-        m = map_parity(x["depth"], x["conf"], y["depth"], y["conf"])
-        assert m["iou"] >= 0.999 and m["rel_med"] <= 1e-5 and m["rel_p99"] <= 3e-3 and m["conf_p99"] <= 3e-3, m
-
-
 def test_speculative_tail_equals_sequential_attempts(gpu_ctx, g1_scene, monkeypatch):
     """The tail rounds run a pixel's candidate hypotheses in parallel and apply the reference's sequential rule
     (pop-time skip dmrecon.cc:371, accept-if-better :391) afterwards.  Host-visible rounds in the same lane layout
     run them one after the other: the maps must be bit-identical."""
     gpu_ctx.load_scene(g1_scene)
     st = api.Settings()
+    monkeypatch.setenv("MI_DMRECON_FRONT", "0")                        # (the front kernel has its own test)
     monkeypatch.setenv("MI_DMRECON_BULK_LPV", "16")
     monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "0")               # never enter the tail
     seq = gpu_ctx.reconstruct(st, [0, 1, 2, 3, 4], want_views=True)
@@ -264,36 +224,35 @@ def test_speculative_tail_equals_sequential_attempts(gpu_ctx, g1_scene, monkeypa
     assert n_seq["n_patch"] == n_spec["n_patch"] and n_seq["n_eval"] == n_spec["n_eval"]
 
 
-@pytest.mark.parametrize("mode,grid", [("1", "0"), ("1", "3"), ("2", "0"), ("2", "8")])
-def test_persistent_tail_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, monkeypatch, mode, grid):
-    """k_tail_persist (a chunk of tail rounds per launch, tickets instead of one grid per round) writes exactly what
-    one launch per round writes: same candidates, same speculative attempts, same sequential rule.  Mode 1: one team,
-    hand-offs through the memory side; mode 2: a team per XCD (job % 8), hand-offs inside its L2.  Forced on for every
-    tail chunk (MI_DMRECON_TAIL_PERSIST_MAX), with the default grid and with a tiny one, so that a workgroup draws
-    many tickets per round and late workgroups find rounds already over.  Nine / five reference views per call:
-    several jobs per team and teams without a job."""
+@pytest.mark.parametrize("per_view", ["1000000", "2", None])
+def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, monkeypatch, per_view):
+    """k_front (the end of the tail: one persistent workgroup per reference view, each view at its own pace) writes
+    exactly what one k_tail launch per round writes: same candidates, same attempts, same sequential rule
+    (dmrecon.cc:365-431).  Handed over as early as the round driver allows (after the first chunk of tail rounds),
+    late (two entries per view), and at the default threshold.  Five / nine reference views per call; on the hard
+    scene views fail patches, replace local views and end at very different rounds."""
     for scene, refs in ((g1_scene, [0, 1, 2, 3, 4]), (h1_scene, list(range(9)))):
         gpu_ctx.load_scene(scene)
-        monkeypatch.setenv("MI_DMRECON_TAIL_PERSIST", "0")
+        monkeypatch.setenv("MI_DMRECON_FRONT", "0")
         ref = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
         s0 = dict(gpu_ctx.last_stats)
-        assert s0["n_tail_rounds_persistent"] == 0
-        monkeypatch.setenv("MI_DMRECON_TAIL_PERSIST", mode)
-        monkeypatch.setenv("MI_DMRECON_TAIL_PERSIST_MAX", "1000000")
-        if grid != "0":
-            monkeypatch.setenv("MI_DMRECON_TAIL_PERSIST_GRID", grid)
+        assert s0["n_front_launches"] == 0
+        if per_view is None:
+            monkeypatch.delenv("MI_DMRECON_FRONT")
+        else:
+            monkeypatch.setenv("MI_DMRECON_FRONT", per_view)
         for rep in range(2):
             got = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
             s1 = dict(gpu_ctx.last_stats)
-            assert s1["n_tail_rounds_persistent"] > 10 and s1["n_rounds"] == s0["n_rounds"]
+            if per_view == "1000000":
+                assert s1["n_front_launches"] == 1 and s1["n_front_rounds_max"] > 5 and s1["n_front_views"] >= 2, s1
+            assert s1["n_rounds"] == s0["n_rounds"], (s1["n_rounds"], s0["n_rounds"], s1["front_first_round"])
             for k in ("n_patch", "n_eval", "n_filled"):
                 assert s1[k] == s0[k], k
             for a, b in zip(got, ref):
                 for k in ("depth", "conf", "dz", "normal", "views"):
                     assert np.array_equal(a[k], b[k]), (k, rep)
-        monkeypatch.delenv("MI_DMRECON_TAIL_PERSIST_MAX")
-        monkeypatch.delenv("MI_DMRECON_TAIL_PERSIST_GRID", raising=False)
-    monkeypatch.delenv("MI_DMRECON_TAIL_PERSIST")
+    monkeypatch.delenv("MI_DMRECON_FRONT", raising=False)
     gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
 
 
@@ -311,7 +270,7 @@ def test_concurrent_calls_are_merged_and_keep_their_own_results(gpu_ctx, g1_scen
     monkeypatch.setenv("MI_DMRECON_MERGE_WINDOW_US", "50000")           # the leader waits 50 ms: everybody joins
     # view 4 gets a non-positive pixel footprint (fault injection): the call that asks for nothing else fails with the
     # reference's exception, the call that asks for 4 among others gets its other views
-    monkeypatch.setenv("MI_DMRECON_INJECT_FOOTPRINT", "4")
+    api.debug_inject_footprint(4)
     plans = [(st, [0, 1]), (st, [2]), (st, [3, 1, 0]), (st, [4]), (st3, [1, 2]), (st, [3, 4])]
     forks = [gpu_ctx.fork() for _ in plans]
     go = threading.Barrier(len(plans))
@@ -354,26 +313,9 @@ def test_concurrent_calls_are_merged_and_keep_their_own_results(gpu_ctx, g1_scen
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert all(o[2]["merged_into_other_call"] == 0 for o in out if o[0] == "ok")
-    monkeypatch.delenv("MI_DMRECON_INJECT_FOOTPRINT")
+    api.debug_inject_footprint(-1)
     for f in forks:
         f.close()
-
-
-def test_middle_layout_rounds_agree_with_the_throughput_layout(gpu_ctx, g1_scene, h1_scene, monkeypatch):
-    """MI_DMRECON_MID_THRESHOLD: host-visible rounds with short lists in the middle lane layout -- the same maps up to
-    the summation order (what any change of layout does)."""
-    for scene, refs in ((g1_scene, [0, 1, 2, 3, 4]), (h1_scene, [0, 8])):
-        gpu_ctx.load_scene(scene)
-        monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "64")          # keep the rounds host-visible for long
-        a = gpu_ctx.reconstruct(api.Settings(), refs)
-        monkeypatch.setenv("MI_DMRECON_MID_THRESHOLD", "100000000")    # every one of them in the middle layout
-        b = gpu_ctx.reconstruct(api.Settings(), refs)
-        monkeypatch.delenv("MI_DMRECON_MID_THRESHOLD")
-        monkeypatch.delenv("MI_DMRECON_TAIL_THRESHOLD")
-        for x, y in zip(a, b):
-            m = map_parity(x["depth"], x["conf"], y["depth"], y["conf"])
-            assert m["iou"] >= 0.995 and m["rel_med"] <= 1e-4 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 5e-3, m
-    gpu_ctx.load_scene(g1_scene)
 
 
 def test_views_end_individually_in_a_batch(gpu_ctx, g1_scene, monkeypatch):
@@ -396,7 +338,7 @@ def test_views_end_individually_in_a_batch(gpu_ctx, g1_scene, monkeypatch):
         assert prog[i].filled == int((res[i]["conf"] > 0).sum())          # Progress::filled is per view
     # (b) a non-positive pixel footprint: the reference throws std::out_of_range for that view (fault injection:
     # with valid cameras the condition cannot be produced from outside)
-    monkeypatch.setenv("MI_DMRECON_INJECT_FOOTPRINT", "4")
+    api.debug_inject_footprint(4)
     out = gpu_ctx.alloc_outputs(st, [0, 4, 1])
     out[1]["depth"].fill(-7.0)
     res = gpu_ctx.reconstruct(st, [0, 4, 1], out=out)
@@ -405,7 +347,7 @@ def test_views_end_individually_in_a_batch(gpu_ctx, g1_scene, monkeypatch):
     assert np.array_equal(res[0]["depth"], base[0]["depth"]) and np.array_equal(res[2]["depth"], base[1]["depth"])
     with pytest.raises(IndexError, match="Negative pixel footprint"):      # alone it is the call's outcome
         gpu_ctx.reconstruct(st, [4])
-    monkeypatch.delenv("MI_DMRECON_INJECT_FOOTPRINT")
+    api.debug_inject_footprint(-1)
 
 
 def test_maps_vs_reference_scale0(ctx_g1, g1):
@@ -528,13 +470,9 @@ def test_hard_scene_patch_vectors_vs_reference(gpu_ctx, h1, h1_scene):
     sets get re-selected.  Same outcome class, depth / confidence within the patch-level tolerance, same views."""
     gpu_ctx.load_scene(h1_scene)
     assert gpu_ctx.global_view_selection(api.Settings(refViewNr=0)) == list(h1["gvs"])
-    for lpv in ("1", "16"):
-        import os
-        os.environ["MI_DMRECON_HOOK_LPV"] = lpv
-        try:
-            out, loc = gpu_ctx.patch_optimize(api.Settings(refViewNr=0), 0, h1["seeds_xy"], h1["seeds_hyp"], h1["seeds_local"])
-        finally:
-            del os.environ["MI_DMRECON_HOOK_LPV"]
+    for lpv in (1, 16):
+        out, loc = gpu_ctx.patch_optimize(api.Settings(refViewNr=0), 0, h1["seeds_xy"], h1["seeds_hyp"], h1["seeds_local"],
+                                          lanes_per_view=lpv)
         ref, ref_loc = h1["opt"], h1["opt_local"]
         agree = (out[:, 0] > 0) == (ref[:, 0] > 0)
         ok = (out[:, 0] > 0) & (ref[:, 0] > 0)
@@ -597,9 +535,8 @@ def test_filter_widths_vs_reference(gpu_ctx, g1, g1_fw, g1_scene, fw, monkeypatc
     xy = np.stack([rng.randint(0, 160, n), rng.randint(0, 120, n)], 1)
     hyp = np.stack([10.0 + rng.uniform(-0.4, 0.4, n), rng.uniform(-5e-3, 5e-3, n), rng.uniform(-5e-3, 5e-3, n)], 1)
     oo, ol = S.patch_optimize(orc.make_settings(ref_view=0, filterWidth=fw), xy, hyp)
-    for lpv in ("1", "16"):
-        monkeypatch.setenv("MI_DMRECON_HOOK_LPV", lpv)
-        go, gl = gpu_ctx.patch_optimize(st, 0, xy, hyp)
+    for lpv in (1, 16):
+        go, gl = gpu_ctx.patch_optimize(st, 0, xy, hyp, lanes_per_view=lpv)
         assert ((go[:, 0] > 0) == (oo[:, 0] > 0)).mean() >= 0.97
         ok = (go[:, 0] > 0) & (oo[:, 0] > 0)
         assert ok.sum() > 40
