@@ -1432,7 +1432,7 @@ int BatchRun::front_rounds() {
     front_first_round = round;
     ev.begin(S, EventLog::FRONT, tail_known);
     D->front(S, nj, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, c->d_round_work.p + (round - 1),
-             wnext, rnext, wcur, rcur, d_off, d_cnt, d_stats, round, 0x7FFFFFF0, c->d_counters);
+             wnext, rnext, wcur, rcur, d_off, d_cnt, d_stats, round, round + 4 * MI_MAX_ROUNDS, c->d_counters);
     ev.end(S);
     ++n_launch;
     front_stats.assign(4 * (size_t)nj, 0u);
