@@ -87,14 +87,19 @@ typedef const __attribute__((address_space(1))) int32_t* gi32_t;
 #define MI_WAVES_PER_SIMD 3
 #endif
 
-#ifdef MI_HIST
-__device__ unsigned long long* g_hist = nullptr;
-#endif
-#ifdef MI_TIMING
-/* development aid: wave 0 / lane 0 logs shader clock stamps into counters->tstamp[] */
-__device__ unsigned long long* g_tbuf;
-__device__ unsigned g_tcnt;
-#define TSTAMP(id) do { if (threadIdx.x == 0 && blockIdx.x == 0 && g_tbuf) { unsigned k = g_tcnt++; if (k < 250) { g_tbuf[2 * k] = (id); g_tbuf[2 * k + 1] = __builtin_readcyclecounter(); } } } while (0)
+#ifdef MI_PROBE
+/* development aid (tools/patch_probe.py, `make -C mve_amd/csrc probe`): the first lane of a wavefront logs (id, shader
+ * clock) pairs of the patch it is working on into LDS; k_front copies the log of an attempt into the debug buffer */
+#define MI_PROBE_LOG 48
+__shared__ unsigned long long g_plog[8][MI_PROBE_LOG];
+__shared__ unsigned g_pidx[8];
+__device__ __forceinline__ void probe_stamp(unsigned id) {
+    if ((threadIdx.x & 63u) == 0) {
+        const unsigned w = (threadIdx.x >> 6) & 7u, k = g_pidx[w];
+        if (k < MI_PROBE_LOG) { g_plog[w][k] = ((unsigned long long)id << 56) | (__builtin_readcyclecounter() & 0x00FFFFFFFFFFFFFFull); g_pidx[w] = k + 1; }
+    }
+}
+#define TSTAMP(id) probe_stamp(id)
 #else
 #define TSTAMP(id) do { } while (0)
 #endif
@@ -102,17 +107,17 @@ __device__ unsigned g_tcnt;
 /* LDS of one 64-lane workgroup = 16 patches (file scope so that the one non-inlined
  * device function below addresses it with ds_* instructions, not flat ones). */
 __shared__ float g_lut[256];                                   /* sRGB -> linear, mvs_tools.cc:22-93 */
-__shared__ float g_rays[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterViewDirs */
+__shared__ float g_geo[MI_PATCHES_PER_WAVE][MI_NS];            /* 1 / |K^-1 (pixel of sample i)|: the unit-ray scale of PatchSampler::masterViewDirs */
 __shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterColorSamples */
 __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelection ncc[] */
 /* the same for the latency layout: one patch per wavefront, at most MI_LAT_SLOTS wavefronts per workgroup.  Separate
  * (smaller) arrays because a kernel's LDS is what it references: the tail kernels then ask for 4 KB instead of 12.8 KB,
  * and a CU filled with bulk workgroups of another call (12 x 12.6 KB of 160 KB) has that much to spare */
 #define MI_LAT_SLOTS 8
-__shared__ float g_rays_lat[MI_LAT_SLOTS][3 * MI_NS];
+__shared__ float g_geo_lat[MI_LAT_SLOTS][MI_NS];
 __shared__ float g_mcol_lat[MI_LAT_SLOTS][3 * MI_NS];
 __shared__ float g_ncc_lat[MI_LAT_SLOTS][MI_MAX_GLOBAL];
-template <int LPV> __device__ __forceinline__ float* lds_rays(int patch) { return LPV == 16 ? g_rays_lat[patch] : g_rays[patch]; }
+template <int LPV> __device__ __forceinline__ float* lds_geo(int patch) { return LPV == 16 ? g_geo_lat[patch] : g_geo[patch]; }
 template <int LPV> __device__ __forceinline__ float* lds_mcol(int patch) { return LPV == 16 ? g_mcol_lat[patch] : g_mcol[patch]; }
 template <int LPV> __device__ __forceinline__ float* lds_ncc(int patch) { return LPV == 16 ? g_ncc_lat[patch] : g_ncc[patch]; }
 
@@ -241,9 +246,7 @@ struct PatchState {
     float xbar0, xbar1, xbar2;   /* PatchSampler::meanX */
     float sqrDevX, mmean;        /* PatchSampler::sqrDevX, masterMeanCol */
     float mfp;                   /* footPrintScaled(centre point) at the current state */
-    float p0x, p0y, p0z;         /* centre patch point (patchPoints[12]) */
-    float jcx, jcy, jcz;         /* reference camera centre */
-    float jz0, jz1, jz2, jz3;    /* third row of the reference [R|t] */
+    float inrm_c;                /* geo[MI_MID]: 1 / |K_s^-1 (x + .5, y + .5, 1)| of the centre pixel */
     float jinv0;                 /* invproj[0] of the reference level */
     unsigned avail;              /* LocalViewSelection::available over global indices */
     /* per view slot */
@@ -255,26 +258,41 @@ struct PatchState {
     DevCounters* counters;       /* rare-event diagnostics are added directly (one atomic per event) */
 };
 
-struct NView {                   /* my neighbour view at the selected mip level */
-    float m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11;   /* K.[R|t]: rows 0,1 pre-multiplied by the level's K */
+/*
+ * Geometry of a sampling pass.  The reference builds sample (di, dj) of a patch as the 3-D point
+ *     P = C + t r,  r = R^T K_s^-1 (x + di + .5, y + dj + .5, 1) / |.|,  t = depth + di dzI + dj dzJ
+ * (computePatchPoints, patch_sampler.cc:273-295; view rays single_view.cc:106-114) and projects it with the neighbour's
+ * K [R|t] (worldToScreen, single_view.h:187-195).  C and the pixel grid are the same for all samples, so
+ *     K_n (R_n P + t_n) = s_C + (t g) (A + di B + dj D)
+ * with s_C = K_n (R_n C + t_n) (the reference camera centre seen from the neighbour), H = K_n R_n R^T K_s^-1 (a per
+ * (reference view, neighbour) matrix, DevJobView::H), A = H (x + .5, y + .5, 1), B = H e_x, D = H e_y and
+ * g = 1 / |K_s^-1 (x + di + .5, y + dj + .5, 1)| (per patch and sample, in LDS): three FMAs for the direction, one
+ * multiply for the scale, three FMAs for the point -- instead of a 3 x 4 matrix product per sample -- and the
+ * ray-advanced twin of fastColAndDeriv (patch_sampler.cc:101-113) is s + (step g) (A + di B + dj D).
+ */
+struct NView {                   /* my neighbour view at the selected mip level (rows 0, 1 carry the level's K) */
+    float sx, sy, sz;            /* s_C */
+    float ax, ay, az;            /* A: the centre pixel */
+    float bx, by, bz;            /* B: one pixel to the right */
+    float dx, dy, dz;            /* D: one pixel down */
     int w, h;
     const uint32_t* img;         /* 16-byte footprint records of the level (DevView::quad) */
 };
 
-__device__ __forceinline__ void project(const NView& nv, float px, float py, float pz, float& u, float& v) {
-    /* SingleView::worldToScreen (single_view.h:187-195) with K.[R|t] pre-multiplied (rows 0, 1 of NView) */
-    const float sx = nv.m0 * px + nv.m1 * py + nv.m2 * pz + nv.m3;
-    const float sy = nv.m4 * px + nv.m5 * py + nv.m6 * pz + nv.m7;
-    const float cz_ = nv.m8 * px + nv.m9 * py + nv.m10 * pz + nv.m11;
-    const float iz = fast_rcp(cz_);
-    u = sx * iz - 0.5f;
-    v = sy * iz - 0.5f;
-}
-
-/* fold the level's calibration into the first two rows of [R|t]: x' = ax.x + cx.z, y' = ay.y + cy.z */
+/* fold the level's calibration into rows 0, 1: x' = ax.x + cx.z, y' = ay.y + cy.z */
 __device__ __forceinline__ void premultiply(NView& nv, float ax, float ay, float cx, float cy) {
-    nv.m0 = ax * nv.m0 + cx * nv.m8; nv.m1 = ax * nv.m1 + cx * nv.m9; nv.m2 = ax * nv.m2 + cx * nv.m10; nv.m3 = ax * nv.m3 + cx * nv.m11;
-    nv.m4 = ay * nv.m4 + cy * nv.m8; nv.m5 = ay * nv.m5 + cy * nv.m9; nv.m6 = ay * nv.m6 + cy * nv.m10; nv.m7 = ay * nv.m7 + cy * nv.m11;
+    nv.sx = ax * nv.sx + cx * nv.sz; nv.ax = ax * nv.ax + cx * nv.az; nv.bx = ax * nv.bx + cx * nv.bz; nv.dx = ax * nv.dx + cx * nv.dz;
+    nv.sy = ay * nv.sy + cy * nv.sz; nv.ay = ay * nv.ay + cy * nv.az; nv.by = ay * nv.by + cy * nv.bz; nv.dy = ay * nv.dy + cy * nv.dz;
+}
+/* rows 0, 1 (no calibration yet) and row 2 of the pass geometry of view J for the patch at pixel (x, y) */
+__device__ __forceinline__ void view_rows01(NView& nv, const DevJobView& J, float fx, float fy) {
+    nv.sx = J.sc[0]; nv.sy = J.sc[1];
+    nv.bx = J.H[0]; nv.dx = J.H[1]; nv.ax = J.H[0] * fx + J.H[1] * fy + J.H[2];
+    nv.by = J.H[3]; nv.dy = J.H[4]; nv.ay = J.H[3] * fx + J.H[4] * fy + J.H[5];
+}
+__device__ __forceinline__ void view_row2(NView& nv, const DevJobView& J, float fx, float fy) {
+    nv.sz = J.sc[2];
+    nv.bz = J.H[6]; nv.dz = J.H[7]; nv.az = J.H[6] * fx + J.H[7] * fy + J.H[8];
 }
 
 /* mip level rule of patch_sampler.cc:72-91 / :353-373 from the view-space depth z of the centre patch point.
@@ -289,16 +307,16 @@ __device__ __forceinline__ int mip_level(float z, float inv0, float mfp, int max
 }
 
 /* One-shot set-up of a view (view selection candidates, parity hook): two dependent loads (the job's record of the
- * view, then the level), no window. */
+ * view, then the level). */
 __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, const DevJobView& J, const PatchState& ps,
                                            NView& nv, int& level) {
-    nv.m0 = J.w2c[0]; nv.m1 = J.w2c[1]; nv.m2 = J.w2c[2]; nv.m3 = J.w2c[3];
-    nv.m4 = J.w2c[4]; nv.m5 = J.w2c[5]; nv.m6 = J.w2c[6]; nv.m7 = J.w2c[7];
-    nv.m8 = J.w2c[8]; nv.m9 = J.w2c[9]; nv.m10 = J.w2c[10]; nv.m11 = J.w2c[11];
-    const float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
+    const float fx = (float)ps.x + 0.5f, fy = (float)ps.y + 0.5f;
+    view_row2(nv, J, fx, fy);
+    const float z = nv.sz + (ps.depth * ps.inrm_c) * nv.az;          /* (worldToCam . centre point).z */
     const int mm = mip_level(z, J.inv0, ps.mfp, J.maxl);
     if (mm < 0) return false;
     level = mm;
+    view_rows01(nv, J, fx, fy);
     const DevView* V = views + J.view;
     const DevLevel& L = V->lv[mm];
     premultiply(nv, L.ax, L.ay, L.cx, L.cy);
@@ -308,25 +326,25 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, co
 }
 
 /*
- * A view slot's selected view, kept across the passes of a patch: the per-pass set-up of the reference
- * (worldToScreen matrices, mip level, patch_sampler.cc:72-91) costs three dependent memory accesses
- * (global_ids[sel] -> DevView -> DevLevel) when done from scratch, which is most of a pass's latency in the tail.
+ * A view slot's selected view, kept across the passes of a patch (latency layout): the per-pass set-up of the
+ * reference (worldToScreen matrices, mip level, patch_sampler.cc:72-91) costs three dependent memory accesses
+ * (job record -> DevView -> DevLevel) when done from scratch, which is most of a pass's latency in the tail.
  * Cached here, a pass re-evaluates the level rule in registers and touches memory only when the view or its
  * level changed.
  */
 struct ViewC {
     int sel;                     /* PatchState::sel this cache belongs to (-2 = empty) */
-    int lvl;                     /* mip level the matrices belong to (-1 = none) */
+    int lvl;                     /* mip level rows 0, 1 of nv belong to (-1 = none) */
     const DevJobView* V;
     float inv0; int maxl;
-    NView nv;                    /* rows 8..11 valid once sel is set; rows 0..7, w, h, img per level */
+    NView nv;                    /* row 2 valid once sel is set; rows 0, 1, w, h, img per level */
 };
 
 __device__ __forceinline__ void viewc_reset(ViewC& vc) {
     vc.sel = -2; vc.lvl = -1; vc.V = nullptr; vc.inv0 = 0.f; vc.maxl = 0;
     vc.nv.w = 0; vc.nv.h = 0; vc.nv.img = nullptr;
-    vc.nv.m0 = vc.nv.m1 = vc.nv.m2 = vc.nv.m3 = vc.nv.m4 = vc.nv.m5 = vc.nv.m6 = vc.nv.m7 = 0.f;
-    vc.nv.m8 = vc.nv.m9 = vc.nv.m10 = vc.nv.m11 = 0.f;
+    vc.nv.sx = vc.nv.sy = vc.nv.sz = vc.nv.ax = vc.nv.ay = vc.nv.az = 0.f;
+    vc.nv.bx = vc.nv.by = vc.nv.bz = vc.nv.dx = vc.nv.dy = vc.nv.dz = 0.f;
 }
 
 
@@ -371,26 +389,28 @@ struct GNSums {
  */
 template <int MODE, int LPV>
 __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& nv, const float* __restrict__ s_lut,
-                                            const float* __restrict__ rays, const float* __restrict__ mcol,
+                                            const float* __restrict__ geo, const float* __restrict__ mcol,
                                             ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub) {
     typedef Lay<LPV> L;
-    const float cpx = ps.jcx, cpy = ps.jcy, cpz = ps.jcz;
     float step = 0.f, dnorm = 0.f;
     bool ok = true;
     if (MODE != PASS_COLOR) {
         /* derivative step size (patch_sampler.cc:93-100): the centre point advanced by its unit ray against
          * patchPoints[12] -- hard-coded there; the centre itself only for filter width 5 (MI_STEP_SAMPLE) */
-        float rx = rays[3 * MI_MID], ry = rays[3 * MI_MID + 1], rz = rays[3 * MI_MID + 2];
-        float u0, v0, u1, v1;
-        if (MI_STEP_SAMPLE == MI_MID)
-            project(nv, ps.p0x, ps.p0y, ps.p0z, u0, v0);
-        else {
+        const float lc = ps.depth * ps.inrm_c;
+        float l0 = lc, vx = nv.ax, vy = nv.ay, vz = nv.az;
+        if (MI_STEP_SAMPLE != MI_MID) {
             constexpr int sj = MI_STEP_SAMPLE / MI_FW - MI_HALF, si = MI_STEP_SAMPLE - (MI_STEP_SAMPLE / MI_FW) * MI_FW - MI_HALF;
-            const float ts = ps.depth + (float)si * ps.dzI + (float)sj * ps.dzJ;
-            project(nv, cpx + ts * rays[3 * MI_STEP_SAMPLE], cpy + ts * rays[3 * MI_STEP_SAMPLE + 1], cpz + ts * rays[3 * MI_STEP_SAMPLE + 2], u0, v0);
+            l0 = (ps.depth + (float)si * ps.dzI + (float)sj * ps.dzJ) * geo[MI_STEP_SAMPLE];
+            vx = nv.ax + (float)si * nv.bx + (float)sj * nv.dx; vy = nv.ay + (float)si * nv.by + (float)sj * nv.dy;
+            vz = nv.az + (float)si * nv.bz + (float)sj * nv.dz;
         }
-        project(nv, ps.p0x + rx, ps.p0y + ry, ps.p0z + rz, u1, v1);
-        float du = u1 - u0, dv = v1 - v0;
+        const float iz0 = fast_rcp(nv.sz + l0 * vz);
+        const float u0 = (nv.sx + l0 * vx) * iz0, v0 = (nv.sy + l0 * vy) * iz0;
+        const float l1 = lc + ps.inrm_c;
+        const float iz1 = fast_rcp(nv.sz + l1 * nv.az);
+        const float u1 = (nv.sx + l1 * nv.ax) * iz1, v1 = (nv.sy + l1 * nv.ay) * iz1;
+        const float du = u1 - u0, dv = v1 - v0;
         dnorm = fast_sqrt(du * du + dv * dv);          /* deriv /= stepSize  ==  deriv * dnorm */
         ok = dnorm > 0.f;
         step = ok ? fast_rcp(dnorm) : 0.f;
@@ -408,61 +428,63 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
 
     constexpr int NITER = (MI_NS + LPV - 1) / LPV;
     /* A sample is handled in two steps so that texel gathers can be in flight while other samples are consumed:
-     * geom()/fetch() = geometry + the footprint gather, consume() = table look-ups, interpolation and the sums.
+     * geom() = geometry + the footprint gather, consume() = table look-ups, interpolation and the sums.
      *   latency layout (one wavefront per patch, nothing else to hide a gather behind): both samples of a lane are
      *   fetched before the first is consumed -- one exposed memory latency per pass instead of two;
      *   throughput layout: a whole row of the 5 x 5 window per gather round (see below). */
     struct Pre { int i; bool live; float fx, fy, gu, gv; u32x4 t; };
-    auto geom = [&](int it, float depth, bool first) -> Pre {      /* first: interior test + the gather itself */
+    auto geom = [&](int it) -> Pre {
         Pre q;
         const int iraw = sub + it * LPV;
         q.live = iraw < MI_NS;                         /* LPV = 16: second trip only for lanes 0..8 */
         const int i = q.live ? iraw : (MI_NS - 1);
         q.i = i;
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
-        const float rx = rays[3 * i], ry = rays[3 * i + 1], rz = rays[3 * i + 2];
-        const float t = depth + (float)di * ps.dzI + (float)dj * ps.dzJ;         /* computePatchPoints */
-        const float px = cpx + t * rx, py = cpy + t * ry, pz = cpz + t * rz;
-        float u, v;
-        project(nv, px, py, pz, u, v);
+        const float fi = (float)di, fj = (float)dj;
+        const float g = geo[i];
+        const float lam = (ps.depth + fi * ps.dzI + fj * ps.dzJ) * g;            /* computePatchPoints: t g */
+        const float vx = nv.ax + fi * nv.bx + fj * nv.dx, vy = nv.ay + fi * nv.by + fj * nv.dy, vz = nv.az + fi * nv.bz + fj * nv.dz;
+        const float sx = nv.sx + lam * vx, sy = nv.sy + lam * vy, sz = nv.sz + lam * vz;
+        const float iz = fast_rcp(sz);
+        const float u = sx * iz - 0.5f, v = sy * iz - 0.5f;                       /* worldToScreen */
         /* strict interior test (patch_sampler.cc:116-119, :386-389) */
-        if (first) ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
+        ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
         q.gu = 0.f; q.gv = 0.f;
         if (MODE != PASS_COLOR) {
-            float u1, v1;
-            project(nv, px + rx * step, py + ry * step, pz + rz * step, u1, v1);
-            q.gu = u1 - u; q.gv = v1 - v;
+            /* the point advanced by `step` along its ray (patch_sampler.cc:101-113); the derivative's 1 / stepSize folded in */
+            const float l2 = step * g;
+            const float iz1 = fast_rcp(sz + l2 * vz);
+            const float u1 = (sx + l2 * vx) * iz1 - 0.5f, v1 = (sy + l2 * vy) * iz1 - 0.5f;
+            q.gu = (u1 - u) * dnorm; q.gv = (v1 - v) * dnorm;
         }
         /* memory-safe even when the sample is outside (result discarded through ok) */
         /* (fmaxf/fminf return the non-NaN operand, so a NaN coordinate clamps to 0 as well) */
         const float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
-        const int left = (int)floorf(uc), top = (int)floorf(vc);
-        q.fx = uc - (float)left; q.fy = vc - (float)top;
+        const float fl = floorf(uc), ft = floorf(vc);
+        const int left = (int)fl, top = (int)ft;
+        q.fx = uc - fl; q.fy = vc - ft;
         /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
          * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
          * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1. */
-        if (first) q.t = *(gtex4_t)(nv.img + 4 * ((size_t)top * nv.w + left));
+        q.t = *(gtex4_t)(nv.img + 4 * ((size_t)top * nv.w + left));
         return q;
     };
-    auto fetch = [&](int it) -> Pre { return geom(it, ps.depth, true); };
     auto consume = [&](const Pre& q) {
         const int i = q.i;
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const float fx = q.fx, fy = q.fy, gu = q.gu, gv = q.gv;
+        const float fxy = fx * fy, gm = gv * fx + gu * fy;
         const uint32_t t00 = q.t.x, t10 = q.t.y, t01 = q.t.z, t11 = q.t.w;
         float n[3], dr[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float c00 = s_lut[(t00 >> (8 * c)) & 255u], c10 = s_lut[(t10 >> (8 * c)) & 255u];
             const float c01 = s_lut[(t01 >> (8 * c)) & 255u], c11 = s_lut[(t11 >> (8 * c)) & 255u];
-            /* mvs_tools.cc:119-128 */
-            const float xa = (1.f - fx) * c00 + fx * c10;
-            const float xb = (1.f - fx) * c01 + fx * c11;
-            n[c] = (1.f - fy) * xa + fy * xb;
-            if (MODE != PASS_COLOR) {
-                /* exact directional derivative of the bilinear surface, mvs_tools.cc:131-143; /= stepSize */
-                dr[c] = (gu * (c10 - c00) + gv * (c01 - c00) + (gv * fx + gu * fy) * (c00 - c10 - c01 + c11)) * dnorm;
-            }
+            /* the bilinear surface (mvs_tools.cc:119-128) as c00 + fx d1 + fy d2 + fx fy d3 and its exact directional
+             * derivative (mvs_tools.cc:131-143) from the same three differences */
+            const float d1 = c10 - c00, d2 = c01 - c00, d3 = (c11 - c10) - d2;
+            n[c] = c00 + fx * d1 + fy * d2 + fxy * d3;
+            if (MODE != PASS_COLOR) dr[c] = gu * d1 + gv * d2 + gm * d3;
         }
         const float wgt = (LPV == 1 || q.live) ? 1.f : 0.f;   /* dead trips (LPV > 1 only) contribute nothing */
         const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
@@ -472,12 +494,13 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         } else {
             const float a0 = (n[0] - S.s0) * wgt, a1 = (n[1] - S.s1) * wgt, a2 = (n[2] - S.s2) * wgt;
             S.a0 += a0; S.a1 += a1; S.a2 += a2;
+            /* ba: sum m (n - s) here, - xbar sum (n - s) after the loop */
             if (PER_CHANNEL) {
                 S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
-                S.ba0 += (m0 - ps.xbar0) * a0; S.ba1 += (m1 - ps.xbar1) * a1; S.ba2 += (m2 - ps.xbar2) * a2;
+                S.ba0 += m0 * a0; S.ba1 += m1 * a1; S.ba2 += m2 * a2;
             } else {
                 S.aa0 += a0 * a0 + a1 * a1 + a2 * a2;
-                S.ba0 += (m0 - ps.xbar0) * a0 + (m1 - ps.xbar1) * a1 + (m2 - ps.xbar2) * a2;
+                S.ba0 += m0 * a0 + m1 * a1 + m2 * a2;
             }
             if (MODE == PASS_DEPTH_FIXED) {
                 const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
@@ -502,25 +525,19 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     };
     if (LPV == 1) {
         /* a row of the window per gather round (5 x 5: its five footprint records are neighbours in memory, 1-2
-         * cache lines fetched once, five gathers in flight); only the texels stay in registers, the geometry of a
-         * sample is computed again when it is consumed (the opaque copy of the depth keeps the compiler from
-         * holding it across the gathers instead) */
+         * cache lines fetched once, five gathers in flight) */
 #pragma unroll 1
         for (int row = 0; row < MI_FW; ++row) {
-            u32x4 tx[MI_FW];
+            Pre q[MI_FW];
 #pragma unroll
-            for (int k = 0; k < MI_FW; ++k) tx[k] = geom(row * MI_FW + k, ps.depth, true).t;
-            float depth2 = ps.depth;
-            asm volatile("" : "+v"(depth2));
+            for (int k = 0; k < MI_FW; ++k) q[k] = geom(row * MI_FW + k);
 #pragma unroll
-            for (int k = 0; k < MI_FW; ++k) {
-                Pre q = geom(row * MI_FW + k, depth2, false); q.t = tx[k]; consume(q);
-            }
+            for (int k = 0; k < MI_FW; ++k) consume(q[k]);
         }
     } else {
         Pre q[NITER];
 #pragma unroll
-        for (int b = 0; b < NITER; ++b) q[b] = fetch(b);
+        for (int b = 0; b < NITER; ++b) q[b] = geom(b);
         TSTAMP(60);
 #pragma unroll
         for (int b = 0; b < NITER; ++b) consume(q[b]);
@@ -532,7 +549,9 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         if (PER_CHANNEL) {
             S.aa1 = L::view_sum(S.aa1); S.aa2 = L::view_sum(S.aa2);
             S.ba1 = L::view_sum(S.ba1); S.ba2 = L::view_sum(S.ba2);
-        }
+            S.ba0 -= ps.xbar0 * S.a0; S.ba1 -= ps.xbar1 * S.a1; S.ba2 -= ps.xbar2 * S.a2;
+        } else
+            S.ba0 -= ps.xbar0 * S.a0 + ps.xbar1 * S.a1 + ps.xbar2 * S.a2;
         cs_out = S;
     }
     if (MODE == PASS_DEPTH_FIXED) { gn.num = L::view_sum(num); gn.den = L::view_sum(den); }
@@ -563,12 +582,12 @@ __device__ __forceinline__ float ncc_from_sums(const PatchState& ps, const Color
 /* Colour pass of view `gidx` (index into the job's global list) -> NCC; -1 on failure. */
 template <int LPV>
 __device__ __forceinline__ float eval_color(PatchState& ps, const DevView* views, int gidx, const float* s_lut,
-                                            const float* rays, const float* mcol, ColorSums& S, bool& ok, bool count, int sub) {
+                                            const float* geo, const float* mcol, ColorSums& S, bool& ok, bool count, int sub) {
     NView nv; int level; GNSums gn;
     ok = false;
     if (gidx < 0) return -1.f;
     if (!setup_view(views, ps.job->gv[gidx], ps, nv, level)) return -1.f;
-    ok = sample_pass<PASS_COLOR, LPV>(ps, nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
+    ok = sample_pass<PASS_COLOR, LPV>(ps, nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
     ps.n_pass++;
     if (!ok) return -1.f;
     if (count) ps.n_eval++;
@@ -576,17 +595,26 @@ __device__ __forceinline__ float eval_color(PatchState& ps, const DevView* views
 }
 
 /* PatchSampler::update + the quantities that depend on the state (patch_sampler.cc:258-295) */
-__device__ __forceinline__ bool set_state(PatchState& ps, const float* rays, float depth, float dzI, float dzJ) {
+__device__ __forceinline__ bool set_state(PatchState& ps, float depth, float dzI, float dzJ) {
     ps.depth = depth; ps.dzI = dzI; ps.dzJ = dzJ;
     /* tmpDepth is linear in (i, j): its minimum over the window is at a corner */
     const float a = (float)MI_HALF * fabsf(dzI) + (float)MI_HALF * fabsf(dzJ);
-    bool ok = (depth - a) > 0.f && depth == depth && a == a;
-    ps.p0x = ps.jcx + depth * rays[3 * MI_MID];
-    ps.p0y = ps.jcy + depth * rays[3 * MI_MID + 1];
-    ps.p0z = ps.jcz + depth * rays[3 * MI_MID + 2];
-    const float z = ps.jz0 * ps.p0x + ps.jz1 * ps.p0y + ps.jz2 * ps.p0z + ps.jz3;
-    ps.mfp = z * ps.jinv0;                            /* footPrintScaled */
+    const bool ok = (depth - a) > 0.f && depth == depth && a == a;
+    /* footPrintScaled of the centre point: its depth along the reference's optical axis is depth x (the z component
+     * of the unit pixel ray in camera coordinates) = depth g_c */
+    ps.mfp = (depth * ps.inrm_c) * ps.jinv0;
     return ok;
+}
+
+/* The centre patch point (patchPoints[nrSamples / 2]) in world coordinates: only the view selection needs it. */
+__device__ __forceinline__ void patch_centre(const PatchState& ps, float& px, float& py, float& pz) {
+    const DevJob* job = ps.job;
+    const float fx = (float)ps.x + 0.5f, fy = (float)ps.y + 0.5f;
+    float rx = job->inv_a * fx + job->inv_c, ry = job->inv_b * fy + job->inv_d, rz = 1.f;
+    rx *= ps.inrm_c; ry *= ps.inrm_c; rz *= ps.inrm_c;
+    px = job->cam_pos[0] + ps.depth * (job->rot_t[0] * rx + job->rot_t[1] * ry + job->rot_t[2] * rz);
+    py = job->cam_pos[1] + ps.depth * (job->rot_t[3] * rx + job->rot_t[4] * ry + job->rot_t[5] * rz);
+    pz = job->cam_pos[2] + ps.depth * (job->rot_t[6] * rx + job->rot_t[7] * ry + job->rot_t[8] * rz);
 }
 
 /* computeColorScale for my view from the colour-pass sums (patch_optimization.cc:81-111).
@@ -640,7 +668,7 @@ template <int LPV>
 __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSettings& st, const DevView* views, int lane) {
     typedef Lay<LPV> L;
     const float* s_lut = g_lut;
-    const float* rays = lds_rays<LPV>(L::patch(lane));
+    const float* geo = lds_geo<LPV>(L::patch(lane));
     const float* mcol = lds_mcol<LPV>(L::patch(lane));
     float* s_ncc = lds_ncc<LPV>(L::patch(lane));
     const int slot = L::vslot(lane), sub = L::sub(lane);
@@ -654,7 +682,7 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
     for (int g = slot; g < G; g += QUAD) {
         if (!((ps.avail >> g) & 1u)) continue;
         ColorSums S; bool ok;
-        const float t = eval_color<LPV>(ps, views, g, s_lut, rays, mcol, S, ok, true, sub);
+        const float t = eval_color<LPV>(ps, views, g, s_lut, geo, mcol, S, ok, true, sub);
         if (t < st.minNCC) drop |= 1u << g;
         if (sub == 0) s_ncc[g] = t;
     }
@@ -662,8 +690,10 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
     ps.avail &= ~drop;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
+    float p0x, p0y, p0z;
+    patch_centre(ps, p0x, p0y, p0z);
     float rdx, rdy, rdz;
-    unit_dir(J->cam_pos, ps.p0x, ps.p0y, ps.p0z, rdx, rdy, rdz);       /* refDir */
+    unit_dir(J->cam_pos, p0x, p0y, p0z, rdx, rdy, rdz);                /* refDir */
     for (;;) {
         selmask = L::view_ballot(ps.sel >= 0, lane);
         if (__popc(selmask) >= K) break;
@@ -676,11 +706,11 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
             if (!((ps.avail >> g) & 1u)) continue;
             const DevJobView* V = &J->gv[g];
             float score = s_ncc[g];
-            const float z = V->w2c[8] * ps.p0x + V->w2c[9] * ps.p0y + V->w2c[10] * ps.p0z + V->w2c[11];
+            const float z = V->w2c_z[0] * p0x + V->w2c_z[1] * p0y + V->w2c_z[2] * p0z + V->w2c_z[3];
             const float nfp = z * V->inv0;
             if (ps.mfp / nfp < 0.5f) score *= 0.01f;
             float vx, vy, vz;
-            unit_dir(V->cam_pos, ps.p0x, ps.p0y, ps.p0z, vx, vy, vz);
+            unit_dir(V->cam_pos, p0x, p0y, p0z, vx, vy, vz);
             float dp = fminf(fmaxf(rdx * vx + rdy * vy + rdz * vz, -1.f), 1.f);
             score *= parallax_to_weight(acosf(dp) * RAD2DEG);
             float ex, ey, ez;
@@ -690,7 +720,7 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
                 if (sl[k] < 0) continue;
                 const DevJobView* U = &J->gv[sl[k]];
                 float sx, sy, sz;
-                unit_dir(U->cam_pos, ps.p0x, ps.p0y, ps.p0z, sx, sy, sz);
+                unit_dir(U->cam_pos, p0x, p0y, p0z, sx, sy, sz);
                 dp = fminf(fmaxf(sx * vx + sy * vy + sz * vz, -1.f), 1.f);
                 score *= parallax_to_weight(acosf(dp) * RAD2DEG);
                 float fx, fy, fz;
@@ -766,23 +796,23 @@ __device__ __forceinline__ bool color_scale_step(PatchState& ps, const DevSettin
  * Returns false where the reference's sampling of this view fails before any texel is read (non-positive footprint).
  */
 __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, const DevView* __restrict__ views) {
+    const float fx = (float)ps.x + 0.5f, fy = (float)ps.y + 0.5f;
+    NView& nv = vc.nv;
     if (vc.sel != ps.sel) {
         vc.sel = ps.sel;
         const DevJobView* V = &ps.job->gv[ps.sel];
         vc.V = V;
-        vc.nv.m8 = V->w2c[8]; vc.nv.m9 = V->w2c[9]; vc.nv.m10 = V->w2c[10]; vc.nv.m11 = V->w2c[11];
+        view_row2(nv, *V, fx, fy);
         vc.inv0 = V->inv0; vc.maxl = V->maxl;
         vc.lvl = -1;
     }
-    NView& nv = vc.nv;
-    const float z = nv.m8 * ps.p0x + nv.m9 * ps.p0y + nv.m10 * ps.p0z + nv.m11;
+    const float z = nv.sz + (ps.depth * ps.inrm_c) * nv.az;          /* (worldToCam . centre point).z */
     const int mm = mip_level(z, vc.inv0, ps.mfp, vc.maxl);
     if (mm < 0) return false;
     if (mm != vc.lvl) {
         vc.lvl = mm;
         const DevJobView* V = vc.V;
-        nv.m0 = V->w2c[0]; nv.m1 = V->w2c[1]; nv.m2 = V->w2c[2]; nv.m3 = V->w2c[3];
-        nv.m4 = V->w2c[4]; nv.m5 = V->w2c[5]; nv.m6 = V->w2c[6]; nv.m7 = V->w2c[7];
+        view_rows01(nv, *V, fx, fy);
         const DevView* DV = views + V->view;
         const DevLevel& Lv = DV->lv[mm];
         premultiply(nv, Lv.ax, Lv.ay, Lv.cx, Lv.cy);
@@ -794,7 +824,7 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
 
 /* One fused pass of my view at the current state; sets ps.ncc (getFastNCC).  Returns success[v]. */
 template <int MODE, int LPV>
-__device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevView* views, const float* s_lut, const float* rays,
+__device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevView* views, const float* s_lut, const float* geo,
                                          const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int sub) {
     bool okv = true;
     ps.ncc = -1.f;
@@ -802,10 +832,8 @@ __device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevVie
     /* the throughput layout has no registers to spare for the cache: set the view up per pass */
     if (LPV == 1) viewc_reset(vc);
     if (ps.sel >= 0) {
-        TSTAMP(50);
         okv = view_prepare(ps, vc, views);
-        TSTAMP(51);
-        if (okv) okv = sample_pass<MODE, LPV>(ps, vc.nv, s_lut, rays, mcol, S, gn, nullptr, nullptr, sub);
+        if (okv) okv = sample_pass<MODE, LPV>(ps, vc.nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
         ps.n_pass++;
         if (okv) {
             ps.ncc = ncc_from_sums(ps, S);
@@ -833,25 +861,42 @@ struct Run {
     float oldncc;                /* per view slot: getFastNCC before the step (:189-192) */
 };
 
-/* view rays (single_view.cc:106-114, mve/depthmap.cc:149-156) of the 5x5 window into LDS */
+/* the pixel ray of (x, y) before / after normalisation (single_view.cc:106-114, mve/depthmap.cc:149-156: K_s^-1 at the
+ * pixel centre, normalised, rotated into the world) */
+__device__ __forceinline__ float pixel_scale(const DevJob* job, int x, int y) {
+    const float rx = job->inv_a * ((float)x + 0.5f) + job->inv_c, ry = job->inv_b * ((float)y + 0.5f) + job->inv_d;
+    return fast_rsqrt(rx * rx + ry * ry + 1.f);
+}
+__device__ __forceinline__ void pixel_ray(const DevJob* job, int x, int y, float& wx, float& wy, float& wz) {
+    float rx = job->inv_a * ((float)x + 0.5f) + job->inv_c, ry = job->inv_b * ((float)y + 0.5f) + job->inv_d, rz = 1.f;
+    const float inrm = fast_rsqrt(rx * rx + ry * ry + rz * rz);
+    rx *= inrm; ry *= inrm; rz *= inrm;
+    wx = job->rot_t[0] * rx + job->rot_t[1] * ry + job->rot_t[2] * rz;
+    wy = job->rot_t[3] * rx + job->rot_t[4] * ry + job->rot_t[5] * rz;
+    wz = job->rot_t[6] * rx + job->rot_t[7] * ry + job->rot_t[8] * rz;
+}
+/* the unit-ray scales of the window's pixels into LDS (NView: g) */
 template <int LPV>
-__device__ __forceinline__ void fill_rays(const DevJob* job, int x, int y, float* rays, int pl) {
+__device__ __forceinline__ void fill_geo(const DevJob* job, int x, int y, float* geo, int pl) {
     for (int i = pl; i < MI_NS; i += 4 * LPV) {
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
-        const float fx = (float)(x + di) + 0.5f, fy = (float)(y + dj) + 0.5f;
-        float rx = job->inv_a * fx + job->inv_c, ry = job->inv_b * fy + job->inv_d, rz = 1.f;
-        const float inrm = fast_rsqrt(rx * rx + ry * ry + rz * rz);
-        rx *= inrm; ry *= inrm; rz *= inrm;
-        rays[3 * i] = job->rot_t[0] * rx + job->rot_t[1] * ry + job->rot_t[2] * rz;
-        rays[3 * i + 1] = job->rot_t[3] * rx + job->rot_t[4] * ry + job->rot_t[5] * rz;
-        rays[3 * i + 2] = job->rot_t[6] * rx + job->rot_t[7] * ry + job->rot_t[8] * rz;
+        geo[i] = pixel_scale(job, x + di, y + dj);
     }
 }
 
-__device__ __forceinline__ void load_job_constants(PatchState& ps, const DevJob* job) {
-    ps.jcx = job->cam_pos[0]; ps.jcy = job->cam_pos[1]; ps.jcz = job->cam_pos[2];
-    ps.jz0 = job->w2c_z[0]; ps.jz1 = job->w2c_z[1]; ps.jz2 = job->w2c_z[2]; ps.jz3 = job->w2c_z[3];
-    ps.jinv0 = job->inv0_s;
+/* getPatchNormal (patch_sampler.cc:242-256): the normalised cross product of the spans of the centre row (right - left
+ * end: samples 14, 10 with 5 x 5 windows) and the centre column (top - bottom: 2, 22), and the centre pixel's view ray */
+__device__ __forceinline__ void patch_normal(const PatchState& ps, float& nx, float& ny, float& nz, float& cx, float& cy, float& cz) {
+    const DevJob* job = ps.job;
+    float rx, ry, rz, lx, ly, lz, tx, ty, tz, bx_, by_, bz_;
+    pixel_ray(job, ps.x + MI_HALF, ps.y, rx, ry, rz); pixel_ray(job, ps.x - MI_HALF, ps.y, lx, ly, lz);
+    pixel_ray(job, ps.x, ps.y - MI_HALF, tx, ty, tz); pixel_ray(job, ps.x, ps.y + MI_HALF, bx_, by_, bz_);
+    pixel_ray(job, ps.x, ps.y, cx, cy, cz);
+    const float tr = ps.depth + (float)MI_HALF * ps.dzI, tl = ps.depth - (float)MI_HALF * ps.dzI;
+    const float tt = ps.depth - (float)MI_HALF * ps.dzJ, tb = ps.depth + (float)MI_HALF * ps.dzJ;
+    const float ax = tr * rx - tl * lx, ay = tr * ry - tl * ly, az = tr * rz - tl * lz;
+    const float bx = tt * tx - tb * bx_, by = tt * ty - tb * by_, bz = tt * tz - tb * bz_;
+    unit_cross(ax, ay, az, bx, by, bz, nx, ny, nz);
 }
 
 /* Returns false if the optimisation is over before it started (the result keeps confidence 0). */
@@ -862,7 +907,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     typedef Lay<LPV> L;
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
-    float* rays = lds_rays<LPV>(L::patch(lane));
+    float* geo = lds_geo<LPV>(L::patch(lane));
     float* mcol = lds_mcol<LPV>(L::patch(lane));
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const int pl = slot * LPV + sub;                 /* lane index inside the patch */
@@ -874,8 +919,9 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     R.iter = 0; R.need = PASS_DEPTH; R.ctx = CTX_CTOR; R.oldncc = -1.f; R.need_vs = false; R.count_color = false;
     /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
     if (x - MI_HALF < 0 || y - MI_HALF < 0 || x + MI_HALF > job->w - 1 || y + MI_HALF > job->h - 1) return false;
-    load_job_constants(ps, job);
-    fill_rays<LPV>(job, x, y, rays, pl);
+    ps.jinv0 = job->inv0_s;
+    ps.inrm_c = pixel_scale(job, x, y);
+    fill_geo<LPV>(job, x, y, geo, pl);
     /* raw master colours */
     const DevView* RV = views + job->ref_view;
     const DevLevel& RL = RV->lv[job->scale];
@@ -926,7 +972,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     ps.xbar0 = x0; ps.xbar1 = x1; ps.xbar2 = x2;
     ps.sqrDevX = sd;
     /* computePatchPoints */
-    if (!set_state(ps, rays, depth0, dzI0, dzJ0)) return false;
+    if (!set_state(ps, depth0, dzI0, dzJ0)) return false;
     if (!(ps.mfp > 0.f)) {                                 /* reference throws std::out_of_range here: the VIEW fails */
         err |= 1u;
         atomicOr(const_cast<int32_t*>(&job->flags), (int)MI_JOB_EFOOTPRINT);
@@ -965,37 +1011,23 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     typedef Lay<LPV> L;
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
-    float* rays = lds_rays<LPV>(L::patch(lane));
-    float* mcol = lds_mcol<LPV>(L::patch(lane));
+    const float* geo = lds_geo<LPV>(L::patch(lane));
+    const float* mcol = lds_mcol<LPV>(L::patch(lane));
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const bool active = slot < st.K;               /* view slots 0..K-1 carry a view once the selection succeeded */
     /* the sums of a pass are consumed within the same turn */
     ColorSums S; GNSums gn;
     S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
-#ifdef MI_HIST
-    if (LPV == 1 && g_hist) {
-        /* diagnostic: how often does a wavefront run a view selection / more than one pass variant in a turn? */
-        const int first = __ffsll((long long)__ballot(true)) - 1;
-        const int nvs = __ballot(R.need_vs) != 0;
-        const int nm = (__ballot(R.need == PASS_DEPTH) != 0) + (__ballot(R.need == PASS_DEPTH_FIXED) != 0)
-                     + (__ballot(R.need == PASS_NORMAL) != 0) + (__ballot(R.need == PASS_COLOR) != 0);
-        if (lane == first) {
-            atomicAdd(&g_hist[40], 1ull); atomicAdd(&g_hist[41], (unsigned long long)nvs); atomicAdd(&g_hist[44 + nm], 1ull);
-            atomicAdd(&g_hist[42], (unsigned long long)__popcll(__ballot(R.need_vs)) / 4ull);
-            atomicAdd(&g_hist[43], (unsigned long long)__popcll(__ballot(true)) / 4ull);
-        }
-    }
-#endif
     if (R.need_vs) {
         R.need_vs = false;
         if (!local_view_selection<LPV>(ps, st, views, lane)) { R.opti = false; return false; }
     }
     bool okv;
     TSTAMP(20 + R.need);
-    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
-    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
-    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
-    else okv = run_pass<PASS_COLOR, LPV>(ps, R.vc, views, s_lut, rays, mcol, S, gn, R.count_color, sub);
+    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    else okv = run_pass<PASS_COLOR, LPV>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
     TSTAMP(30);
     /* ---- finish what led to this pass */
     if (R.ctx == CTX_CTOR || R.ctx == CTX_REPLACED) {
@@ -1039,7 +1071,6 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
         R.need = want_normal ? PASS_NORMAL : PASS_DEPTH_FIXED; R.ctx = CTX_REPASS; R.count_color = false;
         return true;
     }
-    TSTAMP(31);
     if (L::view_ballot(!okv, lane)) { R.opti = false; return false; }       /* fastColAndDeriv failed (:277-280,:321-324) */
     if (active) ps.n_eval++;                                                /* this pass stood in for fastColAndDeriv */
     R.oldncc = ps.ncc;
@@ -1058,7 +1089,7 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
         const float X0 = (float)((i0 * b0 + i1 * b1 + i2 * b2) / det);
         const float X1 = (float)((i3 * b0 + i4 * b1 + i5 * b2) / det);
         const float X2 = (float)((i6 * b0 + i7 * b1 + i8 * b2) / det);
-        step_ok = set_state(ps, rays, ps.depth + X0, ps.dzI + X1, ps.dzJ + X2);
+        step_ok = set_state(ps, ps.depth + X0, ps.dzI + X1, ps.dzJ + X2);
         R.viewRemoved = false;
         R.step_was_normal = true;
     } else {
@@ -1071,7 +1102,7 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
             den = ps.cs0 * ps.cs0 * gn.dd0 + ps.cs1 * ps.cs1 * gn.dd1 + ps.cs2 * ps.cs2 * gn.dd2;
         }
         num = L::patch_sum(num); den = L::patch_sum(den);
-        if (den > 0.f) step_ok = set_state(ps, rays, ps.depth + fast_div(num, den), ps.dzI, ps.dzJ);
+        if (den > 0.f) step_ok = set_state(ps, ps.depth + fast_div(num, den), ps.dzI, ps.dzJ);
         else step_ok = first4;                     /* the first four iterations tolerate denom <= 0 (:177-180) */
         R.step_was_normal = false;
     }
@@ -1098,7 +1129,6 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
                                         unsigned& n_eval, unsigned& n_pass) {
     typedef Lay<LPV> L;
     PatchState& ps = R.ps;
-    const float* rays = lds_rays<LPV>(L::patch(lane));
     n_eval += ps.n_eval; n_pass += ps.n_pass;
     res.conf = 0.f; res.nx = res.ny = res.nz = 0.f;
     res.iters = R.iter;
@@ -1139,17 +1169,10 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
     }
     mean /= (float)cnt;
     const float score = (mean - st.acceptNCC) / (1.f - st.acceptNCC);
-    /* getPatchNormal (patch_sampler.cc:242-256): samples 14,10 (right,left) and 2,22 (top,bottom) */
-    /* right / left = the centre row's ends, top / bottom = the centre column's ends */
-    constexpr int iR = 3 * (MI_MID + MI_HALF), iL = 3 * (MI_MID - MI_HALF), iT = 3 * MI_HALF, iB = 3 * (MI_NS - 1 - MI_HALF);
-    const float tr = ps.depth + (float)MI_HALF * ps.dzI, tl = ps.depth - (float)MI_HALF * ps.dzI;
-    const float tt = ps.depth - (float)MI_HALF * ps.dzJ, tb = ps.depth + (float)MI_HALF * ps.dzJ;
-    const float ax = tr * rays[iR] - tl * rays[iL], ay = tr * rays[iR + 1] - tl * rays[iL + 1], az = tr * rays[iR + 2] - tl * rays[iL + 2];
-    const float bx = tt * rays[iT] - tb * rays[iB], by = tt * rays[iT + 1] - tb * rays[iB + 1], bz = tt * rays[iT + 2] - tb * rays[iB + 2];
-    float nx, ny, nz;
-    unit_cross(ax, ay, az, bx, by, bz, nx, ny, nz);
+    float nx, ny, nz, cx, cy, cz;
+    patch_normal(ps, nx, ny, nz, cx, cy, cz);
     res.nx = nx; res.ny = ny; res.nz = nz;
-    const float dotP = -(nx * rays[3 * MI_MID] + ny * rays[3 * MI_MID + 1] + nz * rays[3 * MI_MID + 2]);   /* viewRayScaled(midx, midy) */
+    const float dotP = -(nx * cx + ny * cy + nz * cz);                     /* viewRayScaled(midx, midy) */
     res.conf = (dotP < 0.2f) ? 0.f : score;
     TSTAMP(41);
 }
@@ -1160,21 +1183,8 @@ __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSetti
                                PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err, DevCounters* counters) {
     Run R;
     TSTAMP(10);
-#ifdef MI_HIST
-    /* diagnostic build: turns per patch vs turns per wavefront (lane divergence of the throughput layout) */
-    unsigned turns = 0;
-    if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
-        do { ++turns; } while (run_turn<LPV>(R, st, views, lane));
-    if (LPV == 1 && g_hist) {
-        unsigned mx = turns;
-        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
-        if ((lane & 3) == 0) { atomicAdd(&g_hist[min(turns, 31u)], 1ull); atomicAdd(&g_hist[32], (unsigned long long)turns); }
-        if (lane == __ffsll(__ballot(true)) - 1) { atomicAdd(&g_hist[33], (unsigned long long)mx); atomicAdd(&g_hist[34], 1ull); }
-    }
-#else
     if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
         while (run_turn<LPV>(R, st, views, lane)) { }
-#endif
     TSTAMP(40);
     run_end<LPV>(R, st, lane, res, n_eval, n_pass);
 }
@@ -1194,7 +1204,7 @@ struct OptArgs {
     unsigned min_work, max_work;  /* this launch only acts if min_work <= n < max_work (layout selection on device) */
     int round;
     DevCounters* counters;
-    unsigned long long* tbuf;     /* MI_TIMING builds only */
+    unsigned long long* tbuf;     /* MI_PROBE builds only: the debug buffer */
     /* One attempt per launch (throughput layout, host-visible rounds): an entry whose pixel has several candidate
      * hypotheses runs them in successive launches over compacted follow-up lists, so that wavefronts stay full
      * (16 patches) instead of idling 15 quads while one entry tries its second neighbour. */
@@ -1268,9 +1278,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
             hd = GF(job->depth + p); hi = GF(job->dz + 2 * p); hj = GF(job->dz + 2 * p + 1); hv = GU(job->views + p);
         }
         PatchResult r;
-        TSTAMP(3);
         optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters);
-        TSTAMP(4);
         ++n_patch; ++attempts;
         const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
         if (accept) {
@@ -1321,18 +1329,10 @@ template <int LPV>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((LPV == 16 ? 2 : MI_BULK_WAVES), (LPV == 16 ? 2 : MI_WAVES_PER_SIMD)))) void k_optimize(OptArgs a) {
     typedef Lay<LPV> L;
     const int lane = threadIdx.x;
-#ifdef MI_TIMING
-    if (threadIdx.x == 0 && blockIdx.x == 0) { g_tbuf = a.tbuf; g_tcnt = 0; }
-#endif
-    TSTAMP(1);
-#ifdef MI_HIST
-    if (threadIdx.x == 0) g_hist = a.tbuf;
-#endif
     const unsigned n = a.follow_in ? *a.follow_in_n : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
     if (n < a.min_work || n >= a.max_work) return;
     for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
     __syncthreads();
-    TSTAMP(2);
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
     for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < n; i += gridDim.x * L::PATCHES) {
         const unsigned e = a.follow_in ? a.follow_in[i] : i;
@@ -1735,7 +1735,26 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                         hv = GU((one ? job->views1 : job->views) + p);
                     }
                     PatchResult r; unsigned ce = 0, cp = 0;
+#ifdef MI_PROBE
+                    if (lane == 0) g_pidx[(tid >> 6) & 7] = 0;
+                    const unsigned long long rt0 = wall_clock64();
+                    TSTAMP(1);
+#endif
                     optimize_patch<16>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
+#ifdef MI_PROBE
+                    TSTAMP(2);
+                    if (lane == 0 && a.tbuf) {
+                        /* record: [0] view | round << 16 | entries << 32, [1] 100 MHz ticks of the attempt, [2] stamps, then the stamps */
+                        const unsigned long long rec = atomicAdd(a.tbuf, 1ull);
+                        if (rec < 400) {
+                            unsigned long long* o = a.tbuf + 8 + rec * (MI_PROBE_LOG + 4);
+                            const unsigned np = g_pidx[(tid >> 6) & 7];
+                            o[0] = (unsigned long long)jobi | ((unsigned long long)(round - a.round) << 16) | ((unsigned long long)n_prev << 32) | ((unsigned long long)natt << 48);
+                            o[1] = wall_clock64() - rt0; o[2] = np; o[3] = (unsigned long long)r.iters | ((unsigned long long)(r.conf > 0.f) << 32);
+                            for (unsigned k = 0; k < np; ++k) o[4 + k] = g_plog[(tid >> 6) & 7][k];
+                        }
+                    }
+#endif
                     ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
                                   + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
                     cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
@@ -1861,7 +1880,7 @@ struct EvalArgs {
 };
 __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     float* s_lut = g_lut;
-    float* s_rays = g_rays[0];
+    float* s_geo = g_geo[0];
     float* s_mcol = g_mcol[0];
     const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += WAVE) s_lut[i] = a.lut[i];
@@ -1869,9 +1888,8 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     /* reuse optimize_patch's setup by replicating its prologue on quad 0 only */
     const DevJob* job = a.job;
     PatchState ps; ps.job = job; ps.x = a.x; ps.y = a.y; ps.n_eval = ps.n_pass = 0; ps.sel = -1; ps.counters = nullptr;
-    ps.jcx = job->cam_pos[0]; ps.jcy = job->cam_pos[1]; ps.jcz = job->cam_pos[2];
-    ps.jz0 = job->w2c_z[0]; ps.jz1 = job->w2c_z[1]; ps.jz2 = job->w2c_z[2]; ps.jz3 = job->w2c_z[3];
     ps.jinv0 = job->inv0_s;
+    ps.inrm_c = pixel_scale(job, a.x, a.y);
     if (lane == 0) for (int k = 0; k < 5; ++k) a.master[k] = 0.f;
     if (a.x - MI_HALF < 0 || a.y - MI_HALF < 0 || a.x + MI_HALF > job->w - 1 || a.y + MI_HALF > job->h - 1) return;
     const DevView* RV = a.views + job->ref_view;
@@ -1879,13 +1897,7 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     const uint32_t* rimg = RV->img + RL.tex_off;
     for (int i = lane; i < MI_NS; i += WAVE) {
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
-        const float fx = (float)(a.x + di) + 0.5f, fy = (float)(a.y + dj) + 0.5f;
-        float rx = job->inv_a * fx + job->inv_c, ry = job->inv_b * fy + job->inv_d, rz = 1.f;
-        const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
-        rx /= nrm; ry /= nrm; rz /= nrm;
-        s_rays[3 * i] = job->rot_t[0] * rx + job->rot_t[1] * ry + job->rot_t[2] * rz;
-        s_rays[3 * i + 1] = job->rot_t[3] * rx + job->rot_t[4] * ry + job->rot_t[5] * rz;
-        s_rays[3 * i + 2] = job->rot_t[6] * rx + job->rot_t[7] * ry + job->rot_t[8] * rz;
+        s_geo[i] = pixel_scale(job, a.x + di, a.y + dj);
         const uint32_t t = rimg[(size_t)(a.y + dj) * RL.w + (a.x + di)];
         s_mcol[3 * i] = s_lut[t & 255u]; s_mcol[3 * i + 1] = s_lut[(t >> 8) & 255u]; s_mcol[3 * i + 2] = s_lut[(t >> 16) & 255u];
     }
@@ -1907,27 +1919,21 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     }
     ps.mmean = mm; ps.xbar0 = x0; ps.xbar1 = x1; ps.xbar2 = x2; ps.sqrDevX = sd;
     ps.cs0 = ps.cs1 = ps.cs2 = 1.f / mm;
-    if (!set_state(ps, s_rays, a.depth, a.dzI, a.dzJ)) return;
+    if (!set_state(ps, a.depth, a.dzI, a.dzJ)) return;
     if (lane == 0) {
         a.master[0] = 1.f; a.master[1] = mm;
-        constexpr int iR = 3 * (MI_MID + MI_HALF), iL = 3 * (MI_MID - MI_HALF), iT = 3 * MI_HALF, iB = 3 * (MI_NS - 1 - MI_HALF);
-        const float tr = ps.depth + (float)MI_HALF * ps.dzI, tl = ps.depth - (float)MI_HALF * ps.dzI;
-        const float tt = ps.depth - (float)MI_HALF * ps.dzJ, tb = ps.depth + (float)MI_HALF * ps.dzJ;
-        const float* rays = s_rays;
-        const float ax = tr * rays[iR] - tl * rays[iL], ay = tr * rays[iR + 1] - tl * rays[iL + 1], az = tr * rays[iR + 2] - tl * rays[iL + 2];
-        const float bx = tt * rays[iT] - tb * rays[iB], by = tt * rays[iT + 1] - tb * rays[iB + 1], bz = tt * rays[iT + 2] - tb * rays[iB + 2];
-        float nx, ny, nz;
-        unit_cross(ax, ay, az, bx, by, bz, nx, ny, nz);
+        float nx, ny, nz, cx, cy, cz;
+        patch_normal(ps, nx, ny, nz, cx, cy, cz);
         a.master[2] = nx; a.master[3] = ny; a.master[4] = nz;
     }
     if (lane < job->n_global) {
         const int g = lane;
         ColorSums S; bool okc;
-        const float ncc = eval_color<1>(ps, a.views, g, s_lut, s_rays, s_mcol, S, okc, true, 0);
+        const float ncc = eval_color<1>(ps, a.views, g, s_lut, s_geo, s_mcol, S, okc, true, 0);
         a.ncc[g] = ncc;
         NView nv; int level = -1; GNSums gn;
         bool okd = setup_view(a.views, job->gv[g], ps, nv, level)
-            && sample_pass<PASS_DUMP, 1>(ps, nv, s_lut, s_rays, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0);
+            && sample_pass<PASS_DUMP, 1>(ps, nv, s_lut, s_geo, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0);
         a.ok[g] = okd ? 1 : 0;
         a.level[g] = level;
     }
@@ -2176,7 +2182,7 @@ using namespace MI_FWNS;
 /* Host-callable launchers (declared in dmrecon_device.h).                     */
 
 #if MI_FW == 5
-unsigned long long* mi_debug_tbuf = nullptr;   /* set by MI_TIMING probes */
+unsigned long long* mi_debug_tbuf = nullptr;   /* the debug buffer of MI_PROBE builds (mi_dmrecon_debug_buffer) */
 #endif
 
 static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,

@@ -733,7 +733,16 @@ void fill_job(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost const& j
         d.global_ids[g] = jh.global[g];
         HostView const& N = c->sc->views[jh.global[g]];
         DevJobView& J = d.gv[g];
-        std::memcpy(J.w2c, N.w2c, sizeof(J.w2c));
+        /* H = R_n R_ref^T K_s^-1, sc = R_n C_ref + t_n (DevJobView), in double, rounded once */
+        const double Ki[9] = {L.invproj[0], 0.0, L.invproj[2], 0.0, L.invproj[4], L.invproj[5], 0.0, 0.0, 1.0};
+        for (int i = 0; i < 3; ++i) {
+            double mr[3];                                          /* row i of R_n R_ref^T */
+            for (int k = 0; k < 3; ++k) mr[k] = (double)N.w2c[4 * i] * rt[k] + (double)N.w2c[4 * i + 1] * rt[3 + k] + (double)N.w2c[4 * i + 2] * rt[6 + k];
+            for (int k = 0; k < 3; ++k) J.H[3 * i + k] = (float)(mr[0] * Ki[k] + mr[1] * Ki[3 + k] + mr[2] * Ki[6 + k]);
+            J.sc[i] = (float)((double)N.w2c[4 * i] * R.cam_pos[0] + (double)N.w2c[4 * i + 1] * R.cam_pos[1]
+                              + (double)N.w2c[4 * i + 2] * R.cam_pos[2] + (double)N.w2c[4 * i + 3]);
+        }
+        std::memcpy(J.w2c_z, N.w2c + 8, sizeof(J.w2c_z));
         J.inv0 = N.levels[0].invproj[0];
         J.maxl = (int)N.levels.size() - 1;
         J.view = jh.global[g];
@@ -1353,6 +1362,8 @@ int BatchRun::tail_rounds(bool& to_front) {
     const unsigned front_max = FRONT_PER_VIEW * (unsigned)nj;
     const ActiveCall& active = *active_call;
     wcur = c->d_work.p; wnext = c->d_work2.p; rcur = c->d_results.p; rnext = c->d_results2.p;
+    /* the hand-over round's list is already that small: the views go their own ways at once */
+    if (front_max > 0 && tail_known <= front_max) { to_front = true; return 0; }
     /* An event record costs ~6 us of queue time on either side of the kernel it brackets -- more than a tenth of a
      * tail round: every 8th round is timed (all of them when tracing); the tail launches are uniform (one dependent
      * patch chain each), their mean stands in for the untimed ones. */
@@ -1900,11 +1911,18 @@ static int mi_dmrecon_pointset_impl(mi_dmrecon_ctx* c, const mi_dmrecon_camera* 
  * that follow (-1: none), see fill_job */
 void mi_dmrecon_debug_inject_footprint(int view_id) { g_inject_footprint.store(view_id); }
 
-/* development aid (not in the public header): allocate / fetch the MI_TIMING stamp buffer */
-int mi_dmrecon_debug_timing(unsigned long long* out, int n) {
-    if (!mi_debug_tbuf) { if (hipMalloc((void**)&mi_debug_tbuf, 500 * sizeof(unsigned long long)) != hipSuccess) return -1; (void)hipMemset(mi_debug_tbuf, 0, 500 * 8); return 0; }
-    if (out) (void)hipMemcpy(out, mi_debug_tbuf, std::min(n, 500) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    (void)hipMemset(mi_debug_tbuf, 0, 500 * 8);
+/* development aid (not in the public header): the debug buffer of MI_PROBE builds (tools/patch_probe.py).  The first
+ * call allocates `n` words on the device; later calls copy up to n words out and clear the buffer. */
+int mi_dmrecon_debug_buffer(unsigned long long* out, int n) {
+    static int cap = 0;
+    if (!mi_debug_tbuf) {
+        if (n <= 0 || hipMalloc((void**)&mi_debug_tbuf, (size_t)n * sizeof(unsigned long long)) != hipSuccess) return -1;
+        cap = n;
+        (void)hipMemset(mi_debug_tbuf, 0, (size_t)cap * 8);
+        return 0;
+    }
+    if (out) (void)hipMemcpy(out, mi_debug_tbuf, (size_t)std::min(n, cap) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipMemset(mi_debug_tbuf, 0, (size_t)cap * 8);
     return 0;
 }
 

@@ -37,7 +37,13 @@ struct DevView {
 /* A global neighbour view as a job sees it: everything a sampling pass needs before it knows the mip level, in one
  * record indexed by the view's position in the job's global list (no global_ids -> DevView indirection). */
 struct DevJobView {
-    float w2c[12];           /* rows of [R|t] */
+    /* H = R_n R_ref^T K_s^-1 (row-major; K_s^-1 of the reference level): the pixel (x + .5, y + .5, 1) of the reference
+     * image as a direction in this view's camera frame; sc = R_n C_ref + t_n: the reference camera centre there.  With
+     * them a patch sample projects as s_C + (t g) H (pixel) -- see NView in dmrecon_device.hip.  Computed in double on
+     * the host, rounded once. */
+    float H[9];
+    float sc[3];
+    float w2c_z[4];          /* third row of [R|t] (SingleView::footPrint of a world point: the view selection) */
     float inv0;              /* invproj[0] of level 0 (SingleView::footPrint) */
     int32_t maxl;            /* number of pyramid levels - 1 */
     int32_t view;            /* index into the DevView table (levels, texels) */

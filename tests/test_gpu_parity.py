@@ -224,34 +224,39 @@ def test_speculative_tail_equals_sequential_attempts(gpu_ctx, g1_scene, monkeypa
     assert n_seq["n_patch"] == n_spec["n_patch"] and n_seq["n_eval"] == n_spec["n_eval"]
 
 
-@pytest.mark.parametrize("per_view", ["1000000", "2", None])
+@pytest.mark.parametrize("per_view", ["all", "1000000", "2", None])
 def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, monkeypatch, per_view):
     """k_front (the end of the tail: one persistent workgroup per reference view, each view at its own pace) writes
     exactly what one k_tail launch per round writes: same candidates, same attempts, same sequential rule
-    (dmrecon.cc:365-431).  Handed over as early as the round driver allows (after the first chunk of tail rounds),
-    late (two entries per view), and at the default threshold.  Five / nine reference views per call; on the hard
-    scene views fail patches, replace local views and end at very different rounds."""
+    (dmrecon.cc:365-431).  "all": the whole propagation after the first round in k_front (rounds with hundreds of
+    entries per view, chunked); then handed over after the bulk rounds, late (two entries per view), and at the default
+    threshold.  Five / nine reference views per call; on the hard scene views fail patches, replace local views and
+    end at very different rounds."""
     for scene, refs in ((g1_scene, [0, 1, 2, 3, 4]), (h1_scene, list(range(9)))):
         gpu_ctx.load_scene(scene)
         monkeypatch.setenv("MI_DMRECON_FRONT", "0")
+        if per_view == "all":
+            monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "1000000000")      # tail rounds from the first round on
         ref = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
         s0 = dict(gpu_ctx.last_stats)
         assert s0["n_front_launches"] == 0
         if per_view is None:
             monkeypatch.delenv("MI_DMRECON_FRONT")
         else:
-            monkeypatch.setenv("MI_DMRECON_FRONT", per_view)
+            monkeypatch.setenv("MI_DMRECON_FRONT", "1000000" if per_view == "all" else per_view)
         for rep in range(2):
             got = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
             s1 = dict(gpu_ctx.last_stats)
-            if per_view == "1000000":
-                assert s1["n_front_launches"] == 1 and s1["n_front_rounds_max"] > 5 and s1["n_front_views"] >= 2, s1
+            if per_view == "all":
+                assert s1["n_front_launches"] == 1 and s1["front_first_round"] == 2 and s1["n_tail_launches"] == 0, s1
+                assert s1["n_front_rounds_max"] > 5 and s1["n_front_views"] == len(refs), s1
             assert s1["n_rounds"] == s0["n_rounds"], (s1["n_rounds"], s0["n_rounds"], s1["front_first_round"])
             for k in ("n_patch", "n_eval", "n_filled"):
                 assert s1[k] == s0[k], k
             for a, b in zip(got, ref):
                 for k in ("depth", "conf", "dz", "normal", "views"):
                     assert np.array_equal(a[k], b[k]), (k, rep)
+        monkeypatch.delenv("MI_DMRECON_TAIL_THRESHOLD", raising=False)
     monkeypatch.delenv("MI_DMRECON_FRONT", raising=False)
     gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
 
