@@ -1,7 +1,13 @@
 """GPU tests at BASELINE.json's full size (config 3: 20 views 1920x1080, scale 2 -> 480x270 maps).
 The oracle cannot run 20 such views in seconds, so the full batch is checked through size-independent
 properties (determinism, invariants of the maps, accuracy against the analytic ground truth of the
-synthetic scene) and ONE view is compared with the CPU oracle under the map-level tolerance."""
+synthetic scene) and THREE views -- among them the two with the largest one-sided border strips -- are compared
+with the CPU oracle under the map-level tolerance, the fill masks against the reference algorithm's own
+order-sensitivity floor on the same views."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -12,8 +18,45 @@ from mve_amd.synth import CONFIGS, make_scene, true_depth
 pytestmark = pytest.mark.gpu
 
 
+_ORACLE_VIEW = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from mve_amd.synth import CONFIGS, make_scene
+from oracle import oracle as orc
+cfg = CONFIGS["C3"]
+S = orc.OracleScene(make_scene(cfg["params"]))
+r = S.reconstruct(orc.make_settings(ref_view=int(sys.argv[1]), scale=cfg["scale"], local_neighbors=cfg["local_neighbors"]))
+np.savez(sys.argv[2], d=r["depth"], c=r["conf"])
+"""
+
+
 @pytest.fixture(scope="module")
-def c3():
+def c3_oracle(tmp_path_factory):
+    """The CPU oracle on views 3, 8 and 12 of the C3 scene, and on 8 and 12 once more with its queue popped worst-first
+    (ORC_QUEUE_ORDER=reverse is read when the oracle library is loaded): five subprocesses side by side, started
+    before the GPU fixture so that they run while the GPU tests do.  Returns get(view, reverse=False) -> maps."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    td = tmp_path_factory.mktemp("c3_oracle")
+    jobs = {}
+    for v, rev in ((3, False), (8, False), (12, False), (8, True), (12, True)):
+        out = str(td / ("v%d%s.npz" % (v, "r" if rev else "")))
+        env = dict(os.environ, OMP_NUM_THREADS="8")
+        if rev:
+            env["ORC_QUEUE_ORDER"] = "reverse"
+        jobs[(v, rev)] = (subprocess.Popen([sys.executable, "-c", _ORACLE_VIEW % root, str(v), out], env=env), out)
+
+    def get(view, reverse=False):
+        p, out = jobs[(view, reverse)]
+        assert p.wait(timeout=1200) == 0
+        return np.load(out)
+    yield get
+    for p, _ in jobs.values():
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.fixture(scope="module")
+def c3(c3_oracle):
     cfg = CONFIGS["C3"]
     scene = make_scene(cfg["params"])
     ctx = api.Context(0)
@@ -98,15 +141,35 @@ def test_c3_deterministic(c3):
         assert m["iou"] >= 0.999 and m["rel_med"] <= 1e-4 and m["rel_p99"] <= 3e-3 and m["conf_p99"] <= 3e-3, m
 
 
-def test_c3_one_view_vs_oracle(c3):
+@pytest.mark.parametrize("view", [3, 8, 12])
+def test_c3_views_vs_oracle(c3, c3_oracle, view):
+    """Depth / confidence of three full-size views against the CPU oracle under the map-level tolerance.  The fill
+    mask: IoU >= 0.98 as SURVEY 8c states -- except where the reference ALGORITHM does not reach that against itself:
+    on views 8 and 12 strips along the top / bottom image border are filled or not depending on which local view set
+    reaches them first, and the same restatement with its queue popped worst-first (another valid order of the same
+    algorithm) differs from the reference by as much (measured: view 12 IoU 0.9713 against itself, 0.9708 GPU vs
+    reference; view 8 0.9850 / 0.9860).  The bound there is that floor, enforced: the GPU sweep may not be further
+    from the reference than the reference's own order sensitivity (- 0.002)."""
+    cfg, scene, ctx, st, res, stats = c3
+    o = c3_oracle(view)
+    m = map_parity(res[view]["depth"], res[view]["conf"], o["d"], o["c"])
+    assert m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
+    assert m["conf_med"] <= 1e-3 and m["conf_p99"] <= 5e-3, m
+    if view == 3:
+        assert m["iou"] >= 0.98, m
+    else:
+        r = c3_oracle(view, reverse=True)
+        floor = map_parity(r["d"], r["c"], o["d"], o["c"])
+        assert floor["iou"] < 0.99, floor                     # the strips are a property of the algorithm on this view
+        assert m["iou"] >= min(0.98, floor["iou"] - 0.002), (m["iou"], floor["iou"])
+        # ... and so are the depths: the sweep is as close to the reference as the reference is to itself
+        assert m["rel_p99"] <= max(3e-3, 1.5 * floor["rel_p99"]), (m, floor)
+
+
+def test_c3_global_view_selection_of_view_3(c3):
     from oracle import oracle as orc
     cfg, scene, ctx, st, res, stats = c3
-    S = orc.OracleScene(scene)
-    o = S.reconstruct(orc.make_settings(ref_view=3, scale=cfg["scale"], local_neighbors=cfg["local_neighbors"]))
-    m = map_parity(res[3]["depth"], res[3]["conf"], o["depth"], o["conf"])
-    assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
-    assert m["conf_med"] <= 1e-3 and m["conf_p99"] <= 5e-3, m
-    assert ctx.global_view_selection(st, 3) == S.global_vs(orc.make_settings(ref_view=3, scale=cfg["scale"]))
+    assert ctx.global_view_selection(st, 3) == orc.OracleScene(scene).global_vs(orc.make_settings(ref_view=3, scale=cfg["scale"]))
 
 
 @pytest.mark.parametrize("name,ref", [("C1", 0), ("C2", 5)])
