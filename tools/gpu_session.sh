@@ -1,28 +1,26 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): the measurement session of the day (tests + bench lines + probes in one call).
-TAG=${1:-r3c}
+# Runs ON THE GPU BOX (through gpurun): SQ counters of the optimise kernels at a lone 20-view call (FRONT on and off).
+TAG=${1:-r3d}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -s KILL 200 python tools/patch_probe.py > $OUT/probe.txt 2>&1
-tail -45 $OUT/probe.txt
-one() {  # label, env...
-  L=$1; shift
-  env "$@" timeout -s KILL 120 python bench.py --no-cpu-baseline --no-one-call --streams 1 --steps-per-call 1 --steps 10 --warmup 2 2>/dev/null > $OUT/b1_$L.json
-  python - $OUT/b1_$L.json $L <<'PY'
-import sys, json
-try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d['roofline']['per_kernel']
-    t = r['k_tail + k_front (tail rounds)']; b = r['k_optimize<1> (host-visible rounds)']
-    print('%-12s' % sys.argv[2], round(d['value'], 1), 'maps/s  ms/step', round(d['ms_per_step'], 2), ' bulk ms', round(b['avg_launch_ms'] * b['launches'] / d['steps'], 2), 'launches', b['launches'] // d['steps'], 'frac', round(b['frac'], 4),
-          ' k_tail ms', round(t['k_tail_ms'] / d['steps'], 2), 'launches', t['k_tail_launches'] // d['steps'], ' k_front ms', round(t['k_front_ms'] / d['steps'], 2), 'rounds', t['k_front_rounds_slowest_view'] // d['steps'], 'attempts', t['k_front_attempts'] // d['steps'])
-except Exception as e:
-    print(sys.argv[2], 'failed', e)
+BP="python bench.py --steps 2 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline --no-one-call"
+for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD" "SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC"; do
+  D=$OUT/pmc_$(echo $C | tr ' ' '+')
+  MI_DMRECON_FRONT=1000000 timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o bench -- $BP > $D.log 2>&1
+done
+python - $OUT <<'PY'
+import csv, sys, collections, glob, os
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(os.path.join(sys.argv[1], "pmc_*", "bench_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+for k in sorted(acc):
+    if not (k.startswith("mi_fw5::k_optimize") or k.startswith("mi_fw5::k_tail") or k.startswith("mi_fw5::k_front") or k.startswith("k_")):
+        pass
+    print(k)
+    for c, (v, n) in sorted(acc[k].items()):
+        print("    %-28s total %.6g  per launch %.6g (n=%d)" % (c, v, v / max(n, 1), n))
 PY
-}
-one f0 MI_DMRECON_FRONT=0
-one f0_t32k MI_DMRECON_FRONT=0 MI_DMRECON_TAIL_THRESHOLD=32768
-one f0_t64k MI_DMRECON_FRONT=0 MI_DMRECON_TAIL_THRESHOLD=65536
-one f0_t128k MI_DMRECON_FRONT=0 MI_DMRECON_TAIL_THRESHOLD=131072
-one f0_t256k MI_DMRECON_FRONT=0 MI_DMRECON_TAIL_THRESHOLD=262144
-one f0_s4096 MI_DMRECON_FRONT=0 MI_DMRECON_SPECULATE=4096
+find $OUT -name "*_kernel_trace.csv" -delete
