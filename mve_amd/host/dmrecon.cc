@@ -288,41 +288,60 @@ private:
             if (rc != 0) { for (std::size_t k = 0; k < s; ++k) mi_dmrecon_ctx_destroy(ctxs[k]); raise_from(rc); }
         }
         mve::Scene::ViewList const& views(g.scene->get_views());
-        /* images stay alive until the copies enqueued from them have run (mi_dmrecon_sync below) */
-        std::vector<mve::ByteImage::Ptr> keep(views.size());
+        /* A decoded image stays alive until the copies enqueued from it have run (mi_dmrecon_sync).  The views go
+         * through in windows of a few per decoding thread: decode + enqueue in parallel, then one sync of every GPU,
+         * then the window's images are released -- the host holds one window of decoded images, not the scene.
+         * An exception of a view's decoder (util::Exception for a missing / corrupt image) must not leave the OpenMP
+         * region: the first one is kept and rethrown after the loop, as it would have reached the DMRecon constructor
+         * of that view in the reference. */
         int failed_rc = 0;
         std::string failed_msg;
+        std::exception_ptr first_exc;
         int const n_threads = (int)std::max<std::size_t>(1, std::min<std::size_t>(env_threads(), views.size()));
+        std::size_t const window = (std::size_t)n_threads * 2;
+        std::vector<mve::ByteImage::Ptr> keep(views.size());
+        for (std::size_t base = 0; base < views.size() && failed_rc == 0 && !first_exc; base += window) {
+            std::size_t const end = std::min(views.size(), base + window);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
-        for (std::size_t i = 0; i < views.size(); ++i) {
-            if (views[i] == nullptr || !views[i]->is_camera_valid()
-                || !views[i]->has_image(g.embedding, mve::IMAGE_TYPE_UINT8))
-                continue;
-            mve::ByteImage::Ptr img = views[i]->get_byte_image(g.embedding);      /* decode: per view, no shared state */
-            if (img == nullptr) continue;
-            keep[i] = img;
-            mve::CameraInfo const& cam = views[i]->get_camera();
-            mi_dmrecon_camera mc;
-            mc.flen = cam.flen; mc.paspect = cam.paspect;
-            mc.ppoint[0] = cam.ppoint[0]; mc.ppoint[1] = cam.ppoint[1];
-            for (int k = 0; k < 9; ++k) mc.rot[k] = cam.rot[k];
-            for (int k = 0; k < 3; ++k) mc.trans[k] = cam.trans[k];
-            for (std::size_t s = 0; s < ns; ++s) {
-                std::lock_guard<std::mutex> lock(*ctx_mu[s]);                     /* a context is not thread-safe */
-                int rc = mi_dmrecon_set_view_async(ctxs[s], (int32_t)i, &mc, img->width(), img->height(), img->channels(),
-                                                   img->get_data_pointer());
-                if (rc != 0) {
+            for (std::size_t i = base; i < end; ++i) {
+                try {
+                    if (views[i] == nullptr || !views[i]->is_camera_valid()
+                        || !views[i]->has_image(g.embedding, mve::IMAGE_TYPE_UINT8))
+                        continue;
+                    mve::ByteImage::Ptr img = views[i]->get_byte_image(g.embedding);  /* decode: per view, no shared state */
+                    if (img == nullptr) continue;
+                    keep[i] = img;
+                    mve::CameraInfo const& cam = views[i]->get_camera();
+                    mi_dmrecon_camera mc;
+                    mc.flen = cam.flen; mc.paspect = cam.paspect;
+                    mc.ppoint[0] = cam.ppoint[0]; mc.ppoint[1] = cam.ppoint[1];
+                    for (int k = 0; k < 9; ++k) mc.rot[k] = cam.rot[k];
+                    for (int k = 0; k < 3; ++k) mc.trans[k] = cam.trans[k];
+                    for (std::size_t s = 0; s < ns; ++s) {
+                        std::lock_guard<std::mutex> lock(*ctx_mu[s]);                 /* a context is not thread-safe */
+                        int rc = mi_dmrecon_set_view_async(ctxs[s], (int32_t)i, &mc, img->width(), img->height(), img->channels(),
+                                                           img->get_data_pointer());
+                        if (rc != 0) {
 #pragma omp critical(mi_dmrecon_upload_error)
-                    if (failed_rc == 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
+                            if (failed_rc == 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
+                        }
+                    }
+                    views[i]->cache_cleanup();
+                } catch (...) {
+#pragma omp critical(mi_dmrecon_upload_error)
+                    if (!first_exc) first_exc = std::current_exception();
                 }
             }
-            views[i]->cache_cleanup();
+            for (std::size_t s = 0; s < ns; ++s) {
+                int rc = mi_dmrecon_sync(ctxs[s]);
+                if (rc != 0 && failed_rc == 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
+            }
+            for (std::size_t i = base; i < end; ++i) keep[i].reset();
         }
-        for (std::size_t s = 0; s < ns && failed_rc == 0; ++s) {
-            int rc = mi_dmrecon_sync(ctxs[s]);
-            if (rc != 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
+        if (first_exc) {
+            for (std::size_t s = 0; s < ns; ++s) mi_dmrecon_ctx_destroy(ctxs[s]);
+            std::rethrow_exception(first_exc);
         }
-        keep.clear();
         mve::Bundle::Features const& feats = g.scene->get_bundle()->get_features();
         std::vector<float> pos(feats.size() * 3);
         std::vector<int32_t> off(feats.size() + 1, 0), ids;

@@ -63,3 +63,28 @@ def test_unmodified_apps_dmrecon_on_the_gpu_library(tmp_path, g1, g1_scene, g1b,
     from oracle.pset_oracle import pointset_from_depthmap
     expect = pointset_from_depthmap(d, None, g1b_scene.cameras[2])
     assert "element vertex %d" % len(expect["pixel"]) in header and "confidence" in header
+
+
+@pytest.mark.skipif(not os.path.exists(APP), reason="build/dmrecon_mi not built (needs the reference tree at build time)")
+def test_shim_deals_views_over_several_gpu_slots(tmp_path, g1_scene):
+    """The shim's multi-GPU path on the one GPU a test box has: MI_DMRECON_DEVICES=0,0 makes two slots (two contexts,
+    two resident copies of the scene, the app's requests dealt round-robin over them) -- the maps must be the ones the
+    single-slot run writes, bit for bit (the reference views are independent; a view's maps do not depend on which
+    GPU holds its copy)."""
+    runs = {}
+    for name, devices in (("one", "0"), ("two", "0,0"), ("three", "0,0,0")):
+        sdir = str(tmp_path / name)
+        scene_io.write_scene(sdir, g1_scene)
+        # MI_DMRECON_MERGE_CALLS=0: every mvs::DMRecon::start() is its own batch, whatever the timing of the app's threads
+        env = dict(os.environ, MI_DMRECON_DEVICES=devices, MI_DMRECON_MERGE_CALLS="0")
+        out = subprocess.run([APP, "-s0", "--keep-conf", "--keep-dz", "--force", "--progress=silent", sdir],
+                             capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        runs[name] = [(scene_io.read_mvei(os.path.join(scene_io.view_dir(sdir, v), "depth-L0.mvei")),
+                       scene_io.read_mvei(os.path.join(scene_io.view_dir(sdir, v), "conf-L0.mvei")),
+                       scene_io.read_mvei(os.path.join(scene_io.view_dir(sdir, v), "dz-L0.mvei"))) for v in range(5)]
+    for name in ("two", "three"):
+        for v in range(5):
+            for a, b in zip(runs["one"][v], runs[name][v]):
+                assert np.array_equal(a, b), (name, v)
+    assert (runs["one"][0][1] > 0).mean() > 0.3
