@@ -113,7 +113,9 @@ __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelec
 /* the same for the latency layout: one patch per wavefront, at most MI_LAT_SLOTS wavefronts per workgroup.  Separate
  * (smaller) arrays because a kernel's LDS is what it references: the tail kernels then ask for 4 KB instead of 12.8 KB,
  * and a CU filled with bulk workgroups of another call (12 x 12.6 KB of 160 KB) has that much to spare */
+#ifndef MI_LAT_SLOTS
 #define MI_LAT_SLOTS 8
+#endif
 __shared__ float g_geo_lat[MI_LAT_SLOTS][MI_NS];
 __shared__ float g_mcol_lat[MI_LAT_SLOTS][3 * MI_NS];
 __shared__ float g_ncc_lat[MI_LAT_SLOTS][MI_MAX_GLOBAL];
@@ -1595,7 +1597,9 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
  *      writes its other state slot.
  * Rounds with more than MI_FRONT_QCAP candidate pairs are processed in chunks (all chunks read the frozen state).
  */
-#define MI_FRONT_WAVES 8
+#ifndef MI_FRONT_WAVES
+#define MI_FRONT_WAVES 8          /* wavefronts of a front workgroup = patch optimisations of a view in flight */
+#endif
 #define MI_FRONT_QCAP 128
 static_assert(MI_FRONT_WAVES <= MI_LAT_SLOTS, "the latency layout's LDS holds one patch per wavefront of a front workgroup");
 struct FrontArgs {
@@ -1624,7 +1628,7 @@ __shared__ unsigned g_fatt[MI_FRONT_QCAP * 4];
 __shared__ unsigned g_fcnt[8];    /* 0: FQs, 1: attempts of the pass, 2: attempts taken, 3: entries of the next list, 4: sum of candidates,
                                    * 5: newly filled pixels of the round */
 
-__global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_front(FrontArgs t) {
+__global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(MI_FRONT_WAVES / 4, MI_FRONT_WAVES / 4))) void k_front(FrontArgs t) {
     const OptArgs& a = t.o;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int jobi = blockIdx.x;

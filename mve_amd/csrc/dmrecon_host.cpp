@@ -145,11 +145,10 @@ struct TailPoll { unsigned rw[MI_TAIL_CHUNK]; DevCounters hc; };
 #define MI_MAX_DEVICES 64
 std::atomic<int> g_active_calls[MI_MAX_DEVICES];
 std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
-/* MI_DMRECON_FRONT default: entries per reference view (average over the batch) below which the rest of the
- * propagation goes to the front kernel */
-#ifndef MI_FRONT_DEFAULT
-#define MI_FRONT_DEFAULT 8
-#endif
+/* MI_DMRECON_FRONT defaults: entries per reference view (average over the batch) below which the rest of the
+ * propagation goes to the front kernel, for a call alone on its GPU / next to other calls (BatchRun::tail_rounds) */
+#define MI_FRONT_ALONE 2
+#define MI_FRONT_SHARED 8
 struct ActiveCall {
     int dev;
     explicit ActiveCall(int d) : dev(d >= 0 && d < MI_MAX_DEVICES ? d : -1) { if (dev >= 0) g_active_calls[dev].fetch_add(1); }
@@ -1356,11 +1355,19 @@ int BatchRun::tail_rounds(bool& to_front) {
      * the round is one patch optimisation long instead of up to four); larger rounds fill the GPU anyway and run
      * them in turn on one wavefront, which wastes nothing.  MI_DMRECON_SPECULATE=<entries> (0 = never). */
     static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 1024u; }();
-    /* MI_DMRECON_FRONT=<entries per view> (read per call; 0 = never): hand the rest of the propagation to k_front once
-     * a round's list is down to that many entries per reference view on average. */
-    const unsigned FRONT_PER_VIEW = [] { const char* e = std::getenv("MI_DMRECON_FRONT"); return e ? (unsigned)std::max(0, std::atoi(e)) : (unsigned)MI_FRONT_DEFAULT; }();
-    const unsigned front_max = FRONT_PER_VIEW * (unsigned)nj;
     const ActiveCall& active = *active_call;
+    /* MI_DMRECON_FRONT=<entries per view> (read per call; 0 = never): hand the rest of the propagation to k_front once
+     * a round's list is down to that many entries per reference view on average.  A front workgroup runs eight patch
+     * optimisations of its view at a time: below ~6 entries per view a view's round is one patch long there (18 us
+     * against 29 us for a k_tail launch), above it rounds take several generations.  Default: 2 for a call that has
+     * the GPU to itself (measured neutral to +1 % on a lone 20-view call: the slowest view decides, and it still has
+     * ~14 entries per round when the average is 8), 8 next to other calls (+6 % depth-maps/s at the bench's plan: a
+     * front workgroup occupies one CU per view instead of a stream of launches that queue behind bulk kernels). */
+    const unsigned FRONT_PER_VIEW = [&] {
+        const char* e = std::getenv("MI_DMRECON_FRONT");
+        return e ? (unsigned)std::max(0, std::atoi(e)) : (active.count() > 1 ? (unsigned)MI_FRONT_SHARED : (unsigned)MI_FRONT_ALONE);
+    }();
+    const unsigned front_max = FRONT_PER_VIEW * (unsigned)nj;
     wcur = c->d_work.p; wnext = c->d_work2.p; rcur = c->d_results.p; rnext = c->d_results2.p;
     /* the hand-over round's list is already that small: the views go their own ways at once */
     if (front_max > 0 && tail_known <= front_max) { to_front = true; return 0; }
