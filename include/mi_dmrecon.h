@@ -34,8 +34,8 @@ extern "C" {
 #define MI_DMRECON_ECANCELLED   -4   /* progress.cancelled observed (dmrecon.cc:101-105) */
 #define MI_DMRECON_EFOOTPRINT   -5   /* std::out_of_range("Negative pixel footprint") (patch_sampler.cc:78-82) */
 
-#define MI_DMRECON_MAX_GLOBAL_VIEWS 32
-#define MI_DMRECON_MAX_LOCAL_VIEWS   4
+#define MI_DMRECON_MAX_GLOBAL_VIEWS 64   /* Settings::globalVSMax (apps/dmrecon -n, default 20) */
+#define MI_DMRECON_MAX_LOCAL_VIEWS   8   /* Settings::nrReconNeighbors (apps/dmrecon --local-neighbors, default 4) */
 
 typedef struct mi_dmrecon_ctx mi_dmrecon_ctx;
 
@@ -58,7 +58,7 @@ typedef struct mi_dmrecon_settings {
     float   acceptNCC;          /* 0.6 */
     float   minRefineDiff;      /* 0.001 */
     int32_t maxIterations;      /* 20 */
-    int32_t nrReconNeighbors;   /* 4; 1..MI_DMRECON_MAX_LOCAL_VIEWS */
+    int32_t nrReconNeighbors;   /* 4; 1..MI_DMRECON_MAX_LOCAL_VIEWS (above 4 a patch runs in the eight-view lane layouts) */
     int32_t globalVSMax;        /* 20; <= MI_DMRECON_MAX_GLOBAL_VIEWS */
     int32_t scale;              /* 0 */
     int32_t useColorScale;      /* 1 */
@@ -85,7 +85,8 @@ typedef struct mi_dmrecon_maps {
     float*   normal;    /* 3 channels (SingleView::normalImg) */
     float*   dz;        /* 2 channels "dz-L<s>"     */
     float*   conf;      /* 1 channel  "conf-L<s>"   */
-    int32_t* views;     /* 4 channels: local view ids of the accepted patch, -1 padded (QueueData::localViewIDs) */
+    int32_t* views;     /* local view ids of the accepted patch, ascending, -1 padded (QueueData::localViewIDs): 4 channels
+                         * for nrReconNeighbors <= 4, 8 channels above (mi_dmrecon_local_view_channels) */
 } mi_dmrecon_maps;
 
 /* Work counters (device-counted) and timings of the last reconstruct call. */
@@ -133,6 +134,8 @@ typedef struct mi_dmrecon_stats {
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);
+/* channels of mi_dmrecon_maps::views / of the local-view arguments of mi_dmrecon_patch_optimize: 4 or 8 */
+int  mi_dmrecon_local_view_channels(int32_t nrReconNeighbors);
 const char* mi_dmrecon_last_error(void);
 void mi_dmrecon_settings_default(mi_dmrecon_settings* s);              /* settings.h:25-51 */
 
@@ -205,10 +208,11 @@ int  mi_dmrecon_reconstruct(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, 
 
 /* Patch-level entry (parity hook; = constructing mvs::PatchOptimization, doAutoOptimization,
  * computeConfidence -- patch_optimization.cc:21-78,170-242,114-142) for n hypotheses in
- * reference view ref_view: xy[2n]; hyp[3n] = depth,dzI,dzJ; local[4n] view ids (-1 = none, may be NULL).
+ * reference view ref_view: xy[2n]; hyp[3n] = depth,dzI,dzJ; local[Cn] view ids (-1 = none, may be NULL),
+ * C = mi_dmrecon_local_view_channels(nrReconNeighbors).
  * lanes_per_view: the lane layout to run them in (1 = throughput layout, 16 patches per wavefront; 16 = latency
  * layout, one patch per wavefront -- the two layouts of the product path, same mathematics).
- * out[8n] = conf, depth, dzI, dzJ, nx, ny, nz, iterationCount; out_local[4n] ascending ids, -1 padded. */
+ * out[8n] = conf, depth, dzI, dzJ, nx, ny, nz, iterationCount; out_local[Cn] ascending ids, -1 padded. */
 int  mi_dmrecon_patch_optimize(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n,
                                const int32_t* xy, const float* hyp, const int32_t* local, int32_t lanes_per_view,
                                float* out, int32_t* out_local);

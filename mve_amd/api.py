@@ -24,11 +24,20 @@ from .scene_io import SceneData
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_DMRECON_LIB") or os.path.join(_HERE, "csrc", "libmi_dmrecon.so")   # env: another build of the same ABI
 
-MAX_GLOBAL_VIEWS = 32
+MAX_GLOBAL_VIEWS = 64
+MAX_LOCAL_VIEWS = 8
+
+
+def local_view_channels(n_local: int) -> int:
+    """Channels of the `views` maps / of patch_optimize's local-view arrays: 4, or 8 for nrReconNeighbors > 4
+    (mi_dmrecon_local_view_channels)."""
+    return 8 if n_local > 4 else 4
+
+
 E_INVAL, E_GVS, E_DEVICE, E_CANCELLED, E_FOOTPRINT = -1, -2, -3, -4, -5
 
 EXPORTS = [
-    "mi_dmrecon_device_count", "mi_dmrecon_last_error", "mi_dmrecon_settings_default",
+    "mi_dmrecon_device_count", "mi_dmrecon_local_view_channels", "mi_dmrecon_last_error", "mi_dmrecon_settings_default",
     "mi_dmrecon_ctx_create", "mi_dmrecon_ctx_destroy", "mi_dmrecon_ctx_fork", "mi_dmrecon_ctx_stream",
     "mi_dmrecon_host_alloc", "mi_dmrecon_host_free",
     "mi_dmrecon_set_view", "mi_dmrecon_set_view_async", "mi_dmrecon_sync", "mi_dmrecon_evict_view", "mi_dmrecon_set_features",
@@ -350,7 +359,7 @@ class Context:
             if want_normal:
                 spec["normal"] = ((h, w, 3), np.float32)
             if want_views:
-                spec["views"] = ((h, w, 4), np.int32)
+                spec["views"] = ((h, w, local_view_channels(st.nrReconNeighbors)), np.int32)
             d = {}
             for k, (shape, dt) in spec.items():
                 if pinned:
@@ -391,9 +400,14 @@ class Context:
         xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
         n = len(xy)
         hyp = np.ascontiguousarray(hyp, np.float32).reshape(n, 3)
-        loc = None if local is None else np.ascontiguousarray(local, np.int32).reshape(n, 4)
+        nch = local_view_channels(st.nrReconNeighbors)
+        loc = None
+        if local is not None:
+            local = np.ascontiguousarray(local, np.int32).reshape(n, -1)
+            loc = np.full((n, nch), -1, np.int32)
+            loc[:, :local.shape[1]] = local                      # (a 4-column array also serves an 8-channel call)
         out = np.zeros((n, 8), np.float32)
-        out_local = np.zeros((n, 4), np.int32)
+        out_local = np.zeros((n, nch), np.int32)
         cs = st.to_c()
         rc = self._L.mi_dmrecon_patch_optimize(self._h, ctypes.byref(cs), ref_view, n, _ptr(xy), _ptr(hyp),
                                                _ptr(loc), int(lanes_per_view), _ptr(out), _ptr(out_local))

@@ -39,7 +39,6 @@
 #include "dmrecon_types.h"
 #include "dmrecon_device.h"
 
-#define QUAD 4
 #define WAVE 64
 
 /* This file is compiled once per supported filter width (mvs::Settings::filterWidth, apps/dmrecon --filter-width):
@@ -119,9 +118,9 @@ __shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelec
 __shared__ float g_geo_lat[MI_LAT_SLOTS][MI_NS];
 __shared__ float g_mcol_lat[MI_LAT_SLOTS][3 * MI_NS];
 __shared__ float g_ncc_lat[MI_LAT_SLOTS][MI_MAX_GLOBAL];
-template <int LPV> __device__ __forceinline__ float* lds_geo(int patch) { return LPV == 16 ? g_geo_lat[patch] : g_geo[patch]; }
-template <int LPV> __device__ __forceinline__ float* lds_mcol(int patch) { return LPV == 16 ? g_mcol_lat[patch] : g_mcol[patch]; }
-template <int LPV> __device__ __forceinline__ float* lds_ncc(int patch) { return LPV == 16 ? g_ncc_lat[patch] : g_ncc[patch]; }
+template <class L> __device__ __forceinline__ float* lds_geo(int patch) { return L::LAT ? g_geo_lat[patch] : g_geo[patch]; }
+template <class L> __device__ __forceinline__ float* lds_mcol(int patch) { return L::LAT ? g_mcol_lat[patch] : g_mcol[patch]; }
+template <class L> __device__ __forceinline__ float* lds_ncc(int patch) { return L::LAT ? g_ncc_lat[patch] : g_ncc[patch]; }
 
 
 /* ------------------------------------------------------------------------- */
@@ -143,6 +142,9 @@ __device__ __forceinline__ float fadd_i(float a, int b) { return a + __int_as_fl
 __device__ __forceinline__ double dmov(double v, int (*f)(int)) {
     return __hiloint2double(f(__double2hiint(v)), f(__double2loint(v)));
 }
+__device__ __forceinline__ unsigned long long dmov_u(unsigned long long v, int (*f)(int)) {
+    return ((unsigned long long)(unsigned)f((int)(unsigned)(v >> 32)) << 32) | (unsigned)f((int)(unsigned)v);
+}
 __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     return __hiloint2double(__shfl_xor(__double2hiint(v), m), __shfl_xor(__double2loint(v), m));
 }
@@ -154,10 +156,17 @@ __device__ __forceinline__ float fast_div(float a, float b) { return a * __built
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 
-template <int LPV> struct Lay;
+/* view sets are 8-bit indices into the job's global list, MI_VIEW_NONE padded, ascending (std::set order): NV of them */
+template <int NV> struct ViewPack;
+template <> struct ViewPack<4> { typedef uint32_t type; static constexpr uint32_t NONE = 0xFFFFFFFFu; };
+template <> struct ViewPack<8> { typedef unsigned long long type; static constexpr unsigned long long NONE = ~0ull; };
 
-template <> struct Lay<1> {
-    static constexpr int PATCHES = 16;
+template <int LPV, int NV> struct Lay;
+
+/* ---- four view slots (nrReconNeighbors <= 4, the reference's default) */
+template <> struct Lay<1, 4> {
+    static constexpr int LPV = 1, NV = 4, PATCHES = 16;
+    static constexpr bool LAT = false;
     __device__ static __forceinline__ int vslot(int lane) { return lane & 3; }
     __device__ static __forceinline__ int sub(int) { return 0; }
     __device__ static __forceinline__ int patch(int lane) { return lane >> 2; }
@@ -174,21 +183,29 @@ template <> struct Lay<1> {
         v += dmov(v, dpp_xor2);
         return v;
     }
-    __device__ static __forceinline__ int patch_or(int v) { v |= dpp_xor1(v); v |= dpp_xor2(v); return v; }
+    __device__ static __forceinline__ unsigned long long patch_or(unsigned long long v) {
+        v |= dmov_u(v, dpp_xor1); v |= dmov_u(v, dpp_xor2);
+        return v;
+    }
     __device__ static __forceinline__ float wave_sum(float v) { return v; }      /* unused in this layout */
-    template <int K> __device__ static __forceinline__ int from_view(int v) { return dpp_bcast<K>(v); }
-    __device__ static __forceinline__ int view_xor1(int v) { return dpp_xor1(v); }
-    __device__ static __forceinline__ int view_xor2(int v) { return dpp_xor2(v); }
+    /* out[k] = v of view slot k of my patch */
+    __device__ static __forceinline__ void from_views(int v, int, int* out) {
+        out[0] = dpp_bcast<0>(v); out[1] = dpp_bcast<1>(v); out[2] = dpp_bcast<2>(v); out[3] = dpp_bcast<3>(v);
+    }
+    /* butterfly partner exchange over the view slots: step 0, 1 (, 2) */
+    template <int S> __device__ static __forceinline__ int view_xor(int v) { return S == 0 ? dpp_xor1(v) : dpp_xor2(v); }
     /* bit k = predicate of view slot k of my patch */
     __device__ static __forceinline__ unsigned view_ballot(bool p, int lane) {
         const unsigned long long b = __ballot(p);
         return (unsigned)(b >> (lane & ~3)) & 0xFu;
     }
+    /* per-view counters of the wavefront's one patch summed into lane 0 (latency layouts only) */
+    __device__ static __forceinline__ unsigned rows_to_lane0(unsigned v) { return v; }
 };
 
-
-template <> struct Lay<16> {
-    static constexpr int PATCHES = 1;
+template <> struct Lay<16, 4> {
+    static constexpr int LPV = 16, NV = 4, PATCHES = 1;
+    static constexpr bool LAT = true;
     __device__ static __forceinline__ int vslot(int lane) { return lane >> 4; }
     __device__ static __forceinline__ int sub(int lane) { return lane & 15; }
     /* LDS slot of the patch = the wavefront's index in its workgroup (k_tail runs four wavefronts per workgroup) */
@@ -228,15 +245,138 @@ template <> struct Lay<16> {
     }
     /* sum over all 64 lanes (inputs arbitrary) */
     __device__ static __forceinline__ float wave_sum(float v) { return patch_sum(view_sum(v)); }
-    __device__ static __forceinline__ int patch_or(int v) { v |= __shfl_xor(v, 16); v |= __shfl_xor(v, 32); return v; }
-    template <int K> __device__ static __forceinline__ int from_view(int v) { return __builtin_amdgcn_readlane(v, 16 * K); }
-    __device__ static __forceinline__ int view_xor1(int v) { return __shfl_xor(v, 16); }
-    __device__ static __forceinline__ int view_xor2(int v) { return __shfl_xor(v, 32); }
+    __device__ static __forceinline__ unsigned long long patch_or(unsigned long long v) {
+        int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+        lo |= __shfl_xor(lo, 16); lo |= __shfl_xor(lo, 32); hi |= __shfl_xor(hi, 16); hi |= __shfl_xor(hi, 32);
+        return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    }
+    __device__ static __forceinline__ void from_views(int v, int, int* out) {
+        out[0] = __builtin_amdgcn_readlane(v, 0); out[1] = __builtin_amdgcn_readlane(v, 16);
+        out[2] = __builtin_amdgcn_readlane(v, 32); out[3] = __builtin_amdgcn_readlane(v, 48);
+    }
+    template <int S> __device__ static __forceinline__ int view_xor(int v) { return __shfl_xor(v, S == 0 ? 16 : 32); }
     __device__ static __forceinline__ unsigned view_ballot(bool p, int) {
         const unsigned long long b = __ballot(p);
         return (unsigned)((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull));
     }
+    __device__ static __forceinline__ unsigned rows_to_lane0(unsigned v) {
+        return (unsigned)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16)
+                        + __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
+    }
 };
+
+/* ---- eight view slots (nrReconNeighbors 5..8, apps/dmrecon --local-neighbors): a patch is an OCTET of lanes in the
+ * throughput layout (8 patches per wavefront), eight 8-lane half rows in the latency layout.  Sums run in the order
+ * ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)) in both. */
+template <> struct Lay<1, 8> {
+    static constexpr int LPV = 1, NV = 8, PATCHES = 8;
+    static constexpr bool LAT = false;
+    __device__ static __forceinline__ int vslot(int lane) { return lane & 7; }
+    __device__ static __forceinline__ int sub(int) { return 0; }
+    __device__ static __forceinline__ int patch(int lane) { return lane >> 3; }
+    __device__ static __forceinline__ float view_sum(float v) { return v; }
+    __device__ static __forceinline__ double view_sum(double v) { return v; }
+    __device__ static __forceinline__ bool view_all(bool p) { return p; }
+    __device__ static __forceinline__ float patch_sum(float v) {
+        v = fadd_i(v, dpp_xor1(__float_as_int(v)));
+        v = fadd_i(v, dpp_xor2(__float_as_int(v)));
+        v = fadd_i(v, dpp_half_mirror(__float_as_int(v)));         /* the quads of an octet are uniform by now */
+        return v;
+    }
+    __device__ static __forceinline__ double patch_sum(double v) {
+        v += dmov(v, dpp_xor1);
+        v += dmov(v, dpp_xor2);
+        v += dmov(v, dpp_half_mirror);
+        return v;
+    }
+    __device__ static __forceinline__ unsigned long long patch_or(unsigned long long v) {
+        v |= dmov_u(v, dpp_xor1); v |= dmov_u(v, dpp_xor2); v |= dmov_u(v, dpp_half_mirror);
+        return v;
+    }
+    __device__ static __forceinline__ float wave_sum(float v) { return v; }      /* unused in this layout */
+    __device__ static __forceinline__ void from_views(int v, int lane, int* out) {
+        /* b[k]: lane k of my own quad; m[k]: lane k of the octet's other quad (half_mirror of a quad-uniform value) */
+        const int b0 = dpp_bcast<0>(v), b1 = dpp_bcast<1>(v), b2 = dpp_bcast<2>(v), b3 = dpp_bcast<3>(v);
+        const int m0 = dpp_half_mirror(b0), m1 = dpp_half_mirror(b1), m2 = dpp_half_mirror(b2), m3 = dpp_half_mirror(b3);
+        const bool upper = (lane & 4) != 0;
+        out[0] = upper ? m0 : b0; out[1] = upper ? m1 : b1; out[2] = upper ? m2 : b2; out[3] = upper ? m3 : b3;
+        out[4] = upper ? b0 : m0; out[5] = upper ? b1 : m1; out[6] = upper ? b2 : m2; out[7] = upper ? b3 : m3;
+    }
+    template <int S> __device__ static __forceinline__ int view_xor(int v) { return S == 0 ? dpp_xor1(v) : S == 1 ? dpp_xor2(v) : dpp_half_mirror(v); }
+    __device__ static __forceinline__ unsigned view_ballot(bool p, int lane) {
+        const unsigned long long b = __ballot(p);
+        return (unsigned)(b >> (lane & ~7)) & 0xFFu;
+    }
+    __device__ static __forceinline__ unsigned rows_to_lane0(unsigned v) { return v; }
+};
+
+template <> struct Lay<8, 8> {
+    static constexpr int LPV = 8, NV = 8, PATCHES = 1;
+    static constexpr bool LAT = true;
+    __device__ static __forceinline__ int vslot(int lane) { return lane >> 3; }
+    __device__ static __forceinline__ int sub(int lane) { return lane & 7; }
+    __device__ static __forceinline__ int patch(int) { return (int)(threadIdx.x >> 6); }
+    __device__ static __forceinline__ float view_sum(float v) {      /* all 8 lanes of the half row get the sum */
+        v = fadd_i(v, dpp_xor1(__float_as_int(v)));
+        v = fadd_i(v, dpp_xor2(__float_as_int(v)));
+        v = fadd_i(v, dpp_half_mirror(__float_as_int(v)));
+        return v;
+    }
+    __device__ static __forceinline__ double view_sum(double v) {
+        v += dmov(v, dpp_xor1);
+        v += dmov(v, dpp_xor2);
+        v += dmov(v, dpp_half_mirror);
+        return v;
+    }
+    __device__ static __forceinline__ bool view_all(bool p) {
+        int v = p ? 1 : 0;
+        v &= dpp_xor1(v); v &= dpp_xor2(v); v &= dpp_half_mirror(v);
+        return v != 0;
+    }
+    __device__ static __forceinline__ float rl(int i, int lane) { return __int_as_float(__builtin_amdgcn_readlane(i, lane)); }
+    __device__ static __forceinline__ float patch_sum(float v) {
+        const int i = __float_as_int(v);
+        return ((rl(i, 0) + rl(i, 8)) + (rl(i, 16) + rl(i, 24))) + ((rl(i, 32) + rl(i, 40)) + (rl(i, 48) + rl(i, 56)));
+    }
+    __device__ static __forceinline__ double rld(int hi, int lo, int lane) {
+        return __hiloint2double(__builtin_amdgcn_readlane(hi, lane), __builtin_amdgcn_readlane(lo, lane));
+    }
+    __device__ static __forceinline__ double patch_sum(double v) {
+        const int hi = __double2hiint(v), lo = __double2loint(v);
+        return ((rld(hi, lo, 0) + rld(hi, lo, 8)) + (rld(hi, lo, 16) + rld(hi, lo, 24)))
+             + ((rld(hi, lo, 32) + rld(hi, lo, 40)) + (rld(hi, lo, 48) + rld(hi, lo, 56)));
+    }
+    __device__ static __forceinline__ float wave_sum(float v) { return patch_sum(view_sum(v)); }
+    __device__ static __forceinline__ unsigned long long patch_or(unsigned long long v) {
+        int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+        lo |= __shfl_xor(lo, 8); lo |= __shfl_xor(lo, 16); lo |= __shfl_xor(lo, 32);
+        hi |= __shfl_xor(hi, 8); hi |= __shfl_xor(hi, 16); hi |= __shfl_xor(hi, 32);
+        return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    }
+    __device__ static __forceinline__ void from_views(int v, int, int* out) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = __builtin_amdgcn_readlane(v, 8 * k);
+    }
+    template <int S> __device__ static __forceinline__ int view_xor(int v) { return __shfl_xor(v, S == 0 ? 8 : S == 1 ? 16 : 32); }
+    __device__ static __forceinline__ unsigned view_ballot(bool p, int) {
+        const unsigned long long b = __ballot(p);
+        unsigned r = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r |= (unsigned)((b >> (8 * k)) & 1ull) << k;
+        return r;
+    }
+    __device__ static __forceinline__ unsigned rows_to_lane0(unsigned v) {
+        unsigned r = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += (unsigned)__builtin_amdgcn_readlane((int)v, 8 * k);
+        return r;
+    }
+};
+
+/* the latency layout that goes with a number of view slots */
+template <int NV> struct LatLay;
+template <> struct LatLay<4> { typedef Lay<16, 4> type; };
+template <> struct LatLay<8> { typedef Lay<8, 8> type; };
 
 /* ------------------------------------------------------------------------- */
 
@@ -250,7 +390,7 @@ struct PatchState {
     float mfp;                   /* footPrintScaled(centre point) at the current state */
     float inrm_c;                /* geo[MI_MID]: 1 / |K_s^-1 (x + .5, y + .5, 1)| of the centre pixel */
     float jinv0;                 /* invproj[0] of the reference level */
-    unsigned avail;              /* LocalViewSelection::available over global indices */
+    unsigned long long avail;    /* LocalViewSelection::available over global indices */
     /* per view slot */
     int sel;                     /* my view: index into job->global_ids, or -1 */
     float cs0, cs1, cs2;         /* PatchOptimization::colorScale[my view] */
@@ -376,24 +516,23 @@ struct GNSums {
 };
 
 /*
- * One pass over the 25 samples of my view (split over the LPV lanes of my view slot) at the current
+ * One pass over the 25 samples of my view (split over the L::LPV lanes of my view slot) at the current
  * patch state.  It always yields the colour sums that getFastNCC / computeColorScale need
  * (patch_sampler.cc:347-393,135-163; patch_optimization.cc:81-111), and in addition
  *   PASS_DEPTH  the colour-scale independent sums of optimizeDepthOnly (used when computeColorScale may
  *               still change the scale between this pass and the step: ctor, after a normal step),
  *   PASS_DEPTH_FIXED  optimizeDepthOnly's numerator / denominator directly (colour scale fixed until the step),
  *   PASS_NORMAL the normal equations of optimizeDepthAndNormal (with the current colour scale),
- *   PASS_DUMP   the raw samples (parity hook, LPV = 1).
+ *   PASS_DUMP   the raw samples (parity hook, L::LPV = 1).
  * The reference samples the same texels twice per Gauss-Newton iteration -- computeNeighColorSamples
  * on the new state, then fastColAndDeriv on that same state in the next iteration (patch_sampler.cc:64-133,
  * mvs_tools.cc:97-145); one fused pass here gathers them once.
  * Returns PatchSampler::success[v]; sums are complete (reduced over the view slot) on return.
  */
-template <int MODE, int LPV>
+template <int MODE, class L>
 __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& nv, const float* __restrict__ s_lut,
                                             const float* __restrict__ geo, const float* __restrict__ mcol,
                                             ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub) {
-    typedef Lay<LPV> L;
     float step = 0.f, dnorm = 0.f;
     bool ok = true;
     if (MODE != PASS_COLOR) {
@@ -423,12 +562,12 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     S.a0 = S.a1 = S.a2 = 0.f; S.aa0 = S.aa1 = S.aa2 = 0.f; S.ba0 = S.ba1 = S.ba2 = 0.f;
     float dr0 = 0.f, dr1 = 0.f, dr2 = 0.f, dn0 = 0.f, dn1 = 0.f, dn2 = 0.f, dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
     float num = 0.f, den = 0.f;
-    typedef typename NormalAcc<LPV>::type acc_t;
+    typedef typename NormalAcc<L::LPV>::type acc_t;
     acc_t A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, B0 = 0, B1 = 0, B2 = 0;
     /* per-channel colour sums are only needed when computeColorScale may follow this pass */
     constexpr bool PER_CHANNEL = (MODE == PASS_COLOR || MODE == PASS_DEPTH);
 
-    constexpr int NITER = (MI_NS + LPV - 1) / LPV;
+    constexpr int NITER = (MI_NS + L::LPV - 1) / L::LPV;
     /* A sample is handled in two steps so that texel gathers can be in flight while other samples are consumed:
      * geom() = geometry + the footprint gather, consume() = table look-ups, interpolation and the sums.
      *   latency layout (one wavefront per patch, nothing else to hide a gather behind): both samples of a lane are
@@ -437,8 +576,8 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     struct Pre { int i; bool live; float fx, fy, gu, gv; u32x4 t; };
     auto geom = [&](int it) -> Pre {
         Pre q;
-        const int iraw = sub + it * LPV;
-        q.live = iraw < MI_NS;                         /* LPV = 16: second trip only for lanes 0..8 */
+        const int iraw = sub + it * L::LPV;
+        q.live = iraw < MI_NS;                         /* L::LPV = 16: second trip only for lanes 0..8 */
         const int i = q.live ? iraw : (MI_NS - 1);
         q.i = i;
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
@@ -488,7 +627,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             n[c] = c00 + fx * d1 + fy * d2 + fxy * d3;
             if (MODE != PASS_COLOR) dr[c] = gu * d1 + gv * d2 + gm * d3;
         }
-        const float wgt = (LPV == 1 || q.live) ? 1.f : 0.f;   /* dead trips (LPV > 1 only) contribute nothing */
+        const float wgt = (L::LPV == 1 || q.live) ? 1.f : 0.f;   /* dead trips (L::LPV > 1 only) contribute nothing */
         const float m0 = mcol[3 * i], m1 = mcol[3 * i + 1], m2 = mcol[3 * i + 2];
         if (MODE == PASS_DUMP) {
             dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
@@ -525,7 +664,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             }
         }
     };
-    if (LPV == 1) {
+    if (L::LPV == 1) {
         /* a row of the window per gather round (5 x 5: its five footprint records are neighbours in memory, 1-2
          * cache lines fetched once, five gathers in flight) */
 #pragma unroll 1
@@ -582,14 +721,14 @@ __device__ __forceinline__ float ncc_from_sums(const PatchState& ps, const Color
 }
 
 /* Colour pass of view `gidx` (index into the job's global list) -> NCC; -1 on failure. */
-template <int LPV>
+template <class L>
 __device__ __forceinline__ float eval_color(PatchState& ps, const DevView* views, int gidx, const float* s_lut,
                                             const float* geo, const float* mcol, ColorSums& S, bool& ok, bool count, int sub) {
     NView nv; int level; GNSums gn;
     ok = false;
     if (gidx < 0) return -1.f;
     if (!setup_view(views, ps.job->gv[gidx], ps, nv, level)) return -1.f;
-    ok = sample_pass<PASS_COLOR, LPV>(ps, nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
+    ok = sample_pass<PASS_COLOR, L>(ps, nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
     ps.n_pass++;
     if (!ok) return -1.f;
     if (count) ps.n_eval++;
@@ -663,16 +802,15 @@ __device__ __forceinline__ void unit_cross(float ax, float ay, float az, float b
 
 /*
  * LocalViewSelection::performVS (local_view_selection.cc:56-147) for one patch.
- * Candidates (bits of ps.avail) are spread over the four view slots; NCCs go through g_ncc.
+ * Candidates (bits of ps.avail) are spread over the view slots of the patch; NCCs go through g_ncc.
  * On return each view slot's ps.sel holds its view (or -1); returns success.
  */
-template <int LPV>
+template <class L>
 __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSettings& st, const DevView* views, int lane) {
-    typedef Lay<LPV> L;
     const float* s_lut = g_lut;
-    const float* geo = lds_geo<LPV>(L::patch(lane));
-    const float* mcol = lds_mcol<LPV>(L::patch(lane));
-    float* s_ncc = lds_ncc<LPV>(L::patch(lane));
+    const float* geo = lds_geo<L>(L::patch(lane));
+    const float* mcol = lds_mcol<L>(L::patch(lane));
+    float* s_ncc = lds_ncc<L>(L::patch(lane));
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const int K = st.K;
     unsigned selmask = L::view_ballot(ps.sel >= 0, lane);
@@ -680,15 +818,15 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
     const DevJob* J = ps.job;
     const int G = J->n_global;
     /* NCC of every available candidate at the current state; drop those below minNCC */
-    unsigned drop = 0;
-    for (int g = slot; g < G; g += QUAD) {
-        if (!((ps.avail >> g) & 1u)) continue;
+    unsigned long long drop = 0;
+    for (int g = slot; g < G; g += L::NV) {
+        if (!((ps.avail >> g) & 1ull)) continue;
         ColorSums S; bool ok;
-        const float t = eval_color<LPV>(ps, views, g, s_lut, geo, mcol, S, ok, true, sub);
-        if (t < st.minNCC) drop |= 1u << g;
+        const float t = eval_color<L>(ps, views, g, s_lut, geo, mcol, S, ok, true, sub);
+        if (t < st.minNCC) drop |= 1ull << g;
         if (sub == 0) s_ncc[g] = t;
     }
-    drop = (unsigned)L::patch_or((int)drop);
+    drop = L::patch_or(drop);
     ps.avail &= ~drop;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
@@ -700,12 +838,11 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
         selmask = L::view_ballot(ps.sel >= 0, lane);
         if (__popc(selmask) >= K) break;
         /* the currently selected views, visible to every lane of the patch */
-        int sl[4];
-        sl[0] = L::template from_view<0>(ps.sel); sl[1] = L::template from_view<1>(ps.sel);
-        sl[2] = L::template from_view<2>(ps.sel); sl[3] = L::template from_view<3>(ps.sel);
+        int sl[L::NV];
+        L::from_views(ps.sel, lane, sl);
         float best = 0.f; int bestg = -1;
-        for (int g = slot; g < G; g += QUAD) {
-            if (!((ps.avail >> g) & 1u)) continue;
+        for (int g = slot; g < G; g += L::NV) {
+            if (!((ps.avail >> g) & 1ull)) continue;
             const DevJobView* V = &J->gv[g];
             float score = s_ncc[g];
             const float z = V->w2c_z[0] * p0x + V->w2c_z[1] * p0y + V->w2c_z[2] * p0z + V->w2c_z[3];
@@ -718,7 +855,7 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
             float ex, ey, ez;
             unit_cross(vx, vy, vz, rdx, rdy, rdz, ex, ey, ez);          /* epipolarPlane[i] */
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < L::NV; ++k) {
                 if (sl[k] < 0) continue;
                 const DevJobView* U = &J->gv[sl[k]];
                 float sx, sy, sz;
@@ -736,15 +873,15 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
             if (score > best) { best = score; bestg = g; }
         }
         /* arg-max over the view slots; ties -> lowest index (strict '>' in an ascending scan, :134-138) */
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const float ob = __int_as_float(r == 0 ? L::view_xor1(__float_as_int(best)) : L::view_xor2(__float_as_int(best)));
-            const int og = r == 0 ? L::view_xor1(bestg) : L::view_xor2(bestg);
+        auto merge = [&](float ob, int og) {
             const bool take = og >= 0 && (bestg < 0 || ob > best || (ob == best && og < bestg));
             if (take) { best = ob; bestg = og; }
-        }
+        };
+        merge(__int_as_float(L::template view_xor<0>(__float_as_int(best))), L::template view_xor<0>(bestg));
+        merge(__int_as_float(L::template view_xor<1>(__float_as_int(best))), L::template view_xor<1>(bestg));
+        if (L::NV == 8) merge(__int_as_float(L::template view_xor<2>(__float_as_int(best))), L::template view_xor<2>(bestg));
         if (bestg < 0) break;                                       /* foundOne == false */
-        ps.avail &= ~(1u << bestg);
+        ps.avail &= ~(1ull << bestg);
         /* give the view to the lowest free view slot */
         const unsigned freemask = ~selmask & ((1u << K) - 1u);
         const int target = __ffs(freemask) - 1;
@@ -761,33 +898,39 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
 
 /* true iff every selected view with a smaller id than mine sampled successfully
  * (computeColorScale returns at the first failing view; std::set iterates ascending ids) */
-template <int LPV>
-__device__ __forceinline__ bool lower_views_ok(const PatchState& ps, bool my_ok) {
-    typedef Lay<LPV> L;
-    int s[4]; int o[4];
-    const int mo = my_ok ? 1 : 0;
-    s[0] = L::template from_view<0>(ps.sel); s[1] = L::template from_view<1>(ps.sel);
-    s[2] = L::template from_view<2>(ps.sel); s[3] = L::template from_view<3>(ps.sel);
-    o[0] = L::template from_view<0>(mo); o[1] = L::template from_view<1>(mo);
-    o[2] = L::template from_view<2>(mo); o[3] = L::template from_view<3>(mo);
+template <class L>
+__device__ __forceinline__ bool lower_views_ok(const PatchState& ps, bool my_ok, int lane) {
+    int s[L::NV]; int o[L::NV];
+    L::from_views(ps.sel, lane, s);
+    L::from_views(my_ok ? 1 : 0, lane, o);
     bool all = true;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < L::NV; ++k)
         if (s[k] >= 0 && s[k] < ps.sel && !o[k]) all = false;
     return all;
 }
 
-struct PatchResult { float conf, depth, dzI, dzJ, nx, ny, nz; unsigned views; int iters; };
+struct PatchResult { float conf, depth, dzI, dzJ, nx, ny, nz; unsigned views, views_hi; int iters; };   /* views_hi: view slots 4..7 (eight-slot layouts) */
+
+/* a pixel's local view set from the state maps (slot `one`: the second state slot); the upper four of an eight-slot set
+ * live in their own map, which only exists for nrReconNeighbors > 4 */
+template <int NV>
+__device__ __forceinline__ unsigned long long load_view_set(const DevJob* job, bool one, int p) {
+    const unsigned lo = GU((one ? job->views1 : job->views) + p);
+    unsigned hi = 0xFFFFFFFFu;
+    if (NV == 8) hi = GU((one ? job->views1_hi : job->views_hi) + p);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long view_set(unsigned lo, unsigned hi) { return ((unsigned long long)hi << 32) | lo; }
 
 /* computeColorScale over the selected views from their colour sums (patch_optimization.cc:81-111):
  * ascending view order, stops at the first view whose sampling failed.  Returns false where the
  * reference sets optiSuccess = false. */
-template <int LPV>
+template <class L>
 __device__ __forceinline__ bool color_scale_step(PatchState& ps, const DevSettings& st, const ColorSums& S, bool okv, int lane) {
-    typedef Lay<LPV> L;
     if (!st.useColorScale) return true;
     const bool active = ps.sel >= 0;
-    const bool lower = lower_views_ok<LPV>(ps, okv || !active);
+    const bool lower = lower_views_ok<L>(ps, okv || !active, lane);
     bool good = true;
     if (active && okv && lower) good = color_scale_update(ps, S);
     return L::view_ballot(!good, lane) == 0;
@@ -825,17 +968,17 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
 }
 
 /* One fused pass of my view at the current state; sets ps.ncc (getFastNCC).  Returns success[v]. */
-template <int MODE, int LPV>
+template <int MODE, class L>
 __device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevView* views, const float* s_lut, const float* geo,
                                          const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int sub) {
     bool okv = true;
     ps.ncc = -1.f;
     if (MODE == PASS_NORMAL) gn.A00 = gn.A01 = gn.A02 = gn.A11 = gn.A12 = gn.A22 = gn.B0 = gn.B1 = gn.B2 = 0.0;
     /* the throughput layout has no registers to spare for the cache: set the view up per pass */
-    if (LPV == 1) viewc_reset(vc);
+    if (L::LPV == 1) viewc_reset(vc);
     if (ps.sel >= 0) {
         okv = view_prepare(ps, vc, views);
-        if (okv) okv = sample_pass<MODE, LPV>(ps, vc.nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
+        if (okv) okv = sample_pass<MODE, L>(ps, vc.nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
         ps.n_pass++;
         if (okv) {
             ps.ncc = ncc_from_sums(ps, S);
@@ -878,9 +1021,9 @@ __device__ __forceinline__ void pixel_ray(const DevJob* job, int x, int y, float
     wz = job->rot_t[6] * rx + job->rot_t[7] * ry + job->rot_t[8] * rz;
 }
 /* the unit-ray scales of the window's pixels into LDS (NView: g) */
-template <int LPV>
+template <class L>
 __device__ __forceinline__ void fill_geo(const DevJob* job, int x, int y, float* geo, int pl) {
-    for (int i = pl; i < MI_NS; i += 4 * LPV) {
+    for (int i = pl; i < MI_NS; i += L::NV * L::LPV) {
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         geo[i] = pixel_scale(job, x + di, y + dj);
     }
@@ -902,17 +1045,16 @@ __device__ __forceinline__ void patch_normal(const PatchState& ps, float& nx, fl
 }
 
 /* Returns false if the optimisation is over before it started (the result keeps confidence 0). */
-template <int LPV>
+template <class L>
 __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
-                                          float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane, unsigned& err,
+                                          float depth0, float dzI0, float dzJ0, unsigned long long hyp_views, int lane, unsigned& err,
                                           DevCounters* counters) {
-    typedef Lay<LPV> L;
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
-    float* geo = lds_geo<LPV>(L::patch(lane));
-    float* mcol = lds_mcol<LPV>(L::patch(lane));
+    float* geo = lds_geo<L>(L::patch(lane));
+    float* mcol = lds_mcol<L>(L::patch(lane));
     const int slot = L::vslot(lane), sub = L::sub(lane);
-    const int pl = slot * LPV + sub;                 /* lane index inside the patch */
+    const int pl = slot * L::LPV + sub;                 /* lane index inside the patch */
     ps.job = job; ps.x = x; ps.y = y; ps.n_eval = 0; ps.n_pass = 0; ps.counters = counters;
     ps.sel = -1; ps.cs0 = ps.cs1 = ps.cs2 = 1.f; ps.ncc = -1.f;
     ps.depth = depth0; ps.dzI = dzI0; ps.dzJ = dzJ0;
@@ -923,21 +1065,21 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     if (x - MI_HALF < 0 || y - MI_HALF < 0 || x + MI_HALF > job->w - 1 || y + MI_HALF > job->h - 1) return false;
     ps.jinv0 = job->inv0_s;
     ps.inrm_c = pixel_scale(job, x, y);
-    fill_geo<LPV>(job, x, y, geo, pl);
+    fill_geo<L>(job, x, y, geo, pl);
     /* raw master colours */
     const DevView* RV = views + job->ref_view;
     const DevLevel& RL = RV->lv[job->scale];
     const uint32_t* rimg = RV->img + RL.tex_off;
-    float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;       /* LPV = 16: my sample's raw master colour */
-    for (int i = pl; i < MI_NS; i += 4 * LPV) {
+    float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;       /* L::LPV = 16: my sample's raw master colour */
+    for (int i = pl; i < MI_NS; i += L::NV * L::LPV) {
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const uint32_t t = GU(rimg + (size_t)(y + dj) * RL.w + (x + di));
         raw0 = s_lut[t & 255u]; raw1 = s_lut[(t >> 8) & 255u]; raw2 = s_lut[(t >> 16) & 255u];
-        if (LPV != 16) { mcol[3 * i] = raw0; mcol[3 * i + 1] = raw1; mcol[3 * i + 2] = raw2; }
+        if (!L::LAT) { mcol[3 * i] = raw0; mcol[3 * i + 1] = raw1; mcol[3 * i + 2] = raw2; }
     }
     /* computeMasterSamples (patch_sampler.cc:297-345) */
     float mm, x0, x1, x2, sd;
-    if (LPV != 16) {
+    if (!L::LAT) {
         /* every lane of the patch redundantly, in the reference's summation order */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         mm = 0.f;
@@ -945,7 +1087,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
         mm /= 3.f * (float)MI_NS;
         if (mm < 0.01f || mm > 0.99f) return false;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int i = pl; i < MI_NS; i += 4 * LPV) { mcol[3 * i] /= mm; mcol[3 * i + 1] /= mm; mcol[3 * i + 2] /= mm; }
+        for (int i = pl; i < MI_NS; i += L::NV * L::LPV) { mcol[3 * i] /= mm; mcol[3 * i + 1] /= mm; mcol[3 * i + 2] /= mm; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         x0 = 0.f; x1 = 0.f; x2 = 0.f;
         for (int i = 0; i < MI_NS; ++i) { x0 += mcol[3 * i]; x1 += mcol[3 * i + 1]; x2 += mcol[3 * i + 2]; }
@@ -983,13 +1125,13 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
 
     TSTAMP(11);
     /* --- LocalViewSelection ctor (local_view_selection.cc:19-54) */
-    ps.avail = job->n_global >= 32 ? 0xFFFFFFFFu : ((1u << job->n_global) - 1u);
+    ps.avail = job->n_global >= 64 ? ~0ull : ((1ull << job->n_global) - 1ull);
     {
         int nprop = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned g = (hyp_views >> (8 * k)) & 0xFFu;
-            if (g != MI_VIEW_NONE) { ++nprop; ps.avail &= ~(1u << g); if (k == slot) ps.sel = (int)g; }
+        for (int k = 0; k < L::NV; ++k) {
+            const unsigned g = (unsigned)(hyp_views >> (8 * k)) & 0xFFu;
+            if (g != MI_VIEW_NONE) { ++nprop; ps.avail &= ~(1ull << g); if (k == slot) ps.sel = (int)g; }
         }
         if (nprop > st.K) { ps.sel = -1; }          /* "Too many local neighbors propagated" */
         if (slot >= st.K) ps.sel = -1;
@@ -1008,13 +1150,12 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
  * fused pass at the current state (colour sums + the Gauss-Newton sums the NEXT step needs), finish the
  * decision of the step that led here, take the next step.  Returns false when the optimisation is over.
  */
-template <int LPV>
+template <class L>
 __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const DevView* views, int lane) {
-    typedef Lay<LPV> L;
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
-    const float* geo = lds_geo<LPV>(L::patch(lane));
-    const float* mcol = lds_mcol<LPV>(L::patch(lane));
+    const float* geo = lds_geo<L>(L::patch(lane));
+    const float* mcol = lds_mcol<L>(L::patch(lane));
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const bool active = slot < st.K;               /* view slots 0..K-1 carry a view once the selection succeeded */
     /* the sums of a pass are consumed within the same turn */
@@ -1022,23 +1163,23 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
     if (R.need_vs) {
         R.need_vs = false;
-        if (!local_view_selection<LPV>(ps, st, views, lane)) { R.opti = false; return false; }
+        if (!local_view_selection<L>(ps, st, views, lane)) { R.opti = false; return false; }
     }
     bool okv;
     TSTAMP(20 + R.need);
-    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, LPV>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
-    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, LPV>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
-    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, LPV>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
-    else okv = run_pass<PASS_COLOR, LPV>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    else okv = run_pass<PASS_COLOR, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
     TSTAMP(30);
     /* ---- finish what led to this pass */
     if (R.ctx == CTX_CTOR || R.ctx == CTX_REPLACED) {
         /* computeColorScale() at the end of the ctor (:77) / after replaceViews (:231) */
-        if (!color_scale_step<LPV>(ps, st, S, okv, lane)) { R.opti = false; return false; }
+        if (!color_scale_step<L>(ps, st, S, okv, lane)) { R.opti = false; return false; }
     } else if (R.ctx == CTX_STEP) {
         if (R.step_was_normal) {
             /* optimizeDepthAndNormal is followed by computeColorScale on the new state (:197-199) */
-            if (!color_scale_step<LPV>(ps, st, S, okv, lane)) { R.opti = false; return false; }
+            if (!color_scale_step<L>(ps, st, S, okv, lane)) { R.opti = false; return false; }
         }
         /* convergence / view replacement (:207-239) */
         const float dn = fabsf(ps.ncc - R.oldncc);
@@ -1126,46 +1267,55 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     return true;
 }
 
-template <int LPV>
+template <class L>
 __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane, PatchResult& res,
                                         unsigned& n_eval, unsigned& n_pass) {
-    typedef Lay<LPV> L;
     PatchState& ps = R.ps;
     n_eval += ps.n_eval; n_pass += ps.n_pass;
     res.conf = 0.f; res.nx = res.ny = res.nz = 0.f;
     res.iters = R.iter;
     res.depth = ps.depth; res.dzI = ps.dzI; res.dzJ = ps.dzJ;
     /* local view ids, ascending (std::set order) */
-    int s[4];
-    s[0] = L::template from_view<0>(ps.sel); s[1] = L::template from_view<1>(ps.sel);
-    s[2] = L::template from_view<2>(ps.sel); s[3] = L::template from_view<3>(ps.sel);
+    constexpr int NV = L::NV;
+    int s[NV];
+    L::from_views(ps.sel, lane, s);
     {
-        int t[4] = {s[0], s[1], s[2], s[3]};
+        int t[NV];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < NV; ++k) t[k] = s[k];
 #pragma unroll
-            for (int b = 0; b < 3 - a; ++b) {
+        for (int a = 0; a < NV - 1; ++a)
+#pragma unroll
+            for (int b = 0; b < NV - 1 - a; ++b) {
                 const unsigned ua = t[b] < 0 ? 0xFFFu : (unsigned)t[b], ub = t[b + 1] < 0 ? 0xFFFu : (unsigned)t[b + 1];
                 if (ua > ub) { const int tmp = t[b]; t[b] = t[b + 1]; t[b + 1] = tmp; }
             }
-        unsigned packed = 0;
+        unsigned packed = 0, packed_hi = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < 4; ++k) packed |= (t[k] < 0 ? MI_VIEW_NONE : (unsigned)t[k]) << (8 * k);
-        res.views = packed;
+        if (NV == 8) {
+            packed_hi = 0;
+#pragma unroll
+            for (int k = 4; k < NV; ++k) packed_hi |= (t[k] < 0 ? MI_VIEW_NONE : (unsigned)t[k]) << (8 * (k - 4));
+        }
+        res.views = packed; res.views_hi = packed_hi;
     }
     if (!R.converged) return;
     /* --- computeConfidence (patch_optimization.cc:114-142): NCCs summed in ascending view order */
-    float c[4];
-    const int ni = __float_as_int(ps.ncc);
-    c[0] = __int_as_float(L::template from_view<0>(ni)); c[1] = __int_as_float(L::template from_view<1>(ni));
-    c[2] = __int_as_float(L::template from_view<2>(ni)); c[3] = __int_as_float(L::template from_view<3>(ni));
+    float c[NV];
+    {
+        int ci[NV];
+        L::from_views(__float_as_int(ps.ncc), lane, ci);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) c[k] = __int_as_float(ci[k]);
+    }
     float mean = 0.f; int cnt = 0;
     unsigned used = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NV; ++r) {
         int bi = -1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < NV; ++k)
             if (s[k] >= 0 && !((used >> k) & 1u) && (bi < 0 || s[k] < s[bi])) bi = k;
         if (bi >= 0) { used |= 1u << bi; mean += c[bi]; ++cnt; }
     }
@@ -1179,16 +1329,16 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
     TSTAMP(41);
 }
 
-template <int LPV>
+template <class L>
 __device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
-                               float depth0, float dzI0, float dzJ0, unsigned hyp_views, int lane,
+                               float depth0, float dzI0, float dzJ0, unsigned long long hyp_views, int lane,
                                PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err, DevCounters* counters) {
     Run R;
     TSTAMP(10);
-    if (run_begin<LPV>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
-        while (run_turn<LPV>(R, st, views, lane)) { }
+    if (run_begin<L>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
+        while (run_turn<L>(R, st, views, lane)) { }
     TSTAMP(40);
-    run_end<LPV>(R, st, lane, res, n_eval, n_pass);
+    run_end<L>(R, st, lane, res, n_eval, n_pass);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1225,10 +1375,9 @@ struct OptArgs {
  * candidates are re-read from the state, which a host-visible round does not write -- k_apply does).
  * Returns true if the pixel state must be overwritten.
  */
-template <int LPV>
+template <class L>
 __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, const DevJob* job, int x, int y, int lane,
                                               unsigned& n_eval, unsigned& n_pass, unsigned& n_patch, unsigned& err, bool& more) {
-    typedef Lay<LPV> L;
     const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
     const bool explicit_hyp = a.hyp != nullptr;
     const bool resume = a.follow_in != nullptr;
@@ -1246,17 +1395,17 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
     } else if (writer) {
         DevResult z;
         z.conf = 0.f; z.depth = 0.f; z.dzI = z.dzJ = 0.f; z.nx = z.ny = z.nz = 0.f;
-        z.views = 0xFFFFFFFFu; z.iters = 0; z.accepted = 0; z.tried = 0;
+        z.views = 0xFFFFFFFFu; z.views_hi = 0xFFFFFFFFu; z.iters = 0; z.accepted = 0; z.tried = 0;
         a.results[e] = z;
     }
     more = false;
     int attempts = 0;
     for (int t = 0; t < 4; ++t) {
-        float hd, hi, hj; unsigned hv;
+        float hd, hi, hj; unsigned long long hv;
         if (explicit_hyp) {
             if (t > 0) break;
             const DevHyp h = a.hyp[e];
-            hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = h.views;
+            hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = view_set(h.views, h.views_hi);
         } else {
             const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
             int bi = -1; float bc = 0.f;
@@ -1277,10 +1426,10 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
             tried |= 1u << bi;
             if (best > bc) continue;                           /* dmrecon.cc:371 */
             const int p = nb[bi];
-            hd = GF(job->depth + p); hi = GF(job->dz + 2 * p); hj = GF(job->dz + 2 * p + 1); hv = GU(job->views + p);
+            hd = GF(job->depth + p); hi = GF(job->dz + 2 * p); hj = GF(job->dz + 2 * p + 1); hv = load_view_set<L::NV>(job, false, p);
         }
         PatchResult r;
-        optimize_patch<LPV>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters);
+        optimize_patch<L>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters);
         ++n_patch; ++attempts;
         const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
         if (accept) {
@@ -1289,7 +1438,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
             if (writer) {
                 DevResult o;
                 o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ;
-                o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.iters = r.iters;
+                o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.views_hi = r.views_hi; o.iters = r.iters;
                 o.accepted = accepted ? 1 : 0; o.tried = tried;
                 a.results[e] = o;
             }
@@ -1301,10 +1450,9 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
 
 /* flush counters: one atomic per wave (per-view counters live in the first lane of each view slot,
  * the patch counter in the first lane of each patch) */
-template <int LPV>
+template <class L>
 __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, unsigned n_eval, unsigned n_pass,
                                                unsigned n_patch, unsigned n_filled, unsigned err) {
-    typedef Lay<LPV> L;
     if (L::sub(lane) != 0) { n_eval = 0; n_pass = 0; }
     if (L::vslot(lane) != 0 || L::sub(lane) != 0) { n_patch = 0; n_filled = 0; }
     for (int off = 32; off > 0; off >>= 1) {
@@ -1324,12 +1472,11 @@ __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, 
 }
 
 /*
- * The hot kernel.  LPV = 1: 16 patches per wavefront (throughput); LPV = 16: one patch per
+ * The hot kernel.  L::LPV = 1: 16 patches per wavefront (throughput); L::LPV = 16: one patch per
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
  */
-template <int LPV>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((LPV == 16 ? 2 : MI_BULK_WAVES), (LPV == 16 ? 2 : MI_WAVES_PER_SIMD)))) void k_optimize(OptArgs a) {
-    typedef Lay<LPV> L;
+template <class L>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 2 : MI_BULK_WAVES), (L::LAT ? 2 : MI_WAVES_PER_SIMD)))) void k_optimize(OptArgs a) {
     const int lane = threadIdx.x;
     const unsigned n = a.follow_in ? *a.follow_in_n : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
     if (n < a.min_work || n >= a.max_work) return;
@@ -1345,7 +1492,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((LPV == 16
             /* the view failed (footprint exception) or was cancelled: nothing of it is touched any more */
             if (L::vslot(lane) == 0 && L::sub(lane) == 0) a.results[e].accepted = 0;
         } else
-            process_entry<LPV>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
+            process_entry<L>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
         if (a.follow_out) {
             /* wave-aggregated append of the entries that still have candidates (one atomic per wavefront) */
             const bool mine = more && L::vslot(lane) == 0 && L::sub(lane) == 0;
@@ -1359,7 +1506,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((LPV == 16
             }
         }
     }
-    flush_counters<LPV>(a.counters, lane, n_eval, n_pass, n_patch, 0u, err);
+    flush_counters<L>(a.counters, lane, n_eval, n_pass, n_patch, 0u, err);
 }
 
 /*
@@ -1409,8 +1556,9 @@ __device__ __forceinline__ Frozen frozen_state(const DevJob* job, int p, int rou
 struct TailRes { PatchResult r; unsigned n_eval, n_pass; };
 __shared__ TailRes g_tail_res[MI_TAIL_WAVES];
 
-template <bool SPEC>
+template <bool SPEC, int NV>
 __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((amdgpu_waves_per_eu((SPEC ? MI_TAIL_SPEC_WAVES : (MI_FW == 7 ? 2 : MI_WAVES_PER_SIMD)), (SPEC ? MI_TAIL_SPEC_WAVES : MI_WAVES_PER_SIMD)))) void k_tail(TailArgs t) {
+    typedef typename LatLay<NV>::type LL;
     const OptArgs& a = t.o;
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const unsigned n_prev = t.round_work[a.round - 1];
@@ -1471,19 +1619,19 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
         if (n_cand == 0 || dir_of(0) != mine) continue;                        /* the workgroup of q's best source does q */
         /* hypothesis of q's rank-s candidate = its source's result (rank 0: the previous round's record in hand;
          * the others: their source's frozen state) */
-        auto hypothesis = [&](int s, float& hd, float& hi, float& hj, unsigned& hv) {
-            hd = pr.depth; hi = pr.dzI; hj = pr.dzJ; hv = pr.views;
+        auto hypothesis = [&](int s, float& hd, float& hi, float& hj, unsigned long long& hv) {
+            hd = pr.depth; hi = pr.dzI; hj = pr.dzJ; hv = view_set(pr.views, pr.views_hi);
             if (s > 0) {
                 const int j = dir_of(s);
                 const int p = j == 0 ? nb[0] : j == 1 ? nb[1] : j == 2 ? nb[2] : nb[3];
                 const bool one = j == 0 ? nf[0].one : j == 1 ? nf[1].one : j == 2 ? nf[2].one : nf[3].one;
                 hd = GF((one ? job->depth1 : job->depth) + p);
                 hi = GF((one ? job->dz1 : job->dz) + 2 * p); hj = GF((one ? job->dz1 : job->dz) + 2 * p + 1);
-                hv = GU((one ? job->views1 : job->views) + p);
+                hv = load_view_set<NV>(job, one, p);
             }
         };
         auto attempt = [&](int s, PatchResult& r, unsigned& ce, unsigned& cp) {
-            float hd, hi, hj; unsigned hv;
+            float hd, hi, hj; unsigned long long hv;
             hypothesis(s, hd, hi, hj, hv);
             if (!lut_ready) {
                 for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
@@ -1491,17 +1639,14 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
                 lut_ready = true;
             }
             ce = 0; cp = 0;
-            optimize_patch<16>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
+            optimize_patch<LL>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
             /* counters of optimize_patch are per view slot (row leaders): bring them to lane 0 */
-            ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
-                          + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
-            cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
-                          + __builtin_amdgcn_readlane((int)cp, 32) + __builtin_amdgcn_readlane((int)cp, 48));
+            ce = LL::rows_to_lane0(ce); cp = LL::rows_to_lane0(cp);
         };
         float best = own;
         bool accepted = false;
         PatchResult fin;
-        fin.conf = 0.f; fin.depth = fin.dzI = fin.dzJ = fin.nx = fin.ny = fin.nz = 0.f; fin.views = 0xFFFFFFFFu; fin.iters = 0;
+        fin.conf = 0.f; fin.depth = fin.dzI = fin.dzJ = fin.nx = fin.ny = fin.nz = 0.f; fin.views = 0xFFFFFFFFu; fin.views_hi = 0xFFFFFFFFu; fin.iters = 0;
         unsigned done = 0;
         if (SPEC) {
             const bool active = wave < n_cand;
@@ -1543,7 +1688,7 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
                 const_cast<DevEntry*>(a.work)[e] = we;
                 DevResult o;
                 o.conf = fin.conf; o.depth = fin.depth; o.dzI = fin.dzI; o.dzJ = fin.dzJ;
-                o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.iters = fin.iters;
+                o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.views_hi = fin.views_hi; o.iters = fin.iters;
                 o.accepted = 1; o.tried = done;
                 a.results[e] = o;
                 const bool one = me.one;                                       /* slot holding the old state */
@@ -1553,6 +1698,7 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
                 dp[q] = fin.depth; zp[2 * q] = fin.dzI; zp[2 * q + 1] = fin.dzJ;
                 np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
                 cq[q] = fin.conf; vp[q] = fin.views; up[q] = a.round;
+                if (NV == 8) (one ? job->views_hi : job->views1_hi)[q] = fin.views_hi;
                 if (own <= 0.f) { ++n_filled; atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u); }
             }
         }
@@ -1617,7 +1763,7 @@ struct FQ {                       /* a pixel this round may rewrite */
     unsigned info;                /* 0..7: direction of the rank-s source (2 bits each), 8..10: candidates, 11: slot of my frozen
                                    * state, 12..15: slot of my neighbours' frozen state */
     float nconf[4];               /* frozen confidence of my four neighbours */
-    float hd, hi, hj; unsigned hv;   /* the rank-0 hypothesis: the best source's result of the previous round */
+    float hd, hi, hj; unsigned hv, hv_hi;   /* the rank-0 hypothesis: the best source's result of the previous round */
     float best; int fin;          /* sequential rule so far: best confidence, rank of the accepted result (-1: none) */
     unsigned done; int next;      /* directions consumed; next rank to consume (= candidates: finished) */
 };
@@ -1628,7 +1774,9 @@ __shared__ unsigned g_fatt[MI_FRONT_QCAP * 4];
 __shared__ unsigned g_fcnt[8];    /* 0: FQs, 1: attempts of the pass, 2: attempts taken, 3: entries of the next list, 4: sum of candidates,
                                    * 5: newly filled pixels of the round */
 
+template <int NV>
 __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(MI_FRONT_WAVES / 4, MI_FRONT_WAVES / 4))) void k_front(FrontArgs t) {
+    typedef typename LatLay<NV>::type LL;
     const OptArgs& a = t.o;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int jobi = blockIdx.x;
@@ -1695,7 +1843,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                             Q.info = order | ((unsigned)n_cand << 8) | (me.one ? 1u << 11 : 0u)
                                    | (nf[0].one ? 1u << 12 : 0u) | (nf[1].one ? 1u << 13 : 0u) | (nf[2].one ? 1u << 14 : 0u) | (nf[3].one ? 1u << 15 : 0u);
                             Q.nconf[0] = nf[0].conf; Q.nconf[1] = nf[1].conf; Q.nconf[2] = nf[2].conf; Q.nconf[3] = nf[3].conf;
-                            Q.hd = GF(&pr->depth); Q.hi = GF(&pr->dzI); Q.hj = GF(&pr->dzJ); Q.hv = GU(&pr->views);
+                            Q.hd = GF(&pr->depth); Q.hi = GF(&pr->dzI); Q.hj = GF(&pr->dzJ); Q.hv = GU(&pr->views); Q.hv_hi = GU(&pr->views_hi);
                             Q.best = own; Q.fin = -1; Q.done = 0; Q.next = 0;
                             g_fq[qi] = Q;
                             g_fr[qi][0].ready = 0; g_fr[qi][1].ready = 0; g_fr[qi][2].ready = 0; g_fr[qi][3].ready = 0;
@@ -1727,7 +1875,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                     const int qi = (int)(att & 0xFFFFu), s = (int)(att >> 16);
                     const FQ& Q = g_fq[qi];
                     const int qx = Q.xy & 0xFFFF, qy = Q.xy >> 16;
-                    float hd = Q.hd, hi = Q.hi, hj = Q.hj; unsigned hv = Q.hv;
+                    float hd = Q.hd, hi = Q.hi, hj = Q.hj; unsigned long long hv = view_set(Q.hv, Q.hv_hi);
                     if (s > 0) {
                         /* a later candidate's hypothesis = its source's frozen state */
                         const int j = (int)((Q.info >> (2 * s)) & 3u);
@@ -1736,7 +1884,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                         const bool one = ((Q.info >> (12 + j)) & 1u) != 0;
                         hd = GF((one ? job->depth1 : job->depth) + p);
                         hi = GF((one ? job->dz1 : job->dz) + 2 * p); hj = GF((one ? job->dz1 : job->dz) + 2 * p + 1);
-                        hv = GU((one ? job->views1 : job->views) + p);
+                        hv = load_view_set<NV>(job, one, p);
                     }
                     PatchResult r; unsigned ce = 0, cp = 0;
 #ifdef MI_PROBE
@@ -1744,7 +1892,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                     const unsigned long long rt0 = wall_clock64();
                     TSTAMP(1);
 #endif
-                    optimize_patch<16>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
+                    optimize_patch<LL>(job, a.st, a.views, qx, qy, hd, hi, hj, hv, lane, r, ce, cp, err, a.counters);
 #ifdef MI_PROBE
                     TSTAMP(2);
                     if (lane == 0 && a.tbuf) {
@@ -1759,10 +1907,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                         }
                     }
 #endif
-                    ce = (unsigned)(__builtin_amdgcn_readlane((int)ce, 0) + __builtin_amdgcn_readlane((int)ce, 16)
-                                  + __builtin_amdgcn_readlane((int)ce, 32) + __builtin_amdgcn_readlane((int)ce, 48));
-                    cp = (unsigned)(__builtin_amdgcn_readlane((int)cp, 0) + __builtin_amdgcn_readlane((int)cp, 16)
-                                  + __builtin_amdgcn_readlane((int)cp, 32) + __builtin_amdgcn_readlane((int)cp, 48));
+                    ce = LL::rows_to_lane0(ce); cp = LL::rows_to_lane0(cp);
                     if (lane == 0) { FR& o = g_fr[qi][s]; o.r = r; o.n_eval = ce; o.n_pass = cp; o.ready = 1; ++st_att; }
                 }
                 __syncthreads();
@@ -1802,7 +1947,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                     ow[en] = we;
                     DevResult o;
                     o.conf = fin.conf; o.depth = fin.depth; o.dzI = fin.dzI; o.dzJ = fin.dzJ;
-                    o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.iters = fin.iters;
+                    o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.views_hi = fin.views_hi; o.iters = fin.iters;
                     o.accepted = 1; o.tried = Q.done;
                     ors[en] = o;
                     const bool one = ((Q.info >> 11) & 1u) != 0;                       /* slot holding the old state */
@@ -1812,6 +1957,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                     dp[q] = fin.depth; zp[2 * q] = fin.dzI; zp[2 * q + 1] = fin.dzJ;
                     np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
                     cq[q] = fin.conf; vp[q] = fin.views; up[q] = round;
+                    if (NV == 8) (one ? job->views_hi : job->views1_hi)[q] = fin.views_hi;
                     if (Q.own <= 0.f) { ++n_filled; atomicAdd(&g_fcnt[5], 1u); }
                 }
             }
@@ -1864,6 +2010,7 @@ __global__ __launch_bounds__(256) void k_front_split(FrontSplitArgs a) {
 struct FlattenArgs {
     float* depth; float* dz; float* conf; float* normal; uint32_t* views; int32_t* upd;
     const float* depth1; const float* dz1; const float* conf1; const float* normal1; const uint32_t* views1; const int32_t* upd1;
+    uint32_t* views_hi; const uint32_t* views1_hi;      /* null unless nrReconNeighbors > 4 */
     unsigned n;
 };
 __global__ __launch_bounds__(256) void k_flatten(FlattenArgs a) {
@@ -1874,6 +2021,7 @@ __global__ __launch_bounds__(256) void k_flatten(FlattenArgs a) {
     a.depth[p] = a.depth1[p]; a.dz[2 * p] = a.dz1[2 * p]; a.dz[2 * p + 1] = a.dz1[2 * p + 1];
     a.normal[3 * p] = a.normal1[3 * p]; a.normal[3 * p + 1] = a.normal1[3 * p + 1]; a.normal[3 * p + 2] = a.normal1[3 * p + 2];
     a.conf[p] = a.conf1[p]; a.views[p] = a.views1[p]; a.upd[p] = s1;
+    if (a.views_hi) a.views_hi[p] = a.views1_hi[p];
 }
 
 /* Parity hook: one hypothesis against every global view; one quad lane per 4 views. */
@@ -1933,11 +2081,11 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
     if (lane < job->n_global) {
         const int g = lane;
         ColorSums S; bool okc;
-        const float ncc = eval_color<1>(ps, a.views, g, s_lut, s_geo, s_mcol, S, okc, true, 0);
+        const float ncc = eval_color<Lay<1, 4> >(ps, a.views, g, s_lut, s_geo, s_mcol, S, okc, true, 0);
         a.ncc[g] = ncc;
         NView nv; int level = -1; GNSums gn;
         bool okd = setup_view(a.views, job->gv[g], ps, nv, level)
-            && sample_pass<PASS_DUMP, 1>(ps, nv, s_lut, s_geo, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0);
+            && sample_pass<PASS_DUMP, Lay<1, 4> >(ps, nv, s_lut, s_geo, s_mcol, S, gn, a.col + g * 3 * MI_NS, a.deriv + g * 3 * MI_NS, 0);
         a.ok[g] = okd ? 1 : 0;
         a.level[g] = level;
     }
@@ -2037,6 +2185,7 @@ __device__ __forceinline__ void write_pixel(const DevJob* job, int pix, const De
     job->normal[3 * pix] = r.nx; job->normal[3 * pix + 1] = r.ny; job->normal[3 * pix + 2] = r.nz;
     job->conf[pix] = r.conf;
     job->views[pix] = r.views;
+    if (job->views_hi) job->views_hi[pix] = r.views_hi;
     job->upd[pix] = round;
 }
 
@@ -2201,8 +2350,15 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
     a.max_attempts = follow_out ? 1 : 4; a.follow_in = follow_in; a.follow_in_n = follow_in_n;
     a.follow_out = follow_out; a.follow_out_n = follow_out_n;
-    if (lanes_per_view == 16) hipLaunchKernelGGL((k_optimize<16>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
-    else hipLaunchKernelGGL((k_optimize<1>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    /* lanes_per_view: 1 = throughput layout, anything else = latency layout; st.K > 4: the eight-slot layouts */
+    const bool lat = lanes_per_view != 1, eight = st.K > 4;
+    if (lat) {
+        if (eight) hipLaunchKernelGGL((k_optimize<Lay<8, 8> >), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<16, 4> >), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    } else {
+        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8> >), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<1, 4> >), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    }
 }
 
 static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
@@ -2242,8 +2398,13 @@ static void launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs,
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
-    if (speculative) hipLaunchKernelGGL((k_tail<true>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
-    else hipLaunchKernelGGL((k_tail<false>), dim3(grid_blocks), dim3(WAVE), 0, s, t);
+    if (st.K > 4) {
+        if (speculative) hipLaunchKernelGGL((k_tail<true, 8>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
+        else hipLaunchKernelGGL((k_tail<false, 8>), dim3(grid_blocks), dim3(WAVE), 0, s, t);
+    } else {
+        if (speculative) hipLaunchKernelGGL((k_tail<true, 4>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
+        else hipLaunchKernelGGL((k_tail<false, 4>), dim3(grid_blocks), dim3(WAVE), 0, s, t);
+    }
 }
 
 static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const DevView* views, const float* lut, const DevSettings& st,
@@ -2263,11 +2424,12 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.work[0] = work0; t.work[1] = work1; t.results[0] = results0; t.results[1] = results1;
     t.job_off = job_off; t.job_count = job_count; t.job_stats = job_stats; t.max_rounds = max_rounds;
-    hipLaunchKernelGGL(k_front, dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
+    if (st.K > 4) hipLaunchKernelGGL((k_front<8>), dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
+    else hipLaunchKernelGGL((k_front<4>), dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
 }
 
 #if MI_FW == 5
-void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px) {
+void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px, bool eight_views) {
     if (total_px == 0) return;
     FlattenArgs a;
     a.depth = maps; a.conf = maps + total_px; a.dz = maps + 2 * total_px; a.normal = maps + 4 * total_px;
@@ -2275,6 +2437,7 @@ void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total
     a.depth1 = m1; a.conf1 = m1 + total_px; a.dz1 = m1 + 2 * total_px; a.normal1 = m1 + 4 * total_px;
     a.views = imaps; a.upd = (int32_t*)(imaps + total_px);
     a.views1 = imaps + 2 * total_px; a.upd1 = (const int32_t*)(imaps + 3 * total_px);
+    a.views_hi = eight_views ? imaps + 4 * total_px : nullptr; a.views1_hi = eight_views ? imaps + 5 * total_px : nullptr;
     a.n = (unsigned)total_px;
     hipLaunchKernelGGL(k_flatten, dim3((unsigned)((total_px + 255) / 256)), dim3(256), 0, s, a);
 }

@@ -705,7 +705,7 @@ void plan_seeds(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost& job, 
         int const y = (int)mround(sy / sz - 0.5f);
         if (x < 0 || y < 0 || x >= L.w || y >= L.h) continue;              /* the sampler's border test fails anyway */
         DevEntry e; e.job = job_index; e.xy = x | (y << 16);
-        DevHyp h; h.depth = norm3(sub(p, R.pos())); h.dzI = 0.f; h.dzJ = 0.f; h.views = 0xFFFFFFFFu;
+        DevHyp h; h.depth = norm3(sub(p, R.pos())); h.dzI = 0.f; h.dzJ = 0.f; h.views = 0xFFFFFFFFu; h.views_hi = 0xFFFFFFFFu;
         job.seeds.push_back(e);
         job.seed_hyp.push_back(h);
     }
@@ -749,6 +749,9 @@ void fill_job(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost const& j
     }
 }
 
+/* patches per wavefront of the throughput layout: a quad per patch, or an octet for nrReconNeighbors > 4 */
+unsigned patches_per_wave(const mi_dmrecon_settings* st) { return st->nrReconNeighbors > 4 ? 8u : (unsigned)MI_PATCHES_PER_WAVE; }
+
 DevSettings dev_settings(const mi_dmrecon_settings* st) {
     DevSettings d;
     d.minNCC = st->minNCC; d.minParallax = st->minParallax; d.acceptNCC = st->acceptNCC;
@@ -758,12 +761,14 @@ DevSettings dev_settings(const mi_dmrecon_settings* st) {
 }
 
 /* Lays the per-pixel state maps of a batch out in the two map buffers and points the jobs at them. */
-int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px) {
+int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px, bool eight_views) {
     total_px = 0;
     for (size_t j = 0; j < jobs.size(); ++j) { jobs[j].pix_off = total_px; total_px += (size_t)jobs[j].w * jobs[j].h; }
-    /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd + views1, upd1 */
+    /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd + views1, upd1 (+ views_hi,
+     * views1_hi: view slots 4..7 of a set, nrReconNeighbors > 4) */
+    const size_t n_imaps = eight_views ? 6 : 4;
     if (c->d_maps.reserve(total_px * 14)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
-    if (c->d_imaps.reserve(total_px * 4)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
+    if (c->d_imaps.reserve(total_px * n_imaps)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
     float* base = c->d_maps.p;
     float* base1 = base + 7 * total_px;
     uint32_t* ibase = c->d_imaps.p;
@@ -781,10 +786,12 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
         dj[j].normal1 = base1 + 4 * total_px + 3 * o;
         dj[j].views1 = ibase + 2 * total_px + o;
         dj[j].upd1 = (int32_t*)(ibase + 3 * total_px + o);
+        dj[j].views_hi = eight_views ? ibase + 4 * total_px + o : nullptr;
+        dj[j].views1_hi = eight_views ? ibase + 5 * total_px + o : nullptr;
     }
     /* slot 1 is only ever read where its stamp says so: the stamps (0xFF.. = -1) are all it needs */
     HIP_TRY(hipMemsetAsync(c->d_maps.p, 0, total_px * 7 * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * 4 * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * n_imaps * sizeof(uint32_t), c->stream));
     return 0;
 }
 
@@ -804,6 +811,8 @@ int mi_dmrecon_device_count(void) {
 }
 
 const char* mi_dmrecon_last_error(void) { return g_err.c_str(); }
+
+int mi_dmrecon_local_view_channels(int32_t nrReconNeighbors) { return nrReconNeighbors > 4 ? 8 : 4; }
 
 void mi_dmrecon_settings_default(mi_dmrecon_settings* s) {          /* libs/dmrecon/settings.h:25-51 */
     s->filterWidth = 5; s->minNCC = 0.3f; s->minParallax = 10.f; s->acceptNCC = 0.6f; s->minRefineDiff = 0.001f;
@@ -1201,7 +1210,7 @@ int BatchRun::upload() {
         const int tx = (jobs[j].w + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, ty = (jobs[j].h + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
         max_tiles = std::max(max_tiles, tx * ty);
     }
-    rc = alloc_maps(c, jobs, dj, total_px);
+    rc = alloc_maps(c, jobs, dj, total_px, st->nrReconNeighbors > 4);
     if (rc) return rc;
     if (c->d_jobs.reserve(nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(jobs) failed");
     HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), nj * sizeof(DevJob), hipMemcpyHostToDevice, S));
@@ -1249,7 +1258,8 @@ int BatchRun::seed_round() {
     HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, S));
     HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), S));
     ev.begin(S, EventLog::BULK, (unsigned)seeds.size());
-    D->optimize(S, 1, ((unsigned)seeds.size() + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE, c->d_jobs.p, c->sc->d_views.p,
+    const unsigned ppw = patches_per_wave(st);
+    D->optimize(S, 1, ((unsigned)seeds.size() + ppw - 1) / ppw, c->d_jobs.p, c->sc->d_views.p,
                 c->sc->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p, nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0,
                 c->d_counters, nullptr, nullptr, nullptr, nullptr);
     ev.end(S);
@@ -1318,7 +1328,8 @@ int BatchRun::bulk_rounds(bool& to_tail) {
              * (about one in five) continue in a follow-up launch over a compacted list (its size stays on the device),
              * so that the wavefronts of both launches are full; the follow-up launch runs all remaining attempts of its
              * entries back to back (third and fourth attempts are rare) */
-            const unsigned waves = (n_work + MI_PATCHES_PER_WAVE - 1) / MI_PATCHES_PER_WAVE;
+            const unsigned ppw = patches_per_wave(st);
+            const unsigned waves = (n_work + ppw - 1) / ppw;
             unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
             D->optimize(S, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr,
                         n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->d_follow.p, fcnt);
@@ -1486,14 +1497,17 @@ int BatchRun::download() {
         if (m.dz) HIP_TRY(hipMemcpyAsync(m.dz, dj[j].dz, np * 8, hipMemcpyDeviceToHost, S));
         if (m.normal) HIP_TRY(hipMemcpyAsync(m.normal, dj[j].normal, np * 12, hipMemcpyDeviceToHost, S));
         if (m.views) {
-            packed.resize(np);
-            HIP_TRY(hipMemcpyAsync(packed.data(), dj[j].views, np * 4, hipMemcpyDeviceToHost, S));
-            HIP_TRY(hipStreamSynchronize(S));
-            for (size_t p = 0; p < np; ++p)
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned g = (packed[p] >> (8 * k)) & 0xFFu;
-                    m.views[4 * p + k] = (g == MI_VIEW_NONE || g >= jobs[j].global.size()) ? -1 : jobs[j].global[g];
-                }
+            const int nch = mi_dmrecon_local_view_channels(st->nrReconNeighbors);
+            for (int half = 0; half < nch / 4; ++half) {
+                packed.resize(np);
+                HIP_TRY(hipMemcpyAsync(packed.data(), half ? dj[j].views_hi : dj[j].views, np * 4, hipMemcpyDeviceToHost, S));
+                HIP_TRY(hipStreamSynchronize(S));
+                for (size_t p = 0; p < np; ++p)
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned g = (packed[p] >> (8 * k)) & 0xFFu;
+                        m.views[(size_t)nch * p + 4 * half + k] = (g == MI_VIEW_NONE || g >= jobs[j].global.size()) ? -1 : jobs[j].global[g];
+                    }
+            }
         }
     }
     HIP_TRY(hipStreamSynchronize(S));
@@ -1609,7 +1623,7 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
             if ((rc = B.tail_rounds(to_front)) != 0) return rc;
             B.mark("phase B rounds");
             if (to_front) { if ((rc = B.front_rounds()) != 0) return rc; B.mark("phase C (front kernel)"); }
-            mi_launch_flatten(B.S, c->d_maps.p, c->d_imaps.p, B.total_px);
+            mi_launch_flatten(B.S, c->d_maps.p, c->d_imaps.p, B.total_px, st->nrReconNeighbors > 4);
         }
         if ((rc = B.download()) != 0) return rc;
         B.fill_stats();
@@ -1761,27 +1775,28 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
     std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
     fill_job(c, st, jobs[0], dj[0]);
     size_t total_px = 0;
-    rc = alloc_maps(c, jobs, dj, total_px);
+    rc = alloc_maps(c, jobs, dj, total_px, st->nrReconNeighbors > 4);
     if (rc) return rc;
     if (n == 0) return 0;
     std::vector<DevEntry> ent(n); std::vector<DevHyp> hy(n);
+    const int nch = mi_dmrecon_local_view_channels(st->nrReconNeighbors);
     for (int i = 0; i < n; ++i) {
         ent[i].job = 0;
         int x = xy[2 * i], y = xy[2 * i + 1];
         if (x < 0 || y < 0 || x >= L.w || y >= L.h) { x = 0; y = 0; }     /* fails the border test -> conf 0 */
         ent[i].xy = x | (y << 16);
         hy[i].depth = hyp[3 * i]; hy[i].dzI = hyp[3 * i + 1]; hy[i].dzJ = hyp[3 * i + 2];
-        unsigned packed = 0; int cnt = 0;
-        for (int k = 0; k < 4; ++k) {
-            int id = local ? local[4 * i + k] : -1;
+        unsigned long long packed = 0; int cnt = 0;
+        for (int k = 0; k < nch; ++k) {
+            int id = local ? local[nch * i + k] : -1;
             if (id < 0) continue;
             std::vector<int>::const_iterator it = std::lower_bound(jh.global.begin(), jh.global.end(), id);
             if (it == jh.global.end() || *it != id) return fail(MI_DMRECON_EINVAL, "local view %d is not a global view", id);
-            packed |= (unsigned)(it - jh.global.begin()) << (8 * cnt);
+            packed |= (unsigned long long)(it - jh.global.begin()) << (8 * cnt);
             ++cnt;
         }
-        for (; cnt < 4; ++cnt) packed |= MI_VIEW_NONE << (8 * cnt);
-        hy[i].views = packed;
+        for (; cnt < 8; ++cnt) packed |= (unsigned long long)MI_VIEW_NONE << (8 * cnt);
+        hy[i].views = (uint32_t)packed; hy[i].views_hi = (uint32_t)(packed >> 32);
     }
     if (c->d_jobs.reserve(1) || c->d_work.reserve(n) || c->d_hyp.reserve(n) || c->d_results.reserve(n))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc failed");
@@ -1791,7 +1806,7 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     /* lanes_per_view = 16 runs the hook through the latency layout, anything else through the throughput layout */
     const int lpv = lanes_per_view == 16 ? 16 : 1;
-    const unsigned ppw = lpv == 16 ? 1u : (unsigned)MI_PATCHES_PER_WAVE;
+    const unsigned ppw = lpv == 16 ? 1u : patches_per_wave(st);
     D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st),
                c->d_work.p, c->d_hyp.p, c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
                nullptr, nullptr, nullptr, nullptr);
@@ -1803,9 +1818,9 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
         float* o = out + 8 * i;
         o[0] = res[i].conf; o[1] = res[i].depth; o[2] = res[i].dzI; o[3] = res[i].dzJ;
         o[4] = res[i].nx; o[5] = res[i].ny; o[6] = res[i].nz; o[7] = (float)res[i].iters;
-        for (int k = 0; k < 4; ++k) {
-            const unsigned g = (res[i].views >> (8 * k)) & 0xFFu;
-            out_local[4 * i + k] = (g == MI_VIEW_NONE || g >= jh.global.size()) ? -1 : jh.global[g];
+        for (int k = 0; k < nch; ++k) {
+            const unsigned g = ((k < 4 ? res[i].views : res[i].views_hi) >> (8 * (k & 3))) & 0xFFu;
+            out_local[nch * i + k] = (g == MI_VIEW_NONE || g >= jh.global.size()) ? -1 : jh.global[g];
         }
     }
     return 0;
@@ -1830,7 +1845,7 @@ static int mi_dmrecon_patch_eval_impl(mi_dmrecon_ctx* c, const mi_dmrecon_settin
     std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
     fill_job(c, st, jobs[0], dj[0]);
     size_t total_px = 0;
-    rc = alloc_maps(c, jobs, dj, total_px);
+    rc = alloc_maps(c, jobs, dj, total_px, st->nrReconNeighbors > 4);
     if (rc) return rc;
     const int G = (int)jh.global.size();
     const size_t NS3 = 3 * (size_t)st->filterWidth * st->filterWidth;       /* floats per view: fw x fw samples, 3 channels */

@@ -8,7 +8,8 @@
 #include <stdint.h>
 
 #define MI_MAX_LEVELS 16
-#define MI_MAX_GLOBAL 32
+#define MI_MAX_GLOBAL 64        /* global views per reference view (Settings::globalVSMax): one bit each in the 64-bit availability mask */
+#define MI_MAX_LOCAL 8          /* local views per patch (Settings::nrReconNeighbors): four or eight view slots */
 #define MI_MAX_FW 7         /* filter widths 3, 5, 7: the device code is compiled once per width (dmrecon_device.hip) */
 #define MI_PATCHES_PER_WAVE 16
 #define MI_VIEW_NONE 0xFFu
@@ -72,6 +73,7 @@ struct DevJob {
     float* normal;    /* 3 ch */
     uint32_t* views;  /* 4 x 8-bit indices into global_ids, MI_VIEW_NONE padded */
     int32_t* upd;     /* round in which the pixel was last written, -1 = never */
+    uint32_t* views_hi;   /* view slots 4..7 of the set (nrReconNeighbors > 4 only, else null) */
     /* Second slot of the pixel state, used by the fused tail rounds only (k_tail): a write of round r goes to
      * the slot that does NOT hold the pixel's state as of the end of round r-1, so the optimisations of a round
      * keep reading the frozen state of the previous round without a separate write-back launch.  The state
@@ -82,6 +84,7 @@ struct DevJob {
     float* normal1;
     uint32_t* views1;
     int32_t* upd1;
+    uint32_t* views1_hi;
 };
 
 #define MI_JOB_EFOOTPRINT 1u   /* device: non-positive master footprint in this view (patch_sampler.cc:78-82 throws) */
@@ -101,11 +104,13 @@ struct DevEntry {
 struct DevHyp {              /* explicit hypothesis (seeds / parity hook) */
     float depth, dzI, dzJ;
     uint32_t views;          /* packed global indices or all MI_VIEW_NONE */
+    uint32_t views_hi;       /* ... of view slots 4..7 */
 };
 struct DevResult {
     float conf, depth, dzI, dzJ;
     float nx, ny, nz;
     uint32_t views;
+    uint32_t views_hi;
     int32_t iters;
     int32_t accepted;        /* propagate mode: 1 if the pixel state must be overwritten */
     uint32_t tried;          /* propagate mode: neighbours (bit k: left, right, up, down) whose hypothesis has been consumed */

@@ -53,8 +53,8 @@ int orc_global_vs(void* scene, const orc_settings* st, int32_t* ids_out);
 int orc_reconstruct(void* scene, const orc_settings* st, float* depth, float* normal, float* dz,
                     float* conf, orc_stats* stats);
 
-/* n hypotheses: xy[2n], hyp[3n] = depth,dzI,dzJ, local[4n] view ids (-1 = none).
- * out[8n] = conf, depth, dzI, dzJ, nx, ny, nz, iterations; out_local[4n]. */
+/* n hypotheses: xy[2n], hyp[3n] = depth,dzI,dzJ, local[8n] view ids (-1 = none; nrReconNeighbors <= 8).
+ * out[8n] = conf, depth, dzI, dzJ, nx, ny, nz, iterations; out_local[8n]. */
 int orc_patch_optimize(void* scene, const orc_settings* st, int n, const int32_t* xy, const float* hyp,
                        const int32_t* local, float* out, int32_t* out_local);
 

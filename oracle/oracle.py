@@ -147,13 +147,16 @@ class OracleScene:
         xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
         n = len(xy)
         hyp = np.ascontiguousarray(hyp, np.float32).reshape(n, 3)
-        loc = np.full((n, 4), -1, np.int32) if local is None else np.ascontiguousarray(local, np.int32).reshape(n, 4)
+        loc = np.full((n, 8), -1, np.int32)                     # up to eight local views (nrReconNeighbors <= 8)
+        if local is not None:
+            local = np.ascontiguousarray(local, np.int32).reshape(n, -1)
+            loc[:, :local.shape[1]] = local
         out = np.zeros((n, 8), np.float32)
-        out_local = np.zeros((n, 4), np.int32)
+        out_local = np.zeros((n, 8), np.int32)
         rc = lib().orc_patch_optimize(self.h, ctypes.byref(st), n, _ptr(xy), _ptr(hyp), _ptr(loc), _ptr(out), _ptr(out_local))
         if rc != 0:
             raise RuntimeError("oracle patch_optimize failed")
-        return out, out_local
+        return out, out_local[:, :(8 if st.nrReconNeighbors > 4 else 4)]
 
     def patch_eval(self, st: OrcSettings, x, y, depth, dzi=0.0, dzj=0.0):
         g = max(self.n_views, 1)
@@ -201,7 +204,7 @@ def run_reference_app(scene_dir: str, scale: int, local_neighbors: int = 4, mast
 
 
 def run_reference_patch_driver(scene_dir: str, ref_view: int, scale: int, local_neighbors: int, mode: str,
-                               seeds: Sequence[Sequence[float]], filter_width: int = 5) -> List[List[str]]:
+                               seeds: Sequence[Sequence[float]], filter_width: int = 5, global_max: int = 20) -> List[List[str]]:
     exe = os.path.join(REF_DIR, "ref_patch_driver")
     with tempfile.TemporaryDirectory() as td:
         sp, op = os.path.join(td, "seeds.txt"), os.path.join(td, "out.txt")
@@ -211,6 +214,7 @@ def run_reference_patch_driver(scene_dir: str, ref_view: int, scale: int, local_
                 loc = [int(v) for v in s[5:] if int(v) >= 0]
                 f.write("%d %d %.9g %.9g %.9g %d %s\n" % (x, y, d, dzi, dzj, len(loc), " ".join(map(str, loc))))
         subprocess.run([exe, scene_dir, str(ref_view), str(scale), str(local_neighbors), mode, sp, op],
-                       check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, REF_FILTER_WIDTH=str(filter_width)))
+                       check=True, stdout=subprocess.DEVNULL,
+                       env=dict(os.environ, REF_FILTER_WIDTH=str(filter_width), REF_GLOBAL_VS_MAX=str(global_max)))
         with open(op) as f:
             return [ln.split() for ln in f if ln.strip()]

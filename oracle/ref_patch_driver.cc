@@ -16,7 +16,7 @@
  *                    colour / derivative samples of fastColAndDeriv
  *   MODE = opt    -> per seed: result of doAutoOptimization + computeConfidence
  * SEEDS: text, one hypothesis per line: x y depth dzI dzJ nlocal [ids...]
- * Environment: REF_FILTER_WIDTH = mvs::Settings::filterWidth (default 5).
+ * Environment: REF_FILTER_WIDTH = mvs::Settings::filterWidth (default 5), REF_GLOBAL_VS_MAX = globalVSMax (default 20).
  */
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +50,7 @@ int main (int argc, char** argv)
     st.nrReconNeighbors = std::atoi(argv[4]);
     st.quiet = true;
     if (char const* fw = std::getenv("REF_FILTER_WIDTH")) st.filterWidth = std::atoi(fw);   /* apps/dmrecon --filter-width */
+    if (char const* gm = std::getenv("REF_GLOBAL_VS_MAX")) st.globalVSMax = std::atoi(gm);  /* apps/dmrecon -n / --neighbors */
     std::string mode = argv[5];
 
     mve::Scene::Ptr scene = mve::Scene::create(scene_path);

@@ -59,6 +59,17 @@ def h1_scene(h1):
 
 
 @pytest.fixture(scope="session")
+def w1():
+    """Scene W1 (42 views): the reference with 40 global views / six and eight local views (make_golden_wide.py)."""
+    return dict(np.load(os.path.join(GOLDEN, "w1_wide_42views_112x84.npz")))
+
+
+@pytest.fixture(scope="session")
+def w1_scene(w1):
+    return scene_from_golden(w1)
+
+
+@pytest.fixture(scope="session")
 def g1_scene(g1):
     return scene_from_golden(g1)
 

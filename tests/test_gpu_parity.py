@@ -450,7 +450,13 @@ def test_edge_cases(gpu_ctx, g1_scene):
     with pytest.raises(ValueError):
         gpu_ctx.reconstruct(api.Settings(filterWidth=9), [0])
     with pytest.raises(ValueError):
-        gpu_ctx.reconstruct(api.Settings(nrReconNeighbors=5), [0])
+        gpu_ctx.reconstruct(api.Settings(nrReconNeighbors=9), [0])       # more than MI_DMRECON_MAX_LOCAL_VIEWS
+    with pytest.raises(ValueError):
+        gpu_ctx.reconstruct(api.Settings(globalVSMax=65), [0])           # more than MI_DMRECON_MAX_GLOBAL_VIEWS
+    # more local neighbours than the scene has other views: no patch finds them, nothing is filled (the reference
+    # needs exactly K selected views, local_view_selection.cc:144-146), the call itself succeeds
+    r = gpu_ctx.reconstruct(api.Settings(nrReconNeighbors=5), [0], want_views=True)[0]
+    assert not (r["depth"] > 0).any() and r["views"].shape[2] == 8
     # an AABB that excludes every feature -> no global views
     with pytest.raises(RuntimeError, match="Global View Selection failed"):
         gpu_ctx.reconstruct(api.Settings(aabbMin=[100, 100, 100], aabbMax=[101, 101, 101]), [0])
@@ -564,3 +570,55 @@ def test_filter_widths_vs_reference(gpu_ctx, g1, g1_fw, g1_scene, fw, monkeypatc
     assert np.abs(e["col"][okv] - o["col"][okv]).max() <= 3e-5 and np.abs(e["ncc"][okv] - o["ncc"][okv]).max() <= 1e-4
     dref = o["deriv"][okv]
     assert np.abs(e["deriv"][okv] - dref).max() <= 1e-4 * max(np.abs(dref).max(), 1.0)
+
+
+# ---- scene W1: 42 views -- more than 32 global views, more than four local views (tests/golden/make_golden_wide.py) ----
+
+def test_wide_view_sets_vs_reference(gpu_ctx, w1, w1_scene, g1_scene, monkeypatch):
+    """apps/dmrecon -n 40 --local-neighbors=6 / --local-neighbors=8 against the reference's own output: the global view
+    selection of 40 views, maps reconstructed with six and eight local views per patch (the eight-slot lane layouts:
+    an octet of lanes per patch in the throughput layout, eight 8-lane half rows in the latency layout), and the
+    reference's own PatchOptimization on 160 hypotheses, half of them with a propagated set of six."""
+    gpu_ctx.load_scene(w1_scene)
+    st6 = api.Settings(refViewNr=0, nrReconNeighbors=6, globalVSMax=40)
+    assert gpu_ctx.global_view_selection(st6) == list(w1["gvs40"]) and len(w1["gvs40"]) == 40
+    for tag, st in (("k6n40", st6), ("k8n20", api.Settings(refViewNr=0, nrReconNeighbors=8, globalVSMax=20))):
+        r = gpu_ctx.reconstruct(st, [0], want_views=True)[0]
+        m = map_parity(r["depth"], r["conf"], w1[tag + "_depth"], w1[tag + "_conf"])
+        assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 5e-3, (tag, m)
+        filled = r["conf"] > 0
+        v = r["views"][filled]
+        assert v.shape[1] == 8 and ((v >= 0).sum(1) == st.nrReconNeighbors).all()           # exactly K views, ...
+        k = st.nrReconNeighbors
+        assert (np.diff(v[:, :k], axis=1) > 0).all() and (v[:, k:] == -1).all() and not (v == 0).any()   # ascending, never the reference view
+        both = filled & (w1[tag + "_depth"] > 0)
+        assert np.abs(r["dz"][both] - w1[tag + "_dz"][both]).max() < 0.05
+    # patch level, both lane layouts
+    ref, ref_loc = w1["opt"], w1["opt_local"]
+    for lpv in (1, 16):
+        out, loc = gpu_ctx.patch_optimize(st6, 0, w1["seeds_xy"], w1["seeds_hyp"], w1["seeds_local"], lanes_per_view=lpv)
+        assert loc.shape == (160, 8)
+        assert ((out[:, 0] > 0) == (ref[:, 0] > 0)).mean() >= 0.97
+        ok = (out[:, 0] > 0) & (ref[:, 0] > 0)
+        assert ok.sum() >= 100
+        assert (np.abs(out[ok, 1] - ref[ok, 1]) / ref[ok, 1] <= 1e-3).mean() >= 0.99
+        assert (np.abs(out[ok, 0] - ref[ok, 0]) <= 5e-3).mean() >= 0.98
+        assert (loc[ok] == ref_loc[ok]).all(1).mean() >= 0.98
+    # three reference views in one call: the fused tail rounds and the front kernel with eight view slots write what
+    # host-visible rounds in the same lane layout write
+    refs = [0, 5, 11]
+    monkeypatch.setenv("MI_DMRECON_FRONT", "0")
+    monkeypatch.setenv("MI_DMRECON_BULK_LPV", "16")
+    monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "0")
+    seq = gpu_ctx.reconstruct(st6, refs, want_views=True)
+    monkeypatch.delenv("MI_DMRECON_BULK_LPV")
+    for front in ("0", "1000000"):
+        monkeypatch.setenv("MI_DMRECON_FRONT", front)
+        monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "1000000000")
+        got = gpu_ctx.reconstruct(st6, refs, want_views=True)
+        assert gpu_ctx.last_stats["n_front_launches"] == (1 if front != "0" else 0)
+        for a, b in zip(seq, got):
+            for key in ("depth", "conf", "dz", "normal", "views"):
+                assert np.array_equal(a[key], b[key]), (front, key)
+    monkeypatch.delenv("MI_DMRECON_FRONT"); monkeypatch.delenv("MI_DMRECON_TAIL_THRESHOLD")
+    gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)

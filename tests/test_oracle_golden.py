@@ -155,3 +155,21 @@ def test_filter_width_7_bit_exact_and_3_to_rounding(g1, g1_fw, g1_scene):
     m = map_parity(r["depth"], r["conf"], g1_fw["fw3_depth"], g1_fw["fw3_conf"])
     assert m["iou"] >= 0.99 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 2e-2, m
     assert not np.array_equal(g1_fw["fw3_depth"], g1["s0v0_depth"]) and not np.array_equal(g1_fw["fw7_depth"], g1["s0v0_depth"])
+
+
+def test_more_than_four_local_and_32_global_views(w1, w1_scene):
+    """apps/dmrecon -n 40 --local-neighbors=6 and --local-neighbors=8 on scene W1 (42 views): the restatement is bit
+    for bit the reference there too (global view selection of 40 views, local sets of six / eight)."""
+    S = orc.OracleScene(w1_scene)
+    st = orc.make_settings(ref_view=0, local_neighbors=6, global_max=40)
+    assert S.global_vs(st) == list(w1["gvs40"]) and len(w1["gvs40"]) == 40
+    r = S.reconstruct(st)
+    assert np.array_equal(r["depth"], w1["k6n40_depth"]) and np.array_equal(r["conf"], w1["k6n40_conf"])
+    assert np.array_equal(r["dz"], w1["k6n40_dz"])
+    r = S.reconstruct(orc.make_settings(ref_view=0, local_neighbors=8, global_max=20))
+    assert np.array_equal(r["depth"], w1["k8n20_depth"]) and np.array_equal(r["conf"], w1["k8n20_conf"])
+    out, loc = S.patch_optimize(st, w1["seeds_xy"], w1["seeds_hyp"], w1["seeds_local"])
+    ok = w1["opt"][:, 0] > 0
+    assert ok.sum() >= 100 and np.array_equal(out[:, 0] > 0, ok)
+    assert np.array_equal(out[ok, :7], w1["opt"][ok, :7]) and np.array_equal(loc[ok], w1["opt_local"][ok])
+    assert ((w1["opt_local"][ok] >= 0).sum(1) == 6).all()
