@@ -585,7 +585,12 @@ def test_wide_view_sets_vs_reference(gpu_ctx, w1, w1_scene, g1_scene, monkeypatc
     for tag, st in (("k6n40", st6), ("k8n20", api.Settings(refViewNr=0, nrReconNeighbors=8, globalVSMax=20))):
         r = gpu_ctx.reconstruct(st, [0], want_views=True)[0]
         m = map_parity(r["depth"], r["conf"], w1[tag + "_depth"], w1[tag + "_conf"])
-        assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 5e-3, (tag, m)
+        # 112 x 84 images, 40 near-by views: the reference ALGORITHM is order-sensitive to rel_p99 8.3e-3 / conf median
+        # 1.5e-2 / conf p99 0.12 here (its restatement with the queue popped worst-first against itself,
+        # tests/test_oracle_golden.py::test_order_sensitivity_floor_on_wide_scene); bounds at ~1.5 x that floor,
+        # the fill mask at the smooth-scene bound
+        assert m["iou"] >= 0.99 and m["rel_med"] <= 1.5e-3 and m["rel_p99"] <= 1.3e-2, (tag, m)
+        assert m["conf_med"] <= 2.2e-2 and m["conf_p99"] <= 0.18, (tag, m)
         filled = r["conf"] > 0
         v = r["views"][filled]
         assert v.shape[1] == 8 and ((v >= 0).sum(1) == st.nrReconNeighbors).all()           # exactly K views, ...

@@ -173,3 +173,26 @@ def test_more_than_four_local_and_32_global_views(w1, w1_scene):
     assert ok.sum() >= 100 and np.array_equal(out[:, 0] > 0, ok)
     assert np.array_equal(out[ok, :7], w1["opt"][ok, :7]) and np.array_equal(loc[ok], w1["opt_local"][ok])
     assert ((w1["opt_local"][ok] >= 0).sum(1) == 6).all()
+
+
+def test_order_sensitivity_floor_on_wide_scene(w1):
+    """The reference algorithm against itself with its queue popped worst-first on scene W1 (small images, 40 near-by
+    global views, six local views): the floor behind the bounds of tests/test_gpu_parity.py::
+    test_wide_view_sets_vs_reference."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import map_parity, ROOT
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from conftest import scene_from_golden, GOLDEN\nfrom oracle import oracle as orc\nimport os\n"
+            "g = dict(np.load(os.path.join(GOLDEN, 'w1_wide_42views_112x84.npz')))\n"
+            "r = orc.OracleScene(scene_from_golden(g)).reconstruct(orc.make_settings(ref_view=0, local_neighbors=6, global_max=40))\n"
+            "np.savez(sys.argv[1], d=r['depth'], c=r['conf'])\n" % (ROOT, os.path.join(ROOT, "tests")))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rev.npz")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, ORC_QUEUE_ORDER="reverse"))
+        rev = np.load(out)
+        m = map_parity(w1["k6n40_depth"], w1["k6n40_conf"], rev["d"], rev["c"])
+    # measured: iou 1.0, rel_med 8.7e-4, rel_p99 8.3e-3, conf_med 1.5e-2, conf_p99 0.12
+    assert m["iou"] >= 0.995 and 4e-3 <= m["rel_p99"] <= 1.5e-2 and 5e-3 <= m["conf_med"] <= 3e-2 and 0.06 <= m["conf_p99"] <= 0.2, m
