@@ -355,7 +355,13 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     cfg = CONFIGS[args.config]
     p = cfg["params"]
-    coll = Collective("nccl", local_rank)
+    # MI_BENCH_SHARE_GPU=1 (development only, never the driver's command): all ranks of an N > 1 launch use GPU 0 and
+    # the gloo backend -- the strong-scaling plumbing and the per-rank time of a 1/N share of the scene on a one-GPU box
+    # (profiles/r3_strong_2ranks_one_gpu.json); the line is labelled with it
+    share_gpu = world > 1 and os.environ.get("MI_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
+    coll = Collective("gloo" if share_gpu else "nccl", local_rank)
 
     scene = make_scene(p)                                   # synthetic, deterministic, identical on every rank
     ctx = api.Context(local_rank)
@@ -419,6 +425,9 @@ def main():
                        "mean_fill": round(fill, 4)},
             "roofline": roof,
         }
+        if share_gpu:
+            out["config"]["ranks_share_one_gpu"] = True
+            out["per_rank_ms_per_step"] = 1000.0 * elapsed / args.steps
         if one_call is not None:
             out["one_call"] = one_call
         if strong is not None:

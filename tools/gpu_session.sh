@@ -1,11 +1,11 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): wide-view-set test + front threshold sweep at the driver's call plan.
-TAG=${1:-r3g}
+TAG=${1:-r3h}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -s KILL 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "wide or scale_and_errors or error" 2>&1 | tail -30 > $OUT/pytest.log
-tail -25 $OUT/pytest.log
+timeout -s KILL 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "wide" 2>&1 | tail -30 > $OUT/pytest.log
+tail -12 $OUT/pytest.log
 drv() {
   L=$1; shift
   env "$@" timeout -s KILL 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-one-call 2>/dev/null > $OUT/drv_$L.json
@@ -18,9 +18,10 @@ except Exception as e:
     print(sys.argv[2], 'failed', e)
 PY
 }
-drv f8 MI_DMRECON_FRONT=8
-drv f16 MI_DMRECON_FRONT=16
-drv f32 MI_DMRECON_FRONT=32
-drv f64 MI_DMRECON_FRONT=64
-drv f8b MI_DMRECON_FRONT=8
-drv f0 MI_DMRECON_FRONT=0
+for R in 1 2; do
+drv f64_$R MI_DMRECON_FRONT=64
+drv f128_$R MI_DMRECON_FRONT=128
+drv f256_$R MI_DMRECON_FRONT=256
+drv fall_$R MI_DMRECON_FRONT=1000000
+drv f32_$R MI_DMRECON_FRONT=32
+done
