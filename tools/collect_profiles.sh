@@ -3,22 +3,23 @@
 # Everything lands in gpurun_out/$TAG/; tools/summarize_profiles.py turns it into profiles/<tag>_*.
 # --pmc passes are separate runs with --kernel-trace only (never with sys/runtime/hip traces), each under its own
 # timeout: a counter group the hardware cannot collect makes rocprofv3 abort and then hang in its finalisation.
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python bench.py --streams 1 --steps-per-call 1 --steps 20 --no-cpu-baseline > $OUT/bench_1thread.json 2> $OUT/bench_1thread.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err      # the driver's command
+python bench.py --no-one-call > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --streams 1 --steps-per-call 1 --steps 20 --no-cpu-baseline --no-one-call > $OUT/bench_1thread.json 2> $OUT/bench_1thread.err
 # one host thread, the default five steps (100 reference views) per call: what the size of a launch does to the bulk kernel
-python bench.py --streams 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_1thread_5steps.json 2> $OUT/bench_1thread_5steps.err
-B1="python bench.py --steps 6 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline"
-B3="python bench.py --steps 30 --warmup 1 --no-cpu-baseline"
+python bench.py --streams 1 --steps 20 --warmup 5 --no-cpu-baseline --no-one-call > $OUT/bench_1thread_5steps.json 2> $OUT/bench_1thread_5steps.err
+B1="python bench.py --steps 6 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline --no-one-call"
+B3="python bench.py --steps 30 --warmup 1 --no-cpu-baseline --no-one-call"
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s1 -o bench -- $B1 > $OUT/s1.log 2>&1
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s3 -o bench -- $B3 > $OUT/s3.log 2>&1
 # PMC at the call plan of the 1-thread line (one step per call) and, for the traffic figure of the default line,
 # at the default plan (6 threads, 5 steps per call)
-BP="python bench.py --steps 2 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline"
-BQ="python bench.py --steps 10 --warmup 1 --no-cpu-baseline"
+BP="python bench.py --steps 2 --warmup 1 --streams 1 --steps-per-call 1 --no-cpu-baseline --no-one-call"
+BQ="python bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-one-call"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
   D=$OUT/pmc_$(echo $C | tr ' ' '+')
   timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o bench -- $BP > $D.log 2>&1
@@ -31,4 +32,4 @@ done
 rm -f $OUT/s1/bench_kernel_trace.csv $OUT/s3/bench_kernel_trace.csv
 find $OUT -name "*_kernel_trace.csv" -path "*pmc*" -delete
 du -sh $OUT
-cat $OUT/bench_default.json $OUT/bench_1thread.json $OUT/bench_1thread_5steps.json | cut -c1-600
+cat $OUT/bench_driver.json $OUT/bench_default.json $OUT/bench_1thread.json $OUT/bench_1thread_5steps.json | cut -c1-600

@@ -13,14 +13,14 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 FETCH_CORR = 2.0
 # steps (passes over the 20 views) behind each PMC run of tools/collect_profiles.sh, warm-up calls included
-STEPS = {"pmc": 3,      # --steps 2 --warmup 1 --streams 1 --steps-per-call 1: three calls of one step
-         "pmcd": 20}    # --steps 10 --warmup 1 (5 steps per call, 2 threads): 2 warm-up + 2 timed calls of five steps
-for n in ("1thread", "default", "1thread_5steps"):
+STEPS = {"pmc": 3,      # --steps 2 --warmup 1 --streams 1 --steps-per-call 1 --no-one-call: three calls of one step
+         "pmcd": 20}    # --steps 10 --warmup 1 --no-one-call (5 steps per call, 2 threads): 2 warm-up + 2 timed calls of five steps
+for n in ("1thread", "default", "driver", "1thread_5steps"):
     f = os.path.join(src, "bench_%s.json" % n)
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, "%s_bench_%s.json" % (tag, n)))
@@ -35,8 +35,9 @@ def short(name):
 
 
 def family(k):
-    if k.startswith("k_tail"):
-        return "k_tail (blind tail rounds)"
+    k = k.split("::")[-1]
+    if k.startswith("k_tail") or k.startswith("k_front<") or k == "k_front":
+        return "k_tail + k_front (tail rounds)"
     if k.startswith("k_optimize"):
         return "k_optimize<1> (host-visible rounds)"
     return None
@@ -108,7 +109,7 @@ for prefix, plan in (("pmc", "1 host thread, 1 step per call"), ("pmcd", "defaul
             "  %s: %.1f MB read + %.1f MB written" % (fm, v[0] / STEPS[prefix] / 1e6, v[1] / STEPS[prefix] / 1e6) for fm, v in sorted(fam.items())]
 if traffic["plans"]:
     json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
-for n in ("1thread", "default", "1thread_5steps"):
+for n in ("1thread", "default", "driver", "1thread_5steps"):
     f = os.path.join(src, "bench_%s.json" % n)
     if os.path.exists(f) and os.path.getsize(f):
         j = json.loads(open(f).read().strip().splitlines()[-1])
