@@ -1775,7 +1775,7 @@ __shared__ unsigned g_fcnt[8];    /* 0: FQs, 1: attempts of the pass, 2: attempt
                                    * 5: newly filled pixels of the round */
 
 template <int NV>
-__global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(MI_FRONT_WAVES / 4, MI_FRONT_WAVES / 4))) void k_front(FrontArgs t) {
+__global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu((MI_FRONT_WAVES >= 8 ? MI_FRONT_WAVES / 4 : 1), (MI_FRONT_WAVES >= 8 ? MI_FRONT_WAVES / 4 : 2)))) void k_front(FrontArgs t) {
     typedef typename LatLay<NV>::type LL;
     const OptArgs& a = t.o;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
