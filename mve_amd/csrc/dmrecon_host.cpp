@@ -149,6 +149,7 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
  * propagation goes to the front kernel, for a call alone on its GPU / next to other calls (BatchRun::tail_rounds) */
 #define MI_FRONT_ALONE 2
 #define MI_FRONT_SHARED 1000000
+#define MI_FRONT_BATCH 48
 struct ActiveCall {
     int dev;
     explicit ActiveCall(int d) : dev(d >= 0 && d < MI_MAX_DEVICES ? d : -1) { if (dev >= 0) g_active_calls[dev].fetch_add(1); }
@@ -1372,13 +1373,15 @@ int BatchRun::tail_rounds(bool& to_front) {
      * optimisations of its view at a time: below ~6 entries per view a view's round is one patch long there (18 us
      * against 29 us for a k_tail launch), above it rounds take several generations.  Default: 2 for a call that has
      * the GPU to itself (measured neutral to +1 % on a lone 20-view call: the slowest view decides, and it still has
-     * ~14 entries per round when the average is 8); next to other calls the WHOLE tail (from
-     * the hand-over round on): a front workgroup occupies one CU per view and leaves the rest of the GPU to the other
-     * calls' bulk rounds, where ~600 launches per batch queue behind them -- measured at the bench's plan (four host
-     * threads, merged batches of 133 views): 1164 / 1177 depth-maps/s against 980 with one launch per round. */
+     * ~14 entries per round when the average is 8); next to other calls, and for batches of
+     * MI_FRONT_BATCH views or more, the WHOLE tail (from the hand-over round on): a front workgroup occupies one CU
+     * per view and leaves the rest of the GPU to the bulk rounds of the other calls, where ~600 launches per batch
+     * queue behind them -- measured at the bench's plan (four host threads, merged batches of 133 views): 1164 / 1177
+     * depth-maps/s against 980 with one launch per round; a lone call of 100 views: 728 against 714. */
     const unsigned FRONT_PER_VIEW = [&] {
         const char* e = std::getenv("MI_DMRECON_FRONT");
-        return e ? (unsigned)std::max(0, std::atoi(e)) : (active.count() > 1 ? (unsigned)MI_FRONT_SHARED : (unsigned)MI_FRONT_ALONE);
+        if (e) return (unsigned)std::max(0, std::atoi(e));
+        return (active.count() > 1 || nj >= MI_FRONT_BATCH) ? (unsigned)MI_FRONT_SHARED : (unsigned)MI_FRONT_ALONE;
     }();
     const unsigned front_max = FRONT_PER_VIEW * (unsigned)nj;
     wcur = c->d_work.p; wnext = c->d_work2.p; rcur = c->d_results.p; rnext = c->d_results2.p;
