@@ -1002,6 +1002,7 @@ struct Run {
     PatchState ps;
     ViewC vc;                    /* my view slot's view, level and texel window */
     bool opti, converged, viewRemoved, step_was_normal, need_vs, count_color;
+    bool bail;                   /* FAST kernels: the patch needs a view selection -- left to the general kernel */
     int iter, need, ctx;
     float oldncc;                /* per view slot: getFastNCC before the step (:189-192) */
 };
@@ -1060,7 +1061,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     ps.depth = depth0; ps.dzI = dzI0; ps.dzJ = dzJ0;
     viewc_reset(R.vc);
     R.opti = true; R.converged = false; R.viewRemoved = false; R.step_was_normal = false;
-    R.iter = 0; R.need = PASS_DEPTH; R.ctx = CTX_CTOR; R.oldncc = -1.f; R.need_vs = false; R.count_color = false;
+    R.iter = 0; R.need = PASS_DEPTH; R.ctx = CTX_CTOR; R.oldncc = -1.f; R.need_vs = false; R.count_color = false; R.bail = false;
     /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
     if (x - MI_HALF < 0 || y - MI_HALF < 0 || x + MI_HALF > job->w - 1 || y + MI_HALF > job->h - 1) return false;
     ps.jinv0 = job->inv0_s;
@@ -1150,7 +1151,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
  * fused pass at the current state (colour sums + the Gauss-Newton sums the NEXT step needs), finish the
  * decision of the step that led here, take the next step.  Returns false when the optimisation is over.
  */
-template <class L>
+template <class L, bool FAST>
 __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const DevView* views, int lane) {
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
@@ -1162,6 +1163,9 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     ColorSums S; GNSums gn;
     S.s0 = S.s1 = S.s2 = S.a0 = S.a1 = S.a2 = S.aa0 = S.aa1 = S.aa2 = S.ba0 = S.ba1 = S.ba2 = 0.f;
     if (R.need_vs) {
+        /* FAST: no view selection in this kernel (it is rare once hypotheses propagate with their view sets: one patch
+         * in a few thousand replaces a view) -- the attempt is abandoned and redone by the general kernel */
+        if (FAST) { R.bail = true; return false; }
         R.need_vs = false;
         if (!local_view_selection<L>(ps, st, views, lane)) { R.opti = false; return false; }
     }
@@ -1329,16 +1333,20 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
     TSTAMP(41);
 }
 
-template <class L>
-__device__ __forceinline__ void optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
+/* Returns false if the attempt was abandoned (FAST kernels only: it needs a view selection); res is void then and only the
+ * passes actually run are counted. */
+template <class L, bool FAST = false>
+__device__ __forceinline__ bool optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
                                float depth0, float dzI0, float dzJ0, unsigned long long hyp_views, int lane,
                                PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err, DevCounters* counters) {
     Run R;
     TSTAMP(10);
     if (run_begin<L>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
-        while (run_turn<L>(R, st, views, lane)) { }
+        while (run_turn<L, FAST>(R, st, views, lane)) { }
     TSTAMP(40);
+    if (FAST && R.bail) { n_pass += R.ps.n_pass; return false; }
     run_end<L>(R, st, lane, res, n_eval, n_pass);
+    return true;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1375,7 +1383,7 @@ struct OptArgs {
  * candidates are re-read from the state, which a host-visible round does not write -- k_apply does).
  * Returns true if the pixel state must be overwritten.
  */
-template <class L>
+template <class L, bool FAST>
 __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, const DevJob* job, int x, int y, int lane,
                                               unsigned& n_eval, unsigned& n_pass, unsigned& n_patch, unsigned& err, bool& more) {
     const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
@@ -1402,6 +1410,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
     int attempts = 0;
     for (int t = 0; t < 4; ++t) {
         float hd, hi, hj; unsigned long long hv;
+        const unsigned tried_before = tried;
         if (explicit_hyp) {
             if (t > 0) break;
             const DevHyp h = a.hyp[e];
@@ -1429,7 +1438,11 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
             hd = GF(job->depth + p); hi = GF(job->dz + 2 * p); hj = GF(job->dz + 2 * p + 1); hv = load_view_set<L::NV>(job, false, p);
         }
         PatchResult r;
-        optimize_patch<L>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters);
+        if (!optimize_patch<L, FAST>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters)) {
+            /* abandoned (FAST): the candidate stays untried, the follow-up launch of the general kernel takes the entry */
+            tried = tried_before; more = true;
+            break;
+        }
         ++n_patch; ++attempts;
         const bool accept = explicit_hyp ? true : (r.conf > 0.f && best < r.conf);   /* dmrecon.cc:378,391 */
         if (accept) {
@@ -1475,7 +1488,7 @@ __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, 
  * The hot kernel.  L::LPV = 1: 16 patches per wavefront (throughput); L::LPV = 16: one patch per
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
  */
-template <class L>
+template <class L, bool FAST>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 2 : MI_BULK_WAVES), (L::LAT ? 2 : MI_WAVES_PER_SIMD)))) void k_optimize(OptArgs a) {
     const int lane = threadIdx.x;
     const unsigned n = a.follow_in ? *a.follow_in_n : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
@@ -1492,7 +1505,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
             /* the view failed (footprint exception) or was cancelled: nothing of it is touched any more */
             if (L::vslot(lane) == 0 && L::sub(lane) == 0) a.results[e].accepted = 0;
         } else
-            process_entry<L>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
+            process_entry<L, FAST>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
         if (a.follow_out) {
             /* wave-aggregated append of the entries that still have candidates (one atomic per wavefront) */
             const bool mine = more && L::vslot(lane) == 0 && L::sub(lane) == 0;
@@ -2352,12 +2365,18 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     a.follow_out = follow_out; a.follow_out_n = follow_out_n;
     /* lanes_per_view: 1 = throughput layout, anything else = latency layout; st.K > 4: the eight-slot layouts */
     const bool lat = lanes_per_view != 1, eight = st.K > 4;
+    /* the first launch of a bulk round (one attempt per entry, a follow-up list for the rest) runs the FAST kernel: no
+     * view selection code in it -- a patch that needs one goes to the follow-up launch, which is the general kernel */
+    const bool fast = !lat && follow_out != nullptr && hyp == nullptr;
     if (lat) {
-        if (eight) hipLaunchKernelGGL((k_optimize<Lay<8, 8> >), dim3(grid_blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_optimize<Lay<16, 4> >), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        if (eight) hipLaunchKernelGGL((k_optimize<Lay<8, 8>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<16, 4>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    } else if (fast) {
+        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
     } else {
-        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8> >), dim3(grid_blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_optimize<Lay<1, 4> >), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
     }
 }
 
