@@ -33,3 +33,15 @@ rm -f $OUT/s1/bench_kernel_trace.csv $OUT/s3/bench_kernel_trace.csv
 find $OUT -name "*_kernel_trace.csv" -path "*pmc*" -delete
 du -sh $OUT
 cat $OUT/bench_driver.json $OUT/bench_default.json $OUT/bench_1thread.json $OUT/bench_1thread_5steps.json | cut -c1-600
+# a round trace of one lone C3 call, the front-kernel patch probe, the drop-in app on the scene on disk
+timeout -s KILL 120 python tools/trace_c3.py > $OUT/round_trace_c3.txt 2>&1
+timeout -s KILL 200 python tools/patch_probe.py > $OUT/patch_probe.txt 2>&1
+timeout -s KILL 300 python tools/app_c3_timing.py > $OUT/app_c3_timing.txt 2>&1
+# BASELINE config 4 (the 20 views of ONE scene sharded over the ranks) on the one GPU of this box: two ranks sharing GPU 0
+# (development mode of bench.py, gloo): what a rank's share of the scene costs -- the strong-scaling prediction
+MI_BENCH_SHARE_GPU=1 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29641 \
+  bench.py --gpus 2 --steps 20 --warmup 5 --scaling strong --no-cpu-baseline > $OUT/strong_2ranks_one_gpu.json 2> $OUT/strong_2ranks_one_gpu.err
+MI_BENCH_SHARE_GPU=1 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29642 \
+  bench.py --gpus 4 --steps 20 --warmup 5 --scaling strong --no-cpu-baseline > $OUT/strong_4ranks_one_gpu.json 2> $OUT/strong_4ranks_one_gpu.err
+tail -c 600 $OUT/strong_2ranks_one_gpu.json; tail -c 600 $OUT/strong_4ranks_one_gpu.json
+tail -5 $OUT/app_c3_timing.txt
