@@ -182,6 +182,7 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup):
     outs = [c.alloc_outputs(st, refs, want_normal=False, pinned=True) for c in ctxs]   # reused, page-locked
     share = [n_calls // n_streams + (1 if i < n_calls % n_streams else 0) for i in range(n_streams)]
     acc, last, t_calls = {}, {}, [0.0] * n_streams
+    t_go = [0.0]
     lock = threading.Lock()
     warmed, go = threading.Barrier(n_streams + 1), threading.Barrier(n_streams + 1)
 
@@ -201,6 +202,9 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup):
                     last["shape"] = r[0]["depth"].shape
                 for k, v in c.last_stats.items():
                     acc[k] = acc.get(k, 0) + v
+                # how the library batched the timed calls: (calls merged into the batch this call ran, its host clock)
+                acc.setdefault("_batches", []).append((int(c.last_stats.get("n_merged_calls", 0)), round(c.last_stats.get("ms_total", 0.0), 1),
+                                                       round(1000.0 * (time.perf_counter() - t_go[0]), 1)))
 
     threads = [threading.Thread(target=worker, args=(i, c, o, n)) for i, (c, o, n) in enumerate(zip(ctxs, outs, share))]
     for t in threads:
@@ -208,11 +212,14 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup):
     warmed.wait()
     coll.barrier()
     t0 = time.perf_counter()
+    t_go[0] = t0
     go.wait()
     for t in threads:
         t.join()
     coll.barrier()
     elapsed = coll.max(time.perf_counter() - t0)
+    batches = acc.pop("_batches", [])
+    last["batches"] = sorted(b for b in batches if b[0] > 0)      # (calls in the batch, ms of the batch, ms since the start when it returned)
     return elapsed, acc, last
 
 
@@ -422,6 +429,8 @@ def main():
                        # (mi_dmrecon_reconstruct; MI_DMRECON_MERGE_CALLS=0 switches it off): how large the batches were
                        "library_batches": int(n_calls - acc.get("merged_into_other_call", 0)),
                        "views_per_library_batch": round(n_maps_rank / max(1, n_calls - acc.get("merged_into_other_call", 0)), 1),
+                       # (calls merged, batch ms, ms after the start of the timed region at which it returned), per batch
+                       "library_batch_log": last.get("batches", [])[:16],
                        "mean_fill": round(fill, 4)},
             "roofline": roof,
         }

@@ -147,6 +147,9 @@ std::atomic<int> g_active_calls[MI_MAX_DEVICES];
 std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 /* MI_DMRECON_FRONT defaults: entries per reference view (average over the batch) below which the rest of the
  * propagation goes to the front kernel, for a call alone on its GPU / next to other calls (BatchRun::tail_rounds) */
+#ifndef MI_FOLLOW_LAT_DEFAULT
+#define MI_FOLLOW_LAT_DEFAULT 0
+#endif
 #define MI_FRONT_ALONE 2
 #define MI_FRONT_SHARED 1000000
 #define MI_FRONT_BATCH 48
@@ -1334,8 +1337,17 @@ int BatchRun::bulk_rounds(bool& to_tail) {
             unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
             D->optimize(S, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr,
                         n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->d_follow.p, fcnt);
-            D->optimize(S, 1, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
-                        c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->d_follow.p, fcnt, nullptr, nullptr);
+            /* The follow-up list is about a fifth of the round's list.  In the throughput layout its launch is never
+             * shorter than one wavefront of 16 patches with up to three attempts in a row (0.25-0.5 ms, measured, however
+             * few entries); below MI_DMRECON_FOLLOW_LAT entries in the round it runs in the latency layout instead
+             * (one patch per wavefront: 10 000 entries in 0.26 ms). */
+            static const unsigned FOLLOW_LAT = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW_LAT"); return e ? (unsigned)std::atoi(e) : (unsigned)MI_FOLLOW_LAT_DEFAULT; }();
+            if (n_work < FOLLOW_LAT)
+                D->optimize(S, 16, std::min(16384u, std::max(256u, n_work / 4)), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+                            c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->d_follow.p, fcnt, nullptr, nullptr);
+            else
+                D->optimize(S, 1, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+                            c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->d_follow.p, fcnt, nullptr, nullptr);
             ++n_launch;
         }
         ev.end(S);

@@ -35,10 +35,9 @@ def short(name):
 
 
 def family(k):
-    k = k.split("::")[-1]
-    if k.startswith("k_tail") or k.startswith("k_front<") or k == "k_front":
+    if "k_tail<" in k or "k_front<" in k:
         return "k_tail + k_front (tail rounds)"
-    if k.startswith("k_optimize"):
+    if "k_optimize<" in k:
         return "k_optimize<1> (host-visible rounds)"
     return None
 
