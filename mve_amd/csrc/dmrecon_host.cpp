@@ -147,9 +147,6 @@ std::atomic<int> g_active_calls[MI_MAX_DEVICES];
 std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 /* MI_DMRECON_FRONT defaults: entries per reference view (average over the batch) below which the rest of the
  * propagation goes to the front kernel, for a call alone on its GPU / next to other calls (BatchRun::tail_rounds) */
-#ifndef MI_FOLLOW_LAT_DEFAULT
-#define MI_FOLLOW_LAT_DEFAULT 0
-#endif
 #define MI_FRONT_ALONE 2
 #define MI_FRONT_SHARED 1000000
 #define MI_FRONT_BATCH 48
@@ -1337,17 +1334,8 @@ int BatchRun::bulk_rounds(bool& to_tail) {
             unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
             D->optimize(S, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr,
                         n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->d_follow.p, fcnt);
-            /* The follow-up list is about a fifth of the round's list.  In the throughput layout its launch is never
-             * shorter than one wavefront of 16 patches with up to three attempts in a row (0.25-0.5 ms, measured, however
-             * few entries); below MI_DMRECON_FOLLOW_LAT entries in the round it runs in the latency layout instead
-             * (one patch per wavefront: 10 000 entries in 0.26 ms). */
-            static const unsigned FOLLOW_LAT = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW_LAT"); return e ? (unsigned)std::atoi(e) : (unsigned)MI_FOLLOW_LAT_DEFAULT; }();
-            if (n_work < FOLLOW_LAT)
-                D->optimize(S, 16, std::min(16384u, std::max(256u, n_work / 4)), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
-                            c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->d_follow.p, fcnt, nullptr, nullptr);
-            else
-                D->optimize(S, 1, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
-                            c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->d_follow.p, fcnt, nullptr, nullptr);
+            D->optimize(S, 1, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
+                        c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->d_follow.p, fcnt, nullptr, nullptr);
             ++n_launch;
         }
         ev.end(S);
@@ -1672,7 +1660,10 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
                            mi_dmrecon_stats* stats) {
     /* (read per call: tests switch them) */
     const bool MERGE = [] { const char* e = std::getenv("MI_DMRECON_MERGE_CALLS"); return e ? std::atoi(e) != 0 : true; }();
-    const int MAX_RUNNING = 2;                               /* batches of one scene in flight at a time */
+    /* Batches of one scene in flight at a time.  Two, measured: their host-visible rounds interleave (a launch of one
+     * fills the drain of the other's and its host round trip) -- taking turns in phase A instead costs 15 % at the
+     * bench's plan, four in flight 30 % */
+    const int MAX_RUNNING = 2;
     const int WINDOW_US = [] { const char* e = std::getenv("MI_DMRECON_MERGE_WINDOW_US"); return e ? std::max(0, std::atoi(e)) : 150; }();
     if (!MERGE || progress || !c || !st || !ref_views || !maps || n_refs <= 0)
         return reconstruct_batch(c, st, n_refs, ref_views, maps, progress, status_out, stats);

@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <deque>
 #include <memory>
+#include <cstdio>
 #include <cstdlib>
 #include <ctime>
 #include <iostream>
@@ -45,6 +46,23 @@
 MVS_NAMESPACE_BEGIN
 
 namespace {
+
+/* MI_DMRECON_TRACE: where the host side of a run spends its time (stderr, milliseconds since the first line) */
+bool tracing() { static bool const on = std::getenv("MI_DMRECON_TRACE") != nullptr; return on; }
+double trace_ms()
+{
+    static std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+void trace(char const* what, double since_ms, long n = -1)
+{
+    if (!tracing()) return;
+    double const now = trace_ms();
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (n >= 0) std::fprintf(stderr, "[mvs::DMRecon shim] t=%9.2f ms  %-34s %9.2f ms  (%ld)\n", now, what, now - since_ms, n);
+    else std::fprintf(stderr, "[mvs::DMRecon shim] t=%9.2f ms  %-34s %9.2f ms\n", now, what, now - since_ms);
+}
 
 [[noreturn]] void raise_from(int rc)
 {
@@ -183,8 +201,10 @@ private:
             }
         });
         mi_dmrecon_stats stats;
+        double const t_call = trace_ms();
         int rc = mi_dmrecon_reconstruct(ex, &batch[0]->st, (int32_t)n, refs.data(), maps.data(), prog.data(), status.data(), &stats);
         std::string msg = rc != 0 ? mi_dmrecon_last_error() : "";
+        trace("batch reconstructed (views)", t_call, (long)n);
         running.store(false);
         relay.join();
         for (std::size_t i = 0; i < n; ++i) {
@@ -280,6 +300,7 @@ private:
     static void upload(Generation& g)
     {
         std::size_t const ns = g.slots.size();
+        double t_mark = trace_ms();
         std::vector<mi_dmrecon_ctx*> ctxs(ns, nullptr);
         std::vector<std::unique_ptr<std::mutex> > ctx_mu;
         for (std::size_t s = 0; s < ns; ++s) {
@@ -287,6 +308,7 @@ private:
             int rc = mi_dmrecon_ctx_create(g.slots[s]->device, &ctxs[s]);
             if (rc != 0) { for (std::size_t k = 0; k < s; ++k) mi_dmrecon_ctx_destroy(ctxs[k]); raise_from(rc); }
         }
+        trace("contexts created (HIP start-up)", t_mark, (long)ns); t_mark = trace_ms();
         mve::Scene::ViewList const& views(g.scene->get_views());
         /* A decoded image stays alive until the copies enqueued from it have run (mi_dmrecon_sync).  The views go
          * through in windows of a few per decoding thread: decode + enqueue in parallel, then one sync of every GPU,
@@ -342,6 +364,7 @@ private:
             for (std::size_t s = 0; s < ns; ++s) mi_dmrecon_ctx_destroy(ctxs[s]);
             std::rethrow_exception(first_exc);
         }
+        trace("views decoded + staged", t_mark, (long)views.size()); t_mark = trace_ms();
         mve::Bundle::Features const& feats = g.scene->get_bundle()->get_features();
         std::vector<float> pos(feats.size() * 3);
         std::vector<int32_t> off(feats.size() + 1, 0), ids;
@@ -363,6 +386,7 @@ private:
             }
         }
         for (std::size_t s = 0; s < ns; ++s) g.slots[s]->parent = ctxs[s];
+        trace("features set", t_mark, (long)feats.size());
     }
 
     static std::size_t env_threads()
@@ -391,6 +415,7 @@ DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
         throw std::invalid_argument("Invalid scale factor");
     if (settings.imageEmbedding.empty())
         throw std::invalid_argument("Invalid image embedding");
+    double const t_ctor = trace_ms();
     try {
         this->scene->get_bundle();
     } catch (std::exception& e) {
@@ -416,6 +441,7 @@ DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
     }
     this->width = w;
     this->height = h;
+    trace("DMRecon constructed (view)", t_ctor, (long)settings.refViewNr);
     if (!settings.quiet)
         std::cout << "scaled image size: " << this->width << " x " << this->height << std::endl;
 }
@@ -465,7 +491,10 @@ DMRecon::start()
     Slot* sl = std::static_pointer_cast<Attachment>(this->slot)->slot;
     Request req;
     req.st = st; req.ref = ref; req.maps = maps; req.prog = &mp;
+    double const t_submit = trace_ms();
     sl->submit(req);                            /* returns when the batch this view ended up in has finished */
+    trace("start(): request served (view)", t_submit, (long)ref);
+    double const t_save = trace_ms();
     int rc = req.rc;
     running.store(false);
     relay.join();
@@ -533,6 +562,7 @@ DMRecon::start()
         view->set_image(undist, name);
     }
     progress.status = RECON_IDLE;
+    trace("start(): images set (view)", t_save, (long)ref);
     if (!settings.quiet) {
         float percent = (float)progress.filled / (float)(width * height);
         std::cout << "Filled " << progress.filled << " pixels, i.e. "
