@@ -368,6 +368,8 @@ def main():
     share_gpu = world > 1 and os.environ.get("MI_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
+        # processes that share a GPU cannot see each other's calls: no front teams (their workgroups must all be resident)
+        os.environ.setdefault("MI_DMRECON_FRONT_TEAM", "1")
     coll = Collective("gloo" if share_gpu else "nccl", local_rank)
 
     scene = make_scene(p)                                   # synthetic, deterministic, identical on every rank

@@ -131,6 +131,7 @@ typedef struct mi_dmrecon_stats {
     int64_t n_front_rounds_sum;  /* ... summed over the views */
     int64_t n_front_attempts;    /* patch optimisations run there (speculative ones included) */
     int64_t n_front_entries;     /* list entries summed over all rounds of all views */
+    int64_t front_team;          /* workgroups per view in that launch (> 1 only for a call that has the GPU to itself) */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);

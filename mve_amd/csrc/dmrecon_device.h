@@ -24,7 +24,13 @@
  *   first_round, first_round + 1, ... until its front is empty (lists alternate between the two buffer pairs).
  *   job_stats[4 j ..]: rounds run, attempts run, sum of list sizes, 100 MHz ticks (zeroed by the caller).
  *   Same maps as one `tail` launch per round.
+ *   team > 1: that many workgroups per view (k_front<TEAM>): the attempts of a round are dealt out over them, every
+ *   member runs the whole round otherwise (same numbering, same state writes) and fetches the others' results from the
+ *   view's mailbox: mail = MI_FRONT_MAIL_WORDS 8-byte words per view, team_flags = MI_FRONT_TEAM_MAX words per view,
+ *   zeroed by the caller.  All n_jobs * team workgroups must be resident at once (the caller keeps it <= the CUs).
  */
+#define MI_FRONT_TEAM_MAX 32
+#define MI_FRONT_MAIL_WORDS (2 * 1024 * 12)
 struct MiDeviceApi {
     int filter_width;
     void (*optimize)(hipStream_t s, int lanes_per_view, unsigned grid_blocks, const DevJob* jobs, const DevView* views,
@@ -44,7 +50,7 @@ struct MiDeviceApi {
                   const DevEntry* list, const DevResult* list_results, const unsigned* list_n,
                   DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
                   const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
-                  DevCounters* counters);
+                  DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags);
 };
 const MiDeviceApi* mi_device_api(int filter_width);
 extern unsigned long long* mi_debug_tbuf;

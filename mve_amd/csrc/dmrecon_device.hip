@@ -1759,7 +1759,8 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
 #ifndef MI_FRONT_WAVES
 #define MI_FRONT_WAVES 8          /* wavefronts of a front workgroup = patch optimisations of a view in flight */
 #endif
-#define MI_FRONT_QCAP 128
+#define MI_FRONT_QCAP 256
+#define MI_FRONT_GRAN 12          /* 8-byte granules {word, pass tag} of one attempt's result in a team's mailbox */
 static_assert(MI_FRONT_WAVES <= MI_LAT_SLOTS, "the latency layout's LDS holds one patch per wavefront of a front workgroup");
 struct FrontArgs {
     OptArgs o;                    /* jobs, views, lut, st, counters; o.round = the first round to run */
@@ -1769,6 +1770,10 @@ struct FrontArgs {
     const unsigned* job_count;    /* [n_jobs] entries of view j in work[0] */
     unsigned* job_stats;          /* [n_jobs][4]: rounds run, attempts run, sum of list sizes, 100 MHz ticks */
     int max_rounds;               /* a view stops here (int32 stamps would last; a guard against an endless front) */
+    /* TEAM: `team` workgroups per view (consecutive blocks) */
+    int team;
+    unsigned long long* mail;     /* [n_jobs][2][MI_FRONT_QCAP * 4][MI_FRONT_GRAN] */
+    unsigned* team_flags;         /* [n_jobs][MI_FRONT_TEAM_MAX], zeroed before the launch */
 };
 struct FQ {                       /* a pixel this round may rewrite */
     int xy, src;                  /* qx | qy << 16; (unused) index of its best source in the previous list */
@@ -1781,18 +1786,43 @@ struct FQ {                       /* a pixel this round may rewrite */
     unsigned done; int next;      /* directions consumed; next rank to consume (= candidates: finished) */
 };
 struct FR { PatchResult r; unsigned n_eval, n_pass; int ready; };
+static_assert(sizeof(PatchResult) == 40 && offsetof(FR, n_eval) == 40 && offsetof(FR, n_pass) == 44 && offsetof(FR, ready) == 48,
+              "a team's mailbox carries the first MI_FRONT_GRAN words of an FR");
 __shared__ FQ g_fq[MI_FRONT_QCAP];
 __shared__ FR g_fr[MI_FRONT_QCAP][4];
 __shared__ unsigned g_fatt[MI_FRONT_QCAP * 4];
-__shared__ unsigned g_fcnt[8];    /* 0: FQs, 1: attempts of the pass, 2: attempts taken, 3: entries of the next list, 4: sum of candidates,
-                                   * 5: newly filled pixels of the round */
+__shared__ unsigned g_fcnt[8];    /* 2: attempts taken, 5: newly filled pixels of the round, 6: the view's flags, 7: team: abort */
+__shared__ unsigned g_ftmp[4];
 
-template <int NV>
+/* exclusive prefix sum of v over the threads tid < MI_FRONT_QCAP (the first wavefronts; the others pass 0) in thread order,
+ * the sum of all in `total` -- called by the WHOLE workgroup (two barriers inside).  Numbering by prefix instead of by
+ * atomic counter: the workgroups of a team number pixels, attempts and list entries identically. */
+__device__ __forceinline__ unsigned front_scan(unsigned v, int tid, unsigned& total) {
+    constexpr int NW = MI_FRONT_QCAP / WAVE;
+    static_assert(NW >= 1 && NW <= 4 && NW <= MI_FRONT_WAVES && MI_FRONT_QCAP % WAVE == 0, "front_scan: g_ftmp holds four wavefront sums");
+    const int lane = tid & (WAVE - 1), wave = tid >> 6;
+    unsigned x = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { const unsigned y = __shfl_up(x, d); if (lane >= d) x += y; }
+    if (lane == WAVE - 1 && wave < NW) g_ftmp[wave] = x;
+    __syncthreads();
+    unsigned before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const unsigned s = g_ftmp[w]; all += s; if (w < wave) before += s; }
+    total = all;
+    __syncthreads();
+    return x - v + before;
+}
+
+template <int NV, bool TEAM>
 __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu((MI_FRONT_WAVES >= 8 ? MI_FRONT_WAVES / 4 : 1), (MI_FRONT_WAVES >= 8 ? MI_FRONT_WAVES / 4 : 2)))) void k_front(FrontArgs t) {
     typedef typename LatLay<NV>::type LL;
+    typedef __attribute__((address_space(1))) unsigned long long* gmail_t;
+    typedef __attribute__((address_space(1))) unsigned* gflag_t;
     const OptArgs& a = t.o;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int jobi = blockIdx.x;
+    const int T = TEAM ? t.team : 1;
+    const int jobi = TEAM ? (int)blockIdx.x / T : (int)blockIdx.x, member = TEAM ? (int)blockIdx.x % T : 0;
     const DevJob* job = a.jobs + jobi;
     unsigned n_prev = t.job_count[jobi];
     if (n_prev == 0) return;
@@ -1802,23 +1832,29 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
     const int W = job->w, H = job->h;
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;   /* per lane; summed at the end */
     unsigned st_rounds = 0, st_att = 0, st_list = 0;
+    unsigned epoch = 0;                                                     /* TEAM: exchanges so far (the same in every member) */
+    bool abort = false;
     int cur = 0;
     int round = a.round;
+    if (tid == 0) g_fcnt[7] = 0;
     __syncthreads();
-    for (; n_prev != 0 && round < t.max_rounds; ++round) {
-        /* a footprint exception (patch_sampler.cc:78-82) or the host's cancel ends the view: one lane looks, all agree */
+    for (; n_prev != 0 && round < t.max_rounds && !abort; ++round) {
+        /* a footprint exception (patch_sampler.cc:78-82) or the host's cancel ends the view: one lane looks, all agree
+         * (the members of a team see the flag at different times: they tell each other at the next exchange) */
         if (tid == 0) g_fcnt[6] = (unsigned)__hip_atomic_load((gi32_t)&job->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (g_fcnt[6] != 0) break;
+        if (!TEAM && g_fcnt[6] != 0) break;
         const DevEntry* pw = t.work[cur] + off; const DevResult* prs = t.results[cur] + off;
         DevEntry* ow = t.work[cur ^ 1] + off; DevResult* ors = t.results[cur ^ 1] + off;
-        if (tid == 0) { g_fcnt[3] = 0; g_fcnt[5] = 0; }
+        if (tid == 0) g_fcnt[5] = 0;
         ++st_rounds; st_list += n_prev;
-        for (unsigned base = 0; base < 4u * n_prev; base += MI_FRONT_QCAP) {
-            if (tid == 0) { g_fcnt[0] = 0; g_fcnt[1] = 0; g_fcnt[2] = 0; g_fcnt[4] = 0; }
-            __syncthreads();
+        unsigned n_next = 0;                                                /* entries of this round's list so far */
+        for (unsigned base = 0; base < 4u * n_prev && !abort; base += MI_FRONT_QCAP) {
+            if (tid == 0) g_fcnt[2] = 0;
             /* ---- 1. one lane per (entry, direction) */
             const unsigned cand = base + (unsigned)tid;
+            bool mine = false; int my_cand = 0;
+            FQ Q;
             if (tid < MI_FRONT_QCAP && cand < 4u * n_prev) {
                 const unsigned ep = cand >> 2, k = cand & 3u;
                 const DevResult* pr = prs + ep;
@@ -1849,52 +1885,56 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                             if (bi >= 0) { order |= (unsigned)bi << (2 * s); ++n_cand; left &= ~(1u << bi); }
                         }
                         if (n_cand > 0 && (int)(order & 3u) == (int)(k ^ 1u)) {        /* I am q's best source: q is mine */
-                            const unsigned qi = atomicAdd(&g_fcnt[0], 1u);
-                            atomicAdd(&g_fcnt[4], (unsigned)n_cand);
-                            FQ Q;
+                            mine = true; my_cand = n_cand;
                             Q.xy = qx | (qy << 16); Q.src = (int)ep; Q.own = own;
                             Q.info = order | ((unsigned)n_cand << 8) | (me.one ? 1u << 11 : 0u)
                                    | (nf[0].one ? 1u << 12 : 0u) | (nf[1].one ? 1u << 13 : 0u) | (nf[2].one ? 1u << 14 : 0u) | (nf[3].one ? 1u << 15 : 0u);
                             Q.nconf[0] = nf[0].conf; Q.nconf[1] = nf[1].conf; Q.nconf[2] = nf[2].conf; Q.nconf[3] = nf[3].conf;
                             Q.hd = GF(&pr->depth); Q.hi = GF(&pr->dzI); Q.hj = GF(&pr->dzJ); Q.hv = GU(&pr->views); Q.hv_hi = GU(&pr->views_hi);
                             Q.best = own; Q.fin = -1; Q.done = 0; Q.next = 0;
-                            g_fq[qi] = Q;
-                            g_fr[qi][0].ready = 0; g_fr[qi][1].ready = 0; g_fr[qi][2].ready = 0; g_fr[qi][3].ready = 0;
                         }
                     }
                 }
             }
+            unsigned tot;
+            const unsigned qi0 = front_scan(mine ? (1u | ((unsigned)my_cand << 16)) : 0u, tid, tot) & 0xFFFFu;
+            const unsigned nq = tot & 0xFFFFu, sum_cand = tot >> 16;
+            if (mine) {
+                g_fq[qi0] = Q;
+                g_fr[qi0][0].ready = 0; g_fr[qi0][1].ready = 0; g_fr[qi0][2].ready = 0; g_fr[qi0][3].ready = 0;
+            }
             __syncthreads();
-            const unsigned nq = g_fcnt[0];
-            /* the first pass: every attempt at once if they fit the workgroup, else the best candidate of every pixel */
-            const bool all_at_once = g_fcnt[4] <= (unsigned)MI_FRONT_WAVES;
-            if ((unsigned)tid < nq) {
-                const int n_cand = (int)((g_fq[tid].info >> 8) & 7u);
-                const int cnt = all_at_once ? n_cand : 1;
-                const unsigned pos = atomicAdd(&g_fcnt[1], (unsigned)cnt);
-                for (int s = 0; s < cnt; ++s) g_fatt[pos + s] = (unsigned)tid | ((unsigned)s << 16);
+            /* the first pass: every attempt at once if they fit the wavefronts of the view, else the best candidate of every pixel */
+            const bool all_at_once = sum_cand <= (unsigned)(T * MI_FRONT_WAVES);
+            unsigned natt;
+            {
+                const unsigned cnt = (unsigned)tid < nq ? (all_at_once ? ((g_fq[tid].info >> 8) & 7u) : 1u) : 0u;
+                const unsigned pos = front_scan(cnt, tid, natt);
+                for (unsigned s = 0; s < cnt; ++s) g_fatt[pos + s] = (unsigned)tid | (s << 16);
             }
             for (;;) {
                 __syncthreads();
-                const unsigned natt = g_fcnt[1];
                 if (natt == 0) break;
-                /* ---- 2. the attempts of this pass, one per wavefront */
+                if (TEAM) ++epoch;
+                gmail_t box = TEAM ? (gmail_t)(t.mail + ((size_t)jobi * 2 + (epoch & 1u)) * (MI_FRONT_QCAP * 4) * MI_FRONT_GRAN) : nullptr;
+                /* ---- 2. the attempts of this pass, one per wavefront; a team deals them out by index */
                 for (;;) {
-                    unsigned idx = 0;
-                    if (lane == 0) idx = atomicAdd(&g_fcnt[2], 1u);
-                    idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+                    unsigned kk = 0;
+                    if (lane == 0) kk = atomicAdd(&g_fcnt[2], 1u);
+                    kk = (unsigned)__builtin_amdgcn_readfirstlane((int)kk);
+                    const unsigned idx = (unsigned)member + kk * (unsigned)T;
                     if (idx >= natt) break;
                     const unsigned att = g_fatt[idx];
                     const int qi = (int)(att & 0xFFFFu), s = (int)(att >> 16);
-                    const FQ& Q = g_fq[qi];
-                    const int qx = Q.xy & 0xFFFF, qy = Q.xy >> 16;
-                    float hd = Q.hd, hi = Q.hi, hj = Q.hj; unsigned long long hv = view_set(Q.hv, Q.hv_hi);
+                    const FQ& Qa = g_fq[qi];
+                    const int qx = Qa.xy & 0xFFFF, qy = Qa.xy >> 16;
+                    float hd = Qa.hd, hi = Qa.hi, hj = Qa.hj; unsigned long long hv = view_set(Qa.hv, Qa.hv_hi);
                     if (s > 0) {
                         /* a later candidate's hypothesis = its source's frozen state */
-                        const int j = (int)((Q.info >> (2 * s)) & 3u);
+                        const int j = (int)((Qa.info >> (2 * s)) & 3u);
                         const int q = qy * W + qx;
                         const int p = j == 0 ? q - 1 : j == 1 ? q + 1 : j == 2 ? q - W : q + W;
-                        const bool one = ((Q.info >> (12 + j)) & 1u) != 0;
+                        const bool one = ((Qa.info >> (12 + j)) & 1u) != 0;
                         hd = GF((one ? job->depth1 : job->depth) + p);
                         hi = GF((one ? job->dz1 : job->dz) + 2 * p); hj = GF((one ? job->dz1 : job->dz) + 2 * p + 1);
                         hv = load_view_set<NV>(job, one, p);
@@ -1921,21 +1961,60 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                     }
 #endif
                     ce = LL::rows_to_lane0(ce); cp = LL::rows_to_lane0(cp);
-                    if (lane == 0) { FR& o = g_fr[qi][s]; o.r = r; o.n_eval = ce; o.n_pass = cp; o.ready = 1; ++st_att; }
+                    if (lane == 0) {
+                        FR& o = g_fr[qi][s]; o.r = r; o.n_eval = ce; o.n_pass = cp; o.ready = 1; ++st_att;
+                        if (TEAM) {
+                            /* to the other members: every word with the pass's tag in one 8-byte agent-scope store (write-through) */
+                            const unsigned* wsrc = (const unsigned*)&o;
+                            gmail_t rec = box + (size_t)idx * MI_FRONT_GRAN;
+#pragma unroll
+                            for (int k = 0; k < MI_FRONT_GRAN; ++k)
+                                __hip_atomic_store(rec + k, ((unsigned long long)epoch << 32) | wsrc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+                if (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* my results have left before my flag does */
+                __syncthreads();
+                if (tid == 0) g_fcnt[2] = 0;
+                if (TEAM) {
+                    /* ---- the exchange: my flag = this pass (+ "my view has ended"), wait for every member's, fetch their results */
+                    gflag_t fl = (gflag_t)(t.team_flags + (size_t)jobi * MI_FRONT_TEAM_MAX);
+                    if (tid == 0) __hip_atomic_store(fl + member, epoch | (g_fcnt[6] != 0 ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid < T) {
+                        unsigned f = 0; bool seen = false;
+                        for (int spin = 0; spin < (1 << 21); ++spin) {
+                            f = __hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((f & 0x7FFFFFFFu) == epoch) { seen = true; break; }
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                        if (!seen) { atomicOr(&g_fcnt[7], 2u); atomicOr(&a.counters->error_flags, 8u); }
+                        else if (f & 0x80000000u) atomicOr(&g_fcnt[7], 1u);
+                    }
+                    __syncthreads();
+                    if (g_fcnt[7] != 0) { abort = true; break; }
+                    for (unsigned u = (unsigned)tid; u < natt * MI_FRONT_GRAN; u += MI_FRONT_WAVES * WAVE) {
+                        const unsigned idx = u / MI_FRONT_GRAN, k = u - idx * MI_FRONT_GRAN;
+                        if ((int)(idx % (unsigned)T) == member) continue;
+                        const unsigned long long g = __hip_atomic_load(box + (size_t)idx * MI_FRONT_GRAN + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(g >> 32) != epoch) err |= 16u;          /* cannot happen: the flag came after the results */
+                        const unsigned att = g_fatt[idx];
+                        FR& o = g_fr[att & 0xFFFFu][att >> 16];
+                        ((unsigned*)&o)[k] = (unsigned)g;
+                        if (k == 0) o.ready = 1;
+                    }
                 }
                 __syncthreads();
-                if (tid == 0) { g_fcnt[1] = 0; g_fcnt[2] = 0; }
-                __syncthreads();
                 /* ---- 3. the reference's sequential rule, one lane per pixel; what it still asks for is the next pass */
+                bool again = false; int again_rank = 0;
                 if ((unsigned)tid < nq) {
-                    FQ& Q = g_fq[tid];
-                    const int n_cand = (int)((Q.info >> 8) & 7u);
-                    int next = Q.next;
+                    FQ& Qr = g_fq[tid];
+                    const int n_cand = (int)((Qr.info >> 8) & 7u);
+                    int next = Qr.next;
                     if (next < n_cand) {
-                        float best = Q.best; int fin = Q.fin; unsigned done = Q.done;
+                        float best = Qr.best; int fin = Qr.fin; unsigned done = Qr.done;
                         while (next < n_cand) {
-                            const int j = (int)((Q.info >> (2 * next)) & 3u);
-                            const float bc = Q.nconf[j];
+                            const int j = (int)((Qr.info >> (2 * next)) & 3u);
+                            const float bc = Qr.nconf[j];
                             if (best > bc) { next = n_cand; break; }                   /* dmrecon.cc:371 (and every later one) */
                             const FR& c = g_fr[tid][next];
                             if (!c.ready) break;
@@ -1944,44 +2023,50 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                             if (c.r.conf > 0.f && best < c.r.conf) { best = c.r.conf; fin = next; }   /* dmrecon.cc:378,391 */
                             ++next;
                         }
-                        Q.best = best; Q.fin = fin; Q.done = done; Q.next = next;
-                        if (next < n_cand) g_fatt[atomicAdd(&g_fcnt[1], 1u)] = (unsigned)tid | ((unsigned)next << 16);
+                        Qr.best = best; Qr.fin = fin; Qr.done = done; Qr.next = next;
+                        if (next < n_cand) { again = true; again_rank = next; }
                     }
                 }
+                const unsigned pos = front_scan(again ? 1u : 0u, tid, natt);
+                if (again) g_fatt[pos] = (unsigned)tid | ((unsigned)again_rank << 16);
             }
-            /* ---- the accepted pixels: this round's list, the other state slot */
-            if ((unsigned)tid < nq) {
-                const FQ& Q = g_fq[tid];
-                if (Q.fin >= 0) {
-                    const PatchResult fin = g_fr[tid][Q.fin].r;
-                    const int qx = Q.xy & 0xFFFF, qy = Q.xy >> 16, q = qy * W + qx;
-                    const unsigned en = atomicAdd(&g_fcnt[3], 1u);
-                    DevEntry we; we.job = jobi; we.xy = Q.xy;
-                    ow[en] = we;
-                    DevResult o;
-                    o.conf = fin.conf; o.depth = fin.depth; o.dzI = fin.dzI; o.dzJ = fin.dzJ;
-                    o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.views_hi = fin.views_hi; o.iters = fin.iters;
-                    o.accepted = 1; o.tried = Q.done;
-                    ors[en] = o;
-                    const bool one = ((Q.info >> 11) & 1u) != 0;                       /* slot holding the old state */
-                    float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
-                    float* cq = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
-                    uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
-                    dp[q] = fin.depth; zp[2 * q] = fin.dzI; zp[2 * q + 1] = fin.dzJ;
-                    np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
-                    cq[q] = fin.conf; vp[q] = fin.views; up[q] = round;
-                    if (NV == 8) (one ? job->views_hi : job->views1_hi)[q] = fin.views_hi;
-                    if (Q.own <= 0.f) { ++n_filled; atomicAdd(&g_fcnt[5], 1u); }
-                }
+            if (abort) break;
+            /* ---- the accepted pixels: this round's list, the other state slot (every member of a team writes them all:
+             * each reads its own copy next round, nobody waits for another's stores) */
+            const bool acc = (unsigned)tid < nq && g_fq[tid].fin >= 0;
+            unsigned n_acc;
+            const unsigned en = n_next + front_scan(acc ? 1u : 0u, tid, n_acc);
+            n_next += n_acc;
+            if (acc) {
+                const FQ& Qw = g_fq[tid];
+                const PatchResult fin = g_fr[tid][Qw.fin].r;
+                const int qx = Qw.xy & 0xFFFF, qy = Qw.xy >> 16, q = qy * W + qx;
+                DevEntry we; we.job = jobi; we.xy = Qw.xy;
+                ow[en] = we;
+                DevResult o;
+                o.conf = fin.conf; o.depth = fin.depth; o.dzI = fin.dzI; o.dzJ = fin.dzJ;
+                o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.views_hi = fin.views_hi; o.iters = fin.iters;
+                o.accepted = 1; o.tried = Qw.done;
+                ors[en] = o;
+                const bool one = ((Qw.info >> 11) & 1u) != 0;                       /* slot holding the old state */
+                float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
+                float* cq = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
+                uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
+                dp[q] = fin.depth; zp[2 * q] = fin.dzI; zp[2 * q + 1] = fin.dzJ;
+                np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
+                cq[q] = fin.conf; vp[q] = fin.views; up[q] = round;
+                if (NV == 8) (one ? job->views_hi : job->views1_hi)[q] = fin.views_hi;
+                if (Qw.own <= 0.f && member == 0) { ++n_filled; atomicAdd(&g_fcnt[5], 1u); }
             }
             __syncthreads();
         }
-        n_prev = g_fcnt[3];
+        n_prev = n_next;
         if (tid == 0 && g_fcnt[5]) atomicAdd(const_cast<uint32_t*>(&job->n_filled), g_fcnt[5]);   /* Progress::filled */
         cur ^= 1;
         __syncthreads();
     }
-    /* counters: per lane so far */
+    /* counters: per lane so far (what the sequential rule counts is the same in every member of a team: the first reports) */
+    if (member != 0) { n_eval = 0; n_pass = 0; n_patch = 0; }
     for (int off2 = 32; off2 > 0; off2 >>= 1) {
         n_eval += __shfl_down(n_eval, off2); n_pass += __shfl_down(n_pass, off2);
         n_patch += __shfl_down(n_patch, off2); n_filled += __shfl_down(n_filled, off2);
@@ -1995,7 +2080,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
         if (err) atomicOr(&a.counters->error_flags, err);
         if (st_att) atomicAdd(&t.job_stats[4 * jobi + 1], st_att);
     }
-    if (tid == 0) {
+    if (tid == 0 && member == 0) {
         t.job_stats[4 * jobi] = st_rounds; t.job_stats[4 * jobi + 2] = st_list;
         t.job_stats[4 * jobi + 3] = (unsigned)(wall_clock64() - t0);
         if (n_prev != 0 && round >= t.max_rounds) atomicOr(&a.counters->error_flags, 8u);    /* the front did not end */
@@ -2430,7 +2515,8 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
                          const DevEntry* list, const DevResult* list_results, const unsigned* list_n,
                          DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
                          const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
-                         DevCounters* counters) {
+                         DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags) {
+    static_assert(MI_FRONT_MAIL_WORDS == 2 * MI_FRONT_QCAP * 4 * MI_FRONT_GRAN, "mailbox size");
     if (n_jobs <= 0) return;
     FrontSplitArgs sp;
     sp.work = list; sp.results = list_results; sp.n_ptr = list_n; sp.owork = work0; sp.oresults = results0;
@@ -2443,8 +2529,14 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.work[0] = work0; t.work[1] = work1; t.results[0] = results0; t.results[1] = results1;
     t.job_off = job_off; t.job_count = job_count; t.job_stats = job_stats; t.max_rounds = max_rounds;
-    if (st.K > 4) hipLaunchKernelGGL((k_front<8>), dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
-    else hipLaunchKernelGGL((k_front<4>), dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
+    t.team = 1; t.mail = nullptr; t.team_flags = nullptr;
+    if (team > 1 && mail && team_flags) {
+        t.team = team > MI_FRONT_TEAM_MAX ? MI_FRONT_TEAM_MAX : team; t.mail = mail; t.team_flags = team_flags;
+        if (st.K > 4) hipLaunchKernelGGL((k_front<8, true>), dim3((unsigned)(n_jobs * t.team)), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
+        else hipLaunchKernelGGL((k_front<4, true>), dim3((unsigned)(n_jobs * t.team)), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
+    }
+    else if (st.K > 4) hipLaunchKernelGGL((k_front<8, false>), dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
+    else hipLaunchKernelGGL((k_front<4, false>), dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
 }
 
 #if MI_FW == 5

@@ -147,9 +147,9 @@ std::atomic<int> g_active_calls[MI_MAX_DEVICES];
 std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 /* MI_DMRECON_FRONT defaults: entries per reference view (average over the batch) below which the rest of the
  * propagation goes to the front kernel, for a call alone on its GPU / next to other calls (BatchRun::tail_rounds) */
-#define MI_FRONT_ALONE 2
-#define MI_FRONT_SHARED 1000000
-#define MI_FRONT_BATCH 48
+#define MI_FRONT_MIN_CAP 256       /* hand-over to k_front: entries per view, at least */
+#define MI_FRONT_PER_TEAM_WG 64    /* ... and per workgroup of a view's team */
+#define MI_FRONT_TEAM_CUS 256     /* workgroups of all teams of a front launch: one per CU */
 struct ActiveCall {
     int dev;
     explicit ActiveCall(int d) : dev(d >= 0 && d < MI_MAX_DEVICES ? d : -1) { if (dev >= 0) g_active_calls[dev].fetch_add(1); }
@@ -244,6 +244,8 @@ struct mi_dmrecon_ctx {
     int stage_flip = 0;
     DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
     DevBuf<unsigned> d_front;                /* k_front: [n_jobs] list offsets | [n_jobs] list sizes | [n_jobs][4] per-view statistics */
+    DevBuf<unsigned long long> d_front_mail; /* k_front teams: a mailbox per view (MI_FRONT_MAIL_WORDS) */
+    DevBuf<unsigned> d_front_flags;          /* ... and MI_FRONT_TEAM_MAX pass flags per view */
     DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
     DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
     TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
@@ -861,7 +863,7 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
     c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release(); c->d_follow.release(); c->d_follow_cnt.release();
-    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release(); c->d_front.release();
+    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release(); c->d_front.release(); c->d_front_mail.release(); c->d_front_flags.release();
     c->d_gvs_feat.release(); c->d_gvs_out.release(); c->d_gvs_base.release(); c->d_gvs_benefit.release(); c->d_gvs_refs.release();
     if (c->h_poll) (void)hipHostFree(c->h_poll);
     if (c->h_dyn) (void)hipHostFree(c->h_dyn);
@@ -1111,7 +1113,7 @@ struct BatchRun {
     /* list + results of the last executed tail round, and their ping-pong partners */
     DevEntry* wcur = nullptr; DevEntry* wnext = nullptr; DevResult* rcur = nullptr; DevResult* rnext = nullptr;
     /* the front kernel (phase C) */
-    bool ran_front = false; int front_first_round = 0;
+    bool ran_front = false; int front_first_round = 0, front_team = 1;
     std::vector<unsigned> front_stats;
     const ActiveCall* active_call = nullptr;   /* reconstruct calls in progress on this GPU */
 
@@ -1126,6 +1128,7 @@ struct BatchRun {
         return hipMemcpy2DAsync(dyn_of(slot), sizeof(JobDyn), (const char*)c->d_jobs.p + offsetof(DevJob, flags), sizeof(DevJob),
                                 sizeof(JobDyn), (size_t)nj, hipMemcpyDeviceToHost, S);
     }
+    void plan_front_team();
     int plan();
     int upload();
     int seed_round();
@@ -1369,19 +1372,21 @@ int BatchRun::tail_rounds(bool& to_front) {
     static const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPECULATE"); return e ? (unsigned)std::atoi(e) : 1024u; }();
     const ActiveCall& active = *active_call;
     /* MI_DMRECON_FRONT=<entries per view> (read per call; 0 = never): hand the rest of the propagation to k_front once
-     * a round's list is down to that many entries per reference view on average.  A front workgroup runs eight patch
-     * optimisations of its view at a time: below ~6 entries per view a view's round is one patch long there (18 us
-     * against 29 us for a k_tail launch), above it rounds take several generations.  Default: 2 for a call that has
-     * the GPU to itself (measured neutral to +1 % on a lone 20-view call: the slowest view decides, and it still has
-     * ~14 entries per round when the average is 8); next to other calls, and for batches of
-     * MI_FRONT_BATCH views or more, the WHOLE tail (from the hand-over round on): a front workgroup occupies one CU
-     * per view and leaves the rest of the GPU to the bulk rounds of the other calls, where ~600 launches per batch
-     * queue behind them -- measured at the bench's plan (four host threads, merged batches of 133 views): 1164 / 1177
-     * depth-maps/s against 980 with one launch per round; a lone call of 100 views: 728 against 714. */
+     * a round's list is down to that many entries per reference view on average.  There every view runs its rounds
+     * at its own pace on 8 x front_team wavefronts; k_tail runs a round of ALL views in one launch as long as its
+     * slowest patch -- better while a view's round has many times more entries than its team has wavefronts
+     * (measured, lone calls of C3: 20 views, team 12: the whole tail 15.2 ms against 8.4 + 12.4 handed over at 64 per
+     * view and 24.4 + 2.3 at 2; 3 views, team 32: 12.2 against 4.8 + 5.8 at 128), hence the default: 64 entries per
+     * wavefront-octet of the team, at least 256 -- which for batches of 48+ views (hand-over round: < 12288 entries)
+     * is the whole tail.  Next to other calls a front workgroup occupies one CU per view and leaves the rest of the
+     * GPU to their bulk rounds, where ~600 launches per batch queue behind them (the bench's plan: 1164-1199
+     * depth-maps/s against 980 with one launch per round); a one-view call there must NOT run its whole propagation
+     * on one workgroup (the drop-in app's first batches did: 800 ms each). */
+    plan_front_team();
     const unsigned FRONT_PER_VIEW = [&] {
         const char* e = std::getenv("MI_DMRECON_FRONT");
         if (e) return (unsigned)std::max(0, std::atoi(e));
-        return (active.count() > 1 || nj >= MI_FRONT_BATCH) ? (unsigned)MI_FRONT_SHARED : (unsigned)MI_FRONT_ALONE;
+        return std::max<unsigned>(MI_FRONT_MIN_CAP, (unsigned)MI_FRONT_PER_TEAM_WG * (unsigned)front_team);
     }();
     const unsigned front_max = FRONT_PER_VIEW * (unsigned)nj;
     wcur = c->d_work.p; wnext = c->d_work2.p; rcur = c->d_results.p; rnext = c->d_results2.p;
@@ -1457,6 +1462,17 @@ int BatchRun::tail_rounds(bool& to_front) {
     }
 }
 
+/* A call that has the GPU to itself gives every view a TEAM of front workgroups (as many as fit the CUs at one workgroup
+ * each: all must be resident, they wait for each other every round).  Not next to other calls: two team launches that
+ * each get a part of the CUs would wait for their missing members until the spin limit ends both (processes that
+ * share a GPU cannot see each other: they must set MI_DMRECON_FRONT_TEAM=1).  MI_DMRECON_FRONT_TEAM=<n> (1 = never). */
+void BatchRun::plan_front_team() {
+    const char* e = std::getenv("MI_DMRECON_FRONT_TEAM");
+    int want = e ? std::atoi(e) : (active_call->count() <= 1 ? MI_FRONT_TEAM_MAX : 1);
+    want = std::min(std::min(want, (int)MI_FRONT_TEAM_MAX), MI_FRONT_TEAM_CUS / std::max(nj, 1));
+    front_team = std::max(1, want);
+}
+
 /* ---- phase C: the rest of the propagation, one persistent workgroup per reference view (k_front, dmrecon_device.hip):
  * each view runs its own rounds from the list the last tail round left, at its own pace, until its front is empty. */
 int BatchRun::front_rounds() {
@@ -1464,9 +1480,16 @@ int BatchRun::front_rounds() {
     HIP_TRY(hipMemcpyAsync(d_off, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));   /* a view's list region = its pixel offset */
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * (size_t)nj * sizeof(unsigned) + nj * sizeof(unsigned), S));
     front_first_round = round;
+    if (front_team > 1) {
+        if (c->d_front_mail.reserve((size_t)nj * MI_FRONT_MAIL_WORDS) || c->d_front_flags.reserve((size_t)nj * MI_FRONT_TEAM_MAX))
+            return fail(MI_DMRECON_EDEVICE, "hipMalloc(front mailboxes) failed");
+        HIP_TRY(hipMemsetAsync(c->d_front_mail.p, 0, (size_t)nj * MI_FRONT_MAIL_WORDS * sizeof(unsigned long long), S));
+        HIP_TRY(hipMemsetAsync(c->d_front_flags.p, 0, (size_t)nj * MI_FRONT_TEAM_MAX * sizeof(unsigned), S));
+    }
     ev.begin(S, EventLog::FRONT, tail_known);
     D->front(S, nj, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, c->d_round_work.p + (round - 1),
-             wnext, rnext, wcur, rcur, d_off, d_cnt, d_stats, round, round + 4 * MI_MAX_ROUNDS, c->d_counters);
+             wnext, rnext, wcur, rcur, d_off, d_cnt, d_stats, round, round + 4 * MI_MAX_ROUNDS, c->d_counters,
+             front_team, front_team > 1 ? c->d_front_mail.p : nullptr, front_team > 1 ? c->d_front_flags.p : nullptr);
     ev.end(S);
     ++n_launch;
     front_stats.assign(4 * (size_t)nj, 0u);
@@ -1544,6 +1567,7 @@ void BatchRun::fill_stats() {
         stats->n_tail_launches = n_tail_launch;
         if (ran_front) {
             stats->n_front_launches = 1;
+            stats->front_team = front_team;
             stats->front_first_round = front_first_round;
             for (int j = 0; j < nj; ++j) {
                 const unsigned* fs = &front_stats[4 * (size_t)j];

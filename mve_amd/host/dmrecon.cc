@@ -110,10 +110,28 @@ public:
         parent = nullptr;
     }
 
+    /* instances attached to this GPU that have not called start() yet: the driver constructs and starts one DMRecon per
+     * OpenMP thread at the same moment -- a thread about to run a batch gives those a moment to file their requests */
+    std::atomic<int> announced{0};
+    void announce() { announced.fetch_add(1); }
+    void withdraw()                            /* the instance starts (its request follows at once) or goes away unstarted */
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        announced.fetch_sub(1);
+        cv.notify_all();
+    }
+
+    void file(Request& r)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        pending.push_back(&r);
+        cv.notify_all();
+    }
+
+    /* returns when the request (filed before) has been served */
     void submit(Request& r)
     {
         std::unique_lock<std::mutex> lk(mu);
-        pending.push_back(&r);
         for (;;) {
             if (r.done) return;
             /* only a thread whose own request is still queued turns executor (one whose request is in flight in
@@ -126,6 +144,14 @@ public:
                     int rc = mi_dmrecon_ctx_fork(parent, &ex);
                     if (rc != 0) { fail_all(rc); continue; }
                     executors.push_back(ex);
+                }
+                /* the threads that have constructed their instance are on their way (microseconds apart): without the
+                 * wait the first to arrive runs a batch of ONE view and the rest a second batch behind it */
+                if (announced.load() > 0) {
+                    auto const until = std::chrono::steady_clock::now() + std::chrono::microseconds(gather_us());
+                    while (announced.load() > 0 && cv.wait_until(lk, until) != std::cv_status::timeout) { }
+                    if (r.done) { idle.push_back(ex); cv.notify_all(); return; }
+                    if (std::find(pending.begin(), pending.end(), &r) == pending.end()) { idle.push_back(ex); cv.notify_all(); continue; }
                 }
                 /* everything pending with the settings of the oldest request, up to max_batch() views */
                 std::vector<Request*> batch;
@@ -159,6 +185,7 @@ private:
     }
     static std::size_t max_executors() { static std::size_t v = env_or("MI_DMRECON_EXECUTORS", 4); return v; }
     static std::size_t max_batch() { static std::size_t v = env_or("MI_DMRECON_MAX_BATCH", 128); return v; }
+    static std::size_t gather_us() { static std::size_t v = env_or("MI_DMRECON_GATHER_US", 2000); return v; }
 
     static bool same_settings(mi_dmrecon_settings const& a, mi_dmrecon_settings const& b)
     {
@@ -313,47 +340,60 @@ private:
         /* A decoded image stays alive until the copies enqueued from it have run (mi_dmrecon_sync).  The views go
          * through in windows of a few per decoding thread: decode + enqueue in parallel, then one sync of every GPU,
          * then the window's images are released -- the host holds one window of decoded images, not the scene.
-         * An exception of a view's decoder (util::Exception for a missing / corrupt image) must not leave the OpenMP
-         * region: the first one is kept and rethrown after the loop, as it would have reached the DMRecon constructor
-         * of that view in the reference. */
+         * An exception of a view's decoder (util::Exception for a missing / corrupt image) must not leave its thread:
+         * the first one is kept and rethrown after the loop, as it would have reached the DMRecon constructor of that
+         * view in the reference. */
         int failed_rc = 0;
         std::string failed_msg;
         std::exception_ptr first_exc;
+        std::mutex err_mu;
+        /* The decoders are plain threads, not an OpenMP team: this runs inside the driver's own parallel region
+         * (apps/dmrecon/dmrecon.cc:285), where a nested `omp parallel` gets ONE thread -- the 20 PNGs of a scene were
+         * decoded one after the other (0.64 s of the drop-in binary's 1.7 s on C3). */
         int const n_threads = (int)std::max<std::size_t>(1, std::min<std::size_t>(env_threads(), views.size()));
         std::size_t const window = (std::size_t)n_threads * 2;
         std::vector<mve::ByteImage::Ptr> keep(views.size());
         for (std::size_t base = 0; base < views.size() && failed_rc == 0 && !first_exc; base += window) {
             std::size_t const end = std::min(views.size(), base + window);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
-            for (std::size_t i = base; i < end; ++i) {
-                try {
-                    if (views[i] == nullptr || !views[i]->is_camera_valid()
-                        || !views[i]->has_image(g.embedding, mve::IMAGE_TYPE_UINT8))
-                        continue;
-                    mve::ByteImage::Ptr img = views[i]->get_byte_image(g.embedding);  /* decode: per view, no shared state */
-                    if (img == nullptr) continue;
-                    keep[i] = img;
-                    mve::CameraInfo const& cam = views[i]->get_camera();
-                    mi_dmrecon_camera mc;
-                    mc.flen = cam.flen; mc.paspect = cam.paspect;
-                    mc.ppoint[0] = cam.ppoint[0]; mc.ppoint[1] = cam.ppoint[1];
-                    for (int k = 0; k < 9; ++k) mc.rot[k] = cam.rot[k];
-                    for (int k = 0; k < 3; ++k) mc.trans[k] = cam.trans[k];
-                    for (std::size_t s = 0; s < ns; ++s) {
-                        std::lock_guard<std::mutex> lock(*ctx_mu[s]);                 /* a context is not thread-safe */
-                        int rc = mi_dmrecon_set_view_async(ctxs[s], (int32_t)i, &mc, img->width(), img->height(), img->channels(),
-                                                           img->get_data_pointer());
-                        if (rc != 0) {
-#pragma omp critical(mi_dmrecon_upload_error)
-                            if (failed_rc == 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
+            std::atomic<std::size_t> next(base);
+            auto work = [&]() {
+                for (;;) {
+                    std::size_t const i = next.fetch_add(1);
+                    if (i >= end) return;
+                    try {
+                        if (views[i] == nullptr || !views[i]->is_camera_valid()
+                            || !views[i]->has_image(g.embedding, mve::IMAGE_TYPE_UINT8))
+                            continue;
+                        mve::ByteImage::Ptr img = views[i]->get_byte_image(g.embedding);  /* decode: per view, no shared state */
+                        if (img == nullptr) continue;
+                        keep[i] = img;
+                        mve::CameraInfo const& cam = views[i]->get_camera();
+                        mi_dmrecon_camera mc;
+                        mc.flen = cam.flen; mc.paspect = cam.paspect;
+                        mc.ppoint[0] = cam.ppoint[0]; mc.ppoint[1] = cam.ppoint[1];
+                        for (int k = 0; k < 9; ++k) mc.rot[k] = cam.rot[k];
+                        for (int k = 0; k < 3; ++k) mc.trans[k] = cam.trans[k];
+                        for (std::size_t s = 0; s < ns; ++s) {
+                            std::lock_guard<std::mutex> lock(*ctx_mu[s]);                 /* a context is not thread-safe */
+                            int rc = mi_dmrecon_set_view_async(ctxs[s], (int32_t)i, &mc, img->width(), img->height(), img->channels(),
+                                                               img->get_data_pointer());
+                            if (rc != 0) {
+                                std::lock_guard<std::mutex> elock(err_mu);
+                                if (failed_rc == 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
+                            }
                         }
+                        views[i]->cache_cleanup();
+                    } catch (...) {
+                        std::lock_guard<std::mutex> elock(err_mu);
+                        if (!first_exc) first_exc = std::current_exception();
                     }
-                    views[i]->cache_cleanup();
-                } catch (...) {
-#pragma omp critical(mi_dmrecon_upload_error)
-                    if (!first_exc) first_exc = std::current_exception();
                 }
-            }
+            };
+            std::vector<std::thread> pool;
+            int const n_here = (int)std::min<std::size_t>((std::size_t)n_threads, end - base);
+            for (int t = 1; t < n_here; ++t) pool.emplace_back(work);
+            work();
+            for (std::size_t t = 0; t < pool.size(); ++t) pool[t].join();
             for (std::size_t s = 0; s < ns; ++s) {
                 int rc = mi_dmrecon_sync(ctxs[s]);
                 if (rc != 0 && failed_rc == 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
@@ -393,7 +433,9 @@ private:
     {
         char const* e = std::getenv("MI_DMRECON_DECODE_THREADS");
         int v = e ? std::atoi(e) : 0;
-        return v > 0 ? (std::size_t)v : 16;
+        if (v > 0) return (std::size_t)v;
+        unsigned const hw = std::thread::hardware_concurrency();
+        return (std::size_t)std::max(1u, std::min(32u, hw ? hw : 16u));
     }
 };
 
@@ -401,6 +443,9 @@ private:
 struct Attachment {
     std::shared_ptr<Generation> gen;
     Slot* slot = nullptr;
+    bool announced = false;                    /* counted in slot->announced until the first start() */
+    void withdraw() { if (announced) { announced = false; slot->withdraw(); } }
+    ~Attachment() { withdraw(); }
 };
 
 }  // namespace
@@ -431,6 +476,7 @@ DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
     std::shared_ptr<Attachment> att = std::make_shared<Attachment>();
     att->gen = Registry::get().generation_for(scene, settings.imageEmbedding);
     att->slot = att->gen->slots[att->gen->next_slot++ % att->gen->slots.size()].get();
+    att->slot->announce(); att->announced = true;
     this->slot = att;
     Slot* slot = att->slot;
     int32_t w = 0, h = 0;
@@ -492,6 +538,9 @@ DMRecon::start()
     Request req;
     req.st = st; req.ref = ref; req.maps = maps; req.prog = &mp;
     double const t_submit = trace_ms();
+    /* filed first, withdrawn second: a gathering thread that sees the count reach zero finds every request */
+    sl->file(req);
+    std::static_pointer_cast<Attachment>(this->slot)->withdraw();
     sl->submit(req);                            /* returns when the batch this view ended up in has finished */
     trace("start(): request served (view)", t_submit, (long)ref);
     double const t_save = trace_ms();

@@ -224,14 +224,18 @@ def test_speculative_tail_equals_sequential_attempts(gpu_ctx, g1_scene, monkeypa
     assert n_seq["n_patch"] == n_spec["n_patch"] and n_seq["n_eval"] == n_spec["n_eval"]
 
 
-@pytest.mark.parametrize("per_view", ["all", "1000000", "2", None])
-def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, monkeypatch, per_view):
+@pytest.mark.parametrize("per_view,team", [("all", "1"), ("1000000", "1"), ("2", "1"), (None, None),
+                                           ("all", "8"), ("all", "3"), ("1000000", "25"), ("2", "2")])
+def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, monkeypatch, per_view, team):
     """k_front (the end of the tail: one persistent workgroup per reference view, each view at its own pace) writes
     exactly what one k_tail launch per round writes: same candidates, same attempts, same sequential rule
     (dmrecon.cc:365-431).  "all": the whole propagation after the first round in k_front (rounds with hundreds of
     entries per view, chunked); then handed over after the bulk rounds, late (two entries per view), and at the default
     threshold.  Five / nine reference views per call; on the hard scene views fail patches, replace local views and
-    end at very different rounds."""
+    end at very different rounds.  team: workgroups per view (the attempts of a round dealt out over them, results
+    exchanged through the view's mailbox; default: eight for a call that has the GPU to itself)."""
+    if team is not None:
+        monkeypatch.setenv("MI_DMRECON_FRONT_TEAM", team)
     for scene, refs in ((g1_scene, [0, 1, 2, 3, 4]), (h1_scene, list(range(9)))):
         gpu_ctx.load_scene(scene)
         monkeypatch.setenv("MI_DMRECON_FRONT", "0")
@@ -250,6 +254,8 @@ def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, m
             if per_view == "all":
                 assert s1["n_front_launches"] == 1 and s1["front_first_round"] == 2 and s1["n_tail_launches"] == 0, s1
                 assert s1["n_front_rounds_max"] > 5 and s1["n_front_views"] == len(refs), s1
+            if s1["n_front_launches"]:
+                assert s1["front_team"] == (min(32, 256 // len(refs)) if team is None else int(team)), s1
             assert s1["n_rounds"] == s0["n_rounds"], (s1["n_rounds"], s0["n_rounds"], s1["front_first_round"])
             for k in ("n_patch", "n_eval", "n_filled"):
                 assert s1[k] == s0[k], k
@@ -258,6 +264,7 @@ def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, m
                     assert np.array_equal(a[k], b[k]), (k, rep)
         monkeypatch.delenv("MI_DMRECON_TAIL_THRESHOLD", raising=False)
     monkeypatch.delenv("MI_DMRECON_FRONT", raising=False)
+    monkeypatch.delenv("MI_DMRECON_FRONT_TEAM", raising=False)
     gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
 
 

@@ -15,4 +15,8 @@ for rep in range(2):
     out = subprocess.run([app, "-s2", "--force", "--progress=silent", sdir], capture_output=True, text=True)
     took = [l for l in out.stdout.splitlines() if "Reconstruction took" in l]
     print("run %d: wall %.2f s rc %d; %s" % (rep, time.time() - t0, out.returncode, took[-1] if took else out.stdout[-300:] + out.stderr[-300:]))
+    if os.environ.get("MI_DMRECON_TRACE"):                  # the shim's host-side phases (mve_amd/host/dmrecon.cc)
+        lines = [l for l in out.stderr.splitlines() if "shim" in l]
+        keep = [l for l in lines if "(view)" not in l] + [l for l in lines if "(view)" in l][:6] + [l for l in lines if "(view)" in l][-6:]
+        print("\n".join(sorted(set(keep), key=lambda l: float(l.split("t=")[1].split("ms")[0]))))
 shutil.rmtree(work)
