@@ -149,7 +149,6 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
  * propagation goes to the front kernel, for a call alone on its GPU / next to other calls (BatchRun::tail_rounds) */
 #define MI_FRONT_MIN_CAP 256       /* hand-over to k_front: entries per view, at least */
 #define MI_FRONT_PER_TEAM_WG 64    /* ... and per workgroup of a view's team */
-#define MI_FRONT_TEAM_CUS 256     /* workgroups of all teams of a front launch: one per CU */
 struct ActiveCall {
     int dev;
     explicit ActiveCall(int d) : dev(d >= 0 && d < MI_MAX_DEVICES ? d : -1) { if (dev >= 0) g_active_calls[dev].fetch_add(1); }
@@ -226,6 +225,7 @@ struct SceneStore {
 
 struct mi_dmrecon_ctx {
     int device = 0;
+    int n_cus = 64;                          /* compute units (queried at creation) */
     hipStream_t stream = nullptr;
     std::shared_ptr<SceneStore> sc;
     DevCounters* d_counters = nullptr;
@@ -828,6 +828,9 @@ void mi_dmrecon_settings_default(mi_dmrecon_settings* s) {          /* libs/dmre
 
 static int create_streams(mi_dmrecon_ctx* c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    /* compute units of this device (a partitioned GPU has fewer than 256): what a front launch with teams may occupy */
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->n_cus = cus;
     return 0;
 }
 
@@ -1469,7 +1472,7 @@ int BatchRun::tail_rounds(bool& to_front) {
 void BatchRun::plan_front_team() {
     const char* e = std::getenv("MI_DMRECON_FRONT_TEAM");
     int want = e ? std::atoi(e) : (active_call->count() <= 1 ? MI_FRONT_TEAM_MAX : 1);
-    want = std::min(std::min(want, (int)MI_FRONT_TEAM_MAX), MI_FRONT_TEAM_CUS / std::max(nj, 1));
+    want = std::min(std::min(want, (int)MI_FRONT_TEAM_MAX), c->n_cus / std::max(nj, 1));
     front_team = std::max(1, want);
 }
 

@@ -136,7 +136,7 @@ public:
             if (r.done) return;
             /* only a thread whose own request is still queued turns executor (one whose request is in flight in
              * another batch just waits for it) */
-            if (std::find(pending.begin(), pending.end(), &r) != pending.end()
+            if (std::find(pending.begin(), pending.end(), &r) != pending.end() && !gathering
                 && (!idle.empty() || executors.size() < max_executors())) {
                 mi_dmrecon_ctx* ex = nullptr;
                 if (!idle.empty()) { ex = idle.back(); idle.pop_back(); }
@@ -148,10 +148,12 @@ public:
                 /* the threads that have constructed their instance are on their way (microseconds apart): without the
                  * wait the first to arrive runs a batch of ONE view and the rest a second batch behind it */
                 if (announced.load() > 0) {
+                    /* (one gatherer at a time: the others wait for their results instead of forking executors of their
+                     * own under the lock the late-comers need to file their requests) */
+                    gathering = true;
                     auto const until = std::chrono::steady_clock::now() + std::chrono::microseconds(gather_us());
                     while (announced.load() > 0 && cv.wait_until(lk, until) != std::cv_status::timeout) { }
-                    if (r.done) { idle.push_back(ex); cv.notify_all(); return; }
-                    if (std::find(pending.begin(), pending.end(), &r) == pending.end()) { idle.push_back(ex); cv.notify_all(); continue; }
+                    gathering = false;
                 }
                 /* everything pending with the settings of the oldest request, up to max_batch() views */
                 std::vector<Request*> batch;
@@ -176,6 +178,7 @@ private:
     std::condition_variable cv;
     std::deque<Request*> pending;
     std::vector<mi_dmrecon_ctx*> executors, idle;
+    bool gathering = false;                    /* a thread is waiting for the announced instances before it runs a batch */
 
     static std::size_t env_or(char const* name, std::size_t dflt)
     {
@@ -269,27 +272,28 @@ class Registry
 public:
     static Registry& get() { static Registry r; return r; }
 
-    /* the generation of (scene, embedding), with every GPU's copy resident; the caller keeps the pointer */
+    /* the generation of (scene, embedding): its GPU slots exist, the scene may still be on its way (make_resident) */
     std::shared_ptr<Generation> generation_for(mve::Scene::Ptr scene, std::string const& embedding)
     {
-        std::shared_ptr<Generation> g;
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            if (!current || current->scene != scene || current->embedding != embedding) {
-                /* like ImagePyramidCache: one scene/embedding at a time; a different one re-uploads */
-                current = std::make_shared<Generation>();
-                current->scene = scene;
-                current->embedding = embedding;
-                init_devices(*current);
-            }
-            g = current;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!current || current->scene != scene || current->embedding != embedding) {
+            /* like ImagePyramidCache: one scene/embedding at a time; a different one re-uploads */
+            current = std::make_shared<Generation>();
+            current->scene = scene;
+            current->embedding = embedding;
+            init_devices(*current);
         }
-        /* outside the registry lock: the first caller stages the scene, the others of this generation wait for it */
-        std::call_once(g->uploaded, [&]() {
-            try { upload(*g); } catch (...) { g->upload_error = std::current_exception(); }
+        return current;
+    }
+
+    /* every GPU's copy resident: the first caller stages the scene, the others of this generation wait for it
+     * (outside the registry lock) */
+    static void make_resident(Generation& g)
+    {
+        std::call_once(g.uploaded, [&]() {
+            try { upload(g); } catch (...) { g.upload_error = std::current_exception(); }
         });
-        if (g->upload_error) std::rethrow_exception(g->upload_error);
-        return g;
+        if (g.upload_error) std::rethrow_exception(g.upload_error);
     }
 
 private:
@@ -476,8 +480,11 @@ DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
     std::shared_ptr<Attachment> att = std::make_shared<Attachment>();
     att->gen = Registry::get().generation_for(scene, settings.imageEmbedding);
     att->slot = att->gen->slots[att->gen->next_slot++ % att->gen->slots.size()].get();
+    /* announced BEFORE the wait for the scene: the driver's threads all sit in that wait while the first of them stages
+     * the views, so by the time it ends every one of them is counted and their start() calls form one batch */
     att->slot->announce(); att->announced = true;
     this->slot = att;
+    Registry::make_resident(*att->gen);
     Slot* slot = att->slot;
     int32_t w = 0, h = 0;
     {
