@@ -36,7 +36,12 @@ cat $OUT/bench_driver.json $OUT/bench_default.json $OUT/bench_1thread.json $OUT/
 # a round trace of one lone C3 call, the front-kernel patch probe, the drop-in app on the scene on disk
 timeout -s KILL 120 python tools/trace_c3.py > $OUT/round_trace_c3.txt 2>&1
 timeout -s KILL 200 python tools/patch_probe.py > $OUT/patch_probe.txt 2>&1
-timeout -s KILL 300 python tools/app_c3_timing.py > $OUT/app_c3_timing.txt 2>&1
+MI_DMRECON_TRACE=1 timeout -s KILL 300 python tools/app_c3_timing.py 2>&1 | grep -v "^\[mi_dmrecon\]" > $OUT/app_c3_timing.txt
+# lone calls of 1..20 views (what a rank's share of a scene costs when the rank has its GPU to itself), a cold first call
+for N in 1 2 3 5 10 20; do
+  timeout -s KILL 100 python tools/trace_c3.py C3 $N 2>&1 | grep -E "phase|total|wall" | sed 's/\[mi_dmrecon\] //' | tr '\n' ';' | cut -c1-420 | sed "s/^/lone call of $N views: /"; echo
+done > $OUT/lone_calls.txt
+timeout -s KILL 200 python tools/cold_call.py C3 20 2>&1 | grep -E "phase|==|context|staged|total" | cut -c1-120 > $OUT/cold_call.txt
 # BASELINE config 4 (the 20 views of ONE scene sharded over the ranks) on the one GPU of this box: two ranks sharing GPU 0
 # (development mode of bench.py, gloo): what a rank's share of the scene costs -- the strong-scaling prediction
 MI_BENCH_SHARE_GPU=1 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29641 \
@@ -44,4 +49,4 @@ MI_BENCH_SHARE_GPU=1 timeout -s KILL 300 python -m torch.distributed.run --nnode
 MI_BENCH_SHARE_GPU=1 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29642 \
   bench.py --gpus 4 --steps 20 --warmup 5 --scaling strong --no-cpu-baseline > $OUT/strong_4ranks_one_gpu.json 2> $OUT/strong_4ranks_one_gpu.err
 tail -c 600 $OUT/strong_2ranks_one_gpu.json; tail -c 600 $OUT/strong_4ranks_one_gpu.json
-tail -5 $OUT/app_c3_timing.txt
+grep -v '(view)' $OUT/app_c3_timing.txt | tail -12; cat $OUT/lone_calls.txt | cut -c1-300
