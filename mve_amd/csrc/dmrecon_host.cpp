@@ -147,6 +147,7 @@ std::atomic<int> g_active_calls[MI_MAX_DEVICES];
 std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 /* MI_DMRECON_FRONT defaults: entries per reference view (average over the batch) below which the rest of the
  * propagation goes to the front kernel, for a call alone on its GPU / next to other calls (BatchRun::tail_rounds) */
+#define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
 #define MI_FRONT_MIN_CAP 256       /* hand-over to k_front: entries per view, at least */
 #define MI_FRONT_PER_TEAM_WG 64    /* ... and per workgroup of a view's team */
 struct ActiveCall {
@@ -1338,6 +1339,21 @@ int BatchRun::bulk_rounds(bool& to_tail) {
             const unsigned ppw = patches_per_wave(st);
             const unsigned waves = (n_work + ppw - 1) / ppw;
             unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
+            /* Rounds below MI_ONE_LAUNCH_MAX entries run as ONE launch of the general kernel, all attempts of an entry in a
+             * row: such a launch fits the GPU at once, so either launch of the two-launch form lasts one wavefront-life
+             * (1 attempt, then up to 3 more) whatever its size -- measured: lone 20-view call 533 -> 548 depth-maps/s, a
+             * lone 3-view call 19.4 -> 17.8 ms, the bench's plan unchanged (thresholds 50 000 / 200 000 / always: 542 /
+             * 546 / 540) */
+            if (n_work < MI_ONE_LAUNCH_MAX) {
+                D->optimize(S, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr,
+                            n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
+                ev.end(S);
+                ++n_launch;
+                ev.begin(S, EventLog::SWEEP, 0);
+                mi_launch_apply(S, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
+                ev.end(S);
+                continue;
+            }
             D->optimize(S, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr,
                         n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->d_follow.p, fcnt);
             D->optimize(S, 1, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,

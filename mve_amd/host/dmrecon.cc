@@ -147,14 +147,18 @@ public:
                 }
                 /* the threads that have constructed their instance are on their way (microseconds apart): without the
                  * wait the first to arrive runs a batch of ONE view and the rest a second batch behind it */
-                if (announced.load() > 0) {
+                if (announced.load() > 0 && gather_pays) {
                     /* (one gatherer at a time: the others wait for their results instead of forking executors of their
                      * own under the lock the late-comers need to file their requests) */
                     gathering = true;
                     auto const until = std::chrono::steady_clock::now() + std::chrono::microseconds(gather_us());
                     while (announced.load() > 0 && cv.wait_until(lk, until) != std::cv_status::timeout) { }
                     gathering = false;
+                    /* a caller that constructs its instances up front and starts them one after the other would pay the
+                     * wait for every view: after a wait that nobody joined, batches start at once until company shows up */
+                    if (pending.size() <= 1) gather_pays = false;
                 }
+                if (pending.size() > 1) gather_pays = true;
                 /* everything pending with the settings of the oldest request, up to max_batch() views */
                 std::vector<Request*> batch;
                 mi_dmrecon_settings const key = pending.front()->st;
@@ -179,6 +183,7 @@ private:
     std::deque<Request*> pending;
     std::vector<mi_dmrecon_ctx*> executors, idle;
     bool gathering = false;                    /* a thread is waiting for the announced instances before it runs a batch */
+    bool gather_pays = true;                   /* the last wait was joined by somebody (or there has been none yet) */
 
     static std::size_t env_or(char const* name, std::size_t dflt)
     {
