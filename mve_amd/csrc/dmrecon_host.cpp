@@ -187,6 +187,56 @@ struct SceneGeom {
     std::vector<float> plx;                  /* [(v1 * nv + v2) * nf + f]: parallax in degrees where both see f */
 };
 
+/*
+ * Everything a batch allocates on top of the resident scene: lists, results, state maps (~200 B per pixel of the batch:
+ * gigabytes for a merged batch of hundreds of views), job records, mailboxes, pinned poll buffers, events.  It belongs
+ * to the SCENE and is leased to a context for the duration of a call (ScratchLease): which of the forked contexts runs
+ * the large merged batch of a step is a matter of arrival order, and a context that meets its first 200-view batch
+ * inside a timed region used to pay hipFree + hipMalloc of its own buffers there -- 0.2 s, and hipFree synchronises
+ * the device, so the batch running next to it stalled too (the bench's plan: 700 instead of 1 180 depth-maps/s in one
+ * run out of ten).
+ */
+struct BatchScratch {
+    DevBuf<DevJob> d_jobs;
+    DevBuf<DevEntry> d_work;
+    DevBuf<DevEntry> d_work2;                /* ping-pong partner of d_work in the tail rounds */
+    DevBuf<DevHyp> d_hyp;
+    DevBuf<DevResult> d_results;
+    DevBuf<DevResult> d_results2;            /* ping-pong partner of d_results in the tail rounds */
+    DevBuf<float> d_maps;                    /* depth | dz | conf | normal per batch */
+    DevBuf<uint32_t> d_imaps;                /* views | upd */
+    DevBuf<unsigned long long> d_keys;
+    DevBuf<unsigned> d_keyoff;
+    DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
+    DevBuf<unsigned> d_front;                /* k_front: [n_jobs] list offsets | [n_jobs] list sizes | [n_jobs][4] per-view statistics */
+    DevBuf<unsigned long long> d_front_mail; /* k_front teams: a mailbox per view (MI_FRONT_MAIL_WORDS) */
+    DevBuf<unsigned> d_front_flags;          /* ... and MI_FRONT_TEAM_MAX pass flags per view */
+    DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
+    DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
+    TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    uint8_t* h_dyn = nullptr;                /* pinned: read-backs of the jobs' flags / n_filled words (JobDyn), three slots */
+    size_t h_dyn_cap = 0;
+    std::vector<int32_t> h_jobdyn;           /* staging of the flag words written to dead jobs */
+    DevBuf<int32_t> d_gvs_feat, d_gvs_out;   /* scratch and result of the device view selection */
+    DevBuf<float> d_gvs_base, d_gvs_benefit;
+    DevBuf<GvsRef> d_gvs_refs;
+    std::vector<hipEvent_t> events;
+    size_t pixels() const { return d_maps.cap / 14; }       /* state maps: 14 floats per pixel */
+    void release() {
+        for (size_t i = 0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
+        events.clear();
+        d_jobs.release(); d_work.release(); d_work2.release(); d_hyp.release(); d_results.release(); d_results2.release();
+        d_follow.release(); d_follow_cnt.release(); d_maps.release(); d_imaps.release(); d_keys.release(); d_keyoff.release();
+        d_round_work.release(); d_front.release(); d_front_mail.release(); d_front_flags.release();
+        d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release();
+        if (h_poll) (void)hipHostFree(h_poll);
+        if (h_dyn) (void)hipHostFree(h_dyn);
+        h_poll = nullptr; h_dyn = nullptr; h_dyn_cap = 0;
+        for (int k = 0; k < 2; ++k) { if (poll_ev[k]) (void)hipEventDestroy(poll_ev[k]); poll_ev[k] = nullptr; }
+    }
+};
+
 /* A reconstruct call waiting to be merged with others on the same scene (see mi_dmrecon_reconstruct) */
 struct MergeReq {
     const mi_dmrecon_settings* st; int32_t n; const int32_t* refs; mi_dmrecon_maps* maps; int32_t* status; mi_dmrecon_stats* stats;
@@ -204,6 +254,9 @@ struct MergeQueue {
 struct SceneStore {
     int device = 0;
     MergeQueue merge;
+    std::mutex pool_mu;                      /* guards scratch_pool */
+    std::vector<BatchScratch> scratch_pool;  /* the scratch sets no call holds at the moment */
+    std::atomic<size_t> max_batch_px{0};     /* pixels of the largest batch so far */
     SceneGeom geom;                          /* guarded by mu; dropped with views_dirty / set_features */
     std::mutex mu;                           /* guards the lazy upload of the DevView table */
     std::vector<HostView> views;
@@ -216,6 +269,7 @@ struct SceneStore {
     DevBuf<float> d_geom_zcam, d_geom_plx, d_geom_fpos, d_geom_inv0;
     ~SceneStore() {
         (void)hipSetDevice(device);
+        for (size_t i = 0; i < scratch_pool.size(); ++i) scratch_pool[i].release();
         for (size_t i = 0; i < views.size(); ++i) if (views[i].d_img) (void)hipFree(views[i].d_img);
         d_views.release();
         d_geom_sees.release(); d_geom_valid.release(); d_geom_zcam.release(); d_geom_plx.release();
@@ -230,34 +284,11 @@ struct mi_dmrecon_ctx {
     hipStream_t stream = nullptr;
     std::shared_ptr<SceneStore> sc;
     DevCounters* d_counters = nullptr;
-    DevBuf<DevJob> d_jobs;
-    DevBuf<DevEntry> d_work;
-    DevBuf<DevEntry> d_work2;                /* ping-pong partner of d_work in the tail rounds */
-    DevBuf<DevHyp> d_hyp;
-    DevBuf<DevResult> d_results;
-    DevBuf<DevResult> d_results2;            /* ping-pong partner of d_results in the tail rounds */
-    DevBuf<float> d_maps;                    /* depth | dz | conf | normal per batch */
-    DevBuf<uint32_t> d_imaps;                /* views | upd */
-    DevBuf<unsigned long long> d_keys;
-    DevBuf<unsigned> d_keyoff;
     DevBuf<uint8_t> d_stage;
     DevBuf<uint8_t> d_stage2;
     int stage_flip = 0;
-    DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
-    DevBuf<unsigned> d_front;                /* k_front: [n_jobs] list offsets | [n_jobs] list sizes | [n_jobs][4] per-view statistics */
-    DevBuf<unsigned long long> d_front_mail; /* k_front teams: a mailbox per view (MI_FRONT_MAIL_WORDS) */
-    DevBuf<unsigned> d_front_flags;          /* ... and MI_FRONT_TEAM_MAX pass flags per view */
-    DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
-    DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
-    TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
-    hipEvent_t poll_ev[2] = {nullptr, nullptr};
-    uint8_t* h_dyn = nullptr;                /* pinned: read-backs of the jobs' flags / n_filled words (JobDyn), three slots */
-    size_t h_dyn_cap = 0;
-    std::vector<int32_t> h_jobdyn;           /* staging of the flag words written to dead jobs */
-    DevBuf<int32_t> d_gvs_feat, d_gvs_out;   /* scratch and result of the device view selection */
-    DevBuf<float> d_gvs_base, d_gvs_benefit;
-    DevBuf<GvsRef> d_gvs_refs;
-    std::vector<hipEvent_t> events;
+    BatchScratch bs;                         /* leased from the scene's pool for the duration of a call (ScratchLease) */
+    size_t floor_px = 0;                     /* pixel-proportional scratch is sized for at least this many pixels (set per call) */
 };
 
 namespace {
@@ -537,26 +568,26 @@ int plan_global_views_device(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
     }
     const size_t m = hr.size();
     if (m == 0) return 0;
-    if (c->d_gvs_refs.reserve(m) || c->d_gvs_feat.reserve(m * nf) || c->d_gvs_base.reserve(m * nv * nf)
-        || c->d_gvs_benefit.reserve(m * nv) || c->d_gvs_out.reserve(m * (MI_GVS_MAX_OUT + 1)))
+    if (c->bs.d_gvs_refs.reserve(m) || c->bs.d_gvs_feat.reserve(m * nf) || c->bs.d_gvs_base.reserve(m * nv * nf)
+        || c->bs.d_gvs_benefit.reserve(m * nv) || c->bs.d_gvs_out.reserve(m * (MI_GVS_MAX_OUT + 1)))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(view selection scratch) failed");
     GvsArgs a;
     a.sc.nv = (int)nv; a.sc.nf = (int)nf;
     a.sc.sees = sc.d_geom_sees.p; a.sc.zcam = sc.d_geom_zcam.p; a.sc.plx = sc.d_geom_plx.p; a.sc.fpos = sc.d_geom_fpos.p;
     a.sc.inv0 = sc.d_geom_inv0.p; a.sc.valid = sc.d_geom_valid.p;
-    a.refs = c->d_gvs_refs.p; a.minParallax = st->minParallax; a.globalVSMax = st->globalVSMax;
+    a.refs = c->bs.d_gvs_refs.p; a.minParallax = st->minParallax; a.globalVSMax = st->globalVSMax;
     a.use_box = 0;
     for (int k = 0; k < 3; ++k) {
         a.aabb_min[k] = st->aabbMin[k]; a.aabb_max[k] = st->aabbMax[k];
         if (st->aabbMin[k] != -std::numeric_limits<float>::max() || st->aabbMax[k] != std::numeric_limits<float>::max()) a.use_box = 1;
     }
-    a.feat = c->d_gvs_feat.p; a.base = c->d_gvs_base.p; a.benefit = c->d_gvs_benefit.p;
-    a.out_ids = c->d_gvs_out.p; a.out_n = c->d_gvs_out.p + m * MI_GVS_MAX_OUT;
-    HIP_TRY(hipMemcpyAsync(c->d_gvs_refs.p, hr.data(), m * sizeof(GvsRef), hipMemcpyHostToDevice, c->stream));
+    a.feat = c->bs.d_gvs_feat.p; a.base = c->bs.d_gvs_base.p; a.benefit = c->bs.d_gvs_benefit.p;
+    a.out_ids = c->bs.d_gvs_out.p; a.out_n = c->bs.d_gvs_out.p + m * MI_GVS_MAX_OUT;
+    HIP_TRY(hipMemcpyAsync(c->bs.d_gvs_refs.p, hr.data(), m * sizeof(GvsRef), hipMemcpyHostToDevice, c->stream));
     mi_gvs_launch(c->stream, a, (int)m);
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> out(m * (MI_GVS_MAX_OUT + 1));
-    HIP_TRY(hipMemcpyAsync(out.data(), c->d_gvs_out.p, out.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out.data(), c->bs.d_gvs_out.p, out.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; ++i) {
         if (slot[i] < 0) continue;
@@ -771,11 +802,12 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
     /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd + views1, upd1 (+ views_hi,
      * views1_hi: view slots 4..7 of a set, nrReconNeighbors > 4) */
     const size_t n_imaps = eight_views ? 6 : 4;
-    if (c->d_maps.reserve(total_px * 14)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
-    if (c->d_imaps.reserve(total_px * n_imaps)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
-    float* base = c->d_maps.p;
+    const size_t cap_px = std::max(total_px, c->floor_px);           /* sized for the largest batch of the scene so far */
+    if (c->bs.d_maps.reserve(cap_px * 14)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
+    if (c->bs.d_imaps.reserve(cap_px * n_imaps)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
+    float* base = c->bs.d_maps.p;
     float* base1 = base + 7 * total_px;
-    uint32_t* ibase = c->d_imaps.p;
+    uint32_t* ibase = c->bs.d_imaps.p;
     for (size_t j = 0; j < jobs.size(); ++j) {
         const size_t o = jobs[j].pix_off;
         dj[j].depth = base + o;
@@ -794,8 +826,8 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
         dj[j].views1_hi = eight_views ? ibase + 5 * total_px + o : nullptr;
     }
     /* slot 1 is only ever read where its stamp says so: the stamps (0xFF.. = -1) are all it needs */
-    HIP_TRY(hipMemsetAsync(c->d_maps.p, 0, total_px * 7 * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_imaps.p, 0xFF, total_px * n_imaps * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->bs.d_maps.p, 0, total_px * 7 * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->bs.d_imaps.p, 0xFF, total_px * n_imaps * sizeof(uint32_t), c->stream));
     return 0;
 }
 
@@ -865,13 +897,8 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (size_t i = 0; i < c->events.size(); ++i) (void)hipEventDestroy(c->events[i]);
-    c->d_jobs.release(); c->d_work.release(); c->d_work2.release(); c->d_hyp.release(); c->d_results.release(); c->d_results2.release(); c->d_follow.release(); c->d_follow_cnt.release();
-    c->d_maps.release(); c->d_imaps.release(); c->d_keys.release(); c->d_keyoff.release(); c->d_stage.release(); c->d_stage2.release(); c->d_round_work.release(); c->d_front.release(); c->d_front_mail.release(); c->d_front_flags.release();
-    c->d_gvs_feat.release(); c->d_gvs_out.release(); c->d_gvs_base.release(); c->d_gvs_benefit.release(); c->d_gvs_refs.release();
-    if (c->h_poll) (void)hipHostFree(c->h_poll);
-    if (c->h_dyn) (void)hipHostFree(c->h_dyn);
-    for (int k = 0; k < 2; ++k) if (c->poll_ev[k]) (void)hipEventDestroy(c->poll_ev[k]);
+    c->bs.release();
+    c->d_stage.release(); c->d_stage2.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
     delete c;                                 /* the scene store goes with its last owner */
@@ -1079,8 +1106,8 @@ struct EventLog {
     size_t n_ev = 0;
     std::vector<Item> items;
     hipEvent_t get(size_t i) {
-        while (c->events.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; c->events.push_back(e); }
-        return c->events[i];
+        while (c->bs.events.size() <= i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; c->bs.events.push_back(e); }
+        return c->bs.events[i];
     }
     void begin(hipStream_t S, int kind, unsigned work) {
         Item it; it.first = n_ev; it.kind = kind; it.work = work;
@@ -1088,9 +1115,9 @@ struct EventLog {
         it.ok = e0 && e1 && hipEventRecord(e0, S) == hipSuccess;
         items.push_back(it); n_ev += 2;
     }
-    void end(hipStream_t S) { Item& it = items.back(); if (it.ok) it.ok = hipEventRecord(c->events[it.first + 1], S) == hipSuccess; }
+    void end(hipStream_t S) { Item& it = items.back(); if (it.ok) it.ok = hipEventRecord(c->bs.events[it.first + 1], S) == hipSuccess; }
     bool ms(const Item& it, float& out) const {
-        return it.ok && hipEventElapsedTime(&out, c->events[it.first], c->events[it.first + 1]) == hipSuccess;
+        return it.ok && hipEventElapsedTime(&out, c->bs.events[it.first], c->bs.events[it.first + 1]) == hipSuccess;
     }
 };
 
@@ -1127,9 +1154,9 @@ struct BatchRun {
         fprintf(stderr, "[mi_dmrecon] phase %-22s %8.3f ms\n", what, t - t_mark);
         t_mark = t;
     }
-    JobDyn* dyn_of(int slot) { return (JobDyn*)c->h_dyn + (size_t)slot * nj; }
+    JobDyn* dyn_of(int slot) { return (JobDyn*)c->bs.h_dyn + (size_t)slot * nj; }
     hipError_t read_dyn(int slot) {
-        return hipMemcpy2DAsync(dyn_of(slot), sizeof(JobDyn), (const char*)c->d_jobs.p + offsetof(DevJob, flags), sizeof(DevJob),
+        return hipMemcpy2DAsync(dyn_of(slot), sizeof(JobDyn), (const char*)c->bs.d_jobs.p + offsetof(DevJob, flags), sizeof(DevJob),
                                 sizeof(JobDyn), (size_t)nj, hipMemcpyDeviceToHost, S);
     }
     void plan_front_team();
@@ -1220,8 +1247,8 @@ int BatchRun::upload() {
     }
     rc = alloc_maps(c, jobs, dj, total_px, st->nrReconNeighbors > 4);
     if (rc) return rc;
-    if (c->d_jobs.reserve(nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(jobs) failed");
-    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), nj * sizeof(DevJob), hipMemcpyHostToDevice, S));
+    if (c->bs.d_jobs.reserve(nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(jobs) failed");
+    HIP_TRY(hipMemcpyAsync(c->bs.d_jobs.p, dj.data(), nj * sizeof(DevJob), hipMemcpyHostToDevice, S));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), S));
     keyoff.resize(nj);
     for (int j = 0; j < nj; ++j) {
@@ -1231,28 +1258,29 @@ int BatchRun::upload() {
         n_seed_feats += jobs[j].n_seeds;
     }
     work_cap = std::max(total_px, seeds.size());
-    if (c->d_work.reserve(work_cap) || c->d_work2.reserve(work_cap) || c->d_results.reserve(work_cap) || c->d_results2.reserve(work_cap)
-        || c->d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->d_keys.reserve(total_px) || c->d_keyoff.reserve(nj)
-        || c->d_round_work.reserve(MI_MAX_ROUNDS) || c->d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->d_follow.reserve(2 * work_cap)
-        || c->d_front.reserve(6 * (size_t)nj))
+    const size_t cap_px = std::max(work_cap, c->floor_px);           /* sized for the largest batch of the scene so far */
+    if (c->bs.d_work.reserve(cap_px) || c->bs.d_work2.reserve(cap_px) || c->bs.d_results.reserve(cap_px) || c->bs.d_results2.reserve(cap_px)
+        || c->bs.d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->bs.d_keys.reserve(cap_px) || c->bs.d_keyoff.reserve(nj)
+        || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->bs.d_follow.reserve(2 * cap_px)
+        || c->bs.d_front.reserve(6 * (size_t)nj))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(work lists) failed");
-    HIP_TRY(hipMemsetAsync(c->d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
-    HIP_TRY(hipMemsetAsync(c->d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), S));
-    HIP_TRY(hipMemcpyAsync(c->d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
-    if (!c->h_poll) {
-        if (hipHostMalloc((void**)&c->h_poll, 3 * sizeof(TailPoll), hipHostMallocDefault) != hipSuccess)
+    HIP_TRY(hipMemsetAsync(c->bs.d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
+    HIP_TRY(hipMemsetAsync(c->bs.d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), S));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
+    if (!c->bs.h_poll) {
+        if (hipHostMalloc((void**)&c->bs.h_poll, 3 * sizeof(TailPoll), hipHostMallocDefault) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(poll buffer) failed");
-        for (int k = 0; k < 2; ++k) if (hipEventCreateWithFlags(&c->poll_ev[k], hipEventDisableTiming) != hipSuccess)
+        for (int k = 0; k < 2; ++k) if (hipEventCreateWithFlags(&c->bs.poll_ev[k], hipEventDisableTiming) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipEventCreate failed");
     }
-    if (c->h_jobdyn.size() < 2 * (size_t)nj) c->h_jobdyn.resize(2 * (size_t)nj);
-    if (c->h_dyn_cap < 3 * (size_t)nj * sizeof(JobDyn)) {
-        if (c->h_dyn) (void)hipHostFree(c->h_dyn);
-        c->h_dyn = nullptr; c->h_dyn_cap = 0;
+    if (c->bs.h_jobdyn.size() < 2 * (size_t)nj) c->bs.h_jobdyn.resize(2 * (size_t)nj);
+    if (c->bs.h_dyn_cap < 3 * (size_t)nj * sizeof(JobDyn)) {
+        if (c->bs.h_dyn) (void)hipHostFree(c->bs.h_dyn);
+        c->bs.h_dyn = nullptr; c->bs.h_dyn_cap = 0;
         const size_t want = 3 * ((size_t)nj + 64) * sizeof(JobDyn);
-        if (hipHostMalloc((void**)&c->h_dyn, want, hipHostMallocDefault) != hipSuccess)
+        if (hipHostMalloc((void**)&c->bs.h_dyn, want, hipHostMallocDefault) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(job poll buffer) failed");
-        c->h_dyn_cap = want;
+        c->bs.h_dyn_cap = want;
     }
     n_alive = nj;
     mark("setup + uploads (async)");
@@ -1262,18 +1290,18 @@ int BatchRun::upload() {
 /* ---- round 0: DMRecon::processFeatures (dmrecon.cc:243-331), every SfM feature of every view in one launch */
 int BatchRun::seed_round() {
     if (seeds.empty()) return 0;
-    HIP_TRY(hipMemcpyAsync(c->d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, S));
-    HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, S));
-    HIP_TRY(hipMemsetAsync(c->d_keys.p, 0, total_px * sizeof(unsigned long long), S));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemsetAsync(c->bs.d_keys.p, 0, total_px * sizeof(unsigned long long), S));
     ev.begin(S, EventLog::BULK, (unsigned)seeds.size());
     const unsigned ppw = patches_per_wave(st);
-    D->optimize(S, 1, ((unsigned)seeds.size() + ppw - 1) / ppw, c->d_jobs.p, c->sc->d_views.p,
-                c->sc->d_lut, ds, c->d_work.p, c->d_hyp.p, c->d_results.p, nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0,
+    D->optimize(S, 1, ((unsigned)seeds.size() + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p,
+                c->sc->d_lut, ds, c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0,
                 c->d_counters, nullptr, nullptr, nullptr, nullptr);
     ev.end(S);
     ++n_launch;
     ev.begin(S, EventLog::SWEEP, 0);
-    mi_launch_apply_seeds(S, c->d_jobs.p, c->d_work.p, c->d_results.p, (unsigned)seeds.size(), c->d_counters, c->d_keys.p, c->d_keyoff.p);
+    mi_launch_apply_seeds(S, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, (unsigned)seeds.size(), c->d_counters, c->bs.d_keys.p, c->bs.d_keyoff.p);
     ev.end(S);
     return 0;
 }
@@ -1293,8 +1321,8 @@ int BatchRun::poll_views(const JobDyn* dyn, unsigned queue_size) {
         if (!why) continue;
         view_rc[i] = why; --n_alive;
         if (progress && why == MI_DMRECON_ECANCELLED) progress[i].status = MI_RECON_CANCELLED;
-        c->h_jobdyn[2 * j] = (int32_t)((uint32_t)dyn[j].flags | MI_JOB_DEAD);   /* stays valid until the copy has run */
-        if (hipMemcpyAsync((char*)(c->d_jobs.p + j) + offsetof(DevJob, flags), &c->h_jobdyn[2 * j], sizeof(int32_t),
+        c->bs.h_jobdyn[2 * j] = (int32_t)((uint32_t)dyn[j].flags | MI_JOB_DEAD);   /* stays valid until the copy has run */
+        if (hipMemcpyAsync((char*)(c->bs.d_jobs.p + j) + offsetof(DevJob, flags), &c->bs.h_jobdyn[2 * j], sizeof(int32_t),
                            hipMemcpyHostToDevice, S) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipMemcpyAsync(job flags) failed");
     }
@@ -1314,10 +1342,10 @@ int BatchRun::bulk_rounds(bool& to_tail) {
     const int max_rounds = MI_MAX_ROUNDS - 2 * (int)MI_TAIL_CHUNK - 2;
     for (; round < max_rounds && n_alive > 0; ++round) {
         ev.begin(S, EventLog::SWEEP, 0);
-        D->generate(S, c->d_jobs.p, nj, max_tiles, c->d_work.p, c->d_round_work.p, round);
+        D->generate(S, c->bs.d_jobs.p, nj, max_tiles, c->bs.d_work.p, c->bs.d_round_work.p, round);
         ev.end(S);
-        TailPoll& P = c->h_poll[0];
-        HIP_TRY(hipMemcpyAsync(&P.rw[0], c->d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
+        TailPoll& P = c->bs.h_poll[0];
+        HIP_TRY(hipMemcpyAsync(&P.rw[0], c->bs.d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
         HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
         HIP_TRY(read_dyn(0));
         HIP_TRY(hipStreamSynchronize(S));
@@ -1329,8 +1357,8 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         const bool tail = n_work < TAIL_THRESHOLD;
         ev.begin(S, EventLog::BULK, n_work);
         if (tail || BULK_LPV == 16)
-            D->optimize(S, 16, std::min(n_work, tail ? 4096u : 16384u), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p,
-                        nullptr, c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
+            D->optimize(S, 16, std::min(n_work, tail ? 4096u : 16384u), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p,
+                        nullptr, c->bs.d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
         else {
             /* one optimisation attempt per entry and launch; the entries whose pixel has further candidate hypotheses
              * (about one in five) continue in a follow-up launch over a compacted list (its size stays on the device),
@@ -1338,37 +1366,37 @@ int BatchRun::bulk_rounds(bool& to_tail) {
              * entries back to back (third and fourth attempts are rare) */
             const unsigned ppw = patches_per_wave(st);
             const unsigned waves = (n_work + ppw - 1) / ppw;
-            unsigned* fcnt = c->d_follow_cnt.p + 4 * (size_t)round;
+            unsigned* fcnt = c->bs.d_follow_cnt.p + 4 * (size_t)round;
             /* Rounds below MI_ONE_LAUNCH_MAX entries run as ONE launch of the general kernel, all attempts of an entry in a
              * row: such a launch fits the GPU at once, so either launch of the two-launch form lasts one wavefront-life
              * (1 attempt, then up to 3 more) whatever its size -- measured: lone 20-view call 533 -> 548 depth-maps/s, a
              * lone 3-view call 19.4 -> 17.8 ms, the bench's plan unchanged (thresholds 50 000 / 200 000 / always: 542 /
              * 546 / 540) */
             if (n_work < MI_ONE_LAUNCH_MAX) {
-                D->optimize(S, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr,
+                D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, nullptr,
                             n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
                 ev.end(S);
                 ++n_launch;
                 ev.begin(S, EventLog::SWEEP, 0);
-                mi_launch_apply(S, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
+                mi_launch_apply(S, (n_work + 255) / 256, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, nullptr, n_work, round, c->d_counters);
                 ev.end(S);
                 continue;
             }
-            D->optimize(S, 1, waves, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr, c->d_results.p, nullptr,
-                        n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->d_follow.p, fcnt);
-            D->optimize(S, 1, std::max(1u, waves / 4), c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->d_work.p, nullptr,
-                        c->d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->d_follow.p, fcnt, nullptr, nullptr);
+            D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, nullptr,
+                        n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->bs.d_follow.p, fcnt);
+            D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
+                        c->bs.d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->bs.d_follow.p, fcnt, nullptr, nullptr);
             ++n_launch;
         }
         ev.end(S);
         ++n_launch;
         ev.begin(S, EventLog::SWEEP, 0);
-        mi_launch_apply(S, (n_work + 255) / 256, c->d_jobs.p, c->d_work.p, c->d_results.p, nullptr, n_work, round, c->d_counters);
+        mi_launch_apply(S, (n_work + 255) / 256, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, nullptr, n_work, round, c->d_counters);
         ev.end(S);
         if (tail) {
             tail_known = n_work;
             /* counters as of the end of the host-visible rounds (slot 2 of the poll buffer; read after the call) */
-            HIP_TRY(hipMemcpyAsync(&c->h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
+            HIP_TRY(hipMemcpyAsync(&c->bs.h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
             have_handover = true;
             ++round; to_tail = true;
             return 0;
@@ -1408,7 +1436,7 @@ int BatchRun::tail_rounds(bool& to_front) {
         return std::max<unsigned>(MI_FRONT_MIN_CAP, (unsigned)MI_FRONT_PER_TEAM_WG * (unsigned)front_team);
     }();
     const unsigned front_max = FRONT_PER_VIEW * (unsigned)nj;
-    wcur = c->d_work.p; wnext = c->d_work2.p; rcur = c->d_results.p; rnext = c->d_results2.p;
+    wcur = c->bs.d_work.p; wnext = c->bs.d_work2.p; rcur = c->bs.d_results.p; rnext = c->bs.d_results2.p;
     /* the hand-over round's list is already that small: the views go their own ways at once */
     if (front_max > 0 && tail_known <= front_max) { to_front = true; return 0; }
     /* An event record costs ~6 us of queue time on either side of the kernel it brackets -- more than a tenth of a
@@ -1430,16 +1458,16 @@ int BatchRun::tail_rounds(bool& to_front) {
         for (unsigned k = 0; k < MI_TAIL_CHUNK; ++k, ++round) {
             const bool timed = (stats != nullptr || trace) && k % TIMED_EVERY == 0;
             if (timed) ev.begin(S, EventLog::TAIL, k);            /* k -> entries after the read-back */
-            D->tail(S, grid, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext, c->d_round_work.p, round,
+            D->tail(S, grid, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, wnext, rnext, c->bs.d_round_work.p, round,
                     c->d_counters, speculative);
             if (timed) ev.end(S);
             std::swap(wcur, wnext); std::swap(rcur, rnext);
         }
         info[slot].ev_last = ev.items.size();
-        TailPoll& P = c->h_poll[slot];
-        if (hipMemcpyAsync(P.rw, c->d_round_work.p + info[slot].first, MI_TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
+        TailPoll& P = c->bs.h_poll[slot];
+        if (hipMemcpyAsync(P.rw, c->bs.d_round_work.p + info[slot].first, MI_TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
             || hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S) != hipSuccess
-            || read_dyn(slot) != hipSuccess || hipEventRecord(c->poll_ev[slot], S) != hipSuccess)
+            || read_dyn(slot) != hipSuccess || hipEventRecord(c->bs.poll_ev[slot], S) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "enqueue of tail rounds failed");
         return 0;
     };
@@ -1450,8 +1478,8 @@ int BatchRun::tail_rounds(bool& to_front) {
         const bool more_room = round + (int)MI_TAIL_CHUNK < MI_MAX_ROUNDS - 1;
         const bool ahead = more_room && !want_front;              /* keep a second chunk in flight */
         if (ahead) if (int rc = enqueue_chunk(slot ^ 1)) return rc;
-        HIP_TRY(hipEventSynchronize(c->poll_ev[slot]));
-        TailPoll& P = c->h_poll[slot];
+        HIP_TRY(hipEventSynchronize(c->bs.poll_ev[slot]));
+        TailPoll& P = c->bs.h_poll[slot];
         hc = P.hc;
         for (size_t q = info[slot].ev_first; q < info[slot].ev_last; ++q) ev.items[q].work = P.rw[ev.items[q].work];
         int end_round = -1;
@@ -1465,7 +1493,7 @@ int BatchRun::tail_rounds(bool& to_front) {
         if (int rc = poll_views(dyn_of(slot), P.rw[MI_TAIL_CHUNK - 1])) return rc;
         if (end_round >= 0) {
             /* an empty round: the propagation is over */
-            if (ahead) HIP_TRY(hipEventSynchronize(c->poll_ev[slot ^ 1]));     /* the chunk in flight is all no-ops */
+            if (ahead) HIP_TRY(hipEventSynchronize(c->bs.poll_ev[slot ^ 1]));     /* the chunk in flight is all no-ops */
             round = end_round;
             done = true;
             return 0;
@@ -1495,24 +1523,24 @@ void BatchRun::plan_front_team() {
 /* ---- phase C: the rest of the propagation, one persistent workgroup per reference view (k_front, dmrecon_device.hip):
  * each view runs its own rounds from the list the last tail round left, at its own pace, until its front is empty. */
 int BatchRun::front_rounds() {
-    unsigned* d_off = c->d_front.p; unsigned* d_cnt = d_off + nj; unsigned* d_stats = d_cnt + nj;
+    unsigned* d_off = c->bs.d_front.p; unsigned* d_cnt = d_off + nj; unsigned* d_stats = d_cnt + nj;
     HIP_TRY(hipMemcpyAsync(d_off, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));   /* a view's list region = its pixel offset */
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * (size_t)nj * sizeof(unsigned) + nj * sizeof(unsigned), S));
     front_first_round = round;
     if (front_team > 1) {
-        if (c->d_front_mail.reserve((size_t)nj * MI_FRONT_MAIL_WORDS) || c->d_front_flags.reserve((size_t)nj * MI_FRONT_TEAM_MAX))
+        if (c->bs.d_front_mail.reserve((size_t)nj * MI_FRONT_MAIL_WORDS) || c->bs.d_front_flags.reserve((size_t)nj * MI_FRONT_TEAM_MAX))
             return fail(MI_DMRECON_EDEVICE, "hipMalloc(front mailboxes) failed");
-        HIP_TRY(hipMemsetAsync(c->d_front_mail.p, 0, (size_t)nj * MI_FRONT_MAIL_WORDS * sizeof(unsigned long long), S));
-        HIP_TRY(hipMemsetAsync(c->d_front_flags.p, 0, (size_t)nj * MI_FRONT_TEAM_MAX * sizeof(unsigned), S));
+        HIP_TRY(hipMemsetAsync(c->bs.d_front_mail.p, 0, (size_t)nj * MI_FRONT_MAIL_WORDS * sizeof(unsigned long long), S));
+        HIP_TRY(hipMemsetAsync(c->bs.d_front_flags.p, 0, (size_t)nj * MI_FRONT_TEAM_MAX * sizeof(unsigned), S));
     }
     ev.begin(S, EventLog::FRONT, tail_known);
-    D->front(S, nj, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, c->d_round_work.p + (round - 1),
+    D->front(S, nj, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, c->bs.d_round_work.p + (round - 1),
              wnext, rnext, wcur, rcur, d_off, d_cnt, d_stats, round, round + 4 * MI_MAX_ROUNDS, c->d_counters,
-             front_team, front_team > 1 ? c->d_front_mail.p : nullptr, front_team > 1 ? c->d_front_flags.p : nullptr);
+             front_team, front_team > 1 ? c->bs.d_front_mail.p : nullptr, front_team > 1 ? c->bs.d_front_flags.p : nullptr);
     ev.end(S);
     ++n_launch;
     front_stats.assign(4 * (size_t)nj, 0u);
-    TailPoll& P = c->h_poll[0];
+    TailPoll& P = c->bs.h_poll[0];
     HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
     HIP_TRY(read_dyn(0));
     HIP_TRY(hipMemcpyAsync(front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
@@ -1596,7 +1624,7 @@ void BatchRun::fill_stats() {
                 stats->ms_front_view_max = std::max(stats->ms_front_view_max, fs[3] * 1e-5);   /* 100 MHz ticks */
             }
         }
-        const DevCounters& ho = have_handover ? c->h_poll[2].hc : hc;      /* the stream has been synchronised */
+        const DevCounters& ho = have_handover ? c->bs.h_poll[2].hc : hc;      /* the stream has been synchronised */
         stats->n_eval_bulk = (int64_t)ho.n_eval; stats->n_patch_bulk = (int64_t)ho.n_patch; stats->n_filled_bulk = (int64_t)ho.n_filled;
         stats->ms_total = now_ms() - t_begin;
     }
@@ -1643,6 +1671,30 @@ int BatchRun::outcome() {
 
 }  // namespace
 
+/* A call's lease on a scratch set of its scene: the smallest free set that holds `pixels` (else the largest there is:
+ * growing one is cheaper than allocating from nothing), back to the pool when the call ends.  A set is only ever
+ * created when every existing one is in use, so a scene owns as many as it has had calls in flight at once. */
+struct ScratchLease {
+    mi_dmrecon_ctx* c;
+    ScratchLease(mi_dmrecon_ctx* c_, size_t pixels) : c(c_) {
+        std::lock_guard<std::mutex> lock(c->sc->pool_mu);
+        std::vector<BatchScratch>& pool = c->sc->scratch_pool;
+        pool.push_back(std::move(c->bs));                 /* what the context held (the hooks allocate without a lease) */
+        size_t pick = 0;
+        for (size_t i = 1; i < pool.size(); ++i) {
+            const size_t a = pool[i].pixels(), b = pool[pick].pixels();
+            if (b >= pixels ? (a >= pixels && a < b) : a > b) pick = i;
+        }
+        c->bs = std::move(pool[pick]);
+        pool.erase(pool.begin() + (std::ptrdiff_t)pick);
+    }
+    ~ScratchLease() {
+        std::lock_guard<std::mutex> lock(c->sc->pool_mu);
+        c->sc->scratch_pool.push_back(std::move(c->bs));
+        c->bs = BatchScratch();
+    }
+};
+
 static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views,
                              mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out,
                              mi_dmrecon_stats* stats) {
@@ -1652,6 +1704,23 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
     HIP_TRY(hipSetDevice(c->device));
     const ActiveCall active_call(c->device);
     if (stats) std::memset(stats, 0, sizeof(*stats));
+    /* pixels of the batch, for the choice of the scratch set (an estimate is enough: the buffers grow if it was low) */
+    size_t px_hint = 0;
+    for (int32_t i = 0; i < n_refs; ++i) {
+        const int32_t v = ref_views[i];
+        if (v < 0 || (size_t)v >= c->sc->views.size()) continue;
+        const HostView& hv = c->sc->views[v];
+        const size_t l = std::min<size_t>((size_t)std::max<int32_t>(0, st->scale), hv.levels.empty() ? 0 : hv.levels.size() - 1);
+        if (!hv.levels.empty()) px_hint += (size_t)hv.levels[l].w * (size_t)hv.levels[l].h;
+    }
+    /* every set grows to the largest batch the scene has seen (~200 B per pixel and set; up to 8 GB per set): after the
+     * first few calls no lease allocates any more, whichever set it gets */
+    {
+        size_t seen = c->sc->max_batch_px.load();
+        while (seen < px_hint && !c->sc->max_batch_px.compare_exchange_weak(seen, px_hint)) { }
+        c->floor_px = std::min<size_t>(std::max(seen, px_hint), ((size_t)8 << 30) / 200);
+    }
+    const ScratchLease lease(c, px_hint);
     BatchRun B;
     B.c = c; B.st = st; B.n_refs = n_refs; B.ref_views = ref_views; B.maps = maps; B.progress = progress;
     B.status_out = status_out; B.stats = stats; B.D = mi_device_api(st->filterWidth); B.ds = dev_settings(st); B.S = c->stream;
@@ -1671,7 +1740,7 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
             if ((rc = B.tail_rounds(to_front)) != 0) return rc;
             B.mark("phase B rounds");
             if (to_front) { if ((rc = B.front_rounds()) != 0) return rc; B.mark("phase C (front kernel)"); }
-            mi_launch_flatten(B.S, c->d_maps.p, c->d_imaps.p, B.total_px, st->nrReconNeighbors > 4);
+            mi_launch_flatten(B.S, c->bs.d_maps.p, c->bs.d_imaps.p, B.total_px, st->nrReconNeighbors > 4);
         }
         if ((rc = B.download()) != 0) return rc;
         B.fill_stats();
@@ -1849,21 +1918,21 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
         for (; cnt < 8; ++cnt) packed |= (unsigned long long)MI_VIEW_NONE << (8 * cnt);
         hy[i].views = (uint32_t)packed; hy[i].views_hi = (uint32_t)(packed >> 32);
     }
-    if (c->d_jobs.reserve(1) || c->d_work.reserve(n) || c->d_hyp.reserve(n) || c->d_results.reserve(n))
+    if (c->bs.d_jobs.reserve(1) || c->bs.d_work.reserve(n) || c->bs.d_hyp.reserve(n) || c->bs.d_results.reserve(n))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc failed");
-    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_work.p, ent.data(), n * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_hyp.p, hy.data(), n * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_jobs.p, dj.data(), sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_work.p, ent.data(), n * sizeof(DevEntry), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_hyp.p, hy.data(), n * sizeof(DevHyp), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     /* lanes_per_view = 16 runs the hook through the latency layout, anything else through the throughput layout */
     const int lpv = lanes_per_view == 16 ? 16 : 1;
     const unsigned ppw = lpv == 16 ? 1u : patches_per_wave(st);
-    D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st),
-               c->d_work.p, c->d_hyp.p, c->d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
+    D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st),
+               c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
                nullptr, nullptr, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     std::vector<DevResult> res(n);
-    HIP_TRY(hipMemcpyAsync(res.data(), c->d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(res.data(), c->bs.d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; ++i) {
         float* o = out + 8 * i;
@@ -1902,12 +1971,12 @@ static int mi_dmrecon_patch_eval_impl(mi_dmrecon_ctx* c, const mi_dmrecon_settin
     const size_t NS3 = 3 * (size_t)st->filterWidth * st->filterWidth;       /* floats per view: fw x fw samples, 3 channels */
     const size_t nfl = 5 + G + 2 * (size_t)G * NS3;
     DevBuf<float> dout; DevBuf<int32_t> diout;
-    if (dout.reserve(nfl) || diout.reserve(2 * G) || c->d_jobs.reserve(1)) return fail(MI_DMRECON_EDEVICE, "hipMalloc failed");
+    if (dout.reserve(nfl) || diout.reserve(2 * G) || c->bs.d_jobs.reserve(1)) return fail(MI_DMRECON_EDEVICE, "hipMalloc failed");
     HIP_TRY(hipMemsetAsync(dout.p, 0, nfl * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(diout.p, 0, 2 * G * sizeof(int32_t), c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dj.data(), sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_jobs.p, dj.data(), sizeof(DevJob), hipMemcpyHostToDevice, c->stream));
     float* d_master = dout.p; float* d_ncc = dout.p + 5; float* d_col = d_ncc + G; float* d_der = d_col + (size_t)G * NS3;
-    D.patch_eval(c->stream, c->d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), x, y, depth, dzI, dzJ,
+    D.patch_eval(c->stream, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st), x, y, depth, dzI, dzJ,
                          d_master, d_ncc, diout.p, d_col, d_der, diout.p + G);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(master, d_master, 5 * 4, hipMemcpyDeviceToHost, c->stream));
