@@ -139,6 +139,7 @@ def load_library() -> ctypes.CDLL:
                                       ctypes.POINTER(i32)]
     L.mi_dmrecon_debug_inject_footprint.argtypes = [ctypes.c_int]          # test hook, not in the public header
     L.mi_dmrecon_debug_inject_footprint.restype = None
+    L.mi_dmrecon_debug_scratch_sets.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]  # test hook, not in the public header
     _lib = L
     return L
 
@@ -243,6 +244,12 @@ class Context:
         c = Context.__new__(Context)
         c._L, c._h, c.device, c.n_views, c._keep = self._L, h, self.device, self.n_views, None
         return c
+
+    def debug_scratch_sets(self):
+        """Test hook: (free scratch sets of this context's scene, pixel capacity of the largest)."""
+        px = ctypes.c_longlong(0)
+        n = self._L.mi_dmrecon_debug_scratch_sets(self._h, ctypes.byref(px))
+        return int(n), int(px.value)
 
     def close(self):
         if getattr(self, "_h", None):

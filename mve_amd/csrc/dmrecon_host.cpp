@@ -2055,6 +2055,17 @@ static int mi_dmrecon_pointset_impl(mi_dmrecon_ctx* c, const mi_dmrecon_camera* 
  * that follow (-1: none), see fill_job */
 void mi_dmrecon_debug_inject_footprint(int view_id) { g_inject_footprint.store(view_id); }
 
+/* test hook (not in the public header): the scratch sets of the context's scene that no call holds at the moment, and the
+ * pixel capacity of the largest of them (ScratchLease) */
+int mi_dmrecon_debug_scratch_sets(mi_dmrecon_ctx* c, long long* pixels_max) {
+    if (!c) return -1;
+    std::lock_guard<std::mutex> lock(c->sc->pool_mu);
+    size_t best = 0;
+    for (const BatchScratch& b : c->sc->scratch_pool) best = std::max(best, b.pixels());
+    if (pixels_max) *pixels_max = (long long)best;
+    return (int)c->sc->scratch_pool.size();
+}
+
 /* development aid (not in the public header): the debug buffer of MI_PROBE builds (tools/patch_probe.py).  The first
  * call allocates `n` words on the device; later calls copy up to n words out and clear the buffer. */
 int mi_dmrecon_debug_buffer(unsigned long long* out, int n) {

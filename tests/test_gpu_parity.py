@@ -268,6 +268,45 @@ def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, m
     gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
 
 
+def test_batch_scratch_is_leased_from_the_scene(gpu_ctx, g1_scene, monkeypatch):
+    """Lists, results and state maps of a batch belong to the scene, not to the context that runs the batch: calls that
+    follow each other on different forked contexts re-use ONE set (whichever context leads a merged batch inside a timed
+    region finds the buffers of the largest batch so far), calls that overlap get one each; the maps do not depend on
+    which set a call got."""
+    import threading
+    gpu_ctx.load_scene(g1_scene)
+    monkeypatch.setenv("MI_DMRECON_MERGE_CALLS", "0")
+    st = api.Settings()
+    ref = gpu_ctx.reconstruct(st, [0, 1, 2, 3, 4], want_views=True)
+    sets0, px0 = gpu_ctx.debug_scratch_sets()
+    assert sets0 >= 1 and px0 >= 5 * 160 * 120
+    forks = [gpu_ctx.fork() for _ in range(3)]
+    for f in forks:                                         # one after the other: no new set, none grows
+        got = f.reconstruct(st, [2], want_views=True)
+        assert np.array_equal(got[0]["depth"], gpu_ctx.reconstruct(st, [2], want_views=True)[0]["depth"])
+        assert f.debug_scratch_sets() == (sets0, px0)
+    go = threading.Barrier(3)
+    out = [None] * 3
+
+    def worker(i):
+        go.wait()
+        out[i] = forks[i].reconstruct(st, [0, 1, 2, 3, 4], want_views=True)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    sets1, px1 = gpu_ctx.debug_scratch_sets()
+    assert sets0 <= sets1 <= max(sets0, 3) and px1 == px0   # at most one per overlapping call, all back in the pool
+    for o in out:
+        for a, b in zip(o, ref):
+            for k in ("depth", "conf", "dz", "normal", "views"):
+                assert np.array_equal(a[k], b[k]), k
+    for f in forks:
+        f.close()
+
+
 def test_concurrent_calls_are_merged_and_keep_their_own_results(gpu_ctx, g1_scene, monkeypatch):
     """Calls that arrive together on forked contexts of one scene with equal settings run as ONE batch
     (mi_dmrecon_reconstruct's merge front end): every caller gets the maps, statuses and errors of its own call; the
