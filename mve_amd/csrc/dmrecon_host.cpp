@@ -223,6 +223,7 @@ struct BatchScratch {
     DevBuf<GvsRef> d_gvs_refs;
     std::vector<hipEvent_t> events;
     size_t pixels() const { return d_maps.cap / 14; }       /* state maps: 14 floats per pixel */
+    bool holds_anything() const { return d_maps.cap || d_work.cap || d_jobs.cap || d_results.cap || d_hyp.cap || h_poll || h_dyn || !events.empty(); }
     void release() {
         for (size_t i = 0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
         events.clear();
@@ -1679,7 +1680,9 @@ struct ScratchLease {
     ScratchLease(mi_dmrecon_ctx* c_, size_t pixels) : c(c_) {
         std::lock_guard<std::mutex> lock(c->sc->pool_mu);
         std::vector<BatchScratch>& pool = c->sc->scratch_pool;
-        pool.push_back(std::move(c->bs));                 /* what the context held (the hooks allocate without a lease) */
+        if (c->bs.holds_anything()) pool.push_back(std::move(c->bs));   /* (the parity hooks allocate without a lease) */
+        c->bs = BatchScratch();
+        if (pool.empty()) return;                         /* the first call of the scene, or every set is in use: a new one */
         size_t pick = 0;
         for (size_t i = 1; i < pool.size(); ++i) {
             const size_t a = pool[i].pixels(), b = pool[pick].pixels();
@@ -1690,7 +1693,7 @@ struct ScratchLease {
     }
     ~ScratchLease() {
         std::lock_guard<std::mutex> lock(c->sc->pool_mu);
-        c->sc->scratch_pool.push_back(std::move(c->bs));
+        if (c->bs.holds_anything()) c->sc->scratch_pool.push_back(std::move(c->bs));
         c->bs = BatchScratch();
     }
 };
