@@ -147,6 +147,9 @@ std::atomic<int> g_active_calls[MI_MAX_DEVICES];
 std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 /* MI_DMRECON_FRONT defaults: entries per reference view (average over the batch) below which the rest of the
  * propagation goes to the front kernel, for a call alone on its GPU / next to other calls (BatchRun::tail_rounds) */
+#define MI_MERGE_SMALL_CALL 48      /* reference views: below this a call waits MI_MERGE_WINDOW_US for company, ... */
+#define MI_MERGE_WINDOW_US 1000
+#define MI_MERGE_WINDOW_BIG_US 150  /* ... from this size on only this long (see mi_dmrecon_reconstruct) */
 #define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
 #define MI_FRONT_MIN_CAP 256       /* hand-over to k_front: entries per view, at least */
 #define MI_FRONT_PER_TEAM_WG 64    /* ... and per workgroup of a view's team */
@@ -1672,8 +1675,7 @@ int BatchRun::outcome() {
 
 }  // namespace
 
-/* A call's lease on a scratch set of its scene: the smallest free set that holds `pixels` (else the largest there is:
- * growing one is cheaper than allocating from nothing), back to the pool when the call ends.  A set is only ever
+/* A call's lease on a scratch set of its scene (the largest free one), back to the pool when the call ends.  A set is only ever
  * created when every existing one is in use, so a scene owns as many as it has had calls in flight at once. */
 struct ScratchLease {
     mi_dmrecon_ctx* c;
@@ -1683,11 +1685,12 @@ struct ScratchLease {
         if (c->bs.holds_anything()) pool.push_back(std::move(c->bs));   /* (the parity hooks allocate without a lease) */
         c->bs = BatchScratch();
         if (pool.empty()) return;                         /* the first call of the scene, or every set is in use: a new one */
+        /* the LARGEST free set: every set a call gets is brought up to the scene's high-water mark (floor_px), so handing
+         * out a small one only moves its growth into this call; small sets stay behind for the moments when more calls
+         * overlap than ever before */
+        (void)pixels;
         size_t pick = 0;
-        for (size_t i = 1; i < pool.size(); ++i) {
-            const size_t a = pool[i].pixels(), b = pool[pick].pixels();
-            if (b >= pixels ? (a >= pixels && a < b) : a > b) pick = i;
-        }
+        for (size_t i = 1; i < pool.size(); ++i) if (pool[i].pixels() > pool[pick].pixels()) pick = i;
         c->bs = std::move(pool[pick]);
         pool.erase(pool.begin() + (std::ptrdiff_t)pick);
     }
@@ -1716,12 +1719,14 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
         const size_t l = std::min<size_t>((size_t)std::max<int32_t>(0, st->scale), hv.levels.empty() ? 0 : hv.levels.size() - 1);
         if (!hv.levels.empty()) px_hint += (size_t)hv.levels[l].w * (size_t)hv.levels[l].h;
     }
-    /* every set grows to the largest batch the scene has seen (~200 B per pixel and set; up to 8 GB per set): after the
-     * first few calls no lease allocates any more, whichever set it gets */
+    /* every set is sized for TWICE the largest batch the scene has seen (~200 B per pixel and set; up to 8 GB per set):
+     * after the first calls no lease allocates any more, whichever set it gets and whether or not its call has been
+     * merged with another one this time (growing a set inside a call costs ~30 ms, and hipFree stalls the batch that
+     * runs next to it as well) */
     {
         size_t seen = c->sc->max_batch_px.load();
         while (seen < px_hint && !c->sc->max_batch_px.compare_exchange_weak(seen, px_hint)) { }
-        c->floor_px = std::min<size_t>(std::max(seen, px_hint), ((size_t)8 << 30) / 200);
+        c->floor_px = std::min<size_t>(2 * std::max(seen, px_hint), ((size_t)8 << 30) / 200);
     }
     const ScratchLease lease(c, px_hint);
     BatchRun B;
@@ -1762,7 +1767,7 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
  * 905 depth-maps/s where six threads with 100 each reach 740-830).  This is what the shim does
  * for mvs::DMRecon::start(); here for callers of the C ABI.
  *   - A call that finds fewer than MI_DMRECON_MERGE_RUNNING (2) batches running becomes a LEADER: it takes every
- *     request pending at that moment (after a wait of MI_DMRECON_MERGE_WINDOW_US = 150 us for more, only if calls of
+ *     request pending at that moment (after a wait of MI_DMRECON_MERGE_WINDOW_US = 1000 / 150 us for more, only if calls of
  *     this scene have met within the last few calls), runs them as one batch on its own context and hands the results out.  The other
  *     calls wait; whoever is still pending when a batch ends becomes the next leader.  A lone caller never waits.
  *   - Per-view statuses go to their callers; a caller all of whose views failed gets the first failure as its return
@@ -1779,7 +1784,13 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
      * fills the drain of the other's and its host round trip) -- taking turns in phase A instead costs 15 % at the
      * bench's plan, four in flight 30 % */
     const int MAX_RUNNING = 2;
-    const int WINDOW_US = [] { const char* e = std::getenv("MI_DMRECON_MERGE_WINDOW_US"); return e ? std::max(0, std::atoi(e)) : 150; }();
+    const int WINDOW_ENV = [] { const char* e = std::getenv("MI_DMRECON_MERGE_WINDOW_US"); return e ? std::max(0, std::atoi(e)) : -1; }();
+    /* A small call gains from company (the bulk kernel reaches 0.30+ of the HBM roof in launches of 100+ views, 0.21 at 20;
+     * the tail is paid once per batch) and waits a millisecond for it -- that also catches the callers that come back
+     * from the batch that has just ended; a call that fills the launches by itself waits only for what arrives with it.
+     * Measured: six host threads x 20-view calls 615-712 -> 706-850 depth-maps/s; with 100-view calls the long wait
+     * turns the bench plan's batches (1 + 1 + 2 calls) into 1 + 3 or 2 + 2: 1 050-1 170 against 1 165-1 220. */
+    const int WINDOW_US = WINDOW_ENV >= 0 ? WINDOW_ENV : (n_refs < MI_MERGE_SMALL_CALL ? MI_MERGE_WINDOW_US : MI_MERGE_WINDOW_BIG_US);
     if (!MERGE || progress || !c || !st || !ref_views || !maps || n_refs <= 0)
         return reconstruct_batch(c, st, n_refs, ref_views, maps, progress, status_out, stats);
     MergeQueue& Q = c->sc->merge;
@@ -1805,9 +1816,10 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
             lock.lock();
             Q.gathering = false;
         }
-        /* take every pending request with my settings, in arrival order (taking only half of them next to a running batch,
-         * so that two half-size batches run side by side afterwards, was measured: 970-1 040 against 1 095-1 210 at the
-         * bench's plan, 467 against 618 with many 20-view calls) */
+        /* take every pending request with my settings, in arrival order.  Measured and dropped: taking only half of them
+         * next to a running batch (two half-size batches side by side afterwards: 970-1 040 against 1 095-1 210 at the
+         * bench's plan), and taking half of them with both slots free (2 + 2 calls instead of 1 + 1 + 2: 1 050-1 290,
+         * mean below 1 + 1 + 2) */
         for (size_t i = 0; i < Q.pending.size();) {
             MergeReq* r = Q.pending[i];
             if (std::memcmp(r->st, st, sizeof(*st)) == 0) { r->taken = true; batch.push_back(r); Q.pending.erase(Q.pending.begin() + i); }
