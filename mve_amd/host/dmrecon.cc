@@ -64,6 +64,15 @@ void trace(char const* what, double since_ms, long n = -1)
     else std::fprintf(stderr, "[mvs::DMRecon shim] t=%9.2f ms  %-34s %9.2f ms\n", now, what, now - since_ms);
 }
 
+/* The HIP runtime takes 90-190 ms to start (first hipGetDeviceCount).  In a program that links this shim it starts in a
+ * helper thread before main() -- next to the driver's own start-up (arguments, scene directory, view headers) instead of
+ * inside the first DMRecon constructor.  Joined at exit, so a run that ends at once (--help) waits for it. */
+struct HipWarmUp {
+    std::thread t;
+    HipWarmUp() : t([]() { (void)mi_dmrecon_device_count(); }) {}
+    ~HipWarmUp() { if (t.joinable()) t.join(); }
+} g_hip_warm_up;
+
 [[noreturn]] void raise_from(int rc)
 {
     std::string msg = mi_dmrecon_last_error();
@@ -339,12 +348,41 @@ private:
         double t_mark = trace_ms();
         std::vector<mi_dmrecon_ctx*> ctxs(ns, nullptr);
         std::vector<std::unique_ptr<std::mutex> > ctx_mu;
-        for (std::size_t s = 0; s < ns; ++s) {
-            ctx_mu.push_back(std::unique_ptr<std::mutex>(new std::mutex()));
-            int rc = mi_dmrecon_ctx_create(g.slots[s]->device, &ctxs[s]);
-            if (rc != 0) { for (std::size_t k = 0; k < s; ++k) mi_dmrecon_ctx_destroy(ctxs[k]); raise_from(rc); }
-        }
-        trace("contexts created (HIP start-up)", t_mark, (long)ns); t_mark = trace_ms();
+        for (std::size_t s = 0; s < ns; ++s) ctx_mu.push_back(std::unique_ptr<std::mutex>(new std::mutex()));
+        /* Three things that do not need each other run side by side: HIP start-up + one context per GPU (~30 ms), MVE's
+         * parse of the bundle file (55 ms alone; the reference's constructor does it first, every OpenMP thread of the
+         * driver at once), and the PNG decoders, which only need a context when their first image is ready. */
+        int ctx_rc = 0;
+        std::string ctx_msg;
+        std::mutex ready_mu;
+        std::condition_variable ready_cv;
+        bool ctx_ready = false;
+        std::thread ctx_thread([&]() {
+            double const t0 = trace_ms();
+            int rc = 0;
+            for (std::size_t s = 0; s < ns && rc == 0; ++s) {
+                rc = mi_dmrecon_ctx_create(g.slots[s]->device, &ctxs[s]);
+                if (rc != 0) ctx_msg = mi_dmrecon_last_error();
+            }
+            trace("contexts created (HIP start-up)", t0, (long)ns);
+            std::lock_guard<std::mutex> lock(ready_mu);
+            ctx_rc = rc; ctx_ready = true;
+            ready_cv.notify_all();
+        });
+        std::exception_ptr bundle_exc;
+        std::thread bundle_thread([&]() {
+            double const t0 = trace_ms();
+            try { g.scene->get_bundle(); }
+            catch (std::exception& e) {                       /* dmrecon.cc:50-59 */
+                bundle_exc = std::make_exception_ptr(std::runtime_error(std::string("Error reading bundle file: ") + e.what()));
+            } catch (...) { bundle_exc = std::current_exception(); }
+            trace("bundle parsed", t0);
+        });
+        auto wait_for_contexts = [&]() -> bool {
+            std::unique_lock<std::mutex> lock(ready_mu);
+            ready_cv.wait(lock, [&] { return ctx_ready; });
+            return ctx_rc == 0;
+        };
         mve::Scene::ViewList const& views(g.scene->get_views());
         /* A decoded image stays alive until the copies enqueued from it have run (mi_dmrecon_sync).  The views go
          * through in windows of a few per decoding thread: decode + enqueue in parallel, then one sync of every GPU,
@@ -376,6 +414,7 @@ private:
                         mve::ByteImage::Ptr img = views[i]->get_byte_image(g.embedding);  /* decode: per view, no shared state */
                         if (img == nullptr) continue;
                         keep[i] = img;
+                        if (!wait_for_contexts()) return;
                         mve::CameraInfo const& cam = views[i]->get_camera();
                         mi_dmrecon_camera mc;
                         mc.flen = cam.flen; mc.paspect = cam.paspect;
@@ -403,16 +442,25 @@ private:
             for (int t = 1; t < n_here; ++t) pool.emplace_back(work);
             work();
             for (std::size_t t = 0; t < pool.size(); ++t) pool[t].join();
+            if (!wait_for_contexts()) break;
             for (std::size_t s = 0; s < ns; ++s) {
                 int rc = mi_dmrecon_sync(ctxs[s]);
                 if (rc != 0 && failed_rc == 0) { failed_rc = rc; failed_msg = mi_dmrecon_last_error(); }
             }
             for (std::size_t i = base; i < end; ++i) keep[i].reset();
         }
-        if (first_exc) {
-            for (std::size_t s = 0; s < ns; ++s) mi_dmrecon_ctx_destroy(ctxs[s]);
-            std::rethrow_exception(first_exc);
+        ctx_thread.join();
+        bundle_thread.join();
+        auto destroy_contexts = [&]() { for (std::size_t s = 0; s < ns; ++s) if (ctxs[s]) mi_dmrecon_ctx_destroy(ctxs[s]); };
+        if (bundle_exc) { destroy_contexts(); std::rethrow_exception(bundle_exc); }     /* the reference's first failure */
+        if (ctx_rc != 0) {
+            destroy_contexts();
+            switch (ctx_rc) {
+                case MI_DMRECON_EINVAL: throw std::invalid_argument(ctx_msg);
+                default: throw std::runtime_error(ctx_msg);
+            }
         }
+        if (first_exc) { destroy_contexts(); std::rethrow_exception(first_exc); }
         trace("views decoded + staged", t_mark, (long)views.size()); t_mark = trace_ms();
         mve::Bundle::Features const& feats = g.scene->get_bundle()->get_features();
         std::vector<float> pos(feats.size() * 3);
@@ -470,15 +518,6 @@ DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
     if (settings.imageEmbedding.empty())
         throw std::invalid_argument("Invalid image embedding");
     double const t_ctor = trace_ms();
-    try {
-        this->scene->get_bundle();
-    } catch (std::exception& e) {
-        throw std::runtime_error(std::string("Error reading bundle file: ") + e.what());
-    }
-    mve::View::Ptr ref = mve_views[settings.refViewNr];
-    if (ref == nullptr || !ref->is_camera_valid()
-        || !ref->has_image(settings.imageEmbedding, mve::IMAGE_TYPE_UINT8))
-        throw std::invalid_argument("Invalid master view");
 
     /* requests are dealt round-robin over the GPUs of the generation (schedule(dynamic,1) over views, apps/dmrecon/
      * dmrecon.cc:285, hands consecutive views to whichever thread is free: any static thread -> GPU map would do) */
@@ -489,7 +528,13 @@ DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
      * the views, so by the time it ends every one of them is counted and their start() calls form one batch */
     att->slot->announce(); att->announced = true;
     this->slot = att;
+    /* stages the scene on first use; the bundle file is read in there, next to the image decoders (dmrecon.cc:50-59:
+     * std::runtime_error "Error reading bundle file: ..." -- before the master view is looked at, as in the reference) */
     Registry::make_resident(*att->gen);
+    mve::View::Ptr ref = mve_views[settings.refViewNr];
+    if (ref == nullptr || !ref->is_camera_valid()
+        || !ref->has_image(settings.imageEmbedding, mve::IMAGE_TYPE_UINT8))
+        throw std::invalid_argument("Invalid master view");
     Slot* slot = att->slot;
     int32_t w = 0, h = 0;
     {
