@@ -202,7 +202,10 @@ int  mi_dmrecon_global_view_selection(mi_dmrecon_ctx* ctx, const mi_dmrecon_sett
  * it is in only through the round at which the batch changes lane layouts (rounding of 1e-7 that now and then flips
  * a convergence decision: bit-equal on small scenes, fill IoU >= 0.999 / depth p99 <= 3e-3 on the C3 scene, far
  * inside the parity tolerances).  The statistics go to the call that ran the batch (stats.n_merged_calls; the
- * others get zeros and stats.merged_into_other_call = 1).  MI_DMRECON_MERGE_CALLS=0 switches this off. */
+ * others get zeros and stats.merged_into_other_call = 1).  MI_DMRECON_MERGE_CALLS=0 switches this off.
+ * A call that has the GPU to itself runs the end of its propagation with several persistent workgroups per view that
+ * wait for each other every round (stats.front_team): every PROCESS that shares its GPU with another process must set
+ * MI_DMRECON_FRONT_TEAM=1 (the library only sees the calls of its own process). */
 int  mi_dmrecon_reconstruct(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t n_refs,
                             const int32_t* ref_views, mi_dmrecon_maps* maps,
                             mi_dmrecon_progress* progress, int32_t* status_out, mi_dmrecon_stats* stats);
