@@ -7,8 +7,10 @@ driver: option names and defaults (scene2pset.cc:159-235), view filters (:268-30
 layout of mve::geom::save_ply_mesh (libs/mve/mesh_io_ply.cc:740-815: x y z [nx ny nz] [red green blue] [confidence]
 [value], binary little endian).  Views are appended in view order, the points of a view in ascending pixel order
 (the reference appends views in OpenMP completion order and numbers a view's points by first use: as a SET the
-output is the reference's).  Not provided: --mask (silhouette clipping), --correspondence, .npts/.bnpts/.off outputs.
-Depth maps are .mvei embeddings, colour images .png embeddings of the view directories (scene_io.py).
+output is the reference's; the rows of the --correspondence table follow the same order).  --mask (silhouette
+clipping, :406-465), --correspondence (:65-118) and the .npts / .bnpts / .off outputs of mve::geom::save_mesh
+(mesh_io_npts.cc:66-98, mesh_io_off.cc) are pinned to the unmodified app by tests/golden/scene2pset_g1_opts.npz.
+Depth maps are .mvei embeddings, colour and mask images .png embeddings of the view directories (scene_io.py).
 """
 from __future__ import annotations
 
@@ -51,7 +53,8 @@ def scene_to_pointset(scene_dir: str, dmname: str = "depth-L0", image: str = "un
     own = ctx is None
     if own:
         ctx = api.Context(0)
-    parts: Dict[str, List[np.ndarray]] = dict(pos=[], normal=[], color=[], scale=[], conf=[], view=[])
+    parts: Dict[str, List[np.ndarray]] = dict(pos=[], normal=[], color=[], scale=[], conf=[], view=[], pixel=[])
+    meta: List[List[int]] = []                                       # --correspondence: view id, width, height, first vertex
     have_color = True
     for vid, vdir, cam in view_entries(scene_dir):
         if ids and vid not in ids:                                   # :271-274
@@ -88,6 +91,8 @@ def scene_to_pointset(scene_dir: str, dmname: str = "depth-L0", image: str = "un
         parts["pos"].append(ps["pos"][keep]); parts["normal"].append(nrm[keep].astype(np.float32))
         parts["scale"].append(ps["scale"][keep]); parts["conf"].append(ps["conf"][keep])
         parts["view"].append(np.full(int(keep.sum()), vid, np.int32))
+        meta.append([vid, depth.shape[1], depth.shape[0], sum(len(p) for p in parts["pixel"])])
+        parts["pixel"].append(ps["pixel"][keep].astype(np.int64))
         if color is None:
             have_color = False
         else:
@@ -98,10 +103,93 @@ def scene_to_pointset(scene_dir: str, dmname: str = "depth-L0", image: str = "un
         ctx.close()
     cat = lambda k, shape, dt: np.concatenate(parts[k]) if parts[k] else np.zeros(shape, dt)
     out = dict(pos=cat("pos", (0, 3), np.float32), normal=cat("normal", (0, 3), np.float32),
-               scale=cat("scale", (0,), np.float32), conf=cat("conf", (0,), np.float32), view=cat("view", (0,), np.int32))
+               scale=cat("scale", (0,), np.float32), conf=cat("conf", (0,), np.float32), view=cat("view", (0,), np.int32),
+               pixel=cat("pixel", (0,), np.int64), meta=np.asarray(meta, np.int64).reshape(-1, 4))
     # the reference writes colours only if every contributing view had an image (save_ply_mesh: sizes must match)
     out["color"] = cat("color", (0, 3), np.uint8) if have_color and parts["color"] else None
     return out
+
+
+def mask_filter(scene_dir: str, ps: Dict[str, np.ndarray], maskname: str, verbose: bool = True) -> Dict[str, np.ndarray]:
+    """Silhouette clipping (scene2pset.cc:406-465): a point is dropped if it projects onto a zero pixel of ANY view's
+    one-channel `maskname` image.  The projection is the reference's float arithmetic, operation by operation
+    (Matrix4f::mult(v, 1), Matrix3f * v: math/matrix.h:475-492; CameraInfo::fill_calibration, camera.cc:125-144)."""
+    from PIL import Image
+    f32 = np.float32
+    pos = ps["pos"].astype(f32)
+    dead = np.zeros(len(pos), bool)
+    for vid, vdir, cam in view_entries(scene_dir):
+        if cam.flen == 0.0:
+            continue
+        mpath = os.path.join(vdir, maskname + ".png")
+        if not os.path.exists(mpath):
+            if verbose:
+                print('Mask not found for image "view %d", skipping.' % vid)
+            continue
+        with Image.open(mpath) as im:
+            if len(im.getbands()) != 1:
+                if verbose:
+                    print('Expected 1-channel mask for image "view %d", skipping.' % vid)
+                continue
+            mask = np.asarray(im)
+        h, w = mask.shape
+        rot, t = np.asarray(cam.rot, f32), np.asarray(cam.trans, f32)
+        fw, fh, flen, pa = f32(w), f32(h), f32(cam.flen), f32(cam.paspect)
+        if (fw / fh) * pa < f32(1.0):                                  # portrait
+            ax, ay = flen * fh / pa, flen * fh
+        else:
+            ax, ay = flen * fw, flen * fw * pa
+        cx, cy = fw * f32(cam.ppoint[0]), fh * f32(cam.ppoint[1])
+        x, y, z = pos[:, 0], pos[:, 1], pos[:, 2]
+        zero = f32(0.0)
+        c = [((zero + rot[3 * r] * x) + rot[3 * r + 1] * y) + rot[3 * r + 2] * z + f32(1.0) * t[r] for r in range(3)]
+        px = ((zero + ax * c[0]) + zero * c[1]) + cx * c[2]
+        py = ((zero + zero * c[0]) + ay * c[1]) + cy * c[2]
+        pz = ((zero + zero * c[0]) + zero * c[1]) + f32(1.0) * c[2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u, v = px / pz, py / pz
+        inside = ~((u < 0) | (v < 0) | (u >= fw) | (v >= fh)) & np.isfinite(u) & np.isfinite(v) & ~dead
+        ix = np.where(inside, u, 0).astype(np.int64); iy = np.where(inside, v, 0).astype(np.int64)
+        hit = inside & (mask[np.clip(iy, 0, h - 1), np.clip(ix, 0, w - 1)] == 0)
+        dead |= hit
+    if verbose:
+        print("Filtered a total of %d points." % int(dead.sum()))
+    keep = ~dead
+    return {k: (v[keep] if isinstance(v, np.ndarray) and k != "meta" and len(v) == len(keep) else v) for k, v in ps.items()}
+
+
+def write_correspondence(mesh_out: str, ps: Dict[str, np.ndarray]) -> None:
+    """<out>_correspondence-data.csv (pixel x, y of every vertex) and -metadata.csv (scene2pset.cc:85-118)."""
+    with open(mesh_out + "_correspondence-data.csv", "w") as f:
+        f.write("x, y\n")
+        off = 0
+        for vid, w, h, first in ps["meta"]:
+            nxt = [m[3] for m in ps["meta"] if m[3] > first]
+            end = min(nxt) if nxt else len(ps["pixel"])
+            px = ps["pixel"][first:end]
+            f.write("".join("%d, %d\n" % (p % w, p // w) for p in px))
+    with open(mesh_out + "_correspondence-metadata.csv", "w") as f:
+        f.write("View_ID, Width, Height, First_Vertex_Index\n")
+        f.write("".join("%d, %d, %d, %d\n" % tuple(m) for m in ps["meta"]))
+
+
+def write_npts(path: str, ps: Dict[str, np.ndarray], binary: bool) -> None:
+    """mve::geom::save_npts_mesh (mesh_io_npts.cc:66-98): position + normal per point, six floats raw or as text."""
+    if len(ps["pos"]) == 0:
+        raise ValueError("Input mesh is empty")
+    rows = np.concatenate([ps["pos"].astype("<f4"), ps["normal"].astype("<f4")], axis=1)
+    with open(path, "wb") as f:
+        if binary:
+            f.write(rows.tobytes())
+        else:                                                        # operator<< of float: printf %g
+            f.write("".join("%g %g %g %g %g %g\n" % tuple(float(x) for x in r) for r in rows).encode("ascii"))
+
+
+def write_off(path: str, ps: Dict[str, np.ndarray]) -> None:
+    """mve::geom::save_off_mesh for a mesh without faces (mesh_io_off.cc): fixed notation, seven digits."""
+    with open(path, "wb") as f:
+        f.write(("OFF\n%d 0 0\n" % len(ps["pos"])).encode("ascii"))
+        f.write("".join("%.7f %.7f %.7f\n" % tuple(float(x) for x in r) for r in ps["pos"].astype(np.float32)).encode("ascii"))
 
 
 def write_ply(path: str, ps: Dict[str, np.ndarray], with_normals: bool, with_scale: bool, with_conf: bool) -> None:
@@ -178,13 +266,18 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("-p", "--poisson-normals", action="store_true")
     ap.add_argument("-S", "--scale-factor", type=float, default=2.5)
     ap.add_argument("-F", "--fssr", type=int, default=None, help="FSSR output, sets -nsc and -di with scale ARG")
+    ap.add_argument("-m", "--mask", default="", help="Name of mask/silhouette image to clip 3D points []")
+    ap.add_argument("-C", "--correspondence", action="store_true", help="Output correspondences (in absence of -m and -b only)")
     a = ap.parse_args(argv)
-    if not a.mesh_out.endswith(".ply"):
-        ap.error("only .ply output is provided by this build")
+    ext = os.path.splitext(a.mesh_out)[1]
+    if ext not in (".ply", ".npts", ".bnpts", ".off"):               # mve::geom::save_mesh, mesh_io.cc:48-66
+        ap.error("Extension not recognized")
     if a.fssr is not None:                                           # scene2pset.cc:205-217
         a.with_conf = a.with_normals = a.with_scale = True
         a.depthmap = "depth-L%d" % a.fssr
         a.image = "undistorted" if a.fssr == 0 else "undist-L%d" % a.fssr
+    if ext in (".npts", ".bnpts"):                                   # scene2pset.cc:225-231
+        a.with_normals, a.with_scale, a.with_conf = True, False, False
     if a.poisson_normals:                                            # :229-233
         a.with_normals = a.with_conf = True
     ids: List[int] = []
@@ -201,8 +294,18 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             return 1
     print('Using depthmap "%s" and color image "%s"' % (a.depthmap, a.image))
     ps = scene_to_pointset(a.scene_dir, a.depthmap, a.image, ids or None, aabb, a.min_fraction, a.scale_factor, a.poisson_normals)
+    if a.mask:
+        print("Filtering points using silhouette masks...")
+        ps = mask_filter(a.scene_dir, ps, a.mask)
     print("Writing final point set (%d points)..." % len(ps["pos"]))
-    write_ply(a.mesh_out, ps, a.with_normals, a.with_scale, a.with_conf)
+    if ext == ".ply":
+        write_ply(a.mesh_out, ps, a.with_normals, a.with_scale, a.with_conf)
+    elif ext == ".off":
+        write_off(a.mesh_out, ps)
+    else:
+        write_npts(a.mesh_out, ps, binary=(ext == ".bnpts"))
+    if a.correspondence and aabb is None and not a.mask:             # scene2pset.cc:374, :481
+        write_correspondence(a.mesh_out, ps)
     return 0
 
 
