@@ -1,26 +1,12 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): front workgroups (next to other calls) with fewer registers, so that bulk wavefronts fit beside them.
-TAG=${1:-r3aq}
-OUT=$PWD/gpurun_out/$TAG
-mkdir -p $OUT
+# Runs ON THE GPU BOX (through gpurun): the whole GPU suite, the smoke test, and the bench with the RCCL path forced on one rank.
 export TMPDIR=/tmp
-show() {
-  python - $1 $2 <<'PY'
-import sys, json
-try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); t = d['roofline']['per_kernel']['k_tail + k_front (tail rounds)']; b = d['roofline']['per_kernel']['k_optimize<1> (host-visible rounds)']
-    print('%-14s' % sys.argv[2], round(d['value'], 1), 'maps/s', 'ms/step', round(d['ms_per_step'], 2), 'bulk ms', round(b['avg_launch_ms'] * b['launches'] / d['steps'], 2), 'frac', round(d['roofline']['bulk_kernel_frac'], 3), 'k_front', round(t['k_front_ms'] / d['steps'], 2))
-except Exception as e:
-    print(sys.argv[2], 'failed', e)
+mkdir -p gpurun_out/r3ap
+timeout -s KILL 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+MI_FORCE_DIST=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 timeout -s KILL 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r3ap/bench_force_dist.json 2> gpurun_out/r3ap/bench_force_dist.err
+tail -c 300 gpurun_out/r3ap/bench_force_dist.err; python - <<'PY'
+import json
+d = json.loads(open('gpurun_out/r3ap/bench_force_dist.json').read().strip().splitlines()[-1])
+print('forced RCCL path:', round(d['value'], 1), d['unit'], 'n_gpus', d['n_gpus'], 'one_call', round(d['one_call']['depth_maps_per_s'], 1), 'batches', d['config'].get('library_batch_log'))
 PY
-}
-drv() { L=$1; shift; env "$@" timeout -s KILL 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-one-call 2>/dev/null > $OUT/drv_$L.json; show $OUT/drv_$L.json drv_$L; }
-dfl() { L=$1; shift; env "$@" timeout -s KILL 300 python bench.py --no-cpu-baseline --no-one-call 2>/dev/null > $OUT/dfl_$L.json; show $OUT/dfl_$L.json dfl_$L; }
-dfl base
-dfl fs3 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_fs3.so
-dfl fs4 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_fs4.so
-drv base
-drv fs3 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_fs3.so
-drv fs4 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_fs4.so
-dfl base_2
-dfl fs3_2 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_fs3.so
