@@ -128,6 +128,23 @@ def test_oracle_is_not_reachable_from_the_product():
                     and "import oracle" not in txt, "%s references the oracle" % f
 
 
+def test_every_run_time_switch_is_documented():
+    """Every environment variable the library or the shim reads is described in INTEGRATION.md (and nothing there names
+    a switch that no longer exists): the switches are part of the drop-in's interface."""
+    import re
+    src = ""
+    for rel in ("mve_amd/csrc/dmrecon_host.cpp", "mve_amd/host/dmrecon.cc"):
+        src += open(os.path.join(ROOT, rel)).read()
+    read = set(re.findall(r'(?:getenv|env_or)\("(MI_DMRECON_[A-Z_]+)"', src))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    named = set(re.findall(r"MI_DMRECON_[A-Z_]+", doc))
+    codes = {n for n in named if re.match(r"MI_DMRECON_(E[A-Z]+|OK)$", n)}          # return codes, not switches
+    assert len(read) >= 12
+    assert read <= named, sorted(read - named)
+    extra = named - read - codes - {"MI_DMRECON_LIB"}                              # MI_DMRECON_LIB: mve_amd/api.py
+    assert not extra, sorted(extra)
+
+
 def test_bench_call_plan():
     """bench.py: how K timed steps become library calls (pure host logic)."""
     import importlib.util
