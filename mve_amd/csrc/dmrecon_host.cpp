@@ -128,7 +128,10 @@ struct DevBuf {
         if (n <= cap) return 0;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        size_t want = n + n / 4 + 64;
+        /* a buffer that has to grow grows to twice what is asked for (a quarter more beyond 4 GB): the calls of a scene
+         * come in a few sizes (one caller's views, two or three callers merged), and hipFree + hipMalloc inside a call --
+         * hipFree synchronises the device -- stalls the batch that runs next to it as well */
+        size_t want = (n * sizeof(T) > ((size_t)4 << 30) ? n + n / 4 : 2 * n) + 64;
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e != hipSuccess) return -1;
         cap = want;
@@ -226,6 +229,19 @@ struct BatchScratch {
     DevBuf<GvsRef> d_gvs_refs;
     std::vector<hipEvent_t> events;
     size_t pixels() const { return d_maps.cap / 14; }       /* state maps: 14 floats per pixel */
+    /* the buffers whose size goes with the pixels of a batch (imaps: 4 words per pixel, 6 with eight view slots) */
+    int reserve_pixels(size_t px, size_t n_imaps) {
+        return d_maps.reserve(px * 14) || d_imaps.reserve(px * n_imaps) || d_work.reserve(px) || d_work2.reserve(px)
+            || d_results.reserve(px) || d_results2.reserve(px) || d_keys.reserve(px) || d_follow.reserve(2 * px);
+    }
+    /* room for a batch of `px` pixels: all pixel-proportional buffers together, so that a set is either large enough or
+     * grows once */
+    int ensure_pixels(size_t px, size_t n_imaps) {
+        if (d_maps.cap >= px * 14 && d_imaps.cap >= px * n_imaps && d_work.cap >= px && d_work2.cap >= px && d_results.cap >= px
+            && d_results2.cap >= px && d_keys.cap >= px && d_follow.cap >= 2 * px)
+            return 0;
+        return reserve_pixels(px, n_imaps);                           /* (DevBuf::reserve adds the headroom) */
+    }
     bool holds_anything() const { return d_maps.cap || d_work.cap || d_jobs.cap || d_results.cap || d_hyp.cap || h_poll || h_dyn || !events.empty(); }
     void release() {
         for (size_t i = 0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
@@ -260,7 +276,6 @@ struct SceneStore {
     MergeQueue merge;
     std::mutex pool_mu;                      /* guards scratch_pool */
     std::vector<BatchScratch> scratch_pool;  /* the scratch sets no call holds at the moment */
-    std::atomic<size_t> max_batch_px{0};     /* pixels of the largest batch so far */
     SceneGeom geom;                          /* guarded by mu; dropped with views_dirty / set_features */
     std::mutex mu;                           /* guards the lazy upload of the DevView table */
     std::vector<HostView> views;
@@ -292,7 +307,6 @@ struct mi_dmrecon_ctx {
     DevBuf<uint8_t> d_stage2;
     int stage_flip = 0;
     BatchScratch bs;                         /* leased from the scene's pool for the duration of a call (ScratchLease) */
-    size_t floor_px = 0;                     /* pixel-proportional scratch is sized for at least this many pixels (set per call) */
 };
 
 namespace {
@@ -806,9 +820,7 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
     /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd + views1, upd1 (+ views_hi,
      * views1_hi: view slots 4..7 of a set, nrReconNeighbors > 4) */
     const size_t n_imaps = eight_views ? 6 : 4;
-    const size_t cap_px = std::max(total_px, c->floor_px);           /* sized for the largest batch of the scene so far */
-    if (c->bs.d_maps.reserve(cap_px * 14)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
-    if (c->bs.d_imaps.reserve(cap_px * n_imaps)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(imaps) failed");
+    if (c->bs.ensure_pixels(total_px, n_imaps)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
     float* base = c->bs.d_maps.p;
     float* base1 = base + 7 * total_px;
     uint32_t* ibase = c->bs.d_imaps.p;
@@ -1262,10 +1274,9 @@ int BatchRun::upload() {
         n_seed_feats += jobs[j].n_seeds;
     }
     work_cap = std::max(total_px, seeds.size());
-    const size_t cap_px = std::max(work_cap, c->floor_px);           /* sized for the largest batch of the scene so far */
-    if (c->bs.d_work.reserve(cap_px) || c->bs.d_work2.reserve(cap_px) || c->bs.d_results.reserve(cap_px) || c->bs.d_results2.reserve(cap_px)
-        || c->bs.d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->bs.d_keys.reserve(cap_px) || c->bs.d_keyoff.reserve(nj)
-        || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->bs.d_follow.reserve(2 * cap_px)
+    if (c->bs.ensure_pixels(work_cap, st->nrReconNeighbors > 4 ? 6 : 4)
+        || c->bs.d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->bs.d_keyoff.reserve(nj)
+        || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_follow_cnt.reserve(4 * MI_MAX_ROUNDS)
         || c->bs.d_front.reserve(6 * (size_t)nj))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(work lists) failed");
     HIP_TRY(hipMemsetAsync(c->bs.d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
@@ -1281,7 +1292,7 @@ int BatchRun::upload() {
     if (c->bs.h_dyn_cap < 3 * (size_t)nj * sizeof(JobDyn)) {
         if (c->bs.h_dyn) (void)hipHostFree(c->bs.h_dyn);
         c->bs.h_dyn = nullptr; c->bs.h_dyn_cap = 0;
-        const size_t want = 3 * ((size_t)nj + 64) * sizeof(JobDyn);
+        const size_t want = 3 * (2 * (size_t)nj + 64) * sizeof(JobDyn);      /* twice the views: see DevBuf::reserve */
         if (hipHostMalloc((void**)&c->bs.h_dyn, want, hipHostMallocDefault) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(job poll buffer) failed");
         c->bs.h_dyn_cap = want;
@@ -1675,7 +1686,7 @@ int BatchRun::outcome() {
 
 }  // namespace
 
-/* A call's lease on a scratch set of its scene (the largest free one), back to the pool when the call ends.  A set is only ever
+/* A call's lease on a scratch set of its scene (best fit), back to the pool when the call ends.  A set is only ever
  * created when every existing one is in use, so a scene owns as many as it has had calls in flight at once. */
 struct ScratchLease {
     mi_dmrecon_ctx* c;
@@ -1685,12 +1696,13 @@ struct ScratchLease {
         if (c->bs.holds_anything()) pool.push_back(std::move(c->bs));   /* (the parity hooks allocate without a lease) */
         c->bs = BatchScratch();
         if (pool.empty()) return;                         /* the first call of the scene, or every set is in use: a new one */
-        /* the LARGEST free set: every set a call gets is brought up to the scene's high-water mark (floor_px), so handing
-         * out a small one only moves its growth into this call; small sets stay behind for the moments when more calls
-         * overlap than ever before */
-        (void)pixels;
+        /* the smallest free set that holds the batch (the large ones stay for the large batches); if none does, the
+         * largest: growing it is cheaper than growing a small one */
         size_t pick = 0;
-        for (size_t i = 1; i < pool.size(); ++i) if (pool[i].pixels() > pool[pick].pixels()) pick = i;
+        for (size_t i = 1; i < pool.size(); ++i) {
+            const size_t a = pool[i].pixels(), b = pool[pick].pixels();
+            if (b >= pixels ? (a >= pixels && a < b) : a > b) pick = i;
+        }
         c->bs = std::move(pool[pick]);
         pool.erase(pool.begin() + (std::ptrdiff_t)pick);
     }
@@ -1719,16 +1731,7 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
         const size_t l = std::min<size_t>((size_t)std::max<int32_t>(0, st->scale), hv.levels.empty() ? 0 : hv.levels.size() - 1);
         if (!hv.levels.empty()) px_hint += (size_t)hv.levels[l].w * (size_t)hv.levels[l].h;
     }
-    /* every set is sized for TWICE the largest batch the scene has seen (~200 B per pixel and set; up to 8 GB per set):
-     * after the first calls no lease allocates any more, whichever set it gets and whether or not its call has been
-     * merged with another one this time (growing a set inside a call costs ~30 ms, and hipFree stalls the batch that
-     * runs next to it as well) */
-    {
-        size_t seen = c->sc->max_batch_px.load();
-        while (seen < px_hint && !c->sc->max_batch_px.compare_exchange_weak(seen, px_hint)) { }
-        c->floor_px = std::min<size_t>(2 * std::max(seen, px_hint), ((size_t)8 << 30) / 200);
-    }
-    const ScratchLease lease(c, px_hint);
+    ScratchLease lease(c, px_hint);
     BatchRun B;
     B.c = c; B.st = st; B.n_refs = n_refs; B.ref_views = ref_views; B.maps = maps; B.progress = progress;
     B.status_out = status_out; B.stats = stats; B.D = mi_device_api(st->filterWidth); B.ds = dev_settings(st); B.S = c->stream;
