@@ -132,6 +132,9 @@ typedef struct mi_dmrecon_stats {
     int64_t n_front_attempts;    /* patch optimisations run there (speculative ones included) */
     int64_t n_front_entries;     /* list entries summed over all rounds of all views */
     int64_t front_team;          /* workgroups per view in that launch (> 1 only for a call that has the GPU to itself) */
+    int64_t front_fallbacks;     /* 1: the teams gave up (a member found no compute unit in time: the GPU is shared with
+                                  * something the library cannot see) and the views finished with one workgroup each */
+    int64_t n_latency_rounds;    /* host-visible rounds in which some view was already in the latency layout */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);
@@ -197,15 +200,17 @@ int  mi_dmrecon_global_view_selection(mi_dmrecon_ctx* ctx, const mi_dmrecon_sett
  * Return value: 0 if at least one view finished; with a single view (or when every view failed) the failing
  * view's own code.
  * Calls without a progress array that arrive at the same time on contexts of one scene (ctx_fork) with equal
- * settings are run as ONE batch by one of the callers (the others wait for their maps): statuses and return codes are
- * those of the separate calls, the maps are those of the views in that batch -- a view's result depends on the batch
- * it is in only through the round at which the batch changes lane layouts (rounding of 1e-7 that now and then flips
- * a convergence decision: bit-equal on small scenes, fill IoU >= 0.999 / depth p99 <= 3e-3 on the C3 scene, far
- * inside the parity tolerances).  The statistics go to the call that ran the batch (stats.n_merged_calls; the
- * others get zeros and stats.merged_into_other_call = 1).  MI_DMRECON_MERGE_CALLS=0 switches this off.
+ * settings are run as ONE batch by one of the callers (the others wait for their maps): statuses, return codes AND maps
+ * are those of the separate calls, bit for bit -- everything that decides the last bits of a view's maps (the round at
+ * which the view leaves the throughput lane layout, whose sums run in another order) is decided per view from the view's
+ * own history, never from the batch (as apps/dmrecon's all-views mode writes what `-m ID` writes,
+ * apps/dmrecon/dmrecon.cc:285-318).  The statistics go to the call that ran the batch (stats.n_merged_calls; the
+ * others get zeros and stats.merged_into_other_call = 1).  MI_DMRECON_MERGE_CALLS=0 switches the merging off.
  * A call that has the GPU to itself runs the end of its propagation with several persistent workgroups per view that
- * wait for each other every round (stats.front_team): every PROCESS that shares its GPU with another process must set
- * MI_DMRECON_FRONT_TEAM=1 (the library only sees the calls of its own process). */
+ * wait for each other every pass (stats.front_team).  Only one call per GPU does so at a time, across processes (an
+ * advisory lock file named after the GPU's PCI address in /dev/shm), and a team whose members are not all given a
+ * compute unit in time -- something the library cannot see holds them -- gives up and the views finish with one
+ * workgroup each (stats.front_fallbacks): slower, the same maps, never an error. */
 int  mi_dmrecon_reconstruct(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t n_refs,
                             const int32_t* ref_views, mi_dmrecon_maps* maps,
                             mi_dmrecon_progress* progress, int32_t* status_out, mi_dmrecon_stats* stats);

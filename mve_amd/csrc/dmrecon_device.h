@@ -15,6 +15,11 @@
  *   follow_out != null: one optimisation attempt per entry; entries with further candidate hypotheses are appended to
  *   follow_out (count *follow_out_n).  follow_in != null: continue the entries work[follow_in[0 .. *follow_in_n)].
  * generate -- k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile count.
+ *   A view's entries go to `work` (count round_work[round]) while the view is in the throughput layout, to `work_lat`
+ *   (round_work_lat[round]) once it has handed over: for good, from the round after the first one in which the VIEW's
+ *   own list had fewer than `handover` entries -- decided on the device from view_count ([3][n_jobs], rotating per round;
+ *   the caller presets slot 0 = what "the round before round 1" counts as, slot 1 = 0) and recorded in view_mode
+ *   ([n_jobs], preset 0; the round of the hand-over).
  * tail -- one fused tail round: candidates from (prev_work, prev_results, round_work[round - 1]) -> this round's list,
  *   results and pixel-state writes (second state slot, see DevJob).  speculative: workgroups of four wavefronts, a
  *   pixel's candidate hypotheses tried at the same time; else one wavefront per pixel tries them in turn.
@@ -27,8 +32,14 @@
  *   team > 1: that many workgroups per view (k_front<TEAM>): the attempts of a round are dealt out over them, every
  *   member runs the whole round otherwise (same numbering, same state writes) and fetches the others' results from the
  *   view's mailbox: mail = MI_FRONT_MAIL_WORDS 8-byte words per view, team_flags = MI_FRONT_TEAM_MAX words per view,
- *   zeroed by the caller.  All n_jobs * team workgroups must be resident at once (the caller keeps it <= the CUs).
+ *   zeroed by the caller; team_filled = one word per view, zeroed.  The members wait for each other at every pass, at
+ *   most spin_ticks (100 MHz ticks): if one does not show up (all n_jobs * team workgroups must be resident at once; the
+ *   caller keeps it <= the CUs, but cannot know what else holds them) the team GIVES UP -- error_flags bit 5 (32) is set
+ *   and job_resume[j] (zeroed by the caller of a first launch) says from where view j goes on: round << 32 | entries << 1
+ *   | list buffer, or >= MI_FRONT_DONE_HOST for a view that ran to its end.  A second launch with job_start = that array
+ *   (no dealing out, the views start where it says) and team = 1 finishes them; same maps either way.
  */
+#define MI_FRONT_DONE_HOST 0xFFFFFFFF00000000ull
 #define MI_FRONT_TEAM_MAX 32
 #define MI_FRONT_MAIL_WORDS (2 * 1024 * 12)
 struct MiDeviceApi {
@@ -41,8 +52,9 @@ struct MiDeviceApi {
     void (*patch_eval)(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                        const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
                        float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
-    void (*generate)(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
-                     unsigned* round_work, int round);
+    void (*generate)(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work, DevEntry* work_lat,
+                     unsigned* round_work, unsigned* round_work_lat, unsigned* view_count, unsigned* view_mode,
+                     unsigned handover, int round);
     void (*tail)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                  const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
                  DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool speculative);
@@ -50,7 +62,9 @@ struct MiDeviceApi {
                   const DevEntry* list, const DevResult* list_results, const unsigned* list_n,
                   DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
                   const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
-                  DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags);
+                  DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags,
+                  const unsigned long long* job_start, unsigned long long* job_resume, unsigned* team_filled, unsigned spin_ticks,
+                  int fault /* test hook: member | round << 8 of the team member that vanishes, -1 = none */);
 };
 const MiDeviceApi* mi_device_api(int filter_width);
 extern unsigned long long* mi_debug_tbuf;

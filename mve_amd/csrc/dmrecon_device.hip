@@ -1767,14 +1767,35 @@ struct FrontArgs {
     DevEntry* work[2];            /* per-view lists (view j's at job_off[j]); [0] holds the lists of round o.round - 1 */
     DevResult* results[2];
     const unsigned* job_off;      /* [n_jobs] */
-    const unsigned* job_count;    /* [n_jobs] entries of view j in work[0] */
-    unsigned* job_stats;          /* [n_jobs][4]: rounds run, attempts run, sum of list sizes, 100 MHz ticks */
+    const unsigned* job_count;    /* [n_jobs] entries of view j in work[0] (a first launch: the view starts at o.round from there) */
+    /* ... or, a launch that CONTINUES an earlier one: where every view goes on -- round << 32 | entries << 1 | list
+     * buffer (MI_FRONT_DONE: nothing left to do); null in a first launch */
+    const unsigned long long* job_start;
+    /* [n_jobs], zeroed before a first launch: how far the view has got, same packing, raised with atomicMax: a view that
+     * ran to its end says MI_FRONT_DONE; a team that gave up (a member did not show up in time: the GPU is shared with
+     * something that holds its compute units) leaves the round to go on from -- every round up to it is complete in
+     * memory, and a round can be run again from its start (it only writes state slots that hold nothing older rounds
+     * read, and the same values) */
+    unsigned long long* job_resume;
+    unsigned* job_stats;          /* [n_jobs][4]: rounds run, attempts run, sum of list sizes, 100 MHz ticks (added to) */
     int max_rounds;               /* a view stops here (int32 stamps would last; a guard against an endless front) */
     /* TEAM: `team` workgroups per view (consecutive blocks) */
     int team;
     unsigned long long* mail;     /* [n_jobs][2][MI_FRONT_QCAP * 4][MI_FRONT_GRAN] */
     unsigned* team_flags;         /* [n_jobs][MI_FRONT_TEAM_MAX], zeroed before the launch */
+    unsigned* team_filled;        /* [n_jobs], zeroed before the launch: pixels newly filled by the view's team (atomicMax of each
+                                   * member's own running count: they all count the same), added to the job by k_front_commit */
+    unsigned spin_ticks;          /* a member waits this long (100 MHz ticks) for the others at an exchange, then the team gives up */
+    int fault_member, fault_round; /* test hook (MI_DMRECON_DEBUG_FRONT_FAULT): this member of every team vanishes at that round of its
+                                    * view (0 = it never shows up), as one that is not given a compute unit would; -1 = none */
 };
+#define MI_FRONT_DONE 0xFFFFFFFF00000000ull
+/* a team member's flag word: bits 0..29 the number of its last finished pass (only ever grows), bit 30 "my team gives up"
+ * (a member did not show up), bit 31 "the view has ended" (footprint exception / cancel); a member that leaves early
+ * leaves all epoch bits set, so that nobody waits for it */
+#define MI_FLAG_EPOCH 0x3FFFFFFFu
+#define MI_FLAG_GAVE_UP 0x40000000u
+#define MI_FLAG_ENDED 0x80000000u
 struct FQ {                       /* a pixel this round may rewrite */
     int xy, src;                  /* qx | qy << 16; (unused) index of its best source in the previous list */
     float own;                    /* its frozen confidence */
@@ -1824,8 +1845,25 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
     const int T = TEAM ? t.team : 1;
     const int jobi = TEAM ? (int)blockIdx.x / T : (int)blockIdx.x, member = TEAM ? (int)blockIdx.x % T : 0;
     const DevJob* job = a.jobs + jobi;
-    unsigned n_prev = t.job_count[jobi];
-    if (n_prev == 0) return;
+    unsigned n_prev; int cur, round;
+    if (t.job_start) {
+        const unsigned long long s0 = t.job_start[jobi];
+        if (s0 >= MI_FRONT_DONE) return;
+        round = (int)(s0 >> 32); n_prev = (unsigned)(s0 & 0xFFFFFFFFull) >> 1; cur = (int)(s0 & 1ull);
+    } else { round = a.round; n_prev = t.job_count[jobi]; cur = 0; }
+    if (n_prev == 0) {
+        if (tid == 0) atomicMax(t.job_resume + jobi, MI_FRONT_DONE);
+        return;
+    }
+    gflag_t fl = TEAM ? (gflag_t)(t.team_flags + (size_t)jobi * MI_FRONT_TEAM_MAX) : nullptr;
+    if (TEAM) {
+        /* a member that only starts when the others have given up (it found no compute unit in time) leaves at once */
+        unsigned f = tid < T ? __hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (__syncthreads_or((f & MI_FLAG_GAVE_UP) != 0)) {
+            if (tid == 0) __hip_atomic_store(fl + member, MI_FLAG_EPOCH | MI_FLAG_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
     for (int i = tid; i < 256; i += MI_FRONT_WAVES * WAVE) g_lut[i] = a.lut[i];
     const unsigned long long t0 = wall_clock64();
     const unsigned off = t.job_off[jobi];
@@ -1833,14 +1871,14 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, n_filled = 0, err = 0;   /* per lane; summed at the end */
     unsigned st_rounds = 0, st_att = 0, st_list = 0;
     unsigned epoch = 0;                                                     /* TEAM: exchanges so far (the same in every member) */
-    bool abort = false;
-    int cur = 0;
-    int round = a.round;
+    unsigned team_filled = 0;                                               /* TEAM: pixels the view's team has newly filled so far */
+    bool abort = false, gave_up = false;
     if (tid == 0) g_fcnt[7] = 0;
     __syncthreads();
     for (; n_prev != 0 && round < t.max_rounds && !abort; ++round) {
         /* a footprint exception (patch_sampler.cc:78-82) or the host's cancel ends the view: one lane looks, all agree
          * (the members of a team see the flag at different times: they tell each other at the next exchange) */
+        if (TEAM && member == t.fault_member && (int)st_rounds >= t.fault_round) return;
         if (tid == 0) g_fcnt[6] = (unsigned)__hip_atomic_load((gi32_t)&job->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (!TEAM && g_fcnt[6] != 0) break;
@@ -1977,21 +2015,32 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                 __syncthreads();
                 if (tid == 0) g_fcnt[2] = 0;
                 if (TEAM) {
-                    /* ---- the exchange: my flag = this pass (+ "my view has ended"), wait for every member's, fetch their results */
-                    gflag_t fl = (gflag_t)(t.team_flags + (size_t)jobi * MI_FRONT_TEAM_MAX);
-                    if (tid == 0) __hip_atomic_store(fl + member, epoch | (g_fcnt[6] != 0 ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    /* ---- the exchange: my flag = this pass (+ "my view has ended"), wait for every member's, fetch their
+                     * results.  Flags only ever grow, a member is waited for until its flag has REACHED this pass (it may be
+                     * a pass ahead by the time it is looked at: it cannot be two, the next exchange needs my flag), and not
+                     * for ever: the wait is bounded by the wall clock */
+                    if (tid == 0) __hip_atomic_store(fl + member, epoch | (g_fcnt[6] != 0 ? MI_FLAG_ENDED : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (tid < T) {
                         unsigned f = 0; bool seen = false;
-                        for (int spin = 0; spin < (1 << 21); ++spin) {
+                        const unsigned long long w0 = wall_clock64();
+                        for (;;) {
                             f = __hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((f & 0x7FFFFFFFu) == epoch) { seen = true; break; }
+                            if ((f & MI_FLAG_EPOCH) >= epoch || (f & (MI_FLAG_GAVE_UP | MI_FLAG_ENDED))) { seen = true; break; }
+                            if (wall_clock64() - w0 > (unsigned long long)t.spin_ticks) break;
                             __builtin_amdgcn_s_sleep(4);
                         }
-                        if (!seen) { atomicOr(&g_fcnt[7], 2u); atomicOr(&a.counters->error_flags, 8u); }
-                        else if (f & 0x80000000u) atomicOr(&g_fcnt[7], 1u);
+                        if (!seen || (f & MI_FLAG_GAVE_UP)) atomicOr(&g_fcnt[7], 2u);
+                        else if (f & MI_FLAG_ENDED) atomicOr(&g_fcnt[7], 1u);
                     }
                     __syncthreads();
-                    if (g_fcnt[7] != 0) { abort = true; break; }
+                    if (g_fcnt[7] != 0) {
+                        /* the view has ended (nothing of it is used any more), or the team gives up: this member says so
+                         * to whoever still waits for it and leaves where the host can pick the view up again */
+                        gave_up = (g_fcnt[7] & 2u) != 0;
+                        if (tid == 0)
+                            __hip_atomic_store(fl + member, MI_FLAG_EPOCH | (gave_up ? MI_FLAG_GAVE_UP : MI_FLAG_ENDED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        abort = true; break;
+                    }
                     for (unsigned u = (unsigned)tid; u < natt * MI_FRONT_GRAN; u += MI_FRONT_WAVES * WAVE) {
                         const unsigned idx = u / MI_FRONT_GRAN, k = u - idx * MI_FRONT_GRAN;
                         if ((int)(idx % (unsigned)T) == member) continue;
@@ -2056,14 +2105,27 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                 np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
                 cq[q] = fin.conf; vp[q] = fin.views; up[q] = round;
                 if (NV == 8) (one ? job->views_hi : job->views1_hi)[q] = fin.views_hi;
-                if (Qw.own <= 0.f && member == 0) { ++n_filled; atomicAdd(&g_fcnt[5], 1u); }
+                if (Qw.own <= 0.f) atomicAdd(&g_fcnt[5], 1u);
             }
             __syncthreads();
         }
+        if (abort) break;
         n_prev = n_next;
-        if (tid == 0 && g_fcnt[5]) atomicAdd(const_cast<uint32_t*>(&job->n_filled), g_fcnt[5]);   /* Progress::filled */
+        /* Progress::filled.  The members of a team all count the same pixels: each raises the view's count to its own */
+        team_filled += g_fcnt[5];
+        if (tid == 0 && g_fcnt[5]) {
+            if (TEAM) atomicMax(t.team_filled + jobi, team_filled);
+            else { atomicAdd(const_cast<uint32_t*>(&job->n_filled), g_fcnt[5]); n_filled += g_fcnt[5]; }
+        }
         cur ^= 1;
         __syncthreads();
+    }
+    /* how far the view has got (see FrontArgs::job_resume): done, or the round a given-up team stopped in */
+    if (tid == 0) {
+        if (gave_up) {
+            atomicMax(t.job_resume + jobi, ((unsigned long long)(unsigned)round << 32) | ((unsigned long long)n_prev << 1) | (unsigned long long)cur);
+            atomicOr(&a.counters->error_flags, 32u);
+        } else if (n_prev == 0 || abort || g_fcnt[6] != 0) atomicMax(t.job_resume + jobi, MI_FRONT_DONE);
     }
     /* counters: per lane so far (what the sequential rule counts is the same in every member of a team: the first reports) */
     if (member != 0) { n_eval = 0; n_pass = 0; n_patch = 0; }
@@ -2081,9 +2143,9 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
         if (st_att) atomicAdd(&t.job_stats[4 * jobi + 1], st_att);
     }
     if (tid == 0 && member == 0) {
-        t.job_stats[4 * jobi] = st_rounds; t.job_stats[4 * jobi + 2] = st_list;
-        t.job_stats[4 * jobi + 3] = (unsigned)(wall_clock64() - t0);
-        if (n_prev != 0 && round >= t.max_rounds) atomicOr(&a.counters->error_flags, 8u);    /* the front did not end */
+        atomicAdd(&t.job_stats[4 * jobi], st_rounds - (gave_up ? 1u : 0u)); atomicAdd(&t.job_stats[4 * jobi + 2], st_list - (gave_up ? n_prev : 0u));
+        atomicAdd(&t.job_stats[4 * jobi + 3], (unsigned)(wall_clock64() - t0));
+        if (n_prev != 0 && !abort && round >= t.max_rounds) atomicOr(&a.counters->error_flags, 8u);    /* the front did not end */
     }
 }
 
@@ -2102,6 +2164,18 @@ __global__ __launch_bounds__(256) void k_front_split(FrontSplitArgs a) {
         const unsigned i = a.job_off[w.job] + atomicAdd(&a.job_count[w.job], 1u);
         a.owork[i] = w; a.oresults[i] = r;
     }
+}
+
+/* After a team launch: the pixels the teams have newly filled (FrontArgs::team_filled) go to their jobs' Progress::filled
+ * and to the call's counter; one lane per view. */
+__global__ __launch_bounds__(256) void k_front_commit(const DevJob* jobs, unsigned* team_filled, DevCounters* counters, int n_jobs) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_jobs) return;
+    const unsigned n = team_filled[j];
+    if (!n) return;
+    team_filled[j] = 0;
+    atomicAdd(const_cast<uint32_t*>(&jobs[j].n_filled), n);
+    atomicAdd(&counters->n_filled, (unsigned long long)n);
 }
 
 /* Fold the second state slot back into the first where it is the newer one (after the last tail round). */
@@ -2194,15 +2268,28 @@ __global__ __launch_bounds__(WAVE) void k_patch_eval(EvalArgs a) {
 
 struct SweepArgs {
     const DevJob* jobs;
-    DevEntry* work;
-    unsigned* round_work;  /* [round] = size of the work list of that round (zeroed before the call) */
+    DevEntry* work;        /* this round's list of the views in the throughput layout ... */
+    DevEntry* work_lat;    /* ... and of the views that have handed over to the latency layout */
+    unsigned* round_work;      /* [round] = size of the throughput list of that round (zeroed before the call) */
+    unsigned* round_work_lat;  /* [round] = size of the latency list */
+    unsigned* view_count;  /* [3][n_jobs]: entries per view of round r at [(r % 3) * n_jobs + view] */
+    unsigned* view_mode;   /* [n_jobs]: 0 = throughput layout, else the round from which the view is in the latency layout */
+    unsigned handover;     /* a view hands over once a round's list of ITS OWN is shorter than this */
+    int n_jobs;
     int round;
 };
 
 /* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull.
  * One lane per pixel, 8 pixels per lane; the block's hits are compacted through ballots + one LDS
  * prefix so that the global work-list counter sees ONE atomic per 2048 pixels (a per-wave atomic on a
- * single word costs ~10 ns each and dominated this kernel at 40 000 waves). */
+ * single word costs ~10 ns each and dominated this kernel at 40 000 waves).
+ *
+ * The lane layout of a view's patch optimisations is the VIEW's own affair: a view leaves the throughput layout for
+ * good in the round after the first one whose list -- its own entries, not the batch's -- had fewer than `handover`
+ * entries.  The two layouts sum a pass's 25 samples in different orders (1e-7), so whatever decides the layout decides
+ * the last bits of the maps: decided per view from the view's own history, a view's maps do not depend on what it was
+ * batched with (other reference views, merged calls, GPU slots).  Decided here, on the device, from the counts the
+ * previous round left: the host can enqueue rounds without reading anything back. */
 #define GEN_PER_THREAD 8
 /* A workgroup scans a MI_GEN_TILE_W x MI_GEN_TILE_H pixel tile; a wavefront takes a 64 x 8 strip of it as eight
  * 8 x 8 sub-tiles (one per trip, lane = pixel of the sub-tile).  The ballot-compacted entries therefore come out
@@ -2215,6 +2302,14 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
     __shared__ unsigned s_base;
     const int jobi = blockIdx.y;
     const DevJob* job = a.jobs + jobi;
+    /* the view's layout this round (every workgroup of the view computes the same from last round's count; the first
+     * one records the hand-over and clears the count slot of the next round) */
+    const unsigned prev_cnt = a.view_count[(unsigned)((a.round + 2) % 3) * (unsigned)a.n_jobs + (unsigned)jobi];
+    const bool lat = a.view_mode[jobi] != 0 || prev_cnt < a.handover;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (lat && a.view_mode[jobi] == 0) a.view_mode[jobi] = (unsigned)a.round;
+        a.view_count[(unsigned)((a.round + 1) % 3) * (unsigned)a.n_jobs + (unsigned)jobi] = 0;
+    }
     if (job->flags != 0) return;                 /* failed / cancelled view */
     const int W = job->w, H = job->h;
     const int tiles_x = (W + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, tiles_y = (H + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
@@ -2251,16 +2346,18 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
-        s_base = tot ? atomicAdd(&a.round_work[a.round], tot) : 0u;
+        s_base = tot ? atomicAdd(&(lat ? a.round_work_lat : a.round_work)[a.round], tot) : 0u;
+        if (tot) atomicAdd(&a.view_count[(unsigned)(a.round % 3) * (unsigned)a.n_jobs + (unsigned)jobi], tot);
     }
     __syncthreads();
     unsigned off = s_base;
     for (int w = 0; w < wave; ++w) off += s_wave_cnt[w];
+    DevEntry* out = lat ? a.work_lat : a.work;
 #pragma unroll
     for (int t = 0; t < GEN_PER_THREAD; ++t)
         if ((hits >> t) & 1u) {
             DevEntry e; e.job = jobi; e.xy = (tx0 + t * 8 + lx) | ((ty0 + wave * 8 + ly) << 16);
-            a.work[off + before[t]] = e;
+            out[off + before[t]] = e;
         }
 }
 
@@ -2474,10 +2571,12 @@ static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* v
     hipLaunchKernelGGL(k_patch_eval, dim3(1), dim3(WAVE), 0, s, a);
 }
 
-static void launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work,
-                        unsigned* round_work, int round) {
+static void launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work, DevEntry* work_lat,
+                        unsigned* round_work, unsigned* round_work_lat, unsigned* view_count, unsigned* view_mode,
+                        unsigned handover, int round) {
     SweepArgs a;
-    a.jobs = jobs; a.work = work; a.round_work = round_work; a.round = round;
+    a.jobs = jobs; a.work = work; a.work_lat = work_lat; a.round_work = round_work; a.round_work_lat = round_work_lat;
+    a.view_count = view_count; a.view_mode = view_mode; a.handover = handover; a.n_jobs = n_jobs; a.round = round;
     hipLaunchKernelGGL(k_generate, dim3(max_tiles, n_jobs), dim3(256), 0, s, a);
 }
 
@@ -2515,25 +2614,32 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
                          const DevEntry* list, const DevResult* list_results, const unsigned* list_n,
                          DevEntry* work0, DevResult* results0, DevEntry* work1, DevResult* results1,
                          const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
-                         DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags) {
+                         DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags,
+                         const unsigned long long* job_start, unsigned long long* job_resume, unsigned* team_filled, unsigned spin_ticks,
+                         int fault) {
     static_assert(MI_FRONT_MAIL_WORDS == 2 * MI_FRONT_QCAP * 4 * MI_FRONT_GRAN, "mailbox size");
     if (n_jobs <= 0) return;
-    FrontSplitArgs sp;
-    sp.work = list; sp.results = list_results; sp.n_ptr = list_n; sp.owork = work0; sp.oresults = results0;
-    sp.job_off = job_off; sp.job_count = job_count;
-    hipLaunchKernelGGL(k_front_split, dim3(16), dim3(256), 0, s, sp);
+    if (!job_start) {
+        FrontSplitArgs sp;
+        sp.work = list; sp.results = list_results; sp.n_ptr = list_n; sp.owork = work0; sp.oresults = results0;
+        sp.job_off = job_off; sp.job_count = job_count;
+        hipLaunchKernelGGL(k_front_split, dim3(16), dim3(256), 0, s, sp);
+    }
     FrontArgs t;
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = nullptr; t.o.hyp = nullptr; t.o.results = nullptr;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = first_round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
     t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.work[0] = work0; t.work[1] = work1; t.results[0] = results0; t.results[1] = results1;
-    t.job_off = job_off; t.job_count = job_count; t.job_stats = job_stats; t.max_rounds = max_rounds;
-    t.team = 1; t.mail = nullptr; t.team_flags = nullptr;
-    if (team > 1 && mail && team_flags) {
+    t.job_off = job_off; t.job_count = job_count; t.job_start = job_start; t.job_resume = job_resume;
+    t.job_stats = job_stats; t.max_rounds = max_rounds;
+    t.team = 1; t.mail = nullptr; t.team_flags = nullptr; t.team_filled = team_filled; t.spin_ticks = spin_ticks;
+    t.fault_member = fault < 0 ? -1 : (fault & 0xFF); t.fault_round = fault < 0 ? 0 : (fault >> 8);
+    if (team > 1 && mail && team_flags && team_filled) {
         t.team = team > MI_FRONT_TEAM_MAX ? MI_FRONT_TEAM_MAX : team; t.mail = mail; t.team_flags = team_flags;
         if (st.K > 4) hipLaunchKernelGGL((k_front<8, true>), dim3((unsigned)(n_jobs * t.team)), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
         else hipLaunchKernelGGL((k_front<4, true>), dim3((unsigned)(n_jobs * t.team)), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
+        hipLaunchKernelGGL(k_front_commit, dim3((unsigned)(n_jobs + 255) / 256), dim3(256), 0, s, jobs, team_filled, counters, n_jobs);
     }
     else if (st.K > 4) hipLaunchKernelGGL((k_front<8, false>), dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
     else hipLaunchKernelGGL((k_front<4, false>), dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);

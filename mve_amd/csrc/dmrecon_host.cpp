@@ -17,6 +17,11 @@
 
 #include <hip/hip_runtime.h>
 #include <omp.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cctype>
 
 #include <algorithm>
 #include <atomic>
@@ -154,6 +159,8 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 #define MI_MERGE_WINDOW_US 1000
 #define MI_MERGE_WINDOW_BIG_US 150  /* ... from this size on only this long (see mi_dmrecon_reconstruct) */
 #define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
+#define MI_VIEW_HANDOVER 320u      /* a view leaves the throughput layout once a round's list of its own is shorter than this */
+#define MI_TEAM_WAIT_US 20000u     /* a front team member waits this long for the others before the team gives up */
 #define MI_FRONT_MIN_CAP 256       /* hand-over to k_front: entries per view, at least */
 #define MI_FRONT_PER_TEAM_WG 64    /* ... and per workgroup of a view's team */
 struct ActiveCall {
@@ -213,8 +220,13 @@ struct BatchScratch {
     DevBuf<uint32_t> d_imaps;                /* views | upd */
     DevBuf<unsigned long long> d_keys;
     DevBuf<unsigned> d_keyoff;
-    DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] work-list size per round */
-    DevBuf<unsigned> d_front;                /* k_front: [n_jobs] list offsets | [n_jobs] list sizes | [n_jobs][4] per-view statistics */
+    DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] per round: size of the list of the views in the latency layout (host-visible
+                                              * rounds), accepted entries (fused tail rounds) */
+    DevBuf<unsigned> d_round_work_t;         /* [MI_MAX_ROUNDS] per round: size of the list of the views in the throughput layout */
+    DevBuf<unsigned> d_view;                 /* k_generate: [3][n_jobs] entries per view of the last rounds | [n_jobs] hand-over rounds */
+    DevBuf<unsigned> d_front;                /* k_front: [n_jobs] list offsets | [n_jobs] list sizes | [n_jobs][4] per-view statistics |
+                                              * [n_jobs] pixels filled by the view's team */
+    DevBuf<unsigned long long> d_front_resume;   /* k_front: [2][n_jobs] where a view goes on (FrontArgs::job_resume / job_start) */
     DevBuf<unsigned long long> d_front_mail; /* k_front teams: a mailbox per view (MI_FRONT_MAIL_WORDS) */
     DevBuf<unsigned> d_front_flags;          /* ... and MI_FRONT_TEAM_MAX pass flags per view */
     DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
@@ -248,7 +260,8 @@ struct BatchScratch {
         events.clear();
         d_jobs.release(); d_work.release(); d_work2.release(); d_hyp.release(); d_results.release(); d_results2.release();
         d_follow.release(); d_follow_cnt.release(); d_maps.release(); d_imaps.release(); d_keys.release(); d_keyoff.release();
-        d_round_work.release(); d_front.release(); d_front_mail.release(); d_front_flags.release();
+        d_round_work.release(); d_round_work_t.release(); d_view.release(); d_front.release(); d_front_resume.release();
+        d_front_mail.release(); d_front_flags.release();
         d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release();
         if (h_poll) (void)hipHostFree(h_poll);
         if (h_dyn) (void)hipHostFree(h_dyn);
@@ -814,13 +827,16 @@ DevSettings dev_settings(const mi_dmrecon_settings* st) {
 }
 
 /* Lays the per-pixel state maps of a batch out in the two map buffers and points the jobs at them. */
-int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px, bool eight_views) {
+int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px, size_t n_list, bool eight_views) {
     total_px = 0;
     for (size_t j = 0; j < jobs.size(); ++j) { jobs[j].pix_off = total_px; total_px += (size_t)jobs[j].w * jobs[j].h; }
     /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd + views1, upd1 (+ views_hi,
      * views1_hi: view slots 4..7 of a set, nrReconNeighbors > 4) */
     const size_t n_imaps = eight_views ? 6 : 4;
-    if (c->bs.ensure_pixels(total_px, n_imaps)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
+    /* ONE sizing step for everything that goes with the pixels of the batch -- the maps AND the lists (n_list: the
+     * longest list the call will hold, the seed list of a coarse scale can exceed the pixels): a later growth of the
+     * lists would reallocate the maps the jobs already point at (DevBuf::reserve frees and allocates anew) */
+    if (c->bs.ensure_pixels(std::max(total_px, n_list), n_imaps)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(maps) failed");
     float* base = c->bs.d_maps.p;
     float* base1 = base + 7 * total_px;
     uint32_t* ibase = c->bs.d_imaps.p;
@@ -1160,7 +1176,10 @@ struct BatchRun {
     /* list + results of the last executed tail round, and their ping-pong partners */
     DevEntry* wcur = nullptr; DevEntry* wnext = nullptr; DevResult* rcur = nullptr; DevResult* rnext = nullptr;
     /* the front kernel (phase C) */
-    bool ran_front = false; int front_first_round = 0, front_team = 1;
+    bool ran_front = false; int front_first_round = 0, front_team = 1, front_fallbacks = 0;
+    unsigned handover = MI_VIEW_HANDOVER;      /* k_generate: a view's own list size below which it leaves the throughput layout */
+    bool host_rounds_only = false;             /* diagnostic: every round host-visible (MI_DMRECON_HOST_ROUNDS) */
+    int n_lat_rounds = 0;                      /* host-visible rounds that had entries in the latency layout */
     std::vector<unsigned> front_stats;
     const ActiveCall* active_call = nullptr;   /* reconstruct calls in progress on this GPU */
 
@@ -1261,25 +1280,33 @@ int BatchRun::upload() {
         const int tx = (jobs[j].w + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, ty = (jobs[j].h + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
         max_tiles = std::max(max_tiles, tx * ty);
     }
-    rc = alloc_maps(c, jobs, dj, total_px, st->nrReconNeighbors > 4);
+    for (int j = 0; j < nj; ++j) {
+        seeds.insert(seeds.end(), jobs[j].seeds.begin(), jobs[j].seeds.end());
+        hyps.insert(hyps.end(), jobs[j].seed_hyp.begin(), jobs[j].seed_hyp.end());
+        n_seed_feats += jobs[j].n_seeds;
+    }
+    rc = alloc_maps(c, jobs, dj, total_px, seeds.size(), st->nrReconNeighbors > 4);
     if (rc) return rc;
+    work_cap = std::max(total_px, seeds.size());
     if (c->bs.d_jobs.reserve(nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(jobs) failed");
     HIP_TRY(hipMemcpyAsync(c->bs.d_jobs.p, dj.data(), nj * sizeof(DevJob), hipMemcpyHostToDevice, S));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), S));
     keyoff.resize(nj);
-    for (int j = 0; j < nj; ++j) {
-        seeds.insert(seeds.end(), jobs[j].seeds.begin(), jobs[j].seeds.end());
-        hyps.insert(hyps.end(), jobs[j].seed_hyp.begin(), jobs[j].seed_hyp.end());
-        keyoff[j] = (unsigned)jobs[j].pix_off;
-        n_seed_feats += jobs[j].n_seeds;
-    }
-    work_cap = std::max(total_px, seeds.size());
-    if (c->bs.ensure_pixels(work_cap, st->nrReconNeighbors > 4 ? 6 : 4)
-        || c->bs.d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->bs.d_keyoff.reserve(nj)
-        || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_follow_cnt.reserve(4 * MI_MAX_ROUNDS)
-        || c->bs.d_front.reserve(6 * (size_t)nj))
+    for (int j = 0; j < nj; ++j) keyoff[j] = (unsigned)jobs[j].pix_off;
+    if (c->bs.d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->bs.d_keyoff.reserve(nj)
+        || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_round_work_t.reserve(MI_MAX_ROUNDS)
+        || c->bs.d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->bs.d_view.reserve(4 * (size_t)nj)
+        || c->bs.d_front.reserve(7 * (size_t)nj) || c->bs.d_front_resume.reserve(2 * (size_t)nj))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(work lists) failed");
     HIP_TRY(hipMemsetAsync(c->bs.d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
+    HIP_TRY(hipMemsetAsync(c->bs.d_round_work_t.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
+    /* MI_DMRECON_VIEW_HANDOVER=<entries> (read per call): a view's own list size below which it leaves the throughput
+     * layout for good (k_generate decides, per view, on the device); 0 = never, 1000000000 = from the first round on */
+    if (const char* e = std::getenv("MI_DMRECON_VIEW_HANDOVER")) handover = (unsigned)std::max(0L, std::atol(e));
+    host_rounds_only = [] { const char* e = std::getenv("MI_DMRECON_HOST_ROUNDS"); return e && std::atoi(e) != 0; }();
+    /* per-view counts of "the round before round 1": none yet -- unless every view starts in the latency layout */
+    HIP_TRY(hipMemsetAsync(c->bs.d_view.p, 0, 4 * (size_t)nj * sizeof(unsigned), S));
+    if (handover < 1000000000u) HIP_TRY(hipMemsetAsync(c->bs.d_view.p, 0xFF, (size_t)nj * sizeof(unsigned), S));
     HIP_TRY(hipMemsetAsync(c->bs.d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), S));
     HIP_TRY(hipMemcpyAsync(c->bs.d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
     if (!c->bs.h_poll) {
@@ -1344,72 +1371,77 @@ int BatchRun::poll_views(const JobDyn* dyn, unsigned queue_size) {
     return 0;
 }
 
-/* ---- phase A: while the work list is large, one host-visible round at a time in the throughput layout (16 patches
- * per wavefront), grid sized to the list: k_generate -> k_optimize<1> (first attempts, then the follow-up list) ->
- * k_apply.  The first round below MI_DMRECON_TAIL_THRESHOLD entries runs in the latency layout and hands over. */
+/* ---- phase A: host-visible rounds, grid sized to the lists: k_generate -> the optimisations -> k_apply.  A round has two
+ * lists: the entries of the views that are still in the throughput layout (16 patches per wavefront; first attempts, then
+ * the follow-up list) and those of the views that have handed over to the latency layout (k_generate decides per view,
+ * from the view's own list sizes: a view's maps do not depend on what it shares a batch with).  Once no view is left in
+ * the throughput layout the fused rounds take over (phase B / C: the same lane layout, the same maps bit for bit). */
 int BatchRun::bulk_rounds(bool& to_tail) {
     to_tail = false;
-    unsigned TAIL_THRESHOLD = 12288;
-    if (const char* e = std::getenv("MI_DMRECON_TAIL_THRESHOLD")) TAIL_THRESHOLD = (unsigned)std::atoi(e);
-    /* diagnostic: MI_DMRECON_BULK_LPV=16 runs the host-visible rounds in the latency layout too (sequential attempts
-     * per entry) -- the bit-exact reference for the fused tail rounds, see tests/test_gpu_parity.py */
-    const int BULK_LPV = [] { const char* e = std::getenv("MI_DMRECON_BULK_LPV"); return (e && std::atoi(e) == 16) ? 16 : 1; }();
+    /* MI_DMRECON_ONE_LAUNCH=<entries> (read per call): rounds below this many entries in the throughput layout run as one
+     * launch of the general kernel (below) */
+    const unsigned ONE_LAUNCH_MAX = [] { const char* e = std::getenv("MI_DMRECON_ONE_LAUNCH"); return e ? (unsigned)std::max(0L, std::atol(e)) : MI_ONE_LAUNCH_MAX; }();
     const int max_rounds = MI_MAX_ROUNDS - 2 * (int)MI_TAIL_CHUNK - 2;
+    unsigned* d_vcount = c->bs.d_view.p; unsigned* d_vmode = d_vcount + 3 * (size_t)nj;
     for (; round < max_rounds && n_alive > 0; ++round) {
         ev.begin(S, EventLog::SWEEP, 0);
-        D->generate(S, c->bs.d_jobs.p, nj, max_tiles, c->bs.d_work.p, c->bs.d_round_work.p, round);
+        D->generate(S, c->bs.d_jobs.p, nj, max_tiles, c->bs.d_work.p, c->bs.d_work2.p, c->bs.d_round_work_t.p, c->bs.d_round_work.p,
+                    d_vcount, d_vmode, handover, round);
         ev.end(S);
         TailPoll& P = c->bs.h_poll[0];
-        HIP_TRY(hipMemcpyAsync(&P.rw[0], c->bs.d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
+        HIP_TRY(hipMemcpyAsync(&P.rw[0], c->bs.d_round_work_t.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
+        HIP_TRY(hipMemcpyAsync(&P.rw[1], c->bs.d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
         HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
         HIP_TRY(read_dyn(0));
         HIP_TRY(hipStreamSynchronize(S));
-        const unsigned n_work = P.rw[0];
+        const unsigned n_thr = P.rw[0], n_lat = P.rw[1];
         hc = P.hc;
-        if (int rc = poll_views(dyn_of(0), n_work)) return rc;
-        if (n_work == 0) { done = true; return 0; }
+        if (int rc = poll_views(dyn_of(0), n_thr + n_lat)) return rc;
+        if (n_thr + n_lat == 0) { done = true; return 0; }
         if (n_alive == 0) return 0;
-        const bool tail = n_work < TAIL_THRESHOLD;
-        ev.begin(S, EventLog::BULK, n_work);
-        if (tail || BULK_LPV == 16)
-            D->optimize(S, 16, std::min(n_work, tail ? 4096u : 16384u), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p,
-                        nullptr, c->bs.d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
-        else {
+        if (n_thr) {
+            ev.begin(S, EventLog::BULK, n_thr);
             /* one optimisation attempt per entry and launch; the entries whose pixel has further candidate hypotheses
              * (about one in five) continue in a follow-up launch over a compacted list (its size stays on the device),
              * so that the wavefronts of both launches are full; the follow-up launch runs all remaining attempts of its
              * entries back to back (third and fourth attempts are rare) */
             const unsigned ppw = patches_per_wave(st);
-            const unsigned waves = (n_work + ppw - 1) / ppw;
+            const unsigned waves = (n_thr + ppw - 1) / ppw;
             unsigned* fcnt = c->bs.d_follow_cnt.p + 4 * (size_t)round;
             /* Rounds below MI_ONE_LAUNCH_MAX entries run as ONE launch of the general kernel, all attempts of an entry in a
              * row: such a launch fits the GPU at once, so either launch of the two-launch form lasts one wavefront-life
              * (1 attempt, then up to 3 more) whatever its size -- measured: lone 20-view call 533 -> 548 depth-maps/s, a
              * lone 3-view call 19.4 -> 17.8 ms, the bench's plan unchanged (thresholds 50 000 / 200 000 / always: 542 /
-             * 546 / 540) */
-            if (n_work < MI_ONE_LAUNCH_MAX) {
+             * 546 / 540).  Same arithmetic either way (tests: the maps do not depend on the form). */
+            if (n_thr < ONE_LAUNCH_MAX)
                 D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, nullptr,
-                            n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
-                ev.end(S);
+                            n_thr, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
+            else {
+                D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, nullptr,
+                            n_thr, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->bs.d_follow.p, fcnt);
+                D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
+                            c->bs.d_results.p, nullptr, n_thr, 0u, 0xFFFFFFFFu, round, c->d_counters, c->bs.d_follow.p, fcnt, nullptr, nullptr);
                 ++n_launch;
-                ev.begin(S, EventLog::SWEEP, 0);
-                mi_launch_apply(S, (n_work + 255) / 256, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, nullptr, n_work, round, c->d_counters);
-                ev.end(S);
-                continue;
             }
-            D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, nullptr,
-                        n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->bs.d_follow.p, fcnt);
-            D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                        c->bs.d_results.p, nullptr, n_work, 0u, 0xFFFFFFFFu, round, c->d_counters, c->bs.d_follow.p, fcnt, nullptr, nullptr);
+            ev.end(S);
             ++n_launch;
         }
-        ev.end(S);
-        ++n_launch;
+        if (n_lat) {
+            /* the views that have handed over: one wavefront per patch, an entry's attempts one after the other */
+            ev.begin(S, EventLog::BULK, n_lat);
+            D->optimize(S, 16, std::min(n_lat, 16384u), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work2.p,
+                        nullptr, c->bs.d_results2.p, nullptr, n_lat, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
+            ev.end(S);
+            ++n_launch; ++n_lat_rounds;
+        }
         ev.begin(S, EventLog::SWEEP, 0);
-        mi_launch_apply(S, (n_work + 255) / 256, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, nullptr, n_work, round, c->d_counters);
+        if (n_thr) mi_launch_apply(S, (n_thr + 255) / 256, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, nullptr, n_thr, round, c->d_counters);
+        if (n_lat) mi_launch_apply(S, (n_lat + 255) / 256, c->bs.d_jobs.p, c->bs.d_work2.p, c->bs.d_results2.p, nullptr, n_lat, round, c->d_counters);
         ev.end(S);
-        if (tail) {
-            tail_known = n_work;
+        if (n_thr == 0 && !host_rounds_only) {
+            /* every view that still has work is in the latency layout: its list (d_work2 / d_results2, round_work[round])
+             * is what the fused rounds go on from */
+            tail_known = n_lat;
             /* counters as of the end of the host-visible rounds (slot 2 of the poll buffer; read after the call) */
             HIP_TRY(hipMemcpyAsync(&c->bs.h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
             have_handover = true;
@@ -1451,7 +1483,7 @@ int BatchRun::tail_rounds(bool& to_front) {
         return std::max<unsigned>(MI_FRONT_MIN_CAP, (unsigned)MI_FRONT_PER_TEAM_WG * (unsigned)front_team);
     }();
     const unsigned front_max = FRONT_PER_VIEW * (unsigned)nj;
-    wcur = c->bs.d_work.p; wnext = c->bs.d_work2.p; rcur = c->bs.d_results.p; rnext = c->bs.d_results2.p;
+    wcur = c->bs.d_work2.p; wnext = c->bs.d_work.p; rcur = c->bs.d_results2.p; rnext = c->bs.d_results.p;   /* (the last host-visible round's list) */
     /* the hand-over round's list is already that small: the views go their own ways at once */
     if (front_max > 0 && tail_known <= front_max) { to_front = true; return 0; }
     /* An event record costs ~6 us of queue time on either side of the kernel it brackets -- more than a tenth of a
@@ -1525,9 +1557,11 @@ int BatchRun::tail_rounds(bool& to_front) {
 }
 
 /* A call that has the GPU to itself gives every view a TEAM of front workgroups (as many as fit the CUs at one workgroup
- * each: all must be resident, they wait for each other every round).  Not next to other calls: two team launches that
- * each get a part of the CUs would wait for their missing members until the spin limit ends both (processes that
- * share a GPU cannot see each other: they must set MI_DMRECON_FRONT_TEAM=1).  MI_DMRECON_FRONT_TEAM=<n> (1 = never). */
+ * each: all must be resident, they wait for each other every pass).  Not next to other calls of this process (their bulk
+ * rounds want the CUs).  What the process cannot see -- another process on the same GPU -- is covered twice: a team
+ * launch needs the GPU's TeamToken (an advisory file lock: one team launch per GPU at a time, across processes), and a team
+ * whose members do not all show up within MI_DMRECON_TEAM_WAIT_US gives up and the views finish with one workgroup
+ * each (front_rounds): slower, never an error.  MI_DMRECON_FRONT_TEAM=<n> (1 = never). */
 void BatchRun::plan_front_team() {
     const char* e = std::getenv("MI_DMRECON_FRONT_TEAM");
     int want = e ? std::atoi(e) : (active_call->count() <= 1 ? MI_FRONT_TEAM_MAX : 1);
@@ -1535,32 +1569,90 @@ void BatchRun::plan_front_team() {
     front_team = std::max(1, want);
 }
 
+/* The right to run front teams on a GPU, for as long as the object lives: an exclusive, non-blocking flock on a file
+ * named after the GPU's PCI address (the device ordinal differs between processes with different visibility masks).
+ * Every attempt opens the file anew, so two calls of one process exclude each other as two processes do.  No file system
+ * to put it on, no permission: no token -- the call runs without teams. */
+struct TeamToken {
+    int fd = -1;
+    explicit TeamToken(int device) {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device) != hipSuccess) std::snprintf(bus, sizeof(bus), "dev%d", device);
+        for (char* q = bus; *q; ++q) if (!std::isalnum((unsigned char)*q)) *q = '_';
+        const char* dirs[2] = {"/dev/shm", "/tmp"};
+        for (int d = 0; d < 2 && fd < 0; ++d) {
+            char path[160];
+            std::snprintf(path, sizeof(path), "%s/mi_dmrecon_team_%s.lock", dirs[d], bus);
+            fd = ::open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+            if (fd >= 0) (void)::fchmod(fd, 0666);           /* (whoever comes next may be another user) */
+        }
+        if (fd >= 0 && ::flock(fd, LOCK_EX | LOCK_NB) != 0) { ::close(fd); fd = -1; }
+    }
+    ~TeamToken() { if (fd >= 0) { (void)::flock(fd, LOCK_UN); ::close(fd); } }
+    bool held() const { return fd >= 0; }
+    TeamToken(const TeamToken&) = delete; TeamToken& operator=(const TeamToken&) = delete;
+};
+
 /* ---- phase C: the rest of the propagation, one persistent workgroup per reference view (k_front, dmrecon_device.hip):
  * each view runs its own rounds from the list the last tail round left, at its own pace, until its front is empty. */
 int BatchRun::front_rounds() {
-    unsigned* d_off = c->bs.d_front.p; unsigned* d_cnt = d_off + nj; unsigned* d_stats = d_cnt + nj;
+    unsigned* d_off = c->bs.d_front.p; unsigned* d_cnt = d_off + nj; unsigned* d_stats = d_cnt + nj; unsigned* d_filled = d_stats + 4 * (size_t)nj;
+    unsigned long long* d_resume = c->bs.d_front_resume.p;
     HIP_TRY(hipMemcpyAsync(d_off, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));   /* a view's list region = its pixel offset */
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * (size_t)nj * sizeof(unsigned) + nj * sizeof(unsigned), S));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 6 * (size_t)nj * sizeof(unsigned), S));                          /* sizes, statistics, team counts */
+    HIP_TRY(hipMemsetAsync(d_resume, 0, 2 * (size_t)nj * sizeof(unsigned long long), S));
     front_first_round = round;
+    const unsigned spin_ticks = [] { const char* e = std::getenv("MI_DMRECON_TEAM_WAIT_US"); return 100u * (e ? (unsigned)std::max(1, std::atoi(e)) : MI_TEAM_WAIT_US); }();
+    /* test hook, MI_DMRECON_DEBUG_FRONT_FAULT=<member>[:<round>]: that member of every team vanishes at that round of its view */
+    const int fault = [] {
+        const char* e = std::getenv("MI_DMRECON_DEBUG_FRONT_FAULT");
+        if (!e || !*e) return -1;
+        const char* colon = std::strchr(e, ':');
+        return (std::atoi(e) & 0xFF) | ((colon ? std::max(0, std::atoi(colon + 1)) : 0) << 8);
+    }();
+    std::unique_ptr<TeamToken> token;
+    if (front_team > 1) {
+        token.reset(new TeamToken(c->device));
+        if (!token->held()) { token.reset(); front_team = 1; }     /* another call (process) runs its teams: none for this one */
+    }
     if (front_team > 1) {
         if (c->bs.d_front_mail.reserve((size_t)nj * MI_FRONT_MAIL_WORDS) || c->bs.d_front_flags.reserve((size_t)nj * MI_FRONT_TEAM_MAX))
             return fail(MI_DMRECON_EDEVICE, "hipMalloc(front mailboxes) failed");
         HIP_TRY(hipMemsetAsync(c->bs.d_front_mail.p, 0, (size_t)nj * MI_FRONT_MAIL_WORDS * sizeof(unsigned long long), S));
         HIP_TRY(hipMemsetAsync(c->bs.d_front_flags.p, 0, (size_t)nj * MI_FRONT_TEAM_MAX * sizeof(unsigned), S));
     }
-    ev.begin(S, EventLog::FRONT, tail_known);
-    D->front(S, nj, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, c->bs.d_round_work.p + (round - 1),
-             wnext, rnext, wcur, rcur, d_off, d_cnt, d_stats, round, round + 4 * MI_MAX_ROUNDS, c->d_counters,
-             front_team, front_team > 1 ? c->bs.d_front_mail.p : nullptr, front_team > 1 ? c->bs.d_front_flags.p : nullptr);
-    ev.end(S);
-    ++n_launch;
     front_stats.assign(4 * (size_t)nj, 0u);
     TailPoll& P = c->bs.h_poll[0];
-    HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
-    HIP_TRY(read_dyn(0));
-    HIP_TRY(hipMemcpyAsync(front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
-    HIP_TRY(hipStreamSynchronize(S));
-    hc = P.hc;
+    const int max_round = round + 4 * MI_MAX_ROUNDS;
+    /* the first launch deals the last tail round's list out to the views and runs them (as teams, if any); should the
+     * teams give up (a member found no compute unit in time: something else holds them), a second launch takes every
+     * unfinished view from the round it stopped in, one workgroup per view */
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool again = attempt == 1;
+        ev.begin(S, EventLog::FRONT, tail_known);
+        D->front(S, nj, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, wcur, rcur, c->bs.d_round_work.p + (round - 1),
+                 wnext, rnext, wcur, rcur, d_off, d_cnt, d_stats, round, max_round, c->d_counters,
+                 again ? 1 : front_team, (!again && front_team > 1) ? c->bs.d_front_mail.p : nullptr,
+                 (!again && front_team > 1) ? c->bs.d_front_flags.p : nullptr,
+                 again ? d_resume : nullptr, again ? d_resume + nj : d_resume, d_filled, spin_ticks, again ? -1 : fault);
+        ev.end(S);
+        ++n_launch;
+        HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
+        HIP_TRY(read_dyn(0));
+        HIP_TRY(hipMemcpyAsync(front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
+        HIP_TRY(hipStreamSynchronize(S));
+        hc = P.hc;
+        token.reset();                                            /* the teams are gone either way */
+        if (!(hc.error_flags & 32u)) break;
+        if (again) return fail(MI_DMRECON_EDEVICE, "front kernel: inconsistent state after a team gave up (flags %u)", hc.error_flags);
+        ++front_fallbacks;
+        if (trace) fprintf(stderr, "[mi_dmrecon] front teams of %d gave up (a member did not show up within %u us): finishing with one workgroup per view\n",
+                           front_team, spin_ticks / 100u);
+        hc.error_flags &= ~32u;
+        c->bs.h_jobdyn.resize(std::max<size_t>(c->bs.h_jobdyn.size(), 2 * (size_t)nj + 1));
+        c->bs.h_jobdyn[2 * (size_t)nj] = (int32_t)hc.error_flags;   /* stays valid until the copy has run (synchronised below) */
+        HIP_TRY(hipMemcpyAsync((char*)c->d_counters + offsetof(DevCounters, error_flags), &c->bs.h_jobdyn[2 * (size_t)nj], sizeof(unsigned), hipMemcpyHostToDevice, S));
+    }
     ran_front = true;
     /* n_rounds as one launch per round counts them: up to the first round that accepted nothing (the slowest view's
      * last round is that one) */
@@ -1627,9 +1719,11 @@ void BatchRun::fill_stats() {
         if (tail_timed > 0) stats->ms_tail_kernel = tail_ms / (double)tail_timed * (double)n_tail_launch;
         stats->ms_opt_kernel = stats->ms_bulk_kernel + stats->ms_tail_kernel + stats->ms_front_kernel;
         stats->n_tail_launches = n_tail_launch;
+        stats->n_latency_rounds = n_lat_rounds;
         if (ran_front) {
             stats->n_front_launches = 1;
             stats->front_team = front_team;
+            stats->front_fallbacks = front_fallbacks;
             stats->front_first_round = front_first_round;
             for (int j = 0; j < nj; ++j) {
                 const unsigned* fs = &front_stats[4 * (size_t)j];
@@ -1671,6 +1765,9 @@ int BatchRun::outcome() {
         else if (!first_rc || (first_rc == MI_DMRECON_ECANCELLED && view_rc[i] != MI_DMRECON_ECANCELLED)) { first_rc = view_rc[i]; first_i = i; }
     }
     if (truncated) return fail(MI_DMRECON_EDEVICE, "propagation did not finish within %d rounds", MI_MAX_ROUNDS);
+    /* device-side diagnostics other than the per-view ones (bit 0: a footprint exception, reported per view; bit 3: the
+     * truncation above): none of them can happen -- if one did, the maps are not to be trusted */
+    if (hc.error_flags & ~(1u | 8u)) return fail(MI_DMRECON_EDEVICE, "device error flags %u (bit 4: a stale mailbox read in a front team)", hc.error_flags);
     if (n_ok > 0) return 0;
     /* every view of the call failed: the first failure's own code and message (a single-view call behaves like
      * DMRecon::start(): the exception / the cancellation is the call's outcome) */
@@ -1707,6 +1804,9 @@ struct ScratchLease {
         pool.erase(pool.begin() + (std::ptrdiff_t)pick);
     }
     ~ScratchLease() {
+        /* nothing of this call may still be queued when the set goes back (the early returns of a failed call leave
+         * kernels and copies in flight; the next holder would write into them, or free them) */
+        (void)hipStreamSynchronize(c->stream);
         std::lock_guard<std::mutex> lock(c->sc->pool_mu);
         if (c->bs.holds_anything()) c->sc->scratch_pool.push_back(std::move(c->bs));
         c->bs = BatchScratch();
@@ -1915,7 +2015,7 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
     std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
     fill_job(c, st, jobs[0], dj[0]);
     size_t total_px = 0;
-    rc = alloc_maps(c, jobs, dj, total_px, st->nrReconNeighbors > 4);
+    rc = alloc_maps(c, jobs, dj, total_px, (size_t)std::max(n, 0), st->nrReconNeighbors > 4);
     if (rc) return rc;
     if (n == 0) return 0;
     std::vector<DevEntry> ent(n); std::vector<DevHyp> hy(n);
@@ -1985,7 +2085,7 @@ static int mi_dmrecon_patch_eval_impl(mi_dmrecon_ctx* c, const mi_dmrecon_settin
     std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
     fill_job(c, st, jobs[0], dj[0]);
     size_t total_px = 0;
-    rc = alloc_maps(c, jobs, dj, total_px, st->nrReconNeighbors > 4);
+    rc = alloc_maps(c, jobs, dj, total_px, 0, st->nrReconNeighbors > 4);
     if (rc) return rc;
     const int G = (int)jh.global.size();
     const size_t NS3 = 3 * (size_t)st->filterWidth * st->filterWidth;       /* floats per view: fw x fw samples, 3 channels */

@@ -69,7 +69,10 @@ void trace(char const* what, double since_ms, long n = -1)
  * inside the first DMRecon constructor.  Joined at exit, so a run that ends at once (--help) waits for it. */
 struct HipWarmUp {
     std::thread t;
-    HipWarmUp() : t([]() { (void)mi_dmrecon_device_count(); }) {}
+    HipWarmUp() {
+        char const* e = std::getenv("MI_DMRECON_WARMUP");               /* =0: a program that links the shim but may never use it */
+        if (!e || std::atoi(e) != 0) t = std::thread([]() { (void)mi_dmrecon_device_count(); });
+    }
     ~HipWarmUp() { if (t.joinable()) t.join(); }
 } g_hip_warm_up;
 
@@ -278,6 +281,10 @@ struct Generation {
     std::vector<std::unique_ptr<Slot> > slots;
     std::once_flag uploaded;
     std::exception_ptr upload_error;
+    /* a view whose image could not be decoded (util::Exception of the codec): kept per view and raised where the reference
+     * would have met it -- in the constructor of a DMRecon whose master view it is (loadColorImage, dmrecon.cc:79), in
+     * start() of one that could select it as a neighbour (dmrecon.cc:240) -- not in everybody's constructor */
+    std::vector<std::exception_ptr> decode_error;
     std::atomic<std::size_t> next_slot{0};
 };
 
@@ -388,11 +395,11 @@ private:
          * through in windows of a few per decoding thread: decode + enqueue in parallel, then one sync of every GPU,
          * then the window's images are released -- the host holds one window of decoded images, not the scene.
          * An exception of a view's decoder (util::Exception for a missing / corrupt image) must not leave its thread:
-         * the first one is kept and rethrown after the loop, as it would have reached the DMRecon constructor of that
-         * view in the reference. */
+         * it is kept with the view (Generation::decode_error; the view is then simply not resident) and raised to the
+         * DMRecon instances that would have met it in the reference. */
         int failed_rc = 0;
         std::string failed_msg;
-        std::exception_ptr first_exc;
+        g.decode_error.assign(views.size(), std::exception_ptr());
         std::mutex err_mu;
         /* The decoders are plain threads, not an OpenMP team: this runs inside the driver's own parallel region
          * (apps/dmrecon/dmrecon.cc:285), where a nested `omp parallel` gets ONE thread -- the 20 PNGs of a scene were
@@ -400,7 +407,7 @@ private:
         int const n_threads = (int)std::max<std::size_t>(1, std::min<std::size_t>(env_threads(), views.size()));
         std::size_t const window = (std::size_t)n_threads * 2;
         std::vector<mve::ByteImage::Ptr> keep(views.size());
-        for (std::size_t base = 0; base < views.size() && failed_rc == 0 && !first_exc; base += window) {
+        for (std::size_t base = 0; base < views.size() && failed_rc == 0; base += window) {
             std::size_t const end = std::min(views.size(), base + window);
             std::atomic<std::size_t> next(base);
             auto work = [&]() {
@@ -432,8 +439,7 @@ private:
                         }
                         views[i]->cache_cleanup();
                     } catch (...) {
-                        std::lock_guard<std::mutex> elock(err_mu);
-                        if (!first_exc) first_exc = std::current_exception();
+                        g.decode_error[i] = std::current_exception();     /* (one writer per view) */
                     }
                 }
             };
@@ -460,7 +466,6 @@ private:
                 default: throw std::runtime_error(ctx_msg);
             }
         }
-        if (first_exc) { destroy_contexts(); std::rethrow_exception(first_exc); }
         trace("views decoded + staged", t_mark, (long)views.size()); t_mark = trace_ms();
         mve::Bundle::Features const& feats = g.scene->get_bundle()->get_features();
         std::vector<float> pos(feats.size() * 3);
@@ -528,13 +533,20 @@ DMRecon::DMRecon(mve::Scene::Ptr _scene, Settings const& _settings)
      * the views, so by the time it ends every one of them is counted and their start() calls form one batch */
     att->slot->announce(); att->announced = true;
     this->slot = att;
+    /* the master view's own validity costs nothing (dmrecon.cc:62-75: SingleView::create decodes no image): checked before
+     * anything is staged -- after the bundle, whose error comes first in the reference (dmrecon.cc:50-59) */
+    mve::View::Ptr ref = mve_views[settings.refViewNr];
+    if (ref == nullptr || !ref->is_camera_valid()
+        || !ref->has_image(settings.imageEmbedding, mve::IMAGE_TYPE_UINT8)) {
+        try { this->scene->get_bundle(); }
+        catch (std::exception& e) { throw std::runtime_error(std::string("Error reading bundle file: ") + e.what()); }
+        throw std::invalid_argument("Invalid master view");
+    }
     /* stages the scene on first use; the bundle file is read in there, next to the image decoders (dmrecon.cc:50-59:
      * std::runtime_error "Error reading bundle file: ..." -- before the master view is looked at, as in the reference) */
     Registry::make_resident(*att->gen);
-    mve::View::Ptr ref = mve_views[settings.refViewNr];
-    if (ref == nullptr || !ref->is_camera_valid()
-        || !ref->has_image(settings.imageEmbedding, mve::IMAGE_TYPE_UINT8))
-        throw std::invalid_argument("Invalid master view");
+    if (settings.refViewNr < att->gen->decode_error.size() && att->gen->decode_error[settings.refViewNr])
+        std::rethrow_exception(att->gen->decode_error[settings.refViewNr]);      /* loadColorImage(scale), dmrecon.cc:79 */
     Slot* slot = att->slot;
     int32_t w = 0, h = 0;
     {
@@ -554,6 +566,25 @@ DMRecon::start()
 {
     progress.start_time = std::time(nullptr);
     if (progress.cancelled) { progress.status = RECON_CANCELLED; return; }
+    {
+        /* a neighbour whose image could not be decoded: the reference meets it when the view selection loads it
+         * (dmrecon.cc:240) -- possible only for views that share a feature with the master view */
+        Generation const& gen = *std::static_pointer_cast<Attachment>(this->slot)->gen;
+        bool any = false;
+        for (std::size_t i = 0; i < gen.decode_error.size() && !any; ++i) any = gen.decode_error[i] != nullptr;
+        if (any) {
+            mve::Bundle::Features const& feats = gen.scene->get_bundle()->get_features();
+            for (std::size_t f = 0; f < feats.size(); ++f) {
+                bool mine = false;
+                for (std::size_t j = 0; j < feats[f].refs.size() && !mine; ++j) mine = feats[f].refs[j].view_id == (int)settings.refViewNr;
+                if (!mine) continue;
+                for (std::size_t j = 0; j < feats[f].refs.size(); ++j) {
+                    std::size_t const v = (std::size_t)feats[f].refs[j].view_id;
+                    if (v < gen.decode_error.size() && gen.decode_error[v]) std::rethrow_exception(gen.decode_error[v]);
+                }
+            }
+        }
+    }
 
     mi_dmrecon_settings st;
     mi_dmrecon_settings_default(&st);

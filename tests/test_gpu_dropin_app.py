@@ -75,8 +75,9 @@ def test_shim_deals_views_over_several_gpu_slots(tmp_path, g1_scene):
     for name, devices in (("one", "0"), ("two", "0,0"), ("three", "0,0,0")):
         sdir = str(tmp_path / name)
         scene_io.write_scene(sdir, g1_scene)
-        # MI_DMRECON_MERGE_CALLS=0: every mvs::DMRecon::start() is its own batch, whatever the timing of the app's threads
-        env = dict(os.environ, MI_DMRECON_DEVICES=devices, MI_DMRECON_MERGE_CALLS="0")
+        # (default settings otherwise: how the app's threads meet inside the shim and the library -- which start() calls
+        # share a batch -- is a matter of timing; the maps are not)
+        env = dict(os.environ, MI_DMRECON_DEVICES=devices)
         out = subprocess.run([APP, "-s0", "--keep-conf", "--keep-dz", "--force", "--progress=silent", sdir],
                              capture_output=True, text=True, timeout=600, env=env)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -88,3 +89,42 @@ def test_shim_deals_views_over_several_gpu_slots(tmp_path, g1_scene):
             for a, b in zip(runs["one"][v], runs[name][v]):
                 assert np.array_equal(a, b), (name, v)
     assert (runs["one"][0][1] > 0).mean() > 0.3
+
+
+def _read_maps(sdir, n_views, scale):
+    out = []
+    for v in range(n_views):
+        vd = scene_io.view_dir(sdir, v)
+        out.append(tuple(open(os.path.join(vd, "%s-L%d.mvei" % (name, scale)), "rb").read() for name in ("depth", "conf", "dz")))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(APP), reason="build/dmrecon_mi not built (needs the reference tree at build time)")
+def test_two_processes_share_the_gpu(tmp_path):
+    """Two dmrecon_mi PROCESSES on GPU 0 at the same time, default environment, each on its own copy of the C3 scene (20
+    views of 1920 x 1080 at scale 2): both finish, and every depth-L2 / conf-L2 / dz-L2 file of either is byte for byte
+    what a run alone writes -- which itself writes the same bytes twice in a row.  (The reference is bit-identical run to
+    run; here the front teams of one process must not wait for ever for compute units the other
+    holds, and the batches the app's threads happen to form must not show in the maps.)"""
+    from mve_amd.synth import CONFIGS, make_scene
+    cfg = CONFIGS["C3"]
+    scene = make_scene(cfg["params"])
+    n = cfg["params"].n_views
+    dirs = [str(tmp_path / name) for name in ("alone", "again", "p1", "p2")]
+    for d in dirs:
+        scene_io.write_scene(d, scene)
+    cmd = [APP, "-s%d" % cfg["scale"], "--keep-conf", "--keep-dz", "--force", "--progress=silent"]
+    for d in dirs[:2]:
+        out = subprocess.run(cmd + [d], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    alone, again = _read_maps(dirs[0], n, cfg["scale"]), _read_maps(dirs[1], n, cfg["scale"])
+    for v in range(n):
+        assert alone[v] == again[v], "run-to-run difference in view %d" % v
+    procs = [subprocess.Popen(cmd + [d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for d in dirs[2:]]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    for d in dirs[2:]:
+        got = _read_maps(d, n, cfg["scale"])
+        for v in range(n):
+            assert got[v] == alone[v], "%s: view %d differs from the run alone" % (os.path.basename(d), v)

@@ -132,13 +132,13 @@ def test_c3_deterministic(c3):
             for k in ("depth", "conf", "dz", "normal", "views"):
                 assert np.array_equal(again[v][k], res[v][k]), (v, k)
     f.close()
-    # A different batch composition switches from the throughput to the latency lane layout at a
-    # different round; the two layouts sum the 25 samples in a different order (1e-7), which now and then
-    # flips a convergence decision.  Such results agree far inside the parity tolerance.
-    sub = ctx.reconstruct(st, [0, 7, 19])
+    # A view's maps are the view's own: in another batch (three views instead of twenty) bit for bit the same -- the round
+    # at which a view leaves the throughput lane layout is decided from the view's own list sizes
+    sub = ctx.reconstruct(st, [0, 7, 19], want_views=True)
     for v, r in zip([0, 7, 19], sub):
-        m = map_parity(r["depth"], r["conf"], res[v]["depth"], res[v]["conf"])
-        assert m["iou"] >= 0.999 and m["rel_med"] <= 1e-4 and m["rel_p99"] <= 3e-3 and m["conf_p99"] <= 3e-3, m
+        for k in ("depth", "conf", "dz", "normal", "views"):
+            assert np.array_equal(r[k], res[v][k]), (v, k)
+    assert stats["n_latency_rounds"] >= 1 and stats["n_bulk_launches"] > 10, stats      # both layouts ran in the big call
 
 
 @pytest.mark.parametrize("view", [3, 8, 12])

@@ -209,11 +209,11 @@ def test_speculative_tail_equals_sequential_attempts(gpu_ctx, g1_scene, monkeypa
     gpu_ctx.load_scene(g1_scene)
     st = api.Settings()
     monkeypatch.setenv("MI_DMRECON_FRONT", "0")                        # (the front kernel has its own test)
-    monkeypatch.setenv("MI_DMRECON_BULK_LPV", "16")
-    monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "0")               # never enter the tail
+    monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", "1000000000")       # every view in the latency layout from the first round on
+    monkeypatch.setenv("MI_DMRECON_HOST_ROUNDS", "1")                  # never enter the tail
     seq = gpu_ctx.reconstruct(st, [0, 1, 2, 3, 4], want_views=True)
     n_seq = dict(gpu_ctx.last_stats)
-    monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "1000000000")      # tail rounds from the first round on
+    monkeypatch.delenv("MI_DMRECON_HOST_ROUNDS")                       # tail rounds from the first round on
     spec = gpu_ctx.reconstruct(st, [0, 1, 2, 3, 4], want_views=True)
     n_spec = dict(gpu_ctx.last_stats)
     assert n_spec["n_tail_launches"] >= 10 and n_seq["n_tail_launches"] == 0
@@ -240,7 +240,7 @@ def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, m
         gpu_ctx.load_scene(scene)
         monkeypatch.setenv("MI_DMRECON_FRONT", "0")
         if per_view == "all":
-            monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "1000000000")      # tail rounds from the first round on
+            monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", "1000000000")       # tail rounds from the first round on
         ref = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
         s0 = dict(gpu_ctx.last_stats)
         assert s0["n_front_launches"] == 0
@@ -262,10 +262,150 @@ def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, m
             for a, b in zip(got, ref):
                 for k in ("depth", "conf", "dz", "normal", "views"):
                     assert np.array_equal(a[k], b[k]), (k, rep)
-        monkeypatch.delenv("MI_DMRECON_TAIL_THRESHOLD", raising=False)
+        monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER", raising=False)
     monkeypatch.delenv("MI_DMRECON_FRONT", raising=False)
     monkeypatch.delenv("MI_DMRECON_FRONT_TEAM", raising=False)
     gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
+
+
+@pytest.mark.parametrize("fault", ["3", "0:7", "5:40"])
+def test_front_team_gives_up_and_the_views_finish(gpu_ctx, g1_scene, h1_scene, monkeypatch, fault):
+    """A front team needs all its workgroups on the GPU at once; what else holds compute units (another process, another
+    program) the library cannot see.  A member that is not there in time must not fail the call: the team gives up, and
+    the views go on from the round they stopped in with one workgroup each -- same maps as without teams, bit for bit.
+    The test hook makes one member of every team vanish: never there ("3"), or after 7 / 40 rounds of its view."""
+    monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", "1000000000")           # the whole propagation in the front kernel
+    monkeypatch.setenv("MI_DMRECON_FRONT", "1000000")
+    monkeypatch.setenv("MI_DMRECON_TEAM_WAIT_US", "3000")
+    for scene, refs in ((g1_scene, [0, 1, 2, 3, 4]), (h1_scene, list(range(9)))):
+        gpu_ctx.load_scene(scene)
+        monkeypatch.setenv("MI_DMRECON_FRONT_TEAM", "1")
+        ref = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
+        s0 = dict(gpu_ctx.last_stats)
+        assert s0["front_fallbacks"] == 0 and s0["front_team"] == 1
+        monkeypatch.setenv("MI_DMRECON_FRONT_TEAM", "8")
+        monkeypatch.setenv("MI_DMRECON_DEBUG_FRONT_FAULT", fault)
+        got = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
+        s1 = dict(gpu_ctx.last_stats)
+        monkeypatch.delenv("MI_DMRECON_DEBUG_FRONT_FAULT")
+        assert s1["front_fallbacks"] == 1 and s1["front_team"] == 8, s1
+        assert s1["n_filled"] == s0["n_filled"], (s1["n_filled"], s0["n_filled"])
+        for a, b in zip(got, ref):
+            for k in ("depth", "conf", "dz", "normal", "views"):
+                assert np.array_equal(a[k], b[k]), (k, fault)
+        # ... and the next call on the same context (same mailboxes, same flags) runs its teams undisturbed
+        again = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
+        assert gpu_ctx.last_stats["front_fallbacks"] == 0 and gpu_ctx.last_stats["front_team"] == 8
+        for a, b in zip(again, ref):
+            assert np.array_equal(a["depth"], b["depth"]) and np.array_equal(a["conf"], b["conf"])
+    for k in ("MI_DMRECON_VIEW_HANDOVER", "MI_DMRECON_FRONT", "MI_DMRECON_TEAM_WAIT_US", "MI_DMRECON_FRONT_TEAM"):
+        monkeypatch.delenv(k)
+    gpu_ctx.load_scene(g1_scene)
+
+
+def test_team_token_is_exclusive_per_gpu(gpu_ctx, g1_scene, monkeypatch):
+    """Only one call per GPU runs front teams at a time, across processes: an advisory lock file named after the GPU's
+    PCI address.  Held by somebody else (here: this test, through a second open of the file), a call runs without teams
+    -- and gets the same maps."""
+    import fcntl
+    import glob
+    gpu_ctx.load_scene(g1_scene)
+    monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", "1000000000")
+    monkeypatch.setenv("MI_DMRECON_FRONT", "1000000")
+    ref = gpu_ctx.reconstruct(api.Settings(), [0, 1, 2, 3, 4])
+    assert gpu_ctx.last_stats["front_team"] > 1
+    locks = glob.glob("/dev/shm/mi_dmrecon_team_*.lock") + glob.glob("/tmp/mi_dmrecon_team_*.lock")
+    assert locks, "the team launch above must have created its lock file"
+    held = [open(p, "r+") for p in locks]
+    for f in held:
+        fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)        # free again after the call: the lock is per front launch
+    got = gpu_ctx.reconstruct(api.Settings(), [0, 1, 2, 3, 4])
+    assert gpu_ctx.last_stats["front_team"] == 1 and gpu_ctx.last_stats["front_fallbacks"] == 0
+    for f in held:
+        f.close()
+    for a, b in zip(got, ref):
+        assert np.array_equal(a["depth"], b["depth"]) and np.array_equal(a["conf"], b["conf"])
+    monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER"); monkeypatch.delenv("MI_DMRECON_FRONT")
+
+
+def test_maps_do_not_depend_on_the_batch(gpu_ctx, g1_scene, h1_scene, monkeypatch):
+    """A reference view's maps are the view's own: alone in a call, with four others, in a call merged with other calls,
+    with one launch per throughput round or two -- bit for bit the same (as the reference's all-views mode writes what
+    `-m ID` writes, apps/dmrecon/dmrecon.cc:285-318).  What could change the last bits -- the round at which the view's
+    patches move from the throughput to the latency lane layout, which sum in different orders -- is decided per view
+    from the view's own list sizes (k_generate), with a threshold low enough here that views hand over at different
+    rounds of one batch."""
+    import threading
+    st = api.Settings()
+    for scene, refs, handover in ((g1_scene, [0, 1, 2, 3, 4], "150"), (h1_scene, list(range(9)), "60"), (g1_scene, [0, 1, 2, 3, 4], None)):
+        gpu_ctx.load_scene(scene)
+        if handover:
+            monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", handover)
+        else:
+            monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER", raising=False)
+        ref = gpu_ctx.reconstruct(st, refs, want_views=True)
+        s_all = dict(gpu_ctx.last_stats)
+        if handover:
+            assert s_all["n_latency_rounds"] >= 2 and s_all["n_bulk_launches"] >= s_all["n_latency_rounds"] + 3, s_all   # both layouts ran
+        # one view per call; sub-batches; another order
+        for v in refs[:3]:
+            one = gpu_ctx.reconstruct(st, [v], want_views=True)[0]
+            for k in ("depth", "conf", "dz", "normal", "views"):
+                assert np.array_equal(one[k], ref[refs.index(v)][k]), (v, k)
+        sub = gpu_ctx.reconstruct(st, [refs[3], refs[1]], want_views=True)
+        for r, v in zip(sub, (refs[3], refs[1])):
+            for k in ("depth", "conf", "dz", "normal", "views"):
+                assert np.array_equal(r[k], ref[refs.index(v)][k]), (v, k)
+        # the throughput rounds as first-attempt launch + follow-up launch instead of one launch: same arithmetic
+        monkeypatch.setenv("MI_DMRECON_ONE_LAUNCH", "0")
+        two = gpu_ctx.reconstruct(st, refs, want_views=True)
+        monkeypatch.delenv("MI_DMRECON_ONE_LAUNCH")
+        for a, b in zip(two, ref):
+            for k in ("depth", "conf", "dz", "normal", "views"):
+                assert np.array_equal(a[k], b[k]), k
+        # calls that meet inside the library are merged into one batch (default): every caller gets its own call's maps
+        forks = [gpu_ctx.fork() for _ in range(3)]
+        parts = [refs[:2], refs[2:3], refs[3:]]
+        out = [None] * 3
+        go = threading.Barrier(3)
+
+        def worker(i):
+            go.wait()
+            out[i] = forks[i].reconstruct(st, parts[i], want_views=True)
+
+        for _ in range(2):
+            th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for part, res in zip(parts, out):
+                for v, r in zip(part, res):
+                    for k in ("depth", "conf", "dz", "normal", "views"):
+                        assert np.array_equal(r[k], ref[refs.index(v)][k]), (v, k)
+        for f in forks:
+            f.close()
+    monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER", raising=False)
+    gpu_ctx.load_scene(g1_scene)
+
+
+def test_more_seeds_than_pixels(gpu_ctx):
+    """Coarse scales of small images: a call's seed list can be longer than its pixels (many SfM features per reference
+    view, few pixels).  The list buffers are sized for it in the same step as the state maps -- growing them afterwards
+    used to reallocate the maps the jobs already pointed at."""
+    from mve_amd.synth import SynthParams, make_scene
+    sc = make_scene(SynthParams(n_views=5, width=160, height=120, n_features=6000))
+    c = api.Context(0)                                          # a fresh context: fresh (unsized) scratch sets
+    c.load_scene(sc)
+    st = api.Settings(scale=2)                                  # 40 x 30 = 1 200 pixels per view, ~6 000 seeds each
+    a = c.reconstruct(st, [0, 1, 2], want_views=True)
+    assert c.last_stats["n_seeds"] > 2 * 3 * 40 * 30 + 64, c.last_stats["n_seeds"]
+    b = c.reconstruct(st, [0, 1, 2], want_views=True)           # second call: buffers already large enough
+    for x, y in zip(a, b):
+        for k in ("depth", "conf", "dz", "views"):
+            assert np.array_equal(x[k], y[k]), k
+    assert all((x["conf"] > 0).mean() > 0.2 for x in a)
+    c.close()
 
 
 def test_batch_scratch_is_leased_from_the_scene(gpu_ctx, g1_scene, monkeypatch):
@@ -663,17 +803,16 @@ def test_wide_view_sets_vs_reference(gpu_ctx, w1, w1_scene, g1_scene, monkeypatc
     # host-visible rounds in the same lane layout write
     refs = [0, 5, 11]
     monkeypatch.setenv("MI_DMRECON_FRONT", "0")
-    monkeypatch.setenv("MI_DMRECON_BULK_LPV", "16")
-    monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "0")
+    monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", "1000000000")
+    monkeypatch.setenv("MI_DMRECON_HOST_ROUNDS", "1")
     seq = gpu_ctx.reconstruct(st6, refs, want_views=True)
-    monkeypatch.delenv("MI_DMRECON_BULK_LPV")
+    monkeypatch.delenv("MI_DMRECON_HOST_ROUNDS")
     for front in ("0", "1000000"):
         monkeypatch.setenv("MI_DMRECON_FRONT", front)
-        monkeypatch.setenv("MI_DMRECON_TAIL_THRESHOLD", "1000000000")
         got = gpu_ctx.reconstruct(st6, refs, want_views=True)
         assert gpu_ctx.last_stats["n_front_launches"] == (1 if front != "0" else 0)
         for a, b in zip(seq, got):
             for key in ("depth", "conf", "dz", "normal", "views"):
                 assert np.array_equal(a[key], b[key]), (front, key)
-    monkeypatch.delenv("MI_DMRECON_FRONT"); monkeypatch.delenv("MI_DMRECON_TAIL_THRESHOLD")
+    monkeypatch.delenv("MI_DMRECON_FRONT"); monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER")
     gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
