@@ -34,6 +34,11 @@ from mve_amd.dist import Collective, rank_views, rank_world, shard_views  # noqa
 from mve_amd.synth import CONFIGS, make_scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guide: 8.0 TB/s; 6.29 TB/s measured copy)
+N_SIMDS = 256 * 4          # 256 CUs x 4 SIMDs
+SHADER_CLOCK_HZ = 2.4e9    # guide: 2400 MHz
+CYCLES_PER_VALU_INST = 4.0 # one f32 VALU wave-instruction occupies its SIMD's issue port for four cycles (measured:
+                           # tools/ubench/valu_rate2.hip, profiles/r4_valu_rate.txt; SQ counters of the kernel itself: 4.1)
+ALGORITHMIC_VALU_PER_SAMPLE = 57.0   # f32 operations per sample the reference's arithmetic needs (VERDICT r3 / DESIGN section 5)
 
 
 def algorithmic_bytes(stats, n_maps, scene, cfg):
@@ -67,7 +72,21 @@ def plan_calls(steps, streams, steps_per_call=0):
     return spc, n_calls, max(1, min(int(streams), n_calls))
 
 
-TRAFFIC_PROFILES = ("r3_traffic.json", "r2_traffic.json")     # newest first
+TRAFFIC_PROFILES = ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json")     # newest first
+# executed VALU wave-instructions per wavefront pass (16 patches x 4 views x 25 samples) of the bulk kernel: SQ_INSTS_VALU of a
+# PMC pass / (device-counted passes / 64); a STORED profile value like `traffic` (profiles/r<N>_traffic.json:
+# "valu_wave_insts_per_wave_pass"), r3's figure when the newest profile does not carry one
+VALU_PER_WAVE_PASS_R3 = 3460.0
+
+
+def stored_valu_per_wave_pass():
+    for name in TRAFFIC_PROFILES:
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            v = json.load(open(f)).get("valu_wave_insts_per_wave_pass")
+            if v:
+                return float(v), "profiles/" + name
+    return VALU_PER_WAVE_PASS_R3, "profiles/r3_pmc.md (1.42e8 VALU wave-instructions per FAST launch / its passes)"
 
 
 def measured_traffic(n_streams, spc):
@@ -91,14 +110,16 @@ def measured_traffic(n_streams, spc):
     return {}, None
 
 
-def cpu_baseline(scene, cfg, gpu_maps=None):
+def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
     """The reference CPU path timed on this box's host cores on a bounded sample of the same workload.
     With gpu_maps (the HIP path's depth / conf maps of the same views) the reference's own output -- which this
     leg produces anyway -- is read back and diffed: the `parity` object of the JSON line."""
     cores = os.cpu_count() or 1
     ref_exe = os.path.join(ROOT, "oracle", "_ref", "dmrecon_ref_fast")
     p, s, k = cfg["params"], cfg["scale"], cfg["local_neighbors"]
-    if os.path.exists(ref_exe):
+    # (a scene of gigabytes -- C5: 100 x 36.6 MB -- is not written to disk as PNGs for the reference binary inside a
+    # bench run: the restatement on one view stands in, `kind` says so)
+    if os.path.exists(ref_exe) and sum(im.nbytes for im in scene.images) < (1 << 30):
         from mve_amd.scene_io import read_mvei, view_dir, write_scene
         n_sample = max(1, min(cores, p.n_views))
         work = tempfile.mkdtemp(prefix="bench_ref_")
@@ -123,11 +144,17 @@ def cpu_baseline(scene, cfg, gpu_maps=None):
                               "%d host cores available, one thread per view" % (n_sample - 1, s, t, cores)}
             parity = None
             if gpu_maps is not None:
-                parity = map_parity_all(
-                    gpu_maps[:n_sample],
-                    [(read_mvei(os.path.join(view_dir(sdir, v), "depth-L%d.mvei" % s)),
-                      read_mvei(os.path.join(view_dir(sdir, v), "conf-L%d.mvei" % s))) for v in range(n_sample)],
-                    "the reference's own depth-L%d / conf-L%d of views 0-%d (the cpu_baseline run), this run" % (s, s, n_sample - 1))
+                ref_maps = [(read_mvei(os.path.join(view_dir(sdir, v), "depth-L%d.mvei" % s)),
+                             read_mvei(os.path.join(view_dir(sdir, v), "conf-L%d.mvei" % s))) for v in range(n_sample)]
+                against = "the reference's own depth-L%d / conf-L%d of views 0-%d (the cpu_baseline run), this run" % (s, s, n_sample - 1)
+                parity = map_parity_all(gpu_maps[:n_sample], ref_maps, against)
+                parity["which"] = "maps of the first timed call"
+                if gpu_maps_last is not None:
+                    pl = map_parity_all(gpu_maps_last[:n_sample], ref_maps, against)
+                    parity["last_timed_call"] = {k: pl[k] for k in ("min_fill_iou", "max_rel_depth_median", "max_rel_depth_p99", "max_conf_abs_p99", "within_bounds")}
+                    parity["last_timed_call"]["bit_identical_to_first"] = bool(all(
+                        np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(gpu_maps[:n_sample], gpu_maps_last[:n_sample])))
+                    parity["within_bounds"] = bool(parity["within_bounds"] and pl["within_bounds"])
             return base, parity
         finally:
             shutil.rmtree(work, ignore_errors=True)
@@ -170,11 +197,13 @@ def map_parity_all(gpu, ref, against):
             "within_bounds": bool(ok)}
 
 
-def timed_region(coll, ctxs, st, refs, n_calls, warmup):
-    """W untimed warm-up calls per host thread, then exactly n_calls library calls of `refs` dealt over the host
-    threads (one forked context / HIP stream each), bracketed by barrier + synchronise on both sides; returns
-    (max-over-ranks elapsed seconds, summed stats, the maps of the first timed call).
-    The host threads live across warm-up and timed region, as the threads of a long-running process do: thread
+def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1):
+    """W untimed warm-up calls per host thread, then `repeats` timed regions of exactly n_calls library calls of `refs`
+    each, dealt over the host threads (one forked context / HIP stream each), every region bracketed by barrier +
+    synchronise on both sides (a library call returns with its maps on the host: the stream is idle when it does);
+    returns (per-region max-over-ranks elapsed seconds, stats summed over all regions, the maps of the first and of the
+    last timed call).
+    The host threads live across warm-up and timed regions, as the threads of a long-running process do: thread
     creation -- and with it the creation of each thread's OpenMP team inside the library (~10 ms) -- is not part of
     a step."""
     import threading
@@ -184,7 +213,8 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup):
     acc, last, t_calls = {}, {}, [0.0] * n_streams
     t_go = [0.0]
     lock = threading.Lock()
-    warmed, go = threading.Barrier(n_streams + 1), threading.Barrier(n_streams + 1)
+    warmed = threading.Barrier(n_streams + 1)
+    go, fin = threading.Barrier(n_streams + 1), threading.Barrier(n_streams + 1)
 
     def worker(i, c, o, n):
         for _ in range(max(warmup, 1)):
@@ -192,34 +222,42 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup):
             c.reconstruct(st, refs, want_normal=False, out=o)
             t_calls[i] = time.perf_counter() - tw
         warmed.wait()
-        go.wait()
-        # (no phase offsets: every host thread starts at once; calls that meet inside the library are merged)
-        for _ in range(n):
-            r = c.reconstruct(st, refs, want_normal=False, out=o)   # synchronous: returns with the maps on the host
-            with lock:
-                if "res" not in last:
-                    last["res"] = [(m["depth"].copy(), m["conf"].copy()) for m in r]
-                    last["shape"] = r[0]["depth"].shape
-                for k, v in c.last_stats.items():
-                    acc[k] = acc.get(k, 0) + v
-                # how the library batched the timed calls: (calls merged into the batch this call ran, its host clock)
-                acc.setdefault("_batches", []).append((int(c.last_stats.get("n_merged_calls", 0)), round(c.last_stats.get("ms_total", 0.0), 1),
-                                                       round(1000.0 * (time.perf_counter() - t_go[0]), 1)))
+        for rep in range(repeats):
+            go.wait()
+            # (no phase offsets: every host thread starts at once; calls that meet inside the library are merged)
+            for _ in range(n):
+                r = c.reconstruct(st, refs, want_normal=False, out=o)   # synchronous: returns with the maps on the host
+                with lock:
+                    if "res" not in last:
+                        last["res"] = [(m["depth"].copy(), m["conf"].copy()) for m in r]
+                        last["shape"] = r[0]["depth"].shape
+                    if rep == repeats - 1:
+                        last["res_last"] = [(m["depth"].copy(), m["conf"].copy()) for m in r]   # (the last one to finish stays)
+                    for k, v in c.last_stats.items():
+                        acc[k] = acc.get(k, 0) + v
+                    # how the library batched the timed calls: (calls merged into the batch this call ran, its host clock)
+                    if rep == 0:
+                        acc.setdefault("_batches", []).append((int(c.last_stats.get("n_merged_calls", 0)), round(c.last_stats.get("ms_total", 0.0), 1),
+                                                               round(1000.0 * (time.perf_counter() - t_go[0]), 1)))
+            fin.wait()
 
     threads = [threading.Thread(target=worker, args=(i, c, o, n)) for i, (c, o, n) in enumerate(zip(ctxs, outs, share))]
     for t in threads:
         t.start()
     warmed.wait()
-    coll.barrier()
-    t0 = time.perf_counter()
-    t_go[0] = t0
-    go.wait()
+    elapsed = []
+    for rep in range(repeats):
+        coll.barrier()
+        t0 = time.perf_counter()
+        t_go[0] = t0
+        go.wait()
+        fin.wait()
+        coll.barrier()
+        elapsed.append(coll.max(time.perf_counter() - t0))
     for t in threads:
         t.join()
-    coll.barrier()
-    elapsed = coll.max(time.perf_counter() - t0)
     batches = acc.pop("_batches", [])
-    last["batches"] = sorted(b for b in batches if b[0] > 0)      # (calls in the batch, ms of the batch, ms since the start when it returned)
+    last["batches"] = sorted(b for b in batches if b[0] > 0)      # first region: (calls in the batch, ms of the batch, ms since the start when it returned)
     return elapsed, acc, last
 
 
@@ -288,6 +326,7 @@ def roofline(acc, n_maps, scene, cfg, n_streams, spc, elapsed):
             # fp32 VALU with SURVEY's algorithmic flop counts (3.6 kflop per derivative evaluation, 1.6 kflop
             # per colour evaluation, mix 19.9 : 11.9), and the L2 with the bytes the passes request from it
             "secondary_roofs": {
+                "valu_issue": valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps_rank),
                 "valu_fp32": {"algorithmic_flop": 2.85e3 * acc["n_eval"], "achieved": 2.85e3 * acc["n_eval"] / opt_s / 1e12 if opt_s > 0 else None,
                               "peak": 157.3, "unit": "TFLOP/s", "frac": 2.85e3 * acc["n_eval"] / opt_s / 1e12 / 157.3 if opt_s > 0 else None},
                 "l2": {"requested_bytes": 400.0 * n_pass, "achieved": 400.0 * n_pass / opt_s / 1e9 if opt_s > 0 else None,
@@ -299,7 +338,60 @@ def roofline(acc, n_maps, scene, cfg, n_streams, spc, elapsed):
             "aggregate_frac": b_alg / elapsed / 1e9 / HBM_PEAK_GBS if elapsed > 0 else None}
 
 
-def run_one_call(ctx, st, views, scene, cfg, n_timed=10):
+def predicted_strong_scaling(n_views):
+    """BASELINE config 4 on 1 / 2 / 4 / 8 GPUs as the measurements of ONE GPU predict it -- no 8-GPU node has run it (the
+    driver's SCALE record would be the measurement): a rank that has its GPU to itself reconstructs its share of the
+    scene's reference views per step, one library call; lone calls of exactly those sizes were timed on one MI355X
+    (tools/lone_calls.py -> profiles/r<N>_lone_calls.json, a STORED profile).  The floor: one view's dependent propagation
+    rounds do not shrink with the share."""
+    for tag in ("r4", "r3"):
+        f = os.path.join(ROOT, "profiles", "%s_lone_calls.json" % tag)
+        if not os.path.exists(f):
+            continue
+        j = json.load(open(f))
+        sizes = {int(k): v for k, v in j.get("sizes", {}).items()}
+        curve = {}
+        for world in (1, 2, 4, 8):
+            share = (n_views + world - 1) // world              # the slowest rank's share (round-robin: ranks differ by <= 1 view)
+            if share in sizes:
+                ms = sizes[share]["ms_median"]
+                curve[str(world)] = {"views_on_slowest_rank": share, "ms_per_step": ms, "depth_maps_per_s": 1000.0 * n_views / ms}
+        if curve:
+            one = sizes.get(1, {}).get("ms_median")
+            return {"predicted": True, "measured_on": "one MI355X: lone calls of a rank's share (%s)" % ("profiles/%s_lone_calls.json" % tag),
+                    "stored_profile": True, "gpus": curve,
+                    "floor_ms_per_step": one, "floor_note": "a single reference view: its ~580 dependent propagation rounds",
+                    "speedup_8_over_1": (curve["8"]["depth_maps_per_s"] / curve["1"]["depth_maps_per_s"]) if ("8" in curve and "1" in curve) else None}
+    return None
+
+
+def valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps):
+    """The ceiling the bulk kernel is actually under (its wavefronts are limited by how fast a SIMD
+    issues their VALU instructions, not by memory): the VALU wave-instructions it EXECUTES -- a stored SQ_INSTS_VALU
+    figure per wavefront pass x the passes this run counted on the device -- over the chip's issue rate, SIMDs x shader
+    clock / 4 cycles per instruction.  `frac` = that floor / the kernel's measured time: 1.0 = every SIMD issues a VALU
+    instruction whenever it can.  `executed_per_algorithmic`: the instructions executed per f32 operation the reference's
+    arithmetic needs (57 per sample): what the formulation adds on top (addressing, table look-ups, control)."""
+    if not acc.get("n_eval") or ms_bulk <= 0:
+        return None
+    per_wave_pass, src = stored_valu_per_wave_pass()
+    passes_bulk = n_pass * (bulk_stats["n_eval"] / acc["n_eval"])           # the bulk kernel's share of the executed passes
+    insts = per_wave_pass * passes_bulk / 64.0                              # a wavefront pass = 64 patch-view passes
+    rate = N_SIMDS * SHADER_CLOCK_HZ / CYCLES_PER_VALU_INST                 # wave-instructions per second, whole chip
+    floor_ms = 1000.0 * insts / rate
+    alg = ALGORITHMIC_VALU_PER_SAMPLE * 25.0 * passes_bulk / 64.0
+    return {"bound": "valu_issue", "kernel": "k_optimize<1> (host-visible rounds)",
+            "executed_valu_wave_insts_per_step": insts / max(steps, 1), "valu_wave_insts_per_wave_pass": per_wave_pass,
+            "source": {"file": src, "stored_profile": True},
+            "peak": rate / 1e9, "unit": "G wave-instructions/s", "cycles_per_valu_wave_inst": CYCLES_PER_VALU_INST,
+            "achieved": insts / (ms_bulk / 1e3) / 1e9,
+            "floor_ms_per_step": floor_ms / max(steps, 1), "measured_ms_per_step": ms_bulk / max(steps, 1),
+            "frac": floor_ms / ms_bulk,
+            "executed_per_algorithmic": insts / alg if alg > 0 else None,
+            "valu_insts_per_sample": per_wave_pass / 25.0}
+
+
+def run_one_call(ctx, st, views, scene, cfg, n_timed=50):
     """What a user of apps/dmrecon gets: ONE library call for the scene's reference views (20 on C3) on one host
     thread, nothing else on the GPU.  Measured after the timed region, same resident scene: 2 warm-up calls, then
     n_timed calls; ms per call (median / mean), depth-maps/s, where the time goes, and the roofline of that call."""
@@ -319,6 +411,9 @@ def run_one_call(ctx, st, views, scene, cfg, n_timed=10):
     return {"what": "one library call = the %d reference views of the scene once, 1 host thread, GPU otherwise idle; "
                     "median of %d calls after the timed region" % (len(views), n_timed),
             "ms_per_call": 1000.0 * med, "ms_per_call_mean": 1000.0 * float(np.mean(ts)),
+            "ms_per_call_min_max": [1000.0 * float(np.min(ts)), 1000.0 * float(np.max(ts))],
+            "ms_front_view_max": acc.get("ms_front_view_max", 0.0) / n_timed, "front_fallbacks": int(acc.get("front_fallbacks", 0)),
+            "valu_issue_frac": (roof["secondary_roofs"]["valu_issue"] or {}).get("frac"),
             "depth_maps_per_s": len(views) / med,
             "ms_host_planning": (acc.get("ms_plan_gvs", 0.0) + acc.get("ms_plan_seeds", 0.0)) / n_timed,
             "ms_bulk_kernel": acc.get("ms_bulk_kernel", 0.0) / n_timed,
@@ -340,6 +435,10 @@ def main():
                          "for several seconds so that an outside utilisation sampler sees the run")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps, barrier + synchronise on both sides) is run this many "
+                         "times in the same process; `value` is the median region, `repeats` lists them all")
+    ap.add_argument("--one-call-n", type=int, default=50, help="library calls behind the `one_call` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-call", action="store_true",
                     help="skip the `one_call` object (one 20-view library call on one host thread, measured after the timed region)")
@@ -372,9 +471,17 @@ def main():
         os.environ.setdefault("MI_DMRECON_FRONT_TEAM", "1")
     coll = Collective("gloo" if share_gpu else "nccl", local_rank)
 
+    t0 = time.perf_counter()
     scene = make_scene(p)                                   # synthetic, deterministic, identical on every rank
+    t_render = time.perf_counter() - t0
     ctx = api.Context(local_rank)
-    ctx.load_scene(scene)                                   # upload + device pyramid: inputs resident in HBM
+    # upload + device pyramid: inputs resident in HBM before any timed region starts.  Timed by itself (`staging`): images
+    # over PCIe from page-locked staging buffers, asynchronously (mi_dmrecon_set_view_async), RGBA pack + pyramid +
+    # footprint records on the device -- the PCIe-inclusive rate of a scene that is reconstructed once
+    t0 = time.perf_counter()
+    ctx.load_scene(scene, pinned_staging=True)
+    t_stage = time.perf_counter() - t0
+    host_bytes = int(sum(im.nbytes for im in scene.images))
     st = api.Settings(scale=cfg["scale"], nrReconNeighbors=cfg["local_neighbors"])
     all_views = list(range(p.n_views))
 
@@ -386,25 +493,33 @@ def main():
     def run_mode(mode):
         mine = rank_views(all_views, rank, world, mode)
         if not mine:                                        # more ranks than views: this rank only keeps the barriers
-            coll.barrier(); coll.barrier()
-            return coll.max(0.0), {}, {}, 0
-        el, acc, last = timed_region(coll, ctxs, st, mine * spc, n_calls, args.warmup)
+            els = []
+            for _ in range(max(1, args.repeats)):
+                coll.barrier(); coll.barrier()
+                els.append(coll.max(0.0))
+            return els, {}, {}, 0
+        el, acc, last = timed_region(coll, ctxs, st, mine * spc, n_calls, args.warmup, repeats=max(1, args.repeats))
         return el, acc, last, len(mine) * spc * n_calls
 
-    elapsed, acc, last, n_maps_rank = run_mode(args.scaling if world > 1 else "weak")
-    n_maps = int(round(coll.sum(n_maps_rank)))
+    elapsed_all, acc, last, n_maps_rank = run_mode(args.scaling if world > 1 else "weak")
+    n_rep = len(elapsed_all)
+    elapsed = float(np.median(elapsed_all))                 # the headline: the median region
+    elapsed_sum = float(np.sum(elapsed_all))                # the statistics are summed over all regions
+    n_maps = int(round(coll.sum(n_maps_rank)))              # depth maps of ONE region, all ranks
     strong = None
     if world > 1 and args.scaling == "weak":
-        s_el, _, _, s_rank = run_mode("strong")
+        s_all, _, _, s_rank = run_mode("strong")
+        s_el = float(np.median(s_all))
         s_maps = int(round(coll.sum(s_rank)))
         strong = {"value": s_maps / s_el, "unit": "depth-maps/s", "ms_per_step": 1000.0 * s_el / args.steps,
+                  "repeats": [s_maps / e for e in s_all],
                   "views_per_rank": [len(shard_views(all_views, r, world)) for r in range(world)],
                   "note": "BASELINE config 4: the %d reference views of ONE scene dealt round-robin over the %d ranks, "
                           "same steps / warm-up / call plan; depth maps of all ranks / slowest rank" % (p.n_views, world)}
 
     one_call = None
     if rank == 0 and world == 1 and not args.no_one_call:
-        one_call = run_one_call(ctx, st, all_views, scene, cfg)
+        one_call = run_one_call(ctx, st, all_views, scene, cfg, n_timed=max(1, args.one_call_n))
 
     if rank == 0:
         res = last["res"]
@@ -414,11 +529,13 @@ def main():
                     if (world == 1 or args.scaling == "weak") else
                     "ONE scene: its reference views are dealt round-robin over the ranks (shard_views), every rank holds the "
                     "whole scene resident, no collective")
-        roof = roofline(acc, n_maps_rank, scene, cfg, n_streams, spc, elapsed)
+        roof = roofline(acc, n_maps_rank * n_rep, scene, cfg, n_streams, spc, elapsed_sum)
         out = {
             "metric": "depth-maps/sec (1920x1080, 20 views, scale=2)" if args.config == "C3" else "depth-maps/sec (%s)" % args.config,
             "value": n_maps / elapsed, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            # every timed region of this process (each exactly `steps` steps between barriers); `value` is their median
+            "repeats": [n_maps / e for e in elapsed_all],
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-view %dx%d synthetic height-field scene, scale=%d (%dx%d depth maps), "
@@ -429,12 +546,18 @@ def main():
                        "host_threads_per_gpu": n_streams, "steps_per_call": spc,
                        # concurrent calls with equal settings are merged into one batch by the library
                        # (mi_dmrecon_reconstruct; MI_DMRECON_MERGE_CALLS=0 switches it off): how large the batches were
-                       "library_batches": int(n_calls - acc.get("merged_into_other_call", 0)),
-                       "views_per_library_batch": round(n_maps_rank / max(1, n_calls - acc.get("merged_into_other_call", 0)), 1),
+                       "library_batches": int(n_calls * n_rep - acc.get("merged_into_other_call", 0)),   # all regions
+                       "views_per_library_batch": round(n_maps_rank * n_rep / max(1, n_calls * n_rep - acc.get("merged_into_other_call", 0)), 1),
                        # (calls merged, batch ms, ms after the start of the timed region at which it returned), per batch
                        "library_batch_log": last.get("batches", [])[:16],
                        "mean_fill": round(fill, 4)},
             "roofline": roof,
+            # the scene's way into HBM, timed by itself before the timed regions (never part of `value`): host images ->
+            # page-locked staging -> PCIe -> RGBA pack, pyramid and footprint records on the device
+            "staging": {"seconds": t_stage, "host_image_bytes": host_bytes, "GB_per_s": host_bytes / t_stage / 1e9,
+                        "synthetic_render_seconds": t_render,
+                        # reconstructing the scene ONCE, staging included: n views / (staging + one pass over them)
+                        "pcie_inclusive_depth_maps_per_s": p.n_views / (t_stage + elapsed * p.n_views / max(n_maps, 1))},
         }
         if share_gpu:
             out["config"]["ranks_share_one_gpu"] = True
@@ -443,8 +566,15 @@ def main():
             out["one_call"] = one_call
         if strong is not None:
             out["strong_scaling"] = strong
+        if args.config == "C3":
+            pred = predicted_strong_scaling(p.n_views)
+            if pred is not None:
+                # (next to the measured sub-object when N > 1; at N = 1 the only thing there is to say about config 4)
+                out.setdefault("strong_scaling", {})["predicted_from_one_gpu"] = pred
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], parity = cpu_baseline(scene, cfg, gpu_maps=res[:p.n_views])
+            # the maps of the FIRST timed call (first region) and of the LAST one (last region) against the reference's
+            last_maps = last.get("res_last", res)
+            out["cpu_baseline"], parity = cpu_baseline(scene, cfg, gpu_maps=res[:p.n_views], gpu_maps_last=last_maps[:p.n_views])
             if parity is not None:
                 out["parity"] = parity
     coll.barrier()
