@@ -197,7 +197,7 @@ def map_parity_all(gpu, ref, against):
             "within_bounds": bool(ok)}
 
 
-def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1):
+def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1, n_keep=None):
     """W untimed warm-up calls per host thread, then `repeats` timed regions of exactly n_calls library calls of `refs`
     each, dealt over the host threads (one forked context / HIP stream each), every region bracketed by barrier +
     synchronise on both sides (a library call returns with its maps on the host: the stream is idle when it does);
@@ -210,7 +210,7 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1):
     n_streams = len(ctxs)
     outs = [c.alloc_outputs(st, refs, want_normal=False, pinned=True) for c in ctxs]   # reused, page-locked
     share = [n_calls // n_streams + (1 if i < n_calls % n_streams else 0) for i in range(n_streams)]
-    acc, last, t_calls = {}, {}, [0.0] * n_streams
+    acc, last, t_calls, done_at = {}, {}, [0.0] * n_streams, [0.0] * n_streams
     t_go = [0.0]
     lock = threading.Lock()
     warmed = threading.Barrier(n_streams + 1)
@@ -229,10 +229,10 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1):
                 r = c.reconstruct(st, refs, want_normal=False, out=o)   # synchronous: returns with the maps on the host
                 with lock:
                     if "res" not in last:
-                        last["res"] = [(m["depth"].copy(), m["conf"].copy()) for m in r]
+                        # (the first n_keep maps of the first timed call: a few milliseconds inside the FIRST region only)
+                        last["res"] = [(m["depth"].copy(), m["conf"].copy()) for m in r[:n_keep]]
                         last["shape"] = r[0]["depth"].shape
-                    if rep == repeats - 1:
-                        last["res_last"] = [(m["depth"].copy(), m["conf"].copy()) for m in r]   # (the last one to finish stays)
+                    done_at[i] = time.perf_counter()
                     for k, v in c.last_stats.items():
                         acc[k] = acc.get(k, 0) + v
                     # how the library batched the timed calls: (calls merged into the batch this call ran, its host clock)
@@ -256,6 +256,9 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1):
         elapsed.append(coll.max(time.perf_counter() - t0))
     for t in threads:
         t.join()
+    # the maps of the LAST timed call: still in the output buffers of the host thread that finished last
+    i_last = int(np.argmax(done_at))
+    last["res_last"] = [(m["depth"].copy(), m["conf"].copy()) for m in outs[i_last][:n_keep]]
     batches = acc.pop("_batches", [])
     last["batches"] = sorted(b for b in batches if b[0] > 0)      # first region: (calls in the batch, ms of the batch, ms since the start when it returned)
     return elapsed, acc, last
@@ -498,7 +501,7 @@ def main():
                 coll.barrier(); coll.barrier()
                 els.append(coll.max(0.0))
             return els, {}, {}, 0
-        el, acc, last = timed_region(coll, ctxs, st, mine * spc, n_calls, args.warmup, repeats=max(1, args.repeats))
+        el, acc, last = timed_region(coll, ctxs, st, mine * spc, n_calls, args.warmup, repeats=max(1, args.repeats), n_keep=len(mine))
         return el, acc, last, len(mine) * spc * n_calls
 
     elapsed_all, acc, last, n_maps_rank = run_mode(args.scaling if world > 1 else "weak")

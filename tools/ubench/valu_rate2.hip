@@ -103,8 +103,8 @@ double run(int waves_per_simd, int iters, float* d) {
     return ms;
 }
 
-#define RUN(M, NAME) { double ms = run<M>(w, iters, d); double r = 8.0 * iters * w / (ms * 1e-3); \
-    printf("waves/SIMD=%d %-34s %8.3f ms  %6.2f cycles per wave-instruction at 2.4 GHz\n", w, NAME, ms, 2.4e9 / r); }
+#define RUN(M, NAME) { printf("[%s]\n", NAME); fflush(stdout); double ms = run<M>(w, iters, d); double r = 8.0 * iters * w / (ms * 1e-3); \
+    printf("waves/SIMD=%d %-34s %8.3f ms  %6.2f cycles per wave-instruction at 2.4 GHz\n", w, NAME, ms, 2.4e9 / r); fflush(stdout); }
 
 int main() {
     float* d; hipMalloc(&d, 256 * 4 * 8 * 64 * 4);
