@@ -2091,20 +2091,33 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                 const PatchResult fin = g_fr[tid][Qw.fin].r;
                 const int qx = Qw.xy & 0xFFFF, qy = Qw.xy >> 16, q = qy * W + qx;
                 DevEntry we; we.job = jobi; we.xy = Qw.xy;
-                ow[en] = we;
                 DevResult o;
                 o.conf = fin.conf; o.depth = fin.depth; o.dzI = fin.dzI; o.dzJ = fin.dzJ;
                 o.nx = fin.nx; o.ny = fin.ny; o.nz = fin.nz; o.views = fin.views; o.views_hi = fin.views_hi; o.iters = fin.iters;
                 o.accepted = 1; o.tried = Qw.done;
-                ors[en] = o;
                 const bool one = ((Qw.info >> 11) & 1u) != 0;                       /* slot holding the old state */
                 float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
                 float* cq = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
                 uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
-                dp[q] = fin.depth; zp[2 * q] = fin.dzI; zp[2 * q + 1] = fin.dzJ;
-                np[3 * q] = fin.nx; np[3 * q + 1] = fin.ny; np[3 * q + 2] = fin.nz;
-                cq[q] = fin.conf; vp[q] = fin.views; up[q] = round;
-                if (NV == 8) (one ? job->views_hi : job->views1_hi)[q] = fin.views_hi;
+                /* TEAM: every member writes every word, and reads back only what it wrote itself -- through ITS XCD's L2.
+                 * The words must go THROUGH that L2 (agent scope), not stay in it: a dirty line that lingers there is
+                 * written back whenever the cache sees fit, and if that is after another member (one pass ahead, on another
+                 * XCD) has written the pixel's NEXT value and lost its own copy of the line, that member fetches the old
+                 * value back from memory (seen once: one pixel of one view, with a second process thrashing the caches). */
+                auto put = [&](void* dst, unsigned v) {
+                    if (TEAM) __hip_atomic_store((unsigned*)dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *(unsigned*)dst = v;
+                };
+                put(&ow[en].job, (unsigned)we.job); put(&ow[en].xy, (unsigned)we.xy);
+                {
+                    const unsigned* src = (const unsigned*)&o; unsigned* dst = (unsigned*)&ors[en];
+#pragma unroll
+                    for (int k = 0; k < (int)(sizeof(DevResult) / 4); ++k) put(dst + k, src[k]);
+                }
+                put(dp + q, __float_as_uint(fin.depth)); put(zp + 2 * q, __float_as_uint(fin.dzI)); put(zp + 2 * q + 1, __float_as_uint(fin.dzJ));
+                put(np + 3 * q, __float_as_uint(fin.nx)); put(np + 3 * q + 1, __float_as_uint(fin.ny)); put(np + 3 * q + 2, __float_as_uint(fin.nz));
+                put(cq + q, __float_as_uint(fin.conf)); put(vp + q, fin.views); put(up + q, (unsigned)round);
+                if (NV == 8) put((one ? job->views_hi : job->views1_hi) + q, fin.views_hi);
                 if (Qw.own <= 0.f) atomicAdd(&g_fcnt[5], 1u);
             }
             __syncthreads();

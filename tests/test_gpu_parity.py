@@ -268,12 +268,12 @@ def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, m
     gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
 
 
-@pytest.mark.parametrize("fault", ["3", "0:7", "5:40"])
+@pytest.mark.parametrize("fault", ["3", "0:7", "5:3"])
 def test_front_team_gives_up_and_the_views_finish(gpu_ctx, g1_scene, h1_scene, monkeypatch, fault):
     """A front team needs all its workgroups on the GPU at once; what else holds compute units (another process, another
     program) the library cannot see.  A member that is not there in time must not fail the call: the team gives up, and
     the views go on from the round they stopped in with one workgroup each -- same maps as without teams, bit for bit.
-    The test hook makes one member of every team vanish: never there ("3"), or after 7 / 40 rounds of its view."""
+    The test hook makes one member of every team vanish: never there ("3"), or after 7 / 3 rounds of its view."""
     monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", "1000000000")           # the whole propagation in the front kernel
     monkeypatch.setenv("MI_DMRECON_FRONT", "1000000")
     monkeypatch.setenv("MI_DMRECON_TEAM_WAIT_US", "3000")
@@ -346,7 +346,7 @@ def test_maps_do_not_depend_on_the_batch(gpu_ctx, g1_scene, h1_scene, monkeypatc
         ref = gpu_ctx.reconstruct(st, refs, want_views=True)
         s_all = dict(gpu_ctx.last_stats)
         if handover:
-            assert s_all["n_latency_rounds"] >= 2 and s_all["n_bulk_launches"] >= s_all["n_latency_rounds"] + 3, s_all   # both layouts ran
+            assert s_all["n_latency_rounds"] >= 1 and s_all["n_bulk_launches"] >= s_all["n_latency_rounds"] + 3, s_all   # both layouts ran
         # one view per call; sub-batches; another order
         for v in refs[:3]:
             one = gpu_ctx.reconstruct(st, [v], want_views=True)[0]

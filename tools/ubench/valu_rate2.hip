@@ -113,7 +113,7 @@ int main() {
         RUN(0, "v_fma_f32") RUN(1, "v_pk_fma_f32") RUN(15, "v_pk_mul_f32") RUN(2, "v_rcp_f32") RUN(3, "v_mad_i64_i32")
         RUN(4, "v_lshlrev_b32_sdwa (byte select)") RUN(5, "v_floor_f32") RUN(13, "v_fract_f32") RUN(6, "v_cvt_i32_f32")
         RUN(7, "v_mad_u32_u24") RUN(8, "v_lshl_add_u64") RUN(9, "v_add_f32_dpp quad_perm") RUN(16, "v_mov_b32_dpp row_shr:1")
-        RUN(10, "v_med3_f32") RUN(14, "v_add_f64") RUN(12, "v_cmp_lt_f32 + s_and_b64")
+        RUN(10, "v_med3_f32") RUN(14, "v_add_f64")
         RUN(11, "ds_read_b32 x8 + wait (1 KB table)")
     }
     return 0;
