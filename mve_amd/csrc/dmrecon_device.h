@@ -31,7 +31,7 @@
  *   Same maps as one `tail` launch per round.
  *   team > 1: that many workgroups per view (k_front<TEAM>): the attempts of a round are dealt out over them, every
  *   member runs the whole round otherwise (same numbering, same state writes) and fetches the others' results from the
- *   view's mailbox: mail = MI_FRONT_MAIL_WORDS 8-byte words per view, team_flags = MI_FRONT_TEAM_MAX words per view,
+ *   view's mailbox: mail = MI_FRONT_MAIL_WORDS 8-byte words per view, team_flags = MI_FRONT_FLAG_STRIDE words per view,
  *   zeroed by the caller; team_filled = one word per view, zeroed.  The members wait for each other at every pass, at
  *   most spin_ticks (100 MHz ticks): if one does not show up (all n_jobs * team workgroups must be resident at once; the
  *   caller keeps it <= the CUs, but cannot know what else holds them) the team GIVES UP -- error_flags bit 5 (32) is set
@@ -41,6 +41,7 @@
  */
 #define MI_FRONT_DONE_HOST 0xFFFFFFFF00000000ull
 #define MI_FRONT_TEAM_MAX 32
+#define MI_FRONT_FLAG_STRIDE 40     /* team_flags words per view: MI_FRONT_TEAM_MAX pass flags, the XCC registration word, "several XCDs" */
 #define MI_FRONT_MAIL_WORDS (2 * 1024 * 12)
 struct MiDeviceApi {
     int filter_width;
@@ -64,7 +65,9 @@ struct MiDeviceApi {
                   const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
                   DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags,
                   const unsigned long long* job_start, unsigned long long* job_resume, unsigned* team_filled, unsigned spin_ticks,
-                  int fault /* test hook: member | round << 8 of the team member that vanishes, -1 = none */);
+                  int fault /* test hook: member | round << 8 of the team member that vanishes (member 255: none), bit 24: the
+                             * team writes through its L2s as if found on several XCDs; -1 = none */,
+                  int n_xcd /* teams: XCDs of the device; a view's team is confined to the blocks of one (b % n_xcd) */);
 };
 const MiDeviceApi* mi_device_api(int filter_width);
 extern unsigned long long* mi_debug_tbuf;

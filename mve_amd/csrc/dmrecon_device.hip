@@ -1786,6 +1786,9 @@ struct FrontArgs {
     unsigned* team_filled;        /* [n_jobs], zeroed before the launch: pixels newly filled by the view's team (atomicMax of each
                                    * member's own running count: they all count the same), added to the job by k_front_commit */
     unsigned spin_ticks;          /* a member waits this long (100 MHz ticks) for the others at an exchange, then the team gives up */
+    int n_jobs;                   /* TEAM: views of the launch (the grid is padded to whole XCD rows) */
+    int n_xcd;                    /* TEAM: XCDs the blocks are dealt over (block b runs on XCD b % n_xcd: observed, not promised -- checked) */
+    int force_write_through;      /* test hook (MI_DMRECON_DEBUG_TEAM_WT): as if a team's members had been found on different XCDs */
     int fault_member, fault_round; /* test hook (MI_DMRECON_DEBUG_FRONT_FAULT): this member of every team vanishes at that round of its
                                     * view (0 = it never shows up), as one that is not given a compute unit would; -1 = none */
 };
@@ -1843,7 +1846,15 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
     const OptArgs& a = t.o;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int T = TEAM ? t.team : 1;
-    const int jobi = TEAM ? (int)blockIdx.x / T : (int)blockIdx.x, member = TEAM ? (int)blockIdx.x % T : 0;
+    /* TEAM: the members of a view's team are blocks with the same b % n_xcd -- in practice the same XCD, i.e. ONE L2: what
+     * the members write (all of them every word, plain stores) and read back then lives in one coherent cache.  Placement is
+     * not promised: every member registers its XCC id, and a team found on several XCDs writes through instead (below). */
+    int jobi = (int)blockIdx.x, member = 0;
+    if (TEAM) {
+        const int xcd = (int)blockIdx.x % t.n_xcd, slot = (int)blockIdx.x / t.n_xcd;
+        jobi = (slot / T) * t.n_xcd + xcd; member = slot % T;
+        if (jobi >= t.n_jobs) return;
+    }
     const DevJob* job = a.jobs + jobi;
     unsigned n_prev; int cur, round;
     if (t.job_start) {
@@ -1855,8 +1866,15 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
         if (tid == 0) atomicMax(t.job_resume + jobi, MI_FRONT_DONE);
         return;
     }
-    gflag_t fl = TEAM ? (gflag_t)(t.team_flags + (size_t)jobi * MI_FRONT_TEAM_MAX) : nullptr;
+    gflag_t fl = TEAM ? (gflag_t)(t.team_flags + (size_t)jobi * MI_FRONT_FLAG_STRIDE) : nullptr;
+    bool write_through = false;                    /* TEAM: set after the first exchange (uniform over the team) */
     if (TEAM) {
+        if (tid == 0) {
+            /* my XCC id into the team's registration word; a second id there marks the team as spread over several XCDs */
+            const unsigned me = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) + 1u;     /* HW_REG_XCC_ID, bits 0..3 */
+            const unsigned old = atomicCAS(t.team_flags + (size_t)jobi * MI_FRONT_FLAG_STRIDE + MI_FRONT_TEAM_MAX, 0u, me);
+            if ((old != 0u && old != me) || t.force_write_through) atomicExch(t.team_flags + (size_t)jobi * MI_FRONT_FLAG_STRIDE + MI_FRONT_TEAM_MAX + 1, 1u);
+        }
         /* a member that only starts when the others have given up (it found no compute unit in time) leaves at once */
         unsigned f = tid < T ? __hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (__syncthreads_or((f & MI_FLAG_GAVE_UP) != 0)) {
@@ -2041,6 +2059,9 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                             __hip_atomic_store(fl + member, MI_FLAG_EPOCH | (gave_up ? MI_FLAG_GAVE_UP : MI_FLAG_ENDED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         abort = true; break;
                     }
+                    /* everybody has registered by now (a member registers before its first flag) */
+                    if (epoch == 1u)
+                        write_through = __hip_atomic_load(fl + MI_FRONT_TEAM_MAX + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
                     for (unsigned u = (unsigned)tid; u < natt * MI_FRONT_GRAN; u += MI_FRONT_WAVES * WAVE) {
                         const unsigned idx = u / MI_FRONT_GRAN, k = u - idx * MI_FRONT_GRAN;
                         if ((int)(idx % (unsigned)T) == member) continue;
@@ -2099,13 +2120,15 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                 float* dp = one ? job->depth : job->depth1; float* zp = one ? job->dz : job->dz1;
                 float* cq = one ? job->conf : job->conf1; float* np = one ? job->normal : job->normal1;
                 uint32_t* vp = one ? job->views : job->views1; int32_t* up = one ? job->upd : job->upd1;
-                /* TEAM: every member writes every word, and reads back only what it wrote itself -- through ITS XCD's L2.
-                 * The words must go THROUGH that L2 (agent scope), not stay in it: a dirty line that lingers there is
-                 * written back whenever the cache sees fit, and if that is after another member (one pass ahead, on another
-                 * XCD) has written the pixel's NEXT value and lost its own copy of the line, that member fetches the old
-                 * value back from memory (seen once: one pixel of one view, with a second process thrashing the caches). */
+                /* TEAM: every member writes every word, and reads back only what it wrote itself -- through its XCD's L2.
+                 * With the whole team on ONE XCD that is one coherent copy.  Members on DIFFERENT XCDs each keep a dirty copy
+                 * of the line in their own L2, written back whenever that cache sees fit -- and if that is after another
+                 * member (one pass ahead) has written the pixel's NEXT value and lost its own copy of the line, that member
+                 * fetches the old value back from memory (seen once, before teams were kept on one XCD: one pixel of one
+                 * view, with a second process thrashing the caches).  Such a team writes THROUGH its L2s (agent scope: the
+                 * line is dropped, the read-back comes from memory: ~9 us per round slower, so only then). */
                 auto put = [&](void* dst, unsigned v) {
-                    if (TEAM) __hip_atomic_store((unsigned*)dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (TEAM && write_through) __hip_atomic_store((unsigned*)dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else *(unsigned*)dst = v;
                 };
                 put(&ow[en].job, (unsigned)we.job); put(&ow[en].xy, (unsigned)we.xy);
@@ -2629,7 +2652,7 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
                          const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
                          DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags,
                          const unsigned long long* job_start, unsigned long long* job_resume, unsigned* team_filled, unsigned spin_ticks,
-                         int fault) {
+                         int fault, int n_xcd) {
     static_assert(MI_FRONT_MAIL_WORDS == 2 * MI_FRONT_QCAP * 4 * MI_FRONT_GRAN, "mailbox size");
     if (n_jobs <= 0) return;
     if (!job_start) {
@@ -2647,11 +2670,16 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
     t.job_off = job_off; t.job_count = job_count; t.job_start = job_start; t.job_resume = job_resume;
     t.job_stats = job_stats; t.max_rounds = max_rounds;
     t.team = 1; t.mail = nullptr; t.team_flags = nullptr; t.team_filled = team_filled; t.spin_ticks = spin_ticks;
-    t.fault_member = fault < 0 ? -1 : (fault & 0xFF); t.fault_round = fault < 0 ? 0 : (fault >> 8);
+    t.fault_member = fault < 0 ? -1 : (fault & 0xFF); t.fault_round = fault < 0 ? 0 : ((fault >> 8) & 0xFFFF);
+    t.force_write_through = fault >= 0 && (fault >> 24) != 0;
+    if (fault >= 0 && (fault & 0xFF) == 0xFF) t.fault_member = -1;          /* (write-through forced, nobody vanishes) */
+    t.n_jobs = n_jobs; t.n_xcd = n_xcd < 1 ? 1 : n_xcd;
     if (team > 1 && mail && team_flags && team_filled) {
         t.team = team > MI_FRONT_TEAM_MAX ? MI_FRONT_TEAM_MAX : team; t.mail = mail; t.team_flags = team_flags;
-        if (st.K > 4) hipLaunchKernelGGL((k_front<8, true>), dim3((unsigned)(n_jobs * t.team)), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
-        else hipLaunchKernelGGL((k_front<4, true>), dim3((unsigned)(n_jobs * t.team)), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
+        /* whole rows of n_xcd blocks: view j's team = the blocks b with b % n_xcd == j % n_xcd of its rows */
+        const unsigned grid = (unsigned)(t.n_xcd * ((n_jobs + t.n_xcd - 1) / t.n_xcd) * t.team);
+        if (st.K > 4) hipLaunchKernelGGL((k_front<8, true>), dim3(grid), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
+        else hipLaunchKernelGGL((k_front<4, true>), dim3(grid), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
         hipLaunchKernelGGL(k_front_commit, dim3((unsigned)(n_jobs + 255) / 256), dim3(256), 0, s, jobs, team_filled, counters, n_jobs);
     }
     else if (st.K > 4) hipLaunchKernelGGL((k_front<8, false>), dim3((unsigned)n_jobs), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);

@@ -1565,7 +1565,9 @@ int BatchRun::tail_rounds(bool& to_front) {
 void BatchRun::plan_front_team() {
     const char* e = std::getenv("MI_DMRECON_FRONT_TEAM");
     int want = e ? std::atoi(e) : (active_call->count() <= 1 ? MI_FRONT_TEAM_MAX : 1);
-    want = std::min(std::min(want, (int)MI_FRONT_TEAM_MAX), c->n_cus / std::max(nj, 1));
+    /* a view's team lives on ONE XCD (one L2: k_front): the views are dealt over the XCDs, the CUs of an XCD over its views */
+    const int n_xcd = std::max(1, c->n_cus / 32), per_xcd = (std::max(nj, 1) + n_xcd - 1) / n_xcd;
+    want = std::min(std::min(want, (int)MI_FRONT_TEAM_MAX), (c->n_cus / n_xcd) / per_xcd);
     front_team = std::max(1, want);
 }
 
@@ -1605,10 +1607,14 @@ int BatchRun::front_rounds() {
     const unsigned spin_ticks = [] { const char* e = std::getenv("MI_DMRECON_TEAM_WAIT_US"); return 100u * (e ? (unsigned)std::max(1, std::atoi(e)) : MI_TEAM_WAIT_US); }();
     /* test hook, MI_DMRECON_DEBUG_FRONT_FAULT=<member>[:<round>]: that member of every team vanishes at that round of its view */
     const int fault = [] {
-        const char* e = std::getenv("MI_DMRECON_DEBUG_FRONT_FAULT");
-        if (!e || !*e) return -1;
-        const char* colon = std::strchr(e, ':');
-        return (std::atoi(e) & 0xFF) | ((colon ? std::max(0, std::atoi(colon + 1)) : 0) << 8);
+        int f = -1;
+        if (const char* e = std::getenv("MI_DMRECON_DEBUG_FRONT_FAULT")) if (*e) {
+            const char* colon = std::strchr(e, ':');
+            f = (std::atoi(e) & 0xFF) | ((colon ? std::max(0, std::atoi(colon + 1)) & 0xFFFF : 0) << 8);
+        }
+        /* test hook, MI_DMRECON_DEBUG_TEAM_WT=1: the teams behave as if their members had been found on several XCDs */
+        if (const char* e = std::getenv("MI_DMRECON_DEBUG_TEAM_WT")) if (std::atoi(e) != 0) f = (f < 0 ? 0xFF : f) | (1 << 24);
+        return f;
     }();
     std::unique_ptr<TeamToken> token;
     if (front_team > 1) {
@@ -1616,10 +1622,10 @@ int BatchRun::front_rounds() {
         if (!token->held()) { token.reset(); front_team = 1; }     /* another call (process) runs its teams: none for this one */
     }
     if (front_team > 1) {
-        if (c->bs.d_front_mail.reserve((size_t)nj * MI_FRONT_MAIL_WORDS) || c->bs.d_front_flags.reserve((size_t)nj * MI_FRONT_TEAM_MAX))
+        if (c->bs.d_front_mail.reserve((size_t)nj * MI_FRONT_MAIL_WORDS) || c->bs.d_front_flags.reserve((size_t)nj * MI_FRONT_FLAG_STRIDE))
             return fail(MI_DMRECON_EDEVICE, "hipMalloc(front mailboxes) failed");
         HIP_TRY(hipMemsetAsync(c->bs.d_front_mail.p, 0, (size_t)nj * MI_FRONT_MAIL_WORDS * sizeof(unsigned long long), S));
-        HIP_TRY(hipMemsetAsync(c->bs.d_front_flags.p, 0, (size_t)nj * MI_FRONT_TEAM_MAX * sizeof(unsigned), S));
+        HIP_TRY(hipMemsetAsync(c->bs.d_front_flags.p, 0, (size_t)nj * MI_FRONT_FLAG_STRIDE * sizeof(unsigned), S));
     }
     front_stats.assign(4 * (size_t)nj, 0u);
     TailPoll& P = c->bs.h_poll[0];
@@ -1634,7 +1640,8 @@ int BatchRun::front_rounds() {
                  wnext, rnext, wcur, rcur, d_off, d_cnt, d_stats, round, max_round, c->d_counters,
                  again ? 1 : front_team, (!again && front_team > 1) ? c->bs.d_front_mail.p : nullptr,
                  (!again && front_team > 1) ? c->bs.d_front_flags.p : nullptr,
-                 again ? d_resume : nullptr, again ? d_resume + nj : d_resume, d_filled, spin_ticks, again ? -1 : fault);
+                 again ? d_resume : nullptr, again ? d_resume + nj : d_resume, d_filled, spin_ticks, again ? -1 : fault,
+                 std::max(1, c->n_cus / 32));
         ev.end(S);
         ++n_launch;
         HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
