@@ -91,7 +91,8 @@ class CStats(ctypes.Structure):
                 ("n_front_views", ctypes.c_int64), ("n_front_rounds_max", ctypes.c_int64),
                 ("n_front_rounds_sum", ctypes.c_int64), ("n_front_attempts", ctypes.c_int64),
                 ("n_front_entries", ctypes.c_int64), ("front_team", ctypes.c_int64),
-                ("front_fallbacks", ctypes.c_int64), ("n_latency_rounds", ctypes.c_int64)]
+                ("front_fallbacks", ctypes.c_int64), ("n_latency_rounds", ctypes.c_int64),
+                ("n_patch_turns", ctypes.c_int64), ("n_wave_turns", ctypes.c_int64)]
 
 
 _lib = None

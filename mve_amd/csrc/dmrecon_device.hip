@@ -380,6 +380,10 @@ template <> struct LatLay<8> { typedef Lay<8, 8> type; };
 
 /* ------------------------------------------------------------------------- */
 
+#ifdef MI_ACTIVITY
+__shared__ unsigned g_act[2];
+#endif
+
 struct PatchState {
     /* uniform over the lanes of a patch */
     const DevJob* job;
@@ -598,16 +602,20 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             const float u1 = (sx + l2 * vx) * iz1 - 0.5f, v1 = (sy + l2 * vy) * iz1 - 0.5f;
             q.gu = (u1 - u) * dnorm; q.gv = (v1 - v) * dnorm;
         }
-        /* memory-safe even when the sample is outside (result discarded through ok) */
-        /* (fmaxf/fminf return the non-NaN operand, so a NaN coordinate clamps to 0 as well) */
-        const float uc = fminf(fmaxf(u, 0.f), wlim - 0.5f), vc = fminf(fmaxf(v, 0.f), hlim - 0.5f);
-        const float fl = floorf(uc), ft = floorf(vc);
-        const int left = (int)fl, top = (int)ft;
-        q.fx = uc - fl; q.fy = vc - ft;
+        /* memory-safe even when the sample is outside (result discarded through ok): clamped into the image -- the footprint
+         * records are edge-clamped themselves, so the last row / column is a valid record.  A sample that passes the
+         * interior test is not moved by the clamp (v_med3_f32: a NaN coordinate comes out as 0). */
+        const float uc = __builtin_amdgcn_fmed3f(u, 0.f, wlim), vc = __builtin_amdgcn_fmed3f(v, 0.f, hlim);
+        /* the bilinear weights: x - floor(x) in one instruction (v_fract_f32: the same value as the subtraction, which is
+         * exact); the texel indices by truncation (the coordinates are not negative) */
+        q.fx = __builtin_amdgcn_fractf(uc); q.fy = __builtin_amdgcn_fractf(vc);
         /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
          * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
-         * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1. */
-        q.t = *(gtex4_t)(nv.img + 4 * ((size_t)top * nv.w + left));
+         * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1.
+         * The record index top * w + left as a 24-bit multiply-add in 32 bits (rows and widths are below 2^24, a level
+         * below 2^32 texels) instead of a 64-bit multiply-add (6.3 issue cycles against 5.6, and no sign extension). */
+        const unsigned rec = __umul24((unsigned)vc, (unsigned)nv.w) + (unsigned)uc;
+        q.t = *(gtex4_t)(nv.img + 4 * (size_t)rec);
         return q;
     };
     auto consume = [&](const Pre& q) {
@@ -1341,8 +1349,20 @@ __device__ __forceinline__ bool optimize_patch(const DevJob* job, const DevSetti
                                PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err, DevCounters* counters) {
     Run R;
     TSTAMP(10);
-    if (run_begin<L>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters))
+    if (run_begin<L>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters)) {
+#ifdef MI_ACTIVITY
+        /* development build (make variant VFLAGS=-DMI_ACTIVITY): how many of a wavefront's patches are still at work in a
+         * turn -- [0] patch-turns, [1] wavefront-turns (k_optimize flushes them into n_stage / n_gather_pass) */
+        bool more;
+        do {
+            if (L::vslot(lane) == 0 && L::sub(lane) == 0) atomicAdd(&g_act[0], 1u);
+            if (lane == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_act[1], 1u);
+            more = run_turn<L, FAST>(R, st, views, lane);
+        } while (more);
+#else
         while (run_turn<L, FAST>(R, st, views, lane)) { }
+#endif
+    }
     TSTAMP(40);
     if (FAST && R.bail) { n_pass += R.ps.n_pass; return false; }
     run_end<L>(R, st, lane, res, n_eval, n_pass);
@@ -1494,6 +1514,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
     const unsigned n = a.follow_in ? *a.follow_in_n : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
     if (n < a.min_work || n >= a.max_work) return;
     for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
+#ifdef MI_ACTIVITY
+    if (lane < 2) g_act[lane] = 0;
+#endif
     __syncthreads();
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
     for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < n; i += gridDim.x * L::PATCHES) {
@@ -1520,6 +1543,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
         }
     }
     flush_counters<L>(a.counters, lane, n_eval, n_pass, n_patch, 0u, err);
+#ifdef MI_ACTIVITY
+    __syncthreads();
+    if (lane == 0 && !L::LAT) { atomicAdd(&a.counters->n_stage, (unsigned long long)g_act[0]); atomicAdd(&a.counters->n_gather_pass, (unsigned long long)g_act[1] * L::PATCHES); }
+#endif
 }
 
 /*
@@ -1897,8 +1924,12 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
         /* a footprint exception (patch_sampler.cc:78-82) or the host's cancel ends the view: one lane looks, all agree
          * (the members of a team see the flag at different times: they tell each other at the next exchange) */
         if (TEAM && member == t.fault_member && (int)st_rounds >= t.fault_round) return;
-        if (tid == 0) g_fcnt[6] = (unsigned)__hip_atomic_load((gi32_t)&job->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
+        /* (looked at every eighth round: an agent-scope load the whole workgroup waits for costs a microsecond of a round
+         * that lasts twenty; a cancelled view goes on for 0.2 ms more) */
+        if ((st_rounds & 7u) == 0u) {
+            if (tid == 0) g_fcnt[6] = (unsigned)__hip_atomic_load((gi32_t)&job->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
         if (!TEAM && g_fcnt[6] != 0) break;
         const DevEntry* pw = t.work[cur] + off; const DevResult* prs = t.results[cur] + off;
         DevEntry* ow = t.work[cur ^ 1] + off; DevResult* ors = t.results[cur ^ 1] + off;

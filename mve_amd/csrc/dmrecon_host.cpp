@@ -1383,71 +1383,122 @@ int BatchRun::bulk_rounds(bool& to_tail) {
     const unsigned ONE_LAUNCH_MAX = [] { const char* e = std::getenv("MI_DMRECON_ONE_LAUNCH"); return e ? (unsigned)std::max(0L, std::atol(e)) : MI_ONE_LAUNCH_MAX; }();
     const int max_rounds = MI_MAX_ROUNDS - 2 * (int)MI_TAIL_CHUNK - 2;
     unsigned* d_vcount = c->bs.d_view.p; unsigned* d_vmode = d_vcount + 3 * (size_t)nj;
-    for (; round < max_rounds && n_alive > 0; ++round) {
+    const unsigned ppw = patches_per_wave(st);
+    /* The rounds are enqueued WITHOUT waiting for their list sizes: every kernel of a round reads its size on the device
+     * (k_generate also decides there which layout a view's entries go to), the grids come from the sizes of the last round
+     * the host has seen (doubled: a list grows at most ~4x per round in the first rounds, and a grid that is too small
+     * only makes its wavefronts stride), and the sizes are read back one round behind -- the host looks at round r - 1
+     * while round r runs.  What it decides from them (when to stop, when every view has handed over) may come a round
+     * late: the rounds enqueued meanwhile are proper rounds of the same propagation (after the end: empty ones). */
+    unsigned known_thr = (unsigned)std::max<size_t>(seeds.size(), 1) * 4u, known_lat = 0;
+    struct Pending { int round; size_t ev_thr, ev_lat; };
+    Pending pend[2]; int n_pend = 0;
+    bool stop = false;
+    auto enqueue = [&](int r) -> int {
         ev.begin(S, EventLog::SWEEP, 0);
         D->generate(S, c->bs.d_jobs.p, nj, max_tiles, c->bs.d_work.p, c->bs.d_work2.p, c->bs.d_round_work_t.p, c->bs.d_round_work.p,
-                    d_vcount, d_vmode, handover, round);
+                    d_vcount, d_vmode, handover, r);
         ev.end(S);
-        TailPoll& P = c->bs.h_poll[0];
-        HIP_TRY(hipMemcpyAsync(&P.rw[0], c->bs.d_round_work_t.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
-        HIP_TRY(hipMemcpyAsync(&P.rw[1], c->bs.d_round_work.p + round, sizeof(unsigned), hipMemcpyDeviceToHost, S));
-        HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
-        HIP_TRY(read_dyn(0));
-        HIP_TRY(hipStreamSynchronize(S));
-        const unsigned n_thr = P.rw[0], n_lat = P.rw[1];
-        hc = P.hc;
-        if (int rc = poll_views(dyn_of(0), n_thr + n_lat)) return rc;
-        if (n_thr + n_lat == 0) { done = true; return 0; }
-        if (n_alive == 0) return 0;
-        if (n_thr) {
-            ev.begin(S, EventLog::BULK, n_thr);
+        const unsigned* n_thr_p = c->bs.d_round_work_t.p + r; const unsigned* n_lat_p = c->bs.d_round_work.p + r;
+        const unsigned est = std::max(2u * known_thr, 65536u);
+        const unsigned waves = (est + ppw - 1) / ppw;
+        /* a view can be in the latency layout from round 2 on (from round 1 if told so): which rounds have such entries is
+         * decided on the device -- the launches for them are part of every round (empty ones cost microseconds) */
+        const bool any_lat = r >= 2 || handover >= 1000000000u;
+        ev.begin(S, EventLog::BULK, 0);                              /* (entries: filled in at the read-back) */
+        const size_t ev_thr = ev.items.size() - 1;
+        size_t ev_lat = (size_t)-1;
+        unsigned* fcnt = c->bs.d_follow_cnt.p + 4 * (size_t)r;
+        /* Rounds below MI_ONE_LAUNCH_MAX entries run as ONE launch of the general kernel, all attempts of an entry in a
+         * row: such a launch fits the GPU at once, so either launch of the two-launch form lasts one wavefront-life
+         * (1 attempt, then up to 3 more) whatever its size -- measured: lone 20-view call 533 -> 548 depth-maps/s, a
+         * lone 3-view call 19.4 -> 17.8 ms, the bench's plan unchanged (thresholds 50 000 / 200 000 / always: 542 /
+         * 546 / 540).  Same arithmetic either way (tests: the maps do not depend on the form); chosen from the last
+         * size the host has seen. */
+        if (known_thr < ONE_LAUNCH_MAX)
+            D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
+                        0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr);
+        else {
             /* one optimisation attempt per entry and launch; the entries whose pixel has further candidate hypotheses
              * (about one in five) continue in a follow-up launch over a compacted list (its size stays on the device),
              * so that the wavefronts of both launches are full; the follow-up launch runs all remaining attempts of its
              * entries back to back (third and fourth attempts are rare) */
-            const unsigned ppw = patches_per_wave(st);
-            const unsigned waves = (n_thr + ppw - 1) / ppw;
-            unsigned* fcnt = c->bs.d_follow_cnt.p + 4 * (size_t)round;
-            /* Rounds below MI_ONE_LAUNCH_MAX entries run as ONE launch of the general kernel, all attempts of an entry in a
-             * row: such a launch fits the GPU at once, so either launch of the two-launch form lasts one wavefront-life
-             * (1 attempt, then up to 3 more) whatever its size -- measured: lone 20-view call 533 -> 548 depth-maps/s, a
-             * lone 3-view call 19.4 -> 17.8 ms, the bench's plan unchanged (thresholds 50 000 / 200 000 / always: 542 /
-             * 546 / 540).  Same arithmetic either way (tests: the maps do not depend on the form). */
-            if (n_thr < ONE_LAUNCH_MAX)
-                D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, nullptr,
-                            n_thr, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
-            else {
-                D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, nullptr,
-                            n_thr, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, c->bs.d_follow.p, fcnt);
-                D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                            c->bs.d_results.p, nullptr, n_thr, 0u, 0xFFFFFFFFu, round, c->d_counters, c->bs.d_follow.p, fcnt, nullptr, nullptr);
-                ++n_launch;
-            }
+            D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
+                        0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, c->bs.d_follow.p, fcnt);
+            D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
+                        c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, c->bs.d_follow.p, fcnt, nullptr, nullptr);
+            ++n_launch;
+        }
+        ev.end(S);
+        ++n_launch;
+        if (any_lat) {
+            /* the views that have handed over: one wavefront per patch, an entry's attempts one after the other */
+            ev.begin(S, EventLog::BULK, 0);
+            ev_lat = ev.items.size() - 1;
+            D->optimize(S, 16, std::min(std::max(2u * known_lat, 1024u), 16384u), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work2.p,
+                        nullptr, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr);
             ev.end(S);
             ++n_launch;
         }
-        if (n_lat) {
-            /* the views that have handed over: one wavefront per patch, an entry's attempts one after the other */
-            ev.begin(S, EventLog::BULK, n_lat);
-            D->optimize(S, 16, std::min(n_lat, 16384u), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work2.p,
-                        nullptr, c->bs.d_results2.p, nullptr, n_lat, 0u, 0xFFFFFFFFu, round, c->d_counters, nullptr, nullptr, nullptr, nullptr);
-            ev.end(S);
-            ++n_launch; ++n_lat_rounds;
-        }
         ev.begin(S, EventLog::SWEEP, 0);
-        if (n_thr) mi_launch_apply(S, (n_thr + 255) / 256, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, nullptr, n_thr, round, c->d_counters);
-        if (n_lat) mi_launch_apply(S, (n_lat + 255) / 256, c->bs.d_jobs.p, c->bs.d_work2.p, c->bs.d_results2.p, nullptr, n_lat, round, c->d_counters);
+        mi_launch_apply(S, std::min((est + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, n_thr_p, 0u, r, c->d_counters);
+        if (any_lat) mi_launch_apply(S, std::min((std::max(2u * known_lat, 1024u) + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work2.p, c->bs.d_results2.p, n_lat_p, 0u, r, c->d_counters);
         ev.end(S);
-        if (n_thr == 0 && !host_rounds_only) {
-            /* every view that still has work is in the latency layout: its list (d_work2 / d_results2, round_work[round])
-             * is what the fused rounds go on from */
-            tail_known = n_lat;
-            /* counters as of the end of the host-visible rounds (slot 2 of the poll buffer; read after the call) */
-            HIP_TRY(hipMemcpyAsync(&c->bs.h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
-            have_handover = true;
-            ++round; to_tail = true;
-            return 0;
+        const int slot = r & 1;
+        TailPoll& P = c->bs.h_poll[slot];
+        if (hipMemcpyAsync(&P.rw[0], n_thr_p, sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
+            || hipMemcpyAsync(&P.rw[1], n_lat_p, sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
+            || hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S) != hipSuccess
+            || read_dyn(slot) != hipSuccess || hipEventRecord(c->bs.poll_ev[slot], S) != hipSuccess)
+            return fail(MI_DMRECON_EDEVICE, "enqueue of a propagation round failed");
+        pend[n_pend].round = r; pend[n_pend].ev_thr = ev_thr; pend[n_pend].ev_lat = ev_lat; ++n_pend;
+        return 0;
+    };
+    /* reads back the oldest round in flight; returns 1 when the propagation has ended there */
+    unsigned last_thr = 1, last_lat = 0; int last_seen = 0;
+    auto retire = [&]() -> int {
+        const Pending pd = pend[0];
+        pend[0] = pend[1]; --n_pend;
+        const int slot = pd.round & 1;
+        HIP_TRY(hipEventSynchronize(c->bs.poll_ev[slot]));
+        TailPoll& P = c->bs.h_poll[slot];
+        const unsigned n_thr = P.rw[0], n_lat = P.rw[1];
+        hc = P.hc;
+        if (int rc = poll_views(dyn_of(slot), n_thr + n_lat)) return rc;
+        known_thr = n_thr; known_lat = n_lat;
+        last_thr = n_thr; last_lat = n_lat; last_seen = pd.round;
+        ev.items[pd.ev_thr].work = n_thr;
+        if (pd.ev_lat != (size_t)-1) ev.items[pd.ev_lat].work = n_lat;
+        else if (n_lat) return fail(MI_DMRECON_EDEVICE, "internal: latency-layout entries in a round enqueued without their launches");
+        if (n_lat) ++n_lat_rounds;
+        return (n_thr + n_lat == 0) ? 1 : 0;
+    };
+    for (; round < max_rounds && n_alive > 0 && !stop; ) {
+        if (int rc = enqueue(round)) return rc;
+        ++round;
+        /* keep ONE round queued behind the one that runs: look at the round before the one just enqueued */
+        while (n_pend > 1 || (stop && n_pend > 0)) {
+            const int r = retire();
+            if (r < 0) return r;
+            if (r == 1) {                                          /* an empty round: the propagation is over */
+                while (n_pend > 0) { HIP_TRY(hipEventSynchronize(c->bs.poll_ev[pend[0].round & 1])); pend[0] = pend[1]; --n_pend; }
+                round = last_seen; done = true;
+                return 0;
+            }
+            if (n_alive == 0) { HIP_TRY(hipStreamSynchronize(S)); return 0; }
+            /* no view is left in the throughput layout: the fused rounds take over after the rounds already enqueued */
+            if (last_thr == 0 && !host_rounds_only) stop = true;
         }
+    }
+    if (stop) {
+        /* every round enqueued has been retired; the last one's latency list is what the fused rounds go on from */
+        if (last_thr != 0) return fail(MI_DMRECON_EDEVICE, "internal: throughput entries after the hand-over");
+        tail_known = last_lat;
+        /* counters as of the end of the host-visible rounds (slot 2 of the poll buffer; read after the call) */
+        HIP_TRY(hipMemcpyAsync(&c->bs.h_poll[2].hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
+        have_handover = true;
+        to_tail = true;
+        return 0;
     }
     if (n_alive > 0) truncated = true;               /* round counters exhausted */
     return 0;
@@ -1717,7 +1768,7 @@ void BatchRun::fill_stats() {
             if (!ev.ms(it, ms)) continue;
             switch (it.kind) {
                 case EventLog::SWEEP: stats->ms_sweep_kernels += ms; break;
-                case EventLog::BULK: stats->ms_bulk_kernel += ms; ++stats->n_bulk_launches; break;
+                case EventLog::BULK: stats->ms_bulk_kernel += ms; if (it.work) ++stats->n_bulk_launches; break;   /* (empty launches of blind rounds: their microseconds count, they do not) */
                 case EventLog::TAIL: if (it.work > 0) { tail_ms += ms; ++tail_timed; } break;
                 case EventLog::FRONT: stats->ms_front_kernel += ms; break;
             }
@@ -1727,6 +1778,7 @@ void BatchRun::fill_stats() {
         stats->ms_opt_kernel = stats->ms_bulk_kernel + stats->ms_tail_kernel + stats->ms_front_kernel;
         stats->n_tail_launches = n_tail_launch;
         stats->n_latency_rounds = n_lat_rounds;
+        stats->n_patch_turns = (int64_t)hc.n_stage; stats->n_wave_turns = (int64_t)hc.n_gather_pass;
         if (ran_front) {
             stats->n_front_launches = 1;
             stats->front_team = front_team;

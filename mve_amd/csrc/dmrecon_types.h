@@ -118,8 +118,8 @@ struct DevResult {
 
 struct DevCounters {
     unsigned long long n_patch, n_eval, n_pass, n_filled, n_seeds_ok;
-    unsigned long long n_stage;        /* texel windows staged into LDS (per patch-view; speculative attempts included) */
-    unsigned long long n_gather_pass;  /* passes of window kernels that had to sample by global gathers */
+    unsigned long long n_stage;        /* -DMI_ACTIVITY builds: turns of patch optimisations in the throughput layout ... */
+    unsigned long long n_gather_pass;  /* ... and the turns their wavefronts ran x patches per wavefront (lane activity = the ratio) */
     unsigned long long n_view_replaced; /* local views dropped by replaceViews (patch_optimization.cc:218-228), attempts of all kinds */
     unsigned long long n_iter14;        /* ... of which only because they were still moving at iteration 14 */
     unsigned int error_flags;  /* bit0: non-positive master footprint (patch_sampler.cc:78-82) */
