@@ -68,6 +68,12 @@ struct MiDeviceApi {
                   int fault /* test hook: member | round << 8 of the team member that vanishes (member 255: none), bit 24: the
                              * team writes through its L2s as if found on several XCDs; -1 = none */,
                   int n_xcd /* teams: XCDs of the device; a view's team is confined to the blocks of one (b % n_xcd) */);
+    /* optimize_spec -- a small round of the throughput layout with every (entry, candidate rank) pair on a quad of its own
+     * (4 x entries quads; spec: 4 x entries records); mi_launch_apply_spec applies the reference's sequential rule to the
+     * records and writes the pixels back.  Same maps and counters as `optimize` + mi_launch_apply. */
+    void (*optimize_spec)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
+                          const DevSettings& st, const DevEntry* work, DevSpec* spec, const unsigned* n_work_ptr, unsigned n_work,
+                          unsigned min_work, unsigned max_work, int round, DevCounters* counters);
 };
 const MiDeviceApi* mi_device_api(int filter_width);
 extern unsigned long long* mi_debug_tbuf;
@@ -75,8 +81,11 @@ extern unsigned long long* mi_debug_tbuf;
 /* ---- kernels that do not depend on the filter width (defined once, in the width-5 object) ---- */
 #define MI_GEN_TILE_W 64
 #define MI_GEN_TILE_H 32
+/* (both act only if min_work <= n < max_work, n = *n_work_ptr if given) */
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
-                     const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters);
+                     const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters);
+void mi_launch_apply_spec(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevSpec* spec,
+                          const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters);
 /* maps: [slot 0: depth | conf | dz x2 | normal x3][slot 1: same], imaps: [views | upd][views1 | upd1], per batch */
 /* eight_views: imaps also holds [views_hi | views1_hi] behind them (nrReconNeighbors > 4) */
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px, bool eight_views);

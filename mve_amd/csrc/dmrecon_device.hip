@@ -1550,6 +1550,88 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
 }
 
 /*
+ * Small rounds of the throughput layout, speculatively.  A round whose list does not fill the GPU lasts as long as its
+ * slowest wavefront, and that is one whose entry tries its second, third and fourth candidate hypothesis one after the
+ * other (an attempt alone on a SIMD is ~100 us of exposed latencies).  The attempts of an entry do not depend on each other
+ * -- they all read the state frozen at the start of the round; only the decisions which of them the reference would have
+ * made, and which result stands, are sequential (dmrecon.cc:365-392) -- so here every (entry, rank) pair gets a quad of
+ * its own, and the sequential rule is applied afterwards from the records (k_apply_spec): same maps and counters, bit for
+ * bit, as process_entry's attempts in a row.
+ */
+struct SpecArgs {
+    OptArgs o;               /* jobs, views, lut, st, work, n_work_ptr / n_work, min_work / max_work, round, counters */
+    DevSpec* spec;           /* [4 x entries] */
+};
+template <class L>
+__device__ __forceinline__ unsigned patch_sum_u(unsigned v) {
+    v += (unsigned)L::template view_xor<0>((int)v); v += (unsigned)L::template view_xor<1>((int)v);
+    if (L::NV == 8) v += (unsigned)L::template view_xor<2>((int)v);
+    return v;
+}
+template <class L>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_BULK_WAVES, MI_WAVES_PER_SIMD))) void k_optimize_spec(SpecArgs t) {
+    const OptArgs& a = t.o;
+    const int lane = threadIdx.x;
+    const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
+    if (n < a.min_work || n >= a.max_work) return;
+    for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
+    __syncthreads();
+    const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
+    unsigned err = 0;
+    for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < 4u * n; i += gridDim.x * L::PATCHES) {
+        const unsigned e = i >> 2; const int s = (int)(i & 3u);
+        const DevEntry ent = a.work[e];
+        const DevJob* job = a.jobs + ent.job;
+        DevSpec* rec = t.spec + i;
+        if (GI(&job->flags) != 0) {                       /* the view failed or was cancelled: nothing of it is touched any more */
+            if (writer && s == 0) rec->n_cand = 0;
+            continue;
+        }
+        const int x = ent.xy & 0xFFFF, y = ent.xy >> 16, W = job->w, pix = y * W + x;
+        const float own = GF(job->conf + pix);
+        const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+        /* the candidates in the reference's order of trial: descending source confidence, lowest direction first on ties
+         * (process_entry picks them one by one with a strict '>') */
+        float c[4]; unsigned elig = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = GF(job->conf + nb[k]);
+            if (GI(job->upd + nb[k]) == a.round - 1 && (own < c[k] - 0.05f || own == 0.f)) elig |= 1u << k;
+        }
+        int n_cand = 0, dir = -1; float bc = 0.f;
+        {
+            unsigned left = elig;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int bi = -1; float bv = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (((left >> k) & 1u) && (bi < 0 || c[k] > bv)) { bi = k; bv = c[k]; }
+                if (bi >= 0) { if (r == s) { dir = bi; bc = bv; } ++n_cand; left &= ~(1u << bi); }
+            }
+        }
+        if (writer && s == 0) rec->n_cand = n_cand;
+        if (s >= n_cand) continue;
+        const int p = dir == 0 ? nb[0] : dir == 1 ? nb[1] : dir == 2 ? nb[2] : nb[3];
+        const float hd = GF(job->depth + p), hi = GF(job->dz + 2 * p), hj = GF(job->dz + 2 * p + 1);
+        const unsigned long long hv = load_view_set<L::NV>(job, false, p);
+        PatchResult r; unsigned ne = 0, np = 0;
+        optimize_patch<L, false>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, ne, np, err, a.counters);
+        if (L::sub(lane) != 0) { ne = 0; np = 0; }
+        ne = patch_sum_u<L>(ne); np = patch_sum_u<L>(np);
+        if (writer) {
+            DevSpec o;
+            o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ; o.nx = r.nx; o.ny = r.ny; o.nz = r.nz;
+            o.views = r.views; o.views_hi = r.views_hi; o.iters = r.iters; o.bc = bc; o.own = own; o.n_eval = ne; o.n_pass = np;
+            o.n_cand = n_cand; o.pad = 0;
+            *rec = o;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) err |= __shfl_down(err, off);
+    if (lane == 0 && err) atomicOr(&a.counters->error_flags, err);
+}
+
+/*
  * One fused round of the propagation tail (replaces generate -> optimise -> apply, three dependent launches, by one).
  *
  * A CANDIDATE is (pixel p accepted in the previous round, one of its 4-neighbours q) for which the push rule
@@ -2432,8 +2514,10 @@ struct ApplyArgs {
     const DevJob* jobs;
     const DevEntry* work;
     const DevResult* results;
+    const DevSpec* spec;             /* k_apply_spec: the speculative attempts of the entries */
     const unsigned* n_work_ptr;
     unsigned n_work;
+    unsigned min_work, max_work;     /* the launch only acts if min_work <= n < max_work */
     int round;
     DevCounters* counters;
     unsigned long long* seed_keys;   /* seeds only: per job pixel arbitration keys */
@@ -2454,6 +2538,7 @@ __device__ __forceinline__ void write_pixel(const DevJob* job, int pix, const De
 /* Jacobi write-back of one propagation round (dmrecon.cc:391-398). */
 __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
     const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
+    if (n < a.min_work || n >= a.max_work) return;
     unsigned filled = 0;
     for (unsigned base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
         const unsigned e = base + threadIdx.x;
@@ -2482,6 +2567,64 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
         }
     }
     if (filled && (threadIdx.x & 63) == 0) atomicAdd(&a.counters->n_filled, (unsigned long long)filled);
+}
+
+/* The write-back of a speculative round (k_optimize_spec): the reference's sequential rule over an entry's candidate
+ * attempts (pop-time test dmrecon.cc:371, acceptance :378,391) from their records, then the Jacobi write-back of k_apply.
+ * Counts what the reference would have run -- not the speculative extras. */
+__global__ __launch_bounds__(256) void k_apply_spec(ApplyArgs a) {
+    const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
+    if (n < a.min_work || n >= a.max_work) return;
+    unsigned filled = 0, n_eval = 0, n_pass = 0, n_patch = 0;
+    for (unsigned base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+        const unsigned e = base + threadIdx.x;
+        bool newly = false;
+        int myjob = -1;
+        if (e < n) {
+            const DevSpec* rec = a.spec + 4 * (size_t)e;
+            const int n_cand = rec[0].n_cand;
+            if (n_cand > 0) {
+                const float own = rec[0].own;
+                float best = own; int fin = -1;
+                for (int s = 0; s < n_cand; ++s) {
+                    if (best > rec[s].bc) break;                                       /* dmrecon.cc:371 (and every later one) */
+                    ++n_patch; n_eval += rec[s].n_eval; n_pass += rec[s].n_pass;
+                    const float cf = rec[s].conf;
+                    if (cf > 0.f && best < cf) { best = cf; fin = s; }                 /* dmrecon.cc:378,391 */
+                }
+                if (fin >= 0) {
+                    const DevSpec f = rec[fin];
+                    const DevEntry ent = a.work[e];
+                    const DevJob* job = a.jobs + ent.job;
+                    myjob = ent.job;
+                    const int pix = (ent.xy >> 16) * job->w + (ent.xy & 0xFFFF);
+                    DevResult r;
+                    r.conf = f.conf; r.depth = f.depth; r.dzI = f.dzI; r.dzJ = f.dzJ; r.nx = f.nx; r.ny = f.ny; r.nz = f.nz;
+                    r.views = f.views; r.views_hi = f.views_hi; r.iters = f.iters; r.accepted = 1; r.tried = 0;
+                    newly = own <= 0.f;
+                    write_pixel(job, pix, r, a.round);
+                }
+            }
+        }
+        filled += (unsigned)__popcll(__ballot(newly));
+        unsigned long long todo = __ballot(newly);
+        while (todo) {                                       /* Progress::filled per view: one atomic per (wavefront, job) */
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lj = __shfl(myjob, leader);
+            const unsigned long long same = __ballot(newly && myjob == lj);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(const_cast<uint32_t*>(&a.jobs[lj].n_filled), (unsigned)__popcll(same));
+            todo &= ~same;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_eval += __shfl_down(n_eval, off); n_pass += __shfl_down(n_pass, off); n_patch += __shfl_down(n_patch, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (filled) atomicAdd(&a.counters->n_filled, (unsigned long long)filled);
+        if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
+        if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
+        if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
+    }
 }
 
 /* Seeds (dmrecon.cc:297-330): several features may round to the same pixel; the sequential
@@ -2629,6 +2772,20 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     }
 }
 
+static void launch_optimize_spec(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
+                                 const DevSettings& st, const DevEntry* work, DevSpec* spec, const unsigned* n_work_ptr, unsigned n_work,
+                                 unsigned min_work, unsigned max_work, int round, DevCounters* counters) {
+    if (grid_blocks == 0) return;
+    SpecArgs t;
+    t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = nullptr;
+    t.o.n_work_ptr = n_work_ptr; t.o.n_work = n_work; t.o.min_work = min_work; t.o.max_work = max_work; t.o.round = round;
+    t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
+    t.o.max_attempts = 1; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
+    t.spec = spec;
+    if (st.K > 4) hipLaunchKernelGGL((k_optimize_spec<Lay<1, 8> >), dim3(grid_blocks), dim3(WAVE), 0, s, t);
+    else hipLaunchKernelGGL((k_optimize_spec<Lay<1, 4> >), dim3(grid_blocks), dim3(WAVE), 0, s, t);
+}
+
 static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                           const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
                           float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level) {
@@ -2649,12 +2806,22 @@ static void launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int m
 
 #if MI_FW == 5
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
-                     const unsigned* n_work_ptr, unsigned n_work, int round, DevCounters* counters) {
+                     const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters) {
     if (grid_blocks == 0) return;
     ApplyArgs a;
-    a.jobs = jobs; a.work = work; a.results = results; a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.round = round;
+    a.jobs = jobs; a.work = work; a.results = results; a.spec = nullptr; a.n_work_ptr = n_work_ptr; a.n_work = n_work;
+    a.min_work = min_work; a.max_work = max_work; a.round = round;
     a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0;
     hipLaunchKernelGGL(k_apply, dim3(grid_blocks), dim3(256), 0, s, a);
+}
+void mi_launch_apply_spec(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevSpec* spec,
+                          const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters) {
+    if (grid_blocks == 0) return;
+    ApplyArgs a;
+    a.jobs = jobs; a.work = work; a.results = nullptr; a.spec = spec; a.n_work_ptr = n_work_ptr; a.n_work = n_work;
+    a.min_work = min_work; a.max_work = max_work; a.round = round;
+    a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0;
+    hipLaunchKernelGGL(k_apply_spec, dim3(grid_blocks), dim3(256), 0, s, a);
 }
 
 #endif
@@ -2736,7 +2903,8 @@ void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* wo
                            const unsigned* key_off) {
     if (n_work == 0) return;
     ApplyArgs a;
-    a.jobs = jobs; a.work = work; a.results = results; a.n_work_ptr = nullptr; a.n_work = n_work; a.round = 0;
+    a.jobs = jobs; a.work = work; a.results = results; a.spec = nullptr; a.n_work_ptr = nullptr; a.n_work = n_work; a.round = 0;
+    a.min_work = 0; a.max_work = 0xFFFFFFFFu;
     a.counters = counters; a.seed_keys = seed_keys; a.key_off = key_off;
     a.phase = 0;
     hipLaunchKernelGGL(k_apply_seeds, dim3((n_work + 255) / 256), dim3(256), 0, s, a);
@@ -2762,5 +2930,5 @@ void mi_launch_pyramid(hipStream_t s, const uint32_t* src, uint32_t* dst, int iw
 
 /* the launchers of this filter width (dmrecon_device.h: mi_device_api); host side only */
 #if !defined(__HIP_DEVICE_COMPILE__)
-extern const MiDeviceApi MI_CAT(mi_device_api_fw, MI_FW) = {MI_FW, launch_optimize, launch_patch_eval, launch_generate, launch_tail, launch_front};
+extern const MiDeviceApi MI_CAT(mi_device_api_fw, MI_FW) = {MI_FW, launch_optimize, launch_patch_eval, launch_generate, launch_tail, launch_front, launch_optimize_spec};
 #endif

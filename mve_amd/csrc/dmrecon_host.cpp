@@ -159,6 +159,7 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 #define MI_MERGE_WINDOW_US 1000
 #define MI_MERGE_WINDOW_BIG_US 150  /* ... from this size on only this long (see mi_dmrecon_reconstruct) */
 #define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
+#define MI_SPEC_ROUNDS 32768u      /* throughput rounds below this many entries try an entry's candidate hypotheses at the same time */
 #define MI_VIEW_HANDOVER 320u      /* a view leaves the throughput layout once a round's list of its own is shorter than this */
 #define MI_TEAM_WAIT_US 20000u     /* a front team member waits this long for the others before the team gives up */
 #define MI_FRONT_MIN_CAP 256       /* hand-over to k_front: entries per view, at least */
@@ -231,6 +232,7 @@ struct BatchScratch {
     DevBuf<unsigned> d_front_flags;          /* ... and MI_FRONT_TEAM_MAX pass flags per view */
     DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
     DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
+    DevBuf<DevSpec> d_spec;                  /* speculative small rounds: four attempt records per entry (BatchRun::bulk_rounds) */
     TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     uint8_t* h_dyn = nullptr;                /* pinned: read-backs of the jobs' flags / n_filled words (JobDyn), three slots */
@@ -259,7 +261,7 @@ struct BatchScratch {
         for (size_t i = 0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
         events.clear();
         d_jobs.release(); d_work.release(); d_work2.release(); d_hyp.release(); d_results.release(); d_results2.release();
-        d_follow.release(); d_follow_cnt.release(); d_maps.release(); d_imaps.release(); d_keys.release(); d_keyoff.release();
+        d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_keys.release(); d_keyoff.release();
         d_round_work.release(); d_round_work_t.release(); d_view.release(); d_front.release(); d_front_resume.release();
         d_front_mail.release(); d_front_flags.release();
         d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release();
@@ -1384,6 +1386,14 @@ int BatchRun::bulk_rounds(bool& to_tail) {
     const int max_rounds = MI_MAX_ROUNDS - 2 * (int)MI_TAIL_CHUNK - 2;
     unsigned* d_vcount = c->bs.d_view.p; unsigned* d_vmode = d_vcount + 3 * (size_t)nj;
     const unsigned ppw = patches_per_wave(st);
+    /* MI_DMRECON_SPEC_ROUNDS=<entries> (read per call; 0 = never): a throughput round that cannot fill the GPU lasts as long
+     * as its slowest wavefront -- one whose entry tries two, three, four candidate hypotheses in a row.  Below this size
+     * every (entry, rank) pair gets a quad of its own (k_optimize_spec / k_apply_spec: same maps, same counters).  The
+     * records are sized for twice the threshold; a round that turns out larger than that runs the plain launches, which
+     * are enqueued next to the speculative ones and look at the size on the device. */
+    const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPEC_ROUNDS"); return e ? (unsigned)std::max(0L, std::atol(e)) : MI_SPEC_ROUNDS; }();
+    const unsigned spec_cap = 2u * SPEC_MAX;
+    if (SPEC_MAX > 0 && c->bs.d_spec.reserve(4 * (size_t)spec_cap)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(speculative records) failed");
     /* The rounds are enqueued WITHOUT waiting for their list sizes: every kernel of a round reads its size on the device
      * (k_generate also decides there which layout a view's entries go to), the grids come from the sizes of the last round
      * the host has seen (doubled: a list grows at most ~4x per round in the first rounds, and a grid that is too small
@@ -1409,6 +1419,14 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         const size_t ev_thr = ev.items.size() - 1;
         size_t ev_lat = (size_t)-1;
         unsigned* fcnt = c->bs.d_follow_cnt.p + 4 * (size_t)r;
+        /* a small round: speculative launches for lists below spec_cap, the plain ones (below) only above it */
+        const bool spec = SPEC_MAX > 0 && known_thr < SPEC_MAX;
+        const unsigned plain_min = spec ? spec_cap : 0u;
+        if (spec) {
+            const unsigned quads = 4u * std::min(std::max(2u * known_thr, 4096u), spec_cap);
+            D->optimize_spec(S, (quads + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, c->bs.d_spec.p, n_thr_p,
+                             0u, 0u, spec_cap, r, c->d_counters);
+        }
         /* Rounds below MI_ONE_LAUNCH_MAX entries run as ONE launch of the general kernel, all attempts of an entry in a
          * row: such a launch fits the GPU at once, so either launch of the two-launch form lasts one wavefront-life
          * (1 attempt, then up to 3 more) whatever its size -- measured: lone 20-view call 533 -> 548 depth-maps/s, a
@@ -1416,15 +1434,15 @@ int BatchRun::bulk_rounds(bool& to_tail) {
          * 546 / 540).  Same arithmetic either way (tests: the maps do not depend on the form); chosen from the last
          * size the host has seen. */
         if (known_thr < ONE_LAUNCH_MAX)
-            D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
-                        0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr);
+            D->optimize(S, 1, spec ? std::max(1u, waves / 2) : waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
+                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr);
         else {
             /* one optimisation attempt per entry and launch; the entries whose pixel has further candidate hypotheses
              * (about one in five) continue in a follow-up launch over a compacted list (its size stays on the device),
              * so that the wavefronts of both launches are full; the follow-up launch runs all remaining attempts of its
              * entries back to back (third and fourth attempts are rare) */
             D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
-                        0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, c->bs.d_follow.p, fcnt);
+                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, c->bs.d_follow.p, fcnt);
             D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
                         c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, c->bs.d_follow.p, fcnt, nullptr, nullptr);
             ++n_launch;
@@ -1441,8 +1459,9 @@ int BatchRun::bulk_rounds(bool& to_tail) {
             ++n_launch;
         }
         ev.begin(S, EventLog::SWEEP, 0);
-        mi_launch_apply(S, std::min((est + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, n_thr_p, 0u, r, c->d_counters);
-        if (any_lat) mi_launch_apply(S, std::min((std::max(2u * known_lat, 1024u) + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work2.p, c->bs.d_results2.p, n_lat_p, 0u, r, c->d_counters);
+        if (spec) mi_launch_apply_spec(S, std::min((spec_cap + 255) / 256, 1024u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_spec.p, n_thr_p, 0u, 0u, spec_cap, r, c->d_counters);
+        mi_launch_apply(S, std::min((est + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, n_thr_p, 0u, plain_min, 0xFFFFFFFFu, r, c->d_counters);
+        if (any_lat) mi_launch_apply(S, std::min((std::max(2u * known_lat, 1024u) + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work2.p, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters);
         ev.end(S);
         const int slot = r & 1;
         TailPoll& P = c->bs.h_poll[slot];

@@ -116,6 +116,20 @@ struct DevResult {
     uint32_t tried;          /* propagate mode: neighbours (bit k: left, right, up, down) whose hypothesis has been consumed */
 };
 
+/* One candidate hypothesis of a work-list entry optimised SPECULATIVELY (small throughput rounds, k_optimize_spec): the
+ * entry's up to four candidates run at the same time on four quads, the reference's sequential rule (dmrecon.cc:371,378,391)
+ * is applied afterwards from these records (k_apply_spec).  Record of (entry e, rank s) at [4 e + s]. */
+struct DevSpec {
+    float conf, depth, dzI, dzJ, nx, ny, nz;
+    uint32_t views, views_hi;
+    int32_t iters;
+    float bc;                /* the candidate's source confidence: order of trial and pop-time test */
+    float own;               /* the pixel's own confidence, frozen at the start of the round */
+    uint32_t n_eval, n_pass; /* what this attempt counted (all view slots) */
+    int32_t n_cand;          /* rank 0 only: candidates of the entry (0: the view has ended) */
+    int32_t pad;
+};
+
 struct DevCounters {
     unsigned long long n_patch, n_eval, n_pass, n_filled, n_seeds_ok;
     unsigned long long n_stage;        /* -DMI_ACTIVITY builds: turns of patch optimisations in the throughput layout ... */

@@ -361,13 +361,22 @@ def test_maps_do_not_depend_on_the_batch(gpu_ctx, g1_scene, h1_scene, monkeypatc
         for r, v in zip(sub, (refs[3], refs[1])):
             for k in ("depth", "conf", "dz", "normal", "views"):
                 assert np.array_equal(r[k], ref[refs.index(v)][k]), (v, k)
-        # the throughput rounds as first-attempt launch + follow-up launch instead of one launch: same arithmetic
-        monkeypatch.setenv("MI_DMRECON_ONE_LAUNCH", "0")
-        two = gpu_ctx.reconstruct(st, refs, want_views=True)
-        monkeypatch.delenv("MI_DMRECON_ONE_LAUNCH")
-        for a, b in zip(two, ref):
-            for k in ("depth", "conf", "dz", "normal", "views"):
-                assert np.array_equal(a[k], b[k]), k
+        # the throughput rounds as first-attempt launch + follow-up launch instead of one launch, without the speculative
+        # small rounds, and with every round speculative (records for 2 x the threshold; larger rounds fall back on the
+        # device): same arithmetic, same counters
+        for env in ({"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0"}, {"MI_DMRECON_SPEC_ROUNDS": "0"},
+                    {"MI_DMRECON_SPEC_ROUNDS": "1000000"}, {"MI_DMRECON_SPEC_ROUNDS": "700", "MI_DMRECON_ONE_LAUNCH": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            two = gpu_ctx.reconstruct(st, refs, want_views=True)
+            s_two = dict(gpu_ctx.last_stats)
+            for k in env:
+                monkeypatch.delenv(k)
+            for a, b in zip(two, ref):
+                for k in ("depth", "conf", "dz", "normal", "views"):
+                    assert np.array_equal(a[k], b[k]), (k, env)
+            for k in ("n_patch", "n_eval", "n_filled", "n_rounds"):
+                assert s_two[k] == s_all[k], (k, env, s_two[k], s_all[k])
         # calls that meet inside the library are merged into one batch (default): every caller gets its own call's maps
         forks = [gpu_ctx.fork() for _ in range(3)]
         parts = [refs[:2], refs[2:3], refs[3:]]
