@@ -55,7 +55,7 @@ struct MiDeviceApi {
                        float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
     void (*generate)(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work, DevEntry* work_lat,
                      unsigned* round_work, unsigned* round_work_lat, unsigned* view_count, unsigned* view_mode,
-                     unsigned handover, int round);
+                     unsigned handover, int round, unsigned* items, unsigned* round_items);
     void (*tail)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                  const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
                  DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool speculative);
@@ -68,11 +68,13 @@ struct MiDeviceApi {
                   int fault /* test hook: member | round << 8 of the team member that vanishes (member 255: none), bit 24: the
                              * team writes through its L2s as if found on several XCDs; -1 = none */,
                   int n_xcd /* teams: XCDs of the device; a view's team is confined to the blocks of one (b % n_xcd) */);
-    /* optimize_spec -- a small round of the throughput layout with every (entry, candidate rank) pair on a quad of its own
-     * (4 x entries quads; spec: 4 x entries records); mi_launch_apply_spec applies the reference's sequential rule to the
-     * records and writes the pixels back.  Same maps and counters as `optimize` + mi_launch_apply. */
+    /* optimize_spec -- a round of the throughput layout with every (entry, candidate rank) pair on a quad of its own: `items`
+     * (entry << 2 | rank, *n_items of them: written by `generate` when given an item list) are the attempts, spec holds
+     * 4 x entries records; mi_launch_apply_spec applies the reference's sequential rule to the records and writes the
+     * pixels back.  Same maps and counters as `optimize` + mi_launch_apply. */
     void (*optimize_spec)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
-                          const DevSettings& st, const DevEntry* work, DevSpec* spec, const unsigned* n_work_ptr, unsigned n_work,
+                          const DevSettings& st, const DevEntry* work, DevSpec* spec, const unsigned* items, const unsigned* n_items,
+                          const unsigned* n_work_ptr, unsigned n_work,
                           unsigned min_work, unsigned max_work, int round, DevCounters* counters);
 };
 const MiDeviceApi* mi_device_api(int filter_width);

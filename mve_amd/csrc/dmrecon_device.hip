@@ -1561,6 +1561,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
 struct SpecArgs {
     OptArgs o;               /* jobs, views, lut, st, work, n_work_ptr / n_work, min_work / max_work, round, counters */
     DevSpec* spec;           /* [4 x entries] */
+    const unsigned* items;   /* the round's (entry, rank) pairs (k_generate), their number in *n_items */
+    const unsigned* n_items;
 };
 template <class L>
 __device__ __forceinline__ unsigned patch_sum_u(unsigned v) {
@@ -1578,11 +1580,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_BULK_WA
     __syncthreads();
     const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
     unsigned err = 0;
-    for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < 4u * n; i += gridDim.x * L::PATCHES) {
-        const unsigned e = i >> 2; const int s = (int)(i & 3u);
+    const unsigned n_items = *t.n_items;
+    for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < n_items; i += gridDim.x * L::PATCHES) {
+        const unsigned item = t.items[i];
+        const unsigned e = item >> 2; const int s = (int)(item & 3u);
         const DevEntry ent = a.work[e];
         const DevJob* job = a.jobs + ent.job;
-        DevSpec* rec = t.spec + i;
+        DevSpec* rec = t.spec + item;
         if (GI(&job->flags) != 0) {                       /* the view failed or was cancelled: nothing of it is touched any more */
             if (writer && s == 0) rec->n_cand = 0;
             continue;
@@ -2426,6 +2430,10 @@ struct SweepArgs {
     unsigned handover;     /* a view hands over once a round's list of ITS OWN is shorter than this */
     int n_jobs;
     int round;
+    /* speculative rounds (k_optimize_spec): besides the entries of the throughput list, one ITEM per (entry, candidate
+     * hypothesis) pair -- entry index << 2 | rank -- so that every attempt of the round gets a quad of its own; null: none */
+    unsigned* items;
+    unsigned* round_items; /* [round] = number of items */
 };
 
 /* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull.
@@ -2448,7 +2456,7 @@ struct SweepArgs {
  * isolated pixels).  The order of the list has no influence on the results. */
 __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
     __shared__ unsigned s_wave_cnt[4];
-    __shared__ unsigned s_base;
+    __shared__ unsigned s_base, s_items, s_ibase;
     const int jobi = blockIdx.y;
     const DevJob* job = a.jobs + jobi;
     /* the view's layout this round (every workgroup of the view computes the same from last round's count; the first
@@ -2470,10 +2478,17 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
     unsigned hits = 0;                       /* bit t = my pixel of sub-tile t is a hit */
     unsigned before[GEN_PER_THREAD];         /* hits of lower lanes of my wave in trip t */
     unsigned wave_total = 0;
+    const bool want_items = a.items != nullptr && !lat;
+    unsigned cands = 0;                      /* 3 bits per trip: candidate hypotheses of my pixel */
+    unsigned ipos[GEN_PER_THREAD];           /* where my pixel's items start among the workgroup's */
+    if (want_items && threadIdx.x == 0) s_items = 0;
+    if (want_items) __syncthreads();
 #pragma unroll
     for (int t = 0; t < GEN_PER_THREAD; ++t) {
         const int x = tx0 + t * 8 + lx, y = ty0 + wave * 8 + ly;
         bool any = false;
+        unsigned cnt = 0;
+        ipos[t] = 0;
         /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
         if (x >= MI_HALF && y >= MI_HALF && x < W - MI_HALF && y < H - MI_HALF) {
             const int pix = y * W + x;
@@ -2483,9 +2498,10 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
             for (int k = 0; k < 4; ++k)
                 if (job->upd[nb[k]] == a.round - 1) {
                     const float c = job->conf[nb[k]];
-                    if (own < c - 0.05f || own == 0.f) any = true;
+                    if (own < c - 0.05f || own == 0.f) { any = true; ++cnt; }
                 }
         }
+        if (want_items && any) { ipos[t] = atomicAdd(&s_items, cnt); cands |= cnt << (3 * t); }
         const unsigned long long m = __ballot(any);
         before[t] = wave_total + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
         wave_total += (unsigned)__popcll(m);
@@ -2497,6 +2513,7 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
         const unsigned tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
         s_base = tot ? atomicAdd(&(lat ? a.round_work_lat : a.round_work)[a.round], tot) : 0u;
         if (tot) atomicAdd(&a.view_count[(unsigned)(a.round % 3) * (unsigned)a.n_jobs + (unsigned)jobi], tot);
+        if (want_items) s_ibase = s_items ? atomicAdd(&a.round_items[a.round], s_items) : 0u;
     }
     __syncthreads();
     unsigned off = s_base;
@@ -2507,6 +2524,10 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
         if ((hits >> t) & 1u) {
             DevEntry e; e.job = jobi; e.xy = (tx0 + t * 8 + lx) | ((ty0 + wave * 8 + ly) << 16);
             out[off + before[t]] = e;
+            if (want_items) {
+                const unsigned cnt = (cands >> (3 * t)) & 7u, ei = off + before[t];
+                for (unsigned r = 0; r < cnt; ++r) a.items[s_ibase + ipos[t] + r] = (ei << 2) | r;
+            }
         }
 }
 
@@ -2773,7 +2794,8 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
 }
 
 static void launch_optimize_spec(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
-                                 const DevSettings& st, const DevEntry* work, DevSpec* spec, const unsigned* n_work_ptr, unsigned n_work,
+                                 const DevSettings& st, const DevEntry* work, DevSpec* spec, const unsigned* items, const unsigned* n_items,
+                                 const unsigned* n_work_ptr, unsigned n_work,
                                  unsigned min_work, unsigned max_work, int round, DevCounters* counters) {
     if (grid_blocks == 0) return;
     SpecArgs t;
@@ -2781,7 +2803,7 @@ static void launch_optimize_spec(hipStream_t s, unsigned grid_blocks, const DevJ
     t.o.n_work_ptr = n_work_ptr; t.o.n_work = n_work; t.o.min_work = min_work; t.o.max_work = max_work; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
     t.o.max_attempts = 1; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
-    t.spec = spec;
+    t.spec = spec; t.items = items; t.n_items = n_items;
     if (st.K > 4) hipLaunchKernelGGL((k_optimize_spec<Lay<1, 8> >), dim3(grid_blocks), dim3(WAVE), 0, s, t);
     else hipLaunchKernelGGL((k_optimize_spec<Lay<1, 4> >), dim3(grid_blocks), dim3(WAVE), 0, s, t);
 }
@@ -2797,10 +2819,11 @@ static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* v
 
 static void launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work, DevEntry* work_lat,
                         unsigned* round_work, unsigned* round_work_lat, unsigned* view_count, unsigned* view_mode,
-                        unsigned handover, int round) {
+                        unsigned handover, int round, unsigned* items, unsigned* round_items) {
     SweepArgs a;
     a.jobs = jobs; a.work = work; a.work_lat = work_lat; a.round_work = round_work; a.round_work_lat = round_work_lat;
     a.view_count = view_count; a.view_mode = view_mode; a.handover = handover; a.n_jobs = n_jobs; a.round = round;
+    a.items = items; a.round_items = round_items;
     hipLaunchKernelGGL(k_generate, dim3(max_tiles, n_jobs), dim3(256), 0, s, a);
 }
 

@@ -224,13 +224,15 @@ struct BatchScratch {
     DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] per round: size of the list of the views in the latency layout (host-visible
                                               * rounds), accepted entries (fused tail rounds) */
     DevBuf<unsigned> d_round_work_t;         /* [MI_MAX_ROUNDS] per round: size of the list of the views in the throughput layout */
+    DevBuf<unsigned> d_round_items;          /* [MI_MAX_ROUNDS] per round: (entry, candidate) pairs of that list (speculative rounds) */
     DevBuf<unsigned> d_view;                 /* k_generate: [3][n_jobs] entries per view of the last rounds | [n_jobs] hand-over rounds */
     DevBuf<unsigned> d_front;                /* k_front: [n_jobs] list offsets | [n_jobs] list sizes | [n_jobs][4] per-view statistics |
                                               * [n_jobs] pixels filled by the view's team */
     DevBuf<unsigned long long> d_front_resume;   /* k_front: [2][n_jobs] where a view goes on (FrontArgs::job_resume / job_start) */
     DevBuf<unsigned long long> d_front_mail; /* k_front teams: a mailbox per view (MI_FRONT_MAIL_WORDS) */
     DevBuf<unsigned> d_front_flags;          /* ... and MI_FRONT_TEAM_MAX pass flags per view */
-    DevBuf<unsigned> d_follow;               /* 2 x work-list capacity: entries that continue with their next hypothesis */
+    DevBuf<unsigned> d_follow;               /* 4 x work-list capacity: entries that continue with their next hypothesis (two-launch
+                                              * rounds) / the (entry, candidate) items of a speculative round (at most four per entry) */
     DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
     DevBuf<DevSpec> d_spec;                  /* speculative small rounds: four attempt records per entry (BatchRun::bulk_rounds) */
     TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
@@ -246,13 +248,13 @@ struct BatchScratch {
     /* the buffers whose size goes with the pixels of a batch (imaps: 4 words per pixel, 6 with eight view slots) */
     int reserve_pixels(size_t px, size_t n_imaps) {
         return d_maps.reserve(px * 14) || d_imaps.reserve(px * n_imaps) || d_work.reserve(px) || d_work2.reserve(px)
-            || d_results.reserve(px) || d_results2.reserve(px) || d_keys.reserve(px) || d_follow.reserve(2 * px);
+            || d_results.reserve(px) || d_results2.reserve(px) || d_keys.reserve(px) || d_follow.reserve(4 * px);
     }
     /* room for a batch of `px` pixels: all pixel-proportional buffers together, so that a set is either large enough or
      * grows once */
     int ensure_pixels(size_t px, size_t n_imaps) {
         if (d_maps.cap >= px * 14 && d_imaps.cap >= px * n_imaps && d_work.cap >= px && d_work2.cap >= px && d_results.cap >= px
-            && d_results2.cap >= px && d_keys.cap >= px && d_follow.cap >= 2 * px)
+            && d_results2.cap >= px && d_keys.cap >= px && d_follow.cap >= 4 * px)
             return 0;
         return reserve_pixels(px, n_imaps);                           /* (DevBuf::reserve adds the headroom) */
     }
@@ -262,7 +264,7 @@ struct BatchScratch {
         events.clear();
         d_jobs.release(); d_work.release(); d_work2.release(); d_hyp.release(); d_results.release(); d_results2.release();
         d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_keys.release(); d_keyoff.release();
-        d_round_work.release(); d_round_work_t.release(); d_view.release(); d_front.release(); d_front_resume.release();
+        d_round_work.release(); d_round_work_t.release(); d_round_items.release(); d_view.release(); d_front.release(); d_front_resume.release();
         d_front_mail.release(); d_front_flags.release();
         d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release();
         if (h_poll) (void)hipHostFree(h_poll);
@@ -1296,12 +1298,13 @@ int BatchRun::upload() {
     keyoff.resize(nj);
     for (int j = 0; j < nj; ++j) keyoff[j] = (unsigned)jobs[j].pix_off;
     if (c->bs.d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->bs.d_keyoff.reserve(nj)
-        || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_round_work_t.reserve(MI_MAX_ROUNDS)
+        || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_round_work_t.reserve(MI_MAX_ROUNDS) || c->bs.d_round_items.reserve(MI_MAX_ROUNDS)
         || c->bs.d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->bs.d_view.reserve(4 * (size_t)nj)
         || c->bs.d_front.reserve(7 * (size_t)nj) || c->bs.d_front_resume.reserve(2 * (size_t)nj))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(work lists) failed");
     HIP_TRY(hipMemsetAsync(c->bs.d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
     HIP_TRY(hipMemsetAsync(c->bs.d_round_work_t.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
+    HIP_TRY(hipMemsetAsync(c->bs.d_round_items.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
     /* MI_DMRECON_VIEW_HANDOVER=<entries> (read per call): a view's own list size below which it leaves the throughput
      * layout for good (k_generate decides, per view, on the device); 0 = never, 1000000000 = from the first round on */
     if (const char* e = std::getenv("MI_DMRECON_VIEW_HANDOVER")) handover = (unsigned)std::max(0L, std::atol(e));
@@ -1405,9 +1408,12 @@ int BatchRun::bulk_rounds(bool& to_tail) {
     Pending pend[2]; int n_pend = 0;
     bool stop = false;
     auto enqueue = [&](int r) -> int {
+        /* a round that will not fill the GPU several times over: speculative launches for lists below spec_cap, the plain
+         * ones (below) only above it */
+        const bool spec = SPEC_MAX > 0 && known_thr < SPEC_MAX;
         ev.begin(S, EventLog::SWEEP, 0);
         D->generate(S, c->bs.d_jobs.p, nj, max_tiles, c->bs.d_work.p, c->bs.d_work2.p, c->bs.d_round_work_t.p, c->bs.d_round_work.p,
-                    d_vcount, d_vmode, handover, r);
+                    d_vcount, d_vmode, handover, r, spec ? c->bs.d_follow.p : nullptr, c->bs.d_round_items.p);
         ev.end(S);
         const unsigned* n_thr_p = c->bs.d_round_work_t.p + r; const unsigned* n_lat_p = c->bs.d_round_work.p + r;
         const unsigned est = std::max(2u * known_thr, 65536u);
@@ -1419,13 +1425,12 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         const size_t ev_thr = ev.items.size() - 1;
         size_t ev_lat = (size_t)-1;
         unsigned* fcnt = c->bs.d_follow_cnt.p + 4 * (size_t)r;
-        /* a small round: speculative launches for lists below spec_cap, the plain ones (below) only above it */
-        const bool spec = SPEC_MAX > 0 && known_thr < SPEC_MAX;
         const unsigned plain_min = spec ? spec_cap : 0u;
         if (spec) {
-            const unsigned quads = 4u * std::min(std::max(2u * known_thr, 4096u), spec_cap);
-            D->optimize_spec(S, (quads + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, c->bs.d_spec.p, n_thr_p,
-                             0u, 0u, spec_cap, r, c->d_counters);
+            /* (items: ~1.3 per entry; the list of them is the follow-up buffer, which a speculative round does not use) */
+            const unsigned quads = std::min(std::max(3u * known_thr, 16384u), 4u * spec_cap);
+            D->optimize_spec(S, (quads + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, c->bs.d_spec.p,
+                             c->bs.d_follow.p, c->bs.d_round_items.p + r, n_thr_p, 0u, 0u, spec_cap, r, c->d_counters);
         }
         /* Rounds below MI_ONE_LAUNCH_MAX entries run as ONE launch of the general kernel, all attempts of an entry in a
          * row: such a launch fits the GPU at once, so either launch of the two-launch form lasts one wavefront-life
