@@ -70,7 +70,7 @@ struct MiDeviceApi {
                   int n_xcd /* teams: XCDs of the device; a view's team is confined to the blocks of one (b % n_xcd) */);
     /* optimize_spec -- a round of the throughput layout with every (entry, candidate rank) pair on a quad of its own: `items`
      * (entry << 2 | rank, *n_items of them: written by `generate` when given an item list) are the attempts, spec holds
-     * 4 x entries records; mi_launch_apply_spec applies the reference's sequential rule to the records and writes the
+     * one record per item; mi_launch_apply_spec applies the reference's sequential rule to the records and writes the
      * pixels back.  Same maps and counters as `optimize` + mi_launch_apply. */
     void (*optimize_spec)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                           const DevSettings& st, const DevEntry* work, DevSpec* spec, const unsigned* items, const unsigned* n_items,
@@ -87,7 +87,7 @@ extern unsigned long long* mi_debug_tbuf;
 void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                      const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters);
 void mi_launch_apply_spec(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevSpec* spec,
-                          const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters);
+                          const unsigned* items, const unsigned* n_items, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters);
 /* maps: [slot 0: depth | conf | dz x2 | normal x3][slot 1: same], imaps: [views | upd][views1 | upd1], per batch */
 /* eight_views: imaps also holds [views_hi | views1_hi] behind them (nrReconNeighbors > 4) */
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px, bool eight_views);

@@ -1586,7 +1586,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_BULK_WA
         const unsigned e = item >> 2; const int s = (int)(item & 3u);
         const DevEntry ent = a.work[e];
         const DevJob* job = a.jobs + ent.job;
-        DevSpec* rec = t.spec + item;
+        DevSpec* rec = t.spec + i;                        /* (an entry's items are consecutive, rank 0 first: k_generate) */
         if (GI(&job->flags) != 0) {                       /* the view failed or was cancelled: nothing of it is touched any more */
             if (writer && s == 0) rec->n_cand = 0;
             continue;
@@ -2535,7 +2535,9 @@ struct ApplyArgs {
     const DevJob* jobs;
     const DevEntry* work;
     const DevResult* results;
-    const DevSpec* spec;             /* k_apply_spec: the speculative attempts of the entries */
+    const DevSpec* spec;             /* k_apply_spec: the speculative attempts, one record per item */
+    const unsigned* items;           /* ... the round's (entry << 2 | rank) items, an entry's consecutive and rank 0 first */
+    const unsigned* n_items;
     const unsigned* n_work_ptr;
     unsigned n_work;
     unsigned min_work, max_work;     /* the launch only acts if min_work <= n < max_work */
@@ -2597,12 +2599,15 @@ __global__ __launch_bounds__(256) void k_apply_spec(ApplyArgs a) {
     const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
     if (n < a.min_work || n >= a.max_work) return;
     unsigned filled = 0, n_eval = 0, n_pass = 0, n_patch = 0;
-    for (unsigned base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
-        const unsigned e = base + threadIdx.x;
+    const unsigned n_items = *a.n_items;
+    for (unsigned base = blockIdx.x * 256; base < n_items; base += gridDim.x * 256) {
+        const unsigned i = base + threadIdx.x;
         bool newly = false;
         int myjob = -1;
-        if (e < n) {
-            const DevSpec* rec = a.spec + 4 * (size_t)e;
+        const unsigned item = i < n_items ? a.items[i] : 1u;
+        if ((item & 3u) == 0u) {                             /* one lane per entry: the one that holds its rank-0 item */
+            const unsigned e = item >> 2;
+            const DevSpec* rec = a.spec + i;
             const int n_cand = rec[0].n_cand;
             if (n_cand > 0) {
                 const float own = rec[0].own;
@@ -2832,16 +2837,17 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
                      const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters) {
     if (grid_blocks == 0) return;
     ApplyArgs a;
-    a.jobs = jobs; a.work = work; a.results = results; a.spec = nullptr; a.n_work_ptr = n_work_ptr; a.n_work = n_work;
+    a.jobs = jobs; a.work = work; a.results = results; a.spec = nullptr; a.items = nullptr; a.n_items = nullptr; a.n_work_ptr = n_work_ptr; a.n_work = n_work;
     a.min_work = min_work; a.max_work = max_work; a.round = round;
     a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0;
     hipLaunchKernelGGL(k_apply, dim3(grid_blocks), dim3(256), 0, s, a);
 }
 void mi_launch_apply_spec(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevSpec* spec,
+                          const unsigned* items, const unsigned* n_items,
                           const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters) {
     if (grid_blocks == 0) return;
     ApplyArgs a;
-    a.jobs = jobs; a.work = work; a.results = nullptr; a.spec = spec; a.n_work_ptr = n_work_ptr; a.n_work = n_work;
+    a.jobs = jobs; a.work = work; a.results = nullptr; a.spec = spec; a.items = items; a.n_items = n_items; a.n_work_ptr = n_work_ptr; a.n_work = n_work;
     a.min_work = min_work; a.max_work = max_work; a.round = round;
     a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0;
     hipLaunchKernelGGL(k_apply_spec, dim3(grid_blocks), dim3(256), 0, s, a);
@@ -2926,7 +2932,7 @@ void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* wo
                            const unsigned* key_off) {
     if (n_work == 0) return;
     ApplyArgs a;
-    a.jobs = jobs; a.work = work; a.results = results; a.spec = nullptr; a.n_work_ptr = nullptr; a.n_work = n_work; a.round = 0;
+    a.jobs = jobs; a.work = work; a.results = results; a.spec = nullptr; a.items = nullptr; a.n_items = nullptr; a.n_work_ptr = nullptr; a.n_work = n_work; a.round = 0;
     a.min_work = 0; a.max_work = 0xFFFFFFFFu;
     a.counters = counters; a.seed_keys = seed_keys; a.key_off = key_off;
     a.phase = 0;

@@ -159,7 +159,7 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 #define MI_MERGE_WINDOW_US 1000
 #define MI_MERGE_WINDOW_BIG_US 150  /* ... from this size on only this long (see mi_dmrecon_reconstruct) */
 #define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
-#define MI_SPEC_ROUNDS 32768u      /* throughput rounds below this many entries try an entry's candidate hypotheses at the same time */
+#define MI_SPEC_ROUNDS 400000u      /* throughput rounds below this many entries try an entry's candidate hypotheses at the same time */
 #define MI_VIEW_HANDOVER 320u      /* a view leaves the throughput layout once a round's list of its own is shorter than this */
 #define MI_TEAM_WAIT_US 20000u     /* a front team member waits this long for the others before the team gives up */
 #define MI_FRONT_MIN_CAP 256       /* hand-over to k_front: entries per view, at least */
@@ -1464,7 +1464,8 @@ int BatchRun::bulk_rounds(bool& to_tail) {
             ++n_launch;
         }
         ev.begin(S, EventLog::SWEEP, 0);
-        if (spec) mi_launch_apply_spec(S, std::min((spec_cap + 255) / 256, 1024u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_spec.p, n_thr_p, 0u, 0u, spec_cap, r, c->d_counters);
+        if (spec) mi_launch_apply_spec(S, std::min((std::max(3u * known_thr, 16384u) + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_spec.p,
+                                       c->bs.d_follow.p, c->bs.d_round_items.p + r, n_thr_p, 0u, 0u, spec_cap, r, c->d_counters);
         mi_launch_apply(S, std::min((est + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, n_thr_p, 0u, plain_min, 0xFFFFFFFFu, r, c->d_counters);
         if (any_lat) mi_launch_apply(S, std::min((std::max(2u * known_lat, 1024u) + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work2.p, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters);
         ev.end(S);

@@ -118,7 +118,8 @@ struct DevResult {
 
 /* One candidate hypothesis of a work-list entry optimised SPECULATIVELY (small throughput rounds, k_optimize_spec): the
  * entry's up to four candidates run at the same time on four quads, the reference's sequential rule (dmrecon.cc:371,378,391)
- * is applied afterwards from these records (k_apply_spec).  Record of (entry e, rank s) at [4 e + s]. */
+ * is applied afterwards from these records (k_apply_spec).  One record per item of the round's item list (an entry's items
+ * are consecutive, rank 0 first). */
 struct DevSpec {
     float conf, depth, dzI, dzJ, nx, ny, nz;
     uint32_t views, views_hi;
