@@ -2642,14 +2642,26 @@ __global__ __launch_bounds__(256) void k_apply_spec(ApplyArgs a) {
             todo &= ~same;
         }
     }
+    /* the call's counters: one atomic per workgroup and counter (an atomic on one word costs ~10 ns: per wavefront they
+     * were most of this kernel's time) */
+    __shared__ unsigned s_red[4];
+    if (threadIdx.x < 4) s_red[threadIdx.x] = 0;
+    __syncthreads();
     for (int off = 32; off > 0; off >>= 1) {
         n_eval += __shfl_down(n_eval, off); n_pass += __shfl_down(n_pass, off); n_patch += __shfl_down(n_patch, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (filled) atomicAdd(&a.counters->n_filled, (unsigned long long)filled);
-        if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
-        if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
-        if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
+        if (filled) atomicAdd(&s_red[0], filled);
+        if (n_eval) atomicAdd(&s_red[1], n_eval);
+        if (n_pass) atomicAdd(&s_red[2], n_pass);
+        if (n_patch) atomicAdd(&s_red[3], n_patch);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_red[0]) atomicAdd(&a.counters->n_filled, (unsigned long long)s_red[0]);
+        if (s_red[1]) atomicAdd(&a.counters->n_eval, (unsigned long long)s_red[1]);
+        if (s_red[2]) atomicAdd(&a.counters->n_pass, (unsigned long long)s_red[2]);
+        if (s_red[3]) atomicAdd(&a.counters->n_patch, (unsigned long long)s_red[3]);
     }
 }
 

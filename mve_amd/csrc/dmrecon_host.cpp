@@ -1464,7 +1464,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
             ++n_launch;
         }
         ev.begin(S, EventLog::SWEEP, 0);
-        if (spec) mi_launch_apply_spec(S, std::min((std::max(3u * known_thr, 16384u) + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_spec.p,
+        if (spec) mi_launch_apply_spec(S, std::min((std::max(3u * known_thr, 16384u) + 255) / 256, 768u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_spec.p,
                                        c->bs.d_follow.p, c->bs.d_round_items.p + r, n_thr_p, 0u, 0u, spec_cap, r, c->d_counters);
         mi_launch_apply(S, std::min((est + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, n_thr_p, 0u, plain_min, 0xFFFFFFFFu, r, c->d_counters);
         if (any_lat) mi_launch_apply(S, std::min((std::max(2u * known_lat, 1024u) + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work2.p, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters);
