@@ -67,7 +67,9 @@ struct MiDeviceApi {
                   const unsigned long long* job_start, unsigned long long* job_resume, unsigned* team_filled, unsigned spin_ticks,
                   int fault /* test hook: member | round << 8 of the team member that vanishes (member 255: none), bit 24: the
                              * team writes through its L2s as if found on several XCDs; -1 = none */,
-                  int n_xcd /* teams: XCDs of the device; a view's team is confined to the blocks of one (b % n_xcd) */);
+                  int n_xcd /* teams: XCDs of the device; a view's team is confined to the blocks of one (b % n_xcd) */,
+                  unsigned* host_done /* page-locked host memory, n_jobs zeroed words, or null: set to 1 per view that has run to its
+                                       * end, after its state has been written back to memory */);
     /* optimize_spec -- a round of the throughput layout with every (entry, candidate rank) pair on a quad of its own: `items`
      * (entry << 2 | rank, *n_items of them: written by `generate` when given an item list) are the attempts, spec holds
      * one record per item; mi_launch_apply_spec applies the reference's sequential rule to the records and writes the
@@ -90,7 +92,8 @@ void mi_launch_apply_spec(hipStream_t s, unsigned grid_blocks, const DevJob* job
                           const unsigned* items, const unsigned* n_items, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work, unsigned max_work, int round, DevCounters* counters);
 /* maps: [slot 0: depth | conf | dz x2 | normal x3][slot 1: same], imaps: [views | upd][views1 | upd1], per batch */
 /* eight_views: imaps also holds [views_hi | views1_hi] behind them (nrReconNeighbors > 4) */
-void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px, bool eight_views);
+/* ... for the pixels [first, first + count) of the batch */
+void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px, bool eight_views, size_t first, size_t count);
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
                            const unsigned* key_off);

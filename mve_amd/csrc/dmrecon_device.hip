@@ -1901,6 +1901,10 @@ struct FrontArgs {
     unsigned spin_ticks;          /* a member waits this long (100 MHz ticks) for the others at an exchange, then the team gives up */
     int n_jobs;                   /* TEAM: views of the launch (the grid is padded to whole XCD rows) */
     int n_xcd;                    /* TEAM: XCDs the blocks are dealt over (block b runs on XCD b % n_xcd: observed, not promised -- checked) */
+    unsigned* host_done;          /* page-locked HOST memory, [n_jobs] zeroed, or null: a view that has run to its end says so here, after its
+                                   * state has been written back from the cache to memory -- the host can flatten and copy its maps while
+                                   * the other views still run */
+    int l2_exchange;              /* TEAM: a team on one XCD exchanges through its L2 (0: always through memory) */
     int force_write_through;      /* test hook (MI_DMRECON_DEBUG_TEAM_WT): as if a team's members had been found on different XCDs */
     int fault_member, fault_round; /* test hook (MI_DMRECON_DEBUG_FRONT_FAULT): this member of every team vanishes at that round of its
                                     * view (0 = it never shows up), as one that is not given a compute unit would; -1 = none */
@@ -1981,6 +1985,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
     }
     gflag_t fl = TEAM ? (gflag_t)(t.team_flags + (size_t)jobi * MI_FRONT_FLAG_STRIDE) : nullptr;
     bool write_through = false;                    /* TEAM: set after the first exchange (uniform over the team) */
+    bool via_l2 = false;                           /* TEAM: the exchanges go through the one L2 of the team's XCD (from the second on) */
     if (TEAM) {
         if (tid == 0) {
             /* my XCC id into the team's registration word; a second id there marks the team as spread over several XCDs */
@@ -2137,12 +2142,20 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                     if (lane == 0) {
                         FR& o = g_fr[qi][s]; o.r = r; o.n_eval = ce; o.n_pass = cp; o.ready = 1; ++st_att;
                         if (TEAM) {
-                            /* to the other members: every word with the pass's tag in one 8-byte agent-scope store (write-through) */
+                            /* to the other members: every word with the pass's tag in one 8-byte store.  A team on ONE XCD (known
+                             * after the first exchange) hands over through that XCD's L2: plain stores stay there (the L1 writes
+                             * through), the readers' agent-scope loads bypass their L1 and are served from it.  Before that, and
+                             * for a team on several XCDs: agent-scope stores, through to memory. */
                             const unsigned* wsrc = (const unsigned*)&o;
                             gmail_t rec = box + (size_t)idx * MI_FRONT_GRAN;
+                            if (via_l2) {
 #pragma unroll
-                            for (int k = 0; k < MI_FRONT_GRAN; ++k)
-                                __hip_atomic_store(rec + k, ((unsigned long long)epoch << 32) | wsrc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                for (int k = 0; k < MI_FRONT_GRAN; ++k) rec[k] = ((unsigned long long)epoch << 32) | wsrc[k];
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < MI_FRONT_GRAN; ++k)
+                                    __hip_atomic_store(rec + k, ((unsigned long long)epoch << 32) | wsrc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                     }
                 }
@@ -2154,7 +2167,11 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                      * results.  Flags only ever grow, a member is waited for until its flag has REACHED this pass (it may be
                      * a pass ahead by the time it is looked at: it cannot be two, the next exchange needs my flag), and not
                      * for ever: the wait is bounded by the wall clock */
-                    if (tid == 0) __hip_atomic_store(fl + member, epoch | (g_fcnt[6] != 0 ? MI_FLAG_ENDED : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) {
+                        const unsigned fv = epoch | (g_fcnt[6] != 0 ? MI_FLAG_ENDED : 0u);
+                        if (via_l2) *(volatile unsigned*)(t.team_flags + (size_t)jobi * MI_FRONT_FLAG_STRIDE + member) = fv;
+                        else __hip_atomic_store(fl + member, fv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     if (tid < T) {
                         unsigned f = 0; bool seen = false;
                         const unsigned long long w0 = wall_clock64();
@@ -2177,8 +2194,10 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
                         abort = true; break;
                     }
                     /* everybody has registered by now (a member registers before its first flag) */
-                    if (epoch == 1u)
+                    if (epoch == 1u) {
                         write_through = __hip_atomic_load(fl + MI_FRONT_TEAM_MAX + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                        via_l2 = !write_through && t.l2_exchange != 0;
+                    }
                     for (unsigned u = (unsigned)tid; u < natt * MI_FRONT_GRAN; u += MI_FRONT_WAVES * WAVE) {
                         const unsigned idx = u / MI_FRONT_GRAN, k = u - idx * MI_FRONT_GRAN;
                         if ((int)(idx % (unsigned)T) == member) continue;
@@ -2272,6 +2291,12 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
         }
         cur ^= 1;
         __syncthreads();
+    }
+    /* a view that ran to its end (nothing accepted in its last round: every member's writes of the rounds before are in the
+     * L2 -- they were acknowledged before the last exchange): one lane writes the cache back and tells the host */
+    if (t.host_done && tid == 0 && member == 0 && n_prev == 0 && !abort) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(t.host_done + jobi, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     /* how far the view has got (see FrontArgs::job_resume): done, or the round a given-up team stopped in */
     if (tid == 0) {
@@ -2891,7 +2916,7 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
                          const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
                          DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags,
                          const unsigned long long* job_start, unsigned long long* job_resume, unsigned* team_filled, unsigned spin_ticks,
-                         int fault, int n_xcd) {
+                         int fault, int n_xcd, unsigned* host_done) {
     static_assert(MI_FRONT_MAIL_WORDS == 2 * MI_FRONT_QCAP * 4 * MI_FRONT_GRAN, "mailbox size");
     if (n_jobs <= 0) return;
     if (!job_start) {
@@ -2910,9 +2935,11 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
     t.job_stats = job_stats; t.max_rounds = max_rounds;
     t.team = 1; t.mail = nullptr; t.team_flags = nullptr; t.team_filled = team_filled; t.spin_ticks = spin_ticks;
     t.fault_member = fault < 0 ? -1 : (fault & 0xFF); t.fault_round = fault < 0 ? 0 : ((fault >> 8) & 0xFFFF);
-    t.force_write_through = fault >= 0 && (fault >> 24) != 0;
+    t.force_write_through = fault >= 0 && ((fault >> 24) & 1) != 0;
     if (fault >= 0 && (fault & 0xFF) == 0xFF) t.fault_member = -1;          /* (write-through forced, nobody vanishes) */
     t.n_jobs = n_jobs; t.n_xcd = n_xcd < 1 ? 1 : n_xcd;
+    t.l2_exchange = (fault >= 0 && ((fault >> 25) & 1)) ? 0 : 1;
+    t.host_done = host_done;
     if (team > 1 && mail && team_flags && team_filled) {
         t.team = team > MI_FRONT_TEAM_MAX ? MI_FRONT_TEAM_MAX : team; t.mail = mail; t.team_flags = team_flags;
         /* whole rows of n_xcd blocks: view j's team = the blocks b with b % n_xcd == j % n_xcd of its rows */
@@ -2926,17 +2953,18 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
 }
 
 #if MI_FW == 5
-void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px, bool eight_views) {
-    if (total_px == 0) return;
+void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px, bool eight_views, size_t first, size_t count) {
+    if (total_px == 0 || count == 0) return;
     FlattenArgs a;
-    a.depth = maps; a.conf = maps + total_px; a.dz = maps + 2 * total_px; a.normal = maps + 4 * total_px;
+    /* (the pixels [first, first + count) of the batch: one view's, or all) */
+    a.depth = maps + first; a.conf = maps + total_px + first; a.dz = maps + 2 * total_px + 2 * first; a.normal = maps + 4 * total_px + 3 * first;
     float* m1 = maps + 7 * total_px;
-    a.depth1 = m1; a.conf1 = m1 + total_px; a.dz1 = m1 + 2 * total_px; a.normal1 = m1 + 4 * total_px;
-    a.views = imaps; a.upd = (int32_t*)(imaps + total_px);
-    a.views1 = imaps + 2 * total_px; a.upd1 = (const int32_t*)(imaps + 3 * total_px);
-    a.views_hi = eight_views ? imaps + 4 * total_px : nullptr; a.views1_hi = eight_views ? imaps + 5 * total_px : nullptr;
-    a.n = (unsigned)total_px;
-    hipLaunchKernelGGL(k_flatten, dim3((unsigned)((total_px + 255) / 256)), dim3(256), 0, s, a);
+    a.depth1 = m1 + first; a.conf1 = m1 + total_px + first; a.dz1 = m1 + 2 * total_px + 2 * first; a.normal1 = m1 + 4 * total_px + 3 * first;
+    a.views = imaps + first; a.upd = (int32_t*)(imaps + total_px + first);
+    a.views1 = imaps + 2 * total_px + first; a.upd1 = (const int32_t*)(imaps + 3 * total_px + first);
+    a.views_hi = eight_views ? imaps + 4 * total_px + first : nullptr; a.views1_hi = eight_views ? imaps + 5 * total_px + first : nullptr;
+    a.n = (unsigned)count;
+    hipLaunchKernelGGL(k_flatten, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,

@@ -239,6 +239,8 @@ struct BatchScratch {
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     uint8_t* h_dyn = nullptr;                /* pinned: read-backs of the jobs' flags / n_filled words (JobDyn), three slots */
     size_t h_dyn_cap = 0;
+    unsigned* h_done = nullptr;              /* pinned, written by k_front: views that have run to their end */
+    size_t h_done_cap = 0;
     std::vector<int32_t> h_jobdyn;           /* staging of the flag words written to dead jobs */
     DevBuf<int32_t> d_gvs_feat, d_gvs_out;   /* scratch and result of the device view selection */
     DevBuf<float> d_gvs_base, d_gvs_benefit;
@@ -269,7 +271,8 @@ struct BatchScratch {
         d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release();
         if (h_poll) (void)hipHostFree(h_poll);
         if (h_dyn) (void)hipHostFree(h_dyn);
-        h_poll = nullptr; h_dyn = nullptr; h_dyn_cap = 0;
+        if (h_done) (void)hipHostFree(h_done);
+        h_poll = nullptr; h_dyn = nullptr; h_dyn_cap = 0; h_done = nullptr; h_done_cap = 0;
         for (int k = 0; k < 2; ++k) { if (poll_ev[k]) (void)hipEventDestroy(poll_ev[k]); poll_ev[k] = nullptr; }
     }
 };
@@ -318,6 +321,7 @@ struct mi_dmrecon_ctx {
     int device = 0;
     int n_cus = 64;                          /* compute units (queried at creation) */
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           /* copies of finished views back to the host while the front kernel still runs */
     std::shared_ptr<SceneStore> sc;
     DevCounters* d_counters = nullptr;
     DevBuf<uint8_t> d_stage;
@@ -897,6 +901,7 @@ void mi_dmrecon_settings_default(mi_dmrecon_settings* s) {          /* libs/dmre
 
 static int create_streams(mi_dmrecon_ctx* c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     /* compute units of this device (a partitioned GPU has fewer than 256): what a front launch with teams may occupy */
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->n_cus = cus;
@@ -933,10 +938,12 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     c->bs.release();
     c->d_stage.release(); c->d_stage2.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;                                 /* the scene store goes with its last owner */
 }
 
@@ -1180,6 +1187,9 @@ struct BatchRun {
     /* list + results of the last executed tail round, and their ping-pong partners */
     DevEntry* wcur = nullptr; DevEntry* wnext = nullptr; DevResult* rcur = nullptr; DevResult* rnext = nullptr;
     /* the front kernel (phase C) */
+    std::vector<char> streamed;                /* views whose maps went back to the host while the front kernel still ran */
+    int n_streamed = 0;
+    int stream_view(int j);
     bool ran_front = false; int front_first_round = 0, front_team = 1, front_fallbacks = 0;
     unsigned handover = MI_VIEW_HANDOVER;      /* k_generate: a view's own list size below which it leaves the throughput layout */
     bool host_rounds_only = false;             /* diagnostic: every round host-visible (MI_DMRECON_HOST_ROUNDS) */
@@ -1689,7 +1699,10 @@ int BatchRun::front_rounds() {
             f = (std::atoi(e) & 0xFF) | ((colon ? std::max(0, std::atoi(colon + 1)) & 0xFFFF : 0) << 8);
         }
         /* test hook, MI_DMRECON_DEBUG_TEAM_WT=1: the teams behave as if their members had been found on several XCDs */
-        if (const char* e = std::getenv("MI_DMRECON_DEBUG_TEAM_WT")) if (std::atoi(e) != 0) f = (f < 0 ? 0xFF : f) | (1 << 24);
+        if (const char* e = std::getenv("MI_DMRECON_DEBUG_TEAM_WT")) {
+            if (std::atoi(e) == 1) f = (f < 0 ? 0xFF : f) | (1 << 24);
+            if (std::atoi(e) == 2) f = (f < 0 ? 0xFF : f) | (1 << 25);       /* 2: exchanges through memory even within one XCD (A/B) */
+        }
         return f;
     }();
     std::unique_ptr<TeamToken> token;
@@ -1704,6 +1717,18 @@ int BatchRun::front_rounds() {
         HIP_TRY(hipMemsetAsync(c->bs.d_front_flags.p, 0, (size_t)nj * MI_FRONT_FLAG_STRIDE * sizeof(unsigned), S));
     }
     front_stats.assign(4 * (size_t)nj, 0u);
+    /* maps of finished views go back while the others run (not for calls with a progress array: a view that is cancelled
+     * after it has ended must not have been written, dmrecon.cc:101-105) */
+    unsigned* h_done = nullptr;
+    streamed.assign((size_t)nj, 0);
+    if (!progress) {
+        if (c->bs.h_done_cap < (size_t)nj) {
+            if (c->bs.h_done) (void)hipHostFree(c->bs.h_done);
+            c->bs.h_done = nullptr; c->bs.h_done_cap = 0;
+            if (hipHostMalloc((void**)&c->bs.h_done, (2 * (size_t)nj + 64) * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) c->bs.h_done_cap = 2 * (size_t)nj + 64;
+        }
+        if (c->bs.h_done) { h_done = c->bs.h_done; std::memset(h_done, 0, (size_t)nj * sizeof(unsigned)); }
+    }
     TailPoll& P = c->bs.h_poll[0];
     const int max_round = round + 4 * MI_MAX_ROUNDS;
     /* the first launch deals the last tail round's list out to the views and runs them (as teams, if any); should the
@@ -1717,12 +1742,26 @@ int BatchRun::front_rounds() {
                  again ? 1 : front_team, (!again && front_team > 1) ? c->bs.d_front_mail.p : nullptr,
                  (!again && front_team > 1) ? c->bs.d_front_flags.p : nullptr,
                  again ? d_resume : nullptr, again ? d_resume + nj : d_resume, d_filled, spin_ticks, again ? -1 : fault,
-                 std::max(1, c->n_cus / 32));
+                 std::max(1, c->n_cus / 32), h_done);
         ev.end(S);
         ++n_launch;
         HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
         HIP_TRY(read_dyn(0));
         HIP_TRY(hipMemcpyAsync(front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
+        if (h_done) {
+            /* while the kernel runs: a view that has ended (it said so in page-locked memory, after writing its state back)
+             * is flattened and copied to the caller's buffers on a second stream -- the views end at very different times
+             * (C3: between 2.5 and 14.5 ms), only the slowest ones' maps are left when the kernel is over */
+            HIP_TRY(hipEventRecord(c->bs.poll_ev[0], S));
+            for (;;) {
+                const bool over = hipEventQuery(c->bs.poll_ev[0]) != hipErrorNotReady;
+                for (int j = 0; j < nj; ++j)
+                    if (!streamed[j] && __atomic_load_n(&h_done[j], __ATOMIC_ACQUIRE) != 0u)
+                        if (int rc = stream_view(j)) return rc;
+                if (over || n_streamed == nj) break;
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+        }
         HIP_TRY(hipStreamSynchronize(S));
         hc = P.hc;
         token.reset();                                            /* the teams are gone either way */
@@ -1748,12 +1787,31 @@ int BatchRun::front_rounds() {
     return 0;
 }
 
+/* One finished view's maps to the caller's buffers on the second stream (the front kernel still runs on the first): its
+ * second state slot folded in, then the copies.  The local view sets (host post-processing) stay for download(). */
+int BatchRun::stream_view(int j) {
+    streamed[j] = 1; ++n_streamed;
+    const int i = ref_of_job[j];
+    if (view_rc[i] != 0) return 0;
+    mi_dmrecon_maps& m = maps[i];
+    if (m.views) { streamed[j] = 2; return 0; }              /* (2: ended, but everything is left to download()) */
+    const size_t np = (size_t)jobs[j].w * jobs[j].h;
+    hipStream_t S2 = c->stream2;
+    mi_launch_flatten(S2, c->bs.d_maps.p, c->bs.d_imaps.p, total_px, st->nrReconNeighbors > 4, jobs[j].pix_off, np);
+    if (m.depth) HIP_TRY(hipMemcpyAsync(m.depth, dj[j].depth, np * 4, hipMemcpyDeviceToHost, S2));
+    if (m.conf) HIP_TRY(hipMemcpyAsync(m.conf, dj[j].conf, np * 4, hipMemcpyDeviceToHost, S2));
+    if (m.dz) HIP_TRY(hipMemcpyAsync(m.dz, dj[j].dz, np * 8, hipMemcpyDeviceToHost, S2));
+    if (m.normal) HIP_TRY(hipMemcpyAsync(m.normal, dj[j].normal, np * 12, hipMemcpyDeviceToHost, S2));
+    return 0;
+}
+
 /* ---- results back to the caller's buffers (views that did not finish keep their buffers untouched) */
 int BatchRun::download() {
     std::vector<uint32_t> packed;
     for (int i = 0; i < n_refs; ++i) {
         const int j = job_of[i];
         if (j < 0 || view_rc[i] != 0) continue;
+        if (!streamed.empty() && streamed[j] == 1) continue;      /* went back while the front kernel ran */
         if (progress) progress[i].status = MI_RECON_SAVING;
         const size_t np = (size_t)jobs[j].w * jobs[j].h;
         mi_dmrecon_maps& m = maps[i];
@@ -1776,6 +1834,7 @@ int BatchRun::download() {
         }
     }
     HIP_TRY(hipStreamSynchronize(S));
+    if (n_streamed) HIP_TRY(hipStreamSynchronize(c->stream2));
     mark("download");
     return 0;
 }
@@ -1891,6 +1950,7 @@ struct ScratchLease {
         /* nothing of this call may still be queued when the set goes back (the early returns of a failed call leave
          * kernels and copies in flight; the next holder would write into them, or free them) */
         (void)hipStreamSynchronize(c->stream);
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         std::lock_guard<std::mutex> lock(c->sc->pool_mu);
         if (c->bs.holds_anything()) c->sc->scratch_pool.push_back(std::move(c->bs));
         c->bs = BatchScratch();
@@ -1935,7 +1995,7 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
             if ((rc = B.tail_rounds(to_front)) != 0) return rc;
             B.mark("phase B rounds");
             if (to_front) { if ((rc = B.front_rounds()) != 0) return rc; B.mark("phase C (front kernel)"); }
-            mi_launch_flatten(B.S, c->bs.d_maps.p, c->bs.d_imaps.p, B.total_px, st->nrReconNeighbors > 4);
+            mi_launch_flatten(B.S, c->bs.d_maps.p, c->bs.d_imaps.p, B.total_px, st->nrReconNeighbors > 4, 0, B.total_px);
         }
         if ((rc = B.download()) != 0) return rc;
         B.fill_stats();
