@@ -1188,7 +1188,7 @@ struct BatchRun {
     DevEntry* wcur = nullptr; DevEntry* wnext = nullptr; DevResult* rcur = nullptr; DevResult* rnext = nullptr;
     /* the front kernel (phase C) */
     std::vector<char> streamed;                /* views whose maps went back to the host while the front kernel still ran */
-    int n_streamed = 0;
+    int n_streamed = 0, n_streamed_early = 0;
     int stream_view(int j);
     bool ran_front = false; int front_first_round = 0, front_team = 1, front_fallbacks = 0;
     unsigned handover = MI_VIEW_HANDOVER;      /* k_generate: a view's own list size below which it leaves the throughput layout */
@@ -1717,15 +1717,18 @@ int BatchRun::front_rounds() {
         HIP_TRY(hipMemsetAsync(c->bs.d_front_flags.p, 0, (size_t)nj * MI_FRONT_FLAG_STRIDE * sizeof(unsigned), S));
     }
     front_stats.assign(4 * (size_t)nj, 0u);
-    /* maps of finished views go back while the others run (not for calls with a progress array: a view that is cancelled
+    /* maps of finished views go back while the others run -- the flags in COHERENT page-locked memory (the default kind is
+     * cached on the device: a running kernel's stores to it only show when the kernel ends) -- (not for calls with a progress array: a view that is cancelled
      * after it has ended must not have been written, dmrecon.cc:101-105) */
     unsigned* h_done = nullptr;
     streamed.assign((size_t)nj, 0);
     if (!progress) {
-        if (c->bs.h_done_cap < (size_t)nj) {
+        /* [views] flags | [views][4] the per-view statistics of the kernel (a copy into pageable memory would hold the host
+         * in the copy call until the kernel is over) */
+        if (c->bs.h_done_cap < 5 * (size_t)nj) {
             if (c->bs.h_done) (void)hipHostFree(c->bs.h_done);
             c->bs.h_done = nullptr; c->bs.h_done_cap = 0;
-            if (hipHostMalloc((void**)&c->bs.h_done, (2 * (size_t)nj + 64) * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) c->bs.h_done_cap = 2 * (size_t)nj + 64;
+            if (hipHostMalloc((void**)&c->bs.h_done, (10 * (size_t)nj + 64) * sizeof(unsigned), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) c->bs.h_done_cap = 10 * (size_t)nj + 64;
         }
         if (c->bs.h_done) { h_done = c->bs.h_done; std::memset(h_done, 0, (size_t)nj * sizeof(unsigned)); }
     }
@@ -1745,24 +1748,29 @@ int BatchRun::front_rounds() {
                  std::max(1, c->n_cus / 32), h_done);
         ev.end(S);
         ++n_launch;
-        HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
-        HIP_TRY(read_dyn(0));
-        HIP_TRY(hipMemcpyAsync(front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
         if (h_done) {
             /* while the kernel runs: a view that has ended (it said so in page-locked memory, after writing its state back)
              * is flattened and copied to the caller's buffers on a second stream -- the views end at very different times
-             * (C3: between 2.5 and 14.5 ms), only the slowest ones' maps are left when the kernel is over */
+             * (C3: between 2.5 and 14.5 ms), only the slowest ones' maps are left when the kernel is over.  (Nothing else is
+             * enqueued behind the kernel before this loop: a strided or pageable read-back holds the host in its call.) */
             HIP_TRY(hipEventRecord(c->bs.poll_ev[0], S));
             for (;;) {
                 const bool over = hipEventQuery(c->bs.poll_ev[0]) != hipErrorNotReady;
                 for (int j = 0; j < nj; ++j)
-                    if (!streamed[j] && __atomic_load_n(&h_done[j], __ATOMIC_ACQUIRE) != 0u)
+                    if (!streamed[j] && __atomic_load_n(&h_done[j], __ATOMIC_ACQUIRE) != 0u) {
                         if (int rc = stream_view(j)) return rc;
+                        if (!over) ++n_streamed_early;
+                        if (trace) fprintf(stderr, "[mi_dmrecon] view %d streamed back at %.3f ms of the front phase (%s)\n", jobs[j].ref_view, now_ms() - t_mark, over ? "kernel over" : "kernel running");
+                    }
                 if (over || n_streamed == nj) break;
                 std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
         }
+        HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
+        HIP_TRY(read_dyn(0));
+        HIP_TRY(hipMemcpyAsync(h_done ? (void*)(h_done + nj) : (void*)front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
         HIP_TRY(hipStreamSynchronize(S));
+        if (h_done) std::memcpy(front_stats.data(), h_done + nj, 4 * (size_t)nj * sizeof(unsigned));
         hc = P.hc;
         token.reset();                                            /* the teams are gone either way */
         if (!(hc.error_flags & 32u)) break;
