@@ -13,7 +13,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 FETCH_CORR = 2.0
@@ -24,6 +24,12 @@ for n in ("1thread", "default", "driver", "1thread_5steps"):
     f = os.path.join(src, "bench_%s.json" % n)
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, "%s_bench_%s.json" % (tag, n)))
+for name, dstname in (("lone_calls.json", "lone_calls.json"), ("valu_rate.txt", "valu_rate.txt"), ("round_trace_c3.txt", "round_trace_c3.txt"),
+                      ("app_c3_timing.txt", "app_c3_timing.txt"), ("cold_call.txt", "cold_call.txt"),
+                      ("strong_2ranks_one_gpu.json", "strong_2ranks_one_gpu.json"), ("bench_c2.json", "bench_c2.json"), ("bench_c5.json", "bench_c5.json")):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, "%s_%s" % (tag, dstname)))
 for s in ("s1", "s3"):
     f = os.path.join(src, s, "bench_kernel_stats.csv")
     if os.path.exists(f):
@@ -37,7 +43,7 @@ def short(name):
 def family(k):
     if "k_tail<" in k or "k_front<" in k:
         return "k_tail + k_front (tail rounds)"
-    if "k_optimize<" in k:
+    if "k_optimize<" in k or "k_optimize_spec<" in k:
         return "k_optimize<1> (host-visible rounds)"
     return None
 
@@ -106,6 +112,23 @@ for prefix, plan in (("pmc", "1 host thread, 1 step per call"), ("pmcd", "defaul
         traffic["plans"][plan] = {fm: {"read_bytes_per_step": v[0] / STEPS[prefix], "written_bytes_per_step": v[1] / STEPS[prefix]} for fm, v in fam.items()}
         lines += ["", "HBM-side traffic per step (20 depth maps), %s:" % plan] + [
             "  %s: %.1f MB read + %.1f MB written" % (fm, v[0] / STEPS[prefix] / 1e6, v[1] / STEPS[prefix] / 1e6) for fm, v in sorted(fam.items())]
+# executed VALU wave-instructions of the bulk kernels per wavefront pass (64 patch-view passes): SQ_INSTS_VALU of the PMC pass
+# over the passes its bench line counted on the device -- bench.py's `valu_issue` roof reads it from here
+try:
+    bl = [l for l in open(os.path.join(src, "pmc_SQ_WAVES+SQ_BUSY_CYCLES+SQ_INSTS_VALU+SQ_ACTIVE_INST_VALU.log")).read().splitlines() if l.startswith("{")]
+    jb = json.loads(bl[-1])
+    steps_timed = jb["steps"]
+    r = jb["roofline"]
+    pk = r["per_kernel"]["k_optimize<1> (host-visible rounds)"]
+    n_eval_bulk_share = (pk["algorithmic_bytes_per_launch"] * pk["launches"]) / (r["algorithmic_bytes_per_launch"] * r["launches"])
+    passes_bulk_per_step = r["n_pass"] * n_eval_bulk_share / steps_timed
+    valu = sum(acc[k]["SQ_INSTS_VALU"][0] for k in acc if family(k) == "k_optimize<1> (host-visible rounds)" and "SQ_INSTS_VALU" in acc[k]) / STEPS["pmc"]
+    traffic["valu_wave_insts_per_wave_pass"] = valu / (passes_bulk_per_step / 64.0)
+    traffic["valu_wave_insts_per_step_bulk"] = valu
+    lines += ["", "Bulk kernels (k_optimize<Lay<1,.>> + k_optimize_spec): %.3e VALU wave-instructions per step, %.3e counted passes per step -> %.0f VALU wave-instructions per wavefront pass (%.1f per sample)"
+              % (valu, passes_bulk_per_step, traffic["valu_wave_insts_per_wave_pass"], traffic["valu_wave_insts_per_wave_pass"] / 25.0)]
+except Exception as e:
+    lines += ["", "(no VALU-per-pass figure: %r)" % (e,)]
 if traffic["plans"]:
     json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 for n in ("1thread", "default", "driver", "1thread_5steps"):
