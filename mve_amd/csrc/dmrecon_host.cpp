@@ -1436,6 +1436,10 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         size_t ev_lat = (size_t)-1;
         unsigned* fcnt = c->bs.d_follow_cnt.p + 4 * (size_t)r;
         const unsigned plain_min = spec ? spec_cap : 0u;
+        /* a list grows at most four-fold per round (a pixel is in it only if one of its four neighbours was written in the
+         * round before), and the host's figure is two rounds old when it enqueues: below a sixteenth of the records' capacity
+         * the plain launches cannot be needed */
+        const bool need_plain = !spec || 16ull * (unsigned long long)known_thr >= (unsigned long long)spec_cap;
         if (spec) {
             /* (items: ~1.3 per entry; the list of them is the follow-up buffer, which a speculative round does not use) */
             const unsigned quads = std::min(std::max(3u * known_thr, 16384u), 4u * spec_cap);
@@ -1448,7 +1452,8 @@ int BatchRun::bulk_rounds(bool& to_tail) {
          * lone 3-view call 19.4 -> 17.8 ms, the bench's plan unchanged (thresholds 50 000 / 200 000 / always: 542 /
          * 546 / 540).  Same arithmetic either way (tests: the maps do not depend on the form); chosen from the last
          * size the host has seen. */
-        if (known_thr < ONE_LAUNCH_MAX)
+        if (!need_plain) { }
+        else if (known_thr < ONE_LAUNCH_MAX)
             D->optimize(S, 1, spec ? std::max(1u, waves / 2) : waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
                         0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr);
         else {
@@ -1476,7 +1481,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         ev.begin(S, EventLog::SWEEP, 0);
         if (spec) mi_launch_apply_spec(S, std::min((std::max(3u * known_thr, 16384u) + 255) / 256, 768u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_spec.p,
                                        c->bs.d_follow.p, c->bs.d_round_items.p + r, n_thr_p, 0u, 0u, spec_cap, r, c->d_counters);
-        mi_launch_apply(S, std::min((est + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, n_thr_p, 0u, plain_min, 0xFFFFFFFFu, r, c->d_counters);
+        if (need_plain) mi_launch_apply(S, std::min((est + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, n_thr_p, 0u, plain_min, 0xFFFFFFFFu, r, c->d_counters);
         if (any_lat) mi_launch_apply(S, std::min((std::max(2u * known_lat, 1024u) + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work2.p, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters);
         ev.end(S);
         const int slot = r & 1;

@@ -1,12 +1,8 @@
 #!/bin/bash
+# Runs ON THE GPU BOX (through gpurun).  Session r4 profiles: the round's profile collection + bench lines of configs 2 and 5.
 export TMPDIR=/tmp
-OUT=gpurun_out/r4m
+OUT=gpurun_out/r4
 mkdir -p $OUT
-timeout -s KILL 120 python tools/trace_c3.py 2>&1 | grep -E "phase|total|streamed" | head -40
-timeout -s KILL 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --one-call-n 30 2>$OUT/bench.err > $OUT/bench.json
-python - $OUT/bench.json <<'PY'
-import sys, json
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-oc = d["one_call"]
-print("value %.1f" % d["value"], "repeats", [round(x) for x in d["repeats"]], "one_call %.2f ms (min %.2f) bulk %.2f front %.2f plan %.2f" % (oc["ms_per_call"], oc["ms_per_call_min_max"][0], oc["ms_bulk_kernel"], oc["ms_front_kernel"], oc["ms_host_planning"]))
-PY
+bash tools/collect_profiles.sh r4 2>&1 | tail -30
+timeout -s KILL 400 python bench.py --config C2 --steps 20 --warmup 3 --one-call-n 30 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; tail -c 1500 $OUT/bench_c2.json
+timeout -s KILL 900 python bench.py --config C5 --steps 2 --warmup 1 --repeats 3 --one-call-n 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; tail -c 2500 $OUT/bench_c5.json; tail -3 $OUT/bench_c5.err
