@@ -2493,6 +2493,9 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
         a.view_count[(unsigned)((a.round + 1) % 3) * (unsigned)a.n_jobs + (unsigned)jobi] = 0;
     }
     if (job->flags != 0) return;                 /* failed / cancelled view */
+    /* a view whose list was empty last round wrote nothing then: its propagation is over, its pixels need not be read again
+     * (the views of a large batch end hundreds of rounds apart) */
+    if (a.round >= 2 && prev_cnt == 0u) return;
     const int W = job->w, H = job->h;
     const int tiles_x = (W + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, tiles_y = (H + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
     if ((int)blockIdx.x >= tiles_x * tiles_y) return;
@@ -2614,7 +2617,14 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
             todo &= ~same;
         }
     }
-    if (filled && (threadIdx.x & 63) == 0) atomicAdd(&a.counters->n_filled, (unsigned long long)filled);
+    /* the call's counter: one atomic per workgroup (an atomic on one word costs ~10 ns; per wavefront they add up to
+     * milliseconds in the launches of a large batch) */
+    __shared__ unsigned s_filled;
+    if (threadIdx.x == 0) s_filled = 0;
+    __syncthreads();
+    if (filled && (threadIdx.x & 63) == 0) atomicAdd(&s_filled, filled);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_filled) atomicAdd(&a.counters->n_filled, (unsigned long long)s_filled);
 }
 
 /* The write-back of a speculative round (k_optimize_spec): the reference's sequential rule over an entry's candidate

@@ -1473,7 +1473,11 @@ int BatchRun::bulk_rounds(bool& to_tail) {
             /* the views that have handed over: one wavefront per patch, an entry's attempts one after the other */
             ev.begin(S, EventLog::BULK, 0);
             ev_lat = ev.items.size() - 1;
-            D->optimize(S, 16, std::min(std::max(2u * known_lat, 1024u), 16384u), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work2.p,
+            /* (the latency list can jump from nothing to a few hundred entries per view in one round, when the views of a batch
+             * hand over together: a grid sized from the last list the host has seen would leave a thousand wavefronts striding
+             * over it -- measured: 8 ms for such a round in a 200-view batch.  Wavefronts without an entry end at once.) */
+            const unsigned lat_grid = std::min(std::max(std::max(4u * known_lat, (unsigned)nj * std::min(handover, 1024u)), 4096u), 32768u);
+            D->optimize(S, 16, lat_grid, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work2.p,
                         nullptr, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr);
             ev.end(S);
             ++n_launch;
@@ -1481,7 +1485,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         ev.begin(S, EventLog::SWEEP, 0);
         if (spec) mi_launch_apply_spec(S, std::min((std::max(3u * known_thr, 16384u) + 255) / 256, 768u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_spec.p,
                                        c->bs.d_follow.p, c->bs.d_round_items.p + r, n_thr_p, 0u, 0u, spec_cap, r, c->d_counters);
-        if (need_plain) mi_launch_apply(S, std::min((est + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, n_thr_p, 0u, plain_min, 0xFFFFFFFFu, r, c->d_counters);
+        if (need_plain) mi_launch_apply(S, std::min((est + 255) / 256, 2048u), c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, n_thr_p, 0u, plain_min, 0xFFFFFFFFu, r, c->d_counters);
         if (any_lat) mi_launch_apply(S, std::min((std::max(2u * known_lat, 1024u) + 255) / 256, 4096u), c->bs.d_jobs.p, c->bs.d_work2.p, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters);
         ev.end(S);
         const int slot = r & 1;

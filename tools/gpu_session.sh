@@ -1,8 +1,12 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun).  Session r4 profiles: the round's profile collection + bench lines of configs 2 and 5.
 export TMPDIR=/tmp
-OUT=gpurun_out/r4
+OUT=gpurun_out/r4p
 mkdir -p $OUT
-bash tools/collect_profiles.sh r4 2>&1 | tail -30
-timeout -s KILL 400 python bench.py --config C2 --steps 20 --warmup 3 --one-call-n 30 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; tail -c 1500 $OUT/bench_c2.json
-timeout -s KILL 900 python bench.py --config C5 --steps 2 --warmup 1 --repeats 3 --one-call-n 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; tail -c 2500 $OUT/bench_c5.json; tail -3 $OUT/bench_c5.err
+for W in 150 1000 3000; do
+MI_DMRECON_MERGE_WINDOW_US=$W timeout -s KILL 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-one-call 2>$OUT/bench$W.err > $OUT/bench$W.json
+python - $OUT/bench$W.json $W <<'PY'
+import sys, json
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("window", sys.argv[2], "value %.1f" % d["value"], "repeats", [round(x) for x in d["repeats"]], d["config"]["library_batch_log"])
+PY
+done
