@@ -157,7 +157,7 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
  * propagation goes to the front kernel, for a call alone on its GPU / next to other calls (BatchRun::tail_rounds) */
 #define MI_MERGE_SMALL_CALL 48      /* reference views: below this a call waits MI_MERGE_WINDOW_US for company, ... */
 #define MI_MERGE_WINDOW_US 1000
-#define MI_MERGE_WINDOW_BIG_US 150  /* ... from this size on only this long (see mi_dmrecon_reconstruct) */
+#define MI_MERGE_WINDOW_BIG_US 3000 /* ... from this size on this long: ~2 % of such a call's own time (see mi_dmrecon_reconstruct) */
 #define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
 #define MI_SPEC_ROUNDS 400000u      /* throughput rounds below this many entries try an entry's candidate hypotheses at the same time */
 #define MI_VIEW_HANDOVER 320u      /* a view leaves the throughput layout once a round's list of its own is shorter than this */
@@ -2031,7 +2031,7 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
  * 905 depth-maps/s where six threads with 100 each reach 740-830).  This is what the shim does
  * for mvs::DMRecon::start(); here for callers of the C ABI.
  *   - A call that finds fewer than MI_DMRECON_MERGE_RUNNING (2) batches running becomes a LEADER: it takes every
- *     request pending at that moment (after a wait of MI_DMRECON_MERGE_WINDOW_US = 1000 / 150 us for more, only if calls of
+ *     request pending at that moment (after a wait of MI_DMRECON_MERGE_WINDOW_US = 1000 / 3000 us for more, only if calls of
  *     this scene have met within the last few calls), runs them as one batch on its own context and hands the results out.  The other
  *     calls wait; whoever is still pending when a batch ends becomes the next leader.  A lone caller never waits.
  *   - Per-view statuses go to their callers; a caller all of whose views failed gets the first failure as its return
@@ -2049,11 +2049,12 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
      * bench's plan, four in flight 30 % */
     const int MAX_RUNNING = 2;
     const int WINDOW_ENV = [] { const char* e = std::getenv("MI_DMRECON_MERGE_WINDOW_US"); return e ? std::max(0, std::atoi(e)) : -1; }();
-    /* A small call gains from company (the bulk kernel reaches 0.30+ of the HBM roof in launches of 100+ views, 0.21 at 20;
-     * the tail is paid once per batch) and waits a millisecond for it -- that also catches the callers that come back
-     * from the batch that has just ended; a call that fills the launches by itself waits only for what arrives with it.
-     * Measured: six host threads x 20-view calls 615-712 -> 706-850 depth-maps/s; with 100-view calls the long wait
-     * turns the bench plan's batches (1 + 1 + 2 calls) into 1 + 3 or 2 + 2: 1 050-1 170 against 1 165-1 220. */
+    /* A call gains from company: the launches of a larger batch fill the GPU better, the latency-bound tail is paid once
+     * per batch, and ONE batch of all the callers' views beats two batches side by side (round 4, the bench's plan of four
+     * 100-view calls: one batch of 400 views 1 335-1 410 depth-maps/s, 1 + 3 calls 1 135-1 300, 1 + 1 + 2 calls 1 100-1 270).
+     * A leader that expects company therefore waits for it -- a millisecond if its own call is small (< 48 views: 3-4 % of
+     * such a call), three if it is large (~2 %); that also catches the callers that come back from the batch that has just
+     * ended.  A caller that has been alone lately does not wait at all (company_credit). */
     const int WINDOW_US = WINDOW_ENV >= 0 ? WINDOW_ENV : (n_refs < MI_MERGE_SMALL_CALL ? MI_MERGE_WINDOW_US : MI_MERGE_WINDOW_BIG_US);
     if (!MERGE || progress || !c || !st || !ref_views || !maps || n_refs <= 0)
         return reconstruct_batch(c, st, n_refs, ref_views, maps, progress, status_out, stats);
