@@ -251,6 +251,9 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1, n_keep=None):
                     if rep == 0:
                         acc.setdefault("_batches", []).append((int(c.last_stats.get("n_merged_calls", 0)), round(c.last_stats.get("ms_total", 0.0), 1),
                                                                round(1000.0 * (time.perf_counter() - t_go[0]), 1)))
+                    # every region: the calls per library batch (the batch's leader reports them)
+                    if int(c.last_stats.get("n_merged_calls", 0)) > 0:
+                        acc.setdefault("_shape", {}).setdefault(rep, []).append(int(c.last_stats.get("n_merged_calls", 0)))
             fin.wait()
 
     threads = [threading.Thread(target=worker, args=(i, c, o, n)) for i, (c, o, n) in enumerate(zip(ctxs, outs, share))]
@@ -271,6 +274,7 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1, n_keep=None):
     # the maps of the LAST timed call: still in the output buffers of the host thread that finished last
     i_last = int(np.argmax(done_at))
     last["res_last"] = [(m["depth"].copy(), m["conf"].copy()) for m in outs[i_last][:n_keep]]
+    last["batch_shapes"] = [sorted(v) for _, v in sorted(acc.pop("_shape", {}).items())]
     batches = acc.pop("_batches", [])
     last["batches"] = sorted(b for b in batches if b[0] > 0)      # first region: (calls in the batch, ms of the batch, ms since the start when it returned)
     return elapsed, acc, last
@@ -565,6 +569,8 @@ def main():
                        "views_per_library_batch": round(n_maps_rank * n_rep / max(1, n_calls * n_rep - acc.get("merged_into_other_call", 0)), 1),
                        # (calls merged, batch ms, ms after the start of the timed region at which it returned), per batch
                        "library_batch_log": last.get("batches", [])[:16],
+                       # calls per library batch in every timed region (same order as `repeats`)
+                       "calls_per_library_batch_by_region": last.get("batch_shapes", []),
                        "mean_fill": round(fill, 4)},
             "roofline": roof,
             # the scene's way into HBM, timed by itself before the timed regions (never part of `value`): host images ->
