@@ -79,11 +79,19 @@ TRAFFIC_PROFILES = ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json")    
 VALU_PER_WAVE_PASS_R3 = 3460.0
 
 
-def stored_valu_per_wave_pass():
+def stored_valu_per_wave_pass(lone=False):
+    """(count, source) at the call plan closest to this run: a lone 20-view call runs all its rounds speculatively (more
+    instructions executed per COUNTED pass: the attempts the reference's rule discards are executed too), the merged batches
+    of the multi-threaded plans run the plain kernels."""
     for name in TRAFFIC_PROFILES:
         f = os.path.join(ROOT, "profiles", name)
         if os.path.exists(f):
-            v = json.load(open(f)).get("valu_wave_insts_per_wave_pass")
+            j = json.load(open(f))
+            by = j.get("valu_wave_insts_per_wave_pass_by_plan", {})
+            for plan, v in by.items():
+                if plan.startswith("1 host thread") == bool(lone) and v:
+                    return float(v), "profiles/%s (%s)" % (name, plan)
+            v = j.get("valu_wave_insts_per_wave_pass")
             if v:
                 return float(v), "profiles/" + name
     return VALU_PER_WAVE_PASS_R3, "profiles/r3_pmc.md (1.42e8 VALU wave-instructions per FAST launch / its passes)"
@@ -254,6 +262,12 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1, n_keep=None):
                     # every region: the calls per library batch (the batch's leader reports them)
                     if int(c.last_stats.get("n_merged_calls", 0)) > 0:
                         acc.setdefault("_shape", {}).setdefault(rep, []).append(int(c.last_stats.get("n_merged_calls", 0)))
+                        if os.environ.get("MI_BENCH_REGION_LOG"):
+                            ls = c.last_stats
+                            sys.stderr.write("region %d batch of %d calls: total %.1f ms = plan %.1f + %.1f, setup %.1f, rounds %.1f, front %.1f, download %.1f | kernels bulk %.1f front %.1f sweeps %.1f | returned at %.1f ms\n" % (
+                                rep, ls["n_merged_calls"], ls["ms_total"], ls["ms_plan_gvs"], ls["ms_plan_seeds"], ls["ms_wall_setup"], ls["ms_wall_rounds"],
+                                ls["ms_wall_front"], ls["ms_wall_download"], ls["ms_bulk_kernel"], ls["ms_front_kernel"],
+                                ls["ms_sweep_kernels"], 1000.0 * (time.perf_counter() - t_go[0])))
             fin.wait()
 
     threads = [threading.Thread(target=worker, args=(i, c, o, n)) for i, (c, o, n) in enumerate(zip(ctxs, outs, share))]
@@ -345,7 +359,7 @@ def roofline(acc, n_maps, scene, cfg, n_streams, spc, elapsed):
             # fp32 VALU with SURVEY's algorithmic flop counts (3.6 kflop per derivative evaluation, 1.6 kflop
             # per colour evaluation, mix 19.9 : 11.9), and the L2 with the bytes the passes request from it
             "secondary_roofs": {
-                "valu_issue": valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps_rank),
+                "valu_issue": valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps_rank, lone=(n_streams == 1 and spc == 1)),
                 "valu_fp32": {"algorithmic_flop": 2.85e3 * acc["n_eval"], "achieved": 2.85e3 * acc["n_eval"] / opt_s / 1e12 if opt_s > 0 else None,
                               "peak": 157.3, "unit": "TFLOP/s", "frac": 2.85e3 * acc["n_eval"] / opt_s / 1e12 / 157.3 if opt_s > 0 else None},
                 "l2": {"requested_bytes": 400.0 * n_pass, "achieved": 400.0 * n_pass / opt_s / 1e9 if opt_s > 0 else None,
@@ -384,7 +398,7 @@ def predicted_strong_scaling(n_views):
     return None
 
 
-def valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps):
+def valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps, lone=False):
     """The ceiling the bulk kernel is actually under (its wavefronts are limited by how fast a SIMD
     issues their VALU instructions, not by memory): the VALU wave-instructions it EXECUTES -- a stored SQ_INSTS_VALU
     figure per wavefront pass x the passes this run counted on the device -- over the chip's issue rate, SIMDs x shader
@@ -393,7 +407,7 @@ def valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps):
     arithmetic needs (57 per sample): what the formulation adds on top (addressing, table look-ups, control)."""
     if not acc.get("n_eval") or ms_bulk <= 0:
         return None
-    per_wave_pass, src = stored_valu_per_wave_pass()
+    per_wave_pass, src = stored_valu_per_wave_pass(lone)
     passes_bulk = n_pass * (bulk_stats["n_eval"] / acc["n_eval"])           # the bulk kernel's share of the executed passes
     insts = per_wave_pass * passes_bulk / 64.0                              # a wavefront pass = 64 patch-view passes
     rate = N_SIMDS * SHADER_CLOCK_HZ / CYCLES_PER_VALU_INST                 # wave-instructions per second, whole chip

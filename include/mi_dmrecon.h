@@ -135,6 +135,7 @@ typedef struct mi_dmrecon_stats {
     int64_t front_fallbacks;     /* 1: the teams gave up (a member found no compute unit in time: the GPU is shared with
                                   * something the library cannot see) and the views finished with one workgroup each */
     int64_t n_latency_rounds;    /* host-visible rounds in which some view was already in the latency layout */
+    double  ms_wall_setup, ms_wall_rounds, ms_wall_front, ms_wall_download;   /* host clock: uploads, host-visible + tail rounds, front phase, download */
     int64_t n_patch_turns, n_wave_turns;   /* development builds (-DMI_ACTIVITY) only: turns of the patch optimisations of the throughput
                                   * layout, and turns of their wavefronts x patches per wavefront: the ratio = lanes at work */
 } mi_dmrecon_stats;

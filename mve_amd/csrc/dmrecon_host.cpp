@@ -76,6 +76,7 @@ int fail(int code, const char* fmt, ...) {
  * 4 to 29 ms, and the same bench ran 5 % faster under rocprofv3, whose helper thread keeps the completion signals warm.
  * The round loops wait for work that is microseconds to a few milliseconds away: poll, with a pause between looks, and
  * only fall back to the blocking call when the wait gets long. */
+double now_ms();
 inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
@@ -272,6 +273,12 @@ struct BatchScratch {
     size_t h_dyn_cap = 0;
     unsigned* h_done = nullptr;              /* pinned, written by k_front: views that have run to their end */
     size_t h_done_cap = 0;
+    uint8_t* h_up = nullptr;                 /* pinned staging of a call's uploads: job table | list offsets | seeds | their hypotheses
+                                              * (a copy from pageable memory is staged by the runtime, with waits of its own) */
+    size_t h_up_cap = 0;
+    int32_t* h_gvs = nullptr;                /* pinned: the device view selection's result (a copy into pageable memory is made by the
+                                              * runtime with a wait of its own, in steps of 10 ms) */
+    size_t h_gvs_cap = 0;
     std::vector<int32_t> h_jobdyn;           /* staging of the flag words written to dead jobs */
     DevBuf<int32_t> d_gvs_feat, d_gvs_out;   /* scratch and result of the device view selection */
     DevBuf<float> d_gvs_base, d_gvs_benefit;
@@ -303,6 +310,9 @@ struct BatchScratch {
         if (h_poll) (void)hipHostFree(h_poll);
         if (h_dyn) (void)hipHostFree(h_dyn);
         if (h_done) (void)hipHostFree(h_done);
+        if (h_gvs) (void)hipHostFree(h_gvs);
+        if (h_up) (void)hipHostFree(h_up);
+        h_gvs = nullptr; h_gvs_cap = 0; h_up = nullptr; h_up_cap = 0;
         h_poll = nullptr; h_dyn = nullptr; h_dyn_cap = 0; h_done = nullptr; h_done_cap = 0;
         for (int k = 0; k < 2; ++k) { if (poll_ev[k]) (void)hipEventDestroy(poll_ev[k]); poll_ev[k] = nullptr; }
     }
@@ -585,10 +595,14 @@ int check_ref_view(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref) {
 }
 
 /* MI_DMRECON_GVS_DEVICE: 0 = host, 1 = device whenever possible, unset = device when the call is large enough for the
- * launch to pay: reference views x views x features >= MI_GVS_DEVICE_MIN_WORK.  Measured: 100
- * reference views of a 100-view scene with 2000 features (2e7) 25 ms on the device against 32 ms of host threads; 20 of
- * a 20-view scene (8e5) 2.0 ms against 1.1 ms -- and host threads cost the GPU nothing when several calls overlap. */
-#define MI_GVS_DEVICE_MIN_WORK 10000000.0
+ * launch to pay: reference views x views x features >= MI_GVS_DEVICE_MIN_WORK.  Measured: 100 reference views of a 100-view
+ * scene with 2000 features (2e7) 25 ms on the device against 32 ms of host threads; 20 of a 20-view scene (8e5) 2.0 ms
+ * against 1.1 ms -- and host threads cost the GPU nothing when several calls overlap.  Round 4: the kernel is the FIRST
+ * thing a call puts on a GPU that has just spent tens of milliseconds in the latency-bound end of the previous batch, and
+ * its serial sums run at whatever clock the GPU has fallen to: 3.8 ms under rocprofv3 (clocks held), 4 to 29 ms in steps
+ * of ~10 ms without (400 reference views of the C3 scene, 1.6e7; profiles/r4_big_batch.txt), against a steady 5.1 ms of
+ * host threads -- the threshold went up tenfold. */
+#define MI_GVS_DEVICE_MIN_WORK 100000000.0
 bool gvs_device_wanted(mi_dmrecon_ctx* c, int n_refs) {
     const char* e = std::getenv("MI_DMRECON_GVS_DEVICE");                /* read per call: tests switch it */
     const int mode = e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
@@ -653,16 +667,31 @@ int plan_global_views_device(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
     }
     a.feat = c->bs.d_gvs_feat.p; a.base = c->bs.d_gvs_base.p; a.benefit = c->bs.d_gvs_benefit.p;
     a.out_ids = c->bs.d_gvs_out.p; a.out_n = c->bs.d_gvs_out.p + m * MI_GVS_MAX_OUT;
+    const bool tr = std::getenv("MI_DMRECON_TRACE") != nullptr;
+    const double tg0 = now_ms();
     HIP_TRY(hipMemcpyAsync(c->bs.d_gvs_refs.p, hr.data(), m * sizeof(GvsRef), hipMemcpyHostToDevice, c->stream));
+    const double tg1 = now_ms();
     mi_gvs_launch(c->stream, a, (int)m);
     HIP_TRY(hipGetLastError());
-    std::vector<int32_t> out(m * (MI_GVS_MAX_OUT + 1));
-    HIP_TRY(hipMemcpyAsync(out.data(), c->bs.d_gvs_out.p, out.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    const double tg2 = now_ms();
+    const size_t n_out = m * (MI_GVS_MAX_OUT + 1);
+    if (c->bs.h_gvs_cap < n_out) {
+        if (c->bs.h_gvs) (void)hipHostFree(c->bs.h_gvs);
+        c->bs.h_gvs = nullptr; c->bs.h_gvs_cap = 0;
+        if (hipHostMalloc((void**)&c->bs.h_gvs, 2 * n_out * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+            return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(view selection result) failed");
+        c->bs.h_gvs_cap = 2 * n_out;
+    }
+    const int32_t* out = c->bs.h_gvs;
+    HIP_TRY(hipMemcpyAsync(c->bs.h_gvs, c->bs.d_gvs_out.p, n_out * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    const double tg3 = now_ms();
     HIP_TRY(wait_stream(c->stream));
+    if (tr) fprintf(stderr, "[mi_dmrecon] device view selection of %zu views: upload call %.3f ms, launch %.3f, read-back call %.3f, wait %.3f\n",
+                    m, tg1 - tg0, tg2 - tg1, tg3 - tg2, now_ms() - tg3);
     for (int i = 0; i < n; ++i) {
         if (slot[i] < 0) continue;
         const int k = out[m * MI_GVS_MAX_OUT + slot[i]];
-        global[i].assign(out.begin() + (size_t)slot[i] * MI_GVS_MAX_OUT, out.begin() + (size_t)slot[i] * MI_GVS_MAX_OUT + k);
+        global[i].assign(out + (size_t)slot[i] * MI_GVS_MAX_OUT, out + (size_t)slot[i] * MI_GVS_MAX_OUT + k);
     }
     return 0;
 }
@@ -939,6 +968,16 @@ static int create_streams(mi_dmrecon_ctx* c) {
     return 0;
 }
 
+/* The runtime gives a stream its hardware queue when the stream is first used -- tens of milliseconds, which used to land
+ * in whichever call first led a batch on this context (the second stream: in its first front phase): used once here. */
+static int warm_streams(mi_dmrecon_ctx* c) {
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream2));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream2));
+    return 0;
+}
+
 int mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out) {
     if (!out) return fail(MI_DMRECON_EINVAL, "null out pointer");
     int n = mi_dmrecon_device_count();
@@ -961,6 +1000,7 @@ int mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->sc->d_lut, sizeof(lut)));
     HIP_TRY(hipMemcpy(c->sc->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(DevCounters)));
+    if (int rc = warm_streams(c)) return rc;
     *out = c;
     return 0;
 }
@@ -986,6 +1026,7 @@ int mi_dmrecon_ctx_fork(mi_dmrecon_ctx* parent, mi_dmrecon_ctx** out) {
     c->sc = parent->sc;
     if (int rc = create_streams(c)) return rc;
     HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(DevCounters)));
+    if (int rc = warm_streams(c)) return rc;
     *out = c;
     return 0;
 }
@@ -1207,6 +1248,7 @@ struct BatchRun {
     std::vector<JobHost> jobs; std::vector<DevJob> dj;
     int nj = 0, n_alive = 0, max_tiles = 0;
     size_t total_px = 0, work_cap = 0, n_seed_feats = 0;
+    size_t up_jobs = 0, up_keyoff = 0, up_seeds = 0, up_hyps = 0;   /* offsets into the pinned upload staging (BatchScratch::h_up) */
     std::vector<DevEntry> seeds; std::vector<DevHyp> hyps; std::vector<unsigned> keyoff;
     /* the rounds */
     EventLog ev;
@@ -1334,10 +1376,28 @@ int BatchRun::upload() {
     if (rc) return rc;
     work_cap = std::max(total_px, seeds.size());
     if (c->bs.d_jobs.reserve(nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(jobs) failed");
-    HIP_TRY(hipMemcpyAsync(c->bs.d_jobs.p, dj.data(), nj * sizeof(DevJob), hipMemcpyHostToDevice, S));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), S));
     keyoff.resize(nj);
     for (int j = 0; j < nj; ++j) keyoff[j] = (unsigned)jobs[j].pix_off;
+    {
+        /* everything the call uploads, through ONE page-locked staging buffer: asynchronous for real */
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        up_jobs = 0; up_keyoff = al(up_jobs + (size_t)nj * sizeof(DevJob)); up_seeds = al(up_keyoff + (size_t)nj * sizeof(unsigned));
+        up_hyps = al(up_seeds + seeds.size() * sizeof(DevEntry));
+        const size_t need = al(up_hyps + hyps.size() * sizeof(DevHyp));
+        if (c->bs.h_up_cap < need) {
+            if (c->bs.h_up) (void)hipHostFree(c->bs.h_up);
+            c->bs.h_up = nullptr; c->bs.h_up_cap = 0;
+            if (hipHostMalloc((void**)&c->bs.h_up, 2 * need, hipHostMallocDefault) != hipSuccess)
+                return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(upload staging) failed");
+            c->bs.h_up_cap = 2 * need;
+        }
+        std::memcpy(c->bs.h_up + up_jobs, dj.data(), (size_t)nj * sizeof(DevJob));
+        std::memcpy(c->bs.h_up + up_keyoff, keyoff.data(), (size_t)nj * sizeof(unsigned));
+        if (!seeds.empty()) std::memcpy(c->bs.h_up + up_seeds, seeds.data(), seeds.size() * sizeof(DevEntry));
+        if (!hyps.empty()) std::memcpy(c->bs.h_up + up_hyps, hyps.data(), hyps.size() * sizeof(DevHyp));
+    }
+    HIP_TRY(hipMemcpyAsync(c->bs.d_jobs.p, c->bs.h_up + up_jobs, nj * sizeof(DevJob), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), S));
     if (c->bs.d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->bs.d_keyoff.reserve(nj)
         || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_round_work_t.reserve(MI_MAX_ROUNDS) || c->bs.d_round_items.reserve(MI_MAX_ROUNDS)
         || c->bs.d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->bs.d_view.reserve(4 * (size_t)nj)
@@ -1354,7 +1414,7 @@ int BatchRun::upload() {
     HIP_TRY(hipMemsetAsync(c->bs.d_view.p, 0, 4 * (size_t)nj * sizeof(unsigned), S));
     if (handover < 1000000000u) HIP_TRY(hipMemsetAsync(c->bs.d_view.p, 0xFF, (size_t)nj * sizeof(unsigned), S));
     HIP_TRY(hipMemsetAsync(c->bs.d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), S));
-    HIP_TRY(hipMemcpyAsync(c->bs.d_keyoff.p, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_keyoff.p, c->bs.h_up + up_keyoff, nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
     if (!c->bs.h_poll) {
         if (hipHostMalloc((void**)&c->bs.h_poll, 3 * sizeof(TailPoll), hipHostMallocDefault) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(poll buffer) failed");
@@ -1378,8 +1438,8 @@ int BatchRun::upload() {
 /* ---- round 0: DMRecon::processFeatures (dmrecon.cc:243-331), every SfM feature of every view in one launch */
 int BatchRun::seed_round() {
     if (seeds.empty()) return 0;
-    HIP_TRY(hipMemcpyAsync(c->bs.d_work.p, seeds.data(), seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, S));
-    HIP_TRY(hipMemcpyAsync(c->bs.d_hyp.p, hyps.data(), hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_work.p, c->bs.h_up + up_seeds, seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_hyp.p, c->bs.h_up + up_hyps, hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, S));
     HIP_TRY(hipMemsetAsync(c->bs.d_keys.p, 0, total_px * sizeof(unsigned long long), S));
     ev.begin(S, EventLog::BULK, (unsigned)seeds.size());
     const unsigned ppw = patches_per_wave(st);
@@ -1726,7 +1786,7 @@ struct TeamToken {
 int BatchRun::front_rounds() {
     unsigned* d_off = c->bs.d_front.p; unsigned* d_cnt = d_off + nj; unsigned* d_stats = d_cnt + nj; unsigned* d_filled = d_stats + 4 * (size_t)nj;
     unsigned long long* d_resume = c->bs.d_front_resume.p;
-    HIP_TRY(hipMemcpyAsync(d_off, keyoff.data(), nj * sizeof(unsigned), hipMemcpyHostToDevice, S));   /* a view's list region = its pixel offset */
+    HIP_TRY(hipMemcpyAsync(d_off, c->bs.h_up + up_keyoff, nj * sizeof(unsigned), hipMemcpyHostToDevice, S));   /* a view's list region = its pixel offset */
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 6 * (size_t)nj * sizeof(unsigned), S));                          /* sizes, statistics, team counts */
     HIP_TRY(hipMemsetAsync(d_resume, 0, 2 * (size_t)nj * sizeof(unsigned long long), S));
     front_first_round = round;
@@ -2032,7 +2092,10 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
     std::memset(&B.hc, 0, sizeof(B.hc));
     try {
         if ((rc = B.plan()) != 0) return rc;
+        double t_ph = now_ms();
+        auto phase = [&](double mi_dmrecon_stats::*field) { const double t = now_ms(); if (stats) stats->*field += t - t_ph; t_ph = t; };
         if ((rc = B.upload()) != 0) return rc;
+        phase(&mi_dmrecon_stats::ms_wall_setup);
         if ((rc = B.seed_round()) != 0) return rc;
         for (int i = 0; progress && i < n_refs; ++i) if (B.view_rc[i] == 0) progress[i].status = MI_RECON_QUEUE;
         /* the propagation sweeps (replace DMRecon::processQueue, dmrecon.cc:333-434) */
@@ -2042,10 +2105,12 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
         if (to_tail) {
             if ((rc = B.tail_rounds(to_front)) != 0) return rc;
             B.mark("phase B rounds");
-            if (to_front) { if ((rc = B.front_rounds()) != 0) return rc; B.mark("phase C (front kernel)"); }
+            phase(&mi_dmrecon_stats::ms_wall_rounds);
+            if (to_front) { if ((rc = B.front_rounds()) != 0) return rc; B.mark("phase C (front kernel)"); phase(&mi_dmrecon_stats::ms_wall_front); }
             mi_launch_flatten(B.S, c->bs.d_maps.p, c->bs.d_imaps.p, B.total_px, st->nrReconNeighbors > 4, 0, B.total_px);
         }
         if ((rc = B.download()) != 0) return rc;
+        phase(&mi_dmrecon_stats::ms_wall_download);
         B.fill_stats();
         return B.outcome();
     } catch (const std::bad_alloc&) {
@@ -2087,6 +2152,18 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
      * such a call), three if it is large (~2 %); that also catches the callers that come back from the batch that has just
      * ended.  A caller that has been alone lately does not wait at all (company_credit). */
     const int WINDOW_US = WINDOW_ENV >= 0 ? WINDOW_ENV : (n_refs < MI_MERGE_SMALL_CALL ? MI_MERGE_WINDOW_US : MI_MERGE_WINDOW_BIG_US);
+    {
+        /* The host planning of a batch is an OpenMP loop on the thread that LEADS the batch, and a thread's OpenMP team is
+         * created at its first parallel region (10-30 ms for 64 threads): which caller leads a merged batch is a matter of
+         * arrival order, so every calling thread gets its team at its first call, whatever its role in it. */
+        static thread_local bool team_ready = false;
+        if (!team_ready) {
+            team_ready = true;
+            const int n_threads = std::max(1, std::min(omp_get_num_procs(), 64));
+#pragma omp parallel num_threads(n_threads)
+            { }
+        }
+    }
     if (!MERGE || progress || !c || !st || !ref_views || !maps || n_refs <= 0)
         return reconstruct_batch(c, st, n_refs, ref_views, maps, progress, status_out, stats);
     MergeQueue& Q = c->sc->merge;

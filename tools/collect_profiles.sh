@@ -25,8 +25,8 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCL
   D=$R/$OUT/pmc_$(echo $C | tr ' ' '+')
   timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o bench -- $BP > $D.log 2>&1
 done
-for C in FETCH_SIZE WRITE_SIZE; do
-  D=$R/$OUT/pmcd_$C
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; do
+  D=$R/$OUT/pmcd_$(echo $C | tr ' ' '+')
   timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o bench -- $BQ > $D.log 2>&1
 done
 cd $R
@@ -41,6 +41,7 @@ MI_DMRECON_TRACE=1 timeout -s KILL 300 python tools/app_c3_timing.py 2>&1 | grep
 timeout -s KILL 300 python tools/lone_calls.py C3 12 > $OUT/lone_calls.json 2> $OUT/lone_calls.err
 timeout -s KILL 200 python tools/cold_call.py C3 20 2>&1 | grep -E "phase|==|context|staged|total" | cut -c1-120 > $OUT/cold_call.txt
 timeout -s KILL 90 build/valu_rate2 > $OUT/valu_rate.txt 2>&1
+timeout -s KILL 200 python tools/big_batch_probe.py 20 > $OUT/big_batch.txt 2>&1
 # BASELINE config 4 (the 20 views of ONE scene sharded over the ranks) on the one GPU of this box: ranks sharing GPU 0
 # (development mode of bench.py, gloo; default environment: the team token and the give-up path do their work)
 MI_BENCH_SHARE_GPU=1 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29641 \

@@ -25,7 +25,7 @@ for n in ("1thread", "default", "driver", "1thread_5steps"):
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, "%s_bench_%s.json" % (tag, n)))
 for name, dstname in (("lone_calls.json", "lone_calls.json"), ("valu_rate.txt", "valu_rate.txt"), ("round_trace_c3.txt", "round_trace_c3.txt"),
-                      ("app_c3_timing.txt", "app_c3_timing.txt"), ("cold_call.txt", "cold_call.txt"),
+                      ("app_c3_timing.txt", "app_c3_timing.txt"), ("cold_call.txt", "cold_call.txt"), ("big_batch.txt", "big_batch.txt"),
                       ("strong_2ranks_one_gpu.json", "strong_2ranks_one_gpu.json"), ("bench_c2.json", "bench_c2.json"), ("bench_c5.json", "bench_c5.json")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f):
@@ -112,23 +112,30 @@ for prefix, plan in (("pmc", "1 host thread, 1 step per call"), ("pmcd", "defaul
         traffic["plans"][plan] = {fm: {"read_bytes_per_step": v[0] / STEPS[prefix], "written_bytes_per_step": v[1] / STEPS[prefix]} for fm, v in fam.items()}
         lines += ["", "HBM-side traffic per step (20 depth maps), %s:" % plan] + [
             "  %s: %.1f MB read + %.1f MB written" % (fm, v[0] / STEPS[prefix] / 1e6, v[1] / STEPS[prefix] / 1e6) for fm, v in sorted(fam.items())]
-# executed VALU wave-instructions of the bulk kernels per wavefront pass (64 patch-view passes): SQ_INSTS_VALU of the PMC pass
-# over the passes its bench line counted on the device -- bench.py's `valu_issue` roof reads it from here
-try:
-    bl = [l for l in open(os.path.join(src, "pmc_SQ_WAVES+SQ_BUSY_CYCLES+SQ_INSTS_VALU+SQ_ACTIVE_INST_VALU.log")).read().splitlines() if l.startswith("{")]
+# executed VALU wave-instructions of the bulk kernels per wavefront pass (64 patch-view passes): SQ_INSTS_VALU of a PMC pass
+# over the passes its bench line counted on the device, at both call plans -- bench.py's `valu_issue` roof reads them here
+def valu_per_wave_pass(prefix, steps_all):
+    log = os.path.join(src, "%s_SQ_WAVES+SQ_BUSY_CYCLES+SQ_INSTS_VALU+SQ_ACTIVE_INST_VALU.log" % prefix)
+    bl = [l for l in open(log).read().splitlines() if l.startswith("{")]
     jb = json.loads(bl[-1])
-    steps_timed = jb["steps"]
     r = jb["roofline"]
     pk = r["per_kernel"]["k_optimize<1> (host-visible rounds)"]
-    n_eval_bulk_share = (pk["algorithmic_bytes_per_launch"] * pk["launches"]) / (r["algorithmic_bytes_per_launch"] * r["launches"])
-    passes_bulk_per_step = r["n_pass"] * n_eval_bulk_share / steps_timed
-    valu = sum(acc[k]["SQ_INSTS_VALU"][0] for k in acc if family(k) == "k_optimize<1> (host-visible rounds)" and "SQ_INSTS_VALU" in acc[k]) / STEPS["pmc"]
-    traffic["valu_wave_insts_per_wave_pass"] = valu / (passes_bulk_per_step / 64.0)
-    traffic["valu_wave_insts_per_step_bulk"] = valu
-    lines += ["", "Bulk kernels (k_optimize<Lay<1,.>> + k_optimize_spec): %.3e VALU wave-instructions per step, %.3e counted passes per step -> %.0f VALU wave-instructions per wavefront pass (%.1f per sample)"
-              % (valu, passes_bulk_per_step, traffic["valu_wave_insts_per_wave_pass"], traffic["valu_wave_insts_per_wave_pass"] / 25.0)]
-except Exception as e:
-    lines += ["", "(no VALU-per-pass figure: %r)" % (e,)]
+    share = (pk["algorithmic_bytes_per_launch"] * pk["launches"]) / (r["algorithmic_bytes_per_launch"] * r["launches"])
+    passes_bulk_per_step = r["n_pass"] * share / (jb["steps"] * len(jb.get("repeats", [1])))
+    a2, _ = (acc, regs) if prefix == "pmc" else collect(prefix)
+    valu = sum(a2[k]["SQ_INSTS_VALU"][0] for k in a2 if family(k) == "k_optimize<1> (host-visible rounds)" and "SQ_INSTS_VALU" in a2[k]) / steps_all
+    return valu, passes_bulk_per_step, valu / (passes_bulk_per_step / 64.0)
+traffic["valu_wave_insts_per_wave_pass_by_plan"] = {}
+for prefix, plan in (("pmc", "1 host thread, 1 step per call"), ("pmcd", "default: 6 host threads, 5 steps per call")):
+    try:
+        valu, passes, per = valu_per_wave_pass(prefix, STEPS[prefix])
+        traffic["valu_wave_insts_per_wave_pass_by_plan"][plan] = per
+        lines += ["", "Bulk kernels (k_optimize<Lay<1,.>> + k_optimize_spec), %s: %.3e VALU wave-instructions per step, %.3e counted passes per step -> %.0f VALU wave-instructions per wavefront pass (%.1f per sample)"
+                  % (plan, valu, passes, per, per / 25.0)]
+    except Exception as e:
+        lines += ["", "(no VALU-per-pass figure for %s: %r)" % (plan, e)]
+if "1 host thread, 1 step per call" in traffic["valu_wave_insts_per_wave_pass_by_plan"]:
+    traffic["valu_wave_insts_per_wave_pass"] = traffic["valu_wave_insts_per_wave_pass_by_plan"]["1 host thread, 1 step per call"]
 if traffic["plans"]:
     json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 for n in ("1thread", "default", "driver", "1thread_5steps"):
