@@ -177,10 +177,13 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
     if gpu_maps is not None:
         against = "oracle restatement (bit-identical to the reference build on every fixture), views %s, this run" % sample
         ref_maps = [(o["depth"], o["conf"]) for o in outs]
-        parity = map_parity_all([gpu_maps[v] for v in sample], ref_maps, against)
+        cb = CONF_P99_BOUND.get(cfg.get("name", ""), 5e-3)
+        parity = map_parity_all([gpu_maps[v] for v in sample], ref_maps, against, cb)
         parity["which"] = "maps of the first timed call"
+        if cb != 5e-3:
+            parity["conf_bound_note"] = "the reference algorithm against itself in reversed queue order on this scene: conf p99 7.8e-3 (view 0), 6.0e-3 (view 50): profiles/r4_c5_order_floor.json"
         if gpu_maps_last is not None:
-            pl = map_parity_all([gpu_maps_last[v] for v in sample], ref_maps, against)
+            pl = map_parity_all([gpu_maps_last[v] for v in sample], ref_maps, against, cb)
             parity["last_timed_call"] = {kk: pl[kk] for kk in ("min_fill_iou", "max_rel_depth_median", "max_rel_depth_p99", "max_conf_abs_p99", "within_bounds")}
             parity["last_timed_call"]["bit_identical_to_first"] = bool(all(
                 np.array_equal(gpu_maps[v][0], gpu_maps_last[v][0]) and np.array_equal(gpu_maps[v][1], gpu_maps_last[v][1]) for v in sample))
@@ -190,7 +193,14 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
                       "the reference binary needs the scene on disk as PNGs: not written for a scene of gigabytes)" % (sample, t)}, parity
 
 
-def map_parity_all(gpu, ref, against):
+# The confidence bound of the largest config: the reference ALGORITHM against itself with its queue popped worst-first (the
+# same restatement, ORC_QUEUE_ORDER=reverse) on views 0 / 50 of the C5 scene differs by conf p99 7.8e-3 / 6.0e-3 (relative
+# depth p99 2.6e-3 / 2.3e-3, fill IoU 0.9999 / 0.9995; profiles/r4_c5_order_floor.json): 5e-3 is below the algorithm's own
+# order sensitivity there
+CONF_P99_BOUND = {"C5": 1e-2}
+
+
+def map_parity_all(gpu, ref, against, conf_p99_bound=5e-3):
     """Worst case over the views of the map-level parity metrics.  Bounds: relative depth median <= 1e-3 / p99 <= 5e-3,
     confidence p99 <= 5e-3 (tests/test_gpu_parity.py), fill-mask IoU >= 0.96 at this size: which pixels of the strips
     along the top / bottom image border get a depth depends on which local view set reaches the strip first -- the
@@ -207,11 +217,11 @@ def map_parity_all(gpu, ref, against):
         med.append(float(np.median(rel))); p99.append(float(np.percentile(rel, 99)))
         cp99.append(float(np.percentile(np.abs(gc[both] - rc[both]), 99)))
         n += 1
-    ok = min(iou) >= 0.96 and max(med) <= 1e-3 and max(p99) <= 5e-3 and max(cp99) <= 5e-3
+    ok = min(iou) >= 0.96 and max(med) <= 1e-3 and max(p99) <= 5e-3 and max(cp99) <= conf_p99_bound
     return {"against": against, "views": n, "min_fill_iou": min(iou), "fill_iou_per_view": [round(v, 4) for v in iou],
             "max_rel_depth_median": max(med),
             "max_rel_depth_p99": max(p99), "max_conf_abs_p99": max(cp99),
-            "bounds": {"fill_iou": 0.96, "rel_depth_median": 1e-3, "rel_depth_p99": 5e-3, "conf_abs_p99": 5e-3},
+            "bounds": {"fill_iou": 0.96, "rel_depth_median": 1e-3, "rel_depth_p99": 5e-3, "conf_abs_p99": conf_p99_bound},
             "reference_vs_itself_reversed_queue": {"fill_iou_view12": 0.9713, "fill_iou_view8": 0.9850,
                                                    "rel_depth_p99": 2.8e-3, "conf_abs_p99": 4.9e-3},
             "within_bounds": bool(ok)}
@@ -492,7 +502,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config], name=args.config)
     p = cfg["params"]
     # MI_BENCH_SHARE_GPU=1 (development only, never the driver's command): all ranks of an N > 1 launch use GPU 0 and
     # the gloo backend -- the strong-scaling plumbing and the per-rank time of a 1/N share of the scene on a one-GPU box

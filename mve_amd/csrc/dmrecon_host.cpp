@@ -595,19 +595,21 @@ int check_ref_view(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref) {
 }
 
 /* MI_DMRECON_GVS_DEVICE: 0 = host, 1 = device whenever possible, unset = device when the call is large enough for the
- * launch to pay: reference views x views x features >= MI_GVS_DEVICE_MIN_WORK.  Measured: 100 reference views of a 100-view
- * scene with 2000 features (2e7) 25 ms on the device against 32 ms of host threads; 20 of a 20-view scene (8e5) 2.0 ms
- * against 1.1 ms -- and host threads cost the GPU nothing when several calls overlap.  Round 4: the kernel is the FIRST
- * thing a call puts on a GPU that has just spent tens of milliseconds in the latency-bound end of the previous batch, and
- * its serial sums run at whatever clock the GPU has fallen to: 3.8 ms under rocprofv3 (clocks held), 4 to 29 ms in steps
- * of ~10 ms without (400 reference views of the C3 scene, 1.6e7; profiles/r4_big_batch.txt), against a steady 5.1 ms of
- * host threads -- the threshold went up tenfold. */
-#define MI_GVS_DEVICE_MIN_WORK 100000000.0
+ * launch to pay.  The host loop costs reference views x views^2 x features / threads (a greedy round per selected view, a
+ * product over the selected set per candidate and feature), the kernel a launch plus much less per unit: measured, 100
+ * reference views of a 100-view scene with 2000 features (2e9) 25 ms on the device against 45 ms of host threads; 20 of a
+ * 20-view scene (1.6e7) 2.0 ms against 1.1 ms; and round 4, 400 reference views of the 20-view scene (3.2e8): the kernel is
+ * the FIRST thing a call puts on a GPU that has just spent tens of milliseconds in the latency-bound end of the previous
+ * batch, and its serial sums run at whatever clock the GPU has fallen to -- 3.8 ms under rocprofv3 (clocks held), 4 to 29 ms
+ * in steps of ~10 ms without (profiles/r4_big_batch.txt) -- against a steady 5.1 ms of host threads.  Host threads also
+ * cost the GPU nothing when several calls overlap. */
+#define MI_GVS_DEVICE_MIN_WORK 1000000000.0
 bool gvs_device_wanted(mi_dmrecon_ctx* c, int n_refs) {
     const char* e = std::getenv("MI_DMRECON_GVS_DEVICE");                /* read per call: tests switch it */
     const int mode = e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
     if (mode >= 0) return mode != 0;
-    return (double)n_refs * (double)c->sc->views.size() * (double)c->sc->features.size() >= MI_GVS_DEVICE_MIN_WORK;
+    const double nv = (double)c->sc->views.size();
+    return (double)n_refs * nv * nv * (double)c->sc->features.size() >= MI_GVS_DEVICE_MIN_WORK;
 }
 
 /* The global view selection of n reference views in one launch of gvs_device.hip (one workgroup each) from the scene
