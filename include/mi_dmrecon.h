@@ -51,7 +51,7 @@ typedef struct mi_dmrecon_camera {
 /* POD mirror of the algorithmic fields of mvs::Settings (libs/dmrecon/settings.h:22-52).
  * refViewNr is passed per call; imageEmbedding / ply / keep* flags stay in the host shim. */
 typedef struct mi_dmrecon_settings {
-    int32_t filterWidth;        /* 3, 5 or 7 (apps/dmrecon --filter-width; default 5, the only width for which the
+    int32_t filterWidth;        /* 3, 5, 7, 9 or 11 (apps/dmrecon --filter-width; default 5, the only width for which the
                                  * reference's hard-coded derivative sample 12 is the centre, patch_sampler.cc:96) */
     float   minNCC;             /* 0.3 */
     float   minParallax;        /* 10 */

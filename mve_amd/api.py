@@ -143,6 +143,8 @@ def load_library() -> ctypes.CDLL:
     L.mi_dmrecon_debug_inject_footprint.argtypes = [ctypes.c_int]          # test hook, not in the public header
     L.mi_dmrecon_debug_inject_footprint.restype = None
     L.mi_dmrecon_debug_scratch_sets.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]  # test hook, not in the public header
+    L.mi_dmrecon_debug_plan_views_host.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, ctypes.POINTER(CSettings), i32, i32, i32, vp,
+                                                   ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double)]   # test hook
     _lib = L
     return L
 
@@ -151,6 +153,41 @@ def debug_inject_footprint(view_id: int) -> None:
     """Test hook: the reference view `view_id` gets a negative pixel footprint in the calls that follow (-1: none) --
     the condition under which the reference's PatchSampler throws std::out_of_range (patch_sampler.cc:78-82)."""
     load_library().mi_dmrecon_debug_inject_footprint(int(view_id))
+
+
+def plan_views_host(scene: "SceneData", st: "Settings", ref_view: int, tables: bool = True, repeats: int = 1):
+    """Test hook: the HOST half of a call's planning -- the global view selection of `ref_view` as a reconstruct call runs
+    it when it does not use the device for it (from the scene tables, or directly: tables=False) -- on the scene's cameras,
+    image sizes and features alone.  Needs no GPU.  Returns (view ids, milliseconds of `repeats - 1` further selections)."""
+    L = load_library()
+    n = len(scene.cameras)
+    cams = (CCamera * n)()
+    widths, heights = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    for i, (cam, img) in enumerate(zip(scene.cameras, scene.images)):
+        if img is None:
+            widths[i], heights[i] = 2, 2                 # (flen 0 below: an invalid view, as one that was never set)
+            continue
+        cams[i].flen, cams[i].paspect = cam.flen, cam.paspect
+        cams[i].ppoint[:] = list(cam.ppoint)
+        cams[i].rot[:] = list(cam.rot)
+        cams[i].trans[:] = list(cam.trans)
+        heights[i], widths[i] = img.shape[0], img.shape[1]
+    feats = scene.features
+    pos = np.asarray([f.pos for f in feats], np.float32).reshape(-1, 3)
+    off = np.zeros(len(feats) + 1, np.int32)
+    off[1:] = np.cumsum([len(f.view_ids) for f in feats])
+    refs = np.asarray([v for f in feats for v in f.view_ids], np.int32)
+    if refs.size == 0:
+        refs = np.zeros(1, np.int32)
+    out = np.zeros(max(n, 1), np.int32)
+    n_out, ms = ctypes.c_int32(0), ctypes.c_double(0.0)
+    cs = st.to_c()
+    rc = L.mi_dmrecon_debug_plan_views_host(n, ctypes.cast(cams, ctypes.c_void_p), _ptr(widths), _ptr(heights), len(feats), _ptr(pos),
+                                            _ptr(off), _ptr(refs), ctypes.byref(cs), int(ref_view), 1 if tables else 0,
+                                            int(repeats), _ptr(out), ctypes.byref(n_out), ctypes.byref(ms))
+    if rc != 0:
+        _raise(rc)
+    return [int(v) for v in out[:n_out.value]], ms.value
 
 
 def device_count() -> int:

@@ -97,6 +97,10 @@ void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
                            const unsigned* key_off);
+/* one dispatch instead of four small copies: a[0..n_a) | b[0..n_b) -> out_rw, *counters -> *out_hc, the (flags, n_filled)
+ * pair of every job -> out_dyn (8 bytes per job); the out pointers are page-locked host memory */
+void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const unsigned* b, int n_b, const DevCounters* counters,
+                            const DevJob* jobs, int n_jobs, unsigned* out_rw, DevCounters* out_hc, void* out_dyn);
 /* dst: w*h records of 16 bytes (texels (x,y) (x+1,y) (x,y+1) (x+1,y+1), edge-clamped) */
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h);
 void mi_launch_pack_rgba(hipStream_t s, const uint8_t* src, uint32_t* dst, int n, int channels);

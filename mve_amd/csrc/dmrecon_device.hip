@@ -42,7 +42,7 @@
 #define WAVE 64
 
 /* This file is compiled once per supported filter width (mvs::Settings::filterWidth, apps/dmrecon --filter-width):
- * -DMI_FW=3 / 5 / 7.  Everything that depends on it lives in a namespace of its own; the host picks the table of
+ * -DMI_FW=3 / 5 / 7 / 9 / 11.  Everything that depends on it lives in a namespace of its own; the host picks the table of
  * launchers (MiDeviceApi, dmrecon_device.h) that belongs to the call's settings. */
 #ifndef MI_FW
 #define MI_FW 5
@@ -59,7 +59,7 @@
 #define MI_FWNS MI_CAT(mi_fw, MI_FW)
 /* wavefronts per SIMD the bulk kernels aim for: width 7 needs 18.8 KB of rays / master colours per wavefront in LDS,
  * which caps the occupancy anyway -- let the compiler use the registers */
-#define MI_BULK_WAVES (MI_FW == 7 ? 1 : MI_WAVES_PER_SIMD)
+#define MI_BULK_WAVES (MI_FW >= 7 ? 1 : MI_WAVES_PER_SIMD)
 
 namespace MI_FWNS {
 
@@ -1079,16 +1079,15 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     const DevView* RV = views + job->ref_view;
     const DevLevel& RL = RV->lv[job->scale];
     const uint32_t* rimg = RV->img + RL.tex_off;
-    float raw0 = 0.f, raw1 = 0.f, raw2 = 0.f;       /* L::LPV = 16: my sample's raw master colour */
-    for (int i = pl; i < MI_NS; i += L::NV * L::LPV) {
-        const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
-        const uint32_t t = GU(rimg + (size_t)(y + dj) * RL.w + (x + di));
-        raw0 = s_lut[t & 255u]; raw1 = s_lut[(t >> 8) & 255u]; raw2 = s_lut[(t >> 16) & 255u];
-        if (!L::LAT) { mcol[3 * i] = raw0; mcol[3 * i + 1] = raw1; mcol[3 * i + 2] = raw2; }
-    }
     /* computeMasterSamples (patch_sampler.cc:297-345) */
     float mm, x0, x1, x2, sd;
-    if (!L::LAT) {
+    if constexpr (!L::LAT) {
+        /* raw master colours */
+        for (int i = pl; i < MI_NS; i += L::NV * L::LPV) {
+            const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
+            const uint32_t t = GU(rimg + (size_t)(y + dj) * RL.w + (x + di));
+            mcol[3 * i] = s_lut[t & 255u]; mcol[3 * i + 1] = s_lut[(t >> 8) & 255u]; mcol[3 * i + 2] = s_lut[(t >> 16) & 255u];
+        }
         /* every lane of the patch redundantly, in the reference's summation order */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         mm = 0.f;
@@ -1107,18 +1106,43 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
             sd += a * a + b * b + c * c;
         }
     } else {
-        /* one sample per lane (lanes 0..24): wave-wide DPP reductions instead of 3 x 75 LDS reads */
-        const bool mine = pl < MI_NS;
-        mm = L::wave_sum(mine ? (raw0 + raw1 + raw2) : 0.f) / (3.f * (float)MI_NS);
+        /* the wavefront is the patch: lane pl holds samples pl, pl + 64, ... (one per lane up to 7 x 7 windows, two with
+         * 9 x 9 and 11 x 11); wave-wide DPP reductions instead of 3 x 75 LDS reads */
+        constexpr int NPL = (MI_NS + WAVE - 1) / WAVE;
+        float raw0[NPL], raw1[NPL], raw2[NPL];
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = pl + q * WAVE;
+            raw0[q] = raw1[q] = raw2[q] = 0.f;
+            if (i < MI_NS) {
+                const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
+                const uint32_t t = GU(rimg + (size_t)(y + dj) * RL.w + (x + di));
+                raw0[q] = s_lut[t & 255u]; raw1[q] = s_lut[(t >> 8) & 255u]; raw2[q] = s_lut[(t >> 16) & 255u];
+            }
+            part += raw0[q] + raw1[q] + raw2[q];
+        }
+        mm = L::wave_sum(part) / (3.f * (float)MI_NS);
         if (mm < 0.01f || mm > 0.99f) return false;
         const float im = fast_rcp(mm);
-        raw0 *= im; raw1 *= im; raw2 *= im;
-        if (mine) { mcol[3 * pl] = raw0; mcol[3 * pl + 1] = raw1; mcol[3 * pl + 2] = raw2; }
-        x0 = L::wave_sum(mine ? raw0 : 0.f) / (float)MI_NS;
-        x1 = L::wave_sum(mine ? raw1 : 0.f) / (float)MI_NS;
-        x2 = L::wave_sum(mine ? raw2 : 0.f) / (float)MI_NS;
-        const float a = raw0 - x0, b = raw1 - x1, c = raw2 - x2;
-        sd = L::wave_sum(mine ? (a * a + b * b + c * c) : 0.f);
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = pl + q * WAVE;
+            raw0[q] *= im; raw1[q] *= im; raw2[q] *= im;
+            if (i < MI_NS) { mcol[3 * i] = raw0[q]; mcol[3 * i + 1] = raw1[q]; mcol[3 * i + 2] = raw2[q]; }
+            p0 += raw0[q]; p1 += raw1[q]; p2 += raw2[q];
+        }
+        x0 = L::wave_sum(p0) / (float)MI_NS;
+        x1 = L::wave_sum(p1) / (float)MI_NS;
+        x2 = L::wave_sum(p2) / (float)MI_NS;
+        part = 0.f;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const float a = raw0[q] - x0, b = raw1[q] - x1, c = raw2[q] - x2;
+            part += (pl + q * WAVE < MI_NS) ? (a * a + b * b + c * c) : 0.f;
+        }
+        sd = L::wave_sum(part);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     ps.mmean = mm;
@@ -1683,7 +1707,7 @@ struct TailRes { PatchResult r; unsigned n_eval, n_pass; };
 __shared__ TailRes g_tail_res[MI_TAIL_WAVES];
 
 template <bool SPEC, int NV>
-__global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((amdgpu_waves_per_eu((SPEC ? MI_TAIL_SPEC_WAVES : (MI_FW == 7 ? 2 : MI_WAVES_PER_SIMD)), (SPEC ? MI_TAIL_SPEC_WAVES : MI_WAVES_PER_SIMD)))) void k_tail(TailArgs t) {
+__global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((amdgpu_waves_per_eu((SPEC ? MI_TAIL_SPEC_WAVES : (MI_FW > 7 ? 1 : MI_FW == 7 ? 2 : MI_WAVES_PER_SIMD)), (SPEC ? MI_TAIL_SPEC_WAVES : MI_WAVES_PER_SIMD)))) void k_tail(TailArgs t) {
     typedef typename LatLay<NV>::type LL;
     const OptArgs& a = t.o;
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
@@ -2795,6 +2819,24 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint32_t* __restrict__ sr
 }
 
 /* RGBA8 level -> 16-byte footprint records (DevView::quad): one lane per texel, neighbours edge-clamped. */
+/* What the host wants to know about a round (or a chunk of rounds), written to page-locked host memory in ONE dispatch:
+ * the list sizes (two runs of words), the batch counters and every job's flags / n_filled pair -- they live in four
+ * places on the device, and four 4-to-100-byte copies are four blit dispatches (4 us each plus the gaps between
+ * dependent dispatches) on the critical path of every host-visible round.  One workgroup. */
+__global__ __launch_bounds__(256) void k_round_report(const unsigned* __restrict__ a, int n_a, const unsigned* __restrict__ b, int n_b,
+                                                       const DevCounters* __restrict__ counters, const DevJob* __restrict__ jobs, int n_jobs,
+                                                       unsigned* __restrict__ out_rw, unsigned* __restrict__ out_hc, unsigned* __restrict__ out_dyn) {
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < n_a; i += 256) out_rw[i] = a[i];
+    for (int i = tid; i < n_b; i += 256) out_rw[n_a + i] = b[i];
+    if (tid < (int)(sizeof(DevCounters) / sizeof(unsigned))) out_hc[tid] = reinterpret_cast<const unsigned*>(counters)[tid];
+    static_assert(offsetof(DevJob, n_filled) == offsetof(DevJob, flags) + 4, "flags and n_filled are read as a pair");
+    for (int j = tid; j < n_jobs; j += 256) {
+        out_dyn[2 * j] = (unsigned)jobs[j].flags;
+        out_dyn[2 * j + 1] = jobs[j].n_filled;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_quadify(const uint32_t* __restrict__ src, u32x4* __restrict__ dst, int w, int h) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= w * h) return;
@@ -2991,6 +3033,11 @@ void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* wo
     hipLaunchKernelGGL(k_apply_seeds, dim3((n_work + 255) / 256), dim3(256), 0, s, a);
 }
 
+void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const unsigned* b, int n_b, const DevCounters* counters,
+                            const DevJob* jobs, int n_jobs, unsigned* out_rw, DevCounters* out_hc, void* out_dyn) {
+    hipLaunchKernelGGL(k_round_report, dim3(1), dim3(256), 0, s, a, n_a, b, n_b, counters, jobs, n_jobs, out_rw,
+                       reinterpret_cast<unsigned*>(out_hc), static_cast<unsigned*>(out_dyn));
+}
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h) {
     hipLaunchKernelGGL(k_quadify, dim3((w * h + 255) / 256), dim3(256), 0, s, src, (u32x4*)dst, w, h);
 }

@@ -35,6 +35,7 @@
 #include <cstring>
 #include <ctime>
 #include <limits>
+#include <immintrin.h>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -230,7 +231,16 @@ struct SceneGeom {
     size_t nv = 0, nf = 0;
     std::vector<uint8_t> sees;               /* [v * nf + f]: v references f and f is inside v's frustum */
     std::vector<float> zcam;                 /* [v * nf + f]: (worldToCam_v . f).z */
-    std::vector<float> plx;                  /* [(v1 * nv + v2) * nf + f]: parallax in degrees where both see f */
+    std::vector<float> plx;                  /* [(v1 * nv + v2) * nf + f]: parallax in degrees where both see f, +inf elsewhere */
+    /* [(v1 * nv + v2) * nf + f]: the factor benefitFromView multiplies a score by for the pair (:76-79,91-98) -- (plx / 10)^2
+     * below minParallax, 1 elsewhere -- for the minParallax of the calls so far (a setting; entries are immutable once
+     * built and shared by the threads that plan with them; guarded by SceneStore::mu) */
+    struct PairFactors {
+        std::vector<float> f;                /* [(v1 * nv + v2) * nf + f] */
+        std::vector<uint8_t> plain;          /* [v1 * nv + v2]: every factor of the pair is 1 (the two views are nowhere closer than
+                                              * minParallax: most pairs) -- multiplying by the row changes nothing */
+    };
+    std::vector<std::pair<float, std::shared_ptr<const PairFactors> > > pen;
 };
 
 /*
@@ -403,12 +413,14 @@ int sync_views(mi_dmrecon_ctx* c) {
 }  // namespace
 
 /* the launchers of the kernels compiled for a filter width (dmrecon_device.hip, one object per width) */
-extern const MiDeviceApi mi_device_api_fw3, mi_device_api_fw5, mi_device_api_fw7;
+extern const MiDeviceApi mi_device_api_fw3, mi_device_api_fw5, mi_device_api_fw7, mi_device_api_fw9, mi_device_api_fw11;
 const MiDeviceApi* mi_device_api(int filter_width) {
     switch (filter_width) {
         case 3: return &mi_device_api_fw3;
         case 5: return &mi_device_api_fw5;
         case 7: return &mi_device_api_fw7;
+        case 9: return &mi_device_api_fw9;
+        case 11: return &mi_device_api_fw11;
         default: return nullptr;
     }
 }
@@ -418,7 +430,7 @@ namespace {
 int check_settings(const mi_dmrecon_settings* st) {
     if (!st) return fail(MI_DMRECON_EINVAL, "null settings");
     if (st->scale < 0) return fail(MI_DMRECON_EINVAL, "Invalid scale factor");            /* dmrecon.cc:41-42 */
-    if (!mi_device_api(st->filterWidth)) return fail(MI_DMRECON_EINVAL, "filterWidth %d unsupported (3, 5 or 7)", st->filterWidth);
+    if (!mi_device_api(st->filterWidth)) return fail(MI_DMRECON_EINVAL, "filterWidth %d unsupported (3, 5, 7, 9 or 11)", st->filterWidth);
     if (st->nrReconNeighbors < 1 || st->nrReconNeighbors > MI_DMRECON_MAX_LOCAL_VIEWS)
         return fail(MI_DMRECON_EINVAL, "nrReconNeighbors must be in 1..%d", MI_DMRECON_MAX_LOCAL_VIEWS);
     if (st->globalVSMax < 1 || st->globalVSMax > MI_DMRECON_MAX_GLOBAL_VIEWS)
@@ -445,6 +457,7 @@ void build_scene_geom(SceneStore& sc) {
     SceneGeom& g = sc.geom;
     const size_t nv = sc.views.size(), nf = sc.features.size();
     g.nv = nv; g.nf = nf; g.built = true; g.on_device = false;
+    g.pen.clear();
     /* the size guard first: a bundle too large for the parallax table (1000 views x 1M features would need 4 TB) gets
      * no tables at all -- the direct path (plan_global_views) needs O(features of the reference view) */
     g.has_plx = nv * nv * nf <= ((size_t)1 << 26);                         /* 256 MB of floats at most */
@@ -470,7 +483,9 @@ void build_scene_geom(SceneStore& sc) {
             dir[(size_t)v * nf + f] = normalized(sub(p, sc.views[v].pos()));
         }
     }
-    g.plx.assign(nv * nv * nf, 0.f);
+    /* (+inf where the two views do not both see the feature: "parallax < minParallax" is false there, which is what
+     * benefitFromView's seesFeature test amounts to, global_view_selection.cc:93-98) */
+    g.plx.assign(nv * nv * nf, std::numeric_limits<float>::infinity());
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
     for (long v1 = 0; v1 < (long)nv; ++v1)
         for (size_t v2 = (size_t)v1 + 1; v2 < nv; ++v2)
@@ -483,17 +498,91 @@ void build_scene_geom(SceneStore& sc) {
             }
 }
 
-/* plan_global_views from the scene tables: the same selection, without a single acos or projection per call */
+/* The pair factors of the scene for one minParallax (SceneGeom::pen); built on first use. */
+std::shared_ptr<const SceneGeom::PairFactors> scene_pair_factors(SceneStore& sc, float minP) {
+    std::lock_guard<std::mutex> lock(sc.mu);
+    SceneGeom& g = sc.geom;
+    for (size_t i = 0; i < g.pen.size(); ++i) if (g.pen[i].first == minP) return g.pen[i].second;
+    auto tab = std::make_shared<SceneGeom::PairFactors>();
+    tab->f.resize(g.plx.size());
+    const float* pl = g.plx.data();
+    float* out = tab->f.data();
+    const long n = (long)g.plx.size();
+    const int nt = std::max(1, std::min(omp_get_num_procs(), 16));
+#pragma omp parallel for schedule(static) num_threads(nt) if (n > (1 << 20))
+    for (long k = 0; k < n; ++k) {
+        /* (written without a branch so that the loop vectorises: the value where plx < minP, the bits of 1.0f elsewhere) */
+        const float plx = pl[k];
+        const float q = plx / 10.f;
+        const float v = q * q;
+        uint32_t vb; std::memcpy(&vb, &v, 4);
+        const uint32_t m = (plx < minP) ? 0xFFFFFFFFu : 0u;
+        const uint32_t rb = (vb & m) | (0x3F800000u & ~m);
+        float r; std::memcpy(&r, &rb, 4);
+        out[k] = r;
+    }
+    tab->plain.assign(g.nv * g.nv, 1);
+    const long npair = (long)(g.nv * g.nv);
+#pragma omp parallel for schedule(static) num_threads(nt) if (n > (1 << 20))
+    for (long pr = 0; pr < npair; ++pr) {
+        const float* row = out + (size_t)pr * g.nf;
+        uint8_t one = 1;
+        for (size_t f = 0; f < g.nf; ++f) if (row[f] != 1.f) { one = 0; break; }
+        tab->plain[(size_t)pr] = one;
+    }
+    if (g.pen.size() >= 2) g.pen.erase(g.pen.begin());                       /* (whoever still plans with it holds it) */
+    g.pen.push_back(std::make_pair(minP, std::shared_ptr<const SceneGeom::PairFactors>(tab)));
+    return g.pen.back().second;
+}
+
+/* out[t] = p[t][0] + p[t][1] + ... + p[t][n - 1], every row summed in index order from 0.f (the order is the result:
+ * float addition does not associate), eight rows at a time: blocks of 8 x 8 are transposed in registers so that ONE
+ * vector addition adds the next element of all eight rows.  (x86-64-v3: AVX2 is part of the build's baseline.) */
+static void sum_rows8(const float* const p[8], size_t n, float out[8]) {
+    __m256 acc = _mm256_setzero_ps();
+    size_t f = 0;
+    for (; f + 8 <= n; f += 8) {
+        const __m256 r0 = _mm256_loadu_ps(p[0] + f), r1 = _mm256_loadu_ps(p[1] + f), r2 = _mm256_loadu_ps(p[2] + f), r3 = _mm256_loadu_ps(p[3] + f);
+        const __m256 r4 = _mm256_loadu_ps(p[4] + f), r5 = _mm256_loadu_ps(p[5] + f), r6 = _mm256_loadu_ps(p[6] + f), r7 = _mm256_loadu_ps(p[7] + f);
+        const __m256 t0 = _mm256_unpacklo_ps(r0, r1), t1 = _mm256_unpackhi_ps(r0, r1), t2 = _mm256_unpacklo_ps(r2, r3), t3 = _mm256_unpackhi_ps(r2, r3);
+        const __m256 t4 = _mm256_unpacklo_ps(r4, r5), t5 = _mm256_unpackhi_ps(r4, r5), t6 = _mm256_unpacklo_ps(r6, r7), t7 = _mm256_unpackhi_ps(r6, r7);
+        const __m256 u0 = _mm256_shuffle_ps(t0, t2, 0x44), u1 = _mm256_shuffle_ps(t0, t2, 0xEE), u2 = _mm256_shuffle_ps(t1, t3, 0x44), u3 = _mm256_shuffle_ps(t1, t3, 0xEE);
+        const __m256 u4 = _mm256_shuffle_ps(t4, t6, 0x44), u5 = _mm256_shuffle_ps(t4, t6, 0xEE), u6 = _mm256_shuffle_ps(t5, t7, 0x44), u7 = _mm256_shuffle_ps(t5, t7, 0xEE);
+        /* column j = element f + j of rows 0..7 */
+        acc = _mm256_add_ps(acc, _mm256_permute2f128_ps(u0, u4, 0x20));
+        acc = _mm256_add_ps(acc, _mm256_permute2f128_ps(u1, u5, 0x20));
+        acc = _mm256_add_ps(acc, _mm256_permute2f128_ps(u2, u6, 0x20));
+        acc = _mm256_add_ps(acc, _mm256_permute2f128_ps(u3, u7, 0x20));
+        acc = _mm256_add_ps(acc, _mm256_permute2f128_ps(u0, u4, 0x31));
+        acc = _mm256_add_ps(acc, _mm256_permute2f128_ps(u1, u5, 0x31));
+        acc = _mm256_add_ps(acc, _mm256_permute2f128_ps(u2, u6, 0x31));
+        acc = _mm256_add_ps(acc, _mm256_permute2f128_ps(u3, u7, 0x31));
+    }
+    _mm256_storeu_ps(out, acc);
+    for (; f < n; ++f) for (int t = 0; t < 8; ++t) out[t] += p[t][f];
+}
+
+/* plan_global_views from the scene tables: the same selection, without a single acos, projection or division per
+ * candidate and round.  DENSE over the scene's features: a candidate's scores are an array of nf floats, 0 where the
+ * feature is not attached to the reference view or not seen by the candidate -- adding +0 to a sum of non-negative
+ * floats changes nothing, so the benefit is the reference's sum over the candidate's features in their order (:66-99)
+ * bit for bit, and every loop below is a contiguous one.  The arrays live with the calling thread (GvsScratch). */
+struct GvsScratch { std::vector<float> base, prod; std::vector<uint8_t> attached; };
 int plan_global_views_tables(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref, std::vector<int>& global) {
+    static thread_local GvsScratch W;
     SceneGeom const& g = c->sc->geom;
     const size_t nv = g.nv, nf = g.nf;
     HostView const& R = c->sc->views[ref];
+    const float minP = st->minParallax;
+    const std::shared_ptr<const SceneGeom::PairFactors> pen_tab = scene_pair_factors(*c->sc, minP);
+    const float* P = pen_tab->f.data();
+    const uint8_t* plain = pen_tab->plain.data();
     const bool no_box = st->aabbMin[0] == -std::numeric_limits<float>::max() && st->aabbMax[0] == std::numeric_limits<float>::max()
                      && st->aabbMin[1] == -std::numeric_limits<float>::max() && st->aabbMax[1] == std::numeric_limits<float>::max()
                      && st->aabbMin[2] == -std::numeric_limits<float>::max() && st->aabbMax[2] == std::numeric_limits<float>::max();
     /* features attached to the reference view (dmrecon.cc:185-196) */
-    std::vector<int> feat;
-    feat.reserve(nf);
+    W.attached.assign(nf, 0);
+    uint8_t* att = W.attached.data();
     const uint8_t* sees_ref = &g.sees[(size_t)ref * nf];
     for (size_t f = 0; f < nf; ++f) {
         if (!sees_ref[f]) continue;
@@ -501,83 +590,78 @@ int plan_global_views_tables(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
             Feature const& ft = c->sc->features[f];
             if (!in_box(mk(ft.pos[0], ft.pos[1], ft.pos[2]), st->aabbMin, st->aabbMax)) continue;
         }
-        feat.push_back((int)f);
-    }
-    /* per view: the attached features it sees too (dmrecon.cc:198-206), as global feature indices */
-    std::vector<std::vector<int> > featInd(nv);
-    for (size_t v = 0; v < nv; ++v) {
-        if ((int)v == ref || !c->sc->views[v].valid) continue;
-        const uint8_t* sv = &g.sees[v * nf];
-        for (size_t l = 0; l < feat.size(); ++l) if (sv[feat[l]]) featInd[v].push_back(feat[l]);
-    }
-    const float minP = st->minParallax;
-    /* the part of benefitFromView's score that does not depend on the selected set (:76-89) */
-    std::vector<std::vector<float> > base(nv);
-    const float inv_m = R.levels[st->scale].invproj[0];
-    for (size_t i = 0; i < nv; ++i) {
-        if ((int)i == ref || !c->sc->views[i].valid) continue;
-        const float inv_n = c->sc->views[i].levels[0].invproj[0];
-        const float* plx_ri = &g.plx[((size_t)ref * nv + i) * nf];
-        base[i].resize(featInd[i].size());
-        for (size_t k = 0; k < featInd[i].size(); ++k) {
-            const size_t f = featInd[i][k];
-            float score = 1.f;
-            const float plx = plx_ri[f];
-            if (plx < minP) score *= (plx / 10.f) * (plx / 10.f);
-            const float mfp = g.zcam[(size_t)ref * nf + f] * inv_m;
-            const float nfp = g.zcam[i * nf + f] * inv_n;
-            float ratio = mfp / nfp;
-            if (ratio > 2.) ratio = 2. / ratio;
-            else if (ratio > 1.) ratio = 1.;
-            score *= ratio;
-            base[i][k] = score;
-        }
+        att[f] = 1;
     }
     std::vector<char> available(nv, 1);                                     /* global_view_selection.cc:23-30 */
     available[ref] = 0;
     for (size_t i = 0; i < nv; ++i) if (!c->sc->views[i].valid) available[i] = 0;
+    /* the part of benefitFromView's score that does not depend on the selected set (:76-89); 0 where the candidate
+     * does not see an attached feature (dmrecon.cc:198-206) */
+    W.base.resize(nv * nf); W.prod.resize(nv * nf);
+    const float inv_m = R.levels[st->scale].invproj[0];
+    const float* z_ref = &g.zcam[(size_t)ref * nf];
+    for (size_t i = 0; i < nv; ++i) {
+        if (!available[i]) continue;
+        const float inv_n = c->sc->views[i].levels[0].invproj[0];
+        const float* p_ri = P + ((size_t)ref * nv + i) * nf;
+        const float* z_i = &g.zcam[i * nf];
+        const uint8_t* sv = &g.sees[i * nf];
+        float* b = W.base.data() + i * nf;
+        for (size_t f = 0; f < nf; ++f) {
+            if (!(att[f] & sv[f])) { b[f] = 0.f; continue; }
+            const float score = p_ri[f];                                    /* 1.f, times (plx / 10)^2 below minParallax */
+            const float mfp = z_ref[f] * inv_m;
+            const float nfp = z_i[f] * inv_n;
+            float ratio = mfp / nfp;
+            if (ratio > 2.) ratio = 2. / ratio;
+            else if (ratio > 1.) ratio = 1.;
+            b[f] = score * ratio;
+        }
+    }
     std::vector<int> selected;          /* kept sorted ascending = std::set order */
-    std::vector<std::vector<std::vector<float> > > pen(nv);
-    std::vector<float> scratch;
+    std::vector<int> cand;
+    std::vector<float> benefit(nv, 0.f);
+    cand.reserve(nv);
     bool foundOne = true;
     while (foundOne && selected.size() < (size_t)st->globalVSMax) {
-        float maxBenefit = 0.f; size_t maxView = 0; foundOne = false;
-        for (size_t i = 0; i < nv; ++i) {
-            if (!available[i]) continue;
-            const size_t nk = featInd[i].size();
-            const size_t ns = selected.size();
-            /* score[k] = base[k] * pen(sel_0)[k] * pen(sel_1)[k] ... in ascending view order (benefitFromView iterates
-             * the std::set), one selected view at a time over all features: the same products in the same order per
-             * feature as the reference, in a form the compiler vectorises; the sum stays sequential in k (:66-99) */
-            scratch.assign(base[i].begin(), base[i].end());
-            float* sc = scratch.data();
+        cand.clear();
+        for (size_t i = 0; i < nv; ++i) if (available[i]) cand.push_back((int)i);
+        /* score[f] = base[f] * factor(sel_0)[f] * factor(sel_1)[f] ... in ascending view order (benefitFromView iterates
+         * the std::set; a selected view that does not see the feature contributes x 1, :93), one selected view at a time
+         * over all features: the same products in the same order per feature as the reference */
+        const size_t ns = selected.size();
+        for (size_t ci = 0; ci < cand.size(); ++ci) {
+            const size_t i = (size_t)cand[ci];
+            float* sc = W.prod.data() + i * nf;
+            const float* b = W.base.data() + i * nf;
+            const float* src = b;                                           /* (x 1 is exact: rows of ones are skipped) */
             for (size_t q = 0; q < ns; ++q) {
-                const float* pq = pen[selected[q]][i].data();
-                for (size_t k = 0; k < nk; ++k) sc[k] *= pq[k];
+                const size_t pr = (size_t)selected[q] * nv + i;
+                if (plain[pr]) continue;
+                const float* pq = P + pr * nf;
+                for (size_t f = 0; f < nf; ++f) sc[f] = src[f] * pq[f];
+                src = sc;
             }
-            float benefit = 0;
-            for (size_t k = 0; k < nk; ++k) benefit += sc[k];
-            if (benefit > maxBenefit) { maxBenefit = benefit; maxView = i; foundOne = true; }
+            if (src == b) std::memcpy(sc, b, nf * sizeof(float));
+        }
+        /* A candidate's benefit is the sum of its scores in feature order -- a chain of dependent additions, four cycles
+         * each; the sums of EIGHT candidates run side by side (independent chains, each in its own order: the same floats). */
+        for (size_t g0 = 0; g0 < cand.size(); g0 += 8) {
+            const size_t m = std::min<size_t>(8, cand.size() - g0);
+            const float* p[8];
+            for (size_t t = 0; t < 8; ++t) p[t] = W.prod.data() + (size_t)cand[g0 + (t < m ? t : 0)] * nf;   /* (a short last group repeats its first candidate) */
+            float b[8];
+            sum_rows8(p, nf, b);
+            for (size_t t = 0; t < m; ++t) benefit[(size_t)cand[g0 + t]] = b[t];
+        }
+        float maxBenefit = 0.f; size_t maxView = 0; foundOne = false;
+        for (size_t i = 0; i < nv; ++i) {                                   /* ascending, strictly greater: the reference's tie-break */
+            if (!available[i]) continue;
+            if (benefit[i] > maxBenefit) { maxBenefit = benefit[i]; maxView = i; foundOne = true; }
         }
         if (foundOne) {
             selected.insert(std::upper_bound(selected.begin(), selected.end(), (int)maxView), (int)maxView);
             available[maxView] = 0;
-            if (selected.size() < (size_t)st->globalVSMax) {
-                pen[maxView].resize(nv);
-                const uint8_t* sm = &g.sees[maxView * nf];
-                for (size_t i = 0; i < nv; ++i) {
-                    if (!available[i]) continue;
-                    std::vector<float>& pv = pen[maxView][i];
-                    pv.assign(featInd[i].size(), 1.f);
-                    const float* pl = &g.plx[(maxView * nv + i) * nf];
-                    for (size_t k = 0; k < featInd[i].size(); ++k) {
-                        const size_t f = featInd[i][k];
-                        if (!sm[f]) continue;
-                        const float plx = pl[f];
-                        if (plx < minP) pv[k] = (plx / 10.f) * (plx / 10.f);
-                    }
-                }
-            }
         }
     }
     global = selected;
@@ -1044,16 +1128,9 @@ void mi_dmrecon_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 void* mi_dmrecon_ctx_stream(mi_dmrecon_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_camera* cam, int32_t width,
-                         int32_t height, int32_t channels, const uint8_t* pixels, bool async) {
-    if (!c || !cam || !pixels) return fail(MI_DMRECON_EINVAL, "null argument");
-    if (view_id < 0 || view_id >= (1 << 20)) return fail(MI_DMRECON_EINVAL, "bad view id %d", view_id);
-    if (width < 2 || height < 2 || width > 65535 || height > 65535) return fail(MI_DMRECON_EINVAL, "bad image size %dx%d", width, height);
-    if (channels < 1 || channels > 4) return fail(MI_DMRECON_EINVAL, "Image with invalid number of channels");
-    HIP_TRY(hipSetDevice(c->device));
-    if ((size_t)view_id >= c->sc->views.size()) c->sc->views.resize(view_id + 1);
-    HostView& v = c->sc->views[view_id];
-    if (v.d_img) { (void)hipFree(v.d_img); v.d_img = nullptr; }
+/* The host half of a view: camera, world-to-camera matrix and the calibration of every pyramid level (no pixels).
+ * Returns the texels over all levels. */
+static size_t host_view_set_camera(HostView& v, const mi_dmrecon_camera* cam, int32_t width, int32_t height) {
     v.cam = *cam;
     v.valid = cam->flen != 0.f;                                   /* CameraInfo::is_valid (View::is_camera_valid) */
     const float* rot = cam->rot; const float* t = cam->trans;
@@ -1083,6 +1160,20 @@ static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_ca
         v.levels.push_back(l);
         off += (size_t)cw * ch;
     }
+    return off;
+}
+
+static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_camera* cam, int32_t width,
+                         int32_t height, int32_t channels, const uint8_t* pixels, bool async) {
+    if (!c || !cam || !pixels) return fail(MI_DMRECON_EINVAL, "null argument");
+    if (view_id < 0 || view_id >= (1 << 20)) return fail(MI_DMRECON_EINVAL, "bad view id %d", view_id);
+    if (width < 2 || height < 2 || width > 65535 || height > 65535) return fail(MI_DMRECON_EINVAL, "bad image size %dx%d", width, height);
+    if (channels < 1 || channels > 4) return fail(MI_DMRECON_EINVAL, "Image with invalid number of channels");
+    HIP_TRY(hipSetDevice(c->device));
+    if ((size_t)view_id >= c->sc->views.size()) c->sc->views.resize(view_id + 1);
+    HostView& v = c->sc->views[view_id];
+    if (v.d_img) { (void)hipFree(v.d_img); v.d_img = nullptr; }
+    const size_t off = host_view_set_camera(v, cam, width, height);
     v.n_texels = off;
     /* RGBA8 levels, then (16-byte aligned) the same levels as 2x2 footprint records: 4 + 16 bytes per texel */
     v.quad_off = (off + 3) & ~(size_t)3;
@@ -1418,7 +1509,8 @@ int BatchRun::upload() {
     HIP_TRY(hipMemsetAsync(c->bs.d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), S));
     HIP_TRY(hipMemcpyAsync(c->bs.d_keyoff.p, c->bs.h_up + up_keyoff, nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
     if (!c->bs.h_poll) {
-        if (hipHostMalloc((void**)&c->bs.h_poll, 3 * sizeof(TailPoll), hipHostMallocDefault) != hipSuccess)
+        /* (mapped: written by k_round_report, not by copies) */
+        if (hipHostMalloc((void**)&c->bs.h_poll, 3 * sizeof(TailPoll), hipHostMallocMapped) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(poll buffer) failed");
         for (int k = 0; k < 2; ++k) if (hipEventCreateWithFlags(&c->bs.poll_ev[k], hipEventDisableTiming) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipEventCreate failed");
@@ -1428,7 +1520,7 @@ int BatchRun::upload() {
         if (c->bs.h_dyn) (void)hipHostFree(c->bs.h_dyn);
         c->bs.h_dyn = nullptr; c->bs.h_dyn_cap = 0;
         const size_t want = 3 * (2 * (size_t)nj + 64) * sizeof(JobDyn);      /* twice the views: see DevBuf::reserve */
-        if (hipHostMalloc((void**)&c->bs.h_dyn, want, hipHostMallocDefault) != hipSuccess)
+        if (hipHostMalloc((void**)&c->bs.h_dyn, want, hipHostMallocMapped) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(job poll buffer) failed");
         c->bs.h_dyn_cap = want;
     }
@@ -1583,10 +1675,9 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         ev.end(S);
         const int slot = r & 1;
         TailPoll& P = c->bs.h_poll[slot];
-        if (hipMemcpyAsync(&P.rw[0], n_thr_p, sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
-            || hipMemcpyAsync(&P.rw[1], n_lat_p, sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
-            || hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S) != hipSuccess
-            || read_dyn(slot) != hipSuccess || hipEventRecord(c->bs.poll_ev[slot], S) != hipSuccess)
+        /* the round's report: both list sizes, the counters and the views' flags in one dispatch (k_round_report) */
+        mi_launch_round_report(S, n_thr_p, 1, n_lat_p, 1, c->d_counters, c->bs.d_jobs.p, nj, P.rw, &P.hc, dyn_of(slot));
+        if (hipGetLastError() != hipSuccess || hipEventRecord(c->bs.poll_ev[slot], S) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "enqueue of a propagation round failed");
         pend[n_pend].round = r; pend[n_pend].ev_thr = ev_thr; pend[n_pend].ev_lat = ev_lat; ++n_pend;
         return 0;
@@ -1700,9 +1791,9 @@ int BatchRun::tail_rounds(bool& to_front) {
         }
         info[slot].ev_last = ev.items.size();
         TailPoll& P = c->bs.h_poll[slot];
-        if (hipMemcpyAsync(P.rw, c->bs.d_round_work.p + info[slot].first, MI_TAIL_CHUNK * sizeof(unsigned), hipMemcpyDeviceToHost, S) != hipSuccess
-            || hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S) != hipSuccess
-            || read_dyn(slot) != hipSuccess || hipEventRecord(c->bs.poll_ev[slot], S) != hipSuccess)
+        mi_launch_round_report(S, c->bs.d_round_work.p + info[slot].first, MI_TAIL_CHUNK, nullptr, 0, c->d_counters, c->bs.d_jobs.p, nj,
+                               P.rw, &P.hc, dyn_of(slot));
+        if (hipGetLastError() != hipSuccess || hipEventRecord(c->bs.poll_ev[slot], S) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "enqueue of tail rounds failed");
         return 0;
     };
@@ -1865,12 +1956,18 @@ int BatchRun::front_rounds() {
                         if (trace) fprintf(stderr, "[mi_dmrecon] view %d streamed back at %.3f ms of the front phase (%s)\n", jobs[j].ref_view, now_ms() - t_mark, over ? "kernel over" : "kernel running");
                     }
                 if (over || n_streamed == nj) break;
-                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                /* (a sleep of any length comes back 50+ us later: the timer slack; this thread has nothing else to do) */
+                for (int k = 0; k < 200; ++k) cpu_relax();
             }
         }
-        HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
-        HIP_TRY(read_dyn(0));
-        HIP_TRY(hipMemcpyAsync(h_done ? (void*)(h_done + nj) : (void*)front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
+        if (h_done) {
+            mi_launch_round_report(S, d_stats, 4 * nj, nullptr, 0, c->d_counters, c->bs.d_jobs.p, nj, h_done + nj, &P.hc, dyn_of(0));
+            HIP_TRY(hipGetLastError());
+        } else {
+            HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
+            HIP_TRY(read_dyn(0));
+            HIP_TRY(hipMemcpyAsync(front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
+        }
         HIP_TRY(wait_stream(S));
         if (h_done) std::memcpy(front_stats.data(), h_done + nj, 4 * (size_t)nj * sizeof(unsigned));
         hc = P.hc;
@@ -2444,6 +2541,41 @@ static int mi_dmrecon_pointset_impl(mi_dmrecon_ctx* c, const mi_dmrecon_camera* 
 /* test hook (not in the public header): the reference view with this id gets a negative pixel footprint in the calls
  * that follow (-1: none), see fill_job */
 void mi_dmrecon_debug_inject_footprint(int view_id) { g_inject_footprint.store(view_id); }
+
+/* Test hook (not in the public header): the HOST half of the planning -- global view selection of reference view `ref`,
+ * exactly the code a reconstruct call runs (plan_global_views: from the scene tables, or directly with tables = 0) -- on
+ * cameras and features alone, so that it can be checked against the oracle without a GPU.  ms_out (optional): the time
+ * of `repeats` selections, the scene tables already built. */
+int mi_dmrecon_debug_plan_views_host(int32_t n_views, const mi_dmrecon_camera* cams, const int32_t* widths, const int32_t* heights,
+                                     int32_t n_feat, const float* pos, const int32_t* off, const int32_t* ids,
+                                     const mi_dmrecon_settings* st, int32_t ref, int32_t tables, int32_t repeats,
+                                     int32_t* ids_out, int32_t* n_out, double* ms_out) {
+    try {
+        if (n_views <= 0 || !cams || !widths || !heights || !st || !ids_out || !n_out) return fail(MI_DMRECON_EINVAL, "null argument");
+        mi_dmrecon_ctx c;
+        c.device = -1;
+        c.sc = std::make_shared<SceneStore>();
+        c.sc->views.resize(n_views);
+        for (int i = 0; i < n_views; ++i) (void)host_view_set_camera(c.sc->views[i], &cams[i], widths[i], heights[i]);
+        c.sc->features.resize(n_feat);
+        for (int i = 0; i < n_feat; ++i) {
+            Feature& f = c.sc->features[i];
+            f.pos[0] = pos[3 * i]; f.pos[1] = pos[3 * i + 1]; f.pos[2] = pos[3 * i + 2];
+            f.ref_begin = off[i]; f.ref_end = off[i + 1];
+        }
+        c.sc->feat_refs.assign(ids, ids + (n_feat ? off[n_feat] : 0));
+        if (!tables) { c.sc->geom.built = true; c.sc->geom.has_plx = false; }   /* as for a bundle too large for the tables */
+        std::vector<int> global;
+        int rc = plan_global_views(&c, st, ref, global);                        /* (builds the tables) */
+        const double t0 = now_ms();
+        for (int k = 1; k < repeats && rc == 0; ++k) rc = plan_global_views(&c, st, ref, global);
+        if (ms_out) *ms_out = now_ms() - t0;
+        if (rc) return rc;
+        *n_out = (int32_t)global.size();
+        for (size_t i = 0; i < global.size(); ++i) ids_out[i] = global[i];
+        return 0;
+    } catch (std::exception const& e) { return fail(MI_DMRECON_EDEVICE, "%s", e.what()); }
+}
 
 /* test hook (not in the public header): the scratch sets of the context's scene that no call holds at the moment, and the
  * pixel capacity of the largest of them (ScratchLease) */

@@ -160,3 +160,42 @@ def test_bench_call_plan():
     assert b.plan_calls(12, 3, 1) == (1, 12, 3) and b.plan_calls(60, 6, 4) == (4, 15, 6)
     with pytest.raises(SystemExit):
         b.plan_calls(10, 6, 4)
+
+
+# ---- the host half of a call's planning, without a GPU ---------------------------------------------------------------
+
+def _host_views(scene, ref, tables, **kw):
+    return api.plan_views_host(scene, api.Settings(refViewNr=ref, **kw), ref, tables=tables)[0]
+
+
+def test_host_view_selection_is_the_references(g1, g1_scene, h1_scene, w1, w1_scene):
+    """GlobalViewSelection as a reconstruct call runs it on the host (plan_global_views: from the scene tables -- dense
+    score arrays, factor rows shared per scene, eight in-order sums side by side -- and directly, the form for bundles too
+    large for tables) against the restatement, which is bit-identical to the reference: the same views for every
+    reference view of the fixtures, with 40 global views, with minParallax / globalVSMax / scale / bounding box changed."""
+    from oracle import oracle as orc
+    for scene, kws in ((g1_scene, [dict(), dict(globalVSMax=2), dict(minParallax=25.0), dict(scale=1)]),
+                       (h1_scene, [dict(), dict(minParallax=4.0)]),
+                       (w1_scene, [dict(globalVSMax=40), dict(globalVSMax=40, minParallax=3.0), dict()])):
+        S = orc.OracleScene(scene)
+        n = len(scene.cameras)
+        for kw in kws:
+            okw = dict(global_max=kw.get("globalVSMax", 20), scale=kw.get("scale", 0))
+            if "minParallax" in kw:
+                okw["minParallax"] = kw["minParallax"]
+            for ref in range(n) if n <= 9 else (0, 7, 20, 41):
+                want = S.global_vs(orc.make_settings(ref_view=ref, **okw))
+                for tables in (True, False):
+                    assert _host_views(scene, ref, tables, **kw) == want, (n, kw, ref, tables)
+    assert _host_views(w1_scene, 0, True, globalVSMax=40) == list(w1["gvs40"])          # the reference binary's own list
+    # a bounding box that cuts the features (dmrecon.cc:190-193)
+    pos = np.array([f.pos for f in g1_scene.features], np.float32)
+    lo, hi = np.percentile(pos, 20, axis=0), np.percentile(pos, 85, axis=0)
+    S = orc.OracleScene(g1_scene)
+    st = orc.make_settings(ref_view=1)
+    st.aabbMin[:], st.aabbMax[:] = [float(v) for v in lo], [float(v) for v in hi]
+    want = S.global_vs(st)
+    for tables in (True, False):
+        assert _host_views(g1_scene, 1, tables, aabbMin=list(lo), aabbMax=list(hi)) == want
+    with pytest.raises(ValueError):
+        _host_views(g1_scene, 7, True)                                                    # master view out of bounds

@@ -648,7 +648,7 @@ def test_edge_cases(gpu_ctx, g1_scene):
     with pytest.raises(ValueError):
         gpu_ctx.reconstruct(api.Settings(filterWidth=4), [0])
     with pytest.raises(ValueError):
-        gpu_ctx.reconstruct(api.Settings(filterWidth=9), [0])
+        gpu_ctx.reconstruct(api.Settings(filterWidth=13), [0])                # compiled for the odd widths 3..11
     with pytest.raises(ValueError):
         gpu_ctx.reconstruct(api.Settings(nrReconNeighbors=9), [0])       # more than MI_DMRECON_MAX_LOCAL_VIEWS
     with pytest.raises(ValueError):
@@ -722,11 +722,12 @@ def test_hard_scene_maps_vs_reference(gpu_ctx, h1, h1_scene):
     assert stats["n_view_replaced"] > 50 and stats["n_iter14"] >= 1
 
 
-# ---- apps/dmrecon --filter-width: 3 x 3 and 7 x 7 windows ---------------------------------------------------
+# ---- apps/dmrecon --filter-width: 3 x 3, 7 x 7, 9 x 9 and 11 x 11 windows ------------------------------------
 
-@pytest.mark.parametrize("fw", [3, 7])
+@pytest.mark.parametrize("fw", [3, 7, 9, 11])
 def test_filter_widths_vs_reference(gpu_ctx, g1, g1_fw, g1_scene, fw, monkeypatch):
-    """mvs::Settings::filterWidth 3 and 7 (the kernels are compiled once per width): maps against the reference's own
+    """mvs::Settings::filterWidth 3, 7, 9 and 11 (the kernels are compiled once per width; from 9 x 9 on a lane of the
+    latency layout holds two samples of the window): maps against the reference's own
     output of `dmrecon --filter-width=N`, patch results against its PatchOptimization class and against the oracle,
     in both lane layouts.  (Width 3: the reference's derivative step reads out of bounds, see tests/golden/
     make_golden_fw.py -- its patch results carry that noise, so the patch-level check is against the oracle there.)"""
@@ -756,9 +757,9 @@ def test_filter_widths_vs_reference(gpu_ctx, g1, g1_fw, g1_scene, fw, monkeypatc
         assert (np.abs(go[ok, 1] - oo[ok, 1]) / oo[ok, 1] <= 1e-3).mean() >= (0.97 if fw == 3 else 0.99)
         assert (np.abs(go[ok, 0] - oo[ok, 0]) <= 5e-3).mean() >= (0.96 if fw == 3 else 0.98)
         assert (gl[ok] == ol[ok]).all(1).mean() >= 0.98
-        if fw == 7:
-            g2, g2l = gpu_ctx.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
-            ref = g1_fw["fw7_opt"]
+        if fw >= 7:
+            g2, g2l = gpu_ctx.patch_optimize(st, 0, g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"], lanes_per_view=lpv)
+            ref = g1_fw["fw%d_opt" % fw]
             both = (g2[:, 0] > 0) & (ref[:, 0] > 0)
             assert both.sum() >= 15 and ((g2[:, 0] > 0) == (ref[:, 0] > 0)).mean() >= 0.95
             assert (np.abs(g2[both, 1] - ref[both, 1]) / ref[both, 1] <= 1e-3).all()

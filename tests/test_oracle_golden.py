@@ -5,6 +5,7 @@ oracle/_ref/ref_patch_driver, i.e. the unmodified libs/dmrecon compiled -O2 -ffp
 The restatement mirrors the reference's float accumulation order, so these are exact comparisons.
 """
 import numpy as np
+import pytest
 
 from oracle import oracle as orc
 
@@ -137,20 +138,24 @@ def test_order_sensitivity_floor_on_hard_scene(h1, h1_scene, monkeypatch):
     assert 0.99 <= m["iou"] <= 0.999 and 5e-3 <= m["rel_p99"] <= 3e-2 and 0.03 <= m["conf_p99"] <= 0.15, m
 
 
-def test_filter_width_7_bit_exact_and_3_to_rounding(g1, g1_fw, g1_scene):
+def test_filter_widths_7_9_11_bit_exact_and_3_to_rounding(g1, g1_fw, g1_scene):
     """apps/dmrecon --filter-width (mvs::Settings::filterWidth): 7 x 7 windows keep quirk Q3 (derivative step at
     patchPoints[12] = row 1, column 5) and are restated bit for bit.  With 3 x 3 windows the reference reads
     patchPoints[12] of a 9-element vector (undefined behaviour); the restatement uses the centre sample, the step
     only scales a finite difference that is divided out again: agreement to rounding."""
     from conftest import map_parity
     S = orc.OracleScene(g1_scene)
-    r = S.reconstruct(orc.make_settings(ref_view=0, filterWidth=7))
-    assert np.array_equal(r["depth"], g1_fw["fw7_depth"]) and np.array_equal(r["conf"], g1_fw["fw7_conf"])
-    assert np.array_equal(r["dz"], g1_fw["fw7_dz"])
-    out, loc = S.patch_optimize(orc.make_settings(ref_view=0, filterWidth=7), g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
-    ok = g1_fw["fw7_opt"][:, 0] > 0
-    assert ok.sum() >= 15 and np.array_equal(out[:, 0] > 0, ok)
-    assert np.array_equal(out[ok, :7], g1_fw["fw7_opt"][ok, :7]) and np.array_equal(loc[ok], g1_fw["fw7_opt_local"][ok])
+    for fw in (7, 9, 11):                                    # 9 x 9 and 11 x 11: the same quirk, the same bits
+        r = S.reconstruct(orc.make_settings(ref_view=0, filterWidth=fw))
+        assert np.array_equal(r["depth"], g1_fw["fw%d_depth" % fw]) and np.array_equal(r["conf"], g1_fw["fw%d_conf" % fw]), fw
+        assert np.array_equal(r["dz"], g1_fw["fw%d_dz" % fw]), fw
+        out, loc = S.patch_optimize(orc.make_settings(ref_view=0, filterWidth=fw), g1["seeds_xy"], g1["seeds_hyp"], g1["seeds_local"])
+        ok = g1_fw["fw%d_opt" % fw][:, 0] > 0
+        assert ok.sum() >= 15 and np.array_equal(out[:, 0] > 0, ok), fw
+        assert np.array_equal(out[ok, :7], g1_fw["fw%d_opt" % fw][ok, :7]) and np.array_equal(loc[ok], g1_fw["fw%d_opt_local" % fw][ok]), fw
+    for bad in (1, 4, 13):                                   # even widths are undefined behaviour in the reference
+        with pytest.raises(Exception):
+            S.reconstruct(orc.make_settings(ref_view=0, filterWidth=bad))
     r = S.reconstruct(orc.make_settings(ref_view=0, filterWidth=3))
     m = map_parity(r["depth"], r["conf"], g1_fw["fw3_depth"], g1_fw["fw3_conf"])
     assert m["iou"] >= 0.99 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 2e-2, m
