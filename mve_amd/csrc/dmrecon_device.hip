@@ -1595,7 +1595,10 @@ __device__ __forceinline__ unsigned patch_sum_u(unsigned v) {
     return v;
 }
 template <class L>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MI_BULK_WAVES, MI_WAVES_PER_SIMD))) void k_optimize_spec(SpecArgs t) {
+#ifndef MI_SPEC_WAVES
+#define MI_SPEC_WAVES MI_WAVES_PER_SIMD
+#endif
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((MI_FW >= 7 ? 1 : MI_SPEC_WAVES), MI_SPEC_WAVES))) void k_optimize_spec(SpecArgs t) {
     const OptArgs& a = t.o;
     const int lane = threadIdx.x;
     const unsigned n = a.n_work_ptr ? *a.n_work_ptr : a.n_work;

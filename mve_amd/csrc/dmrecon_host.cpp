@@ -1047,7 +1047,15 @@ void mi_dmrecon_settings_default(mi_dmrecon_settings* s) {          /* libs/dmre
 
 static int create_streams(mi_dmrecon_ctx* c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    /* The second stream carries the maps of finished views back while the front kernel still runs on the first: it must
+     * not share a hardware queue with it.  The runtime deals the streams of one priority over a handful of queues (four by
+     * default): with four forked contexts -- eight streams -- a context's two streams could land on the same one, and its
+     * copies then waited for the kernel they were meant to run next to (a 400-view batch: 31 ms = its 830 MB of maps over
+     * PCIe, in the two regions out of five that such a context led).  Streams of another priority have queues of their own. */
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { prio_least = prio_greatest = 0; (void)hipGetLastError(); }
+    if (prio_greatest != prio_least) HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest));
+    else HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     /* compute units of this device (a partitioned GPU has fewer than 256): what a front launch with teams may occupy */
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->n_cus = cus;

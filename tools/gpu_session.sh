@@ -1,8 +1,14 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): the round's profile collection + bench lines of configs 2 and 5.
+# Runs ON THE GPU BOX (through gpurun): the driver's command, five times, front wall clocks per region.
 export TMPDIR=/tmp
-OUT=gpurun_out/r4
+OUT=gpurun_out/r4b
 mkdir -p $OUT
-bash tools/collect_profiles.sh r4 2>&1 | tail -12
-timeout -s KILL 400 python bench.py --config C2 --steps 20 --warmup 3 --one-call-n 30 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; tail -c 300 $OUT/bench_c2.json
-timeout -s KILL 900 python bench.py --config C5 --steps 2 --warmup 1 --repeats 3 --one-call-n 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; tail -c 300 $OUT/bench_c5.json; tail -3 $OUT/bench_c5.err
+for k in 1 2 3 4 5; do
+  MI_BENCH_REGION_LOG=1 timeout -s KILL 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --one-call-n 10 > $OUT/q.json 2> $OUT/q.err
+  python - <<PY
+import json,re
+d=json.loads(open("$OUT/q.json").read().strip().splitlines()[-1])
+fr=[float(m) for m in re.findall(r"front ([0-9.]+), download", open("$OUT/q.err").read())]
+print("run $k", round(d["value"],1), [round(x) for x in d["repeats"]], "front wall", fr, "one_call", round(d["one_call"]["ms_per_call"],2))
+PY
+done
