@@ -118,6 +118,22 @@ def measured_traffic(n_streams, spc, config_is_c3=True):
     return {}, None
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup quota / period), or None: a box can show 256 cores to
+    os.cpu_count() and give the process tree the time of 16 -- then 20 reference threads share 16 cores' worth."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                   # cgroup v1
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
     """The reference CPU path timed on this box's host cores on a bounded sample of the same workload.
     With gpu_maps (the HIP path's depth / conf maps of the same views) the reference's own output -- which this
@@ -145,11 +161,15 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
                 if ln.startswith("Reconstruction took"):
                     app_ms = float(ln.split()[2].rstrip("ms.").rstrip("ms"))
             t = (app_ms / 1000.0) if app_ms else wall
+            quota = cpu_quota()
             base = {"value": n_sample / t, "unit": "depth-maps/s", "cores": min(cores, n_sample), "kind": "reference",
+                    "cpu_quota": quota,
                     "sample": "unmodified apps/dmrecon (oracle/_ref/dmrecon_ref_fast: -O3 -march=x86-64-v3 "
                               "-funsafe-math-optimizations, OpenMP over views) on views 0-%d of the same scene at scale %d; "
                               "time = the app's own 'Reconstruction took' (%.1f s, includes its PNG decode + pyramid); "
-                              "%d host cores available, one thread per view" % (n_sample - 1, s, t, cores)}
+                              "%d host cores visible%s, one thread per view" % (
+                                  n_sample - 1, s, t, cores,
+                                  "" if quota is None else " (the container's CPU quota: the time of %.0f)" % quota)}
             parity = None
             if gpu_maps is not None:
                 ref_maps = [(read_mvei(os.path.join(view_dir(sdir, v), "depth-L%d.mvei" % s)),

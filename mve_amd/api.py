@@ -144,7 +144,8 @@ def load_library() -> ctypes.CDLL:
     L.mi_dmrecon_debug_inject_footprint.restype = None
     L.mi_dmrecon_debug_scratch_sets.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]  # test hook, not in the public header
     L.mi_dmrecon_debug_plan_views_host.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, ctypes.POINTER(CSettings), i32, i32, i32, vp,
-                                                   ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double)]   # test hook
+                                                   ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double), i32, vp, vp,
+                                                   ctypes.POINTER(i32)]                                     # test hook
     _lib = L
     return L
 
@@ -155,10 +156,11 @@ def debug_inject_footprint(view_id: int) -> None:
     load_library().mi_dmrecon_debug_inject_footprint(int(view_id))
 
 
-def plan_views_host(scene: "SceneData", st: "Settings", ref_view: int, tables: bool = True, repeats: int = 1):
+def plan_views_host(scene: "SceneData", st: "Settings", ref_view: int, tables: bool = True, repeats: int = 1, seeds: bool = False):
     """Test hook: the HOST half of a call's planning -- the global view selection of `ref_view` as a reconstruct call runs
     it when it does not use the device for it (from the scene tables, or directly: tables=False) -- on the scene's cameras,
-    image sizes and features alone.  Needs no GPU.  Returns (view ids, milliseconds of `repeats - 1` further selections)."""
+    image sizes and features alone.  Needs no GPU.  Returns (view ids, milliseconds of `repeats - 1` further selections),
+    with seeds=True also the view's seeds as (xy [n, 2], depth [n])."""
     L = load_library()
     n = len(scene.cameras)
     cams = (CCamera * n)()
@@ -182,12 +184,18 @@ def plan_views_host(scene: "SceneData", st: "Settings", ref_view: int, tables: b
     out = np.zeros(max(n, 1), np.int32)
     n_out, ms = ctypes.c_int32(0), ctypes.c_double(0.0)
     cs = st.to_c()
+    cap = len(feats) if seeds else 0
+    sxy, sd, ns = np.zeros((max(cap, 1), 2), np.int32), np.zeros(max(cap, 1), np.float32), ctypes.c_int32(0)
     rc = L.mi_dmrecon_debug_plan_views_host(n, ctypes.cast(cams, ctypes.c_void_p), _ptr(widths), _ptr(heights), len(feats), _ptr(pos),
                                             _ptr(off), _ptr(refs), ctypes.byref(cs), int(ref_view), 1 if tables else 0,
-                                            int(repeats), _ptr(out), ctypes.byref(n_out), ctypes.byref(ms))
+                                            int(repeats), _ptr(out), ctypes.byref(n_out), ctypes.byref(ms),
+                                            cap, _ptr(sxy), _ptr(sd), ctypes.byref(ns) if seeds else None)
     if rc != 0:
         _raise(rc)
-    return [int(v) for v in out[:n_out.value]], ms.value
+    ids = [int(v) for v in out[:n_out.value]]
+    if seeds:
+        return ids, ms.value, (sxy[:ns.value].copy(), sd[:ns.value].copy())
+    return ids, ms.value
 
 
 def device_count() -> int:

@@ -230,6 +230,7 @@ struct SceneGeom {
     bool on_device = false;                  /* the tables below are in SceneStore::d_geom_* (gvs_device.hip) */
     size_t nv = 0, nf = 0;
     std::vector<uint8_t> sees;               /* [v * nf + f]: v references f and f is inside v's frustum */
+    std::vector<uint8_t> refs;               /* [v * nf + f]: v references f (Feature::contains_view_id) */
     std::vector<float> zcam;                 /* [v * nf + f]: (worldToCam_v . f).z */
     std::vector<float> plx;                  /* [(v1 * nv + v2) * nf + f]: parallax in degrees where both see f, +inf elsewhere */
     /* [(v1 * nv + v2) * nf + f]: the factor benefitFromView multiplies a score by for the pair (:76-79,91-98) -- (plx / 10)^2
@@ -463,9 +464,11 @@ void build_scene_geom(SceneStore& sc) {
     g.has_plx = nv * nv * nf <= ((size_t)1 << 26);                         /* 256 MB of floats at most */
     if (!g.has_plx) {
         std::vector<uint8_t>().swap(g.sees); std::vector<float>().swap(g.zcam); std::vector<float>().swap(g.plx);
+        std::vector<uint8_t>().swap(g.refs);
         return;
     }
     g.sees.assign(nv * nf, 0);
+    g.refs.assign(nv * nf, 0);
     g.zcam.assign(nv * nf, 0.f);
     /* unit directions camera -> feature (parallax(), mvs_tools.h:46-56), only needed while building */
     std::vector<V3> dir(nv * nf);
@@ -476,7 +479,9 @@ void build_scene_geom(SceneStore& sc) {
         const V3 p = mk(ft.pos[0], ft.pos[1], ft.pos[2]);
         for (int j = ft.ref_begin; j < ft.ref_end; ++j) {
             const int v = sc.feat_refs[j];
-            if (v < 0 || v >= (int)nv || !sc.views[v].valid) continue;
+            if (v < 0 || v >= (int)nv) continue;
+            g.refs[(size_t)v * nf + f] = 1;
+            if (!sc.views[v].valid) continue;
             if (!sc.views[v].pointInFrustum(p)) continue;                  /* dmrecon.cc:190,203 */
             g.sees[(size_t)v * nf + f] = 1;
             g.zcam[(size_t)v * nf + f] = xform(sc.views[v].w2c, p)[2];     /* SingleView::footPrint's depth */
@@ -909,11 +914,22 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
 void plan_seeds(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost& job, int job_index) {
     HostView const& R = c->sc->views[job.ref_view];
     HostLevel const& L = R.levels[st->scale];
-    for (size_t i = 0; i < c->sc->features.size(); ++i) {
+    /* (the scene tables, where they exist, answer "does view v reference feature i" with one byte: the scan of the
+     * feature's view list is the reference's own Feature::contains_view_id) */
+    SceneGeom const& G = c->sc->geom;
+    const bool tab = G.built && G.has_plx && G.refs.size() == G.nv * G.nf && G.nf == c->sc->features.size();
+    const size_t nf = c->sc->features.size();
+    for (size_t i = 0; i < nf; ++i) {
         Feature const& f = c->sc->features[i];
-        bool use = contains_view(c, f, job.ref_view);
-        for (size_t g = 0; !use && g < job.global.size(); ++g)
-            if (contains_view(c, f, job.global[g])) use = true;
+        bool use;
+        if (tab) {
+            use = (size_t)job.ref_view < G.nv && G.refs[(size_t)job.ref_view * nf + i];
+            for (size_t g = 0; !use && g < job.global.size(); ++g) use = G.refs[(size_t)job.global[g] * nf + i] != 0;
+        } else {
+            use = contains_view(c, f, job.ref_view);
+            for (size_t g = 0; !use && g < job.global.size(); ++g)
+                if (contains_view(c, f, job.global[g])) use = true;
+        }
         if (!use) continue;
         V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
         if (!R.pointInFrustum(p)) continue;
@@ -2553,11 +2569,12 @@ void mi_dmrecon_debug_inject_footprint(int view_id) { g_inject_footprint.store(v
 /* Test hook (not in the public header): the HOST half of the planning -- global view selection of reference view `ref`,
  * exactly the code a reconstruct call runs (plan_global_views: from the scene tables, or directly with tables = 0) -- on
  * cameras and features alone, so that it can be checked against the oracle without a GPU.  ms_out (optional): the time
- * of `repeats` selections, the scene tables already built. */
+ * of `repeats` selections, the scene tables already built.  n_seeds_out (optional): also the view's seeds. */
 int mi_dmrecon_debug_plan_views_host(int32_t n_views, const mi_dmrecon_camera* cams, const int32_t* widths, const int32_t* heights,
                                      int32_t n_feat, const float* pos, const int32_t* off, const int32_t* ids,
                                      const mi_dmrecon_settings* st, int32_t ref, int32_t tables, int32_t repeats,
-                                     int32_t* ids_out, int32_t* n_out, double* ms_out) {
+                                     int32_t* ids_out, int32_t* n_out, double* ms_out,
+                                     int32_t seed_cap, int32_t* seed_xy_out, float* seed_depth_out, int32_t* n_seeds_out) {
     try {
         if (n_views <= 0 || !cams || !widths || !heights || !st || !ids_out || !n_out) return fail(MI_DMRECON_EINVAL, "null argument");
         mi_dmrecon_ctx c;
@@ -2581,6 +2598,17 @@ int mi_dmrecon_debug_plan_views_host(int32_t n_views, const mi_dmrecon_camera* c
         if (rc) return rc;
         *n_out = (int32_t)global.size();
         for (size_t i = 0; i < global.size(); ++i) ids_out[i] = global[i];
+        if (n_seeds_out) {
+            /* ... and the seeds of the view (plan_seeds: the host half of processFeatures), in feature order */
+            JobHost job;
+            job.ref_view = ref; job.global = global;
+            plan_seeds(&c, st, job, 0);
+            *n_seeds_out = (int32_t)job.seeds.size();
+            for (size_t i = 0; i < job.seeds.size() && (int32_t)i < seed_cap; ++i) {
+                if (seed_xy_out) { seed_xy_out[2 * i] = (int32_t)(job.seeds[i].xy & 0xFFFF); seed_xy_out[2 * i + 1] = (int32_t)(job.seeds[i].xy >> 16); }
+                if (seed_depth_out) seed_depth_out[i] = job.seed_hyp[i].depth;
+            }
+        }
         return 0;
     } catch (std::exception const& e) { return fail(MI_DMRECON_EDEVICE, "%s", e.what()); }
 }

@@ -199,3 +199,10 @@ def test_host_view_selection_is_the_references(g1, g1_scene, h1_scene, w1, w1_sc
         assert _host_views(g1_scene, 1, tables, aabbMin=list(lo), aabbMax=list(hi)) == want
     with pytest.raises(ValueError):
         _host_views(g1_scene, 7, True)                                                    # master view out of bounds
+    # the seeds (the host half of processFeatures): the reference table and the scan of the features' view lists agree
+    for scene, kw in ((g1_scene, dict()), (w1_scene, dict(globalVSMax=3)), (h1_scene, dict(scale=1))):
+        for ref in (0, len(scene.cameras) - 1):
+            a = api.plan_views_host(scene, api.Settings(refViewNr=ref, **kw), ref, tables=True, seeds=True)
+            b = api.plan_views_host(scene, api.Settings(refViewNr=ref, **kw), ref, tables=False, seeds=True)
+            assert a[0] == b[0] and len(a[2][0]) > 20
+            assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])

@@ -260,3 +260,73 @@ def test_c3_cancel_during_propagation(c3):
     # the context is still usable and gives the same maps as before
     again = ctx.reconstruct(st, refs, want_views=True)
     assert np.array_equal(again[3]["depth"], res[3]["depth"])
+
+
+# ---- BASELINE config 5 at its full size: 100 views of 4032 x 3024, scale 3 (504 x 378 maps) --------------------------
+
+_ORACLE_C5 = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from mve_amd.synth import CONFIGS, make_cameras, make_features, SceneData
+from oracle import oracle as orc
+cfg = CONFIGS["C5"]
+p = cfg["params"]
+cams = make_cameras(p)
+imgs = np.load(sys.argv[2], mmap_mode="r")                      # the images the test process rendered
+S = orc.OracleScene(SceneData(cams, [imgs[i] for i in range(p.n_views)], make_features(p, cams)))
+out = {}
+for v in sys.argv[3:]:                       # (one after the other: a reconstruction prepares the scene's views for itself)
+    r = S.reconstruct(orc.make_settings(ref_view=int(v), scale=cfg["scale"], local_neighbors=cfg["local_neighbors"]))
+    out["d" + v], out["c" + v] = r["depth"], r["conf"]
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.skipif(os.environ.get("MI_TEST_C5_FULL") != "1",
+                    reason="2.3 minutes (1.4 of them rendering 100 x 12 MP on the box's 16-CPU quota): set MI_TEST_C5_FULL=1; "
+                           "its last run is in profiles/r4_c5_fullsize_test.txt, and `bench.py --config C5` checks the same "
+                           "three views inside its run")
+def test_config5_full_size_views_vs_oracle(tmp_path):
+    """All 100 reference views of the config-5 scene in one call; views 0, 50 and 99 against the CPU oracle (one process
+    next to the GPU work, on the images this process rendered: the three views one after the other).  Confidence bound 1e-2:
+    the reference algorithm against itself with its queue reversed is at 6.0e-3 .. 7.8e-3 on this scene
+    (tools/c5_order_floor.py, profiles/r4_c5_order_floor.json).  The three views alone give the bits they have in the
+    batch of 100."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    views = (0, 50, 99)
+    out = str(tmp_path / "c5_oracle.npz")
+    proc = None
+    try:
+        import time
+        cfg = CONFIGS["C5"]
+        n = cfg["params"].n_views
+        t0 = time.time(); scene = make_scene(cfg["params"]); t1 = time.time()
+        img_file = str(tmp_path / "c5_images.npy")
+        np.save(img_file, np.stack(scene.images))
+        proc = subprocess.Popen([sys.executable, "-c", _ORACLE_C5 % root, out, img_file] + [str(v) for v in views])
+        ctx = api.Context(0)
+        ctx.load_scene(scene, pinned_staging=True); t2 = time.time()
+        st = api.Settings(scale=cfg["scale"], nrReconNeighbors=cfg["local_neighbors"])
+        res = ctx.reconstruct(st, list(range(n))); t3 = time.time()
+        print("C5: scene rendered in %.1f s, staged in %.1f s, 100 views reconstructed in %.2f s (first call)" % (t1 - t0, t2 - t1, t3 - t2))
+        assert len(res) == n and res[0]["depth"].shape == (378, 504)
+        for v in range(n):
+            d, c = res[v]["depth"], res[v]["conf"]
+            filled = c > 0
+            assert np.isfinite(d).all() and (d[filled] > 0).all() and (d[~filled] == 0).all() and c.max() <= 1.0
+            assert filled.mean() > 0.5, (v, filled.mean())
+        again = ctx.reconstruct(st, list(views))
+        for k, v in enumerate(views):
+            for name in ("depth", "conf", "dz"):
+                assert np.array_equal(again[k][name], res[v][name]), (v, name)
+        assert proc.wait(timeout=1500) == 0
+        print("C5: oracle process done %.1f s after the start" % (time.time() - t0))
+        o = np.load(out)
+        for v in views:
+            m = map_parity(res[v]["depth"], res[v]["conf"], o["d%d" % v], o["c%d" % v])
+            print("C5 view", v, m)
+            assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 1e-2, (v, m)
+        ctx.close()
+    finally:
+        if proc is not None and proc.poll() is None:
+            proc.kill()
