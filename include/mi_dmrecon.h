@@ -131,13 +131,16 @@ typedef struct mi_dmrecon_stats {
     int64_t n_front_rounds_sum;  /* ... summed over the views */
     int64_t n_front_attempts;    /* patch optimisations run there (speculative ones included) */
     int64_t n_front_entries;     /* list entries summed over all rounds of all views */
-    int64_t front_team;          /* workgroups per view in that launch (> 1 only for a call that has the GPU to itself) */
+    int64_t front_team;          /* workgroups per view in that launch (> 1 only for a call that has the GPU to itself): the
+                                  * smallest team; the views with the longest lists may have larger ones (front_team_max) */
     int64_t front_fallbacks;     /* 1: the teams gave up (a member found no compute unit in time: the GPU is shared with
                                   * something the library cannot see) and the views finished with one workgroup each */
     int64_t n_latency_rounds;    /* host-visible rounds in which some view was already in the latency layout */
     double  ms_wall_setup, ms_wall_rounds, ms_wall_front, ms_wall_download;   /* host clock: uploads, host-visible + tail rounds, front phase, download */
     int64_t n_patch_turns, n_wave_turns;   /* development builds (-DMI_ACTIVITY) only: turns of the patch optimisations of the throughput
                                   * layout, and turns of their wavefronts x patches per wavefront: the ratio = lanes at work */
+    int64_t front_team_max;      /* the largest team of the front launch (the views with the longest lists get the teams of the
+                                  * XCDs that hold fewer views) */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);

@@ -93,7 +93,8 @@ class CStats(ctypes.Structure):
                 ("n_front_entries", ctypes.c_int64), ("front_team", ctypes.c_int64),
                 ("front_fallbacks", ctypes.c_int64), ("n_latency_rounds", ctypes.c_int64),
                 ("ms_wall_setup", ctypes.c_double), ("ms_wall_rounds", ctypes.c_double), ("ms_wall_front", ctypes.c_double), ("ms_wall_download", ctypes.c_double),
-                ("n_patch_turns", ctypes.c_int64), ("n_wave_turns", ctypes.c_int64)]
+                ("n_patch_turns", ctypes.c_int64), ("n_wave_turns", ctypes.c_int64),
+                ("front_team_max", ctypes.c_int64)]
 
 
 _lib = None

@@ -69,7 +69,10 @@ struct MiDeviceApi {
                              * team writes through its L2s as if found on several XCDs; -1 = none */,
                   int n_xcd /* teams: XCDs of the device; a view's team is confined to the blocks of one (b % n_xcd) */,
                   unsigned* host_done /* page-locked host memory, n_jobs zeroed words, or null: set to 1 per view that has run to its
-                                       * end, after its state has been written back to memory */);
+                                       * end, after its state has been written back to memory */,
+                  const unsigned* block_map /* teams: per block of the grid job | member << 16 | team size << 24, 0xFFFFFFFF = none;
+                                             * the blocks of a team share b % n_xcd */,
+                  unsigned grid_blocks);
     /* optimize_spec -- a round of the throughput layout with every (entry, candidate rank) pair on a quad of its own: `items`
      * (entry << 2 | rank, *n_items of them: written by `generate` when given an item list) are the attempts, spec holds
      * one record per item; mi_launch_apply_spec applies the reference's sequential rule to the records and writes the
@@ -97,10 +100,10 @@ void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
                            const unsigned* key_off);
-/* one dispatch instead of four small copies: a[0..n_a) | b[0..n_b) -> out_rw, *counters -> *out_hc, the (flags, n_filled)
- * pair of every job -> out_dyn (8 bytes per job); the out pointers are page-locked host memory */
+/* one dispatch instead of four small copies: a[0..n_a) | b[0..n_b) -> out_rw, *counters -> *out_hc, per job (flags, n_filled,
+ * view_count[job] or 0) -> out_dyn (12 bytes per job); the out pointers are page-locked host memory */
 void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const unsigned* b, int n_b, const DevCounters* counters,
-                            const DevJob* jobs, int n_jobs, unsigned* out_rw, DevCounters* out_hc, void* out_dyn);
+                            const DevJob* jobs, int n_jobs, unsigned* out_rw, DevCounters* out_hc, void* out_dyn, const unsigned* view_count);
 /* dst: w*h records of 16 bytes (texels (x,y) (x+1,y) (x,y+1) (x+1,y+1), edge-clamped) */
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h);
 void mi_launch_pack_rgba(hipStream_t s, const uint8_t* src, uint32_t* dst, int n, int channels);

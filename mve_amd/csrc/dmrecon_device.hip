@@ -1919,8 +1919,11 @@ struct FrontArgs {
     unsigned long long* job_resume;
     unsigned* job_stats;          /* [n_jobs][4]: rounds run, attempts run, sum of list sizes, 100 MHz ticks (added to) */
     int max_rounds;               /* a view stops here (int32 stamps would last; a guard against an endless front) */
-    /* TEAM: `team` workgroups per view (consecutive blocks) */
-    int team;
+    /* TEAM: the workgroups of a view's team and what each block of the grid is -- job | member << 16 | team size << 24,
+     * 0xFFFFFFFF for a block without work -- decided by the host: the members of a team are blocks with the same
+     * b % n_xcd, and the views whose lists are longest get the teams of the XCDs that hold fewer views */
+    int team;                     /* (the smallest team of the launch; 1 = no teams) */
+    const unsigned* block_map;
     unsigned long long* mail;     /* [n_jobs][2][MI_FRONT_QCAP * 4][MI_FRONT_GRAN] */
     unsigned* team_flags;         /* [n_jobs][MI_FRONT_TEAM_MAX], zeroed before the launch */
     unsigned* team_filled;        /* [n_jobs], zeroed before the launch: pixels newly filled by the view's team (atomicMax of each
@@ -1989,15 +1992,15 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
     typedef __attribute__((address_space(1))) unsigned* gflag_t;
     const OptArgs& a = t.o;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int T = TEAM ? t.team : 1;
     /* TEAM: the members of a view's team are blocks with the same b % n_xcd -- in practice the same XCD, i.e. ONE L2: what
      * the members write (all of them every word, plain stores) and read back then lives in one coherent cache.  Placement is
      * not promised: every member registers its XCC id, and a team found on several XCDs writes through instead (below). */
-    int jobi = (int)blockIdx.x, member = 0;
+    int jobi = (int)blockIdx.x, member = 0, T = 1;
     if (TEAM) {
-        const int xcd = (int)blockIdx.x % t.n_xcd, slot = (int)blockIdx.x / t.n_xcd;
-        jobi = (slot / T) * t.n_xcd + xcd; member = slot % T;
-        if (jobi >= t.n_jobs) return;
+        const unsigned m = t.block_map[blockIdx.x];
+        if (m == 0xFFFFFFFFu) return;
+        jobi = (int)(m & 0xFFFFu); member = (int)((m >> 16) & 0xFFu); T = (int)(m >> 24);
+        if (jobi >= t.n_jobs || T < 1 || member >= T) return;
     }
     const DevJob* job = a.jobs + jobi;
     unsigned n_prev; int cur, round;
@@ -2828,15 +2831,17 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint32_t* __restrict__ sr
  * dependent dispatches) on the critical path of every host-visible round.  One workgroup. */
 __global__ __launch_bounds__(256) void k_round_report(const unsigned* __restrict__ a, int n_a, const unsigned* __restrict__ b, int n_b,
                                                        const DevCounters* __restrict__ counters, const DevJob* __restrict__ jobs, int n_jobs,
-                                                       unsigned* __restrict__ out_rw, unsigned* __restrict__ out_hc, unsigned* __restrict__ out_dyn) {
+                                                       unsigned* __restrict__ out_rw, unsigned* __restrict__ out_hc, unsigned* __restrict__ out_dyn,
+                                                       const unsigned* __restrict__ view_count) {
     const int tid = (int)threadIdx.x;
     for (int i = tid; i < n_a; i += 256) out_rw[i] = a[i];
     for (int i = tid; i < n_b; i += 256) out_rw[n_a + i] = b[i];
     if (tid < (int)(sizeof(DevCounters) / sizeof(unsigned))) out_hc[tid] = reinterpret_cast<const unsigned*>(counters)[tid];
     static_assert(offsetof(DevJob, n_filled) == offsetof(DevJob, flags) + 4, "flags and n_filled are read as a pair");
     for (int j = tid; j < n_jobs; j += 256) {
-        out_dyn[2 * j] = (unsigned)jobs[j].flags;
-        out_dyn[2 * j + 1] = jobs[j].n_filled;
+        out_dyn[3 * j] = (unsigned)jobs[j].flags;
+        out_dyn[3 * j + 1] = jobs[j].n_filled;
+        out_dyn[3 * j + 2] = view_count ? view_count[j] : 0u;    /* the view's list of this round (k_generate), where there is one */
     }
 }
 
@@ -2971,7 +2976,7 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
                          const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
                          DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags,
                          const unsigned long long* job_start, unsigned long long* job_resume, unsigned* team_filled, unsigned spin_ticks,
-                         int fault, int n_xcd, unsigned* host_done) {
+                         int fault, int n_xcd, unsigned* host_done, const unsigned* block_map, unsigned grid_blocks) {
     static_assert(MI_FRONT_MAIL_WORDS == 2 * MI_FRONT_QCAP * 4 * MI_FRONT_GRAN, "mailbox size");
     if (n_jobs <= 0) return;
     if (!job_start) {
@@ -2995,10 +3000,11 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
     t.n_jobs = n_jobs; t.n_xcd = n_xcd < 1 ? 1 : n_xcd;
     t.l2_exchange = (fault >= 0 && ((fault >> 25) & 1)) ? 0 : 1;
     t.host_done = host_done;
-    if (team > 1 && mail && team_flags && team_filled) {
+    t.block_map = nullptr;
+    if (team > 1 && mail && team_flags && team_filled && block_map && grid_blocks > 0) {
         t.team = team > MI_FRONT_TEAM_MAX ? MI_FRONT_TEAM_MAX : team; t.mail = mail; t.team_flags = team_flags;
-        /* whole rows of n_xcd blocks: view j's team = the blocks b with b % n_xcd == j % n_xcd of its rows */
-        const unsigned grid = (unsigned)(t.n_xcd * ((n_jobs + t.n_xcd - 1) / t.n_xcd) * t.team);
+        t.block_map = block_map;
+        const unsigned grid = grid_blocks;
         if (st.K > 4) hipLaunchKernelGGL((k_front<8, true>), dim3(grid), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
         else hipLaunchKernelGGL((k_front<4, true>), dim3(grid), dim3(MI_FRONT_WAVES * WAVE), 0, s, t);
         hipLaunchKernelGGL(k_front_commit, dim3((unsigned)(n_jobs + 255) / 256), dim3(256), 0, s, jobs, team_filled, counters, n_jobs);
@@ -3037,9 +3043,9 @@ void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* wo
 }
 
 void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const unsigned* b, int n_b, const DevCounters* counters,
-                            const DevJob* jobs, int n_jobs, unsigned* out_rw, DevCounters* out_hc, void* out_dyn) {
+                            const DevJob* jobs, int n_jobs, unsigned* out_rw, DevCounters* out_hc, void* out_dyn, const unsigned* view_count) {
     hipLaunchKernelGGL(k_round_report, dim3(1), dim3(256), 0, s, a, n_a, b, n_b, counters, jobs, n_jobs, out_rw,
-                       reinterpret_cast<unsigned*>(out_hc), static_cast<unsigned*>(out_dyn));
+                       reinterpret_cast<unsigned*>(out_hc), static_cast<unsigned*>(out_dyn), view_count);
 }
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h) {
     hipLaunchKernelGGL(k_quadify, dim3((w * h + 255) / 256), dim3(256), 0, s, src, (u32x4*)dst, w, h);

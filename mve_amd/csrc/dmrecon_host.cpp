@@ -269,6 +269,7 @@ struct BatchScratch {
     DevBuf<unsigned> d_round_work_t;         /* [MI_MAX_ROUNDS] per round: size of the list of the views in the throughput layout */
     DevBuf<unsigned> d_round_items;          /* [MI_MAX_ROUNDS] per round: (entry, candidate) pairs of that list (speculative rounds) */
     DevBuf<unsigned> d_view;                 /* k_generate: [3][n_jobs] entries per view of the last rounds | [n_jobs] hand-over rounds */
+    DevBuf<unsigned> d_front_map;            /* k_front with teams: what every block of the grid is (FrontArgs::block_map) */
     DevBuf<unsigned> d_front;                /* k_front: [n_jobs] list offsets | [n_jobs] list sizes | [n_jobs][4] per-view statistics |
                                               * [n_jobs] pixels filled by the view's team */
     DevBuf<unsigned long long> d_front_resume;   /* k_front: [2][n_jobs] where a view goes on (FrontArgs::job_resume / job_start) */
@@ -316,7 +317,7 @@ struct BatchScratch {
         d_jobs.release(); d_work.release(); d_work2.release(); d_hyp.release(); d_results.release(); d_results2.release();
         d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_keys.release(); d_keyoff.release();
         d_round_work.release(); d_round_work_t.release(); d_round_items.release(); d_view.release(); d_front.release(); d_front_resume.release();
-        d_front_mail.release(); d_front_flags.release();
+        d_front_mail.release(); d_front_flags.release(); d_front_map.release();
         d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release();
         if (h_poll) (void)hipHostFree(h_poll);
         if (h_dyn) (void)hipHostFree(h_dyn);
@@ -1328,7 +1329,7 @@ static int mi_dmrecon_global_view_selection_impl(mi_dmrecon_ctx* c, const mi_dmr
 namespace {
 
 /* the two words of a DevJob the device writes and the host polls, copied back as a strided 8-byte column */
-struct JobDyn { int32_t flags; uint32_t n_filled; };
+struct JobDyn { int32_t flags; uint32_t n_filled; uint32_t list; /* the view's list of the round reported (k_round_report), else stale */ };
 
 /* hipEvent pairs around the timed launches of a call, recorded on the stream the launch goes to */
 struct EventLog {
@@ -1380,7 +1381,10 @@ struct BatchRun {
     std::vector<char> streamed;                /* views whose maps went back to the host while the front kernel still ran */
     int n_streamed = 0, n_streamed_early = 0;
     int stream_view(int j);
-    bool ran_front = false; int front_first_round = 0, front_team = 1, front_fallbacks = 0;
+    bool ran_front = false; int front_first_round = 0, front_team = 1, front_team_max = 1, front_fallbacks = 0;
+    std::vector<unsigned> view_filled;       /* ... and the pixels the view had filled by then */
+    std::vector<unsigned> view_list;         /* entries of every view's list in the last host-visible round read back (0: not known) */
+    std::vector<unsigned> front_map; unsigned front_grid = 0;   /* teams: what every block of the front launch is (FrontArgs::block_map) */
     unsigned handover = MI_VIEW_HANDOVER;      /* k_generate: a view's own list size below which it leaves the throughput layout */
     bool host_rounds_only = false;             /* diagnostic: every round host-visible (MI_DMRECON_HOST_ROUNDS) */
     int n_lat_rounds = 0;                      /* host-visible rounds that had entries in the latency layout */
@@ -1396,7 +1400,7 @@ struct BatchRun {
     JobDyn* dyn_of(int slot) { return (JobDyn*)c->bs.h_dyn + (size_t)slot * nj; }
     hipError_t read_dyn(int slot) {
         return hipMemcpy2DAsync(dyn_of(slot), sizeof(JobDyn), (const char*)c->bs.d_jobs.p + offsetof(DevJob, flags), sizeof(DevJob),
-                                sizeof(JobDyn), (size_t)nj, hipMemcpyDeviceToHost, S);
+                                2 * sizeof(uint32_t), (size_t)nj, hipMemcpyDeviceToHost, S);
     }
     void plan_front_team();
     int plan();
@@ -1700,7 +1704,8 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         const int slot = r & 1;
         TailPoll& P = c->bs.h_poll[slot];
         /* the round's report: both list sizes, the counters and the views' flags in one dispatch (k_round_report) */
-        mi_launch_round_report(S, n_thr_p, 1, n_lat_p, 1, c->d_counters, c->bs.d_jobs.p, nj, P.rw, &P.hc, dyn_of(slot));
+        mi_launch_round_report(S, n_thr_p, 1, n_lat_p, 1, c->d_counters, c->bs.d_jobs.p, nj, P.rw, &P.hc, dyn_of(slot),
+                               d_vcount + (size_t)(r % 3) * nj);
         if (hipGetLastError() != hipSuccess || hipEventRecord(c->bs.poll_ev[slot], S) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "enqueue of a propagation round failed");
         pend[n_pend].round = r; pend[n_pend].ev_thr = ev_thr; pend[n_pend].ev_lat = ev_lat; ++n_pend;
@@ -1717,6 +1722,9 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         const unsigned n_thr = P.rw[0], n_lat = P.rw[1];
         hc = P.hc;
         if (int rc = poll_views(dyn_of(slot), n_thr + n_lat)) return rc;
+        view_list.resize((size_t)nj);
+        view_filled.resize((size_t)nj);
+        for (int j = 0; j < nj; ++j) { view_list[j] = dyn_of(slot)[j].list; view_filled[j] = dyn_of(slot)[j].n_filled; }
         known_thr = n_thr; known_lat = n_lat;
         last_thr = n_thr; last_lat = n_lat; last_seen = pd.round;
         ev.items[pd.ev_thr].work = n_thr;
@@ -1816,7 +1824,7 @@ int BatchRun::tail_rounds(bool& to_front) {
         info[slot].ev_last = ev.items.size();
         TailPoll& P = c->bs.h_poll[slot];
         mi_launch_round_report(S, c->bs.d_round_work.p + info[slot].first, MI_TAIL_CHUNK, nullptr, 0, c->d_counters, c->bs.d_jobs.p, nj,
-                               P.rw, &P.hc, dyn_of(slot));
+                               P.rw, &P.hc, dyn_of(slot), nullptr);
         if (hipGetLastError() != hipSuccess || hipEventRecord(c->bs.poll_ev[slot], S) != hipSuccess)
             return fail(MI_DMRECON_EDEVICE, "enqueue of tail rounds failed");
         return 0;
@@ -1867,11 +1875,52 @@ int BatchRun::tail_rounds(bool& to_front) {
  * each (front_rounds): slower, never an error.  MI_DMRECON_FRONT_TEAM=<n> (1 = never). */
 void BatchRun::plan_front_team() {
     const char* e = std::getenv("MI_DMRECON_FRONT_TEAM");
-    int want = e ? std::atoi(e) : (active_call->count() <= 1 ? MI_FRONT_TEAM_MAX : 1);
-    /* a view's team lives on ONE XCD (one L2: k_front): the views are dealt over the XCDs, the CUs of an XCD over its views */
-    const int n_xcd = std::max(1, c->n_cus / 32), per_xcd = (std::max(nj, 1) + n_xcd - 1) / n_xcd;
-    want = std::min(std::min(want, (int)MI_FRONT_TEAM_MAX), (c->n_cus / n_xcd) / per_xcd);
-    front_team = std::max(1, want);
+    const int want = std::min(e ? std::atoi(e) : (active_call->count() <= 1 ? MI_FRONT_TEAM_MAX : 1), (int)MI_FRONT_TEAM_MAX);
+    front_team = front_team_max = 1; front_map.clear(); front_grid = 0;
+    if (want <= 1 || nj <= 0 || nj >= 65536) return;
+    /* A view's team lives on ONE XCD (one L2: k_front): the views are dealt over the XCDs, the CUs of an XCD over its views.
+     * When the views do not divide evenly, the XCDs that hold one view fewer have larger teams to give -- 20 views on 8 XCDs:
+     * four XCDs with three teams of 10, four with two teams of 16 -- and they go to the views with the most pixels still
+     * empty at the hand-over: the call lasts as long as its slowest view, and what is left to fill is what tells the long
+     * fronts from the short ones (measured, C3: the four slowest fronts, 11.5-14.4 ms with 10 workgroups each, are among the
+     * eight views with the most empty pixels; their lists at the hand-over -- 100 to 170 entries, as everybody's -- say
+     * nothing).  Team size does not show in the maps (tests: teams of 1, 2, 3, 8, 25). */
+    const int n_xcd = std::max(1, c->n_cus / 32), cus_x = std::max(1, c->n_cus / n_xcd);
+    const int base = nj / n_xcd, rem = nj % n_xcd;                  /* XCDs 0 .. rem - 1 hold base + 1 views */
+    struct Slot { int xcd, team; };
+    std::vector<Slot> slots;
+    std::vector<int> team_x((size_t)n_xcd, 0), views_x((size_t)n_xcd, 0);
+    int tmin = MI_FRONT_TEAM_MAX;
+    for (int x = 0; x < n_xcd; ++x) {
+        views_x[x] = base + (x < rem ? 1 : 0);
+        if (views_x[x] == 0) continue;
+        team_x[x] = std::max(1, std::min(want, cus_x / views_x[x]));
+        tmin = std::min(tmin, team_x[x]);
+        front_team_max = std::max(front_team_max, team_x[x]);
+        for (int k = 0; k < views_x[x]; ++k) slots.push_back(Slot{x, team_x[x]});
+    }
+    if (tmin <= 1) { front_team_max = 1; return; }                  /* some view would be alone anyway: no teams at all */
+    /* the largest teams to the views with the most empty pixels (ties, and a hand-over the host has no counts of: by index) */
+    std::stable_sort(slots.begin(), slots.end(), [](Slot const& a, Slot const& b) { return a.team > b.team; });
+    std::vector<int> order((size_t)nj);
+    for (int j = 0; j < nj; ++j) order[j] = j;
+    if (view_filled.size() == (size_t)nj) {
+        auto empty = [&](int j) { return (long long)jobs[j].w * jobs[j].h - (long long)view_filled[j]; };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return empty(a) > empty(b); });
+    }
+    /* block b runs on XCD b % n_xcd; its XCD's blocks in launch order are the members of that XCD's teams, team after team */
+    int rows = 0;
+    for (int x = 0; x < n_xcd; ++x) rows = std::max(rows, views_x[x] * team_x[x]);
+    front_grid = (unsigned)(rows * n_xcd);
+    if (front_grid > 16384u) { front_team_max = 1; front_grid = 0; return; }
+    front_map.assign(front_grid, 0xFFFFFFFFu);
+    std::vector<int> next_row((size_t)n_xcd, 0);
+    for (size_t k = 0; k < slots.size(); ++k) {
+        const int j = order[k], x = slots[k].xcd, T = slots[k].team;
+        for (int m = 0; m < T; ++m) front_map[(size_t)(next_row[x] + m) * n_xcd + x] = (unsigned)j | ((unsigned)m << 16) | ((unsigned)T << 24);
+        next_row[x] += T;
+    }
+    front_team = tmin;
 }
 
 /* The right to run front teams on a GPU, for as long as the object lives: an exclusive, non-blocking flock on a file
@@ -1932,6 +1981,10 @@ int BatchRun::front_rounds() {
             return fail(MI_DMRECON_EDEVICE, "hipMalloc(front mailboxes) failed");
         HIP_TRY(hipMemsetAsync(c->bs.d_front_mail.p, 0, (size_t)nj * MI_FRONT_MAIL_WORDS * sizeof(unsigned long long), S));
         HIP_TRY(hipMemsetAsync(c->bs.d_front_flags.p, 0, (size_t)nj * MI_FRONT_FLAG_STRIDE * sizeof(unsigned), S));
+        if (front_map.size() != front_grid || front_grid == 0) return fail(MI_DMRECON_EDEVICE, "internal: front teams without a block map");
+        if (c->bs.d_front_map.reserve(front_grid)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(front block map) failed");
+        /* (a few hundred words from the call's own memory: the stream is idle here, the copy is staged at once) */
+        HIP_TRY(hipMemcpyAsync(c->bs.d_front_map.p, front_map.data(), front_grid * sizeof(unsigned), hipMemcpyHostToDevice, S));
     }
     front_stats.assign(4 * (size_t)nj, 0u);
     /* maps of finished views go back while the others run -- the flags in COHERENT page-locked memory (the default kind is
@@ -1962,7 +2015,7 @@ int BatchRun::front_rounds() {
                  again ? 1 : front_team, (!again && front_team > 1) ? c->bs.d_front_mail.p : nullptr,
                  (!again && front_team > 1) ? c->bs.d_front_flags.p : nullptr,
                  again ? d_resume : nullptr, again ? d_resume + nj : d_resume, d_filled, spin_ticks, again ? -1 : fault,
-                 std::max(1, c->n_cus / 32), h_done);
+                 std::max(1, c->n_cus / 32), h_done, (!again && front_team > 1) ? c->bs.d_front_map.p : nullptr, front_grid);
         ev.end(S);
         ++n_launch;
         if (h_done) {
@@ -1985,7 +2038,7 @@ int BatchRun::front_rounds() {
             }
         }
         if (h_done) {
-            mi_launch_round_report(S, d_stats, 4 * nj, nullptr, 0, c->d_counters, c->bs.d_jobs.p, nj, h_done + nj, &P.hc, dyn_of(0));
+            mi_launch_round_report(S, d_stats, 4 * nj, nullptr, 0, c->d_counters, c->bs.d_jobs.p, nj, h_done + nj, &P.hc, dyn_of(0), nullptr);
             HIP_TRY(hipGetLastError());
         } else {
             HIP_TRY(hipMemcpyAsync(&P.hc, c->d_counters, sizeof(hc), hipMemcpyDeviceToHost, S));
@@ -2097,6 +2150,7 @@ void BatchRun::fill_stats() {
         if (ran_front) {
             stats->n_front_launches = 1;
             stats->front_team = front_team;
+            stats->front_team_max = front_team > 1 ? front_team_max : 1;
             stats->front_fallbacks = front_fallbacks;
             stats->front_first_round = front_first_round;
             for (int j = 0; j < nj; ++j) {
@@ -2124,7 +2178,12 @@ void BatchRun::fill_stats() {
         if (ran_front)
             for (int j = 0; j < nj; ++j) {
                 const unsigned* fs = &front_stats[4 * (size_t)j];
-                fprintf(stderr, "[mi_dmrecon] front view %d: %u rounds, %u attempts, %u entries, %.3f ms\n", jobs[j].ref_view, fs[0], fs[1], fs[2], fs[3] * 1e-5);
+                unsigned team = 1;
+                for (size_t b = 0; b < front_map.size() && front_team > 1; ++b)
+                    if (front_map[b] != 0xFFFFFFFFu && (int)(front_map[b] & 0xFFFFu) == j) { team = front_map[b] >> 24; break; }
+                fprintf(stderr, "[mi_dmrecon] front view %d: %u rounds, %u attempts, %u entries, %.3f ms, team of %u, list at the hand-over %u, filled %u of %d\n", jobs[j].ref_view,
+                        fs[0], fs[1], fs[2], fs[3] * 1e-5, team, view_list.size() == (size_t)nj ? view_list[j] : 0u,
+                        view_filled.size() == (size_t)nj ? view_filled[j] : 0u, jobs[j].w * jobs[j].h);
             }
         fprintf(stderr, "[mi_dmrecon] total %.2f ms host wall\n", now_ms() - t_begin);
     }

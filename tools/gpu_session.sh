@@ -1,3 +1,4 @@
 #!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the whole GPU suite.
 export TMPDIR=/tmp
-timeout -s KILL 1500 python -m pytest tests/test_gpu_fullsize.py -q -k config5_full_size -s --durations=3 2>&1 | tail -12
+timeout -s KILL 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -6
