@@ -1367,7 +1367,8 @@ struct BatchRun {
     int nj = 0, n_alive = 0, max_tiles = 0;
     size_t total_px = 0, work_cap = 0, n_seed_feats = 0;
     size_t up_jobs = 0, up_keyoff = 0, up_seeds = 0, up_hyps = 0;   /* offsets into the pinned upload staging (BatchScratch::h_up) */
-    std::vector<DevEntry> seeds; std::vector<DevHyp> hyps; std::vector<unsigned> keyoff;
+    size_t n_seeds_total = 0;                  /* seeds of all views of the batch (they go from the plans straight into the pinned staging) */
+    std::vector<unsigned> keyoff;
     /* the rounds */
     EventLog ev;
     int round = 1;
@@ -1460,7 +1461,7 @@ int BatchRun::plan() {
         plans[i].w = L.w; plans[i].h = L.h;
         job_of[i] = (int)jobs.size();
         ref_of_job.push_back(i);
-        jobs.push_back(plans[i]);
+        jobs.push_back(std::move(plans[i]));
     }
     if (jobs.empty()) {
         /* no view got through: the first failing view's own code and message (a single-view call behaves like
@@ -1483,19 +1484,24 @@ int BatchRun::upload() {
     if (rc) return rc;
     nj = (int)jobs.size();
     dj.resize(nj);
+    /* (a merged batch of 400 views: 8 000 per-view geometries and 13 MB of seeds -- by a few threads, the seeds from the
+     * views' plans straight into the pinned staging; it was 9 ms of one thread) */
+    const int n_threads = std::max(1, std::min(std::min(nj / 4, omp_get_num_procs()), 16));
+#pragma omp parallel for schedule(static) num_threads(n_threads) if (n_threads > 1)
+    for (int j = 0; j < nj; ++j) fill_job(c, st, jobs[j], dj[j]);
+    std::vector<size_t> seed_off((size_t)nj + 1, 0);
     for (int j = 0; j < nj; ++j) {
-        fill_job(c, st, jobs[j], dj[j]);
         const int tx = (jobs[j].w + MI_GEN_TILE_W - 1) / MI_GEN_TILE_W, ty = (jobs[j].h + MI_GEN_TILE_H - 1) / MI_GEN_TILE_H;
         max_tiles = std::max(max_tiles, tx * ty);
-    }
-    for (int j = 0; j < nj; ++j) {
-        seeds.insert(seeds.end(), jobs[j].seeds.begin(), jobs[j].seeds.end());
-        hyps.insert(hyps.end(), jobs[j].seed_hyp.begin(), jobs[j].seed_hyp.end());
+        seed_off[(size_t)j + 1] = seed_off[j] + jobs[j].seeds.size();
         n_seed_feats += jobs[j].n_seeds;
     }
-    rc = alloc_maps(c, jobs, dj, total_px, seeds.size(), st->nrReconNeighbors > 4);
+    n_seeds_total = seed_off[nj];
+    mark("  upload: job records");
+    rc = alloc_maps(c, jobs, dj, total_px, n_seeds_total, st->nrReconNeighbors > 4);
     if (rc) return rc;
-    work_cap = std::max(total_px, seeds.size());
+    mark("  upload: state maps");
+    work_cap = std::max(total_px, n_seeds_total);
     if (c->bs.d_jobs.reserve(nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(jobs) failed");
     keyoff.resize(nj);
     for (int j = 0; j < nj; ++j) keyoff[j] = (unsigned)jobs[j].pix_off;
@@ -1503,8 +1509,8 @@ int BatchRun::upload() {
         /* everything the call uploads, through ONE page-locked staging buffer: asynchronous for real */
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
         up_jobs = 0; up_keyoff = al(up_jobs + (size_t)nj * sizeof(DevJob)); up_seeds = al(up_keyoff + (size_t)nj * sizeof(unsigned));
-        up_hyps = al(up_seeds + seeds.size() * sizeof(DevEntry));
-        const size_t need = al(up_hyps + hyps.size() * sizeof(DevHyp));
+        up_hyps = al(up_seeds + n_seeds_total * sizeof(DevEntry));
+        const size_t need = al(up_hyps + n_seeds_total * sizeof(DevHyp));
         if (c->bs.h_up_cap < need) {
             if (c->bs.h_up) (void)hipHostFree(c->bs.h_up);
             c->bs.h_up = nullptr; c->bs.h_up_cap = 0;
@@ -1512,14 +1518,22 @@ int BatchRun::upload() {
                 return fail(MI_DMRECON_EDEVICE, "hipHostMalloc(upload staging) failed");
             c->bs.h_up_cap = 2 * need;
         }
-        std::memcpy(c->bs.h_up + up_jobs, dj.data(), (size_t)nj * sizeof(DevJob));
         std::memcpy(c->bs.h_up + up_keyoff, keyoff.data(), (size_t)nj * sizeof(unsigned));
-        if (!seeds.empty()) std::memcpy(c->bs.h_up + up_seeds, seeds.data(), seeds.size() * sizeof(DevEntry));
-        if (!hyps.empty()) std::memcpy(c->bs.h_up + up_hyps, hyps.data(), hyps.size() * sizeof(DevHyp));
+        uint8_t* const hu = c->bs.h_up;
+#pragma omp parallel for schedule(static) num_threads(n_threads) if (n_threads > 1)
+        for (int j = 0; j < nj; ++j) {
+            std::memcpy(hu + up_jobs + (size_t)j * sizeof(DevJob), &dj[j], sizeof(DevJob));
+            const size_t n = jobs[j].seeds.size();
+            if (n) {
+                std::memcpy(hu + up_seeds + seed_off[j] * sizeof(DevEntry), jobs[j].seeds.data(), n * sizeof(DevEntry));
+                std::memcpy(hu + up_hyps + seed_off[j] * sizeof(DevHyp), jobs[j].seed_hyp.data(), n * sizeof(DevHyp));
+            }
+        }
     }
+    mark("  upload: staging");
     HIP_TRY(hipMemcpyAsync(c->bs.d_jobs.p, c->bs.h_up + up_jobs, nj * sizeof(DevJob), hipMemcpyHostToDevice, S));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), S));
-    if (c->bs.d_hyp.reserve(std::max<size_t>(seeds.size(), 1)) || c->bs.d_keyoff.reserve(nj)
+    if (c->bs.d_hyp.reserve(std::max<size_t>(n_seeds_total, 1)) || c->bs.d_keyoff.reserve(nj)
         || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_round_work_t.reserve(MI_MAX_ROUNDS) || c->bs.d_round_items.reserve(MI_MAX_ROUNDS)
         || c->bs.d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->bs.d_view.reserve(4 * (size_t)nj)
         || c->bs.d_front.reserve(7 * (size_t)nj) || c->bs.d_front_resume.reserve(2 * (size_t)nj))
@@ -1559,19 +1573,19 @@ int BatchRun::upload() {
 
 /* ---- round 0: DMRecon::processFeatures (dmrecon.cc:243-331), every SfM feature of every view in one launch */
 int BatchRun::seed_round() {
-    if (seeds.empty()) return 0;
-    HIP_TRY(hipMemcpyAsync(c->bs.d_work.p, c->bs.h_up + up_seeds, seeds.size() * sizeof(DevEntry), hipMemcpyHostToDevice, S));
-    HIP_TRY(hipMemcpyAsync(c->bs.d_hyp.p, c->bs.h_up + up_hyps, hyps.size() * sizeof(DevHyp), hipMemcpyHostToDevice, S));
+    if (n_seeds_total == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(c->bs.d_work.p, c->bs.h_up + up_seeds, n_seeds_total * sizeof(DevEntry), hipMemcpyHostToDevice, S));
+    HIP_TRY(hipMemcpyAsync(c->bs.d_hyp.p, c->bs.h_up + up_hyps, n_seeds_total * sizeof(DevHyp), hipMemcpyHostToDevice, S));
     HIP_TRY(hipMemsetAsync(c->bs.d_keys.p, 0, total_px * sizeof(unsigned long long), S));
-    ev.begin(S, EventLog::BULK, (unsigned)seeds.size());
+    ev.begin(S, EventLog::BULK, (unsigned)n_seeds_total);
     const unsigned ppw = patches_per_wave(st);
-    D->optimize(S, 1, ((unsigned)seeds.size() + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p,
-                c->sc->d_lut, ds, c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)seeds.size(), 0u, 0xFFFFFFFFu, 0,
+    D->optimize(S, 1, ((unsigned)n_seeds_total + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p,
+                c->sc->d_lut, ds, c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n_seeds_total, 0u, 0xFFFFFFFFu, 0,
                 c->d_counters, nullptr, nullptr, nullptr, nullptr);
     ev.end(S);
     ++n_launch;
     ev.begin(S, EventLog::SWEEP, 0);
-    mi_launch_apply_seeds(S, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, (unsigned)seeds.size(), c->d_counters, c->bs.d_keys.p, c->bs.d_keyoff.p);
+    mi_launch_apply_seeds(S, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, (unsigned)n_seeds_total, c->d_counters, c->bs.d_keys.p, c->bs.d_keyoff.p);
     ev.end(S);
     return 0;
 }
@@ -1626,7 +1640,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
      * only makes its wavefronts stride), and the sizes are read back one round behind -- the host looks at round r - 1
      * while round r runs.  What it decides from them (when to stop, when every view has handed over) may come a round
      * late: the rounds enqueued meanwhile are proper rounds of the same propagation (after the end: empty ones). */
-    unsigned known_thr = (unsigned)std::max<size_t>(seeds.size(), 1) * 4u, known_lat = 0;
+    unsigned known_thr = (unsigned)std::max<size_t>(n_seeds_total, 1) * 4u, known_lat = 0;
     struct Pending { int round; size_t ev_thr, ev_lat; };
     Pending pend[2]; int n_pend = 0;
     bool stop = false;

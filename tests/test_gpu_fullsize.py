@@ -121,9 +121,19 @@ def test_c3_view_selection_on_device(c3, monkeypatch):
             assert ctx.global_view_selection(s, ref) == host, (ref, gmax)
 
 
-def test_c3_deterministic(c3):
+def test_c3_deterministic(c3, monkeypatch):
     cfg, scene, ctx, st, res, stats = c3
     refs = list(range(cfg["params"].n_views))
+    # 20 views on the 8 XCDs: four XCDs hold three views (teams of 10), four hold two (teams of 16, given to the views with the
+    # most empty pixels at the hand-over); with every team held to 10 workgroups the same bits
+    assert stats["front_team"] == 10 and stats["front_team_max"] == 16, stats
+    monkeypatch.setenv("MI_DMRECON_FRONT_TEAM", "10")
+    uniform = ctx.reconstruct(st, refs, want_views=True)
+    assert ctx.last_stats["front_team"] == 10 and ctx.last_stats["front_team_max"] == 10
+    monkeypatch.delenv("MI_DMRECON_FRONT_TEAM")
+    for v in range(len(refs)):
+        for k in ("depth", "conf", "dz", "normal", "views"):
+            assert np.array_equal(uniform[v][k], res[v][k]), (v, k)
     # the same call again, and the same call on a forked context (own stream): bit-identical maps
     f = ctx.fork()
     for c in (ctx, f):
