@@ -1,12 +1,8 @@
 #!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the round's final profile collection + the bench line of config 2 + the drop-in tests.
 export TMPDIR=/tmp
-OUT=gpurun_out/r4b
+OUT=gpurun_out/r4
 mkdir -p $OUT
-timeout -s KILL 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -3
-MI_BENCH_REGION_LOG=1 timeout -s KILL 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --one-call-n 20 > $OUT/q.json 2> $OUT/q.err
-python - <<PY
-import json,re
-d=json.loads(open("$OUT/q.json").read().strip().splitlines()[-1])
-print(round(d["value"],1), [round(x) for x in d["repeats"]], "one_call", round(d["one_call"]["ms_per_call"],2))
-PY
-grep "^region" $OUT/q.err | cut -c1-200
+bash tools/collect_profiles.sh r4 2>&1 | tail -6
+timeout -s KILL 400 python bench.py --config C2 --steps 20 --warmup 3 --one-call-n 30 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; tail -c 200 $OUT/bench_c2.json
+timeout -s KILL 600 python -m pytest tests/test_gpu_dropin_app.py -x -q 2>&1 | tail -2
