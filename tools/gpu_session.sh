@@ -1,8 +1,6 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): the round's final profile collection + the bench line of config 2 + the drop-in tests.
+# Runs ON THE GPU BOX (through gpurun): the bench line of config 5 on the round's final binary.
 export TMPDIR=/tmp
 OUT=gpurun_out/r4
 mkdir -p $OUT
-bash tools/collect_profiles.sh r4 2>&1 | tail -6
-timeout -s KILL 400 python bench.py --config C2 --steps 20 --warmup 3 --one-call-n 30 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; tail -c 200 $OUT/bench_c2.json
-timeout -s KILL 600 python -m pytest tests/test_gpu_dropin_app.py -x -q 2>&1 | tail -2
+timeout -s KILL 235 python bench.py --config C5 --steps 2 --warmup 1 --repeats 3 --one-call-n 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; tail -c 600 $OUT/bench_c5.json; tail -2 $OUT/bench_c5.err
