@@ -89,7 +89,9 @@ typedef struct mi_dmrecon_maps {
                          * for nrReconNeighbors <= 4, 8 channels above (mi_dmrecon_local_view_channels) */
 } mi_dmrecon_maps;
 
-/* Work counters (device-counted) and timings of the last reconstruct call. */
+/* Work counters (device-counted) and timings of the last reconstruct call.  The library fills the WHOLE struct of the
+ * header it was built with: a caller passes an object of this header's type, i.e. library and callers are built from
+ * the same header (fields are only ever appended; mve_amd/host/Makefile rebuilds the shim when this file changes). */
 typedef struct mi_dmrecon_stats {
     int64_t n_patch;        /* patch optimisations started (PatchOptimization objects) */
     int64_t n_eval;         /* patch-view evaluations: 25 bilinear samples of one neighbour view (SURVEY 8d unit) */
