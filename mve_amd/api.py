@@ -157,6 +157,25 @@ def debug_inject_footprint(view_id: int) -> None:
     load_library().mi_dmrecon_debug_inject_footprint(int(view_id))
 
 
+def front_teams(n_views: int, n_cus: int = 256, want: int = 32, empty=None):
+    """Test hook: the block map of a front launch with teams for n_views reference views on a device of n_cus compute
+    units (the library's build_front_teams; no GPU needed).  Returns dict(grid, team_min, team_max, map=[(job, member, team) or None])."""
+    L = load_library()
+    L.mi_dmrecon_debug_front_teams.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                               ctypes.POINTER(ctypes.c_int32)]
+    cap = 16384
+    m = np.zeros(cap, np.uint32)
+    e = None if empty is None else np.ascontiguousarray(empty, np.int64)
+    g, tmin, tmax = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    rc = L.mi_dmrecon_debug_front_teams(int(n_views), int(n_cus), int(want), _ptr(e), _ptr(m), cap, ctypes.byref(g), ctypes.byref(tmin),
+                                        ctypes.byref(tmax))
+    if rc != 0:
+        _raise(rc)
+    blocks = [None if v == 0xFFFFFFFF else (int(v & 0xFFFF), int((v >> 16) & 0xFF), int(v >> 24)) for v in m[:g.value]]
+    return dict(grid=g.value, team_min=tmin.value, team_max=tmax.value, map=blocks)
+
+
 def plan_views_host(scene: "SceneData", st: "Settings", ref_view: int, tables: bool = True, repeats: int = 1, seeds: bool = False):
     """Test hook: the HOST half of a call's planning -- the global view selection of `ref_view` as a reconstruct call runs
     it when it does not use the device for it (from the scene tables, or directly: tables=False) -- on the scene's cameras,

@@ -1887,54 +1887,71 @@ int BatchRun::tail_rounds(bool& to_front) {
  * launch needs the GPU's TeamToken (an advisory file lock: one team launch per GPU at a time, across processes), and a team
  * whose members do not all show up within MI_DMRECON_TEAM_WAIT_US gives up and the views finish with one workgroup
  * each (front_rounds): slower, never an error.  MI_DMRECON_FRONT_TEAM=<n> (1 = never). */
-void BatchRun::plan_front_team() {
-    const char* e = std::getenv("MI_DMRECON_FRONT_TEAM");
-    const int want = std::min(e ? std::atoi(e) : (active_call->count() <= 1 ? MI_FRONT_TEAM_MAX : 1), (int)MI_FRONT_TEAM_MAX);
-    front_team = front_team_max = 1; front_map.clear(); front_grid = 0;
-    if (want <= 1 || nj <= 0 || nj >= 65536) return;
-    /* A view's team lives on ONE XCD (one L2: k_front): the views are dealt over the XCDs, the CUs of an XCD over its views.
-     * When the views do not divide evenly, the XCDs that hold one view fewer have larger teams to give -- 20 views on 8 XCDs:
-     * four XCDs with three teams of 10, four with two teams of 16 -- and they go to the views with the most pixels still
-     * empty at the hand-over: the call lasts as long as its slowest view, and what is left to fill is what tells the long
-     * fronts from the short ones (measured, C3: the four slowest fronts, 11.5-14.4 ms with 10 workgroups each, are among the
-     * eight views with the most empty pixels; their lists at the hand-over -- 100 to 170 entries, as everybody's -- say
-     * nothing).  Team size does not show in the maps (tests: teams of 1, 2, 3, 8, 25). */
-    const int n_xcd = std::max(1, c->n_cus / 32), cus_x = std::max(1, c->n_cus / n_xcd);
+/* What a front launch with teams looks like (BatchRun::plan_front_team; a pure function of its arguments, so that it can be
+ * checked without a GPU: mi_dmrecon_debug_front_teams).
+ * A view's team lives on ONE XCD (one L2: k_front): the views are dealt over the XCDs, the CUs of an XCD over its views.
+ * When the views do not divide evenly, the XCDs that hold one view fewer have larger teams to give -- 20 views on 8 XCDs:
+ * four XCDs with three teams of 10, four with two teams of 16 -- and they go to the views with the most pixels still
+ * empty at the hand-over: the call lasts as long as its slowest view, and what is left to fill is what tells the long
+ * fronts from the short ones (measured, C3: the four slowest fronts, 11.5-14.4 ms with 10 workgroups each, are among the
+ * eight views with the most empty pixels; their lists at the hand-over -- 100 to 170 entries, as everybody's -- say
+ * nothing).  Team size does not show in the maps (tests: teams of 1, 2, 3, 8, 25, mixed).
+ * want: the largest team allowed; empty: per view the pixels not filled yet, or null (then: by index). */
+struct FrontTeams {
+    int team_min = 1, team_max = 1;          /* 1 / 1: no teams (some view would be alone anyway) */
+    unsigned grid = 0;
+    std::vector<unsigned> map;               /* [grid] job | member << 16 | team size << 24, 0xFFFFFFFF = a block without work */
+};
+FrontTeams build_front_teams(int nj, int n_cus, int want, const long long* empty) {
+    FrontTeams ft;
+    want = std::min(want, (int)MI_FRONT_TEAM_MAX);
+    if (want <= 1 || nj <= 0 || nj >= 65536) return ft;
+    const int n_xcd = std::max(1, n_cus / 32), cus_x = std::max(1, n_cus / n_xcd);
     const int base = nj / n_xcd, rem = nj % n_xcd;                  /* XCDs 0 .. rem - 1 hold base + 1 views */
     struct Slot { int xcd, team; };
     std::vector<Slot> slots;
     std::vector<int> team_x((size_t)n_xcd, 0), views_x((size_t)n_xcd, 0);
-    int tmin = MI_FRONT_TEAM_MAX;
+    int tmin = MI_FRONT_TEAM_MAX, tmax = 1;
     for (int x = 0; x < n_xcd; ++x) {
         views_x[x] = base + (x < rem ? 1 : 0);
         if (views_x[x] == 0) continue;
         team_x[x] = std::max(1, std::min(want, cus_x / views_x[x]));
         tmin = std::min(tmin, team_x[x]);
-        front_team_max = std::max(front_team_max, team_x[x]);
+        tmax = std::max(tmax, team_x[x]);
         for (int k = 0; k < views_x[x]; ++k) slots.push_back(Slot{x, team_x[x]});
     }
-    if (tmin <= 1) { front_team_max = 1; return; }                  /* some view would be alone anyway: no teams at all */
+    if (tmin <= 1) return ft;
     /* the largest teams to the views with the most empty pixels (ties, and a hand-over the host has no counts of: by index) */
     std::stable_sort(slots.begin(), slots.end(), [](Slot const& a, Slot const& b) { return a.team > b.team; });
     std::vector<int> order((size_t)nj);
     for (int j = 0; j < nj; ++j) order[j] = j;
-    if (view_filled.size() == (size_t)nj) {
-        auto empty = [&](int j) { return (long long)jobs[j].w * jobs[j].h - (long long)view_filled[j]; };
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return empty(a) > empty(b); });
-    }
+    if (empty) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return empty[a] > empty[b]; });
     /* block b runs on XCD b % n_xcd; its XCD's blocks in launch order are the members of that XCD's teams, team after team */
     int rows = 0;
     for (int x = 0; x < n_xcd; ++x) rows = std::max(rows, views_x[x] * team_x[x]);
-    front_grid = (unsigned)(rows * n_xcd);
-    if (front_grid > 16384u) { front_team_max = 1; front_grid = 0; return; }
-    front_map.assign(front_grid, 0xFFFFFFFFu);
+    const unsigned grid = (unsigned)(rows * n_xcd);
+    if (grid > 16384u) return ft;
+    ft.map.assign(grid, 0xFFFFFFFFu);
     std::vector<int> next_row((size_t)n_xcd, 0);
     for (size_t k = 0; k < slots.size(); ++k) {
         const int j = order[k], x = slots[k].xcd, T = slots[k].team;
-        for (int m = 0; m < T; ++m) front_map[(size_t)(next_row[x] + m) * n_xcd + x] = (unsigned)j | ((unsigned)m << 16) | ((unsigned)T << 24);
+        for (int m = 0; m < T; ++m) ft.map[(size_t)(next_row[x] + m) * n_xcd + x] = (unsigned)j | ((unsigned)m << 16) | ((unsigned)T << 24);
         next_row[x] += T;
     }
-    front_team = tmin;
+    ft.grid = grid; ft.team_min = tmin; ft.team_max = tmax;
+    return ft;
+}
+
+void BatchRun::plan_front_team() {
+    const char* e = std::getenv("MI_DMRECON_FRONT_TEAM");
+    const int want = e ? std::atoi(e) : (active_call->count() <= 1 ? MI_FRONT_TEAM_MAX : 1);
+    std::vector<long long> empty;
+    if (view_filled.size() == (size_t)nj) {
+        empty.resize((size_t)nj);
+        for (int j = 0; j < nj; ++j) empty[j] = (long long)jobs[j].w * jobs[j].h - (long long)view_filled[j];
+    }
+    FrontTeams ft = build_front_teams(nj, c->n_cus, want, empty.empty() ? nullptr : empty.data());
+    front_team = ft.team_min; front_team_max = ft.team_max; front_grid = ft.grid; front_map.swap(ft.map);
 }
 
 /* The right to run front teams on a GPU, for as long as the object lives: an exclusive, non-blocking flock on a file
@@ -2638,6 +2655,22 @@ static int mi_dmrecon_pointset_impl(mi_dmrecon_ctx* c, const mi_dmrecon_camera* 
 /* test hook (not in the public header): the reference view with this id gets a negative pixel footprint in the calls
  * that follow (-1: none), see fill_job */
 void mi_dmrecon_debug_inject_footprint(int view_id) { g_inject_footprint.store(view_id); }
+
+/* Test hook (not in the public header): the block map of a front launch with teams (build_front_teams) for n_views views on
+ * a device of n_cus compute units; map_out gets min(grid, cap) words.  Needs no GPU. */
+int mi_dmrecon_debug_front_teams(int32_t n_views, int32_t n_cus, int32_t want, const int64_t* empty, uint32_t* map_out, int32_t cap,
+                                 int32_t* grid_out, int32_t* team_min_out, int32_t* team_max_out) {
+    try {
+        std::vector<long long> e;
+        if (empty) e.assign(empty, empty + std::max(n_views, 0));
+        const FrontTeams ft = build_front_teams(n_views, n_cus, want, empty ? e.data() : nullptr);
+        if (grid_out) *grid_out = (int32_t)ft.grid;
+        if (team_min_out) *team_min_out = ft.team_min;
+        if (team_max_out) *team_max_out = ft.team_max;
+        for (size_t i = 0; map_out && i < ft.map.size() && (int32_t)i < cap; ++i) map_out[i] = ft.map[i];
+        return 0;
+    } catch (std::exception const& ex) { return fail(MI_DMRECON_EDEVICE, "%s", ex.what()); }
+}
 
 /* Test hook (not in the public header): the HOST half of the planning -- global view selection of reference view `ref`,
  * exactly the code a reconstruct call runs (plan_global_views: from the scene tables, or directly with tables = 0) -- on

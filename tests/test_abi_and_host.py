@@ -206,3 +206,45 @@ def test_host_view_selection_is_the_references(g1, g1_scene, h1_scene, w1, w1_sc
             b = api.plan_views_host(scene, api.Settings(refViewNr=ref, **kw), ref, tables=False, seeds=True)
             assert a[0] == b[0] and len(a[2][0]) > 20
             assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
+
+
+def test_front_teams_block_map():
+    """The block map of a front launch with teams (k_front reads job | member | team size per block): every view has
+    exactly its team's members, all on blocks with the same b % n_xcd (one XCD: one L2), an XCD is never asked for more
+    workgroups than it has compute units (default limit), and the XCDs that hold fewer views give the larger teams -- to
+    the views with the most empty pixels."""
+    import collections
+    for n_cus in (256, 304, 64, 32):
+        n_xcd, cus_x = max(1, n_cus // 32), n_cus // max(1, n_cus // 32)
+        for n in list(range(1, 70)) + [100, 255, 256, 400]:
+            rng = np.random.RandomState(n)
+            empty = rng.randint(0, 50000, n)
+            ft = api.front_teams(n, n_cus, 32, empty)
+            per_xcd = (n + n_xcd - 1) // n_xcd
+            if cus_x // per_xcd <= 1:
+                assert ft["team_min"] == 1 and ft["team_max"] == 1 and ft["grid"] == 0, (n_cus, n)
+                continue
+            assert ft["team_min"] == min(32, cus_x // per_xcd) and ft["grid"] == len(ft["map"]) and ft["grid"] % n_xcd == 0
+            jobs = collections.defaultdict(list)
+            used = collections.Counter()
+            for b, blk in enumerate(ft["map"]):
+                if blk is not None:
+                    jobs[blk[0]].append((blk[1], blk[2], b % n_xcd))
+                    used[b % n_xcd] += 1
+            assert sorted(jobs) == list(range(n)), (n_cus, n)
+            for j, ms in jobs.items():
+                T = ms[0][1]
+                assert all(t == T for _, t, _ in ms) and sorted(m for m, _, _ in ms) == list(range(T)), (n_cus, n, j)
+                assert len({x for _, _, x in ms}) == 1 and ft["team_min"] <= T <= ft["team_max"], (n_cus, n, j)
+            assert max(used.values()) <= cus_x, (n_cus, n, used)
+            # the more a view has left to fill, the larger (never the smaller) its team
+            order = sorted(range(n), key=lambda j: (-empty[j], j))
+            sizes = [jobs[j][0][1] for j in order]
+            assert sizes == sorted(sizes, reverse=True), (n_cus, n)
+    ft = api.front_teams(20, 256, 32, None)
+    assert collections.Counter(blk[2] for blk in ft["map"] if blk and blk[1] == 0) == {16: 8, 10: 12}
+    ft = api.front_teams(9, 256, 32, None)
+    assert collections.Counter(blk[2] for blk in ft["map"] if blk and blk[1] == 0) == {32: 7, 16: 2}
+    ft = api.front_teams(5, 256, 8, None)                                   # MI_DMRECON_FRONT_TEAM=8: an upper limit
+    assert ft["team_min"] == ft["team_max"] == 8
+    assert api.front_teams(20, 256, 1, None)["grid"] == 0

@@ -1,5 +1,4 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): the drop-in tests and the parity tests on the rebuilt binaries.
+# Runs ON THE GPU BOX (through gpurun): parity tests + the C3 team / determinism test on the final binary.
 export TMPDIR=/tmp
-timeout -s KILL 200 python -m pytest tests/test_gpu_dropin_app.py tests/test_gpu_parity.py -x -q 2>&1 | tail -2
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout -s KILL 100 python -m pytest tests/test_gpu_parity.py "tests/test_gpu_fullsize.py::test_c3_deterministic" -x -q 2>&1 | tail -2
