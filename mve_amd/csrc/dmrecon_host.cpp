@@ -85,13 +85,27 @@ inline void cpu_relax() {
     std::this_thread::yield();
 #endif
 }
+/* A LARGE batch (set for the calling thread by PatientWaits) waits for rounds of milliseconds: after a short spin it naps
+ * 50 us between looks -- a wait ends at most one nap late (25 waits per batch of 270 ms), and the thread does not burn a
+ * core per call in flight: eight ranks of a node, or four processes on one GPU, each spinning through their batches add
+ * up to more CPU time than a container may have (the GPU boxes of this project: the time of 16 cores). */
+thread_local bool g_patient_waits = false;
+struct PatientWaits {
+    bool old;
+    explicit PatientWaits(bool on) : old(g_patient_waits) { g_patient_waits = on; }
+    ~PatientWaits() { g_patient_waits = old; }
+};
+inline void wait_pause(unsigned spins) {
+    if (g_patient_waits && spins >= 64u) std::this_thread::sleep_for(std::chrono::microseconds(50));   /* (64 looks: ~100 us) */
+    else for (int k = 0; k < 32; ++k) cpu_relax();
+}
 inline hipError_t wait_event(hipEvent_t e) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
         const hipError_t q = hipEventQuery(e);
         if (q != hipErrorNotReady) return q;
-        for (int k = 0; k < 32; ++k) cpu_relax();
-        if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) return hipEventSynchronize(e);
+        wait_pause(spins);
+        if (!g_patient_waits && (spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) return hipEventSynchronize(e);
     }
 }
 inline hipError_t wait_stream(hipStream_t s) {
@@ -99,8 +113,8 @@ inline hipError_t wait_stream(hipStream_t s) {
     for (unsigned spins = 0;; ++spins) {
         const hipError_t q = hipStreamQuery(s);
         if (q != hipErrorNotReady) return q;
-        for (int k = 0; k < 32; ++k) cpu_relax();
-        if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) return hipStreamSynchronize(s);
+        wait_pause(spins);
+        if (!g_patient_waits && (spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) return hipStreamSynchronize(s);
     }
 }
 
@@ -2064,8 +2078,10 @@ int BatchRun::front_rounds() {
                         if (trace) fprintf(stderr, "[mi_dmrecon] view %d streamed back at %.3f ms of the front phase (%s)\n", jobs[j].ref_view, now_ms() - t_mark, over ? "kernel over" : "kernel running");
                     }
                 if (over || n_streamed == nj) break;
-                /* (a sleep of any length comes back 50+ us later: the timer slack; this thread has nothing else to do) */
-                for (int k = 0; k < 200; ++k) cpu_relax();
+                /* (a sleep of any length comes back 50+ us later: the timer slack; a small call has nothing better to do
+                 * than look again at once, a large batch naps: see PatientWaits) */
+                if (g_patient_waits) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                else for (int k = 0; k < 200; ++k) cpu_relax();
             }
         }
         if (h_done) {
@@ -2297,6 +2313,7 @@ static int reconstruct_batch(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
         if (!hv.levels.empty()) px_hint += (size_t)hv.levels[l].w * (size_t)hv.levels[l].h;
     }
     ScratchLease lease(c, px_hint);
+    PatientWaits patient(n_refs >= MI_MERGE_SMALL_CALL);
     BatchRun B;
     B.c = c; B.st = st; B.n_refs = n_refs; B.ref_views = ref_views; B.maps = maps; B.progress = progress;
     B.status_out = status_out; B.stats = stats; B.D = mi_device_api(st->filterWidth); B.ds = dev_settings(st); B.S = c->stream;
