@@ -248,3 +248,21 @@ def test_front_teams_block_map():
     ft = api.front_teams(5, 256, 8, None)                                   # MI_DMRECON_FRONT_TEAM=8: an upper limit
     assert ft["team_min"] == ft["team_max"] == 8
     assert api.front_teams(20, 256, 1, None)["grid"] == 0
+
+
+def test_host_view_selection_at_config3_size():
+    """The same check at BASELINE config 3's size (20 views, ~2 000 features: rows of ~2 000 floats through the
+    eight-row in-order sums, 19 greedy rounds): all 20 reference views, both paths, and a smaller globalVSMax."""
+    from oracle import oracle as orc
+    from mve_amd.synth import CONFIGS, make_scene
+    cfg = CONFIGS["C3"]
+    scene = make_scene(cfg["params"])
+    S = orc.OracleScene(scene)
+    for ref in range(cfg["params"].n_views):
+        want = S.global_vs(orc.make_settings(ref_view=ref, scale=cfg["scale"]))
+        assert len(want) == 19
+        assert _host_views(scene, ref, True, scale=cfg["scale"]) == want, ref
+        if ref in (0, 11):
+            assert _host_views(scene, ref, False, scale=cfg["scale"]) == want, ref
+            w5 = S.global_vs(orc.make_settings(ref_view=ref, scale=cfg["scale"], global_max=5))
+            assert _host_views(scene, ref, True, scale=cfg["scale"], globalVSMax=5) == w5, ref
