@@ -89,7 +89,7 @@ typedef const __attribute__((address_space(1))) int32_t* gi32_t;
 #ifdef MI_PROBE
 /* development aid (tools/patch_probe.py, `make -C mve_amd/csrc probe`): the first lane of a wavefront logs (id, shader
  * clock) pairs of the patch it is working on into LDS; k_front copies the log of an attempt into the debug buffer */
-#define MI_PROBE_LOG 48
+#define MI_PROBE_LOG 96
 __shared__ unsigned long long g_plog[8][MI_PROBE_LOG];
 __shared__ unsigned g_pidx[8];
 __device__ __forceinline__ void probe_stamp(unsigned id) {
@@ -560,6 +560,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         ok = dnorm > 0.f;
         step = ok ? fast_rcp(dnorm) : 0.f;
     }
+    TSTAMP(50);                                        /* (pass set-up done: the derivative step) */
     const float wlim = (float)(nv.w - 1), hlim = (float)(nv.h - 1);
     ColorSums S;
     S.s0 = ps.xbar0 * ps.mmean; S.s1 = ps.xbar1 * ps.mmean; S.s2 = ps.xbar2 * ps.mmean;
@@ -986,6 +987,7 @@ __device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevVie
     if (L::LPV == 1) viewc_reset(vc);
     if (ps.sel >= 0) {
         okv = view_prepare(ps, vc, views);
+        TSTAMP(52);
         if (okv) okv = sample_pass<MODE, L>(ps, vc.nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
         ps.n_pass++;
         if (okv) {
@@ -1240,6 +1242,7 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
         if (conv) { R.converged = true; return false; }
         ++R.iter;
     }
+    TSTAMP(31);                                        /* (what led to this pass is finished: colour scale / convergence / replacement) */
     /* ---- loop condition of the main loop (:185-186) */
     if (R.iter >= 4 && R.iter >= st.maxIterations) return false;
     /* ---- take the step of iteration `iter` from the sums of this pass */
@@ -1285,6 +1288,7 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
         else step_ok = first4;                     /* the first four iterations tolerate denom <= 0 (:177-180) */
         R.step_was_normal = false;
     }
+    TSTAMP(33);                                        /* (the step is taken: sums across the views, solve, set_state) */
     if (!step_ok) { R.opti = false; return false; }
     /* the colour scale only changes right after a normal step (and in the ctor): every other pass can
      * bake it in, which leaves 7 instead of 21 values to reduce across the view slot */

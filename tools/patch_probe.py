@@ -11,7 +11,8 @@ cfg = CONFIGS["C3"]
 sc = make_scene(cfg["params"])
 ctx = api.Context(0); ctx.load_scene(sc)
 L = api.load_library()
-NW = 8 + 400 * 52
+LOG = 96                                   # MI_PROBE_LOG of dmrecon_device.hip
+NW = 8 + 400 * (LOG + 4)
 L.mi_dmrecon_debug_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.mi_dmrecon_debug_buffer(None, NW)
 st = api.Settings(scale=cfg["scale"], nrReconNeighbors=cfg["local_neighbors"])
@@ -25,7 +26,7 @@ n = min(int(buf[0]), 400)
 print("records", int(buf[0]), "kept", n)
 us, cyc, seg, iters_h = [], [], collections.defaultdict(list), collections.Counter()
 for r in range(n):
-    o = buf[8 + r * 52: 8 + (r + 1) * 52]
+    o = buf[8 + r * (LOG + 4): 8 + (r + 1) * (LOG + 4)]
     ticks, np_, meta = int(o[1]), int(o[2]), int(o[3])
     ids = [int(v >> np.uint64(56)) for v in o[4:4 + np_]]
     ts = [int(v & np.uint64(0x00FFFFFFFFFFFFFF)) for v in o[4:4 + np_]]
