@@ -89,10 +89,14 @@ typedef struct mi_dmrecon_maps {
                          * for nrReconNeighbors <= 4, 8 channels above (mi_dmrecon_local_view_channels) */
 } mi_dmrecon_maps;
 
-/* Work counters (device-counted) and timings of the last reconstruct call.  The library fills the WHOLE struct of the
- * header it was built with: a caller passes an object of this header's type, i.e. library and callers are built from
- * the same header (fields are only ever appended; mve_amd/host/Makefile rebuilds the shim when this file changes). */
+/* Work counters (device-counted) and timings of the last reconstruct call.  The struct only ever grows at its end, and
+ * it carries its own size: the CALLER sets struct_size = sizeof(mi_dmrecon_stats) of the header it was built with before
+ * every call, the library fills min(struct_size, its own sizeof) bytes and writes that number back -- a caller built
+ * against an older (shorter) header is never overrun, one built against a newer header sees from struct_size which
+ * fields it got.  A struct_size below 8 or absurdly large is MI_DMRECON_EINVAL (an object that was never initialised).
+ * (The reference has no such struct: nothing of this is constrained by its interface.) */
 typedef struct mi_dmrecon_stats {
+    int64_t struct_size;    /* in: sizeof(mi_dmrecon_stats) as the caller knows it; out: the bytes the library filled */
     int64_t n_patch;        /* patch optimisations started (PatchOptimization objects) */
     int64_t n_eval;         /* patch-view evaluations: 25 bilinear samples of one neighbour view (SURVEY 8d unit) */
     int64_t n_filled;       /* pixels with depth (progress.filled) */

@@ -75,7 +75,8 @@ class CMaps(ctypes.Structure):
 
 
 class CStats(ctypes.Structure):
-    _fields_ = [("n_patch", ctypes.c_int64), ("n_eval", ctypes.c_int64), ("n_filled", ctypes.c_int64),
+    _fields_ = [("struct_size", ctypes.c_int64),
+                ("n_patch", ctypes.c_int64), ("n_eval", ctypes.c_int64), ("n_filled", ctypes.c_int64),
                 ("n_seeds", ctypes.c_int64), ("n_seeds_ok", ctypes.c_int64), ("n_rounds", ctypes.c_int64),
                 ("n_launches", ctypes.c_int64), ("ms_total", ctypes.c_double),
                 ("ms_opt_kernel", ctypes.c_double), ("ms_sweep_kernels", ctypes.c_double),
@@ -462,6 +463,7 @@ class Context:
             maps[i].views = _ptr(d.get("views"))
         status = np.zeros(n, np.int32)
         stats = CStats()
+        stats.struct_size = ctypes.sizeof(CStats)             # the library fills what the caller has room for (mi_dmrecon.h)
         rc = self._L.mi_dmrecon_reconstruct(self._h, ctypes.byref(cs), n, _ptr(refs), maps, progress,
                                             _ptr(status), ctypes.byref(stats))
         if rc != 0:

@@ -13,7 +13,8 @@
  * optimize -- lanes_per_view: 1 = 16 patches per wavefront (throughput), 16 = one patch per wavefront (latency).
  *   The launch only acts if min_work <= n < max_work, n = *n_work_ptr (if given) or n_work.
  *   follow_out != null: one optimisation attempt per entry; entries with further candidate hypotheses are appended to
- *   follow_out (count *follow_out_n).  follow_in != null: continue the entries work[follow_in[0 .. *follow_in_n)].
+ *   follow_out (count *follow_out_n).  follow_in != null: continue the entries work[follow_in[0 .. *follow_in_n)] -- with
+ *   ONE more attempt each if the launch has a follow_out of its own, else with all the attempts they have left.
  * generate -- k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile count.
  *   A view's entries go to `work` (count round_work[round]) while the view is in the throughput layout, to `work_lat`
  *   (round_work_lat[round]) once it has handed over: for good, from the round after the first one in which the VIEW's
@@ -72,7 +73,9 @@ struct MiDeviceApi {
                                        * end, after its state has been written back to memory */,
                   const unsigned* block_map /* teams: per block of the grid job | member << 16 | team size << 24, 0xFFFFFFFF = none;
                                              * the blocks of a team share b % n_xcd */,
-                  unsigned grid_blocks);
+                  unsigned grid_blocks,
+                  const unsigned* job_order /* one workgroup per view: the view every block runs (a permutation of 0 .. n_jobs - 1: the
+                                             * views the host expects to run longest first), or null: block b runs view b */);
     /* optimize_spec -- a round of the throughput layout with every (entry, candidate rank) pair on a quad of its own: `items`
      * (entry << 2 | rank, *n_items of them: written by `generate` when given an item list) are the attempts, spec holds
      * one record per item; mi_launch_apply_spec applies the reference's sequential rule to the records and writes the

@@ -446,9 +446,15 @@ __device__ __forceinline__ void view_row2(NView& nv, const DevJobView& J, float 
 __device__ __forceinline__ int mip_level(float z, float inv0, float mfp, int maxl) {
     const float nfp = z * inv0;                  /* SingleView::footPrint */
     if (!(nfp > 0.f)) return -1;
-    float ratio = nfp / mfp;
+    const float ratio = nfp / mfp;               /* (an IEEE division: the synthetic scenes sit exactly on the rule's threshold, Q4) */
+    /* the reference doubles the ratio until it reaches 0.5, at most MI_MAX_LEVELS times (patch_sampler.cc:85-91): the
+     * doublings are exact, so their number is the negated exponent of ratio = f 2^e, f in [0.5, 1) -- one v_frexp_exp_i32_f32
+     * instead of a loop with a branch per level (a dependent chain of ~40 cycles per level in the latency layout) */
     int mm = 0;
-    while (ratio < 0.5f && mm < MI_MAX_LEVELS) { ++mm; ratio *= 2.f; }
+    if (ratio < 0.5f) {
+        const int e = -__builtin_amdgcn_frexp_expf(ratio);
+        mm = (ratio > 0.f && e < MI_MAX_LEVELS) ? e : MI_MAX_LEVELS;
+    }
     return mm > maxl ? maxl : mm;                /* clampLevel with minLevel 0 (dmrecon.cc:240) */
 }
 
@@ -1509,6 +1515,94 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
     return accepted;
 }
 
+/*
+ * ONE optimisation attempt of a work-list entry -- the form of the large host-visible rounds: the first launch runs every
+ * entry's first attempt (FAST), a second launch the second attempt of the entries the reference's rule still asks one of,
+ * the rest goes to process_entry above (all remaining attempts in a row, a few per cent of the entries).  Same candidates in
+ * the same order, same pop-time and acceptance tests (dmrecon.cc:365-392), same records as process_entry -- but nothing of
+ * an entry's chain of attempts is live across the optimisation except `tried`, `best` and the runner-up's confidence: no
+ * loop around optimize_patch, hence none of the 260-300 bytes of scratch per lane the loop form needs.
+ * more: the entry has a further candidate the rule still asks for (or its attempt was abandoned: FAST).
+ */
+template <class L, bool FAST>
+__device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned e, const DevJob* job, int x, int y, int lane,
+                                                     unsigned& n_eval, unsigned& n_pass, unsigned& n_patch, unsigned& err, bool& more) {
+    const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
+    const bool resume = a.follow_in != nullptr;
+    const int W = job->w;
+    const int pix = y * W + x;
+    if (!FAST && a.hyp != nullptr) {
+        /* explicit mode (seeds, parity hook): the one hypothesis given; the result is always recorded */
+        const DevHyp h = a.hyp[e];
+        PatchResult r;
+        optimize_patch<L, false>(job, a.st, a.views, x, y, h.depth, h.dzI, h.dzJ, view_set(h.views, h.views_hi), lane, r, n_eval, n_pass, err, a.counters);
+        ++n_patch;
+        more = false;
+        if (writer) {
+            DevResult o;
+            o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ;
+            o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.views_hi = r.views_hi; o.iters = r.iters;
+            o.accepted = r.conf > 0.f ? 1 : 0; o.tried = 0;
+            a.results[e] = o;
+        }
+        return;
+    }
+    const float own = GF(job->conf + pix);
+    float best = own;
+    unsigned tried = 0;
+    if (resume) {
+        const DevResult* prev = a.results + e;
+        tried = GU(&prev->tried);
+        if (GI(&prev->accepted) != 0) best = GF(&prev->conf);
+    }
+    /* the best untried candidate (highest source confidence, lowest direction on ties: process_entry's strict '>') and the
+     * confidence of the one that would come after it */
+    const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+    int bi = -1; float bc = 0.f, bc2 = 0.f; bool has2 = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((tried >> k) & 1u) continue;
+        const float c = GF(job->conf + nb[k]);
+        const bool use = GI(job->upd + nb[k]) == a.round - 1 && (own < c - 0.05f || own == 0.f);
+        if (!use) continue;
+        if (bi < 0 || c > bc) { if (bi >= 0) { bc2 = has2 ? fmaxf(bc2, bc) : bc; has2 = true; } bi = k; bc = c; }
+        else { bc2 = has2 ? fmaxf(bc2, c) : c; has2 = true; }
+    }
+    more = false;
+    DevResult z;
+    z.conf = 0.f; z.depth = 0.f; z.dzI = z.dzJ = 0.f; z.nx = z.ny = z.nz = 0.f;
+    z.views = 0xFFFFFFFFu; z.views_hi = 0xFFFFFFFFu; z.iters = 0; z.accepted = 0; z.tried = tried;
+    if (bi < 0 || best > bc) {                                 /* nothing (left) to try: dmrecon.cc:371 skips this candidate and every later one */
+        if (!resume && writer) a.results[e] = z;
+        return;
+    }
+    const int p = bi == 0 ? nb[0] : bi == 1 ? nb[1] : bi == 2 ? nb[2] : nb[3];
+    const float hd = GF(job->depth + p), hi = GF(job->dz + 2 * p), hj = GF(job->dz + 2 * p + 1);
+    const unsigned long long hv = load_view_set<L::NV>(job, false, p);
+    PatchResult r;
+    if (!optimize_patch<L, FAST>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters)) {
+        /* abandoned (FAST): the candidate stays untried, the next launch (the general kernel) takes the entry */
+        if (!resume && writer) a.results[e] = z;
+        more = true;
+        return;
+    }
+    ++n_patch;
+    tried |= 1u << bi;
+    const bool accept = r.conf > 0.f && best < r.conf;         /* dmrecon.cc:378,391 */
+    if (accept) best = r.conf;
+    more = has2 && !(best > bc2);
+    if (writer) {
+        if (accept) {
+            DevResult o;
+            o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ;
+            o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.views_hi = r.views_hi; o.iters = r.iters;
+            o.accepted = 1; o.tried = tried;
+            a.results[e] = o;
+        } else if (!resume) { z.tried = tried; a.results[e] = z; }
+        else if (more) a.results[e].tried = tried;
+    }
+}
+
 /* flush counters: one atomic per wave (per-view counters live in the first lane of each view slot,
  * the patch counter in the first lane of each patch) */
 template <class L>
@@ -1536,8 +1630,9 @@ __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, 
  * The hot kernel.  L::LPV = 1: 16 patches per wavefront (throughput); L::LPV = 16: one patch per
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
  */
-template <class L, bool FAST>
+template <class L, bool FAST, bool SINGLE = FAST>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 2 : MI_BULK_WAVES), (L::LAT ? 2 : MI_WAVES_PER_SIMD)))) void k_optimize(OptArgs a) {
+    static_assert(SINGLE || !FAST, "the FAST kernel runs one attempt per entry");
     const int lane = threadIdx.x;
     const unsigned n = a.follow_in ? *a.follow_in_n : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
     if (n < a.min_work || n >= a.max_work) return;
@@ -1555,8 +1650,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
         if (GI(&job->flags) != 0) {
             /* the view failed (footprint exception) or was cancelled: nothing of it is touched any more */
             if (L::vslot(lane) == 0 && L::sub(lane) == 0) a.results[e].accepted = 0;
-        } else
-            process_entry<L, FAST>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
+        } else if (SINGLE)
+            process_entry_single<L, FAST>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
+        else
+            process_entry<L, false>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
         if (a.follow_out) {
             /* wave-aggregated append of the entries that still have candidates (one atomic per wavefront) */
             const bool mine = more && L::vslot(lane) == 0 && L::sub(lane) == 0;
@@ -1942,6 +2039,11 @@ struct FrontArgs {
     int force_write_through;      /* test hook (MI_DMRECON_DEBUG_TEAM_WT): as if a team's members had been found on different XCDs */
     int fault_member, fault_round; /* test hook (MI_DMRECON_DEBUG_FRONT_FAULT): this member of every team vanishes at that round of its
                                     * view (0 = it never shows up), as one that is not given a compute unit would; -1 = none */
+    const unsigned* job_order;    /* one workgroup per view: the view block b runs (null: view b).  A batch with more views than
+                                   * the GPU holds front workgroups (one per CU: 256 registers x 8 wavefronts) runs them in waves, and
+                                   * the launch lasts as long as the last workgroup: the host puts the views with the most left to
+                                   * fill FIRST (longest processing time first), so that the long fronts start at once and the short
+                                   * ones fill the CUs that become free */
 };
 #define MI_FRONT_DONE 0xFFFFFFFF00000000ull
 /* a team member's flag word: bits 0..29 the number of its last finished pass (only ever grows), bit 30 "my team gives up"
@@ -2000,6 +2102,7 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
      * the members write (all of them every word, plain stores) and read back then lives in one coherent cache.  Placement is
      * not promised: every member registers its XCC id, and a team found on several XCDs writes through instead (below). */
     int jobi = (int)blockIdx.x, member = 0, T = 1;
+    if (!TEAM && t.job_order) jobi = (int)t.job_order[blockIdx.x];
     if (TEAM) {
         const unsigned m = t.block_map[blockIdx.x];
         if (m == 0xFFFFFFFFu) return;
@@ -2886,13 +2989,20 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     const bool lat = lanes_per_view != 1, eight = st.K > 4;
     /* the first launch of a bulk round (one attempt per entry, a follow-up list for the rest) runs the FAST kernel: no
      * view selection code in it -- a patch that needs one goes to the follow-up launch, which is the general kernel */
-    const bool fast = !lat && follow_out != nullptr && hyp == nullptr;
+    const bool fast = !lat && follow_out != nullptr && follow_in == nullptr && hyp == nullptr;
+    /* ... a launch that continues a follow-up list AND leaves one runs one attempt per entry as well, in the general kernel
+     * (process_entry_single), and so do the seeds (one hypothesis each); only a propagation launch without a follow-up list
+     * of its own runs an entry's attempts in a row */
+    const bool single = !lat && (hyp != nullptr || (follow_out != nullptr && follow_in != nullptr));
     if (lat) {
         if (eight) hipLaunchKernelGGL((k_optimize<Lay<8, 8>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
         else hipLaunchKernelGGL((k_optimize<Lay<16, 4>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
     } else if (fast) {
         if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
         else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    } else if (single) {
+        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, false, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, false, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
     } else {
         if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
         else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
@@ -2980,7 +3090,7 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
                          const unsigned* job_off, unsigned* job_count, unsigned* job_stats, int first_round, int max_rounds,
                          DevCounters* counters, int team, unsigned long long* mail, unsigned* team_flags,
                          const unsigned long long* job_start, unsigned long long* job_resume, unsigned* team_filled, unsigned spin_ticks,
-                         int fault, int n_xcd, unsigned* host_done, const unsigned* block_map, unsigned grid_blocks) {
+                         int fault, int n_xcd, unsigned* host_done, const unsigned* block_map, unsigned grid_blocks, const unsigned* job_order) {
     static_assert(MI_FRONT_MAIL_WORDS == 2 * MI_FRONT_QCAP * 4 * MI_FRONT_GRAN, "mailbox size");
     if (n_jobs <= 0) return;
     if (!job_start) {
@@ -3004,7 +3114,7 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
     t.n_jobs = n_jobs; t.n_xcd = n_xcd < 1 ? 1 : n_xcd;
     t.l2_exchange = (fault >= 0 && ((fault >> 25) & 1)) ? 0 : 1;
     t.host_done = host_done;
-    t.block_map = nullptr;
+    t.block_map = nullptr; t.job_order = job_order;
     if (team > 1 && mail && team_flags && team_filled && block_map && grid_blocks > 0) {
         t.team = team > MI_FRONT_TEAM_MAX ? MI_FRONT_TEAM_MAX : team; t.mail = mail; t.team_flags = team_flags;
         t.block_map = block_map;

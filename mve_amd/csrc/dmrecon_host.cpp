@@ -14,6 +14,7 @@
  * fails with MI_DMRECON_EDEVICE otherwise.
  */
 #include "../../include/mi_dmrecon.h"
+#include "../../include/mi_dmrecon_debug.h"
 
 #include <hip/hip_runtime.h>
 #include <omp.h>
@@ -22,6 +23,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cctype>
+#include <cerrno>
 
 #include <algorithm>
 #include <atomic>
@@ -205,6 +207,7 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 #define MI_MERGE_SMALL_CALL 48      /* reference views: below this a call waits MI_MERGE_WINDOW_US for company, ... */
 #define MI_MERGE_WINDOW_US 1000
 #define MI_MERGE_WINDOW_BIG_US 3000 /* ... from this size on this long: ~2 % of such a call's own time (see mi_dmrecon_reconstruct) */
+#define MI_FOLLOW_LISTS 8          /* follow-up list counters per round (five in use: BatchRun::bulk_rounds) */
 #define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
 #define MI_SPEC_ROUNDS 400000u      /* throughput rounds below this many entries try an entry's candidate hypotheses at the same time */
 #define MI_VIEW_HANDOVER 320u      /* a view leaves the throughput layout once a round's list of its own is shorter than this */
@@ -283,6 +286,7 @@ struct BatchScratch {
     DevBuf<unsigned> d_round_work_t;         /* [MI_MAX_ROUNDS] per round: size of the list of the views in the throughput layout */
     DevBuf<unsigned> d_round_items;          /* [MI_MAX_ROUNDS] per round: (entry, candidate) pairs of that list (speculative rounds) */
     DevBuf<unsigned> d_view;                 /* k_generate: [3][n_jobs] entries per view of the last rounds | [n_jobs] hand-over rounds */
+    DevBuf<unsigned> d_front_order;          /* k_front, one workgroup per view: the view every block runs (FrontArgs::job_order) */
     DevBuf<unsigned> d_front_map;            /* k_front with teams: what every block of the grid is (FrontArgs::block_map) */
     DevBuf<unsigned> d_front;                /* k_front: [n_jobs] list offsets | [n_jobs] list sizes | [n_jobs][4] per-view statistics |
                                               * [n_jobs] pixels filled by the view's team */
@@ -291,7 +295,7 @@ struct BatchScratch {
     DevBuf<unsigned> d_front_flags;          /* ... and MI_FRONT_TEAM_MAX pass flags per view */
     DevBuf<unsigned> d_follow;               /* 4 x work-list capacity: entries that continue with their next hypothesis (two-launch
                                               * rounds) / the (entry, candidate) items of a speculative round (at most four per entry) */
-    DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][4] sizes of the follow-up lists */
+    DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][MI_FOLLOW_LISTS] sizes of the follow-up lists */
     DevBuf<DevSpec> d_spec;                  /* speculative small rounds: four attempt records per entry (BatchRun::bulk_rounds) */
     TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
@@ -324,14 +328,17 @@ struct BatchScratch {
             return 0;
         return reserve_pixels(px, n_imaps);                           /* (DevBuf::reserve adds the headroom) */
     }
-    bool holds_anything() const { return d_maps.cap || d_work.cap || d_jobs.cap || d_results.cap || d_hyp.cap || h_poll || h_dyn || !events.empty(); }
+    bool holds_anything() const {
+        return d_maps.cap || d_work.cap || d_jobs.cap || d_results.cap || d_hyp.cap || d_spec.cap || d_gvs_out.cap || d_gvs_feat.cap
+            || h_poll || h_dyn || h_gvs || h_up || h_done || !events.empty();
+    }
     void release() {
         for (size_t i = 0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
         events.clear();
         d_jobs.release(); d_work.release(); d_work2.release(); d_hyp.release(); d_results.release(); d_results2.release();
         d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_keys.release(); d_keyoff.release();
         d_round_work.release(); d_round_work_t.release(); d_round_items.release(); d_view.release(); d_front.release(); d_front_resume.release();
-        d_front_mail.release(); d_front_flags.release(); d_front_map.release();
+        d_front_mail.release(); d_front_flags.release(); d_front_map.release(); d_front_order.release();
         d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release();
         if (h_poll) (void)hipHostFree(h_poll);
         if (h_dyn) (void)hipHostFree(h_dyn);
@@ -1399,6 +1406,7 @@ struct BatchRun {
     bool ran_front = false; int front_first_round = 0, front_team = 1, front_team_max = 1, front_fallbacks = 0;
     std::vector<unsigned> view_filled;       /* ... and the pixels the view had filled by then */
     std::vector<unsigned> view_list;         /* entries of every view's list in the last host-visible round read back (0: not known) */
+    std::vector<unsigned> front_order;       /* one workgroup per view: the views in the order their workgroups start (FrontArgs::job_order) */
     std::vector<unsigned> front_map; unsigned front_grid = 0;   /* teams: what every block of the front launch is (FrontArgs::block_map) */
     unsigned handover = MI_VIEW_HANDOVER;      /* k_generate: a view's own list size below which it leaves the throughput layout */
     bool host_rounds_only = false;             /* diagnostic: every round host-visible (MI_DMRECON_HOST_ROUNDS) */
@@ -1549,7 +1557,7 @@ int BatchRun::upload() {
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), S));
     if (c->bs.d_hyp.reserve(std::max<size_t>(n_seeds_total, 1)) || c->bs.d_keyoff.reserve(nj)
         || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_round_work_t.reserve(MI_MAX_ROUNDS) || c->bs.d_round_items.reserve(MI_MAX_ROUNDS)
-        || c->bs.d_follow_cnt.reserve(4 * MI_MAX_ROUNDS) || c->bs.d_view.reserve(4 * (size_t)nj)
+        || c->bs.d_follow_cnt.reserve(MI_FOLLOW_LISTS * MI_MAX_ROUNDS) || c->bs.d_view.reserve(4 * (size_t)nj)
         || c->bs.d_front.reserve(7 * (size_t)nj) || c->bs.d_front_resume.reserve(2 * (size_t)nj))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc(work lists) failed");
     HIP_TRY(hipMemsetAsync(c->bs.d_round_work.p, 0, MI_MAX_ROUNDS * sizeof(unsigned), S));
@@ -1562,7 +1570,7 @@ int BatchRun::upload() {
     /* per-view counts of "the round before round 1": none yet -- unless every view starts in the latency layout */
     HIP_TRY(hipMemsetAsync(c->bs.d_view.p, 0, 4 * (size_t)nj * sizeof(unsigned), S));
     if (handover < 1000000000u) HIP_TRY(hipMemsetAsync(c->bs.d_view.p, 0xFF, (size_t)nj * sizeof(unsigned), S));
-    HIP_TRY(hipMemsetAsync(c->bs.d_follow_cnt.p, 0, 4 * MI_MAX_ROUNDS * sizeof(unsigned), S));
+    HIP_TRY(hipMemsetAsync(c->bs.d_follow_cnt.p, 0, MI_FOLLOW_LISTS * MI_MAX_ROUNDS * sizeof(unsigned), S));
     HIP_TRY(hipMemcpyAsync(c->bs.d_keyoff.p, c->bs.h_up + up_keyoff, nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
     if (!c->bs.h_poll) {
         /* (mapped: written by k_round_report, not by copies) */
@@ -1647,6 +1655,9 @@ int BatchRun::bulk_rounds(bool& to_tail) {
      * are enqueued next to the speculative ones and look at the size on the device. */
     const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPEC_ROUNDS"); return e ? (unsigned)std::max(0L, std::atol(e)) : MI_SPEC_ROUNDS; }();
     const unsigned spec_cap = 2u * SPEC_MAX;
+    /* MI_DMRECON_SINGLE_FOLLOW=0 (read per call): the follow-up list of a large round in ONE launch, all remaining attempts of
+     * an entry in a row (round 4's form; same maps and counters) */
+    const bool SINGLE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_SINGLE_FOLLOW"); return !e || std::atoi(e) != 0; }();
     if (SPEC_MAX > 0 && c->bs.d_spec.reserve(4 * (size_t)spec_cap)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(speculative records) failed");
     /* The rounds are enqueued WITHOUT waiting for their list sizes: every kernel of a round reads its size on the device
      * (k_generate also decides there which layout a view's entries go to), the grids come from the sizes of the last round
@@ -1675,7 +1686,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         ev.begin(S, EventLog::BULK, 0);                              /* (entries: filled in at the read-back) */
         const size_t ev_thr = ev.items.size() - 1;
         size_t ev_lat = (size_t)-1;
-        unsigned* fcnt = c->bs.d_follow_cnt.p + 4 * (size_t)r;
+        unsigned* fcnt = c->bs.d_follow_cnt.p + MI_FOLLOW_LISTS * (size_t)r;
         const unsigned plain_min = spec ? spec_cap : 0u;
         /* a list grows at most four-fold per round (a pixel is in it only if one of its four neighbours was written in the
          * round before), and the host's figure is two rounds old when it enqueues: below a sixteenth of the records' capacity
@@ -1704,9 +1715,25 @@ int BatchRun::bulk_rounds(bool& to_tail) {
              * entries back to back (third and fourth attempts are rare) */
             D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
                         0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, c->bs.d_follow.p, fcnt);
-            D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                        c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, c->bs.d_follow.p, fcnt, nullptr, nullptr);
-            ++n_launch;
+            if (SINGLE_FOLLOW) {
+                /* every further attempt as a launch of its own over the entries the reference's rule still asks one of (about
+                 * a fifth, a thirtieth, ... of the list), again ONE attempt per entry: no chain of attempts is live across an
+                 * optimisation, hence no spills (the loop form: 304 bytes of scratch per lane), and every wavefront is full.
+                 * An entry has at most four candidates, and its first attempt may have been abandoned by the FAST kernel:
+                 * four follow-up launches (d_follow holds four lists of a round's entries: BatchScratch::reserve_pixels; the
+                 * last launch's own list stays empty) */
+                unsigned* fl[5] = {c->bs.d_follow.p, c->bs.d_follow.p + total_px, c->bs.d_follow.p + 2 * total_px, c->bs.d_follow.p + 3 * total_px, c->bs.d_follow.p};
+                unsigned div = 4;
+                for (int k = 0; k < 4; ++k, div *= 4) {
+                    D->optimize(S, 1, std::max(64u, waves / div), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
+                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[k], fcnt + k, fl[k + 1], fcnt + k + 1);
+                    ++n_launch;
+                }
+            } else {
+                D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
+                            c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, c->bs.d_follow.p, fcnt, nullptr, nullptr);
+                ++n_launch;
+            }
         }
         ev.end(S);
         ++n_launch;
@@ -1971,9 +1998,29 @@ void BatchRun::plan_front_team() {
 /* The right to run front teams on a GPU, for as long as the object lives: an exclusive, non-blocking flock on a file
  * named after the GPU's PCI address (the device ordinal differs between processes with different visibility masks).
  * Every attempt opens the file anew, so two calls of one process exclude each other as two processes do.  No file system
- * to put it on, no permission: no token -- the call runs without teams. */
+ * to put it on, no permission, a file that is not what it should be: no token -- the call runs without teams.
+ * The name is predictable and the directory world-writable, so the file is treated as somebody else's: an existing one is
+ * opened READ-ONLY (enough for flock) and never followed if it is a symbolic link, it must be a regular file with one
+ * link (not a hard link to something of the victim's), and its mode is never touched; only a file this process has just
+ * created itself (O_EXCL) gets its mode set -- readable by everybody, so that whoever comes next, another user perhaps,
+ * can take the lock.  What a foreign lock holder can do is keep a GPU's calls from running teams: slower, never wrong. */
 struct TeamToken {
     int fd = -1;
+    static int open_lock(const char* path) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int f = ::open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC | O_NONBLOCK);
+            if (f < 0 && errno == ENOENT) {
+                f = ::open(path, O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0644);
+                if (f < 0 && errno == EEXIST) continue;              /* somebody else created it meanwhile: open theirs */
+                if (f >= 0) (void)::fchmod(f, 0644);                 /* (our own new file: the umask may have taken the read bits) */
+            }
+            if (f < 0) return -1;
+            struct stat sb;
+            if (::fstat(f, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_nlink != 1) { ::close(f); return -1; }
+            return f;
+        }
+        return -1;
+    }
     explicit TeamToken(int device) {
         char bus[64] = {0};
         if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device) != hipSuccess) std::snprintf(bus, sizeof(bus), "dev%d", device);
@@ -1982,8 +2029,7 @@ struct TeamToken {
         for (int d = 0; d < 2 && fd < 0; ++d) {
             char path[160];
             std::snprintf(path, sizeof(path), "%s/mi_dmrecon_team_%s.lock", dirs[d], bus);
-            fd = ::open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
-            if (fd >= 0) (void)::fchmod(fd, 0666);           /* (whoever comes next may be another user) */
+            fd = open_lock(path);
         }
         if (fd >= 0 && ::flock(fd, LOCK_EX | LOCK_NB) != 0) { ::close(fd); fd = -1; }
     }
@@ -2031,6 +2077,23 @@ int BatchRun::front_rounds() {
         /* (a few hundred words from the call's own memory: the stream is idle here, the copy is staged at once) */
         HIP_TRY(hipMemcpyAsync(c->bs.d_front_map.p, front_map.data(), front_grid * sizeof(unsigned), hipMemcpyHostToDevice, S));
     }
+    /* One workgroup per view and more views than the GPU holds front workgroups (one per CU): the launch runs them in waves
+     * and lasts as long as its last workgroup -- the views with the most left to fill go first (they are the ones with the
+     * long fronts: plan_front_team), the short ones fill the CUs that become free.  MI_DMRECON_FRONT_ORDER=0: in index order. */
+    const unsigned* d_order = nullptr;
+    {
+        const char* e = std::getenv("MI_DMRECON_FRONT_ORDER");
+        if ((!e || std::atoi(e) != 0) && nj > 1 && view_filled.size() == (size_t)nj) {
+            front_order.resize((size_t)nj);
+            for (int j = 0; j < nj; ++j) front_order[j] = (unsigned)j;
+            std::stable_sort(front_order.begin(), front_order.end(), [&](unsigned a, unsigned b) {
+                return (long long)jobs[a].w * jobs[a].h - (long long)view_filled[a] > (long long)jobs[b].w * jobs[b].h - (long long)view_filled[b];
+            });
+            if (c->bs.d_front_order.reserve((size_t)nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(front order) failed");
+            HIP_TRY(hipMemcpyAsync(c->bs.d_front_order.p, front_order.data(), (size_t)nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
+            d_order = c->bs.d_front_order.p;
+        }
+    }
     front_stats.assign(4 * (size_t)nj, 0u);
     /* maps of finished views go back while the others run -- the flags in COHERENT page-locked memory (the default kind is
      * cached on the device: a running kernel's stores to it only show when the kernel ends) -- (not for calls with a progress array: a view that is cancelled
@@ -2060,7 +2123,7 @@ int BatchRun::front_rounds() {
                  again ? 1 : front_team, (!again && front_team > 1) ? c->bs.d_front_mail.p : nullptr,
                  (!again && front_team > 1) ? c->bs.d_front_flags.p : nullptr,
                  again ? d_resume : nullptr, again ? d_resume + nj : d_resume, d_filled, spin_ticks, again ? -1 : fault,
-                 std::max(1, c->n_cus / 32), h_done, (!again && front_team > 1) ? c->bs.d_front_map.p : nullptr, front_grid);
+                 std::max(1, c->n_cus / 32), h_done, (!again && front_team > 1) ? c->bs.d_front_map.p : nullptr, front_grid, d_order);
         ev.end(S);
         ++n_launch;
         if (h_done) {
@@ -2669,11 +2732,11 @@ static int mi_dmrecon_pointset_impl(mi_dmrecon_ctx* c, const mi_dmrecon_camera* 
     return 0;
 }
 
-/* test hook (not in the public header): the reference view with this id gets a negative pixel footprint in the calls
+/* test hook (include/mi_dmrecon_debug.h): the reference view with this id gets a negative pixel footprint in the calls
  * that follow (-1: none), see fill_job */
 void mi_dmrecon_debug_inject_footprint(int view_id) { g_inject_footprint.store(view_id); }
 
-/* Test hook (not in the public header): the block map of a front launch with teams (build_front_teams) for n_views views on
+/* Test hook (include/mi_dmrecon_debug.h): the block map of a front launch with teams (build_front_teams) for n_views views on
  * a device of n_cus compute units; map_out gets min(grid, cap) words.  Needs no GPU. */
 int mi_dmrecon_debug_front_teams(int32_t n_views, int32_t n_cus, int32_t want, const int64_t* empty, uint32_t* map_out, int32_t cap,
                                  int32_t* grid_out, int32_t* team_min_out, int32_t* team_max_out) {
@@ -2689,7 +2752,7 @@ int mi_dmrecon_debug_front_teams(int32_t n_views, int32_t n_cus, int32_t want, c
     } catch (std::exception const& ex) { return fail(MI_DMRECON_EDEVICE, "%s", ex.what()); }
 }
 
-/* Test hook (not in the public header): the HOST half of the planning -- global view selection of reference view `ref`,
+/* Test hook (include/mi_dmrecon_debug.h): the HOST half of the planning -- global view selection of reference view `ref`,
  * exactly the code a reconstruct call runs (plan_global_views: from the scene tables, or directly with tables = 0) -- on
  * cameras and features alone, so that it can be checked against the oracle without a GPU.  ms_out (optional): the time
  * of `repeats` selections, the scene tables already built.  n_seeds_out (optional): also the view's seeds. */
@@ -2736,7 +2799,7 @@ int mi_dmrecon_debug_plan_views_host(int32_t n_views, const mi_dmrecon_camera* c
     } catch (std::exception const& e) { return fail(MI_DMRECON_EDEVICE, "%s", e.what()); }
 }
 
-/* test hook (not in the public header): the scratch sets of the context's scene that no call holds at the moment, and the
+/* test hook (include/mi_dmrecon_debug.h): the scratch sets of the context's scene that no call holds at the moment, and the
  * pixel capacity of the largest of them (ScratchLease) */
 int mi_dmrecon_debug_scratch_sets(mi_dmrecon_ctx* c, long long* pixels_max) {
     if (!c) return -1;
@@ -2747,7 +2810,7 @@ int mi_dmrecon_debug_scratch_sets(mi_dmrecon_ctx* c, long long* pixels_max) {
     return (int)c->sc->scratch_pool.size();
 }
 
-/* development aid (not in the public header): the debug buffer of MI_PROBE builds (tools/patch_probe.py).  The first
+/* development aid (include/mi_dmrecon_debug.h): the debug buffer of MI_PROBE builds (tools/patch_probe.py).  The first
  * call allocates `n` words on the device; later calls copy up to n words out and clear the buffer. */
 int mi_dmrecon_debug_buffer(unsigned long long* out, int n) {
     static int cap = 0;
@@ -2769,8 +2832,21 @@ int mi_dmrecon_global_view_selection(mi_dmrecon_ctx* c, const mi_dmrecon_setting
 }
 
 int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* ref_views, mi_dmrecon_maps* maps, mi_dmrecon_progress* progress, int32_t* status_out, mi_dmrecon_stats* stats) {
-    try { return mi_dmrecon_reconstruct_impl(c, st, n_refs, ref_views, maps, progress, status_out, stats); }
-    catch (const std::bad_alloc&) { return fail(MI_DMRECON_EDEVICE, "out of host memory"); }
+    /* the statistics are gathered in an object of THIS build's type and handed over in the size the caller has room for
+     * (mi_dmrecon_stats::struct_size): a caller built against a shorter header is not overrun */
+    mi_dmrecon_stats full;
+    std::memset(&full, 0, sizeof(full));
+    size_t room = 0;
+    if (stats) {
+        if (stats->struct_size < (int64_t)sizeof(int64_t) || stats->struct_size > (int64_t)(1 << 20))
+            return fail(MI_DMRECON_EINVAL, "mi_dmrecon_stats::struct_size must be set to sizeof(mi_dmrecon_stats) before the call");
+        room = std::min((size_t)stats->struct_size, sizeof(full));
+    }
+    int rc;
+    try { rc = mi_dmrecon_reconstruct_impl(c, st, n_refs, ref_views, maps, progress, status_out, stats ? &full : nullptr); }
+    catch (const std::bad_alloc&) { rc = fail(MI_DMRECON_EDEVICE, "out of host memory"); }
+    if (stats) { full.struct_size = (int64_t)room; std::memcpy(stats, &full, room); }
+    return rc;
 }
 
 int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n, const int32_t* xy, const float* hyp, const int32_t* local, int32_t lanes_per_view, float* out, int32_t* out_local) {

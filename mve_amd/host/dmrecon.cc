@@ -248,6 +248,7 @@ private:
             }
         });
         mi_dmrecon_stats stats;
+        stats.struct_size = (int64_t)sizeof(stats);           /* the library fills what this build has room for */
         double const t_call = trace_ms();
         int rc = mi_dmrecon_reconstruct(ex, &batch[0]->st, (int32_t)n, refs.data(), maps.data(), prog.data(), status.data(), &stats);
         std::string msg = rc != 0 ? mi_dmrecon_last_error() : "";

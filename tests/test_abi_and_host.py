@@ -13,8 +13,8 @@ from mve_amd import api
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "mi_dmrecon.h")).read()
+def header_functions(header="mi_dmrecon.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mi_dmrecon_[a-z_]+)\s*\(", src)))
 
@@ -26,6 +26,39 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libmi_dmrecon.so does not export %s" % n
     assert sorted(api.EXPORTS) == names
+
+
+def test_library_exports_nothing_undeclared():
+    """... and nothing else: the dynamic symbols the library defines are exactly the functions of include/mi_dmrecon.h plus
+    the test hooks of include/mi_dmrecon_debug.h (mve_amd/csrc/exports.map keeps launchers, kernel handles and C++ helpers
+    local; a hook nobody declared, or a C++ symbol that slipped out, fails here)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH], text=True)
+    exported = sorted({l.split()[-1].split("@")[0] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in "TDBRW"})
+    hooks = header_functions("mi_dmrecon_debug.h")
+    assert len(hooks) == 5 and all(h.startswith("mi_dmrecon_debug_") for h in hooks)
+    assert exported == sorted(header_functions() + hooks), sorted(set(exported) ^ set(header_functions() + hooks))
+
+
+def test_stats_struct_carries_its_size():
+    """mi_dmrecon_stats::struct_size: the caller says how much room it has, the library never writes beyond it (a caller
+    built against an older, shorter header) -- and an object whose size was never set is refused.  No GPU needed: the
+    argument check comes first."""
+    L = api.load_library()
+    st = api.Settings().to_c()
+    stats = api.CStats()                                       # struct_size = 0: never initialised
+    refs = np.zeros(1, np.int32)
+    maps = (api.CMaps * 1)()
+    rc = L.mi_dmrecon_reconstruct(None, ctypes.byref(st), 1, refs.ctypes.data_as(ctypes.c_void_p), maps, None, None, ctypes.byref(stats))
+    assert rc == api.E_INVAL and b"struct_size" in L.mi_dmrecon_last_error()
+    # a short object (the first 16 fields of an "older header") followed by a canary: the canary survives the call
+    buf = (ctypes.c_int64 * 32)(*([0x5A5A5A5A5A5A5A5A] * 32))
+    buf[0] = 16 * 8
+    rc = L.mi_dmrecon_reconstruct(None, ctypes.byref(st), 1, refs.ctypes.data_as(ctypes.c_void_p), maps, None, None,
+                                  ctypes.cast(buf, ctypes.POINTER(api.CStats)))
+    assert rc != 0                                             # (null context: the call itself fails ...)
+    assert buf[0] == 16 * 8 and all(buf[i] == 0 for i in range(1, 16))       # ... its statistics are zeros, in the caller's size
+    assert all(buf[i] == 0x5A5A5A5A5A5A5A5A for i in range(16, 32))
 
 
 def header_struct(name):

@@ -321,7 +321,7 @@ def test_team_token_is_exclusive_per_gpu(gpu_ctx, g1_scene, monkeypatch):
     assert gpu_ctx.last_stats["front_team"] > 1
     locks = glob.glob("/dev/shm/mi_dmrecon_team_*.lock") + glob.glob("/tmp/mi_dmrecon_team_*.lock")
     assert locks, "the team launch above must have created its lock file"
-    held = [open(p, "r+") for p in locks]
+    held = [open(p, "r") for p in locks]                # (read-only is enough for flock, and all the library itself asks for)
     for f in held:
         fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)        # free again after the call: the lock is per front launch
     got = gpu_ctx.reconstruct(api.Settings(), [0, 1, 2, 3, 4])
