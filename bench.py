@@ -134,7 +134,7 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
+def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None, global_views=None):
     """The reference CPU path timed on this box's host cores on a bounded sample of the same workload.
     With gpu_maps (the HIP path's depth / conf maps of the same views) the reference's own output -- which this
     leg produces anyway -- is read back and diffed: the `parity` object of the JSON line."""
@@ -143,16 +143,34 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
     p, s, k = cfg["params"], cfg["scale"], cfg["local_neighbors"]
     # (a scene of gigabytes -- C5: 100 x 36.6 MB -- is not written to disk as PNGs for the reference binary inside a
     # bench run: the restatement on one view stands in, `kind` says so)
-    if os.path.exists(ref_exe) and sum(im.nbytes for im in scene.images) < (1 << 30):
-        from mve_amd.scene_io import read_mvei, view_dir, write_scene
-        n_sample = max(1, min(cores, p.n_views))
+    big = sum(im.nbytes for im in scene.images) >= (1 << 30)
+    if os.path.exists(ref_exe) and (not big or global_views is not None):
+        from mve_amd.scene_io import SceneData, read_mvei, view_dir, write_scene
         work = tempfile.mkdtemp(prefix="bench_ref_")
         try:
             sdir = os.path.join(work, "scene")
-            write_scene(sdir, scene)
+            if not big:
+                n_sample = max(1, min(cores, p.n_views))
+                sample = list(range(n_sample))
+                write_scene(sdir, scene)
+                which = "views 0-%d" % (n_sample - 1)
+            else:
+                # a scene of gigabytes (C5: 100 x 36.6 MB): a bounded sample -- the first, the middle and the last reference
+                # view -- and on disk only the images the reference will read for them: the sample's global view sets (the
+                # library's selection, which is the reference's: tests; a view without its image is no candidate for the
+                # reference, dmrecon.cc:62-79, and a greedy selection does not change when never-selected candidates are
+                # missing), stored uncompressed (.mvei) so that neither side spends its time in a PNG codec
+                sample = sorted(set([0, p.n_views // 2, p.n_views - 1]))
+                need = set(sample)
+                for v in sample:
+                    need.update(int(g) for g in global_views(v))
+                sub = SceneData(scene.cameras, [im if i in need else None for i, im in enumerate(scene.images)], scene.features)
+                write_scene(sdir, sub, raw=True)
+                n_sample = len(sample)
+                which = "views %s (on disk: the %d images of their global view sets, uncompressed)" % (sample, len(need))
             env = dict(os.environ, OMP_NUM_THREADS=str(cores))
             cmd = [ref_exe, "-s%d" % s, "--local-neighbors=%d" % k, "--force", "--progress=silent", "--keep-conf",
-                   "--list-view=0-%d" % (n_sample - 1), sdir]
+                   "--list-view=%s" % ",".join(str(v) for v in sample), sdir]
             t0 = time.time()
             out = subprocess.run(cmd, check=True, env=env, capture_output=True, text=True).stdout
             wall = time.time() - t0
@@ -165,23 +183,24 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
             base = {"value": n_sample / t, "unit": "depth-maps/s", "cores": min(cores, n_sample), "kind": "reference",
                     "cpu_quota": quota,
                     "sample": "unmodified apps/dmrecon (oracle/_ref/dmrecon_ref_fast: -O3 -march=x86-64-v3 "
-                              "-funsafe-math-optimizations, OpenMP over views) on views 0-%d of the same scene at scale %d; "
-                              "time = the app's own 'Reconstruction took' (%.1f s, includes its PNG decode + pyramid); "
+                              "-funsafe-math-optimizations, OpenMP over views) on %s of the same scene at scale %d; "
+                              "time = the app's own 'Reconstruction took' (%.1f s, includes its image decode + pyramid); "
                               "%d host cores visible%s, one thread per view" % (
-                                  n_sample - 1, s, t, cores,
+                                  which, s, t, cores,
                                   "" if quota is None else " (the container's CPU quota: the time of %.0f)" % quota)}
             parity = None
             if gpu_maps is not None:
                 ref_maps = [(read_mvei(os.path.join(view_dir(sdir, v), "depth-L%d.mvei" % s)),
-                             read_mvei(os.path.join(view_dir(sdir, v), "conf-L%d.mvei" % s))) for v in range(n_sample)]
-                against = "the reference's own depth-L%d / conf-L%d of views 0-%d (the cpu_baseline run), this run" % (s, s, n_sample - 1)
-                parity = map_parity_all(gpu_maps[:n_sample], ref_maps, against)
+                             read_mvei(os.path.join(view_dir(sdir, v), "conf-L%d.mvei" % s))) for v in sample]
+                against = "the reference's own depth-L%d / conf-L%d of %s (the cpu_baseline run), this run" % (s, s, which.split(" (")[0])
+                bounds = parity_bounds(cfg.get("name", ""))
+                parity = map_parity_all([gpu_maps[v] for v in sample], ref_maps, against, bounds, sample)
                 parity["which"] = "maps of the first timed call"
                 if gpu_maps_last is not None:
-                    pl = map_parity_all(gpu_maps_last[:n_sample], ref_maps, against)
+                    pl = map_parity_all([gpu_maps_last[v] for v in sample], ref_maps, against, bounds, sample)
                     parity["last_timed_call"] = {k: pl[k] for k in ("min_fill_iou", "max_rel_depth_median", "max_rel_depth_p99", "max_conf_abs_p99", "within_bounds")}
                     parity["last_timed_call"]["bit_identical_to_first"] = bool(all(
-                        np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(gpu_maps[:n_sample], gpu_maps_last[:n_sample])))
+                        np.array_equal(gpu_maps[v][0], gpu_maps_last[v][0]) and np.array_equal(gpu_maps[v][1], gpu_maps_last[v][1]) for v in sample))
                     parity["within_bounds"] = bool(parity["within_bounds"] and pl["within_bounds"])
             return base, parity
         finally:
@@ -197,13 +216,11 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
     if gpu_maps is not None:
         against = "oracle restatement (bit-identical to the reference build on every fixture), views %s, this run" % sample
         ref_maps = [(o["depth"], o["conf"]) for o in outs]
-        cb = CONF_P99_BOUND.get(cfg.get("name", ""), 5e-3)
-        parity = map_parity_all([gpu_maps[v] for v in sample], ref_maps, against, cb)
+        cb = parity_bounds(cfg.get("name", ""))
+        parity = map_parity_all([gpu_maps[v] for v in sample], ref_maps, against, cb, sample)
         parity["which"] = "maps of the first timed call"
-        if cb != 5e-3:
-            parity["conf_bound_note"] = "the reference algorithm against itself in reversed queue order on this scene: conf p99 7.8e-3 (view 0), 6.0e-3 (view 50): profiles/r4_c5_order_floor.json"
         if gpu_maps_last is not None:
-            pl = map_parity_all([gpu_maps_last[v] for v in sample], ref_maps, against, cb)
+            pl = map_parity_all([gpu_maps_last[v] for v in sample], ref_maps, against, cb, sample)
             parity["last_timed_call"] = {kk: pl[kk] for kk in ("min_fill_iou", "max_rel_depth_median", "max_rel_depth_p99", "max_conf_abs_p99", "within_bounds")}
             parity["last_timed_call"]["bit_identical_to_first"] = bool(all(
                 np.array_equal(gpu_maps[v][0], gpu_maps_last[v][0]) and np.array_equal(gpu_maps[v][1], gpu_maps_last[v][1]) for v in sample))
@@ -213,19 +230,41 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None):
                       "the reference binary needs the scene on disk as PNGs: not written for a scene of gigabytes)" % (sample, t)}, parity
 
 
-# The confidence bound of the largest config: the reference ALGORITHM against itself with its queue popped worst-first (the
-# same restatement, ORC_QUEUE_ORDER=reverse) on views 0 / 50 of the C5 scene differs by conf p99 7.8e-3 / 6.0e-3 (relative
-# depth p99 2.6e-3 / 2.3e-3, fill IoU 0.9999 / 0.9995; profiles/r4_c5_order_floor.json): 5e-3 is below the algorithm's own
-# order sensitivity there
-CONF_P99_BOUND = {"C5": 1e-2}
+def parity_bounds(config_name):
+    """The map-level bounds of a configuration and where each comes from.  Relative depth median <= 1e-3 / p99 <= 5e-3 and
+    confidence p99 <= 5e-3 are the tolerances of tests/test_gpu_parity.py; fill IoU >= 0.98 is SURVEY 8c's.  Where the
+    reference ALGORITHM does not reach such a figure against itself -- the restatement with its queue popped in another
+    order: reversed, random, the reference's order with other tie-breaks -- the bound is that measured floor with a margin
+    (tests/golden/order_floor_<config>.json, written by tools/order_floor.py from the CPU restatement; C5:
+    profiles/r4_c5_order_floor.json): a parallel sweep is one more re-ordering of the same algorithm and cannot be asked to be
+    closer to the reference than the reference's own orders are to each other."""
+    b = {"fill_iou": 0.98, "rel_depth_median": 1e-3, "rel_depth_p99": 5e-3, "conf_abs_p99": 5e-3, "sources": {}}
+    f = os.path.join(ROOT, "tests", "golden", "order_floor_%s.json" % config_name.lower())
+    if os.path.exists(f):
+        j = json.load(open(f))
+        # per view: SURVEY's 0.98, or -- where the reference algorithm's own orders fall below it -- their minimum - 0.002
+        per_view = {int(v): min(0.98, float(x) - 0.002) for v, x in j["worst"]["iou"].items()}
+        b["fill_iou_per_view"] = per_view
+        b["fill_iou"] = round(min(per_view.values()), 4)
+        low = sorted(v for v, x in per_view.items() if x < 0.98)
+        b["sources"]["fill_iou"] = ("per view min(0.98, floor - 0.002), floor = the reference algorithm (CPU restatement) against itself: the "
+                                    "minimum over %d alternative queue orders (%s), tests/golden/%s; below 0.98 on views %s"
+                                    % (len(j["orders"]), ", ".join(j["orders"]), os.path.basename(f), low))
+        for key, src in (("conf_abs_p99", "max_conf_abs_p99"), ("rel_depth_p99", "max_rel_depth_p99")):
+            if 1.5 * float(j[src]) > b[key]:
+                b[key] = round(1.5 * float(j[src]), 5)
+                b["sources"][key] = "1.5 x the reference algorithm's own order sensitivity (%.2e over those orders, worst view)" % float(j[src])
+    elif config_name == "C5":
+        # the restatement against itself with its queue reversed on views 0 / 50 of the C5 scene: confidence p99 7.8e-3 /
+        # 6.0e-3 (tools/c5_order_floor.py -> profiles/r4_c5_order_floor.json)
+        b["conf_abs_p99"] = 1e-2
+        b["sources"]["conf_abs_p99"] = "the reference algorithm against itself in reversed queue order on this scene: conf p99 7.8e-3 (view 0), 6.0e-3 (view 50): profiles/r4_c5_order_floor.json"
+    return b
 
 
-def map_parity_all(gpu, ref, against, conf_p99_bound=5e-3):
-    """Worst case over the views of the map-level parity metrics.  Bounds: relative depth median <= 1e-3 / p99 <= 5e-3,
-    confidence p99 <= 5e-3 (tests/test_gpu_parity.py), fill-mask IoU >= 0.96 at this size: which pixels of the strips
-    along the top / bottom image border get a depth depends on which local view set reaches the strip first -- the
-    reference algorithm against ITSELF with its queue popped worst-first gives IoU 0.9713 on view 12 and 0.9850 on view
-    8 of this scene (the same strips), everywhere else the masks agree to 0.999."""
+def map_parity_all(gpu, ref, against, bounds, view_ids=None):
+    """Worst case over the views of the map-level parity metrics against `bounds` (parity_bounds: every bound with its source;
+    the fill mask per view where the bounds are per view)."""
     iou, med, p99, cp99, n = [], [], [], [], 0
     for (gd, gc), (rd, rc) in zip(gpu, ref):
         rd = np.asarray(rd, np.float32).reshape(gd.shape)
@@ -237,13 +276,16 @@ def map_parity_all(gpu, ref, against, conf_p99_bound=5e-3):
         med.append(float(np.median(rel))); p99.append(float(np.percentile(rel, 99)))
         cp99.append(float(np.percentile(np.abs(gc[both] - rc[both]), 99)))
         n += 1
-    ok = min(iou) >= 0.96 and max(med) <= 1e-3 and max(p99) <= 5e-3 and max(cp99) <= conf_p99_bound
+    pv = bounds.get("fill_iou_per_view")
+    ids = list(view_ids) if view_ids is not None else list(range(n))
+    iou_ok = all(v >= (pv.get(i, bounds["fill_iou"]) if pv else bounds["fill_iou"]) for i, v in zip(ids, iou))
+    ok = (iou_ok and max(med) <= bounds["rel_depth_median"] and max(p99) <= bounds["rel_depth_p99"]
+          and max(cp99) <= bounds["conf_abs_p99"])
     return {"against": against, "views": n, "min_fill_iou": min(iou), "fill_iou_per_view": [round(v, 4) for v in iou],
             "max_rel_depth_median": max(med),
             "max_rel_depth_p99": max(p99), "max_conf_abs_p99": max(cp99),
-            "bounds": {"fill_iou": 0.96, "rel_depth_median": 1e-3, "rel_depth_p99": 5e-3, "conf_abs_p99": conf_p99_bound},
-            "reference_vs_itself_reversed_queue": {"fill_iou_view12": 0.9713, "fill_iou_view8": 0.9850,
-                                                   "rel_depth_p99": 2.8e-3, "conf_abs_p99": 4.9e-3},
+            "bounds": {k: ([round(v[i], 4) for i in sorted(v)] if k == "fill_iou_per_view" else v) for k, v in bounds.items() if k != "sources"},
+            "bound_sources": bounds.get("sources", {}),
             "within_bounds": bool(ok)}
 
 
@@ -258,7 +300,10 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1, n_keep=None):
     a step."""
     import threading
     n_streams = len(ctxs)
-    outs = [c.alloc_outputs(st, refs, want_normal=False, pinned=True) for c in ctxs]   # reused, page-locked
+    # refs: the reference views of every call, or a function (host thread, call number of that thread) -> views (all calls
+    # the same number of views of the same size: the distinct-scenes variant walks through its scenes)
+    refs_of = refs if callable(refs) else (lambda i, k: refs)
+    outs = [c.alloc_outputs(st, refs_of(i, 0), want_normal=False, pinned=True) for i, c in enumerate(ctxs)]   # reused, page-locked
     share = [n_calls // n_streams + (1 if i < n_calls % n_streams else 0) for i in range(n_streams)]
     acc, last, t_calls, done_at = {}, {}, [0.0] * n_streams, [0.0] * n_streams
     t_go = [0.0]
@@ -267,16 +312,16 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1, n_keep=None):
     go, fin = threading.Barrier(n_streams + 1), threading.Barrier(n_streams + 1)
 
     def worker(i, c, o, n):
-        for _ in range(max(warmup, 1)):
+        for w in range(max(warmup, 1)):
             tw = time.perf_counter()
-            c.reconstruct(st, refs, want_normal=False, out=o)
+            c.reconstruct(st, refs_of(i, w), want_normal=False, out=o)
             t_calls[i] = time.perf_counter() - tw
         warmed.wait()
         for rep in range(repeats):
             go.wait()
             # (no phase offsets: every host thread starts at once; calls that meet inside the library are merged)
-            for _ in range(n):
-                r = c.reconstruct(st, refs, want_normal=False, out=o)   # synchronous: returns with the maps on the host
+            for k in range(n):
+                r = c.reconstruct(st, refs_of(i, k), want_normal=False, out=o)   # synchronous: returns with the maps on the host
                 with lock:
                     if "res" not in last:
                         # (the first n_keep maps of the first timed call: a few milliseconds inside the FIRST region only)
@@ -490,6 +535,54 @@ def run_one_call(ctx, st, views, scene, cfg, n_timed=50):
             "frac": roof["frac"], "frac_on_passes": roof["frac_on_passes"]}
 
 
+def run_distinct_scenes(coll, device, cfg, st, n_scenes, spc, n_calls, n_streams, warmup, repeats):
+    """The headline's plan on DISTINCT data: the timed steps walk through `n_scenes` differently seeded scenes (cameras,
+    texture and features of their own, same size and settings), all resident in one context -- a region of 20 steps = 400
+    depth maps of 20 scenes, where the headline reconstructs the same 20 views twenty times (its images: a 200 MB hot set
+    that every one of the 400 concurrent jobs shares).  Step s of a region is scene s mod n_scenes.  The scenes are rendered
+    on the GPU (mve_amd/csrc/synth_render_gpu.hip: harness code) -- 20 scenes on the box's CPU quota would take 100 s."""
+    import dataclasses
+    from mve_amd.synth import merge_scenes
+    p = cfg["params"]
+    t0 = time.perf_counter()
+    scenes = [make_scene(dataclasses.replace(p, texture_seed=p.texture_seed + 31 * k, camera_seed=p.camera_seed + 17 * k,
+                                             feature_seed=p.feature_seed + 13 * k), gpu=True) for k in range(n_scenes)]
+    big = merge_scenes(scenes)
+    t_render = time.perf_counter() - t0
+    ctx = api.Context(device)
+    t0 = time.perf_counter()
+    ctx.load_scene(big, pinned_staging=True)
+    t_stage = time.perf_counter() - t0
+    ctxs = [ctx] + [ctx.fork() for _ in range(n_streams - 1)]
+    share = [n_calls // n_streams + (1 if i < n_calls % n_streams else 0) for i in range(n_streams)]
+    first = [sum(share[:i]) for i in range(n_streams)]            # the region's steps in thread order: thread i holds calls first[i] ...
+
+    def refs_of(i, k):
+        out = []
+        for s_ in range(spc):
+            sc = ((first[i] + k) * spc + s_) % n_scenes
+            out += list(range(sc * p.n_views, (sc + 1) * p.n_views))
+        return out
+    el, acc, last = timed_region(coll, ctxs, st, refs_of, n_calls, warmup, repeats=repeats, n_keep=p.n_views)
+    n_maps = p.n_views * spc * n_calls
+    fill = float(np.mean([(c > 0).mean() for _, c in last["res"]]))
+    ms_bulk = acc.get("ms_bulk_kernel", 0.0)
+    bulk_stats = {"n_eval": acc.get("n_eval_bulk", 0), "n_patch": acc.get("n_patch_bulk", 0), "n_filled": acc.get("n_filled_bulk", 0)}
+    b_bulk = algorithmic_bytes(bulk_stats, n_maps * len(el), big, cfg)
+    for c in ctxs[1:]:
+        c.close()
+    ctx.close()
+    return {"scenes": n_scenes, "value": n_maps / float(np.median(el)), "unit": "depth-maps/s", "repeats": [n_maps / e for e in el],
+            "what": "the same call plan, every step a different one of %d differently seeded scenes (step s = scene s mod %d), "
+                    "all %d views resident in one context" % (n_scenes, n_scenes, big.n_views),
+            "resident_host_image_GB": sum(im.nbytes for im in big.images) / 1e9,
+            "render_seconds_gpu": t_render, "staging_seconds": t_stage, "mean_fill_first_call": round(fill, 4),
+            "bulk_kernel_frac": (b_bulk / (ms_bulk / 1e3) / 1e9 / HBM_PEAK_GBS) if ms_bulk > 0 else None,
+            "ms_bulk_kernel_per_step": ms_bulk / max(1, n_maps * len(el) // p.n_views),
+            "ms_front_kernel_per_step": acc.get("ms_front_kernel", 0.0) / max(1, n_maps * len(el) // p.n_views),
+            "calls_per_library_batch_by_region": last.get("batch_shapes", [])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -503,6 +596,9 @@ def main():
                          "times in the same process; `value` is the median region, `repeats` lists them all")
     ap.add_argument("--one-call-n", type=int, default=50, help="library calls behind the `one_call` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct-scenes", type=int, default=-1,
+                    help="after the timed regions, the same plan once more on this many differently seeded scenes "
+                         "(config.distinct_scenes_variant); -1 = 20 for config C3 on one GPU, else none; 0 = none")
     ap.add_argument("--no-one-call", action="store_true",
                     help="skip the `one_call` object (one 20-view library call on one host thread, measured after the timed region)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -535,7 +631,9 @@ def main():
     coll = Collective("gloo" if share_gpu else "nccl", local_rank)
 
     t0 = time.perf_counter()
-    scene = make_scene(p)                                   # synthetic, deterministic, identical on every rank
+    # synthetic, deterministic, identical on every rank; the large configuration (C5: 100 x 12 MP) is rendered on the GPU
+    # (harness code, mve_amd/csrc/synth_render_gpu.hip: 87 s on the box's CPU quota otherwise)
+    scene = make_scene(p, gpu=(p.n_views * p.width * p.height > 400e6))
     t_render = time.perf_counter() - t0
     ctx = api.Context(local_rank)
     # upload + device pyramid: inputs resident in HBM before any timed region starts.  Timed by itself (`staging`): images
@@ -584,6 +682,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_one_call:
         one_call = run_one_call(ctx, st, all_views, scene, cfg, n_timed=max(1, args.one_call_n))
 
+    distinct = None
+    n_distinct = args.distinct_scenes if args.distinct_scenes >= 0 else (20 if (args.config == "C3" and world == 1) else 0)
+    if rank == 0 and world == 1 and n_distinct > 0:
+        distinct = run_distinct_scenes(coll, local_rank, cfg, st, n_distinct, spc, n_calls, n_streams, min(args.warmup, 2), max(1, min(args.repeats, 3)))
+
     if rank == 0:
         res = last["res"]
         shape = last["shape"]
@@ -615,7 +718,10 @@ def main():
                        "library_batch_log": last.get("batches", [])[:16],
                        # calls per library batch in every timed region (same order as `repeats`)
                        "calls_per_library_batch_by_region": last.get("batch_shapes", []),
-                       "mean_fill": round(fill, 4)},
+                       "mean_fill": round(fill, 4),
+                       # what `value` batches: every timed step reconstructs the SAME scene's reference views (one resident
+                       # scene: a saturated-throughput figure whose concurrent jobs share one image set) ...
+                       "distinct_scenes": 1},
             "roofline": roof,
             # the scene's way into HBM, timed by itself before the timed regions (never part of `value`): host images ->
             # page-locked staging -> PCIe -> RGBA pack, pyramid and footprint records on the device
@@ -629,6 +735,11 @@ def main():
             out["per_rank_ms_per_step"] = 1000.0 * elapsed / args.steps
         if one_call is not None:
             out["one_call"] = one_call
+            # ... what ONE scene reconstructed once gets (a user of apps/dmrecon): the `one_call` object's rate
+            out["config"]["single_scene_value"] = one_call["depth_maps_per_s"]
+        if distinct is not None:
+            # ... and the same plan on distinct data: every step another scene
+            out["config"]["distinct_scenes_variant"] = distinct
         if strong is not None:
             out["strong_scaling"] = strong
         if args.config == "C3":
@@ -639,7 +750,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # the maps of the FIRST timed call (first region) and of the LAST one (last region) against the reference's
             last_maps = last.get("res_last", res)
-            out["cpu_baseline"], parity = cpu_baseline(scene, cfg, gpu_maps=res[:p.n_views], gpu_maps_last=last_maps[:p.n_views])
+            out["cpu_baseline"], parity = cpu_baseline(scene, cfg, gpu_maps=res[:p.n_views], gpu_maps_last=last_maps[:p.n_views],
+                                                       global_views=lambda v: ctx.global_view_selection(st, v))
             if parity is not None:
                 out["parity"] = parity
     coll.barrier()

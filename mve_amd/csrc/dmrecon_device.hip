@@ -164,6 +164,74 @@ template <> struct ViewPack<8> { typedef unsigned long long type; static constex
 template <int LPV, int NV> struct Lay;
 
 /* ---- four view slots (nrReconNeighbors <= 4, the reference's default) */
+#ifdef MI_TRANSPOSED
+/*
+ * The throughput layout with the lanes TRANSPOSED: lane = view slot * 16 + patch instead of patch * 4 + view slot.  The same
+ * 16 patches x 4 view slots, the same arithmetic in the same order -- the sums over the view slots run (v0 + v1) + (v2 + v3)
+ * in both, so the maps are the same bits -- but the 16 lanes of a DPP row now gather from ONE neighbour image, at the
+ * positions of 16 patches that lie within a few pixels of each other (k_generate emits a wavefront's entries sub-tile by
+ * sub-tile): consecutive lanes ask for records that are neighbours in memory, where the quad layout put four different
+ * images side by side (no two consecutive lanes ever shared a cache line, and the texture path looked 64 lines up per
+ * gather).  What the quad layout did with DPP quad permutes -- the exchanges across the view slots of a patch: two to nine
+ * sums per pass, a few ballots per turn -- crosses DPP rows here: v_permlane16_swap / v_permlane32_swap (gfx950), or an LDS
+ * permute (-DMI_T_SHFL).
+ */
+#ifdef MI_T_SHFL
+__device__ __forceinline__ int x16(int v) { return __shfl_xor(v, 16); }
+__device__ __forceinline__ int x32(int v) { return __shfl_xor(v, 32); }
+#else
+/* v_permlane16_swap_b32 vdst, src: the odd rows of vdst and the even rows of src change places; with both = v the partner
+ * row's value arrives in the second result for the even rows (0, 2) and in the first for the odd rows (1, 3) */
+__device__ __forceinline__ int x16(int v) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 16u) ? r[0] : r[1]);
+}
+/* v_permlane32_swap_b32 vdst, src: the upper half of vdst and the lower half of src change places */
+__device__ __forceinline__ int x32(int v) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 32u) ? r[0] : r[1]);
+}
+#endif
+template <> struct Lay<1, 4> {
+    static constexpr int LPV = 1, NV = 4, PATCHES = 16;
+    static constexpr bool LAT = false;
+    __device__ static __forceinline__ int vslot(int lane) { return lane >> 4; }
+    __device__ static __forceinline__ int sub(int) { return 0; }
+    __device__ static __forceinline__ int patch(int lane) { return lane & 15; }
+    __device__ static __forceinline__ float view_sum(float v) { return v; }
+    __device__ static __forceinline__ double view_sum(double v) { return v; }
+    __device__ static __forceinline__ bool view_all(bool p) { return p; }
+    __device__ static __forceinline__ float patch_sum(float v) {
+        v = fadd_i(v, x16(__float_as_int(v)));              /* v0 + v1 | v2 + v3 */
+        v = fadd_i(v, x32(__float_as_int(v)));              /* (v0 + v1) + (v2 + v3) */
+        return v;
+    }
+    __device__ static __forceinline__ double patch_sum(double v) {
+        v += dmov(v, x16);
+        v += dmov(v, x32);
+        return v;
+    }
+    __device__ static __forceinline__ unsigned long long patch_or(unsigned long long v) {
+        v |= dmov_u(v, x16); v |= dmov_u(v, x32);
+        return v;
+    }
+    __device__ static __forceinline__ float wave_sum(float v) { return v; }      /* unused in this layout */
+    /* out[k] = v of view slot k of my patch: mine, and my partners' across 16, 32 and 48 lanes */
+    __device__ static __forceinline__ void from_views(int v, int lane, int* out) {
+        const int a = x16(v), b = x32(v), c = x32(a);
+        const int s = lane >> 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = (k == s) ? v : (k == (s ^ 1)) ? a : (k == (s ^ 2)) ? b : c;
+    }
+    template <int S> __device__ static __forceinline__ int view_xor(int v) { return S == 0 ? x16(v) : x32(v); }
+    /* bit k = predicate of view slot k of my patch */
+    __device__ static __forceinline__ unsigned view_ballot(bool p, int lane) {
+        const unsigned long long r = __ballot(p) >> (lane & 15);
+        return (unsigned)((r & 1ull) | ((r >> 15) & 2ull) | ((r >> 30) & 4ull) | ((r >> 45) & 8ull));
+    }
+    __device__ static __forceinline__ unsigned rows_to_lane0(unsigned v) { return v; }
+};
+#else
 template <> struct Lay<1, 4> {
     static constexpr int LPV = 1, NV = 4, PATCHES = 16;
     static constexpr bool LAT = false;
@@ -202,6 +270,7 @@ template <> struct Lay<1, 4> {
     /* per-view counters of the wavefront's one patch summed into lane 0 (latency layouts only) */
     __device__ static __forceinline__ unsigned rows_to_lane0(unsigned v) { return v; }
 };
+#endif
 
 template <> struct Lay<16, 4> {
     static constexpr int LPV = 16, NV = 4, PATCHES = 1;

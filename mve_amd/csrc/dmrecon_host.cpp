@@ -72,6 +72,23 @@ int fail(int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                                       \
     } while (0)
 
+/* Host threads a planning loop may use: the cores the process can actually run on -- a container may show 256 cores to
+ * omp_get_num_procs() and give the process tree the CPU time of 16 (cgroup cpu.max: the GPU boxes of this project) --, at
+ * most 64.  Read once. */
+int host_threads_cap() {
+    static const int cap = [] {
+        int n = std::max(1, omp_get_num_procs());
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                 /* cgroup v2: "<quota> <period>" or "max <period>" */
+            char q[32] = {0}; double per = 0.0;
+            if (std::fscanf(f, "%31s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0.0)
+                n = std::min(n, std::max(1, (int)std::ceil(std::atof(q) / per)));
+            std::fclose(f);
+        }
+        return std::min(n, 64);
+    }();
+    return cap;
+}
+
 /* ---- small float helpers with the accumulation order of libs/math (vector.h:434-458,542-551;
  *      matrix.h:475-493): left-to-right sums starting from T(0). */
 /* Waiting for the GPU.  A blocking hipStreamSynchronize / hipEventSynchronize puts the thread to sleep and the wake-up can
@@ -375,6 +392,10 @@ struct SceneStore {
     std::vector<HostView> views;
     std::vector<Feature> features;
     std::vector<int> feat_refs;
+    /* the features every view is referenced by, ascending (the bundle's view lists inverted; built with the features):
+     * a reference view's seed candidates are the features of itself and of its global views -- the union of a few of
+     * these lists -- instead of a scan of every feature of the scene */
+    std::vector<int> by_view_off, by_view;
     bool views_dirty = true;
     DevBuf<DevView> d_views;
     float* d_lut = nullptr;
@@ -396,6 +417,7 @@ struct mi_dmrecon_ctx {
     int n_cus = 64;                          /* compute units (queried at creation) */
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;           /* copies of finished views back to the host while the front kernel still runs */
+    hipStream_t stream3 = nullptr;           /* ... a second one: the views alternate, two copy engines at work */
     std::shared_ptr<SceneStore> sc;
     DevCounters* d_counters = nullptr;
     DevBuf<uint8_t> d_stage;
@@ -494,7 +516,7 @@ void build_scene_geom(SceneStore& sc) {
     g.zcam.assign(nv * nf, 0.f);
     /* unit directions camera -> feature (parallax(), mvs_tools.h:46-56), only needed while building */
     std::vector<V3> dir(nv * nf);
-    const int nt = std::max(1, std::min(omp_get_num_procs(), 32));
+    const int nt = std::max(1, std::min(host_threads_cap(), 32));
 #pragma omp parallel for schedule(static) num_threads(nt)
     for (long f = 0; f < (long)nf; ++f) {
         Feature const& ft = sc.features[f];
@@ -535,7 +557,7 @@ std::shared_ptr<const SceneGeom::PairFactors> scene_pair_factors(SceneStore& sc,
     const float* pl = g.plx.data();
     float* out = tab->f.data();
     const long n = (long)g.plx.size();
-    const int nt = std::max(1, std::min(omp_get_num_procs(), 16));
+    const int nt = std::max(1, std::min(host_threads_cap(), 16));
 #pragma omp parallel for schedule(static) num_threads(nt) if (n > (1 << 20))
     for (long k = 0; k < n; ++k) {
         /* (written without a branch so that the loop vectorises: the value where plx < minP, the bits of 1.0f elsewhere) */
@@ -933,6 +955,22 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
 }
 
 /* The host half of DMRecon::processFeatures (dmrecon.cc:258-296): feature -> (pixel, initDepth) */
+/* by_view / by_view_off of a scene's features (SceneStore) */
+void build_features_by_view(SceneStore& sc) {
+    int max_id = -1;
+    for (int v : sc.feat_refs) max_id = std::max(max_id, v);
+    sc.by_view_off.assign((size_t)(max_id + 2), 0);
+    for (int v : sc.feat_refs) if (v >= 0) ++sc.by_view_off[(size_t)v + 1];
+    for (size_t v = 1; v < sc.by_view_off.size(); ++v) sc.by_view_off[v] += sc.by_view_off[v - 1];
+    sc.by_view.assign(sc.feat_refs.size(), 0);
+    std::vector<int> fill(sc.by_view_off.begin(), sc.by_view_off.end());
+    for (size_t f = 0; f < sc.features.size(); ++f)
+        for (int j = sc.features[f].ref_begin; j < sc.features[f].ref_end; ++j) {
+            const int v = sc.feat_refs[j];
+            if (v >= 0) sc.by_view[(size_t)fill[v]++] = (int)f;                 /* (features in ascending order per view) */
+        }
+}
+
 void plan_seeds(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost& job, int job_index) {
     HostView const& R = c->sc->views[job.ref_view];
     HostLevel const& L = R.levels[st->scale];
@@ -941,13 +979,30 @@ void plan_seeds(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost& job, 
     SceneGeom const& G = c->sc->geom;
     const bool tab = G.built && G.has_plx && G.refs.size() == G.nv * G.nf && G.nf == c->sc->features.size();
     const size_t nf = c->sc->features.size();
-    for (size_t i = 0; i < nf; ++i) {
+    /* without the tables (a scene too large for them): the candidates are the features the reference view or one of its
+     * global views is referenced by (dmrecon.cc:262-270: useFeature), in the order of the bundle -- the union of their
+     * by-view lists instead of a scan of every feature's view list for every one of those views */
+    std::vector<int> cand;
+    const bool by_view = !tab && c->sc->by_view_off.size() > 1;
+    if (by_view) {
+        auto add = [&](int v) {
+            if (v < 0 || (size_t)v + 1 >= c->sc->by_view_off.size()) return;
+            cand.insert(cand.end(), c->sc->by_view.begin() + c->sc->by_view_off[v], c->sc->by_view.begin() + c->sc->by_view_off[(size_t)v + 1]);
+        };
+        add(job.ref_view);
+        for (size_t g = 0; g < job.global.size(); ++g) add(job.global[g]);
+        std::sort(cand.begin(), cand.end());
+        cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+    }
+    const size_t n_iter = by_view ? cand.size() : nf;
+    for (size_t it = 0; it < n_iter; ++it) {
+        const size_t i = by_view ? (size_t)cand[it] : it;
         Feature const& f = c->sc->features[i];
-        bool use;
+        bool use = by_view;
         if (tab) {
             use = (size_t)job.ref_view < G.nv && G.refs[(size_t)job.ref_view * nf + i];
             for (size_t g = 0; !use && g < job.global.size(); ++g) use = G.refs[(size_t)job.global[g] * nf + i] != 0;
-        } else {
+        } else if (!by_view) {
             use = contains_view(c, f, job.ref_view);
             for (size_t g = 0; !use && g < job.global.size(); ++g)
                 if (contains_view(c, f, job.global[g])) use = true;
@@ -1092,8 +1147,13 @@ static int create_streams(mi_dmrecon_ctx* c) {
      * PCIe, in the two regions out of five that such a context led).  Streams of another priority have queues of their own. */
     int prio_least = 0, prio_greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { prio_least = prio_greatest = 0; (void)hipGetLastError(); }
-    if (prio_greatest != prio_least) HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest));
-    else HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (prio_greatest != prio_least) {
+        HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest));
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    }
     /* compute units of this device (a partitioned GPU has fewer than 256): what a front launch with teams may occupy */
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->n_cus = cus;
@@ -1105,8 +1165,10 @@ static int create_streams(mi_dmrecon_ctx* c) {
 static int warm_streams(mi_dmrecon_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream2));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream3));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream2));
+    HIP_TRY(hipStreamSynchronize(c->stream3));
     return 0;
 }
 
@@ -1142,11 +1204,13 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)wait_stream(c->stream);
     if (c->stream2) (void)wait_stream(c->stream2);
+    if (c->stream3) (void)wait_stream(c->stream3);
     c->bs.release();
     c->d_stage.release(); c->d_stage2.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     delete c;                                 /* the scene store goes with its last owner */
 }
 
@@ -1287,6 +1351,7 @@ static int mi_dmrecon_set_features_impl(mi_dmrecon_ctx* c, int32_t n, const floa
         f.ref_begin = off[i]; f.ref_end = off[i + 1];
     }
     c->sc->feat_refs.assign(ids, ids + (n ? off[n] : 0));
+    build_features_by_view(*c->sc);
     c->sc->geom.built = false;
     return 0;
 }
@@ -1448,7 +1513,7 @@ int BatchRun::plan() {
         else if (progress) progress[i].status = MI_RECON_GLOBALVS;
     }
     std::vector<JobHost> plans(n_refs);
-    const int n_threads = std::max(1, std::min(std::min(n_refs, omp_get_num_procs()), 64));
+    const int n_threads = std::max(1, std::min(n_refs, host_threads_cap()));
     bool gvs_done = false;
     if (gvs_device_wanted(c, n_refs)) {
         std::vector<std::vector<int> > gl(n_refs);
@@ -1508,7 +1573,7 @@ int BatchRun::upload() {
     dj.resize(nj);
     /* (a merged batch of 400 views: 8 000 per-view geometries and 13 MB of seeds -- by a few threads, the seeds from the
      * views' plans straight into the pinned staging; it was 9 ms of one thread) */
-    const int n_threads = std::max(1, std::min(std::min(nj / 4, omp_get_num_procs()), 16));
+    const int n_threads = std::max(1, std::min(std::min(nj / 4, host_threads_cap()), 16));
 #pragma omp parallel for schedule(static) num_threads(n_threads) if (n_threads > 1)
     for (int j = 0; j < nj; ++j) fill_job(c, st, jobs[j], dj[j]);
     std::vector<size_t> seed_off((size_t)nj + 1, 0);
@@ -2078,17 +2143,24 @@ int BatchRun::front_rounds() {
         HIP_TRY(hipMemcpyAsync(c->bs.d_front_map.p, front_map.data(), front_grid * sizeof(unsigned), hipMemcpyHostToDevice, S));
     }
     /* One workgroup per view and more views than the GPU holds front workgroups (one per CU): the launch runs them in waves
-     * and lasts as long as its last workgroup -- the views with the most left to fill go first (they are the ones with the
-     * long fronts: plan_front_team), the short ones fill the CUs that become free.  MI_DMRECON_FRONT_ORDER=0: in index order. */
+     * and lasts as long as its last workgroup.  The views with the most left to fill are the ones with the long fronts
+     * (plan_front_team): the quarter of the views with the most empty pixels starts FIRST (the launch cannot be shorter than
+     * its longest view, so that one must not wait for a CU), the others follow SHORTEST first -- they fill the CUs that
+     * become free, and they END early and one after the other: the maps of a finished view go back to the host while the
+     * kernel still runs (stream_view), 2 MB per view over PCIe -- 830 MB for 400 views, as long as the front itself --, and
+     * with everything sorted longest-first all views ended together and most of that transfer came AFTER the kernel
+     * (measured, 400 views: front 56.2 -> 36.5 ms, but 16.5 ms of copies behind it).  MI_DMRECON_FRONT_ORDER=0: index order,
+     * 2: longest first throughout. */
     const unsigned* d_order = nullptr;
     {
         const char* e = std::getenv("MI_DMRECON_FRONT_ORDER");
-        if ((!e || std::atoi(e) != 0) && nj > 1 && view_filled.size() == (size_t)nj) {
+        const int mode = e ? std::atoi(e) : 1;
+        if (mode != 0 && nj > 1 && view_filled.size() == (size_t)nj) {
             front_order.resize((size_t)nj);
             for (int j = 0; j < nj; ++j) front_order[j] = (unsigned)j;
-            std::stable_sort(front_order.begin(), front_order.end(), [&](unsigned a, unsigned b) {
-                return (long long)jobs[a].w * jobs[a].h - (long long)view_filled[a] > (long long)jobs[b].w * jobs[b].h - (long long)view_filled[b];
-            });
+            auto empty_px = [&](unsigned a) { return (long long)jobs[a].w * jobs[a].h - (long long)view_filled[a]; };
+            std::stable_sort(front_order.begin(), front_order.end(), [&](unsigned a, unsigned b) { return empty_px(a) > empty_px(b); });
+            if (mode != 2) std::reverse(front_order.begin() + nj / 4, front_order.end());
             if (c->bs.d_front_order.reserve((size_t)nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(front order) failed");
             HIP_TRY(hipMemcpyAsync(c->bs.d_front_order.p, front_order.data(), (size_t)nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
             d_order = c->bs.d_front_order.p;
@@ -2190,7 +2262,9 @@ int BatchRun::stream_view(int j) {
     mi_dmrecon_maps& m = maps[i];
     if (m.views) { streamed[j] = 2; return 0; }              /* (2: ended, but everything is left to download()) */
     const size_t np = (size_t)jobs[j].w * jobs[j].h;
-    hipStream_t S2 = c->stream2;
+    /* (the views alternate between two streams: two copy engines share the transfer; MI_DMRECON_COPY_STREAMS=1: one) */
+    static const bool two = [] { const char* e = std::getenv("MI_DMRECON_COPY_STREAMS"); return !e || std::atoi(e) != 1; }();
+    hipStream_t S2 = (two && (n_streamed & 1)) ? c->stream3 : c->stream2;
     mi_launch_flatten(S2, c->bs.d_maps.p, c->bs.d_imaps.p, total_px, st->nrReconNeighbors > 4, jobs[j].pix_off, np);
     if (m.depth) HIP_TRY(hipMemcpyAsync(m.depth, dj[j].depth, np * 4, hipMemcpyDeviceToHost, S2));
     if (m.conf) HIP_TRY(hipMemcpyAsync(m.conf, dj[j].conf, np * 4, hipMemcpyDeviceToHost, S2));
@@ -2228,7 +2302,7 @@ int BatchRun::download() {
         }
     }
     HIP_TRY(wait_stream(S));
-    if (n_streamed) HIP_TRY(wait_stream(c->stream2));
+    if (n_streamed) { HIP_TRY(wait_stream(c->stream2)); HIP_TRY(wait_stream(c->stream3)); }
     mark("download");
     return 0;
 }
@@ -2351,6 +2425,7 @@ struct ScratchLease {
          * kernels and copies in flight; the next holder would write into them, or free them) */
         (void)wait_stream(c->stream);
         if (c->stream2) (void)wait_stream(c->stream2);
+        if (c->stream3) (void)wait_stream(c->stream3);
         std::lock_guard<std::mutex> lock(c->sc->pool_mu);
         if (c->bs.holds_anything()) c->sc->scratch_pool.push_back(std::move(c->bs));
         c->bs = BatchScratch();
@@ -2448,11 +2523,13 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
     {
         /* The host planning of a batch is an OpenMP loop on the thread that LEADS the batch, and a thread's OpenMP team is
          * created at its first parallel region (10-30 ms for 64 threads): which caller leads a merged batch is a matter of
-         * arrival order, so every calling thread gets its team at its first call, whatever its role in it. */
+         * arrival order, so every calling thread gets its team at its first call, whatever its role in it -- a team of
+         * the size the planning of THIS call would use (the views of the call, the cores the process may run on: not 64
+         * idle workers per caller thread on a container with the CPU time of 16). */
         static thread_local bool team_ready = false;
         if (!team_ready) {
             team_ready = true;
-            const int n_threads = std::max(1, std::min(omp_get_num_procs(), 64));
+            const int n_threads = std::max(1, std::min(std::max(n_refs, 1) * 4, host_threads_cap()));
 #pragma omp parallel num_threads(n_threads)
             { }
         }
@@ -2775,6 +2852,7 @@ int mi_dmrecon_debug_plan_views_host(int32_t n_views, const mi_dmrecon_camera* c
             f.ref_begin = off[i]; f.ref_end = off[i + 1];
         }
         c.sc->feat_refs.assign(ids, ids + (n_feat ? off[n_feat] : 0));
+        build_features_by_view(*c.sc);
         if (!tables) { c.sc->geom.built = true; c.sc->geom.has_plx = false; }   /* as for a bundle too large for the tables */
         std::vector<int> global;
         int rc = plan_global_views(&c, st, ref, global);                        /* (builds the tables) */

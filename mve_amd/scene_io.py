@@ -110,8 +110,11 @@ def view_dir(scene_path: str, view_id: int) -> str:
     return os.path.join(scene_path, "views", "view_%04d.mve" % view_id)
 
 
-def write_scene(scene_path: str, scene: SceneData, embedding: str = "undistorted") -> None:
-    """Write an MVE scene directory that the unmodified apps/dmrecon accepts."""
+def write_scene(scene_path: str, scene: SceneData, embedding: str = "undistorted", raw: bool = False) -> None:
+    """Write an MVE scene directory that the unmodified apps/dmrecon accepts.  A view whose image is None gets its
+    meta.ini only: MVE then has no such embedding for it and dmrecon skips it as a neighbour (dmrecon.cc:62-79).
+    raw=True stores the embedding as <embedding>.mvei (uncompressed; MVE finds image files by extension,
+    libs/mve/view.cc:656-709) -- for scenes of gigabytes, where PNG encoding and decoding would dominate."""
     os.makedirs(os.path.join(scene_path, "views"), exist_ok=True)
     for vid, (cam, img) in enumerate(zip(scene.cameras, scene.images)):
         d = view_dir(scene_path, vid)
@@ -129,7 +132,10 @@ def write_scene(scene_path: str, scene: SceneData, embedding: str = "undistorted
             f.write("id = %d\n" % vid)
             f.write("name = synth%04d\n" % vid)
         if img is not None:
-            write_png(os.path.join(d, embedding + ".png"), img)
+            if raw:
+                write_mvei(os.path.join(d, embedding + ".mvei"), img)
+            else:
+                write_png(os.path.join(d, embedding + ".png"), img)
     with open(os.path.join(scene_path, "synth_0.out"), "w") as f:
         f.write("drews 1.0\n")
         f.write("%d %d\n" % (scene.n_views, len(scene.features)))

@@ -141,7 +141,22 @@ def _lib():
     return _LIB
 
 
-def _render(p: SynthParams, cam: Camera, w: int, h: int, ppoint, want_rgb: bool, want_depth: bool):
+_LIB_GPU = None
+
+
+def _lib_gpu():
+    """The same renderer as a HIP kernel (mve_amd/csrc/synth_render_gpu.hip): harness only, for the large scenes."""
+    global _LIB_GPU
+    if _LIB_GPU is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmi_synth_gpu.so")
+        if not os.path.exists(path):
+            raise RuntimeError("%s missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        _LIB_GPU = ctypes.CDLL(path)
+        _LIB_GPU.mi_synth_render_gpu.restype = ctypes.c_int
+    return _LIB_GPU
+
+
+def _render(p: SynthParams, cam: Camera, w: int, h: int, ppoint, want_rgb: bool, want_depth: bool, gpu: bool = False):
     c2 = Camera(cam.flen, cam.paspect, ppoint if ppoint is not None else cam.ppoint, cam.rot, cam.trans)
     ax, ay, cx, cy = _calib(c2, w, h)
     fx, fy, mix = _texture_basis(p)
@@ -156,14 +171,19 @@ def _render(p: SynthParams, cam: Camera, w: int, h: int, ppoint, want_rgb: bool,
     rgb = np.empty((h, w, 3), np.uint8) if want_rgb else None
     dep = np.empty((h, w), np.float32) if want_depth else None
     vp = ctypes.c_void_p
+    if gpu and want_rgb and not want_depth:
+        rc = _lib_gpu().mi_synth_render_gpu(ctypes.byref(cp), vp(fx.ctypes.data), vp(fy.ctypes.data), vp(mix.ctypes.data), vp(rgb.ctypes.data))
+        if rc != 0:
+            raise RuntimeError("mi_synth_render_gpu failed (HIP error %d)" % rc)
+        return rgb, None
     _lib().mi_synth_render(ctypes.byref(cp), vp(fx.ctypes.data), vp(fy.ctypes.data), vp(mix.ctypes.data),
                            vp(rgb.ctypes.data if want_rgb else None),
                            vp(dep.ctypes.data if want_depth else None))
     return rgb, dep
 
 
-def render_view(p: SynthParams, cam: Camera) -> np.ndarray:
-    return _render(p, cam, p.width, p.height, None, True, False)[0]
+def render_view(p: SynthParams, cam: Camera, gpu: bool = False) -> np.ndarray:
+    return _render(p, cam, p.width, p.height, None, True, False, gpu)[0]
 
 
 def true_depth(p: SynthParams, cam: Camera, w: int, h: int, ppoint=None) -> np.ndarray:
@@ -201,9 +221,24 @@ def make_features(p: SynthParams, cams: List[Camera]) -> List[Feature]:
     return feats
 
 
-def make_scene(p: SynthParams) -> SceneData:
+def make_scene(p: SynthParams, gpu: bool = False) -> SceneData:
+    """gpu=True: the images are rendered by the HIP kernel (a byte may differ by one from the OpenMP renderer's, which
+    the golden fixtures were made with: use it where everybody reads the same images anyway, i.e. the large scenes)."""
     cams = make_cameras(p)
-    return SceneData(cams, [render_view(p, c) for c in cams], make_features(p, cams))
+    return SceneData(cams, [render_view(p, c, gpu) for c in cams], make_features(p, cams))
+
+
+def merge_scenes(scenes: List[SceneData]) -> SceneData:
+    """Several independent scenes as ONE resident set of views: scene k's views get the ids after scene k - 1's, its
+    features reference only its own views -- so the global view selection of a reference view stays inside its scene
+    (views of other scenes share no feature with it, global_view_selection.cc:62-101), and a batch of reference views
+    from all of them reads that many DISTINCT image sets (the bench's distinct-scenes variant)."""
+    cams, imgs, feats, off = [], [], [], 0
+    for sc in scenes:
+        cams += list(sc.cameras); imgs += list(sc.images)
+        feats += [Feature(list(f.pos), [v + off for v in f.view_ids]) for f in sc.features]
+        off += sc.n_views
+    return SceneData(cams, imgs, feats)
 
 
 # The BASELINE.json configurations (SURVEY.md section 8 header).

@@ -32,13 +32,13 @@ np.savez(sys.argv[2], d=r["depth"], c=r["conf"])
 
 @pytest.fixture(scope="module")
 def c3_oracle(tmp_path_factory):
-    """The CPU oracle on views 3, 8 and 12 of the C3 scene, and on 8 and 12 once more with its queue popped worst-first
-    (ORC_QUEUE_ORDER=reverse is read when the oracle library is loaded): five subprocesses side by side, started
+    """The CPU oracle on views 3, 8 and 12 of the C3 scene, and on 12 once more with its queue popped worst-first
+    (ORC_QUEUE_ORDER=reverse): four subprocesses side by side, started
     before the GPU fixture so that they run while the GPU tests do.  Returns get(view, reverse=False) -> maps."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     td = tmp_path_factory.mktemp("c3_oracle")
     jobs = {}
-    for v, rev in ((3, False), (8, False), (12, False), (8, True), (12, True)):
+    for v, rev in ((3, False), (8, False), (12, False), (12, True)):
         out = str(td / ("v%d%s.npz" % (v, "r" if rev else "")))
         env = dict(os.environ, OMP_NUM_THREADS="8")
         if rev:
@@ -155,25 +155,28 @@ def test_c3_deterministic(c3, monkeypatch):
 def test_c3_views_vs_oracle(c3, c3_oracle, view):
     """Depth / confidence of three full-size views against the CPU oracle under the map-level tolerance.  The fill
     mask: IoU >= 0.98 as SURVEY 8c states -- except where the reference ALGORITHM does not reach that against itself:
-    on views 8 and 12 strips along the top / bottom image border are filled or not depending on which local view set
-    reaches them first, and the same restatement with its queue popped worst-first (another valid order of the same
-    algorithm) differs from the reference by as much (measured: view 12 IoU 0.9713 against itself, 0.9708 GPU vs
-    reference; view 8 0.9850 / 0.9860).  The bound there is that floor, enforced: the GPU sweep may not be further
-    from the reference than the reference's own order sensitivity (- 0.002)."""
+    strips along the image border are filled or not depending on which local view set reaches them first, and the same
+    restatement with its queue popped in another order (reversed, random, the reference's order with other tie-breaks:
+    seven orders per view, tools/order_floor.py -> tests/golden/order_floor_c3.json, computed on the CPU) loses them
+    too: against the reference's own order the worst of those orders reaches 0.9581 on view 12 and 0.9847 on view 8
+    (0.9441 on view 14, 0.9696 on view 17, 0.9713 on view 13; 0.9938 on view 3).  The GPU sweep is one more re-ordering of
+    the same algorithm: per view it must reach min(0.98, that view's floor - 0.002) -- measured: 0.9938 / 0.9856 / 0.9708 on
+    views 3 / 8 / 12 -- and its depths 1.5 x the floor's relative depth p99 at most."""
+    import json
     cfg, scene, ctx, st, res, stats = c3
+    floors = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "order_floor_c3.json")))
     o = c3_oracle(view)
     m = map_parity(res[view]["depth"], res[view]["conf"], o["d"], o["c"])
     assert m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
     assert m["conf_med"] <= 1e-3 and m["conf_p99"] <= 5e-3, m
-    if view == 3:
-        assert m["iou"] >= 0.98, m
-    else:
+    floor_iou = floors["worst"]["iou"][str(view)]
+    assert m["iou"] >= min(0.98, floor_iou - 0.002), (m["iou"], floor_iou)
+    assert m["rel_p99"] <= max(3e-3, 1.5 * floors["worst"]["rel_p99"][str(view)]), (m, floors["worst"]["rel_p99"][str(view)])
+    if view == 12:
+        # the fixture is what this restatement computes: its reversed order, recomputed here, against the stored figure
         r = c3_oracle(view, reverse=True)
-        floor = map_parity(r["d"], r["c"], o["d"], o["c"])
-        assert floor["iou"] < 0.99, floor                     # the strips are a property of the algorithm on this view
-        assert m["iou"] >= min(0.98, floor["iou"] - 0.002), (m["iou"], floor["iou"])
-        # ... and so are the depths: the sweep is as close to the reference as the reference is to itself
-        assert m["rel_p99"] <= max(3e-3, 1.5 * floor["rel_p99"]), (m, floor)
+        again = map_parity(r["d"], r["c"], o["d"], o["c"])
+        assert abs(again["iou"] - floors["views"][str(view)]["orders"]["reverse"]["iou"]) < 1e-6, again
 
 
 def test_c3_global_view_selection_of_view_3(c3):
@@ -292,13 +295,11 @@ np.savez(sys.argv[1], **out)
 """
 
 
-@pytest.mark.skipif(os.environ.get("MI_TEST_C5_FULL") != "1",
-                    reason="2.3 minutes (1.4 of them rendering 100 x 12 MP on the box's 16-CPU quota): set MI_TEST_C5_FULL=1; "
-                           "its last run is in profiles/r4_c5_fullsize_test.txt, and `bench.py --config C5` checks the same "
-                           "three views inside its run")
 def test_config5_full_size_views_vs_oracle(tmp_path):
     """All 100 reference views of the config-5 scene in one call; views 0, 50 and 99 against the CPU oracle (one process
-    next to the GPU work, on the images this process rendered: the three views one after the other).  Confidence bound 1e-2:
+    next to the GPU work, on the images this process rendered: the three views one after the other).  The scene is rendered
+    on the GPU (mve_amd/csrc/synth_render_gpu.hip, harness code: 100 x 12 MP take 87 s on the box's 16-CPU quota, well under a
+    second there; GPU path and oracle read the same images).  Confidence bound 1e-2:
     the reference algorithm against itself with its queue reversed is at 6.0e-3 .. 7.8e-3 on this scene
     (tools/c5_order_floor.py, profiles/r4_c5_order_floor.json).  The three views alone give the bits they have in the
     batch of 100."""
@@ -310,7 +311,7 @@ def test_config5_full_size_views_vs_oracle(tmp_path):
         import time
         cfg = CONFIGS["C5"]
         n = cfg["params"].n_views
-        t0 = time.time(); scene = make_scene(cfg["params"]); t1 = time.time()
+        t0 = time.time(); scene = make_scene(cfg["params"], gpu=True); t1 = time.time()
         img_file = str(tmp_path / "c5_images.npy")
         np.save(img_file, np.stack(scene.images))
         proc = subprocess.Popen([sys.executable, "-c", _ORACLE_C5 % root, out, img_file] + [str(v) for v in views])

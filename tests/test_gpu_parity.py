@@ -264,6 +264,15 @@ def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, m
             for a, b in zip(got, ref):
                 for k in ("depth", "conf", "dz", "normal", "views"):
                     assert np.array_equal(a[k], b[k]), (k, rep)
+        if team == "1":
+            # one workgroup per view: the order in which the views' workgroups start (default: the most empty pixels first)
+            # is scheduling only
+            monkeypatch.setenv("MI_DMRECON_FRONT_ORDER", "0")
+            got = gpu_ctx.reconstruct(api.Settings(), refs, want_views=True)
+            monkeypatch.delenv("MI_DMRECON_FRONT_ORDER")
+            for a, b in zip(got, ref):
+                for k in ("depth", "conf", "dz", "normal", "views"):
+                    assert np.array_equal(a[k], b[k]), (k, "front order")
         monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER", raising=False)
     monkeypatch.delenv("MI_DMRECON_FRONT", raising=False)
     monkeypatch.delenv("MI_DMRECON_FRONT_TEAM", raising=False)
@@ -364,7 +373,10 @@ def test_maps_do_not_depend_on_the_batch(gpu_ctx, g1_scene, h1_scene, monkeypatc
         # the throughput rounds as first-attempt launch + follow-up launch instead of one launch, without the speculative
         # small rounds, and with every round speculative (records for 2 x the threshold; larger rounds fall back on the
         # device): same arithmetic, same counters
+        # (ONE_LAUNCH=0: first attempts, then one launch per further attempt; with SINGLE_FOLLOW=0 one follow-up launch that
+        # runs an entry's remaining attempts in a row)
         for env in ({"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0"}, {"MI_DMRECON_SPEC_ROUNDS": "0"},
+                    {"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0", "MI_DMRECON_SINGLE_FOLLOW": "0"},
                     {"MI_DMRECON_SPEC_ROUNDS": "1000000"}, {"MI_DMRECON_SPEC_ROUNDS": "700", "MI_DMRECON_ONE_LAUNCH": "0"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)

@@ -201,3 +201,36 @@ def test_order_sensitivity_floor_on_wide_scene(w1):
         m = map_parity(w1["k6n40_depth"], w1["k6n40_conf"], rev["d"], rev["c"])
     # measured: iou 1.0, rel_med 8.7e-4, rel_p99 8.3e-3, conf_med 1.5e-2, conf_p99 0.12
     assert m["iou"] >= 0.995 and 4e-3 <= m["rel_p99"] <= 1.5e-2 and 5e-3 <= m["conf_med"] <= 3e-2 and 0.06 <= m["conf_p99"] <= 0.2, m
+
+
+def test_queue_order_probes_are_orders_of_the_same_algorithm(g1, g1_scene, monkeypatch):
+    """ORC_QUEUE_ORDER (read by the restatement at every reconstruction): unset -> the reference's own pop order, bit for bit
+    (the fixtures above); reverse / random:<seed> / jitter:<seed> -> the same algorithm in another valid order: a probe of how
+    much the result depends on the order (tools/order_floor.py -> tests/golden/order_floor_c3.json, the floor the fill-mask
+    bounds of the GPU sweep are set against).  The probes are deterministic, differ from the reference order in the last digits
+    only, and leave the default untouched."""
+    import json
+    import os
+    S = orc.OracleScene(g1_scene)
+    st = orc.make_settings(ref_view=0, scale=0)
+    got = {}
+    for order in ("reverse", "random:1", "random:2", "jitter:1"):
+        monkeypatch.setenv("ORC_QUEUE_ORDER", order)
+        a = S.reconstruct(st)
+        b = S.reconstruct(st)
+        assert np.array_equal(a["depth"], b["depth"])                    # deterministic
+        got[order] = a
+    monkeypatch.delenv("ORC_QUEUE_ORDER")
+    ref = S.reconstruct(st)
+    assert np.array_equal(ref["depth"], g1["s0v0_depth"])                # the default is still the reference's order
+    for order, a in got.items():
+        ma, mb = a["depth"] > 0, ref["depth"] > 0
+        both = ma & mb
+        assert both.sum() / max((ma | mb).sum(), 1) > 0.9, order
+        rel = np.abs(a["depth"][both] - ref["depth"][both]) / ref["depth"][both]
+        assert np.median(rel) < 5e-3 and not np.array_equal(a["depth"], ref["depth"]), order
+    assert not np.array_equal(got["random:1"]["depth"], got["random:2"]["depth"])
+    # the committed floor of the C3 scene: seven orders for every one of its 20 views
+    f = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "order_floor_c3.json")))
+    assert len(f["views"]) == 20 and all(len(v["orders"]) == 7 for v in f["views"].values())
+    assert abs(f["min_fill_iou"] - min(f["worst"]["iou"].values())) < 1e-12 and 0.9 < f["min_fill_iou"] < 0.98
