@@ -72,7 +72,7 @@ def plan_calls(steps, streams, steps_per_call=0):
     return spc, n_calls, max(1, min(int(streams), n_calls))
 
 
-TRAFFIC_PROFILES = ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json")     # newest first
+TRAFFIC_PROFILES = ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json")     # newest first
 # executed VALU wave-instructions per wavefront pass (16 patches x 4 views x 25 samples) of the bulk kernel: SQ_INSTS_VALU of a
 # PMC pass / (device-counted passes / 64); a STORED profile value like `traffic` (profiles/r<N>_traffic.json:
 # "valu_wave_insts_per_wave_pass"), r3's figure when the newest profile does not carry one
@@ -90,7 +90,7 @@ def stored_valu_per_wave_pass(lone=False):
             by = j.get("valu_wave_insts_per_wave_pass_by_plan", {})
             for plan, v in by.items():
                 if plan.startswith("1 host thread") == bool(lone) and v:
-                    return float(v), "profiles/%s (%s)" % (name, plan)
+                    return float(v), "profiles/%s (profiled plan: %s)" % (name, plan)
             v = j.get("valu_wave_insts_per_wave_pass")
             if v:
                 return float(v), "profiles/" + name
@@ -109,12 +109,14 @@ def measured_traffic(n_streams, spc, config_is_c3=True):
         if not os.path.exists(f) or not config_is_c3:
             continue
         j = json.load(open(f))
-        want = "1 host thread" if (n_streams == 1 and spc == 1) else "default"
-        for plan, fams in j.get("plans", {}).items():
-            if plan.startswith(want):
-                return fams, {"file": "profiles/" + name, "profiled_plan": plan, "stored_profile": True,
-                              "this_run_plan": "%d host thread(s), %d step(s) per call" % (n_streams, spc),
-                              "correction": j.get("correction", "")}
+        this = "%d host thread(s), %d step(s) per call" % (n_streams, spc)
+        plans = j.get("plans", {})
+        # the profile taken at exactly this run's plan, else the nearest kind (a lone call / a merged multi-thread batch)
+        pick = this if this in plans else next((pl for pl in plans if pl.startswith("1 host thread") == (n_streams == 1 and spc == 1)), None)
+        if pick is not None:
+            return plans[pick], {"file": "profiles/" + name, "profiled_plan": pick, "stored_profile": True,
+                                 "this_run_plan": this, "profiled_plan_is_this_runs": pick == this,
+                                 "correction": j.get("correction", "")}
     return {}, None
 
 

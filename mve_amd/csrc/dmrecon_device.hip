@@ -1627,15 +1627,16 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
     /* the best untried candidate (highest source confidence, lowest direction on ties: process_entry's strict '>') and the
      * confidence of the one that would come after it */
     const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
-    int bi = -1; float bc = 0.f, bc2 = 0.f; bool has2 = false;
+    /* (confidences are >= 0: a runner-up of -1 stands for "none" -- the pop-time test best > bc2 then holds by itself) */
+    int bi = -1; float bc = 0.f, bc2 = -1.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if ((tried >> k) & 1u) continue;
         const float c = GF(job->conf + nb[k]);
         const bool use = GI(job->upd + nb[k]) == a.round - 1 && (own < c - 0.05f || own == 0.f);
         if (!use) continue;
-        if (bi < 0 || c > bc) { if (bi >= 0) { bc2 = has2 ? fmaxf(bc2, bc) : bc; has2 = true; } bi = k; bc = c; }
-        else { bc2 = has2 ? fmaxf(bc2, c) : c; has2 = true; }
+        if (bi < 0 || c > bc) { if (bi >= 0) bc2 = fmaxf(bc2, bc); bi = k; bc = c; }
+        else bc2 = fmaxf(bc2, c);
     }
     more = false;
     DevResult z;
@@ -1659,7 +1660,7 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
     tried |= 1u << bi;
     const bool accept = r.conf > 0.f && best < r.conf;         /* dmrecon.cc:378,391 */
     if (accept) best = r.conf;
-    more = has2 && !(best > bc2);
+    more = !(best > bc2);
     if (writer) {
         if (accept) {
             DevResult o;
@@ -1671,6 +1672,33 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
         else if (more) a.results[e].tried = tried;
     }
 }
+
+/*
+ * Which part of a work list a workgroup takes.  The workgroups of a launch are dealt round-robin over the 8 XCDs (block b runs
+ * on XCD b % 8: observed, not promised -- a wrong guess costs locality, nothing else), and every XCD has an L2 of its own.  A
+ * round's list is ordered by reference view and image tile (k_generate's workgroups append in dispatch order), i.e. entries that
+ * are neighbours in the list sample the same neighbour images at nearby positions.  Dealt out block by block, consecutive
+ * wavefronts of the list land on eight different XCDs and every L2 fetches every image region for itself; here XCD x takes the
+ * x-th EIGHTH of the list: its workgroups walk through one contiguous range, and what one wavefront's patches pulled into the
+ * XCD's L2 is what the next wavefront's patches ask for.  (The launchers round grids up to multiples of 8.)
+ * Usage: for (XcdRange r(n_units); r.next(u); ) -- u: the unit (a wavefront's worth of the list) this workgroup takes next.
+ */
+#ifndef MI_XCDS
+#define MI_XCDS 8
+#endif
+struct XcdRange {
+    unsigned per_x, base, j, jn;
+    __device__ __forceinline__ explicit XcdRange(unsigned n_units) {
+        const unsigned nx = (gridDim.x % MI_XCDS == 0 && gridDim.x >= MI_XCDS) ? MI_XCDS : 1u;   /* (a grid that is no multiple: block order) */
+        per_x = (n_units + nx - 1) / nx;
+        base = (blockIdx.x % nx) * per_x; j = blockIdx.x / nx; jn = gridDim.x / nx;
+    }
+    __device__ __forceinline__ bool next(unsigned& unit) {
+        if (j >= per_x) return false;
+        unit = base + j; j += jn;
+        return true;
+    }
+};
 
 /* flush counters: one atomic per wave (per-view counters live in the first lane of each view slot,
  * the patch counter in the first lane of each patch) */
@@ -1711,10 +1739,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
 #endif
     __syncthreads();
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
-    for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < n; i += gridDim.x * L::PATCHES) {
-        const unsigned e = a.follow_in ? a.follow_in[i] : i;
-        const DevEntry ent = a.work[e];
+    unsigned unit;
+    for (XcdRange xr((n + L::PATCHES - 1) / L::PATCHES); xr.next(unit); ) {
+        const unsigned i = unit * L::PATCHES + L::patch(lane);
+        const bool live = i < n;                             /* (the last wavefront of the list: lanes without an entry idle) */
+        const unsigned e = !live ? 0u : (a.follow_in ? a.follow_in[i] : i);
         bool more = false;
+        if (live) {
+        const DevEntry ent = a.work[e];
         const DevJob* job = a.jobs + ent.job;
         if (GI(&job->flags) != 0) {
             /* the view failed (footprint exception) or was cancelled: nothing of it is touched any more */
@@ -1723,6 +1755,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
             process_entry_single<L, FAST>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
         else
             process_entry<L, false>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
+        }
         if (a.follow_out) {
             /* wave-aggregated append of the entries that still have candidates (one atomic per wavefront) */
             const bool mine = more && L::vslot(lane) == 0 && L::sub(lane) == 0;
@@ -1778,7 +1811,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((MI_FW >= 
     const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
     unsigned err = 0;
     const unsigned n_items = *t.n_items;
-    for (unsigned i = blockIdx.x * L::PATCHES + L::patch(lane); i < n_items; i += gridDim.x * L::PATCHES) {
+    unsigned unit;
+    for (XcdRange xr((n_items + L::PATCHES - 1) / L::PATCHES); xr.next(unit); ) {
+        const unsigned i = unit * L::PATCHES + L::patch(lane);
+        if (i >= n_items) continue;
         const unsigned item = t.items[i];
         const unsigned e = item >> 2; const int s = (int)(item & 3u);
         const DevEntry ent = a.work[e];
@@ -3048,6 +3084,7 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
                         const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n) {
     if (grid_blocks == 0) return;
+    grid_blocks = (grid_blocks + MI_XCDS - 1) / MI_XCDS * MI_XCDS;      /* (XcdRange: every XCD the same number of workgroups) */
     OptArgs a;
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
     a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
@@ -3083,6 +3120,7 @@ static void launch_optimize_spec(hipStream_t s, unsigned grid_blocks, const DevJ
                                  const unsigned* n_work_ptr, unsigned n_work,
                                  unsigned min_work, unsigned max_work, int round, DevCounters* counters) {
     if (grid_blocks == 0) return;
+    grid_blocks = (grid_blocks + MI_XCDS - 1) / MI_XCDS * MI_XCDS;
     SpecArgs t;
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = nullptr;
     t.o.n_work_ptr = n_work_ptr; t.o.n_work = n_work; t.o.min_work = min_work; t.o.max_work = max_work; t.o.round = round;

@@ -417,7 +417,6 @@ struct mi_dmrecon_ctx {
     int n_cus = 64;                          /* compute units (queried at creation) */
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;           /* copies of finished views back to the host while the front kernel still runs */
-    hipStream_t stream3 = nullptr;           /* ... a second one: the views alternate, two copy engines at work */
     std::shared_ptr<SceneStore> sc;
     DevCounters* d_counters = nullptr;
     DevBuf<uint8_t> d_stage;
@@ -1147,13 +1146,8 @@ static int create_streams(mi_dmrecon_ctx* c) {
      * PCIe, in the two regions out of five that such a context led).  Streams of another priority have queues of their own. */
     int prio_least = 0, prio_greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { prio_least = prio_greatest = 0; (void)hipGetLastError(); }
-    if (prio_greatest != prio_least) {
-        HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest));
-    } else {
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
-    }
+    if (prio_greatest != prio_least) HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest));
+    else HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     /* compute units of this device (a partitioned GPU has fewer than 256): what a front launch with teams may occupy */
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->n_cus = cus;
@@ -1165,10 +1159,8 @@ static int create_streams(mi_dmrecon_ctx* c) {
 static int warm_streams(mi_dmrecon_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream2));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream3));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream2));
-    HIP_TRY(hipStreamSynchronize(c->stream3));
     return 0;
 }
 
@@ -1204,13 +1196,11 @@ void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)wait_stream(c->stream);
     if (c->stream2) (void)wait_stream(c->stream2);
-    if (c->stream3) (void)wait_stream(c->stream3);
     c->bs.release();
     c->d_stage.release(); c->d_stage2.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     delete c;                                 /* the scene store goes with its last owner */
 }
 
@@ -2143,24 +2133,23 @@ int BatchRun::front_rounds() {
         HIP_TRY(hipMemcpyAsync(c->bs.d_front_map.p, front_map.data(), front_grid * sizeof(unsigned), hipMemcpyHostToDevice, S));
     }
     /* One workgroup per view and more views than the GPU holds front workgroups (one per CU): the launch runs them in waves
-     * and lasts as long as its last workgroup.  The views with the most left to fill are the ones with the long fronts
-     * (plan_front_team): the quarter of the views with the most empty pixels starts FIRST (the launch cannot be shorter than
-     * its longest view, so that one must not wait for a CU), the others follow SHORTEST first -- they fill the CUs that
-     * become free, and they END early and one after the other: the maps of a finished view go back to the host while the
-     * kernel still runs (stream_view), 2 MB per view over PCIe -- 830 MB for 400 views, as long as the front itself --, and
-     * with everything sorted longest-first all views ended together and most of that transfer came AFTER the kernel
-     * (measured, 400 views: front 56.2 -> 36.5 ms, but 16.5 ms of copies behind it).  MI_DMRECON_FRONT_ORDER=0: index order,
-     * 2: longest first throughout. */
+     * and lasts as long as its last workgroup -- the views with the most left to fill go first (they are the ones with the
+     * long fronts: plan_front_team), the short ones fill the CUs that become free (measured, 400 views: the kernel 56.2 ->
+     * 36.6 ms).  What that does not buy in full: the maps of a finished view go back to the host while the kernel still
+     * runs (stream_view), 2 MB per view -- 830 MB for 400 views = 31 ms at the 27 GB/s of the box's PCIe link, nearly as long
+     * as the front itself --, and longest-first makes the views end together: 12 ms of that transfer then come after the
+     * kernel (front + rest of the copies 56.4 -> 48.8 ms).  Measured and dropped: the long quarter first and the others
+     * SHORTEST first, so that they end one after the other -- the estimate (empty pixels) does not order the middle of the
+     * field well enough, the kernel was 51.5 ms (+ 0.7); two alternating copy streams -- the link is the limit, not the copy
+     * engine (profiles/r5_ab_experiments.txt).  MI_DMRECON_FRONT_ORDER=0: index order. */
     const unsigned* d_order = nullptr;
     {
         const char* e = std::getenv("MI_DMRECON_FRONT_ORDER");
-        const int mode = e ? std::atoi(e) : 1;
-        if (mode != 0 && nj > 1 && view_filled.size() == (size_t)nj) {
+        if ((!e || std::atoi(e) != 0) && nj > 1 && view_filled.size() == (size_t)nj) {
             front_order.resize((size_t)nj);
             for (int j = 0; j < nj; ++j) front_order[j] = (unsigned)j;
             auto empty_px = [&](unsigned a) { return (long long)jobs[a].w * jobs[a].h - (long long)view_filled[a]; };
             std::stable_sort(front_order.begin(), front_order.end(), [&](unsigned a, unsigned b) { return empty_px(a) > empty_px(b); });
-            if (mode != 2) std::reverse(front_order.begin() + nj / 4, front_order.end());
             if (c->bs.d_front_order.reserve((size_t)nj)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(front order) failed");
             HIP_TRY(hipMemcpyAsync(c->bs.d_front_order.p, front_order.data(), (size_t)nj * sizeof(unsigned), hipMemcpyHostToDevice, S));
             d_order = c->bs.d_front_order.p;
@@ -2262,9 +2251,7 @@ int BatchRun::stream_view(int j) {
     mi_dmrecon_maps& m = maps[i];
     if (m.views) { streamed[j] = 2; return 0; }              /* (2: ended, but everything is left to download()) */
     const size_t np = (size_t)jobs[j].w * jobs[j].h;
-    /* (the views alternate between two streams: two copy engines share the transfer; MI_DMRECON_COPY_STREAMS=1: one) */
-    static const bool two = [] { const char* e = std::getenv("MI_DMRECON_COPY_STREAMS"); return !e || std::atoi(e) != 1; }();
-    hipStream_t S2 = (two && (n_streamed & 1)) ? c->stream3 : c->stream2;
+    hipStream_t S2 = c->stream2;
     mi_launch_flatten(S2, c->bs.d_maps.p, c->bs.d_imaps.p, total_px, st->nrReconNeighbors > 4, jobs[j].pix_off, np);
     if (m.depth) HIP_TRY(hipMemcpyAsync(m.depth, dj[j].depth, np * 4, hipMemcpyDeviceToHost, S2));
     if (m.conf) HIP_TRY(hipMemcpyAsync(m.conf, dj[j].conf, np * 4, hipMemcpyDeviceToHost, S2));
@@ -2302,7 +2289,7 @@ int BatchRun::download() {
         }
     }
     HIP_TRY(wait_stream(S));
-    if (n_streamed) { HIP_TRY(wait_stream(c->stream2)); HIP_TRY(wait_stream(c->stream3)); }
+    if (n_streamed) HIP_TRY(wait_stream(c->stream2));
     mark("download");
     return 0;
 }
@@ -2425,8 +2412,7 @@ struct ScratchLease {
          * kernels and copies in flight; the next holder would write into them, or free them) */
         (void)wait_stream(c->stream);
         if (c->stream2) (void)wait_stream(c->stream2);
-        if (c->stream3) (void)wait_stream(c->stream3);
-        std::lock_guard<std::mutex> lock(c->sc->pool_mu);
+            std::lock_guard<std::mutex> lock(c->sc->pool_mu);
         if (c->bs.holds_anything()) c->sc->scratch_pool.push_back(std::move(c->bs));
         c->bs = BatchScratch();
     }

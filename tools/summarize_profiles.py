@@ -13,13 +13,16 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 FETCH_CORR = 2.0
 # steps (passes over the 20 views) behind each PMC run of tools/collect_profiles.sh, warm-up calls included
 STEPS = {"pmc": 3,      # --steps 2 --warmup 1 --streams 1 --steps-per-call 1 --no-one-call: three calls of one step
-         "pmcd": 20}    # --steps 10 --warmup 1 --no-one-call (5 steps per call, 2 threads): 2 warm-up + 2 timed calls of five steps
+         "pmcd": 40}    # --steps 20 --warmup 1 --no-one-call: the DRIVER's plan, 4 host threads x 5 steps per call -- one warm-up
+                        # batch and one timed batch of 400 views each
+# the call plans the PMC passes were taken at, named exactly as bench.py names the plan of a run (`this_run_plan`)
+PLAN = {"pmc": "1 host thread(s), 1 step(s) per call", "pmcd": "4 host thread(s), 5 step(s) per call"}
 for n in ("1thread", "default", "driver", "1thread_5steps"):
     f = os.path.join(src, "bench_%s.json" % n)
     if os.path.exists(f) and os.path.getsize(f):
@@ -33,7 +36,7 @@ for name, dstname in (("lone_calls.json", "lone_calls.json"), ("valu_rate.txt", 
 for s in ("s1", "s3"):
     f = os.path.join(src, s, "bench_kernel_stats.csv")
     if os.path.exists(f):
-        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, "1thread" if s == "s1" else "6threads")))
+        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, "1thread_1step" if s == "s1" else "4threads_5steps")))
 
 
 def short(name):
@@ -100,7 +103,7 @@ for k in sorted(acc, key=lambda k: -acc[k].get("FETCH_SIZE", [0, 0])[0]):
 # counts: rocprofv3 also sees the empty tail rounds that the host enqueues blind)
 traffic = {"correction": "read bytes = FETCH_SIZE x 1024 x 2 (128-byte requests tallied at 64 B; calibrated, profiles/r2_pmc_calibration.md); "
                          "written bytes = WRITE_SIZE x 1024", "plans": {}}
-for prefix, plan in (("pmc", "1 host thread, 1 step per call"), ("pmcd", "default: 6 host threads, 5 steps per call")):
+for prefix, plan in (("pmc", PLAN["pmc"]), ("pmcd", PLAN["pmcd"])):
     a, _ = (acc, regs) if prefix == "pmc" else collect("pmcd")
     fam = collections.defaultdict(lambda: [0.0, 0.0])
     for k in a:
@@ -126,7 +129,7 @@ def valu_per_wave_pass(prefix, steps_all):
     valu = sum(a2[k]["SQ_INSTS_VALU"][0] for k in a2 if family(k) == "k_optimize<1> (host-visible rounds)" and "SQ_INSTS_VALU" in a2[k]) / steps_all
     return valu, passes_bulk_per_step, valu / (passes_bulk_per_step / 64.0)
 traffic["valu_wave_insts_per_wave_pass_by_plan"] = {}
-for prefix, plan in (("pmc", "1 host thread, 1 step per call"), ("pmcd", "default: 6 host threads, 5 steps per call")):
+for prefix, plan in (("pmc", PLAN["pmc"]), ("pmcd", PLAN["pmcd"])):
     try:
         valu, passes, per = valu_per_wave_pass(prefix, STEPS[prefix])
         traffic["valu_wave_insts_per_wave_pass_by_plan"][plan] = per
@@ -134,8 +137,8 @@ for prefix, plan in (("pmc", "1 host thread, 1 step per call"), ("pmcd", "defaul
                   % (plan, valu, passes, per, per / 25.0)]
     except Exception as e:
         lines += ["", "(no VALU-per-pass figure for %s: %r)" % (plan, e)]
-if "1 host thread, 1 step per call" in traffic["valu_wave_insts_per_wave_pass_by_plan"]:
-    traffic["valu_wave_insts_per_wave_pass"] = traffic["valu_wave_insts_per_wave_pass_by_plan"]["1 host thread, 1 step per call"]
+if PLAN["pmc"] in traffic["valu_wave_insts_per_wave_pass_by_plan"]:
+    traffic["valu_wave_insts_per_wave_pass"] = traffic["valu_wave_insts_per_wave_pass_by_plan"][PLAN["pmc"]]
 if traffic["plans"]:
     json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 for n in ("1thread", "default", "driver", "1thread_5steps"):
