@@ -1,9 +1,8 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): round 5, session C -- XCD-aware work-list ranges (every XCD an eighth of a round's list)
-# against block order (-DMI_XCDS=1) and the transposed lane layout, on ONE scene and on 20 DISTINCT scenes; the parity tests on
-# the product build; instruction-cache counters of the bulk kernels.
+# Runs ON THE GPU BOX (through gpurun): round 5, session D -- the second wind of the front (a one-workgroup-per-view launch
+# stopped when few views are left, the rest continued with teams): its test, the parity file, bench lines with and without.
 export TMPDIR=/tmp
-O=gpurun_out/r5c
+O=gpurun_out/r5d
 mkdir -p $O
 line() { python - "$1" <<'PY'
 import json, sys
@@ -15,35 +14,14 @@ print("%s: value %.1f %s | bulk frac %.3f | one_call %.2f ms (bulk %.2f front %.
       oc.get("ms_bulk_kernel", 0), oc.get("ms_front_kernel", 0), d.get("value", 0), d.get("ms_bulk_kernel_per_step", 0), d.get("ms_front_kernel_per_step", 0)))
 PY
 }
-timeout -s KILL 400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-AB="--steps 20 --warmup 5 --repeats 3 --no-cpu-baseline --distinct-scenes 20 --one-call-n 20"
-MI_BENCH_REGION_LOG=1 timeout -s KILL 300 python bench.py $AB > $O/bench_base.json 2> $O/bench_base.err
-line $O/bench_base.json; grep "^region" $O/bench_base.err | sed -n '3p;6p'
-for V in nox tr; do
-  L=build/libmi_dmrecon_$V.so
-  [ -f $L ] || continue
-  MI_BENCH_REGION_LOG=1 MI_DMRECON_LIB=$PWD/$L timeout -s KILL 300 python bench.py $AB > $O/bench_$V.json 2> $O/bench_$V.err
-  line $O/bench_$V.json; grep "^region" $O/bench_$V.err | sed -n '3p;6p'
-done
-MI_BENCH_REGION_LOG=1 timeout -s KILL 300 python bench.py $AB > $O/bench_base2.json 2> $O/bench_base2.err
-line $O/bench_base2.json
-# instruction cache and L2 of the bulk kernels at the driver's plan (one counter group per run)
-rocprofv3 -L 2>/dev/null | grep -i -E "ICACHE|IFETCH|INST_CACHE" | head -20 > $O/counters_icache.txt; head -12 $O/counters_icache.txt
-R=$PWD; cd /tmp
-BQ="python $R/bench.py --steps 20 --warmup 1 --repeats 1 --no-cpu-baseline --no-one-call --distinct-scenes 0"
-for C in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_IFETCH"; do
-  D=$R/$O/pmcd_$(echo $C | tr ' ' '+')
-  timeout -s KILL 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -o bench -- $BQ > $D.log 2>&1
-  python - "$D" <<'PY'
-import csv, collections, glob, os, sys
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
-for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "k_optimize" in k or "k_front" in k:
-            acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
-for k, c in acc.items():
-    print(k[:70], {n: "%.4g" % v for n, v in c.items()})
-PY
-done
-cd $R; find $O -name "*_kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +2M -delete; du -sh $O
+timeout -s KILL 500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+AB="--steps 20 --warmup 5 --repeats 3 --no-cpu-baseline --distinct-scenes 0 --no-one-call"
+MI_DMRECON_TRACE=1 MI_BENCH_REGION_LOG=1 timeout -s KILL 300 python bench.py --steps 20 --warmup 2 --repeats 1 --no-cpu-baseline --distinct-scenes 0 --no-one-call 2> $O/trace.err > /dev/null
+grep -E "front:|second launch|phase C|download" $O/trace.err | tail -8
+MI_BENCH_REGION_LOG=1 timeout -s KILL 300 python bench.py $AB > $O/bench_wind.json 2> $O/bench_wind.err
+line $O/bench_wind.json; grep "^region" $O/bench_wind.err | tail -2
+MI_DMRECON_SECOND_WIND=0 MI_BENCH_REGION_LOG=1 timeout -s KILL 300 python bench.py $AB > $O/bench_nowind.json 2> $O/bench_nowind.err
+line $O/bench_nowind.json; grep "^region" $O/bench_nowind.err | tail -1
+MI_BENCH_REGION_LOG=1 timeout -s KILL 500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err
+line $O/bench_driver.json; grep "^region" $O/bench_driver.err | sed -n '5p;8p'
+timeout -s KILL 900 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_parity.py > $O/pytest_rest.log 2>&1; tail -4 $O/pytest_rest.log
