@@ -636,7 +636,13 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         step = ok ? fast_rcp(dnorm) : 0.f;
     }
     TSTAMP(50);                                        /* (pass set-up done: the derivative step) */
-    const float wlim = (float)(nv.w - 1), hlim = (float)(nv.h - 1);
+    /* The strict interior test 0 < u < w - 1, 0 < v < h - 1 (patch_sampler.cc:116-119, :386-389) and the memory-safe clamp in one:
+     * the coordinates are clamped into [FLT_MIN, the float below w - 1] -- a sample inside the image is not moved by that, one
+     * outside (or on the edge, or NaN: v_med3 then returns the lower bound) is --, so "the clamp changed nothing" IS the test:
+     * one v_med3 and one v_cmp_eq per coordinate instead of one v_med3 and two compares.  (A coordinate in (0, 1.2e-38) would
+     * be counted as outside.) */
+    const float wlim = __uint_as_float(__float_as_uint((float)(nv.w - 1)) - 1u), hlim = __uint_as_float(__float_as_uint((float)(nv.h - 1)) - 1u);
+    constexpr float kLo = 1.17549435e-38f;
     ColorSums S;
     S.s0 = ps.xbar0 * ps.mmean; S.s1 = ps.xbar1 * ps.mmean; S.s2 = ps.xbar2 * ps.mmean;
     S.a0 = S.a1 = S.a2 = 0.f; S.aa0 = S.aa1 = S.aa2 = 0.f; S.ba0 = S.ba1 = S.ba2 = 0.f;
@@ -668,8 +674,10 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         const float sx = nv.sx + lam * vx, sy = nv.sy + lam * vy, sz = nv.sz + lam * vz;
         const float iz = fast_rcp(sz);
         const float u = sx * iz - 0.5f, v = sy * iz - 0.5f;                       /* worldToScreen */
-        /* strict interior test (patch_sampler.cc:116-119, :386-389) */
-        ok = ok && (u > 0.f && u < wlim && v > 0.f && v < hlim);
+        /* memory-safe even when the sample is outside (result discarded through ok): clamped into the image -- the footprint
+         * records are edge-clamped themselves, so the last row / column is a valid record */
+        const float uc = __builtin_amdgcn_fmed3f(u, kLo, wlim), vc = __builtin_amdgcn_fmed3f(v, kLo, hlim);
+        ok = ok && (uc == u && vc == v);                                          /* the strict interior test (see above) */
         q.gu = 0.f; q.gv = 0.f;
         if (MODE != PASS_COLOR) {
             /* the point advanced by `step` along its ray (patch_sampler.cc:101-113); the derivative's 1 / stepSize folded in */
@@ -678,10 +686,6 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             const float u1 = (sx + l2 * vx) * iz1 - 0.5f, v1 = (sy + l2 * vy) * iz1 - 0.5f;
             q.gu = (u1 - u) * dnorm; q.gv = (v1 - v) * dnorm;
         }
-        /* memory-safe even when the sample is outside (result discarded through ok): clamped into the image -- the footprint
-         * records are edge-clamped themselves, so the last row / column is a valid record.  A sample that passes the
-         * interior test is not moved by the clamp (v_med3_f32: a NaN coordinate comes out as 0). */
-        const float uc = __builtin_amdgcn_fmed3f(u, 0.f, wlim), vc = __builtin_amdgcn_fmed3f(v, 0.f, hlim);
         /* the bilinear weights: x - floor(x) in one instruction (v_fract_f32: the same value as the subtraction, which is
          * exact); the texel indices by truncation (the coordinates are not negative) */
         q.fx = __builtin_amdgcn_fractf(uc); q.fy = __builtin_amdgcn_fractf(vc);
@@ -2197,7 +2201,10 @@ __device__ __forceinline__ unsigned front_scan(unsigned v, int tid, unsigned& to
 }
 
 template <int NV, bool TEAM>
-__global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu((MI_FRONT_WAVES >= 8 ? MI_FRONT_WAVES / 4 : 1), (MI_FRONT_WAVES >= 8 ? MI_FRONT_WAVES / 4 : 2)))) void k_front(FrontArgs t) {
+#ifndef MI_FRONT_SOLO_OCC
+#define MI_FRONT_SOLO_OCC (MI_FRONT_WAVES >= 8 ? MI_FRONT_WAVES / 4 : 2)
+#endif
+__global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu((TEAM ? (MI_FRONT_WAVES >= 8 ? MI_FRONT_WAVES / 4 : 1) : MI_FRONT_SOLO_OCC), (TEAM ? (MI_FRONT_WAVES >= 8 ? MI_FRONT_WAVES / 4 : 2) : MI_FRONT_SOLO_OCC)))) void k_front(FrontArgs t) {
     typedef typename LatLay<NV>::type LL;
     typedef __attribute__((address_space(1))) unsigned long long* gmail_t;
     typedef __attribute__((address_space(1))) unsigned* gflag_t;
