@@ -66,38 +66,48 @@ def collect(prefix):
     return acc, regs
 
 
+HEAD = ["| kernel | launches | FETCH MB | WRITE MB | L2 hit % | VALU-active % of wave cycles | wave-cycles/VALU inst | wait-any % | LDS-active % | LDS bank-conflict % of LDS-active | L1 accesses | L1->L2 read req | L1 pending-stall % of L1 busy | VGPR/AGPR/SGPR | LDS B | scratch B |",
+        "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+
+
+def table(acc, regs):
+    out = []
+    for k in sorted(acc, key=lambda k: -acc[k].get("FETCH_SIZE", [0, 0])[0]):
+        c = acc[k]
+        if k.startswith("__amd"):
+            continue
+        def avg(n):
+            return c[n][0] / c[n][1] if n in c and c[n][1] else None
+        n = max(v[1] for v in c.values())
+        hit, miss = avg("TCC_HIT_sum"), avg("TCC_MISS_sum")
+        act = avg("SQ_ACTIVE_INST_VALU")
+        wc, valu, wany = avg("SQ_WAVE_CYCLES"), avg("SQ_INSTS_VALU"), avg("SQ_WAIT_ANY")
+        lds_a, lds_c = avg("SQ_ACTIVE_INST_LDS"), avg("SQ_LDS_BANK_CONFLICT")
+        f = lambda v, s=1.0, fmt="%.3f": "-" if v is None else fmt % (v * s)
+        l1a, l1r, l1p, l1g = avg("TCP_TOTAL_CACHE_ACCESSES_sum"), avg("TCP_TCC_READ_REQ_sum"), avg("TCP_PENDING_STALL_CYCLES_sum"), avg("TCP_GATE_EN1_sum")
+        out.append("| `%s` | %d | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
+            k, n, f(avg("FETCH_SIZE"), FETCH_CORR / 1024), f(avg("WRITE_SIZE"), 1 / 1024),
+            "-" if hit is None or hit + miss == 0 else "%.1f" % (100 * hit / (hit + miss)),
+            "-" if not wc or act is None else "%.1f" % (100 * act / wc),
+            "-" if not valu or wc is None else "%.2f" % (wc / valu),
+            "-" if not wc or wany is None else "%.1f" % (100 * wany / wc),
+            "-" if not wc or lds_a is None else "%.1f" % (100 * lds_a / wc),
+            "-" if not lds_a or lds_c is None else "%.1f" % (100 * lds_c / lds_a),
+            "-" if l1a is None else "%.3g" % l1a, "-" if l1r is None else "%.3g" % l1r,
+            "-" if not l1g or l1p is None else "%.1f" % (100 * l1p / l1g),
+            "/".join(regs[k][:3]), regs[k][3], regs[k][4]))
+    return out
+
+
 acc, regs = collect("pmc")
 lines = ["# %s -- PMC counters of the C3 bench (rocprofv3 --pmc, one counter group per run; tools/collect_profiles.sh)" % tag, "",
-         "Per launch averages over `python bench.py --steps 2 --warmup 1 --streams 1 --steps-per-call 1` (3 reconstructions",
-         "of the 20-view scene).  FETCH MB = FETCH_SIZE x 1024 x 2 (every fabric read request moves 128 B, the counter tallies",
+         "FETCH MB = FETCH_SIZE x 1024 x 2 (every fabric read request moves 128 B, the counter tallies",
          "64 B: calibrated on known byte counts in this kernel's own access pattern, profiles/r2_pmc_calibration.md);",
-         "WRITE MB = WRITE_SIZE x 1024 (exact).  k_tail averages include the empty rounds enqueued blind.", "",
-         "| kernel | launches | FETCH MB | WRITE MB | L2 hit % | VALU-active % of wave cycles | wave-cycles/VALU inst | wait-any % | LDS-active % | LDS bank-conflict % of LDS-active | L1 accesses | L1->L2 read req | L1 pending-stall % of L1 busy | VGPR/AGPR/SGPR | LDS B | scratch B |",
-         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
-for k in sorted(acc, key=lambda k: -acc[k].get("FETCH_SIZE", [0, 0])[0]):
-    c = acc[k]
-    if k.startswith("__amd"):
-        continue
-    def avg(n):
-        return c[n][0] / c[n][1] if n in c and c[n][1] else None
-    n = max(v[1] for v in c.values())
-    hit, miss = avg("TCC_HIT_sum"), avg("TCC_MISS_sum")
-    act = avg("SQ_ACTIVE_INST_VALU")
-    wc, valu, wany = avg("SQ_WAVE_CYCLES"), avg("SQ_INSTS_VALU"), avg("SQ_WAIT_ANY")
-    lds_a, lds_c = avg("SQ_ACTIVE_INST_LDS"), avg("SQ_LDS_BANK_CONFLICT")
-    f = lambda v, s=1.0, fmt="%.3f": "-" if v is None else fmt % (v * s)
-    l1a, l1r, l1p, l1g = avg("TCP_TOTAL_CACHE_ACCESSES_sum"), avg("TCP_TCC_READ_REQ_sum"), avg("TCP_PENDING_STALL_CYCLES_sum"), avg("TCP_GATE_EN1_sum")
-    lines.append("| `%s` | %d | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
-        k, n, f(avg("FETCH_SIZE"), FETCH_CORR / 1024), f(avg("WRITE_SIZE"), 1 / 1024),
-        "-" if hit is None or hit + miss == 0 else "%.1f" % (100 * hit / (hit + miss)),
-        "-" if not wc or act is None else "%.1f" % (100 * act / wc),
-        "-" if not valu or wc is None else "%.2f" % (wc / valu),
-        "-" if not wc or wany is None else "%.1f" % (100 * wany / wc),
-        "-" if not wc or lds_a is None else "%.1f" % (100 * lds_a / wc),
-        "-" if not lds_a or lds_c is None else "%.1f" % (100 * lds_c / lds_a),
-        "-" if l1a is None else "%.3g" % l1a, "-" if l1r is None else "%.3g" % l1r,
-        "-" if not l1g or l1p is None else "%.1f" % (100 * l1p / l1g),
-        "/".join(regs[k][:3]), regs[k][3], regs[k][4]))
+         "WRITE MB = WRITE_SIZE x 1024 (exact).  Per launch averages.", "",
+         "## One lone 20-view call: `python bench.py --steps 2 --warmup 1 --streams 1 --steps-per-call 1` (3 reconstructions of the scene)", ""] + HEAD + table(acc, regs)
+accd, regsd = collect("pmcd")
+if accd:
+    lines += ["", "## The driver's plan: `python bench.py --steps 20 --warmup 1` (4 host threads x 5 steps per call: two 400-view batches)", ""] + HEAD + table(accd, regsd)
 
 # HBM-side bytes per STEP of the two optimise kernel families, at both call plans (bench.py divides by ITS launch
 # counts: rocprofv3 also sees the empty tail rounds that the host enqueues blind)
