@@ -163,6 +163,25 @@ template <> struct ViewPack<8> { typedef unsigned long long type; static constex
 
 template <int LPV, int NV> struct Lay;
 
+/* The value of the lane 16 / 32 lanes away (lane ^ 16, lane ^ 32): exchanges ACROSS the DPP rows of a wavefront, which DPP itself
+ * cannot do.  gfx950 has them as VALU instructions -- v_permlane16_swap_b32 vdst, src: the odd rows of vdst and the even rows
+ * of src change places (with both = v the partner row's value arrives in the second result for the even rows 0, 2 and in the
+ * first for the odd rows 1, 3); v_permlane32_swap_b32: the upper half of vdst and the lower half of src change places -- no
+ * trip through the scalar unit (v_readlane + its hazards) or the LDS crossbar (-DMI_T_SHFL: ds_bpermute). */
+#ifdef MI_T_SHFL
+__device__ __forceinline__ int x16(int v) { return __shfl_xor(v, 16); }
+__device__ __forceinline__ int x32(int v) { return __shfl_xor(v, 32); }
+#else
+__device__ __forceinline__ int x16(int v) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 16u) ? r[0] : r[1]);
+}
+__device__ __forceinline__ int x32(int v) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 32u) ? r[0] : r[1]);
+}
+#endif
+
 /* ---- four view slots (nrReconNeighbors <= 4, the reference's default) */
 #ifdef MI_TRANSPOSED
 /*
@@ -176,22 +195,6 @@ template <int LPV, int NV> struct Lay;
  * sums per pass, a few ballots per turn -- crosses DPP rows here: v_permlane16_swap / v_permlane32_swap (gfx950), or an LDS
  * permute (-DMI_T_SHFL).
  */
-#ifdef MI_T_SHFL
-__device__ __forceinline__ int x16(int v) { return __shfl_xor(v, 16); }
-__device__ __forceinline__ int x32(int v) { return __shfl_xor(v, 32); }
-#else
-/* v_permlane16_swap_b32 vdst, src: the odd rows of vdst and the even rows of src change places; with both = v the partner
- * row's value arrives in the second result for the even rows (0, 2) and in the first for the odd rows (1, 3) */
-__device__ __forceinline__ int x16(int v) {
-    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-    return (int)((threadIdx.x & 16u) ? r[0] : r[1]);
-}
-/* v_permlane32_swap_b32 vdst, src: the upper half of vdst and the lower half of src change places */
-__device__ __forceinline__ int x32(int v) {
-    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-    return (int)((threadIdx.x & 32u) ? r[0] : r[1]);
-}
-#endif
 template <> struct Lay<1, 4> {
     static constexpr int LPV = 1, NV = 4, PATCHES = 16;
     static constexpr bool LAT = false;
@@ -298,7 +301,12 @@ template <> struct Lay<16, 4> {
         v &= dpp_xor1(v); v &= dpp_xor2(v); v &= dpp_half_mirror(v); v &= dpp_mirror(v);
         return v != 0;
     }
-    /* inputs are already uniform within each row: four readlanes instead of LDS permutes */
+    /* inputs are already uniform within each row: four readlanes instead of LDS permutes.  (-DMI_LAT_PERMLANE: the same sums,
+     * (v0 + v1) + (v2 + v3), by two cross-row exchanges x16 / x32 -- v_permlane16/32_swap -- instead of the trip through the
+     * scalar unit.  Measured, same lease: the front of a lone 20-view call 14.8-15.1 ms against 13.4 with the readlanes, the
+     * front of a 400-view batch 2.09 against 1.85 ms per step: the swaps sit in the turn's dependent chain and are slower than
+     * v_readlane + s_nop.) */
+#ifndef MI_LAT_PERMLANE
     __device__ static __forceinline__ float patch_sum(float v) {
         const int i = __float_as_int(v);
         return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16)))
@@ -312,6 +320,18 @@ template <> struct Lay<16, 4> {
         const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
         return (r0 + r1) + (r2 + r3);
     }
+#else
+    __device__ static __forceinline__ float patch_sum(float v) {
+        v = fadd_i(v, x16(__float_as_int(v)));
+        v = fadd_i(v, x32(__float_as_int(v)));
+        return v;
+    }
+    __device__ static __forceinline__ double patch_sum(double v) {
+        v += dmov(v, x16);
+        v += dmov(v, x32);
+        return v;
+    }
+#endif
     /* sum over all 64 lanes (inputs arbitrary) */
     __device__ static __forceinline__ float wave_sum(float v) { return patch_sum(view_sum(v)); }
     __device__ static __forceinline__ unsigned long long patch_or(unsigned long long v) {
