@@ -224,6 +224,7 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 #define MI_MERGE_SMALL_CALL 48      /* reference views: below this a call waits MI_MERGE_WINDOW_US for company, ... */
 #define MI_MERGE_WINDOW_US 1000
 #define MI_MERGE_WINDOW_BIG_US 3000 /* ... from this size on this long: ~2 % of such a call's own time (see mi_dmrecon_reconstruct) */
+#define MI_SINGLE_FOLLOW 4         /* follow-up launches of one attempt per entry in a large round (BatchRun::bulk_rounds) */
 #define MI_FOLLOW_LISTS 8          /* follow-up list counters per round (five in use: BatchRun::bulk_rounds) */
 #define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
 #define MI_SPEC_ROUNDS 400000u      /* throughput rounds below this many entries try an entry's candidate hypotheses at the same time */
@@ -1710,9 +1711,10 @@ int BatchRun::bulk_rounds(bool& to_tail) {
      * are enqueued next to the speculative ones and look at the size on the device. */
     const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPEC_ROUNDS"); return e ? (unsigned)std::max(0L, std::atol(e)) : MI_SPEC_ROUNDS; }();
     const unsigned spec_cap = 2u * SPEC_MAX;
-    /* MI_DMRECON_SINGLE_FOLLOW=0 (read per call): the follow-up list of a large round in ONE launch, all remaining attempts of
-     * an entry in a row (round 4's form; same maps and counters) */
-    const bool SINGLE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_SINGLE_FOLLOW"); return !e || std::atoi(e) != 0; }();
+    /* MI_DMRECON_SINGLE_FOLLOW=<n> (read per call): 0 = the follow-up list of a large round in ONE launch, all remaining attempts
+     * of an entry in a row (round 4's form); n = 1 .. 3: n single-attempt follow-up launches, then one for the rest; 4: every
+     * further attempt a launch of its own.  Same maps and counters. */
+    const int SINGLE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_SINGLE_FOLLOW"); return e ? std::atoi(e) : MI_SINGLE_FOLLOW; }();
     if (SPEC_MAX > 0 && c->bs.d_spec.reserve(4 * (size_t)spec_cap)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(speculative records) failed");
     /* The rounds are enqueued WITHOUT waiting for their list sizes: every kernel of a round reads its size on the device
      * (k_generate also decides there which layout a view's entries go to), the grids come from the sizes of the last round
@@ -1779,9 +1781,18 @@ int BatchRun::bulk_rounds(bool& to_tail) {
                  * last launch's own list stays empty) */
                 unsigned* fl[5] = {c->bs.d_follow.p, c->bs.d_follow.p + total_px, c->bs.d_follow.p + 2 * total_px, c->bs.d_follow.p + 3 * total_px, c->bs.d_follow.p};
                 unsigned div = 4;
-                for (int k = 0; k < 4; ++k, div *= 4) {
+                /* (MI_DMRECON_SINGLE_FOLLOW=<n>, 1 <= n < 4: n single-attempt follow-up launches, then ONE launch that runs what
+                 * is left of its entries' attempts in a row -- a launch lasts a wavefront-life however few entries it has, and the
+                 * third and fourth attempts are a few thousandths of the list) */
+                const int n_single = SINGLE_FOLLOW >= 4 ? 4 : std::max(1, SINGLE_FOLLOW);
+                for (int k = 0; k < n_single; ++k, div *= 4) {
                     D->optimize(S, 1, std::max(64u, waves / div), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
                                 c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[k], fcnt + k, fl[k + 1], fcnt + k + 1);
+                    ++n_launch;
+                }
+                if (n_single < 4) {
+                    D->optimize(S, 1, std::max(64u, waves / div), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
+                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[n_single], fcnt + n_single, nullptr, nullptr);
                     ++n_launch;
                 }
             } else {

@@ -377,6 +377,7 @@ def test_maps_do_not_depend_on_the_batch(gpu_ctx, g1_scene, h1_scene, monkeypatc
         # runs an entry's remaining attempts in a row)
         for env in ({"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0"}, {"MI_DMRECON_SPEC_ROUNDS": "0"},
                     {"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0", "MI_DMRECON_SINGLE_FOLLOW": "0"},
+                    {"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0", "MI_DMRECON_SINGLE_FOLLOW": "1"},
                     {"MI_DMRECON_SPEC_ROUNDS": "1000000"}, {"MI_DMRECON_SPEC_ROUNDS": "700", "MI_DMRECON_ONE_LAUNCH": "0"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
