@@ -56,7 +56,9 @@ struct MiDeviceApi {
                        float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
     void (*generate)(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work, DevEntry* work_lat,
                      unsigned* round_work, unsigned* round_work_lat, unsigned* view_count, unsigned* view_mode,
-                     unsigned handover, int round, unsigned* items, unsigned* round_items);
+                     unsigned handover, int round, unsigned* items, unsigned* round_items,
+                     int self_round /* 1: the entries are the pixels written in round - 1 themselves (the seed re-optimisation
+                                     * round, DevSettings::self_round), not their neighbours */);
     void (*tail)(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevView* views, const float* lut,
                  const DevSettings& st, const DevEntry* prev_work, const DevResult* prev_results, DevEntry* work,
                  DevResult* results, unsigned* round_work, int round, DevCounters* counters, bool speculative);

@@ -1555,6 +1555,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
     }
     more = false;
     int attempts = 0;
+    const bool self_round = a.st.self_round != 0 && !explicit_hyp;
     for (int t = 0; t < 4; ++t) {
         float hd, hi, hj; unsigned long long hv;
         const unsigned tried_before = tried;
@@ -1562,6 +1563,10 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
             if (t > 0) break;
             const DevHyp h = a.hyp[e];
             hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = view_set(h.views, h.views_hi);
+        } else if (self_round) {
+            /* the seed re-optimisation round: the pixel's own converged state is the one hypothesis (DevSettings::self_round) */
+            if (t > 0) break;
+            hd = GF(job->depth + pix); hi = GF(job->dz + 2 * pix); hj = GF(job->dz + 2 * pix + 1); hv = load_view_set<L::NV>(job, false, pix);
         } else {
             const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
             int bi = -1; float bc = 0.f;
@@ -1653,8 +1658,11 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
     const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
     /* (confidences are >= 0: a runner-up of -1 stands for "none" -- the pop-time test best > bc2 then holds by itself) */
     int bi = -1; float bc = 0.f, bc2 = -1.f;
+    const bool self_round = a.st.self_round != 0;      /* the seed re-optimisation round: the one candidate is the pixel itself */
+    if (self_round && !(tried & 1u)) { bi = 4; bc = own; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        if (self_round) break;
         if ((tried >> k) & 1u) continue;
         const float c = GF(job->conf + nb[k]);
         const bool use = GI(job->upd + nb[k]) == a.round - 1 && (own < c - 0.05f || own == 0.f);
@@ -1670,7 +1678,7 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
         if (!resume && writer) a.results[e] = z;
         return;
     }
-    const int p = bi == 0 ? nb[0] : bi == 1 ? nb[1] : bi == 2 ? nb[2] : nb[3];
+    const int p = bi == 0 ? nb[0] : bi == 1 ? nb[1] : bi == 2 ? nb[2] : bi == 3 ? nb[3] : pix;
     const float hd = GF(job->depth + p), hi = GF(job->dz + 2 * p), hj = GF(job->dz + 2 * p + 1);
     const unsigned long long hv = load_view_set<L::NV>(job, false, p);
     PatchResult r;
@@ -1681,7 +1689,7 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
         return;
     }
     ++n_patch;
-    tried |= 1u << bi;
+    tried |= bi == 4 ? 1u : (1u << bi);
     const bool accept = r.conf > 0.f && best < r.conf;         /* dmrecon.cc:378,391 */
     if (accept) best = r.conf;
     more = !(best > bc2);
@@ -1860,7 +1868,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((MI_FW >= 
             if (GI(job->upd + nb[k]) == a.round - 1 && (own < c[k] - 0.05f || own == 0.f)) elig |= 1u << k;
         }
         int n_cand = 0, dir = -1; float bc = 0.f;
-        {
+        if (a.st.self_round) { n_cand = 1; if (s == 0) { dir = 4; bc = own; } }       /* the seed re-optimisation round: the pixel itself */
+        else {
             unsigned left = elig;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1873,7 +1882,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((MI_FW >= 
         }
         if (writer && s == 0) rec->n_cand = n_cand;
         if (s >= n_cand) continue;
-        const int p = dir == 0 ? nb[0] : dir == 1 ? nb[1] : dir == 2 ? nb[2] : nb[3];
+        const int p = dir == 0 ? nb[0] : dir == 1 ? nb[1] : dir == 2 ? nb[2] : dir == 3 ? nb[3] : pix;
         const float hd = GF(job->depth + p), hi = GF(job->dz + 2 * p), hj = GF(job->dz + 2 * p + 1);
         const unsigned long long hv = load_view_set<L::NV>(job, false, p);
         PatchResult r; unsigned ne = 0, np = 0;
@@ -2728,6 +2737,8 @@ struct SweepArgs {
      * hypothesis) pair -- entry index << 2 | rank -- so that every attempt of the round gets a quad of its own; null: none */
     unsigned* items;
     unsigned* round_items; /* [round] = number of items */
+    int self_round;        /* 1: the seed re-optimisation round -- the entries are the pixels written in the round before THEMSELVES
+                            * (DevSettings::self_round), one candidate each */
 };
 
 /* Which pixels must be (re)optimised this round: the push rule of dmrecon.cc:400-431 as a pull.
@@ -2791,12 +2802,15 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
             const int pix = y * W + x;
             const float own = job->conf[pix];
             const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
+            if (a.self_round) { if (job->upd[pix] == a.round - 1) { any = true; cnt = 1; } }
+            else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (job->upd[nb[k]] == a.round - 1) {
-                    const float c = job->conf[nb[k]];
-                    if (own < c - 0.05f || own == 0.f) { any = true; ++cnt; }
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (job->upd[nb[k]] == a.round - 1) {
+                        const float c = job->conf[nb[k]];
+                        if (own < c - 0.05f || own == 0.f) { any = true; ++cnt; }
+                    }
+            }
         }
         if (want_items && any) { ipos[t] = atomicAdd(&s_items, cnt); cands |= cnt << (3 * t); }
         const unsigned long long m = __ballot(any);
@@ -3169,8 +3183,9 @@ static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* v
 
 static void launch_generate(hipStream_t s, const DevJob* jobs, int n_jobs, int max_tiles, DevEntry* work, DevEntry* work_lat,
                         unsigned* round_work, unsigned* round_work_lat, unsigned* view_count, unsigned* view_mode,
-                        unsigned handover, int round, unsigned* items, unsigned* round_items) {
+                        unsigned handover, int round, unsigned* items, unsigned* round_items, int self_round) {
     SweepArgs a;
+    a.self_round = self_round;
     a.jobs = jobs; a.work = work; a.work_lat = work_lat; a.round_work = round_work; a.round_work_lat = round_work_lat;
     a.view_count = view_count; a.view_mode = view_mode; a.handover = handover; a.n_jobs = n_jobs; a.round = round;
     a.items = items; a.round_items = round_items;

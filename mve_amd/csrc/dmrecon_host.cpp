@@ -1070,6 +1070,7 @@ DevSettings dev_settings(const mi_dmrecon_settings* st) {
     d.minNCC = st->minNCC; d.minParallax = st->minParallax; d.acceptNCC = st->acceptNCC;
     d.minRefineDiff = st->minRefineDiff; d.maxIterations = st->maxIterations; d.K = st->nrReconNeighbors;
     d.useColorScale = st->useColorScale;
+    d.self_round = 0;
     return d;
 }
 
@@ -1726,13 +1727,23 @@ int BatchRun::bulk_rounds(bool& to_tail) {
     struct Pending { int round; size_t ev_thr, ev_lat; };
     Pending pend[2]; int n_pend = 0;
     bool stop = false;
+    /* MI_DMRECON_SEED_REOPT=1 (read per call; default 0): the reference pushes a seed's OWN pixel (dmrecon.cc:316-326) and, when it
+     * pops it, re-optimises it from its converged state; only if that strictly raises its confidence is the pixel rewritten
+     * and its four neighbours pushed (:365-398).  With the switch, round 1 is that re-optimisation for every pixel the seeds
+     * wrote (the entries are those pixels themselves, their own state the hypothesis, the same strict acceptance), and
+     * only the pixels it rewrites are sources of round 2.  Default: every seed propagates at once (measured parity-neutral
+     * in round 2 and again here, tests/test_gpu_parity.py::test_seed_reoptimisation_round). */
+    const bool SEED_REOPT = [] { const char* e = std::getenv("MI_DMRECON_SEED_REOPT"); return e && std::atoi(e) != 0; }();
     auto enqueue = [&](int r) -> int {
         /* a round that will not fill the GPU several times over: speculative launches for lists below spec_cap, the plain
          * ones (below) only above it */
         const bool spec = SPEC_MAX > 0 && known_thr < SPEC_MAX;
+        const bool self = SEED_REOPT && r == 1;
+        DevSettings ds = this->ds;                                   /* (shadows the member for this round's launches) */
+        ds.self_round = self ? 1 : 0;
         ev.begin(S, EventLog::SWEEP, 0);
         D->generate(S, c->bs.d_jobs.p, nj, max_tiles, c->bs.d_work.p, c->bs.d_work2.p, c->bs.d_round_work_t.p, c->bs.d_round_work.p,
-                    d_vcount, d_vmode, handover, r, spec ? c->bs.d_follow.p : nullptr, c->bs.d_round_items.p);
+                    d_vcount, d_vmode, handover, r, spec ? c->bs.d_follow.p : nullptr, c->bs.d_round_items.p, self ? 1 : 0);
         ev.end(S);
         const unsigned* n_thr_p = c->bs.d_round_work_t.p + r; const unsigned* n_lat_p = c->bs.d_round_work.p + r;
         const unsigned est = std::max(2u * known_thr, 65536u);

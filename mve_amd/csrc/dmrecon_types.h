@@ -94,6 +94,10 @@ struct DevJob {
 struct DevSettings {
     float minNCC, minParallax, acceptNCC, minRefineDiff;
     int32_t maxIterations, K, useColorScale;
+    /* Not a setting of the reference: 1 in the ONE round in which every pixel written by a seed is re-optimised from its own
+     * converged state, as the reference does when it pops a seed (it pushes the seed's OWN pixel, dmrecon.cc:316-326, and
+     * propagates from it only if that re-optimisation strictly raised its confidence, :365-398) -- MI_DMRECON_SEED_REOPT. */
+    int32_t self_round;
 };
 
 /* Work list entry + result of one patch optimisation attempt chain. */

@@ -735,6 +735,49 @@ def test_hard_scene_maps_vs_reference(gpu_ctx, h1, h1_scene):
     assert stats["n_view_replaced"] > 50 and stats["n_iter14"] >= 1
 
 
+def test_seed_reoptimisation_round(gpu_ctx, g1, g1_scene, h1, h1_scene, monkeypatch):
+    """MI_DMRECON_SEED_REOPT=1: the reference's seed semantics -- a seed's OWN pixel is pushed (dmrecon.cc:316-326), re-optimised
+    from its converged state when popped, and propagates only if that strictly raised its confidence (:365-398) -- as one extra
+    round: round 1 re-optimises every pixel the seeds wrote, only the pixels it rewrites are sources of round 2.  The default
+    (every seed propagates at once) is a deliberate deviation; this is the switch to compare them.  Both meet the same
+    map-level tolerances against the reference's own maps; with the switch the forms of a round are still bit-identical to
+    each other, there is one round more, one attempt more per seed pixel, and some seeds no longer propagate."""
+    for scene, fix, views, bounds in ((g1_scene, g1, (0,), None), (h1_scene, h1, (0, 8), (0.985, 3e-2, 0.15))):
+        gpu_ctx.load_scene(scene)
+        st = api.Settings()
+        base = gpu_ctx.reconstruct(st, list(views), want_views=True)
+        s0 = dict(gpu_ctx.last_stats)
+        monkeypatch.setenv("MI_DMRECON_SEED_REOPT", "1")
+        got = gpu_ctx.reconstruct(st, list(views), want_views=True)
+        s1 = dict(gpu_ctx.last_stats)
+        assert s1["n_seeds_ok"] == s0["n_seeds_ok"] and s1["n_seeds"] == s0["n_seeds"]
+        for v, r, b in zip(views, got, base):
+            m = map_parity(r["depth"], r["conf"], fix["s0v%d_depth" % v], fix["s0v%d_conf" % v])
+            mb = map_parity(b["depth"], b["conf"], fix["s0v%d_depth" % v], fix["s0v%d_conf" % v])
+            print("seed re-optimisation, view %d: with %s / without %s" % (v, {k: round(x, 5) for k, x in m.items()}, {k: round(x, 5) for k, x in mb.items()}))
+            if bounds is None:
+                assert_map_parity(m)
+            else:
+                assert m["iou"] >= bounds[0] and m["rel_med"] <= 1e-3 and m["rel_p99"] <= bounds[1] and m["conf_p99"] <= bounds[2], m
+            assert not np.array_equal(r["depth"], b["depth"])            # it IS another propagation
+        # the forms of a round with the switch on: plain launches / one launch / speculative, host-visible rounds only
+        for env in ({"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0"}, {"MI_DMRECON_SPEC_ROUNDS": "0"},
+                    {"MI_DMRECON_SPEC_ROUNDS": "1000000"}, {"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0", "MI_DMRECON_SINGLE_FOLLOW": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            two = gpu_ctx.reconstruct(st, list(views), want_views=True)
+            s2 = dict(gpu_ctx.last_stats)
+            for k in env:
+                monkeypatch.delenv(k)
+            for a, b in zip(two, got):
+                for k in ("depth", "conf", "dz", "normal", "views"):
+                    assert np.array_equal(a[k], b[k]), (k, env)
+            for k in ("n_patch", "n_eval", "n_filled", "n_rounds"):
+                assert s2[k] == s1[k], (k, env, s2[k], s1[k])
+        monkeypatch.delenv("MI_DMRECON_SEED_REOPT")
+    gpu_ctx.load_scene(g1_scene)
+
+
 # ---- apps/dmrecon --filter-width: 3 x 3, 7 x 7, 9 x 9 and 11 x 11 windows ------------------------------------
 
 @pytest.mark.parametrize("fw", [3, 7, 9, 11])

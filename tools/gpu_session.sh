@@ -1,17 +1,15 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): round 5, session J -- how many single-attempt follow-up launches a large round should have.
+# Runs ON THE GPU BOX (through gpurun): round 5, session K -- the seed re-optimisation round (MI_DMRECON_SEED_REOPT=1).
 export TMPDIR=/tmp
-O=gpurun_out/r5j
+O=gpurun_out/r5k
 mkdir -p $O
-line() { python - "$1" <<'PY'
-import json, sys
-j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print("%s: value %.1f %s | bulk frac %.3f" % (sys.argv[1], j["value"], [round(v) for v in j["repeats"]], j["roofline"]["bulk_kernel_frac"]))
+timeout -s KILL 500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -s -k "seed_reopt or batch or more_seeds" > $O/pytest.log 2>&1; grep -E "seed re-opt|passed|failed|Error|assert" $O/pytest.log | head -20
+AB="--steps 20 --warmup 3 --repeats 2 --distinct-scenes 0 --one-call-n 10"
+MI_DMRECON_SEED_REOPT=1 timeout -s KILL 400 python bench.py $AB > $O/bench_reopt.json 2> $O/bench_reopt.err
+python - <<PY
+import json
+j = json.loads(open("$O/bench_reopt.json").read().strip().splitlines()[-1])
+p = j["parity"]
+print("reopt: value %.1f one_call %.2f ms | parity" % (j["value"], j["one_call"]["ms_per_call"]), {k: p[k] for k in ("min_fill_iou", "max_rel_depth_median", "max_rel_depth_p99", "max_conf_abs_p99", "within_bounds")})
+print(p["fill_iou_per_view"]); print("mean fill", j["config"]["mean_fill"], "n_patch", j["roofline"]["n_patch"], "n_eval", j["roofline"]["n_eval"])
 PY
-}
-timeout -s KILL 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "batch" 2>&1 | tail -2
-AB="--steps 20 --warmup 5 --repeats 3 --no-cpu-baseline --distinct-scenes 0 --no-one-call"
-for E in 4 1 2 0 4; do
-  MI_DMRECON_SINGLE_FOLLOW=$E MI_BENCH_REGION_LOG=1 timeout -s KILL 300 python bench.py $AB > $O/bench_sf$E.json 2> $O/bench_sf$E.err
-  line $O/bench_sf$E.json; grep "^region" $O/bench_sf$E.err | tail -1
-done
