@@ -33,6 +33,9 @@ extern "C" {
 #define MI_DMRECON_EDEVICE      -3   /* HIP runtime error */
 #define MI_DMRECON_ECANCELLED   -4   /* progress.cancelled observed (dmrecon.cc:101-105) */
 #define MI_DMRECON_EFOOTPRINT   -5   /* std::out_of_range("Negative pixel footprint") (patch_sampler.cc:78-82) */
+#define MI_DMRECON_ENOIMAGE     -6   /* a view the global view selection picked has no image (it was registered with its camera
+                                      * only, mi_dmrecon_set_view with pixels = NULL): the reference fails there with the
+                                      * exception of the image's loader (dmrecon.cc:236-240 loads the selected views) */
 
 #define MI_DMRECON_MAX_GLOBAL_VIEWS 64   /* Settings::globalVSMax (apps/dmrecon -n, default 20) */
 #define MI_DMRECON_MAX_LOCAL_VIEWS   8   /* Settings::nrReconNeighbors (apps/dmrecon --local-neighbors, default 4) */
@@ -176,6 +179,12 @@ void* mi_dmrecon_ctx_stream(mi_dmrecon_ctx* ctx);
  * builds the Gaussian pyramid on the device (image_tools.h:619-690) and keeps every level resident in HBM. */
 int  mi_dmrecon_set_view(mi_dmrecon_ctx* ctx, int32_t view_id, const mi_dmrecon_camera* cam,
                          int32_t width, int32_t height, int32_t channels, const uint8_t* pixels);
+/* pixels = NULL registers the view with its camera and image size ONLY: the reference creates a SingleView for every view
+ * with a valid camera and an image of the embedding (dmrecon.cc:62-79) and loads images lazily -- a view whose image cannot be
+ * decoded is still a candidate of everybody's global view selection, and only a reconstruction that SELECTS it fails
+ * (dmrecon.cc:236-240).  Such a view takes part in mi_dmrecon_global_view_selection as any other; a reference view that
+ * selects it ends with MI_DMRECON_ENOIMAGE (its own status; the others of a batch finish); as a reference view itself it is
+ * "Invalid master view". */
 /* Same, without waiting: the host->device copy, the RGBA pack and the pyramid kernels are only enqueued.
  * `pixels` must stay valid (and should be page-locked, mi_dmrecon_host_alloc, for the copy to be truly
  * asynchronous) until mi_dmrecon_sync() -- the staging path for scenes whose level-0 images do not fit
@@ -206,7 +215,8 @@ int  mi_dmrecon_global_view_selection(mi_dmrecon_ctx* ctx, const mi_dmrecon_sett
  * globalViewSelection, processFeatures, processQueue).  The views are independent; batching
  * them fills the GPU.  maps[i] / progress[i] belong to ref_views[i]; progress may be NULL.
  * Views end individually, as mvs::DMRecon instances do: status_out[i] (may be NULL) receives the view's own
- * outcome -- 0, MI_DMRECON_EGVS, MI_DMRECON_EFOOTPRINT (patch_sampler.cc:78-82 throws for that view only) or
+ * outcome -- 0, MI_DMRECON_EGVS, MI_DMRECON_ENOIMAGE (a selected view was registered without pixels),
+ * MI_DMRECON_EFOOTPRINT (patch_sampler.cc:78-82 throws for that view only) or
  * MI_DMRECON_ECANCELLED (progress[i].cancelled was set, before or during the run: dmrecon.cc:101-105,353) -- and
  * the maps of a view that did not finish are left untouched.  progress[i].filled counts that view's pixels.
  * Return value: 0 if at least one view finished; with a single view (or when every view failed) the failing

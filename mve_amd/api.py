@@ -34,7 +34,7 @@ def local_view_channels(n_local: int) -> int:
     return 8 if n_local > 4 else 4
 
 
-E_INVAL, E_GVS, E_DEVICE, E_CANCELLED, E_FOOTPRINT = -1, -2, -3, -4, -5
+E_INVAL, E_GVS, E_DEVICE, E_CANCELLED, E_FOOTPRINT, E_NOIMAGE = -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
     "mi_dmrecon_device_count", "mi_dmrecon_local_view_channels", "mi_dmrecon_last_error", "mi_dmrecon_settings_default",
@@ -345,6 +345,19 @@ class Context:
             img = img[:, :, None]
         fn = self._L.mi_dmrecon_set_view_async if asynchronous else self._L.mi_dmrecon_set_view
         rc = fn(self._h, view_id, ctypes.byref(c), img.shape[1], img.shape[0], img.shape[2], _ptr(img))
+        if rc != 0:
+            _raise(rc)
+        self.n_views = max(self.n_views, view_id + 1)
+
+    def set_view_camera_only(self, view_id: int, cam, width: int, height: int):
+        """Registers a view with its camera and image size only (mi_dmrecon_set_view with pixels = NULL): a candidate of the
+        view selections whose image could not be loaded; a reference view that selects it ends with E_NOIMAGE."""
+        c = CCamera()
+        c.flen, c.paspect = cam.flen, cam.paspect
+        c.ppoint[:] = list(cam.ppoint)
+        c.rot[:] = list(cam.rot)
+        c.trans[:] = list(cam.trans)
+        rc = self._L.mi_dmrecon_set_view(self._h, view_id, ctypes.byref(c), int(width), int(height), 3, None)
         if rc != 0:
             _raise(rc)
         self.n_views = max(self.n_views, view_id + 1)

@@ -722,7 +722,8 @@ int check_ref_view(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref) {
     const size_t nv = c->sc->views.size();
     if (ref < 0 || (size_t)ref >= nv) return fail(MI_DMRECON_EINVAL, "Master view index out of bounds");
     HostView const& R = c->sc->views[ref];
-    if (!R.valid) return fail(MI_DMRECON_EINVAL, "Invalid master view");
+    /* (device < 0: the host-only planning hook, mi_dmrecon_debug_plan_views_host -- cameras and features, no images at all) */
+    if (!R.valid || (c->device >= 0 && !R.d_img)) return fail(MI_DMRECON_EINVAL, "Invalid master view");
     if ((size_t)st->scale >= R.levels.size()) return fail(MI_DMRECON_EINVAL, "scale %d beyond pyramid of view %d", st->scale, ref);
     return 0;
 }
@@ -1267,15 +1268,22 @@ static size_t host_view_set_camera(HostView& v, const mi_dmrecon_camera* cam, in
 
 static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_camera* cam, int32_t width,
                          int32_t height, int32_t channels, const uint8_t* pixels, bool async) {
-    if (!c || !cam || !pixels) return fail(MI_DMRECON_EINVAL, "null argument");
+    if (!c || !cam) return fail(MI_DMRECON_EINVAL, "null argument");
     if (view_id < 0 || view_id >= (1 << 20)) return fail(MI_DMRECON_EINVAL, "bad view id %d", view_id);
     if (width < 2 || height < 2 || width > 65535 || height > 65535) return fail(MI_DMRECON_EINVAL, "bad image size %dx%d", width, height);
-    if (channels < 1 || channels > 4) return fail(MI_DMRECON_EINVAL, "Image with invalid number of channels");
+    if (pixels && (channels < 1 || channels > 4)) return fail(MI_DMRECON_EINVAL, "Image with invalid number of channels");
     HIP_TRY(hipSetDevice(c->device));
     if ((size_t)view_id >= c->sc->views.size()) c->sc->views.resize(view_id + 1);
     HostView& v = c->sc->views[view_id];
     if (v.d_img) { (void)hipFree(v.d_img); v.d_img = nullptr; }
     const size_t off = host_view_set_camera(v, cam, width, height);
+    if (!pixels) {
+        /* camera and image size only (mi_dmrecon.h): a candidate of the view selections whose image could not be loaded */
+        v.n_texels = 0;
+        c->sc->views_dirty = true;
+        c->sc->geom.built = false;
+        return 0;
+    }
     v.n_texels = off;
     /* RGBA8 levels, then (16-byte aligned) the same levels as 2x2 footprint records: 4 + 16 bytes per texel */
     v.quad_off = (off + 3) & ~(size_t)3;
@@ -1529,6 +1537,17 @@ int BatchRun::plan() {
         if (r == 0 && plans[i].global.empty()) r = fail(MI_DMRECON_EGVS, "Global View Selection failed");
         view_rc[i] = r;
         if (r) plan_err[i] = g_err;
+    }
+    /* a selected view that was registered without pixels (mi_dmrecon_set_view with a null image: its image could not be loaded
+     * by the caller): the reference fails here, when it loads the selected views (dmrecon.cc:236-240) */
+    for (int i = 0; i < n_refs; ++i) {
+        if (view_rc[i]) continue;
+        for (int g : plans[i].global)
+            if (c->device >= 0 && g >= 0 && (size_t)g < c->sc->views.size() && !c->sc->views[g].d_img) {
+                view_rc[i] = fail(MI_DMRECON_ENOIMAGE, "view %d, selected as a neighbour of view %d, has no image", g, ref_views[i]);
+                plan_err[i] = g_err;
+                break;
+            }
     }
     mark("global view selection");
     const double t_gvs_done = now_ms();
@@ -2401,6 +2420,9 @@ int BatchRun::outcome() {
         case MI_DMRECON_ECANCELLED: return fail(first_rc, "cancelled");
         case MI_DMRECON_EFOOTPRINT: return fail(first_rc, "Negative pixel footprint");
         case MI_DMRECON_EGVS: return fail(first_rc, "Global View Selection failed");
+        case MI_DMRECON_ENOIMAGE:
+            if (first_i >= 0 && !plan_err[first_i].empty()) { g_err = plan_err[first_i]; return first_rc; }
+            return fail(first_rc, "a selected neighbour view has no image");
         default:
             if (first_i >= 0 && !plan_err[first_i].empty()) { g_err = plan_err[first_i]; return first_rc; }
             return fail(first_rc ? first_rc : MI_DMRECON_EDEVICE, "reconstruction failed");
@@ -2627,7 +2649,8 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
             else if (n_ok == 0) {
                 r->rc = first;
                 r->err = first == MI_DMRECON_ECANCELLED ? "cancelled" : first == MI_DMRECON_EFOOTPRINT ? "Negative pixel footprint"
-                       : first == MI_DMRECON_EGVS ? "Global View Selection failed" : "reconstruction failed";
+                       : first == MI_DMRECON_EGVS ? "Global View Selection failed"
+                       : first == MI_DMRECON_ENOIMAGE ? "a selected neighbour view has no image" : "reconstruction failed";
             } else r->rc = 0;
             if (r->stats) {
                 if (r == &me) *r->stats = bs;

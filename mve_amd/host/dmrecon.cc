@@ -262,7 +262,8 @@ private:
                 q.rc = status[i];
                 q.err = status[i] == MI_DMRECON_EGVS ? "Global View Selection failed"
                       : status[i] == MI_DMRECON_EFOOTPRINT ? "Negative pixel footprint"
-                      : status[i] == MI_DMRECON_ECANCELLED ? "cancelled" : "reconstruction failed";
+                      : status[i] == MI_DMRECON_ECANCELLED ? "cancelled"
+                      : status[i] == MI_DMRECON_ENOIMAGE ? "a selected neighbour view has no image" : "reconstruction failed";
             } else if (rc != 0) { q.rc = rc; q.err = msg; }
         }
     }
@@ -441,6 +442,26 @@ private:
                         views[i]->cache_cleanup();
                     } catch (...) {
                         g.decode_error[i] = std::current_exception();     /* (one writer per view) */
+                        /* The reference still has a SingleView for this view (valid camera, an image of the embedding whose
+                         * header it could read: dmrecon.cc:62-79) -- a candidate of everybody's global view selection -- and
+                         * only meets the broken image when a reconstruction SELECTS it (dmrecon.cc:236-240).  Registered with
+                         * its camera and size only: the library's selections see it, and a view that selects it gets
+                         * MI_DMRECON_ENOIMAGE, which start() turns back into this exception. */
+                        try {
+                            mve::View::ImageProxy const* px = views[i]->get_image_proxy(g.embedding);
+                            if (px != nullptr && px->width > 1 && px->height > 1 && wait_for_contexts()) {
+                                mve::CameraInfo const& cam = views[i]->get_camera();
+                                mi_dmrecon_camera mc;
+                                mc.flen = cam.flen; mc.paspect = cam.paspect;
+                                mc.ppoint[0] = cam.ppoint[0]; mc.ppoint[1] = cam.ppoint[1];
+                                for (int k = 0; k < 9; ++k) mc.rot[k] = cam.rot[k];
+                                for (int k = 0; k < 3; ++k) mc.trans[k] = cam.trans[k];
+                                for (std::size_t s = 0; s < ns; ++s) {
+                                    std::lock_guard<std::mutex> lock(*ctx_mu[s]);
+                                    (void)mi_dmrecon_set_view(ctxs[s], (int32_t)i, &mc, px->width, px->height, 3, nullptr);
+                                }
+                            }
+                        } catch (...) { }
                     }
                 }
             };
@@ -567,26 +588,6 @@ DMRecon::start()
 {
     progress.start_time = std::time(nullptr);
     if (progress.cancelled) { progress.status = RECON_CANCELLED; return; }
-    {
-        /* a neighbour whose image could not be decoded: the reference meets it when the view selection loads it
-         * (dmrecon.cc:240) -- possible only for views that share a feature with the master view */
-        Generation const& gen = *std::static_pointer_cast<Attachment>(this->slot)->gen;
-        bool any = false;
-        for (std::size_t i = 0; i < gen.decode_error.size() && !any; ++i) any = gen.decode_error[i] != nullptr;
-        if (any) {
-            mve::Bundle::Features const& feats = gen.scene->get_bundle()->get_features();
-            for (std::size_t f = 0; f < feats.size(); ++f) {
-                bool mine = false;
-                for (std::size_t j = 0; j < feats[f].refs.size() && !mine; ++j) mine = feats[f].refs[j].view_id == (int)settings.refViewNr;
-                if (!mine) continue;
-                for (std::size_t j = 0; j < feats[f].refs.size(); ++j) {
-                    std::size_t const v = (std::size_t)feats[f].refs[j].view_id;
-                    if (v < gen.decode_error.size() && gen.decode_error[v]) std::rethrow_exception(gen.decode_error[v]);
-                }
-            }
-        }
-    }
-
     mi_dmrecon_settings st;
     mi_dmrecon_settings_default(&st);
     st.filterWidth = (int32_t)settings.filterWidth;
@@ -637,6 +638,21 @@ DMRecon::start()
     running.store(false);
     relay.join();
     if (rc == MI_DMRECON_ECANCELLED) { progress.status = RECON_CANCELLED; return; }
+    if (rc == MI_DMRECON_ENOIMAGE) {
+        /* the global view selection picked a view whose image could not be decoded: the reference fails here with the decoder's
+         * own exception (it loads the selected views, dmrecon.cc:236-240) -- the first such view in the order of the selection */
+        progress.status = RECON_IDLE;
+        Generation const& gen = *std::static_pointer_cast<Attachment>(this->slot)->gen;
+        int32_t ids[MI_DMRECON_MAX_GLOBAL_VIEWS]; int32_t n_ids = 0;
+        {
+            std::lock_guard<std::mutex> lock(sl->parent_mu);
+            if (mi_dmrecon_global_view_selection(sl->parent, &st, ref, ids, &n_ids) != 0) n_ids = 0;
+        }
+        for (int32_t k = 0; k < n_ids; ++k)
+            if (ids[k] >= 0 && (std::size_t)ids[k] < gen.decode_error.size() && gen.decode_error[ids[k]])
+                std::rethrow_exception(gen.decode_error[ids[k]]);
+        throw std::runtime_error(req.err.empty() ? "a selected neighbour view has no image" : req.err);
+    }
     if (rc != 0) {
         progress.status = RECON_IDLE;
         switch (rc) {

@@ -128,3 +128,40 @@ def test_two_processes_share_the_gpu(tmp_path):
         got = _read_maps(d, n, cfg["scale"])
         for v in range(n):
             assert got[v] == alone[v], "%s: view %d differs from the run alone" % (os.path.basename(d), v)
+
+
+@pytest.mark.skipif(not os.path.exists(APP), reason="build/dmrecon_mi not built (needs the reference tree at build time)")
+def test_a_view_whose_image_cannot_be_loaded_fails_only_those_who_select_it(tmp_path):
+    """The reference loads images lazily: a view whose image cannot be decoded is still a candidate of everybody's global
+    view selection (it has a valid camera and an image of the embedding whose header can be read, dmrecon.cc:62-79), and only
+    the reconstructions that SELECT it -- and its own -- fail, when the selected views are loaded (dmrecon.cc:236-240).  The
+    shim decodes every view up front; a view whose decoder throws is registered with its camera only
+    (mi_dmrecon_set_view(..., pixels = NULL)), the library's view selections see it, and a view that selects it gets
+    MI_DMRECON_ENOIMAGE, which the shim turns back into the decoder's exception.  Checked against the reference binary itself on
+    the same broken scenes: the same views get a depth map.  (Embeddings stored as .mvei: a truncated one makes MVE's loader
+    throw; a truncated PNG makes libpng abort the process, in the reference as here.)"""
+    from mve_amd.synth import SynthParams, make_scene
+    from oracle import oracle as orc
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "dmrecon_ref_fast")
+    sc = make_scene(SynthParams(n_views=6, width=160, height=120, n_features=300))
+    sel0 = orc.OracleScene(sc).global_vs(orc.make_settings(ref_view=0, global_max=2))
+    assert len(sel0) == 2
+    not_selected = [v for v in range(1, 6) if v not in sel0][0]
+    for victim in (not_selected, sel0[0]):
+        written = {}
+        for name, exe in (("shim", APP), ("reference", ref_exe)):
+            if not os.path.exists(exe):
+                continue
+            sdir = str(tmp_path / ("%s_%d" % (name, victim)))
+            scene_io.write_scene(sdir, sc, raw=True)
+            f = os.path.join(scene_io.view_dir(sdir, victim), "undistorted.mvei")
+            data = open(f, "rb").read()
+            open(f, "wb").write(data[:len(data) // 2])                  # header intact, pixel data cut short
+            out = subprocess.run([exe, "-s0", "-n2", "--force", "--progress=silent", sdir], capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+            written[name] = [os.path.exists(os.path.join(scene_io.view_dir(sdir, v), "depth-L0.mvei")) for v in range(6)]
+        assert not written["shim"][victim]                               # its own reconstruction fails (its master image)
+        assert written["shim"][0] == (victim == not_selected)            # view 0 fails exactly when it selects the broken view
+        assert sum(written["shim"]) >= 3
+        if "reference" in written:
+            assert written["shim"] == written["reference"], (victim, written)

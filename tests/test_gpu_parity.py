@@ -735,6 +735,43 @@ def test_hard_scene_maps_vs_reference(gpu_ctx, h1, h1_scene):
     assert stats["n_view_replaced"] > 50 and stats["n_iter14"] >= 1
 
 
+def test_views_registered_without_pixels(gpu_ctx, g1_scene):
+    """mi_dmrecon_set_view(..., pixels = NULL): a view with its camera and image size only -- what the reference has for a view
+    whose image cannot be loaded: still a candidate of the global view selections (dmrecon.cc:62-79), fatal only for the
+    reconstructions that select it (dmrecon.cc:236-240: MI_DMRECON_ENOIMAGE here, per view), "Invalid master view" as a
+    reference view itself."""
+    gpu_ctx.load_scene(g1_scene)
+    st = api.Settings(globalVSMax=2)
+    sel = gpu_ctx.global_view_selection(st, 0)
+    assert len(sel) == 2
+    other = [v for v in range(1, 5) if v not in sel][0]
+    ref = gpu_ctx.reconstruct(st, [0, other], want_views=True)
+    h, w = g1_scene.images[0].shape[:2]
+    # a view nobody of the call selects loses its pixels: same selection, same maps
+    lost = [v for v in range(1, 5) if v not in sel and v not in gpu_ctx.global_view_selection(st, other) and v != other]
+    if lost:
+        gpu_ctx.set_view_camera_only(lost[0], g1_scene.cameras[lost[0]], w, h)
+        assert gpu_ctx.global_view_selection(st, 0) == sel
+        got = gpu_ctx.reconstruct(st, [0, other], want_views=True)
+        for a, b in zip(got, ref):
+            for k in ("depth", "conf", "dz", "views"):
+                assert np.array_equal(a[k], b[k]), k
+        with pytest.raises(ValueError, match="Invalid master view"):
+            gpu_ctx.reconstruct(st, [lost[0]])
+    # a view that view 0 selects loses its pixels: view 0 ends with E_NOIMAGE, the other view of the call finishes
+    gpu_ctx.set_view_camera_only(sel[0], g1_scene.cameras[sel[0]], w, h)
+    assert gpu_ctx.global_view_selection(st, 0) == sel                     # still a candidate, still selected
+    if sel[0] not in gpu_ctx.global_view_selection(st, other):
+        got = gpu_ctx.reconstruct(st, [0, other], want_views=True)
+        assert got[0]["status"] == api.E_NOIMAGE and got[1]["status"] == 0
+        assert np.array_equal(got[1]["depth"], ref[1]["depth"])
+    with pytest.raises(RuntimeError, match="has no image"):
+        gpu_ctx.reconstruct(st, [0])
+    gpu_ctx.load_scene(g1_scene)                                           # every view with its pixels again
+    again = gpu_ctx.reconstruct(st, [0, other], want_views=True)
+    assert np.array_equal(again[0]["depth"], ref[0]["depth"])
+
+
 def test_seed_reoptimisation_round(gpu_ctx, g1, g1_scene, h1, h1_scene, monkeypatch):
     """MI_DMRECON_SEED_REOPT=1: the reference's seed semantics -- a seed's OWN pixel is pushed (dmrecon.cc:316-326), re-optimised
     from its converged state when popped, and propagates only if that strictly raised its confidence (:365-398) -- as one extra
