@@ -714,7 +714,14 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
          * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1.
          * The record index top * w + left as a 24-bit multiply-add in 32 bits (rows and widths are below 2^24, a level
          * below 2^32 texels) instead of a 64-bit multiply-add (6.3 issue cycles against 5.6, and no sign extension). */
+#ifdef MI_TILED_QUADS
+        /* experiment: the records block-linear, 8 x 8 per tile (k_quadify), so that records that are neighbours in the image in
+         * BOTH directions are neighbours in memory -- six more VALU instructions per sample in an instruction-bound kernel */
+        const unsigned ux = (unsigned)uc, uy = (unsigned)vc;
+        const unsigned rec = ((__umul24(uy >> 3, (unsigned)(nv.w + 7) >> 3) + (ux >> 3)) << 6) | ((uy & 7u) << 3) | (ux & 7u);
+#else
         const unsigned rec = __umul24((unsigned)vc, (unsigned)nv.w) + (unsigned)uc;
+#endif
         q.t = *(gtex4_t)(nv.img + 4 * (size_t)rec);
         return q;
     };
@@ -3105,7 +3112,11 @@ __global__ __launch_bounds__(256) void k_quadify(const uint32_t* __restrict__ sr
     const int x1 = x + 1 < w ? x + 1 : x, y1 = y + 1 < h ? y + 1 : y;
     u32x4 o;
     o.x = src[y * w + x]; o.y = src[y * w + x1]; o.z = src[y1 * w + x]; o.w = src[y1 * w + x1];
+#ifdef MI_TILED_QUADS
+    dst[(((unsigned)(y >> 3) * ((unsigned)(w + 7) >> 3) + (unsigned)(x >> 3)) << 6) | ((unsigned)(y & 7) << 3) | (unsigned)(x & 7)] = o;
+#else
     dst[i] = o;
+#endif
 }
 
 

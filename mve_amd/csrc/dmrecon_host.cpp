@@ -1253,7 +1253,11 @@ static size_t host_view_set_camera(HostView& v, const mi_dmrecon_camera* cam, in
     HostLevel l0; l0.w = cw; l0.h = ch; l0.tex_off = 0;
     calibration(pc, (float)cw, (float)ch, l0.proj, l0.invproj);
     v.levels.push_back(l0);
-    off += (size_t)cw * ch;
+    /* (a level's slot holds its texels row by row AND -- four times that, behind the levels -- its footprint records; the slot
+     * is padded to whole 8 x 8 tiles so that a block-linear arrangement of the records fits as well: the -DMI_TILED_QUADS
+     * experiment of the device code.  < 1 % of a view's memory.) */
+    auto slot = [](int w, int h) { return (size_t)((w + 7) & ~7) * (size_t)((h + 7) & ~7); };
+    off += slot(cw, ch);
     while (std::min(cw, ch) >= 30 && v.levels.size() < MI_MAX_LEVELS) {
         if (cw % 2 == 1) pc.ppoint[0] = pc.ppoint[0] * float(cw) / float(cw + 1);
         if (ch % 2 == 1) pc.ppoint[1] = pc.ppoint[1] * float(ch) / float(ch + 1);
@@ -1261,7 +1265,7 @@ static size_t host_view_set_camera(HostView& v, const mi_dmrecon_camera* cam, in
         HostLevel l; l.w = cw; l.h = ch; l.tex_off = (uint32_t)off;
         calibration(pc, (float)cw, (float)ch, l.proj, l.invproj);
         v.levels.push_back(l);
-        off += (size_t)cw * ch;
+        off += slot(cw, ch);
     }
     return off;
 }
