@@ -156,6 +156,12 @@ __device__ __forceinline__ float fast_div(float a, float b) { return a * __built
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 
+/* two floats that travel together through the packed-f32 instructions of gfx950 (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32):
+ * an even-aligned register pair; a value that is the same for both halves is read twice from one register (op_sel) */
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 sp2(float a) { return mk2(a, a); }
+
 /* view sets are 8-bit indices into the job's global list, MI_VIEW_NONE padded, ascending (std::set order): NV of them */
 template <int NV> struct ViewPack;
 template <> struct ViewPack<4> { typedef uint32_t type; static constexpr uint32_t NONE = 0xFFFFFFFFu; };
@@ -666,20 +672,53 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     ColorSums S;
     S.s0 = ps.xbar0 * ps.mmean; S.s1 = ps.xbar1 * ps.mmean; S.s2 = ps.xbar2 * ps.mmean;
     S.a0 = S.a1 = S.a2 = 0.f; S.aa0 = S.aa1 = S.aa2 = 0.f; S.ba0 = S.ba1 = S.ba2 = 0.f;
-    float dr0 = 0.f, dr1 = 0.f, dr2 = 0.f, dn0 = 0.f, dn1 = 0.f, dn2 = 0.f, dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
-    float num = 0.f, den = 0.f;
+    /* Float accumulators are PAIRS: the latency layouts run the samples of a lane two at a time as packed f32 (v_pk_fma_f32 /
+     * v_pk_mul_f32 / v_pk_add_f32: two samples' arithmetic per instruction -- a third fewer instructions in a pass whose
+     * length is a dependent chain; front of a lone call 13.3-13.6 -> 12.7 ms) -- half x takes the first sample of a pair and
+     * a sample handled alone, half y the second; the halves are added after the loop.  The throughput layout handles its 25
+     * samples one by one (below) and only ever touches half x. */
+    f2 Pa0 = sp2(0.f), Pa1 = sp2(0.f), Pa2 = sp2(0.f), Paa0 = sp2(0.f), Paa1 = sp2(0.f), Paa2 = sp2(0.f);
+    f2 Pba0 = sp2(0.f), Pba1 = sp2(0.f), Pba2 = sp2(0.f);
+    f2 Pdr0 = sp2(0.f), Pdr1 = sp2(0.f), Pdr2 = sp2(0.f), Pdn0 = sp2(0.f), Pdn1 = sp2(0.f), Pdn2 = sp2(0.f);
+    f2 Pdd0 = sp2(0.f), Pdd1 = sp2(0.f), Pdd2 = sp2(0.f);
+    f2 Pnum = sp2(0.f), Pden = sp2(0.f);
     typedef typename NormalAcc<L::LPV>::type acc_t;
+    /* the normal equations: double in the throughput layout (25 terms per lane, as the reference accumulates), there the two
+     * halves of a pair are added one after the other; float pairs in the latency layouts (2-4 terms per lane) */
     acc_t A00 = 0, A01 = 0, A02 = 0, A11 = 0, A12 = 0, A22 = 0, B0 = 0, B1 = 0, B2 = 0;
+    f2 PA00 = sp2(0.f), PA01 = sp2(0.f), PA02 = sp2(0.f), PA11 = sp2(0.f), PA12 = sp2(0.f), PA22 = sp2(0.f);
+    f2 PB0 = sp2(0.f), PB1 = sp2(0.f), PB2 = sp2(0.f);
     /* per-channel colour sums are only needed when computeColorScale may follow this pass */
     constexpr bool PER_CHANNEL = (MODE == PASS_COLOR || MODE == PASS_DEPTH);
 
     constexpr int NITER = (MI_NS + L::LPV - 1) / L::LPV;
+    const f2 Ss0 = sp2(S.s0), Ss1 = sp2(S.s1), Ss2 = sp2(S.s2);
+    const f2 Cs0 = sp2(ps.cs0), Cs1 = sp2(ps.cs1), Cs2 = sp2(ps.cs2);
     /* A sample is handled in two steps so that texel gathers can be in flight while other samples are consumed:
      * geom() = geometry + the footprint gather, consume() = table look-ups, interpolation and the sums.
-     *   latency layout (one wavefront per patch, nothing else to hide a gather behind): both samples of a lane are
+     *   latency layout (one wavefront per patch, nothing else to hide a gather behind): all samples of a lane are
      *   fetched before the first is consumed -- one exposed memory latency per pass instead of two;
-     *   throughput layout: a whole row of the 5 x 5 window per gather round (see below). */
+     *   throughput layout: a whole row of the 5 x 5 window per gather round (see below).
+     * geom2() / consume2() are the same for two samples at once, in packed arithmetic. */
     struct Pre { int i; bool live; float fx, fy, gu, gv; u32x4 t; };
+    struct Pre2 { int i0, i1; f2 wgt, fx, fy, gu, gv; u32x4 tA, tB; };
+    auto record = [&](float uc, float vc) -> u32x4 {
+        /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
+         * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
+         * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1.
+         * The record index top * w + left as a 24-bit multiply-add in 32 bits (rows and widths are below 2^24, a level
+         * below 2^32 texels) instead of a 64-bit multiply-add (6.3 issue cycles against 5.6, and no sign extension);
+         * the texel indices by truncation (the coordinates are not negative). */
+#ifdef MI_TILED_QUADS
+        /* experiment: the records block-linear, 8 x 8 per tile (k_quadify), so that records that are neighbours in the image in
+         * BOTH directions are neighbours in memory -- six more VALU instructions per sample in an instruction-bound kernel */
+        const unsigned ux = (unsigned)uc, uy = (unsigned)vc;
+        const unsigned rec = ((__umul24(uy >> 3, (unsigned)(nv.w + 7) >> 3) + (ux >> 3)) << 6) | ((uy & 7u) << 3) | (ux & 7u);
+#else
+        const unsigned rec = __umul24((unsigned)vc, (unsigned)nv.w) + (unsigned)uc;
+#endif
+        return *(gtex4_t)(nv.img + 4 * (size_t)rec);
+    };
     auto geom = [&](int it) -> Pre {
         Pre q;
         const int iraw = sub + it * L::LPV;
@@ -707,22 +746,42 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             q.gu = (u1 - u) * dnorm; q.gv = (v1 - v) * dnorm;
         }
         /* the bilinear weights: x - floor(x) in one instruction (v_fract_f32: the same value as the subtraction, which is
-         * exact); the texel indices by truncation (the coordinates are not negative) */
+         * exact) */
         q.fx = __builtin_amdgcn_fractf(uc); q.fy = __builtin_amdgcn_fractf(vc);
-        /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
-         * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
-         * bounds the throughput layout: two 8-byte row gathers cost 2.45 L1 accesses per lane and sample, this 1.
-         * The record index top * w + left as a 24-bit multiply-add in 32 bits (rows and widths are below 2^24, a level
-         * below 2^32 texels) instead of a 64-bit multiply-add (6.3 issue cycles against 5.6, and no sign extension). */
-#ifdef MI_TILED_QUADS
-        /* experiment: the records block-linear, 8 x 8 per tile (k_quadify), so that records that are neighbours in the image in
-         * BOTH directions are neighbours in memory -- six more VALU instructions per sample in an instruction-bound kernel */
-        const unsigned ux = (unsigned)uc, uy = (unsigned)vc;
-        const unsigned rec = ((__umul24(uy >> 3, (unsigned)(nv.w + 7) >> 3) + (ux >> 3)) << 6) | ((uy & 7u) << 3) | (ux & 7u);
-#else
-        const unsigned rec = __umul24((unsigned)vc, (unsigned)nv.w) + (unsigned)uc;
-#endif
-        q.t = *(gtex4_t)(nv.img + 4 * (size_t)rec);
+        q.t = record(uc, vc);
+        return q;
+    };
+    auto geom2 = [&](int ita, int itb) -> Pre2 {
+        Pre2 q;
+        const int ra = sub + ita * L::LPV, rb = sub + itb * L::LPV;
+        const bool la = ra < MI_NS, lb = rb < MI_NS;
+        const int i0 = la ? ra : (MI_NS - 1), i1 = lb ? rb : (MI_NS - 1);
+        q.i0 = i0; q.i1 = i1;
+        q.wgt = mk2(la ? 1.f : 0.f, lb ? 1.f : 0.f);
+        const int dj0 = i0 / MI_FW - MI_HALF, di0 = i0 - (i0 / MI_FW) * MI_FW - MI_HALF;
+        const int dj1 = i1 / MI_FW - MI_HALF, di1 = i1 - (i1 / MI_FW) * MI_FW - MI_HALF;
+        const f2 fi = mk2((float)di0, (float)di1), fj = mk2((float)dj0, (float)dj1);
+        const f2 g = mk2(geo[i0], geo[i1]);
+        const f2 lam = (sp2(ps.depth) + fi * sp2(ps.dzI) + fj * sp2(ps.dzJ)) * g;
+        const f2 vx = sp2(nv.ax) + fi * sp2(nv.bx) + fj * sp2(nv.dx), vy = sp2(nv.ay) + fi * sp2(nv.by) + fj * sp2(nv.dy);
+        const f2 vz = sp2(nv.az) + fi * sp2(nv.bz) + fj * sp2(nv.dz);
+        const f2 sx = sp2(nv.sx) + lam * vx, sy = sp2(nv.sy) + lam * vy, sz = sp2(nv.sz) + lam * vz;
+        const f2 iz = mk2(fast_rcp(sz.x), fast_rcp(sz.y));
+        const f2 u = sx * iz - sp2(0.5f), v = sy * iz - sp2(0.5f);
+        const f2 uc = mk2(__builtin_amdgcn_fmed3f(u.x, kLo, wlim), __builtin_amdgcn_fmed3f(u.y, kLo, wlim));
+        const f2 vc = mk2(__builtin_amdgcn_fmed3f(v.x, kLo, hlim), __builtin_amdgcn_fmed3f(v.y, kLo, hlim));
+        ok = ok && (uc.x == u.x && vc.x == v.x) && (uc.y == u.y && vc.y == v.y);
+        q.gu = sp2(0.f); q.gv = sp2(0.f);
+        if (MODE != PASS_COLOR) {
+            const f2 l2 = sp2(step) * g;
+            const f2 z1 = sz + l2 * vz;
+            const f2 iz1 = mk2(fast_rcp(z1.x), fast_rcp(z1.y));
+            const f2 u1 = (sx + l2 * vx) * iz1 - sp2(0.5f), v1 = (sy + l2 * vy) * iz1 - sp2(0.5f);
+            q.gu = (u1 - u) * sp2(dnorm); q.gv = (v1 - v) * sp2(dnorm);
+        }
+        q.fx = mk2(__builtin_amdgcn_fractf(uc.x), __builtin_amdgcn_fractf(uc.y));
+        q.fy = mk2(__builtin_amdgcn_fractf(vc.x), __builtin_amdgcn_fractf(vc.y));
+        q.tA = record(uc.x, vc.x); q.tB = record(uc.y, vc.y);
         return q;
     };
     auto consume = [&](const Pre& q) {
@@ -749,24 +808,24 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             dump_der[3 * i] = dr[0]; dump_der[3 * i + 1] = dr[1]; dump_der[3 * i + 2] = dr[2];
         } else {
             const float a0 = (n[0] - S.s0) * wgt, a1 = (n[1] - S.s1) * wgt, a2 = (n[2] - S.s2) * wgt;
-            S.a0 += a0; S.a1 += a1; S.a2 += a2;
+            Pa0.x += a0; Pa1.x += a1; Pa2.x += a2;
             /* ba: sum m (n - s) here, - xbar sum (n - s) after the loop */
             if (PER_CHANNEL) {
-                S.aa0 += a0 * a0; S.aa1 += a1 * a1; S.aa2 += a2 * a2;
-                S.ba0 += m0 * a0; S.ba1 += m1 * a1; S.ba2 += m2 * a2;
+                Paa0.x += a0 * a0; Paa1.x += a1 * a1; Paa2.x += a2 * a2;
+                Pba0.x += m0 * a0; Pba1.x += m1 * a1; Pba2.x += m2 * a2;
             } else {
-                S.aa0 += a0 * a0 + a1 * a1 + a2 * a2;
-                S.ba0 += m0 * a0 + m1 * a1 + m2 * a2;
+                Paa0.x += a0 * a0 + a1 * a1 + a2 * a2;
+                Pba0.x += m0 * a0 + m1 * a1 + m2 * a2;
             }
             if (MODE == PASS_DEPTH_FIXED) {
                 const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
-                num += wgt * (g0 * (m0 - ps.cs0 * n[0]) + g1 * (m1 - ps.cs1 * n[1]) + g2 * (m2 - ps.cs2 * n[2]));
-                den += wgt * (g0 * g0 + g1 * g1 + g2 * g2);
+                Pnum.x += wgt * (g0 * (m0 - ps.cs0 * n[0]) + g1 * (m1 - ps.cs1 * n[1]) + g2 * (m2 - ps.cs2 * n[2]));
+                Pden.x += wgt * (g0 * g0 + g1 * g1 + g2 * g2);
             } else if (MODE == PASS_DEPTH) {
                 const float e0 = dr[0] * wgt, e1 = dr[1] * wgt, e2 = dr[2] * wgt;
-                dr0 += e0 * (m0 - ps.cs0 * n[0]); dr1 += e1 * (m1 - ps.cs1 * n[1]); dr2 += e2 * (m2 - ps.cs2 * n[2]);
-                dn0 += e0 * n[0]; dn1 += e1 * n[1]; dn2 += e2 * n[2];
-                dd0 += e0 * dr[0]; dd1 += e1 * dr[1]; dd2 += e2 * dr[2];
+                Pdr0.x += e0 * (m0 - ps.cs0 * n[0]); Pdr1.x += e1 * (m1 - ps.cs1 * n[1]); Pdr2.x += e2 * (m2 - ps.cs2 * n[2]);
+                Pdn0.x += e0 * n[0]; Pdn1.x += e1 * n[1]; Pdn2.x += e2 * n[2];
+                Pdd0.x += e0 * dr[0]; Pdd1.x += e1 * dr[1]; Pdd2.x += e2 * dr[2];
             } else if (MODE == PASS_NORMAL) {
                 const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
                 const float r0_ = m0 - ps.cs0 * n[0], r1_ = m1 - ps.cs1 * n[1], r2_ = m2 - ps.cs2 * n[2];
@@ -779,9 +838,70 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             }
         }
     };
+    auto consume2 = [&](const Pre2& q) {
+        const int i0 = q.i0, i1 = q.i1;
+        const f2 fx = q.fx, fy = q.fy, gu = q.gu, gv = q.gv;
+        const f2 fxy = fx * fy, gm = gv * fx + gu * fy;
+        f2 n[3], dr[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f2 c00 = mk2(s_lut[(q.tA.x >> (8 * c)) & 255u], s_lut[(q.tB.x >> (8 * c)) & 255u]);
+            const f2 c10 = mk2(s_lut[(q.tA.y >> (8 * c)) & 255u], s_lut[(q.tB.y >> (8 * c)) & 255u]);
+            const f2 c01 = mk2(s_lut[(q.tA.z >> (8 * c)) & 255u], s_lut[(q.tB.z >> (8 * c)) & 255u]);
+            const f2 c11 = mk2(s_lut[(q.tA.w >> (8 * c)) & 255u], s_lut[(q.tB.w >> (8 * c)) & 255u]);
+            const f2 d1 = c10 - c00, d2 = c01 - c00, d3 = (c11 - c10) - d2;
+            n[c] = c00 + fx * d1 + fy * d2 + fxy * d3;
+            if (MODE != PASS_COLOR) dr[c] = gu * d1 + gv * d2 + gm * d3;
+        }
+        const f2 m0 = mk2(mcol[3 * i0], mcol[3 * i1]), m1 = mk2(mcol[3 * i0 + 1], mcol[3 * i1 + 1]), m2 = mk2(mcol[3 * i0 + 2], mcol[3 * i1 + 2]);
+        if (MODE == PASS_DUMP) {
+            dump_col[3 * i0] = n[0].x; dump_col[3 * i0 + 1] = n[1].x; dump_col[3 * i0 + 2] = n[2].x;
+            dump_der[3 * i0] = dr[0].x; dump_der[3 * i0 + 1] = dr[1].x; dump_der[3 * i0 + 2] = dr[2].x;
+            dump_col[3 * i1] = n[0].y; dump_col[3 * i1 + 1] = n[1].y; dump_col[3 * i1 + 2] = n[2].y;
+            dump_der[3 * i1] = dr[0].y; dump_der[3 * i1 + 1] = dr[1].y; dump_der[3 * i1 + 2] = dr[2].y;
+        } else {
+            f2 a0 = n[0] - Ss0, a1 = n[1] - Ss1, a2 = n[2] - Ss2;
+            if (L::LPV != 1) { a0 *= q.wgt; a1 *= q.wgt; a2 *= q.wgt; }      /* dead trips (L::LPV > 1 only) contribute nothing */
+            Pa0 += a0; Pa1 += a1; Pa2 += a2;
+            if (PER_CHANNEL) {
+                Paa0 += a0 * a0; Paa1 += a1 * a1; Paa2 += a2 * a2;
+                Pba0 += m0 * a0; Pba1 += m1 * a1; Pba2 += m2 * a2;
+            } else {
+                Paa0 += a0 * a0 + a1 * a1 + a2 * a2;
+                Pba0 += m0 * a0 + m1 * a1 + m2 * a2;
+            }
+            if (MODE == PASS_DEPTH_FIXED) {
+                const f2 g0 = Cs0 * dr[0], g1 = Cs1 * dr[1], g2 = Cs2 * dr[2];
+                f2 tn = g0 * (m0 - Cs0 * n[0]) + g1 * (m1 - Cs1 * n[1]) + g2 * (m2 - Cs2 * n[2]);
+                f2 td = g0 * g0 + g1 * g1 + g2 * g2;
+                if (L::LPV != 1) { tn *= q.wgt; td *= q.wgt; }
+                Pnum += tn; Pden += td;
+            } else if (MODE == PASS_DEPTH) {
+                f2 e0 = dr[0], e1 = dr[1], e2 = dr[2];
+                if (L::LPV != 1) { e0 *= q.wgt; e1 *= q.wgt; e2 *= q.wgt; }
+                Pdr0 += e0 * (m0 - Cs0 * n[0]); Pdr1 += e1 * (m1 - Cs1 * n[1]); Pdr2 += e2 * (m2 - Cs2 * n[2]);
+                Pdn0 += e0 * n[0]; Pdn1 += e1 * n[1]; Pdn2 += e2 * n[2];
+                Pdd0 += e0 * dr[0]; Pdd1 += e1 * dr[1]; Pdd2 += e2 * dr[2];
+            } else if (MODE == PASS_NORMAL) {
+                const f2 g0 = Cs0 * dr[0], g1 = Cs1 * dr[1], g2 = Cs2 * dr[2];
+                const f2 r0_ = m0 - Cs0 * n[0], r1_ = m1 - Cs1 * n[1], r2_ = m2 - Cs2 * n[2];
+                f2 gg = g0 * g0 + g1 * g1 + g2 * g2;
+                f2 gr = g0 * r0_ + g1 * r1_ + g2 * r2_;
+                if (L::LPV != 1) { gg *= q.wgt; gr *= q.wgt; }
+                const int dj0 = i0 / MI_FW - MI_HALF, di0 = i0 - (i0 / MI_FW) * MI_FW - MI_HALF;
+                const int dj1 = i1 / MI_FW - MI_HALF, di1 = i1 - (i1 / MI_FW) * MI_FW - MI_HALF;
+                const f2 fi = mk2((float)di0, (float)di1), fj = mk2((float)dj0, (float)dj1);
+                const f2 igg = fi * gg, jgg = fj * gg, iigg = fi * igg, ijgg = fi * jgg, jjgg = fj * jgg, igr = fi * gr, jgr = fj * gr;
+                PA00 += gg; PA01 += igg; PA02 += jgg; PA11 += iigg; PA12 += ijgg; PA22 += jjgg;
+                PB0 += gr; PB1 += igr; PB2 += jgr;
+            }
+        }
+    };
     if (L::LPV == 1) {
         /* a row of the window per gather round (5 x 5: its five footprint records are neighbours in memory, 1-2
-         * cache lines fetched once, five gathers in flight) */
+         * cache lines fetched once, five gathers in flight).  One sample at a time: in this layout the packed form measured
+         * SLOWER (profiles/r5_ab_experiments.txt P: three wavefronts per SIMD already fill the issue slots, a packed
+         * instruction costs more than half of two plain ones, and the register pairs spill) */
 #pragma unroll 1
         for (int row = 0; row < MI_FW; ++row) {
             Pre q[MI_FW];
@@ -791,33 +911,44 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             for (int k = 0; k < MI_FW; ++k) consume(q[k]);
         }
     } else {
-        Pre q[NITER];
+        constexpr int NP = NITER / 2;
+        Pre2 q[NP > 0 ? NP : 1];
+        Pre qs;
 #pragma unroll
-        for (int b = 0; b < NITER; ++b) q[b] = geom(b);
+        for (int b = 0; b < NP; ++b) q[b] = geom2(2 * b, 2 * b + 1);
+        if (NITER & 1) qs = geom(NITER - 1);
         TSTAMP(60);
 #pragma unroll
-        for (int b = 0; b < NITER; ++b) consume(q[b]);
+        for (int b = 0; b < NP; ++b) consume2(q[b]);
+        if (NITER & 1) consume(qs);
         TSTAMP(61);
     }
+    /* the two halves of a pair accumulator (the throughput layout only ever used half x) */
+    auto hs = [](f2 p) -> float { return L::LPV == 1 ? p.x : p.x + p.y; };
     if (MODE != PASS_DUMP) {
-        S.a0 = L::view_sum(S.a0); S.a1 = L::view_sum(S.a1); S.a2 = L::view_sum(S.a2);
-        S.aa0 = L::view_sum(S.aa0); S.ba0 = L::view_sum(S.ba0);
+        S.a0 = L::view_sum(hs(Pa0)); S.a1 = L::view_sum(hs(Pa1)); S.a2 = L::view_sum(hs(Pa2));
+        S.aa0 = L::view_sum(hs(Paa0)); S.ba0 = L::view_sum(hs(Pba0));
         if (PER_CHANNEL) {
-            S.aa1 = L::view_sum(S.aa1); S.aa2 = L::view_sum(S.aa2);
-            S.ba1 = L::view_sum(S.ba1); S.ba2 = L::view_sum(S.ba2);
+            S.aa1 = L::view_sum(hs(Paa1)); S.aa2 = L::view_sum(hs(Paa2));
+            S.ba1 = L::view_sum(hs(Pba1)); S.ba2 = L::view_sum(hs(Pba2));
             S.ba0 -= ps.xbar0 * S.a0; S.ba1 -= ps.xbar1 * S.a1; S.ba2 -= ps.xbar2 * S.a2;
         } else
             S.ba0 -= ps.xbar0 * S.a0 + ps.xbar1 * S.a1 + ps.xbar2 * S.a2;
         cs_out = S;
     }
-    if (MODE == PASS_DEPTH_FIXED) { gn.num = L::view_sum(num); gn.den = L::view_sum(den); }
+    if (MODE == PASS_DEPTH_FIXED) { gn.num = L::view_sum(hs(Pnum)); gn.den = L::view_sum(hs(Pden)); }
     if (MODE == PASS_DEPTH) {
-        gn.dr0 = L::view_sum(dr0); gn.dr1 = L::view_sum(dr1); gn.dr2 = L::view_sum(dr2);
-        gn.dn0 = L::view_sum(dn0); gn.dn1 = L::view_sum(dn1); gn.dn2 = L::view_sum(dn2);
-        gn.dd0 = L::view_sum(dd0); gn.dd1 = L::view_sum(dd1); gn.dd2 = L::view_sum(dd2);
+        gn.dr0 = L::view_sum(hs(Pdr0)); gn.dr1 = L::view_sum(hs(Pdr1)); gn.dr2 = L::view_sum(hs(Pdr2));
+        gn.dn0 = L::view_sum(hs(Pdn0)); gn.dn1 = L::view_sum(hs(Pdn1)); gn.dn2 = L::view_sum(hs(Pdn2));
+        gn.dd0 = L::view_sum(hs(Pdd0)); gn.dd1 = L::view_sum(hs(Pdd1)); gn.dd2 = L::view_sum(hs(Pdd2));
         gn.c00 = ps.cs0; gn.c01 = ps.cs1; gn.c02 = ps.cs2;
     }
     if (MODE == PASS_NORMAL) {
+        if (L::LPV != 1) {
+            A00 += (acc_t)(hs(PA00)); A01 += (acc_t)(hs(PA01)); A02 += (acc_t)(hs(PA02));
+            A11 += (acc_t)(hs(PA11)); A12 += (acc_t)(hs(PA12)); A22 += (acc_t)(hs(PA22));
+            B0 += (acc_t)(hs(PB0)); B1 += (acc_t)(hs(PB1)); B2 += (acc_t)(hs(PB2));
+        }
         gn.A00 = (double)L::view_sum(A00); gn.A01 = (double)L::view_sum(A01); gn.A02 = (double)L::view_sum(A02);
         gn.A11 = (double)L::view_sum(A11); gn.A12 = (double)L::view_sum(A12); gn.A22 = (double)L::view_sum(A22);
         gn.B0 = (double)L::view_sum(B0); gn.B1 = (double)L::view_sum(B1); gn.B2 = (double)L::view_sum(B2);
