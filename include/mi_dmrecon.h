@@ -150,6 +150,9 @@ typedef struct mi_dmrecon_stats {
                                   * layout, and turns of their wavefronts x patches per wavefront: the ratio = lanes at work */
     int64_t front_team_max;      /* the largest team of the front launch (the views with the longest lists get the teams of the
                                   * XCDs that hold fewer views) */
+    int64_t n_sparse_records;    /* large batches: the maps went back as a snapshot taken at the hand-over (copied while the front
+                                  * kernel ran) plus this many pixels the front changed afterwards (0: the maps were copied in
+                                  * full; -1: the list outgrew its buffer and they were copied in full after all) */
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);

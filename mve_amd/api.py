@@ -95,7 +95,7 @@ class CStats(ctypes.Structure):
                 ("front_fallbacks", ctypes.c_int64), ("n_latency_rounds", ctypes.c_int64),
                 ("ms_wall_setup", ctypes.c_double), ("ms_wall_rounds", ctypes.c_double), ("ms_wall_front", ctypes.c_double), ("ms_wall_download", ctypes.c_double),
                 ("n_patch_turns", ctypes.c_int64), ("n_wave_turns", ctypes.c_int64),
-                ("front_team_max", ctypes.c_int64)]
+                ("front_team_max", ctypes.c_int64), ("n_sparse_records", ctypes.c_int64)]
 
 
 _lib = None

@@ -102,6 +102,11 @@ void mi_launch_apply_spec(hipStream_t s, unsigned grid_blocks, const DevJob* job
 /* eight_views: imaps also holds [views_hi | views1_hi] behind them (nrReconNeighbors > 4) */
 /* ... for the pixels [first, first + count) of the batch */
 void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total_px, bool eight_views, size_t first, size_t count);
+/* the pixels [first, first + count) of the batch that were written from round r0 on, appended as records of `stride` words
+ * ({view, pixel - first, depth, conf, dzI, dzJ [, nx, ny, nz]}) to `out` (page-locked host memory, `cap` records; *d_count counts
+ * them all, also those that did not fit) */
+void mi_launch_emit_changed(hipStream_t s, const float* maps, const uint32_t* imaps, size_t total_px, size_t first, size_t count,
+                            int r0, unsigned view, unsigned stride, unsigned* d_count, unsigned cap, uint32_t* out);
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
                            const unsigned* key_off);

@@ -2790,6 +2790,49 @@ __global__ __launch_bounds__(256) void k_flatten(FlattenArgs a) {
     if (a.views_hi) a.views_hi[p] = a.views1_hi[p];
 }
 
+/*
+ * The pixels of one view that were written from round r0 on, as records {view, pixel, depth, conf, dzI, dzJ [, nx, ny, nz]}
+ * appended to ONE list in page-locked host memory (all views of a batch; one atomic per wavefront).  What it is for
+ * (BatchRun::front_rounds): the maps of a large batch are copied to the caller while the front kernel still runs -- a
+ * snapshot of the state at the hand-over, 16 bytes per pixel over PCIe, hidden behind the kernel -- and what the front
+ * changed afterwards (a few per cent of the pixels) follows as this list, which the host writes over the snapshot.  A pixel's
+ * state is the slot with the larger stamp (k_flatten).  Records beyond the list's capacity are dropped: the host sees the
+ * count and copies the maps in full instead.
+ */
+struct EmitArgs {
+    const float* depth; const float* dz; const float* conf; const float* normal; const int32_t* upd;
+    const float* depth1; const float* dz1; const float* conf1; const float* normal1; const int32_t* upd1;
+    unsigned n; int r0; unsigned view; unsigned stride;     /* stride: words per record, 6 or 9 (with the normal) */
+    unsigned* count; unsigned cap; uint32_t* out;
+};
+__global__ __launch_bounds__(256) void k_emit_changed(EmitArgs a) {
+    const unsigned p = blockIdx.x * 256 + threadIdx.x;
+    int s0 = -1, s1 = -1;
+    if (p < a.n) { s0 = a.upd[p]; s1 = a.upd1[p]; }
+    const bool mine = p < a.n && (s0 >= a.r0 || s1 >= a.r0);
+    const unsigned long long b = __ballot(mine);
+    if (b == 0) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned base = 0;
+    if (lane == __ffsll((long long)b) - 1) base = atomicAdd(a.count, (unsigned)__popcll(b));
+    base = (unsigned)__shfl((int)base, __ffsll((long long)b) - 1);
+    if (!mine) return;
+    const unsigned k = base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+    if (k >= a.cap) return;
+    const bool one = s1 > s0;
+    uint32_t* o = a.out + (size_t)k * a.stride;
+    o[0] = a.view; o[1] = p;
+    o[2] = __float_as_uint(one ? a.depth1[p] : a.depth[p]);
+    o[3] = __float_as_uint(one ? a.conf1[p] : a.conf[p]);
+    o[4] = __float_as_uint(one ? a.dz1[2 * p] : a.dz[2 * p]);
+    o[5] = __float_as_uint(one ? a.dz1[2 * p + 1] : a.dz[2 * p + 1]);
+    if (a.stride >= 9) {
+        o[6] = __float_as_uint(one ? a.normal1[3 * p] : a.normal[3 * p]);
+        o[7] = __float_as_uint(one ? a.normal1[3 * p + 1] : a.normal[3 * p + 1]);
+        o[8] = __float_as_uint(one ? a.normal1[3 * p + 2] : a.normal[3 * p + 2]);
+    }
+}
+
 /* Parity hook: one hypothesis against every global view; one quad lane per 4 views. */
 struct EvalArgs {
     const DevJob* job; const DevView* views; const float* lut; DevSettings st;
@@ -3431,6 +3474,18 @@ void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total
     a.views_hi = eight_views ? imaps + 4 * total_px + first : nullptr; a.views1_hi = eight_views ? imaps + 5 * total_px + first : nullptr;
     a.n = (unsigned)count;
     hipLaunchKernelGGL(k_flatten, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a);
+}
+
+void mi_launch_emit_changed(hipStream_t s, const float* maps, const uint32_t* imaps, size_t total_px, size_t first, size_t count,
+                            int r0, unsigned view, unsigned stride, unsigned* d_count, unsigned cap, uint32_t* out) {
+    if (total_px == 0 || count == 0) return;
+    EmitArgs a;
+    a.depth = maps + first; a.conf = maps + total_px + first; a.dz = maps + 2 * total_px + 2 * first; a.normal = maps + 4 * total_px + 3 * first;
+    const float* m1 = maps + 7 * total_px;
+    a.depth1 = m1 + first; a.conf1 = m1 + total_px + first; a.dz1 = m1 + 2 * total_px + 2 * first; a.normal1 = m1 + 4 * total_px + 3 * first;
+    a.upd = (const int32_t*)(imaps + total_px + first); a.upd1 = (const int32_t*)(imaps + 3 * total_px + first);
+    a.n = (unsigned)count; a.r0 = r0; a.view = view; a.stride = stride; a.count = d_count; a.cap = cap; a.out = out;
+    hipLaunchKernelGGL(k_emit_changed, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,

@@ -324,6 +324,11 @@ struct BatchScratch {
     uint8_t* h_up = nullptr;                 /* pinned staging of a call's uploads: job table | list offsets | seeds | their hypotheses
                                               * (a copy from pageable memory is staged by the runtime, with waits of its own) */
     size_t h_up_cap = 0;
+    uint32_t* h_sparse = nullptr;            /* pinned, written by k_emit_changed: the pixels the front changed after the maps' snapshot */
+    size_t h_sparse_cap = 0;                 /* ... in words */
+    unsigned* h_emit_end = nullptr;          /* pinned: [views] the list's length after each view's records (copied behind its kernel) */
+    size_t h_emit_cap = 0;
+    DevBuf<unsigned> d_sparse_count;         /* the list's length on the device */
     int32_t* h_gvs = nullptr;                /* pinned: the device view selection's result (a copy into pageable memory is made by the
                                               * runtime with a wait of its own, in steps of 10 ms) */
     size_t h_gvs_cap = 0;
@@ -348,7 +353,7 @@ struct BatchScratch {
     }
     bool holds_anything() const {
         return d_maps.cap || d_work.cap || d_jobs.cap || d_results.cap || d_hyp.cap || d_spec.cap || d_gvs_out.cap || d_gvs_feat.cap
-            || h_poll || h_dyn || h_gvs || h_up || h_done || !events.empty();
+            || h_poll || h_dyn || h_gvs || h_up || h_done || h_sparse || h_emit_end || !events.empty();
     }
     void release() {
         for (size_t i = 0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
@@ -357,7 +362,10 @@ struct BatchScratch {
         d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_keys.release(); d_keyoff.release();
         d_round_work.release(); d_round_work_t.release(); d_round_items.release(); d_view.release(); d_front.release(); d_front_resume.release();
         d_front_mail.release(); d_front_flags.release(); d_front_map.release(); d_front_order.release();
-        d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release();
+        d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release(); d_sparse_count.release();
+        if (h_sparse) (void)hipHostFree(h_sparse);
+        if (h_emit_end) (void)hipHostFree(h_emit_end);
+        h_sparse = nullptr; h_sparse_cap = 0; h_emit_end = nullptr; h_emit_cap = 0;
         if (h_poll) (void)hipHostFree(h_poll);
         if (h_dyn) (void)hipHostFree(h_dyn);
         if (h_done) (void)hipHostFree(h_done);
@@ -1472,6 +1480,16 @@ struct BatchRun {
     std::vector<char> streamed;                /* views whose maps went back to the host while the front kernel still ran */
     int n_streamed = 0, n_streamed_early = 0;
     int stream_view(int j);
+    /* large batches: the maps go back as a snapshot taken at the hand-over (copied while the front kernel runs) plus the
+     * list of the pixels the front changed afterwards (front_rounds) */
+    bool sparse = false, sparse_overflow = false;
+    int sparse_r0 = 0;                         /* the first round whose writes the snapshot may have missed */
+    unsigned sparse_stride = 6, sparse_cap = 0, sparse_done_end = 0;   /* words per record, records the list holds, records scattered so far */
+    std::vector<char> snapped;                 /* views whose snapshot is on its way */
+    std::vector<int> emit_order; size_t emit_seen = 0;
+    int snapshot_views();
+    int emit_view(int j);
+    void scatter_emitted(bool all);
     bool ran_front = false; int front_first_round = 0, front_team = 1, front_team_max = 1, front_fallbacks = 0;
     std::vector<unsigned> view_filled;       /* ... and the pixels the view had filled by then */
     std::vector<unsigned> view_list;         /* entries of every view's list in the last host-visible round read back (0: not known) */
@@ -1926,6 +1944,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
  * Once the lists are down to a few entries per view the rest goes to the front kernel (phase C). */
 int BatchRun::tail_rounds(bool& to_front) {
     to_front = false;
+    sparse_r0 = round;            /* every write so far went to the first state slot, with a stamp below this round */
     /* Rounds up to this many entries try a pixel's candidate hypotheses at the same time (four wavefronts per pixel:
      * the round is one patch optimisation long instead of up to four); larger rounds fill the GPU anyway and run
      * them in turn on one wavefront, which wastes nothing.  MI_DMRECON_SPECULATE=<entries> (0 = never). */
@@ -2216,6 +2235,51 @@ int BatchRun::front_rounds() {
         }
         if (c->bs.h_done) { h_done = c->bs.h_done; std::memset(h_done, 0, (size_t)nj * sizeof(unsigned)); }
     }
+    /* Large batches (MI_DMRECON_SPARSE_MAPS=<views>, default 48; 0 = never): the maps do not wait for their views to end.
+     * One workgroup per view and the long views first makes the views end together, and 16 bytes per pixel of every view
+     * -- 830 MB for 400 views of C3: 31 ms on the box's PCIe link -- then stood behind the front kernel (16 of 253 ms per
+     * batch).  Now: (1) the state as of the hand-over is copied to the caller's buffers WHILE the kernel runs (the first
+     * state slot; what the kernel writes under the copy is read torn, and does not matter:) (2) when a view has ended, the
+     * pixels written since the hand-over -- either slot, stamp >= sparse_r0: a few per cent -- go to a list in page-locked
+     * memory (k_emit_changed), and (3) the host writes them over the snapshot.  Same maps, bit for bit
+     * (test_sparse_maps_equal_full_copies).  A list that outgrows its buffer: everything is copied in full afterwards. */
+    sparse = false; sparse_overflow = false; emit_order.clear(); emit_seen = 0; sparse_done_end = 0;
+    snapped.assign((size_t)nj, 0);
+    {
+        const char* e = std::getenv("MI_DMRECON_SPARSE_MAPS");
+        const int min_views = e ? std::atoi(e) : MI_MERGE_SMALL_CALL;
+        if (h_done && min_views > 0 && nj >= min_views && sparse_r0 > 0) {
+            bool normal = false;
+            for (int i = 0; i < n_refs; ++i) if (maps[i].normal) normal = true;
+            sparse_stride = normal ? 9u : 6u;
+            BatchScratch& bs = c->bs;
+            /* an eighth of the pixels the scratch set holds (C3: the front rewrites 3-4 % of a view's pixels) -- of the SET, not
+             * of this batch: the set's buffers have their headroom, and a list sized by the batch was allocated anew (150 MB
+             * of page-locked memory: 40 ms) by the first batch larger than the warm-up's */
+            const size_t cap = std::min<size_t>(0x7FFFFFFFu, std::max<size_t>(65536, std::max(total_px, bs.pixels()) / 8));
+            bool ok = true;
+            if (bs.h_sparse_cap < cap * sparse_stride) {
+                if (bs.h_sparse) (void)hipHostFree(bs.h_sparse);
+                bs.h_sparse = nullptr; bs.h_sparse_cap = 0;
+                if (hipHostMalloc((void**)&bs.h_sparse, cap * sparse_stride * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) bs.h_sparse_cap = cap * sparse_stride;
+                else { (void)hipGetLastError(); ok = false; }
+            }
+            if (ok && bs.h_emit_cap < (size_t)nj) {
+                if (bs.h_emit_end) (void)hipHostFree(bs.h_emit_end);
+                bs.h_emit_end = nullptr; bs.h_emit_cap = 0;
+                if (hipHostMalloc((void**)&bs.h_emit_end, 2 * (size_t)nj * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) bs.h_emit_cap = 2 * (size_t)nj;
+                else { (void)hipGetLastError(); ok = false; }
+            }
+            if (ok && bs.d_sparse_count.reserve(1)) ok = false;
+            if (ok) {
+                sparse_cap = (unsigned)(bs.h_sparse_cap / sparse_stride);
+                if (const char* dc = std::getenv("MI_DMRECON_DEBUG_SPARSE_CAP")) sparse_cap = std::min(sparse_cap, (unsigned)std::max(1, std::atoi(dc)));   /* test hook */
+                for (int j = 0; j < nj; ++j) bs.h_emit_end[j] = 0xFFFFFFFFu;
+                HIP_TRY(hipMemsetAsync(bs.d_sparse_count.p, 0, sizeof(unsigned), S));     /* (before the front kernel, on its stream) */
+                sparse = true;
+            }
+        }
+    }
     TailPoll& P = c->bs.h_poll[0];
     const int max_round = round + 4 * MI_MAX_ROUNDS;
     /* the first launch deals the last tail round's list out to the views and runs them (as teams, if any); should the
@@ -2238,14 +2302,16 @@ int BatchRun::front_rounds() {
              * (C3: between 2.5 and 14.5 ms), only the slowest ones' maps are left when the kernel is over.  (Nothing else is
              * enqueued behind the kernel before this loop: a strided or pageable read-back holds the host in its call.) */
             HIP_TRY(hipEventRecord(c->bs.poll_ev[0], S));
+            if (sparse && !again) if (int rc = snapshot_views()) return rc;
             for (;;) {
                 const bool over = hipEventQuery(c->bs.poll_ev[0]) != hipErrorNotReady;
                 for (int j = 0; j < nj; ++j)
                     if (!streamed[j] && __atomic_load_n(&h_done[j], __ATOMIC_ACQUIRE) != 0u) {
-                        if (int rc = stream_view(j)) return rc;
+                        if (int rc = (sparse && snapped[j]) ? emit_view(j) : stream_view(j)) return rc;
                         if (!over) ++n_streamed_early;
                         if (trace) fprintf(stderr, "[mi_dmrecon] view %d streamed back at %.3f ms of the front phase (%s)\n", jobs[j].ref_view, now_ms() - t_mark, over ? "kernel over" : "kernel running");
                     }
+                if (sparse) scatter_emitted(false);
                 if (over || n_streamed == nj) break;
                 /* (a sleep of any length comes back 50+ us later: the timer slack; a small call has nothing better to do
                  * than look again at once, a large batch naps: see PatientWaits) */
@@ -2262,6 +2328,14 @@ int BatchRun::front_rounds() {
             HIP_TRY(hipMemcpyAsync(front_stats.data(), d_stats, 4 * (size_t)nj * sizeof(unsigned), hipMemcpyDeviceToHost, S));
         }
         HIP_TRY(wait_stream(S));
+        if (sparse) {
+            HIP_TRY(wait_stream(c->stream2));
+            scatter_emitted(true);
+            if (sparse_overflow)                                  /* the list did not hold it all: full copies after all (download()) */
+                for (int j = 0; j < nj; ++j) if (snapped[j] && streamed[j] == 1) { streamed[j] = 0; --n_streamed; snapped[j] = 0; }
+            if (trace) fprintf(stderr, "[mi_dmrecon] maps: snapshot of %d views at the hand-over (round %d) + %u changed pixels%s\n",
+                               (int)emit_order.size(), sparse_r0, sparse_done_end, sparse_overflow ? " -- list overflow, full copies instead" : "");
+        }
         if (h_done) std::memcpy(front_stats.data(), h_done + nj, 4 * (size_t)nj * sizeof(unsigned));
         hc = P.hc;
         token.reset();                                            /* the teams are gone either way */
@@ -2285,6 +2359,75 @@ int BatchRun::front_rounds() {
     if (hc.error_flags & 8u) truncated = true;
     else done = true;
     return 0;
+}
+
+/* The maps as of the hand-over, every view of the batch, to the callers' buffers on the second stream while the front
+ * kernel runs on the first (front_rounds).  The first state slot holds all of it: the host-visible rounds only write that. */
+int BatchRun::snapshot_views() {
+    hipStream_t S2 = c->stream2;
+    for (int j = 0; j < nj; ++j) {
+        const int i = ref_of_job[j];
+        if (view_rc[i] != 0 || streamed[j]) continue;
+        mi_dmrecon_maps& m = maps[i];
+        if (m.views) continue;                                /* (the local view sets: download(), as for a streamed view) */
+        const size_t np = (size_t)jobs[j].w * jobs[j].h;
+        if (m.depth) HIP_TRY(hipMemcpyAsync(m.depth, dj[j].depth, np * 4, hipMemcpyDeviceToHost, S2));
+        if (m.conf) HIP_TRY(hipMemcpyAsync(m.conf, dj[j].conf, np * 4, hipMemcpyDeviceToHost, S2));
+        if (m.dz) HIP_TRY(hipMemcpyAsync(m.dz, dj[j].dz, np * 8, hipMemcpyDeviceToHost, S2));
+        if (m.normal) HIP_TRY(hipMemcpyAsync(m.normal, dj[j].normal, np * 12, hipMemcpyDeviceToHost, S2));
+        snapped[j] = 1;
+    }
+    return 0;
+}
+
+/* A view that has ended: the pixels written since the snapshot, appended to the list (second stream, behind the snapshot
+ * copies), and the list's length behind them. */
+int BatchRun::emit_view(int j) {
+    streamed[j] = 1; ++n_streamed;
+    hipStream_t S2 = c->stream2;
+    mi_launch_emit_changed(S2, c->bs.d_maps.p, c->bs.d_imaps.p, total_px, jobs[j].pix_off, (size_t)jobs[j].w * jobs[j].h, sparse_r0,
+                           (unsigned)j, sparse_stride, c->bs.d_sparse_count.p, sparse_cap, c->bs.h_sparse);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&c->bs.h_emit_end[emit_order.size()], c->bs.d_sparse_count.p, sizeof(unsigned), hipMemcpyDeviceToHost, S2));
+    emit_order.push_back(j);
+    return 0;
+}
+
+/* Writes the records that have arrived over the snapshot (a view's snapshot copies are ahead of its records on the second
+ * stream: they have landed).  all = false: only when enough has gathered to be worth a team of threads. */
+void BatchRun::scatter_emitted(bool all) {
+    unsigned end = sparse_done_end;
+    size_t seen = emit_seen;
+    while (seen < emit_order.size()) {
+        const unsigned e = __atomic_load_n(&c->bs.h_emit_end[seen], __ATOMIC_ACQUIRE);
+        if (e == 0xFFFFFFFFu) break;
+        end = e; ++seen;
+    }
+    if (seen == emit_seen) return;
+    if (!all && seen - emit_seen < 32 && end - sparse_done_end < (1u << 18)) return;
+    emit_seen = seen;
+    if (end > sparse_cap) { sparse_overflow = true; end = sparse_cap; }
+    const unsigned first = sparse_done_end;
+    if (end <= first) return;
+    sparse_done_end = end;
+    const uint32_t* rec = c->bs.h_sparse;
+    const unsigned stride = sparse_stride;
+    const long long n = (long long)end - (long long)first;
+    const int n_threads = (int)std::max<long long>(1, std::min<long long>(host_threads_cap(), n / 8192));
+#pragma omp parallel for schedule(static) num_threads(n_threads) if (n_threads > 1)
+    for (long long k = 0; k < n; ++k) {
+        const uint32_t* r = rec + (size_t)(first + k) * stride;
+        const unsigned j = r[0];
+        const size_t p = r[1];
+        if (j >= (unsigned)nj) continue;
+        const int i = ref_of_job[j];
+        if (view_rc[i] != 0 || p >= (size_t)jobs[j].w * jobs[j].h) continue;
+        mi_dmrecon_maps& m = maps[i];
+        if (m.depth) std::memcpy(&m.depth[p], &r[2], 4);
+        if (m.conf) std::memcpy(&m.conf[p], &r[3], 4);
+        if (m.dz) std::memcpy(&m.dz[2 * p], &r[4], 8);
+        if (stride >= 9 && m.normal) std::memcpy(&m.normal[3 * p], &r[6], 12);
+    }
 }
 
 /* One finished view's maps to the caller's buffers on the second stream (the front kernel still runs on the first): its
@@ -2367,6 +2510,7 @@ void BatchRun::fill_stats() {
             stats->n_front_launches = 1;
             stats->front_team = front_team;
             stats->front_team_max = front_team > 1 ? front_team_max : 1;
+            stats->n_sparse_records = sparse ? (sparse_overflow ? -1 : (int64_t)sparse_done_end) : 0;
             stats->front_fallbacks = front_fallbacks;
             stats->front_first_round = front_first_round;
             for (int j = 0; j < nj; ++j) {

@@ -224,6 +224,39 @@ def test_speculative_tail_equals_sequential_attempts(gpu_ctx, g1_scene, monkeypa
     assert n_seq["n_patch"] == n_spec["n_patch"] and n_seq["n_eval"] == n_spec["n_eval"]
 
 
+def test_sparse_maps_equal_full_copies(gpu_ctx, g1_scene, h1_scene, monkeypatch):
+    """Large batches get their maps as a snapshot taken at the hand-over to the front kernel (copied while the kernel
+    runs) plus the list of the pixels the front changed afterwards, written over the snapshot by the host
+    (BatchRun::front_rounds, k_emit_changed).  The maps are the ones a full copy after the kernel gives, bit for bit --
+    with and without the normal map (records of 9 / 6 words), for views listed several times (a merged batch's callers
+    may ask for the same view), and when the list outgrows its buffer (everything is copied in full then)."""
+    st = api.Settings()
+    for scene, refs in ((g1_scene, [0, 1, 2, 3, 4, 2, 0]), (h1_scene, list(range(9)))):
+        gpu_ctx.load_scene(scene)
+        monkeypatch.setenv("MI_DMRECON_SPARSE_MAPS", "0")
+        full = gpu_ctx.reconstruct(st, refs, want_normal=True)
+        assert gpu_ctx.last_stats["n_sparse_records"] == 0
+        for want_normal in (True, False):
+            monkeypatch.setenv("MI_DMRECON_SPARSE_MAPS", "1")
+            got = gpu_ctx.reconstruct(st, refs, want_normal=want_normal)
+            s = dict(gpu_ctx.last_stats)
+            assert s["n_front_launches"] == 1 and s["n_sparse_records"] > 0, s        # the path ran
+            assert s["n_sparse_records"] < 0.5 * s["n_filled"], s                       # ... and the list is the small part
+            for a, b in zip(got, full):
+                for k in ("depth", "conf", "dz") + (("normal",) if want_normal else ()):
+                    assert np.array_equal(a[k], b[k]), (k, want_normal)
+        # a list that does not fit (test hook: room for 100 records): full copies after all
+        monkeypatch.setenv("MI_DMRECON_SPARSE_MAPS", "1")
+        monkeypatch.setenv("MI_DMRECON_DEBUG_SPARSE_CAP", "100")
+        got = gpu_ctx.reconstruct(st, refs, want_normal=True)
+        assert gpu_ctx.last_stats["n_sparse_records"] == -1
+        monkeypatch.delenv("MI_DMRECON_DEBUG_SPARSE_CAP")
+        for a, b in zip(got, full):
+            for k in ("depth", "conf", "dz", "normal"):
+                assert np.array_equal(a[k], b[k]), (k, "overflow")
+        monkeypatch.delenv("MI_DMRECON_SPARSE_MAPS")
+
+
 @pytest.mark.parametrize("per_view,team", [("all", "1"), ("1000000", "1"), ("2", "1"), (None, None),
                                            ("all", "8"), ("all", "3"), ("1000000", "25"), ("2", "2")])
 def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, monkeypatch, per_view, team):
