@@ -864,99 +864,154 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
             if (c->sc->geom.has_plx) return plan_global_views_tables(c, st, ref, global);
         }
     }
-    /* features attached to the reference view (dmrecon.cc:185-196), local index = position in `feat` */
+    /* The direct form (a bundle too large for the scene tables: hundreds of views).  Everything below is kept to the views
+     * that can be selected at all -- a candidate's benefit is a sum over the features it shares with the reference view
+     * (global_view_selection.cc:62-101), and only a benefit above zero is ever selected (:44-52) -- so the cost of a
+     * reference view goes with the features it has and the views THEY are attached to, not with the size of the bundle
+     * (no per-view arrays over all views, no scan of every feature's view list).  What remains is the greedy loop itself:
+     * 400 views / 40 000 features in 20 separate blocks of 20 views (bench.py's distinct-scenes variant) take 7 ms of a
+     * core per reference view, 5.5 of them in the loop -- one parallax per selected view, candidate and feature, which the
+     * scene tables hold ready for bundles small enough to have them (0.3 ms per view there).
+     * Same sums in the same order: the views are walked in ascending order, ties go to the lower id as in the reference. */
+    /* features attached to the reference view (dmrecon.cc:185-196), local index = position in `feat`: the reference view's
+     * own list of the inverted bundle (ascending, as the reference walks the bundle), or a scan of the bundle */
     std::vector<int> feat;
-    for (size_t i = 0; i < c->sc->features.size(); ++i) {
+    auto consider = [&](size_t i) {
         Feature const& f = c->sc->features[i];
-        if (!contains_view(c, f, ref)) continue;
         V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
-        if (!R.pointInFrustum(p)) continue;
-        if (!in_box(p, st->aabbMin, st->aabbMax)) continue;
+        if (!R.pointInFrustum(p)) return;
+        if (!in_box(p, st->aabbMin, st->aabbMax)) return;
         feat.push_back((int)i);
+    };
+    if ((size_t)ref + 1 < c->sc->by_view_off.size()) {
+        int last = -1;
+        for (int k = c->sc->by_view_off[ref]; k < c->sc->by_view_off[(size_t)ref + 1]; ++k) {
+            const int i = c->sc->by_view[(size_t)k];
+            if (i != last) consider((size_t)i);               /* (a feature that lists the view twice is still one feature) */
+            last = i;
+        }
+    } else {
+        for (size_t i = 0; i < c->sc->features.size(); ++i)
+            if (contains_view(c, c->sc->features[i], ref)) consider(i);
     }
     const size_t nf = feat.size();
-    std::vector<std::vector<int> > featInd(nv);             /* per view: local feature indices, ascending */
-    std::vector<std::vector<uint8_t> > sees(nv);
-    for (size_t v = 0; v < nv; ++v) sees[v].assign(nf, 0);
-    for (size_t l = 0; l < nf; ++l) {                       /* dmrecon.cc:198-206 */
+    /* the views that see one of those features (dmrecon.cc:198-206), ascending; slot[v] = position in `act`, or -1 */
+    std::vector<int> slot(nv, -1), act;
+    for (size_t l = 0; l < nf; ++l) {
+        Feature const& f = c->sc->features[feat[l]];
+        for (int j = f.ref_begin; j < f.ref_end; ++j) {
+            const int id = c->sc->feat_refs[j];
+            if (id < 0 || id >= (int)nv || !c->sc->views[id].valid || slot[id] >= 0) continue;
+            slot[id] = 0; act.push_back(id);
+        }
+    }
+    std::sort(act.begin(), act.end());
+    for (size_t a = 0; a < act.size(); ++a) slot[act[a]] = (int)a;
+    const size_t na = act.size();
+    std::vector<std::vector<int> > featInd(na);             /* per such view: local feature indices, ascending */
+    std::vector<std::vector<uint8_t> > sees(na);
+    for (size_t a = 0; a < na; ++a) sees[a].assign(nf, 0);
+    for (size_t l = 0; l < nf; ++l) {
         Feature const& f = c->sc->features[feat[l]];
         V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
         for (int j = f.ref_begin; j < f.ref_end; ++j) {
             int id = c->sc->feat_refs[j];
             if (id < 0 || id >= (int)nv || !c->sc->views[id].valid) continue;
-            if (c->sc->views[id].pointInFrustum(p)) { featInd[id].push_back((int)l); sees[id][l] = 1; }
+            const size_t a = (size_t)slot[id];
+            if (c->sc->views[id].pointInFrustum(p)) { featInd[a].push_back((int)l); sees[a][l] = 1; }
         }
     }
-    /* unit directions camera -> feature for every view that has features (parallax(), mvs_tools.h:46-56) */
-    std::vector<std::vector<V3> > dir(nv);
-    for (size_t v = 0; v < nv; ++v) {
-        if (featInd[v].empty() && (int)v != ref) continue;
-        dir[v].resize(nf);
+    /* unit directions camera -> feature for the reference view and every view that has features (parallax(), mvs_tools.h:46-56) */
+    std::vector<V3> dir_ref(nf);
+    for (size_t l = 0; l < nf; ++l) {
+        Feature const& f = c->sc->features[feat[l]];
+        dir_ref[l] = normalized(sub(mk(f.pos[0], f.pos[1], f.pos[2]), R.pos()));
+    }
+    std::vector<std::vector<V3> > dir(na);
+    for (size_t a = 0; a < na; ++a) {
+        if (featInd[a].empty()) continue;
+        if (act[a] == ref) { dir[a] = dir_ref; continue; }
+        dir[a].resize(nf);
         for (size_t l = 0; l < nf; ++l) {
             Feature const& f = c->sc->features[feat[l]];
-            dir[v][l] = normalized(sub(mk(f.pos[0], f.pos[1], f.pos[2]), c->sc->views[v].pos()));
+            dir[a][l] = normalized(sub(mk(f.pos[0], f.pos[1], f.pos[2]), c->sc->views[act[a]].pos()));
         }
     }
-    auto parallax_l = [&](size_t l, size_t v1, size_t v2) {
-        float dp = std::max(std::min(dot3(dir[v1][l].v, dir[v2][l].v), 1.f), -1.f);
+    auto parallax_d = [&](V3 const& d1, V3 const& d2) {
+        float dp = std::max(std::min(dot3(d1.v, d2.v), 1.f), -1.f);
         return std::acos(dp) * 180.f / kPi;
     };
+    /* The only thing the parallax is used for is `plx < minParallax` and, below it, (plx / 10)^2 (:76-79, :91-98): a pair of
+     * directions whose cosine is clearly below cos(minParallax) -- by a margin a thousand times the rounding of the dot
+     * product and of acos -- is not below it, and its arc cosine (the direct form's main cost: one per selected view,
+     * candidate and feature) need not be taken. */
+    const float cos_clear = std::cos(std::min(std::max(st->minParallax, 0.f), 180.f) * kPi / 180.f) - 1e-4f;
+    auto penalty = [&](V3 const& d1, V3 const& d2) -> float {      /* the factor of (:76-79) / (:94-97): 1 or (plx / 10)^2 */
+        if (dot3(d1.v, d2.v) < cos_clear) return 1.f;
+        const float plx = parallax_d(d1, d2);
+        return plx < st->minParallax ? (plx / 10.f) * (plx / 10.f) : 1.f;
+    };
     /* the part of benefitFromView's score that does not depend on the selected set (:76-89) */
-    std::vector<std::vector<float> > base(nv);
-    for (size_t i = 0; i < nv; ++i) {
-        if ((int)i == ref || !c->sc->views[i].valid) continue;
-        base[i].resize(featInd[i].size());
-        for (size_t k = 0; k < featInd[i].size(); ++k) {
-            const size_t l = featInd[i][k];
+    std::vector<std::vector<float> > base(na);
+    std::vector<char> available(na, 1);                                     /* global_view_selection.cc:23-30 */
+    for (size_t a = 0; a < na; ++a) {
+        const int i = act[a];
+        if (i == ref || featInd[a].empty()) { available[a] = 0; continue; }   /* (no shared feature: benefit 0, never selected) */
+        base[a].resize(featInd[a].size());
+        for (size_t k = 0; k < featInd[a].size(); ++k) {
+            const size_t l = featInd[a][k];
             Feature const& f = c->sc->features[feat[l]];
             V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
             float score = 1.f;
-            float plx = parallax_l(l, ref, i);
-            if (plx < st->minParallax) score *= (plx / 10.f) * (plx / 10.f);
+            score *= penalty(dir_ref[l], dir[a][l]);
             float mfp = R.footPrint(p, st->scale);
             float nfp = c->sc->views[i].footPrint(p, 0);
             float ratio = mfp / nfp;
             if (ratio > 2.) ratio = 2. / ratio;
             else if (ratio > 1.) ratio = 1.;
             score *= ratio;
-            base[i][k] = score;
+            base[a][k] = score;
         }
     }
-    std::vector<char> available(nv, 1);                                     /* global_view_selection.cc:23-30 */
-    available[ref] = 0;
-    for (size_t i = 0; i < nv; ++i) if (!c->sc->views[i].valid) available[i] = 0;
-    std::vector<int> selected;          /* kept sorted ascending = std::set order */
+    std::vector<int> selected;          /* view ids, kept sorted ascending = std::set order */
+    std::vector<size_t> selected_a;     /* ... and their positions in `act`, in the same order */
     /* pen[c][i][k]: factor view c (once selected) contributes to feature k of candidate i (:91-98) */
-    std::vector<std::vector<std::vector<float> > > pen(nv);
+    std::vector<std::vector<std::vector<float> > > pen(na);
+    std::vector<std::vector<char> > plain(na);   /* plain[c][i]: every factor of the pair is 1 -- multiplying by them changes nothing */
     bool foundOne = true;
     while (foundOne && selected.size() < (size_t)st->globalVSMax) {
-        float maxBenefit = 0.f; size_t maxView = 0; foundOne = false;
-        for (size_t i = 0; i < nv; ++i) {
-            if (!available[i]) continue;
+        float maxBenefit = 0.f; size_t maxA = 0; foundOne = false;
+        for (size_t a = 0; a < na; ++a) {
+            if (!available[a]) continue;
             float benefit = 0;
-            const size_t nk = featInd[i].size();
+            const size_t nk = featInd[a].size();
             for (size_t k = 0; k < nk; ++k) {
-                float score = base[i][k];
-                for (size_t s = 0; s < selected.size(); ++s) score *= pen[selected[s]][i][k];
+                float score = base[a][k];
+                for (size_t s = 0; s < selected_a.size(); ++s) if (!plain[selected_a[s]][a]) score *= pen[selected_a[s]][a][k];
                 benefit += score;
             }
-            if (benefit > maxBenefit) { maxBenefit = benefit; maxView = i; foundOne = true; }
+            if (benefit > maxBenefit) { maxBenefit = benefit; maxA = a; foundOne = true; }
         }
         if (foundOne) {
-            selected.insert(std::upper_bound(selected.begin(), selected.end(), (int)maxView), (int)maxView);
-            available[maxView] = 0;
+            const size_t at = (size_t)(std::upper_bound(selected.begin(), selected.end(), act[maxA]) - selected.begin());
+            selected.insert(selected.begin() + (std::ptrdiff_t)at, act[maxA]);
+            selected_a.insert(selected_a.begin() + (std::ptrdiff_t)at, maxA);
+            available[maxA] = 0;
             if (selected.size() < (size_t)st->globalVSMax) {
-                pen[maxView].resize(nv);
-                for (size_t i = 0; i < nv; ++i) {
-                    if (!available[i]) continue;
-                    std::vector<float>& pv = pen[maxView][i];
-                    pv.assign(featInd[i].size(), 1.f);
-                    for (size_t k = 0; k < featInd[i].size(); ++k) {
-                        const size_t l = featInd[i][k];
-                        if (!sees[maxView][l]) continue;
-                        float plx = parallax_l(l, maxView, i);
-                        if (plx < st->minParallax) pv[k] = (plx / 10.f) * (plx / 10.f);
+                pen[maxA].resize(na);
+                plain[maxA].assign(na, 1);
+                for (size_t a = 0; a < na; ++a) {
+                    if (!available[a]) continue;
+                    std::vector<float>& pv = pen[maxA][a];
+                    pv.assign(featInd[a].size(), 1.f);
+                    bool ones = true;
+                    for (size_t k = 0; k < featInd[a].size(); ++k) {
+                        const size_t l = featInd[a][k];
+                        if (!sees[maxA][l]) continue;
+                        pv[k] = penalty(dir[maxA][l], dir[a][l]);
+                        if (pv[k] != 1.f) ones = false;
                     }
+                    plain[maxA][a] = ones ? 1 : 0;
                 }
             }
         }
