@@ -122,7 +122,7 @@ typedef struct mi_dmrecon_stats {
                              * once; a pass can stand for two of the reference's evaluations, see n_eval) */
     int64_t truncated;      /* 1 if the propagation ran out of round counters (the call fails with EDEVICE) */
     int64_t n_eval_bulk, n_patch_bulk, n_filled_bulk;   /* the share of n_eval / n_patch / n_filled of the host-visible rounds */
-    int64_t n_view_replaced; /* local views dropped by replaceViews (patch_optimization.cc:218-228; speculative attempts included) */
+    int64_t n_view_replaced; /* local views dropped by replaceViews (patch_optimization.cc:218-228), by the attempts the reference's rule makes */
     int64_t n_iter14;        /* ... of which only by the iteration-14 rule (still moving at iterationCount == 14) */
     int64_t gvs_on_device;   /* 1 if the global view selection of this call ran on the GPU (gvs_device.hip) */
     double  ms_plan_gvs;     /* host clock: global view selection of all reference views of the call */

@@ -1252,6 +1252,10 @@ struct Run {
     bool bail;                   /* FAST kernels: the patch needs a view selection -- left to the general kernel */
     int iter, need, ctx;
     float oldncc;                /* per view slot: getFastNCC before the step (:189-192) */
+    /* speculative attempts (k_optimize_spec): what an attempt would do to anything but its own result is only noted --
+     * bit 0: the footprint exception, bits 8..15 / 16..23: views replaced / ... by the iteration-14 rule alone -- and carried
+     * out by k_apply_spec for the attempts the reference's rule consumes (a discarded attempt must not fail a view) */
+    unsigned deferred;
 };
 
 /* the pixel ray of (x, y) before / after normalisation (single_view.cc:106-114, mve/depthmap.cc:149-156: K_s^-1 at the
@@ -1296,7 +1300,7 @@ __device__ __forceinline__ void patch_normal(const PatchState& ps, float& nx, fl
 template <class L>
 __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
                                           float depth0, float dzI0, float dzJ0, unsigned long long hyp_views, int lane, unsigned& err,
-                                          DevCounters* counters) {
+                                          DevCounters* counters, bool defer = false) {
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
     float* geo = lds_geo<L>(L::patch(lane));
@@ -1309,6 +1313,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     viewc_reset(R.vc);
     R.opti = true; R.converged = false; R.viewRemoved = false; R.step_was_normal = false;
     R.iter = 0; R.need = PASS_DEPTH; R.ctx = CTX_CTOR; R.oldncc = -1.f; R.need_vs = false; R.count_color = false; R.bail = false;
+    R.deferred = 0;
     /* --- PatchSampler ctor: border test (patch_sampler.cc:44-50) */
     if (x - MI_HALF < 0 || y - MI_HALF < 0 || x + MI_HALF > job->w - 1 || y + MI_HALF > job->h - 1) return false;
     ps.jinv0 = job->inv0_s;
@@ -1390,6 +1395,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
     /* computePatchPoints */
     if (!set_state(ps, depth0, dzI0, dzJ0)) return false;
     if (!(ps.mfp > 0.f)) {                                 /* reference throws std::out_of_range here: the VIEW fails */
+        if (defer) { R.deferred |= 1u; return false; }
         err |= 1u;
         atomicOr(const_cast<int32_t*>(&job->flags), (int)MI_JOB_EFOOTPRINT);
         return false;
@@ -1422,7 +1428,7 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
  * fused pass at the current state (colour sums + the Gauss-Newton sums the NEXT step needs), finish the
  * decision of the step that led here, take the next step.  Returns false when the optimisation is over.
  */
-template <class L, bool FAST>
+template <class L, bool FAST, bool DEFER = false>
 __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const DevView* views, int lane) {
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
@@ -1464,8 +1470,10 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
         const bool conv = L::view_ballot(moving, lane) == 0;
         const unsigned r14 = L::view_ballot(replace && !(ps.ncc < st.acceptNCC), lane);
         if (rmask) {
-            if (slot == 0 && sub == 0) {
-                /* diagnostics (rare events): views replaced, and how many of them by the iteration-14 rule alone */
+            if (DEFER) R.deferred += ((unsigned)__popc(rmask) << 8) + ((unsigned)__popc(r14) << 16);   /* (a patch replaces a handful) */
+            else if (!FAST && slot == 0 && sub == 0) {
+                /* diagnostics (rare events): views replaced, and how many of them by the iteration-14 rule alone (not in the FAST
+                 * kernels: a patch that replaces a view is abandoned there and redone -- and counted -- by the general kernel) */
                 atomicAdd(&ps.counters->n_view_replaced, (unsigned long long)__popc(rmask));
                 if (r14) atomicAdd(&ps.counters->n_iter14, (unsigned long long)__popc(r14));
             }
@@ -1608,13 +1616,14 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
 
 /* Returns false if the attempt was abandoned (FAST kernels only: it needs a view selection); res is void then and only the
  * passes actually run are counted. */
-template <class L, bool FAST = false>
+template <class L, bool FAST = false, bool DEFER = false>
 __device__ __forceinline__ bool optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
                                float depth0, float dzI0, float dzJ0, unsigned long long hyp_views, int lane,
-                               PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err, DevCounters* counters) {
+                               PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err, DevCounters* counters,
+                               unsigned* deferred = nullptr) {
     Run R;
     TSTAMP(10);
-    if (run_begin<L>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters)) {
+    if (run_begin<L>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters, DEFER)) {
 #ifdef MI_ACTIVITY
         /* development build (make variant VFLAGS=-DMI_ACTIVITY): how many of a wavefront's patches are still at work in a
          * turn -- [0] patch-turns, [1] wavefront-turns (k_optimize flushes them into n_stage / n_gather_pass) */
@@ -1622,13 +1631,14 @@ __device__ __forceinline__ bool optimize_patch(const DevJob* job, const DevSetti
         do {
             if (L::vslot(lane) == 0 && L::sub(lane) == 0) atomicAdd(&g_act[0], 1u);
             if (lane == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_act[1], 1u);
-            more = run_turn<L, FAST>(R, st, views, lane);
+            more = run_turn<L, FAST, DEFER>(R, st, views, lane);
         } while (more);
 #else
-        while (run_turn<L, FAST>(R, st, views, lane)) { }
+        while (run_turn<L, FAST, DEFER>(R, st, views, lane)) { }
 #endif
     }
     TSTAMP(40);
+    if (DEFER) *deferred = R.deferred;
     if (FAST && R.bail) { n_pass += R.ps.n_pass; return false; }
     run_end<L>(R, st, lane, res, n_eval, n_pass);
     return true;
@@ -2024,14 +2034,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((MI_FW >= 
         const float hd = GF(job->depth + p), hi = GF(job->dz + 2 * p), hj = GF(job->dz + 2 * p + 1);
         const unsigned long long hv = load_view_set<L::NV>(job, false, p);
         PatchResult r; unsigned ne = 0, np = 0;
-        optimize_patch<L, false>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, ne, np, err, a.counters);
+        unsigned deferred = 0;
+        optimize_patch<L, false, true>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, ne, np, err, a.counters, &deferred);
         if (L::sub(lane) != 0) { ne = 0; np = 0; }
         ne = patch_sum_u<L>(ne); np = patch_sum_u<L>(np);
         if (writer) {
             DevSpec o;
             o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ; o.nx = r.nx; o.ny = r.ny; o.nz = r.nz;
             o.views = r.views; o.views_hi = r.views_hi; o.iters = r.iters; o.bc = bc; o.own = own; o.n_eval = ne; o.n_pass = np;
-            o.n_cand = n_cand; o.pad = 0;
+            o.n_cand = n_cand; o.pad = (int32_t)deferred;
             *rec = o;
         }
     }
@@ -3114,6 +3125,18 @@ __global__ __launch_bounds__(256) void k_apply_spec(ApplyArgs a) {
                 for (int s = 0; s < n_cand; ++s) {
                     if (best > rec[s].bc) break;                                       /* dmrecon.cc:371 (and every later one) */
                     ++n_patch; n_eval += rec[s].n_eval; n_pass += rec[s].n_pass;
+                    if (const unsigned d = (unsigned)rec[s].pad) {
+                        /* what this attempt noted instead of doing (Run::deferred) -- it is one the rule consumes: the views it
+                         * replaced, and the footprint exception, which ends the VIEW as in every other form of a round */
+                        if ((d >> 8) & 0xFFu) atomicAdd(&a.counters->n_view_replaced, (unsigned long long)((d >> 8) & 0xFFu));
+                        if ((d >> 16) & 0xFFu) atomicAdd(&a.counters->n_iter14, (unsigned long long)((d >> 16) & 0xFFu));
+                        if (d & 1u) {
+                            atomicOr(const_cast<int32_t*>(&a.jobs[a.work[e].job].flags), (int)MI_JOB_EFOOTPRINT);
+                            atomicOr(&a.counters->error_flags, 1u);
+                            fin = -1;
+                            break;
+                        }
+                    }
                     const float cf = rec[s].conf;
                     if (cf > 0.f && best < cf) { best = cf; fin = s; }                 /* dmrecon.cc:378,391 */
                 }

@@ -132,7 +132,7 @@ struct DevSpec {
     float own;               /* the pixel's own confidence, frozen at the start of the round */
     uint32_t n_eval, n_pass; /* what this attempt counted (all view slots) */
     int32_t n_cand;          /* rank 0 only: candidates of the entry (0: the view has ended) */
-    int32_t pad;
+    int32_t pad;             /* Run::deferred: what the attempt noted instead of doing (footprint exception, views replaced) */
 };
 
 struct DevCounters {
