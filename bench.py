@@ -721,6 +721,11 @@ def main():
                        # calls per library batch in every timed region (same order as `repeats`)
                        "calls_per_library_batch_by_region": last.get("batch_shapes", []),
                        "mean_fill": round(fill, 4),
+                       # how the maps of a timed batch reached the host (mi_dmrecon_stats::n_sparse_records): batches of 48+ views get a
+                       # snapshot of the state at the hand-over to the front kernel, copied while that kernel runs, plus the pixels
+                       # the front changed afterwards (this many per depth map; 0: the maps of a view are copied when the view has
+                       # ended; MI_DMRECON_SPARSE_MAPS) -- the maps are on the host when a call returns either way
+                       "maps_changed_pixels_per_depth_map": round(max(0, acc.get("n_sparse_records", 0)) / max(1, n_maps_rank * n_rep), 1),
                        # what `value` batches: every timed step reconstructs the SAME scene's reference views (one resident
                        # scene: a saturated-throughput figure whose concurrent jobs share one image set) ...
                        "distinct_scenes": 1},
