@@ -389,8 +389,12 @@ struct MergeQueue {
     int running = 0;                         /* batches being executed */
     bool gathering = false;                  /* a leader is waiting a moment for more requests before it starts */
     int company_credit = 0;                  /* > 0: calls of this scene have met lately -- worth a short wait for more */
-    int expect = 0;                          /* calls the largest of the recent batches served: a leader that has gathered that many
-                                              * does not wait for its window to run out */
+    /* How many calls of this scene are under way at a time, lately (the largest figure of the last eight batches, counted when
+     * a batch forms: its own calls + those still pending + those inside batches that are running): a leader that has gathered
+     * all of them that CAN come -- the ones inside a running batch cannot -- does not wait for its window to run out.  (Counting
+     * the calls a batch served instead would lock a pattern in: four callers that once met two and two would have gone on
+     * leaving in pairs.) */
+    int expect = 0, running_calls = 0, recent[8] = {0, 0, 0, 0, 0, 0, 0, 0}, recent_i = 0;
 };
 
 struct SceneStore {
@@ -2790,12 +2794,10 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
         batch.push_back(&me);
         if (Q.company_credit > 0 && WINDOW_US > 0) {              /* others are probably on their way: let them join me */
             Q.gathering = true;                              /* (nobody else starts to lead meanwhile) */
-            /* ... until the window has run out, or as many calls are there as the recent batches served (the four callers of
+            /* ... until the window has run out, or every call that can come is there (MergeQueue::expect; the four callers of
              * the bench's plan arrive within a few hundred microseconds of each other: the rest of the 3 ms was 1 % of a batch) */
-            const int expect = Q.expect;
-            const bool full = Q.cv.wait_for(lock, std::chrono::microseconds(WINDOW_US),
-                                            [&] { return expect > 1 && (int)Q.pending.size() + 1 >= expect; });
-            if (!full && Q.expect > 1) --Q.expect;           /* fewer callers than there used to be: expect fewer, step by step */
+            (void)Q.cv.wait_for(lock, std::chrono::microseconds(WINDOW_US),
+                                [&] { return Q.expect > 1 && (int)Q.pending.size() + 1 >= Q.expect - Q.running_calls; });
             Q.gathering = false;
         }
         /* take every pending request with my settings, in arrival order.  Measured and dropped: taking only half of them
@@ -2807,7 +2809,9 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
             if (std::memcmp(r->st, st, sizeof(*st)) == 0) { r->taken = true; batch.push_back(r); Q.pending.erase(Q.pending.begin() + i); }
             else ++i;
         }
-        Q.expect = std::max(Q.expect, (int)batch.size());
+        Q.recent[Q.recent_i++ & 7] = (int)batch.size() + (int)Q.pending.size() + Q.running_calls;
+        Q.expect = *std::max_element(Q.recent, Q.recent + 8);
+        Q.running_calls += (int)batch.size();
     }
     Q.cv.notify_all();                                       /* requests with other settings may lead now */
     /* whatever happens below (std::bad_alloc included): the batch stops counting as running, and every follower that
@@ -2818,6 +2822,7 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
             {
                 std::lock_guard<std::mutex> lock(Q.mu);
                 --Q.running;
+                Q.running_calls -= (int)batch.size();
                 for (MergeReq* r : batch) {
                     if (r == me || r->done) continue;
                     if (!r->served) { r->rc = MI_DMRECON_EDEVICE; r->err = "the merged batch this call was part of failed"; }

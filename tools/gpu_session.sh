@@ -1,9 +1,10 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): round 5, session U -- the one-workgroup-per-view front with TWELVE wavefronts per
-# workgroup at 168 registers (264 B of scratch per lane) instead of eight at 256: more attempts of a view in flight per CU.
+# Runs ON THE GPU BOX (through gpurun): round 5, session V -- two attempts per wavefront in the one-workgroup-per-view front
+# (Lay<8, 4>, MI_DMRECON_FRONT_TWIN): bit-identity test, then the driver's plan with and without.
 export TMPDIR=/tmp
-O=gpurun_out/r5u
+O=gpurun_out/r5v
 mkdir -p $O
+true
 line() { python - "$1" <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
@@ -12,5 +13,7 @@ PY
 }
 AB="--steps 20 --warmup 5 --repeats 3 --no-cpu-baseline --distinct-scenes 0 --no-one-call"
 run() { V=$1; shift; env "$@" MI_BENCH_REGION_LOG=1 timeout -s KILL 240 python bench.py $AB > $O/bench_$V.json 2> $O/bench_$V.err; line $O/bench_$V.json; grep "^region" $O/bench_$V.err | sed -n '3p'; }
-run fw12 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_fw12.so
-run main A=1
+run twin A=1
+run single MI_DMRECON_FRONT_TWIN=0
+run twin2 A=1
+run single2 MI_DMRECON_FRONT_TWIN=0
