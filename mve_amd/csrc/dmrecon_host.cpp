@@ -41,6 +41,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "dmrecon_device.h"
@@ -260,8 +261,23 @@ struct JobHost {          /* host-side plan of one reference view */
  * in each view (-> footPrint) and the parallax between two views at a feature.  Built once per scene (like the image
  * pyramids) so that the global view selection of a reference view is table look-ups plus its greedy loop; the float
  * operations behind every entry are the ones the per-view code performs, so the selection is bit-identical. */
+/* The parallax of the features two views share, for bundles too large for the dense tables below: per pair of views the
+ * features both are attached to (ascending) and the angle between their directions camera -> feature (parallax(),
+ * mvs_tools.h:46-56) -- what the greedy loop of the global view selection asks for once per selected view, candidate and
+ * feature, for every reference view that meets the pair.  Built on first use by whichever planning thread asks first,
+ * immutable afterwards, dropped with the scene's tables.  A scene whose pairs outgrow the budget goes on computing. */
+struct PairList { std::vector<int> f; std::vector<float> plx; };
+struct PairCache {
+    static constexpr int SHARDS = 64;
+    static constexpr size_t BUDGET = (size_t)1 << 30;
+    std::mutex mu[SHARDS];
+    std::unordered_map<uint64_t, std::shared_ptr<const PairList> > map[SHARDS];
+    std::atomic<size_t> bytes{0};
+};
+
 struct SceneGeom {
     bool built = false, has_plx = false;
+    std::shared_ptr<PairCache> pairs;        /* the direct form's cache (has_plx == false) */
     bool on_device = false;                  /* the tables below are in SceneStore::d_geom_* (gvs_device.hip) */
     size_t nv = 0, nf = 0;
     std::vector<uint8_t> sees;               /* [v * nf + f]: v references f and f is inside v's frustum */
@@ -520,7 +536,9 @@ void build_scene_geom(SceneStore& sc) {
     /* the size guard first: a bundle too large for the parallax table (1000 views x 1M features would need 4 TB) gets
      * no tables at all -- the direct path (plan_global_views) needs O(features of the reference view) */
     g.has_plx = nv * nv * nf <= ((size_t)1 << 26);                         /* 256 MB of floats at most */
+    g.pairs.reset();
     if (!g.has_plx) {
+        g.pairs = std::make_shared<PairCache>();
         std::vector<uint8_t>().swap(g.sees); std::vector<float>().swap(g.zcam); std::vector<float>().swap(g.plx);
         std::vector<uint8_t>().swap(g.refs);
         return;
@@ -853,6 +871,50 @@ int plan_global_views_device(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
  * unit directions feature->camera are computed once, and the pairwise parallax penalty of a newly
  * selected view is computed once instead of once per greedy round (multiplying by a cached factor,
  * or by 1.0f where the reference skips, gives bit-identical products). */
+/* the shared features of views v1, v2 and their parallaxes (PairCache): from the cache, or built now */
+std::shared_ptr<const PairList> pair_list(SceneStore& sc, PairCache* pc, int v1, int v2) {
+    if (v1 > v2) std::swap(v1, v2);
+    const uint64_t key = ((uint64_t)(uint32_t)v1 << 32) | (uint32_t)v2;
+    const int shard = (int)((key * 0x9E3779B97F4A7C15ull) >> 58);
+    if (pc) {
+        std::lock_guard<std::mutex> lock(pc->mu[shard]);
+        auto it = pc->map[shard].find(key);
+        if (it != pc->map[shard].end()) return it->second;
+    }
+    auto L = std::make_shared<PairList>();
+    const std::vector<int>& off = sc.by_view_off;
+    if ((size_t)v2 + 1 < off.size() && v1 >= 0) {
+        const V3 c1 = sc.views[v1].pos(), c2 = sc.views[v2].pos();
+        int a = off[v1], b = off[v2];
+        const int ea = off[(size_t)v1 + 1], eb = off[(size_t)v2 + 1];
+        while (a < ea && b < eb) {
+            const int fa = sc.by_view[(size_t)a], fb = sc.by_view[(size_t)b];
+            if (fa < fb) ++a;
+            else if (fb < fa) ++b;
+            else {
+                if (L->f.empty() || L->f.back() != fa) {
+                    Feature const& f = sc.features[(size_t)fa];
+                    const V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
+                    const V3 d1 = normalized(sub(p, c1)), d2 = normalized(sub(p, c2));
+                    const float dp = std::max(std::min(dot3(d1.v, d2.v), 1.f), -1.f);     /* (symmetric in its arguments, bit for bit) */
+                    L->f.push_back(fa); L->plx.push_back(std::acos(dp) * 180.f / kPi);
+                }
+                ++a; ++b;
+            }
+        }
+    }
+    if (pc) {
+        const size_t sz = L->f.size() * (sizeof(int) + sizeof(float)) + 64;
+        if (pc->bytes.load(std::memory_order_relaxed) + sz <= PairCache::BUDGET) {
+            std::lock_guard<std::mutex> lock(pc->mu[shard]);
+            auto ins = pc->map[shard].emplace(key, L);
+            if (ins.second) pc->bytes.fetch_add(sz, std::memory_order_relaxed);
+            return ins.first->second;
+        }
+    }
+    return L;
+}
+
 int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref, std::vector<int>& global) {
     const size_t nv = c->sc->views.size();
     if (int r = check_ref_view(c, st, ref)) return r;
@@ -872,10 +934,9 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
      * that can be selected at all -- a candidate's benefit is a sum over the features it shares with the reference view
      * (global_view_selection.cc:62-101), and only a benefit above zero is ever selected (:44-52) -- so the cost of a
      * reference view goes with the features it has and the views THEY are attached to, not with the size of the bundle
-     * (no per-view arrays over all views, no scan of every feature's view list).  What remains is the greedy loop itself:
-     * 400 views / 40 000 features in 20 separate blocks of 20 views (bench.py's distinct-scenes variant) take 7 ms of a
-     * core per reference view, 5.5 of them in the loop -- one parallax per selected view, candidate and feature, which the
-     * scene tables hold ready for bundles small enough to have them (0.3 ms per view there).
+     * (no per-view arrays over all views, no scan of every feature's view list), and the parallaxes of the greedy loop -- one
+     * per selected view, candidate and feature -- come from a cache per pair of views (PairCache: the dense scene tables'
+     * counterpart for bundles too large to have them).
      * Same sums in the same order: the views are walked in ascending order, ties go to the lower id as in the reference. */
     /* features attached to the reference view (dmrecon.cc:185-196), local index = position in `feat`: the reference view's
      * own list of the inverted bundle (ascending, as the reference walks the bundle), or a scan of the bundle */
@@ -925,35 +986,25 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
             if (c->sc->views[id].pointInFrustum(p)) { featInd[a].push_back((int)l); sees[a][l] = 1; }
         }
     }
-    /* unit directions camera -> feature for the reference view and every view that has features (parallax(), mvs_tools.h:46-56) */
-    std::vector<V3> dir_ref(nf);
-    for (size_t l = 0; l < nf; ++l) {
-        Feature const& f = c->sc->features[feat[l]];
-        dir_ref[l] = normalized(sub(mk(f.pos[0], f.pos[1], f.pos[2]), R.pos()));
+    /* The parallax of a feature between two views -- all the greedy loop wants from it is `plx < minParallax` and, below it,
+     * (plx / 10)^2 (:76-79, :91-98) -- comes from the scene's pair cache: the features two views share with their angles,
+     * computed once per pair and scene instead of once per selected view, candidate, feature AND reference view (the arc
+     * cosines were 5.5 of the 7 ms a reference view of a 400-view bundle took).  Both lists ascend: one walk per pair. */
+    PairCache* pc = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c->sc->mu);
+        if (!c->sc->geom.pairs) c->sc->geom.pairs = std::make_shared<PairCache>();
+        pc = c->sc->geom.pairs.get();
     }
-    std::vector<std::vector<V3> > dir(na);
-    for (size_t a = 0; a < na; ++a) {
-        if (featInd[a].empty()) continue;
-        if (act[a] == ref) { dir[a] = dir_ref; continue; }
-        dir[a].resize(nf);
-        for (size_t l = 0; l < nf; ++l) {
-            Feature const& f = c->sc->features[feat[l]];
-            dir[a][l] = normalized(sub(mk(f.pos[0], f.pos[1], f.pos[2]), c->sc->views[act[a]].pos()));
-        }
-    }
-    auto parallax_d = [&](V3 const& d1, V3 const& d2) {
-        float dp = std::max(std::min(dot3(d1.v, d2.v), 1.f), -1.f);
-        return std::acos(dp) * 180.f / kPi;
-    };
-    /* The only thing the parallax is used for is `plx < minParallax` and, below it, (plx / 10)^2 (:76-79, :91-98): a pair of
-     * directions whose cosine is clearly below cos(minParallax) -- by a margin a thousand times the rounding of the dot
-     * product and of acos -- is not below it, and its arc cosine (the direct form's main cost: one per selected view,
-     * candidate and feature) need not be taken. */
-    const float cos_clear = std::cos(std::min(std::max(st->minParallax, 0.f), 180.f) * kPi / 180.f) - 1e-4f;
-    auto penalty = [&](V3 const& d1, V3 const& d2) -> float {      /* the factor of (:76-79) / (:94-97): 1 or (plx / 10)^2 */
-        if (dot3(d1.v, d2.v) < cos_clear) return 1.f;
-        const float plx = parallax_d(d1, d2);
-        return plx < st->minParallax ? (plx / 10.f) * (plx / 10.f) : 1.f;
+    auto factor = [&](float plx) -> float { return plx < st->minParallax ? (plx / 10.f) * (plx / 10.f) : 1.f; };
+    /* the parallax of feature `gid` in the pair's list, the cursor moving on (a feature both views are attached to is in it) */
+    auto lookup = [&](PairList const& PL, size_t& cur, int gid, int v1, int v2) -> float {
+        while (cur < PL.f.size() && PL.f[cur] < gid) ++cur;
+        if (cur < PL.f.size() && PL.f[cur] == gid) return PL.plx[cur];
+        Feature const& f = c->sc->features[(size_t)gid];                   /* (not reached: computed as the list would have) */
+        const V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
+        const V3 d1 = normalized(sub(p, c->sc->views[std::min(v1, v2)].pos())), d2 = normalized(sub(p, c->sc->views[std::max(v1, v2)].pos()));
+        return std::acos(std::max(std::min(dot3(d1.v, d2.v), 1.f), -1.f)) * 180.f / kPi;
     };
     /* the part of benefitFromView's score that does not depend on the selected set (:76-89) */
     std::vector<std::vector<float> > base(na);
@@ -962,12 +1013,14 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
         const int i = act[a];
         if (i == ref || featInd[a].empty()) { available[a] = 0; continue; }   /* (no shared feature: benefit 0, never selected) */
         base[a].resize(featInd[a].size());
+        const std::shared_ptr<const PairList> PL = pair_list(*c->sc, pc, ref, i);
+        size_t cur = 0;
         for (size_t k = 0; k < featInd[a].size(); ++k) {
             const size_t l = featInd[a][k];
             Feature const& f = c->sc->features[feat[l]];
             V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
             float score = 1.f;
-            score *= penalty(dir_ref[l], dir[a][l]);
+            score *= factor(lookup(*PL, cur, feat[l], ref, i));
             float mfp = R.footPrint(p, st->scale);
             float nfp = c->sc->views[i].footPrint(p, 0);
             float ratio = mfp / nfp;
@@ -982,6 +1035,7 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
     /* pen[c][i][k]: factor view c (once selected) contributes to feature k of candidate i (:91-98) */
     std::vector<std::vector<std::vector<float> > > pen(na);
     std::vector<std::vector<char> > plain(na);   /* plain[c][i]: every factor of the pair is 1 -- multiplying by them changes nothing */
+    std::vector<float> scr;
     bool foundOne = true;
     while (foundOne && selected.size() < (size_t)st->globalVSMax) {
         float maxBenefit = 0.f; size_t maxA = 0; foundOne = false;
@@ -989,11 +1043,15 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
             if (!available[a]) continue;
             float benefit = 0;
             const size_t nk = featInd[a].size();
-            for (size_t k = 0; k < nk; ++k) {
-                float score = base[a][k];
-                for (size_t s = 0; s < selected_a.size(); ++s) if (!plain[selected_a[s]][a]) score *= pen[selected_a[s]][a][k];
-                benefit += score;
+            /* a feature's score = its base x the factors of the selected views in ascending view order (:91-98): view by view
+             * over all features (contiguous, and the same products in the same order), then the sum in feature order */
+            scr.assign(base[a].begin(), base[a].end());
+            for (size_t s = 0; s < selected_a.size(); ++s) {
+                if (plain[selected_a[s]][a]) continue;
+                const float* pv = pen[selected_a[s]][a].data();
+                for (size_t k = 0; k < nk; ++k) scr[k] *= pv[k];
             }
+            for (size_t k = 0; k < nk; ++k) benefit += scr[k];
             if (benefit > maxBenefit) { maxBenefit = benefit; maxA = a; foundOne = true; }
         }
         if (foundOne) {
@@ -1009,10 +1067,12 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
                     std::vector<float>& pv = pen[maxA][a];
                     pv.assign(featInd[a].size(), 1.f);
                     bool ones = true;
+                    const std::shared_ptr<const PairList> PL = pair_list(*c->sc, pc, act[maxA], act[a]);
+                    size_t cur = 0;
                     for (size_t k = 0; k < featInd[a].size(); ++k) {
                         const size_t l = featInd[a][k];
                         if (!sees[maxA][l]) continue;
-                        pv[k] = penalty(dir[maxA][l], dir[a][l]);
+                        pv[k] = factor(lookup(*PL, cur, feat[l], act[maxA], act[a]));
                         if (pv[k] != 1.f) ones = false;
                     }
                     plain[maxA][a] = ones ? 1 : 0;
