@@ -37,8 +37,8 @@ extern "C" {
                                       * only, mi_dmrecon_set_view with pixels = NULL): the reference fails there with the
                                       * exception of the image's loader (dmrecon.cc:236-240 loads the selected views) */
 
-#define MI_DMRECON_MAX_GLOBAL_VIEWS 64   /* Settings::globalVSMax (apps/dmrecon -n, default 20) */
-#define MI_DMRECON_MAX_LOCAL_VIEWS   8   /* Settings::nrReconNeighbors (apps/dmrecon --local-neighbors, default 4) */
+#define MI_DMRECON_MAX_GLOBAL_VIEWS 128  /* Settings::globalVSMax (apps/dmrecon -n, default 20) */
+#define MI_DMRECON_MAX_LOCAL_VIEWS  16   /* Settings::nrReconNeighbors (apps/dmrecon --local-neighbors, default 4) */
 
 typedef struct mi_dmrecon_ctx mi_dmrecon_ctx;
 
@@ -61,7 +61,8 @@ typedef struct mi_dmrecon_settings {
     float   acceptNCC;          /* 0.6 */
     float   minRefineDiff;      /* 0.001 */
     int32_t maxIterations;      /* 20 */
-    int32_t nrReconNeighbors;   /* 4; 1..MI_DMRECON_MAX_LOCAL_VIEWS (above 4 a patch runs in the eight-view lane layouts) */
+    int32_t nrReconNeighbors;   /* 4; 1..MI_DMRECON_MAX_LOCAL_VIEWS (above 4 a patch runs in the eight-view lane layouts, above 8 in the
+                                 * sixteen-view one, which has host-visible rounds only: correct, not fast) */
     int32_t globalVSMax;        /* 20; <= MI_DMRECON_MAX_GLOBAL_VIEWS */
     int32_t scale;              /* 0 */
     int32_t useColorScale;      /* 1 */
@@ -89,7 +90,7 @@ typedef struct mi_dmrecon_maps {
     float*   dz;        /* 2 channels "dz-L<s>"     */
     float*   conf;      /* 1 channel  "conf-L<s>"   */
     int32_t* views;     /* local view ids of the accepted patch, ascending, -1 padded (QueueData::localViewIDs): 4 channels
-                         * for nrReconNeighbors <= 4, 8 channels above (mi_dmrecon_local_view_channels) */
+                         * for nrReconNeighbors <= 4, 8 channels up to 8, 16 above (mi_dmrecon_local_view_channels) */
 } mi_dmrecon_maps;
 
 /* Work counters (device-counted) and timings of the last reconstruct call.  The struct only ever grows at its end, and

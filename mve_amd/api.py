@@ -24,14 +24,14 @@ from .scene_io import SceneData
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_DMRECON_LIB") or os.path.join(_HERE, "csrc", "libmi_dmrecon.so")   # env: another build of the same ABI
 
-MAX_GLOBAL_VIEWS = 64
-MAX_LOCAL_VIEWS = 8
+MAX_GLOBAL_VIEWS = 128
+MAX_LOCAL_VIEWS = 16
 
 
 def local_view_channels(n_local: int) -> int:
-    """Channels of the `views` maps / of patch_optimize's local-view arrays: 4, or 8 for nrReconNeighbors > 4
+    """Channels of the `views` maps / of patch_optimize's local-view arrays: 4, 8 for nrReconNeighbors > 4, 16 above 8
     (mi_dmrecon_local_view_channels)."""
-    return 8 if n_local > 4 else 4
+    return 16 if n_local > 8 else 8 if n_local > 4 else 4
 
 
 E_INVAL, E_GVS, E_DEVICE, E_CANCELLED, E_FOOTPRINT, E_NOIMAGE = -1, -2, -3, -4, -5, -6

@@ -108,7 +108,10 @@ __device__ __forceinline__ void probe_stamp(unsigned id) {
 __shared__ float g_lut[256];                                   /* sRGB -> linear, mvs_tools.cc:22-93 */
 __shared__ float g_geo[MI_PATCHES_PER_WAVE][MI_NS];            /* 1 / |K^-1 (pixel of sample i)|: the unit-ray scale of PatchSampler::masterViewDirs */
 __shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterColorSamples */
-__shared__ float g_ncc[MI_PATCHES_PER_WAVE][MI_MAX_GLOBAL];    /* LocalViewSelection ncc[] */
+/* LocalViewSelection ncc[] of the throughput layouts: L::PATCHES x DevSettings::ncc_stride floats of DYNAMIC shared memory, sized
+ * by the launcher -- 64 per patch unless globalVSMax asks for more (MI_MAX_GLOBAL = 128): the 4 KB a wavefront of 16 patches has
+ * always had; 8 KB per wavefront would cost the general kernels a wavefront per SIMD (160 KB per CU, 12 wavefronts) */
+extern __shared__ float g_ncc_dyn[];
 /* the same for the latency layout: one patch per wavefront, at most MI_LAT_SLOTS wavefronts per workgroup.  Separate
  * (smaller) arrays because a kernel's LDS is what it references: the tail kernels then ask for 4 KB instead of 12.8 KB,
  * and a CU filled with bulk workgroups of another call (12 x 12.6 KB of 160 KB) has that much to spare */
@@ -120,7 +123,7 @@ __shared__ float g_mcol_lat[MI_LAT_SLOTS][3 * MI_NS];
 __shared__ float g_ncc_lat[MI_LAT_SLOTS][MI_MAX_GLOBAL];
 template <class L> __device__ __forceinline__ float* lds_geo(int patch) { return L::LAT ? g_geo_lat[patch] : g_geo[patch]; }
 template <class L> __device__ __forceinline__ float* lds_mcol(int patch) { return L::LAT ? g_mcol_lat[patch] : g_mcol[patch]; }
-template <class L> __device__ __forceinline__ float* lds_ncc(int patch) { return L::LAT ? g_ncc_lat[patch] : g_ncc[patch]; }
+template <class L> __device__ __forceinline__ float* lds_ncc(int patch, int stride) { return L::LAT ? g_ncc_lat[patch] : g_ncc_dyn + patch * stride; }
 
 
 /* ------------------------------------------------------------------------- */
@@ -468,6 +471,56 @@ template <> struct Lay<8, 8> {
     }
 };
 
+/* ---- sixteen view slots (nrReconNeighbors 9..16): a patch is a DPP ROW of lanes, four patches per wavefront, in the throughput
+ * layout -- the only layout such a patch has: its views never hand over to the fused rounds (the host keeps every round of
+ * such a call host-visible), there is no FAST and no speculative kernel for it.  A rarely used setting (the reference's
+ * default is 4; apps/dmrecon --local-neighbors): built for the reference's semantics, not for speed.  Sums run in the order
+ * (((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7))) + (the same of v8..v15). */
+template <> struct Lay<1, 16> {
+    static constexpr int LPV = 1, NV = 16, PATCHES = 4;
+    static constexpr bool LAT = false;
+    __device__ static __forceinline__ int vslot(int lane) { return lane & 15; }
+    __device__ static __forceinline__ int sub(int) { return 0; }
+    __device__ static __forceinline__ int patch(int lane) { return lane >> 4; }
+    __device__ static __forceinline__ float view_sum(float v) { return v; }
+    __device__ static __forceinline__ double view_sum(double v) { return v; }
+    __device__ static __forceinline__ bool view_all(bool p) { return p; }
+    __device__ static __forceinline__ float patch_sum(float v) {
+        v = fadd_i(v, dpp_xor1(__float_as_int(v)));
+        v = fadd_i(v, dpp_xor2(__float_as_int(v)));
+        v = fadd_i(v, dpp_half_mirror(__float_as_int(v)));         /* (the quads of an octet are uniform by now) */
+        v = fadd_i(v, dpp_mirror(__float_as_int(v)));              /* (... and the octets of the row) */
+        return v;
+    }
+    __device__ static __forceinline__ double patch_sum(double v) {
+        v += dmov(v, dpp_xor1);
+        v += dmov(v, dpp_xor2);
+        v += dmov(v, dpp_half_mirror);
+        v += dmov(v, dpp_mirror);
+        return v;
+    }
+    __device__ static __forceinline__ unsigned long long patch_or(unsigned long long v) {
+        v |= dmov_u(v, dpp_xor1); v |= dmov_u(v, dpp_xor2); v |= dmov_u(v, dpp_half_mirror); v |= dmov_u(v, dpp_mirror);
+        return v;
+    }
+    __device__ static __forceinline__ float wave_sum(float v) { return v; }      /* unused in this layout */
+    /* out[k] = v of view slot k of my patch (an LDS permute per slot: this layout is not the fast path) */
+    __device__ static __forceinline__ void from_views(int v, int lane, int* out) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[k] = __shfl(v, (lane & ~15) | k);
+    }
+    /* butterfly partner exchange over the view slots: steps 0..3 (the mirrors stand for xor 4 / xor 8 on values that are
+     * uniform over the quads / octets after the steps before them) */
+    template <int S> __device__ static __forceinline__ int view_xor(int v) {
+        return S == 0 ? dpp_xor1(v) : S == 1 ? dpp_xor2(v) : S == 2 ? dpp_half_mirror(v) : dpp_mirror(v);
+    }
+    __device__ static __forceinline__ unsigned view_ballot(bool p, int lane) {
+        const unsigned long long b = __ballot(p);
+        return (unsigned)(b >> (lane & ~15)) & 0xFFFFu;
+    }
+    __device__ static __forceinline__ unsigned rows_to_lane0(unsigned v) { return v; }
+};
+
 /* the latency layout that goes with a number of view slots */
 template <int NV> struct LatLay;
 template <> struct LatLay<4> { typedef Lay<16, 4> type; };
@@ -479,6 +532,35 @@ template <> struct LatLay<8> { typedef Lay<8, 8> type; };
 __shared__ unsigned g_act[2];
 #endif
 
+/* LocalViewSelection::available over the job's global list: bit g % 64 of word g / 64 (MI_MAX_GLOBAL bits) */
+struct Avail {
+    unsigned long long w[MI_AVAIL_WORDS];
+    __device__ __forceinline__ bool test(int g) const {
+        unsigned long long v = w[0];
+#pragma unroll
+        for (int k = 1; k < MI_AVAIL_WORDS; ++k) v = (g >> 6) == k ? w[k] : v;
+        return ((v >> (g & 63)) & 1ull) != 0;
+    }
+    __device__ __forceinline__ void clear(int g) {
+        const unsigned long long m = ~(1ull << (g & 63));
+#pragma unroll
+        for (int k = 0; k < MI_AVAIL_WORDS; ++k) w[k] &= (g >> 6) == k ? m : ~0ull;
+    }
+    __device__ __forceinline__ void set(int g) {
+        const unsigned long long m = 1ull << (g & 63);
+#pragma unroll
+        for (int k = 0; k < MI_AVAIL_WORDS; ++k) w[k] |= (g >> 6) == k ? m : 0ull;
+    }
+    /* the first n views available */
+    __device__ __forceinline__ void first(int n) {
+#pragma unroll
+        for (int k = 0; k < MI_AVAIL_WORDS; ++k) {
+            const int r = n - 64 * k;
+            w[k] = r >= 64 ? ~0ull : (r <= 0 ? 0ull : ((1ull << r) - 1ull));
+        }
+    }
+};
+
 struct PatchState {
     /* uniform over the lanes of a patch */
     const DevJob* job;
@@ -489,7 +571,7 @@ struct PatchState {
     float mfp;                   /* footPrintScaled(centre point) at the current state */
     float inrm_c;                /* geo[MI_MID]: 1 / |K_s^-1 (x + .5, y + .5, 1)| of the centre pixel */
     float jinv0;                 /* invproj[0] of the reference level */
-    unsigned long long avail;    /* LocalViewSelection::available over global indices */
+    Avail avail;                 /* LocalViewSelection::available over global indices */
     /* per view slot */
     int sel;                     /* my view: index into job->global_ids, or -1 */
     float cs0, cs1, cs2;         /* PatchOptimization::colorScale[my view] */
@@ -1048,7 +1130,7 @@ __device__ __forceinline__ void unit_cross(float ax, float ay, float az, float b
 
 /*
  * LocalViewSelection::performVS (local_view_selection.cc:56-147) for one patch.
- * Candidates (bits of ps.avail) are spread over the view slots of the patch; NCCs go through g_ncc.
+ * Candidates (bits of ps.avail) are spread over the view slots of the patch; NCCs go through shared memory (lds_ncc).
  * On return each view slot's ps.sel holds its view (or -1); returns success.
  */
 template <class L>
@@ -1056,7 +1138,7 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
     const float* s_lut = g_lut;
     const float* geo = lds_geo<L>(L::patch(lane));
     const float* mcol = lds_mcol<L>(L::patch(lane));
-    float* s_ncc = lds_ncc<L>(L::patch(lane));
+    float* s_ncc = lds_ncc<L>(L::patch(lane), st.ncc_stride);
     const int slot = L::vslot(lane), sub = L::sub(lane);
     const int K = st.K;
     unsigned selmask = L::view_ballot(ps.sel >= 0, lane);
@@ -1064,16 +1146,17 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
     const DevJob* J = ps.job;
     const int G = J->n_global;
     /* NCC of every available candidate at the current state; drop those below minNCC */
-    unsigned long long drop = 0;
+    Avail drop;
+    drop.first(0);
     for (int g = slot; g < G; g += L::NV) {
-        if (!((ps.avail >> g) & 1ull)) continue;
+        if (!ps.avail.test(g)) continue;
         ColorSums S; bool ok;
         const float t = eval_color<L>(ps, views, g, s_lut, geo, mcol, S, ok, true, sub);
-        if (t < st.minNCC) drop |= 1ull << g;
+        if (t < st.minNCC) drop.set(g);
         if (sub == 0) s_ncc[g] = t;
     }
-    drop = L::patch_or(drop);
-    ps.avail &= ~drop;
+#pragma unroll
+    for (int k = 0; k < MI_AVAIL_WORDS; ++k) ps.avail.w[k] &= ~L::patch_or(drop.w[k]);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     float p0x, p0y, p0z;
@@ -1088,7 +1171,7 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
         L::from_views(ps.sel, lane, sl);
         float best = 0.f; int bestg = -1;
         for (int g = slot; g < G; g += L::NV) {
-            if (!((ps.avail >> g) & 1ull)) continue;
+            if (!ps.avail.test(g)) continue;
             const DevJobView* V = &J->gv[g];
             float score = s_ncc[g];
             const float z = V->w2c_z[0] * p0x + V->w2c_z[1] * p0y + V->w2c_z[2] * p0z + V->w2c_z[3];
@@ -1125,9 +1208,10 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
         };
         merge(__int_as_float(L::template view_xor<0>(__float_as_int(best))), L::template view_xor<0>(bestg));
         merge(__int_as_float(L::template view_xor<1>(__float_as_int(best))), L::template view_xor<1>(bestg));
-        if (L::NV == 8) merge(__int_as_float(L::template view_xor<2>(__float_as_int(best))), L::template view_xor<2>(bestg));
+        if (L::NV >= 8) merge(__int_as_float(L::template view_xor<2>(__float_as_int(best))), L::template view_xor<2>(bestg));
+        if (L::NV == 16) merge(__int_as_float(L::template view_xor<3>(__float_as_int(best))), L::template view_xor<3>(bestg));
         if (bestg < 0) break;                                       /* foundOne == false */
-        ps.avail &= ~(1ull << bestg);
+        ps.avail.clear(bestg);
         /* give the view to the lowest free view slot */
         const unsigned freemask = ~selmask & ((1u << K) - 1u);
         const int target = __ffs(freemask) - 1;
@@ -1158,13 +1242,21 @@ __device__ __forceinline__ bool lower_views_ok(const PatchState& ps, bool my_ok,
 
 struct PatchResult { float conf, depth, dzI, dzJ, nx, ny, nz; unsigned views, views_hi; int iters; };   /* views_hi: view slots 4..7 (eight-slot layouts) */
 
+/* View slots 8..15 of a sixteen-slot set live apart from the rest -- two words per pixel in DevJob::views_x, per explicit
+ * hypothesis in DevJob::hyp_x, per entry of a round's list in DevJob::results_x (all null unless nrReconNeighbors > 8) -- so that
+ * the records and the kernels of four and eight slots are what they were. */
+__device__ __forceinline__ unsigned long long load_x(const uint32_t* base, size_t i) {
+    if (!base) return ~0ull;
+    return ((unsigned long long)GU(base + 2 * i + 1) << 32) | GU(base + 2 * i);
+}
+
 /* a pixel's local view set from the state maps (slot `one`: the second state slot); the upper four of an eight-slot set
  * live in their own map, which only exists for nrReconNeighbors > 4 */
 template <int NV>
 __device__ __forceinline__ unsigned long long load_view_set(const DevJob* job, bool one, int p) {
     const unsigned lo = GU((one ? job->views1 : job->views) + p);
     unsigned hi = 0xFFFFFFFFu;
-    if (NV == 8) hi = GU((one ? job->views1_hi : job->views_hi) + p);
+    if (NV >= 8) hi = GU((one ? job->views1_hi : job->views_hi) + p);
     return ((unsigned long long)hi << 32) | lo;
 }
 __device__ __forceinline__ unsigned long long view_set(unsigned lo, unsigned hi) { return ((unsigned long long)hi << 32) | lo; }
@@ -1300,7 +1392,7 @@ __device__ __forceinline__ void patch_normal(const PatchState& ps, float& nx, fl
 template <class L>
 __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
                                           float depth0, float dzI0, float dzJ0, unsigned long long hyp_views, int lane, unsigned& err,
-                                          DevCounters* counters, bool defer = false) {
+                                          DevCounters* counters, bool defer = false, unsigned long long hyp_x = ~0ull) {
     PatchState& ps = R.ps;
     const float* s_lut = g_lut;
     float* geo = lds_geo<L>(L::patch(lane));
@@ -1403,13 +1495,13 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
 
     TSTAMP(11);
     /* --- LocalViewSelection ctor (local_view_selection.cc:19-54) */
-    ps.avail = job->n_global >= 64 ? ~0ull : ((1ull << job->n_global) - 1ull);
+    ps.avail.first(job->n_global);
     {
         int nprop = 0;
 #pragma unroll
         for (int k = 0; k < L::NV; ++k) {
-            const unsigned g = (unsigned)(hyp_views >> (8 * k)) & 0xFFu;
-            if (g != MI_VIEW_NONE) { ++nprop; ps.avail &= ~(1ull << g); if (k == slot) ps.sel = (int)g; }
+            const unsigned g = (unsigned)((k < 8 ? hyp_views : hyp_x) >> (8 * (k & 7))) & 0xFFu;
+            if (g != MI_VIEW_NONE) { ++nprop; ps.avail.clear((int)g); if (k == slot) ps.sel = (int)g; }
         }
         if (nprop > st.K) { ps.sel = -1; }          /* "Too many local neighbors propagated" */
         if (slot >= st.K) ps.sel = -1;
@@ -1554,7 +1646,7 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
 
 template <class L>
 __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane, PatchResult& res,
-                                        unsigned& n_eval, unsigned& n_pass) {
+                                        unsigned& n_eval, unsigned& n_pass, unsigned long long* res_x = nullptr) {
     PatchState& ps = R.ps;
     n_eval += ps.n_eval; n_pass += ps.n_pass;
     res.conf = 0.f; res.nx = res.ny = res.nz = 0.f;
@@ -1578,12 +1670,19 @@ __device__ __forceinline__ void run_end(Run& R, const DevSettings& st, int lane,
         unsigned packed = 0, packed_hi = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < 4; ++k) packed |= (t[k] < 0 ? MI_VIEW_NONE : (unsigned)t[k]) << (8 * k);
-        if (NV == 8) {
+        unsigned packed_x[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (NV >= 8) {
             packed_hi = 0;
 #pragma unroll
-            for (int k = 4; k < NV; ++k) packed_hi |= (t[k] < 0 ? MI_VIEW_NONE : (unsigned)t[k]) << (8 * (k - 4));
+            for (int k = 4; k < 8; ++k) packed_hi |= (t[k] < 0 ? MI_VIEW_NONE : (unsigned)t[k]) << (8 * (k - 4));
+        }
+        if (NV == 16) {
+            packed_x[0] = packed_x[1] = 0;
+#pragma unroll
+            for (int k = 8; k < NV; ++k) packed_x[(k - 8) >> 2] |= (t[k] < 0 ? MI_VIEW_NONE : (unsigned)t[k]) << (8 * (k & 3));
         }
         res.views = packed; res.views_hi = packed_hi;
+        if (NV == 16 && res_x) *res_x = ((unsigned long long)packed_x[1] << 32) | packed_x[0];   /* view slots 8..15 */
     }
     if (!R.converged) return;
     /* --- computeConfidence (patch_optimization.cc:114-142): NCCs summed in ascending view order */
@@ -1620,10 +1719,10 @@ template <class L, bool FAST = false, bool DEFER = false>
 __device__ __forceinline__ bool optimize_patch(const DevJob* job, const DevSettings& st, const DevView* views, int x, int y,
                                float depth0, float dzI0, float dzJ0, unsigned long long hyp_views, int lane,
                                PatchResult& res, unsigned& n_eval, unsigned& n_pass, unsigned& err, DevCounters* counters,
-                               unsigned* deferred = nullptr) {
+                               unsigned* deferred = nullptr, unsigned long long hyp_x = ~0ull, unsigned long long* res_x = nullptr) {
     Run R;
     TSTAMP(10);
-    if (run_begin<L>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters, DEFER)) {
+    if (run_begin<L>(R, job, st, views, x, y, depth0, dzI0, dzJ0, hyp_views, lane, err, counters, DEFER, hyp_x)) {
 #ifdef MI_ACTIVITY
         /* development build (make variant VFLAGS=-DMI_ACTIVITY): how many of a wavefront's patches are still at work in a
          * turn -- [0] patch-turns, [1] wavefront-turns (k_optimize flushes them into n_stage / n_gather_pass) */
@@ -1640,7 +1739,7 @@ __device__ __forceinline__ bool optimize_patch(const DevJob* job, const DevSetti
     TSTAMP(40);
     if (DEFER) *deferred = R.deferred;
     if (FAST && R.bail) { n_pass += R.ps.n_pass; return false; }
-    run_end<L>(R, st, lane, res, n_eval, n_pass);
+    run_end<L>(R, st, lane, res, n_eval, n_pass, res_x);
     return true;
 }
 
@@ -1705,16 +1804,18 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
     int attempts = 0;
     const bool self_round = a.st.self_round != 0 && !explicit_hyp;
     for (int t = 0; t < 4; ++t) {
-        float hd, hi, hj; unsigned long long hv;
+        float hd, hi, hj; unsigned long long hv, hx = ~0ull;
         const unsigned tried_before = tried;
         if (explicit_hyp) {
             if (t > 0) break;
             const DevHyp h = a.hyp[e];
             hd = h.depth; hi = h.dzI; hj = h.dzJ; hv = view_set(h.views, h.views_hi);
+            if (L::NV == 16) hx = load_x(job->hyp_x, e);
         } else if (self_round) {
             /* the seed re-optimisation round: the pixel's own converged state is the one hypothesis (DevSettings::self_round) */
             if (t > 0) break;
             hd = GF(job->depth + pix); hi = GF(job->dz + 2 * pix); hj = GF(job->dz + 2 * pix + 1); hv = load_view_set<L::NV>(job, false, pix);
+            if (L::NV == 16) hx = load_x(job->views_x, (size_t)pix);
         } else {
             const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
             int bi = -1; float bc = 0.f;
@@ -1736,9 +1837,10 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
             if (best > bc) continue;                           /* dmrecon.cc:371 */
             const int p = nb[bi];
             hd = GF(job->depth + p); hi = GF(job->dz + 2 * p); hj = GF(job->dz + 2 * p + 1); hv = load_view_set<L::NV>(job, false, p);
+            if (L::NV == 16) hx = load_x(job->views_x, (size_t)p);
         }
-        PatchResult r;
-        if (!optimize_patch<L, FAST>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters)) {
+        PatchResult r; unsigned long long rx = ~0ull;
+        if (!optimize_patch<L, FAST>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters, nullptr, hx, &rx)) {
             /* abandoned (FAST): the candidate stays untried, the follow-up launch of the general kernel takes the entry */
             tried = tried_before; more = true;
             break;
@@ -1754,6 +1856,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
                 o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.views_hi = r.views_hi; o.iters = r.iters;
                 o.accepted = accepted ? 1 : 0; o.tried = tried;
                 a.results[e] = o;
+                if (L::NV == 16 && job->results_x) { job->results_x[2 * (size_t)e] = (unsigned)rx; job->results_x[2 * (size_t)e + 1] = (unsigned)(rx >> 32); }
             }
         }
     }
@@ -1780,8 +1883,9 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
     if (!FAST && a.hyp != nullptr) {
         /* explicit mode (seeds, parity hook): the one hypothesis given; the result is always recorded */
         const DevHyp h = a.hyp[e];
-        PatchResult r;
-        optimize_patch<L, false>(job, a.st, a.views, x, y, h.depth, h.dzI, h.dzJ, view_set(h.views, h.views_hi), lane, r, n_eval, n_pass, err, a.counters);
+        PatchResult r; unsigned long long rx = ~0ull;
+        optimize_patch<L, false>(job, a.st, a.views, x, y, h.depth, h.dzI, h.dzJ, view_set(h.views, h.views_hi), lane, r, n_eval, n_pass, err, a.counters,
+                                 nullptr, L::NV == 16 ? load_x(job->hyp_x, e) : ~0ull, &rx);
         ++n_patch;
         more = false;
         if (writer) {
@@ -1790,6 +1894,7 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
             o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.views_hi = r.views_hi; o.iters = r.iters;
             o.accepted = r.conf > 0.f ? 1 : 0; o.tried = 0;
             a.results[e] = o;
+            if (L::NV == 16 && job->results_x) { job->results_x[2 * (size_t)e] = (unsigned)rx; job->results_x[2 * (size_t)e + 1] = (unsigned)(rx >> 32); }
         }
         return;
     }
@@ -1829,8 +1934,9 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
     const int p = bi == 0 ? nb[0] : bi == 1 ? nb[1] : bi == 2 ? nb[2] : bi == 3 ? nb[3] : pix;
     const float hd = GF(job->depth + p), hi = GF(job->dz + 2 * p), hj = GF(job->dz + 2 * p + 1);
     const unsigned long long hv = load_view_set<L::NV>(job, false, p);
-    PatchResult r;
-    if (!optimize_patch<L, FAST>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters)) {
+    PatchResult r; unsigned long long rx = ~0ull;
+    if (!optimize_patch<L, FAST>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, n_eval, n_pass, err, a.counters,
+                                 nullptr, L::NV == 16 ? load_x(job->views_x, (size_t)p) : ~0ull, &rx)) {
         /* abandoned (FAST): the candidate stays untried, the next launch (the general kernel) takes the entry */
         if (!resume && writer) a.results[e] = z;
         more = true;
@@ -1848,6 +1954,7 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
             o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.views_hi = r.views_hi; o.iters = r.iters;
             o.accepted = 1; o.tried = tried;
             a.results[e] = o;
+            if (L::NV == 16 && job->results_x) { job->results_x[2 * (size_t)e] = (unsigned)rx; job->results_x[2 * (size_t)e + 1] = (unsigned)(rx >> 32); }
         } else if (!resume) { z.tried = tried; a.results[e] = z; }
         else if (more) a.results[e].tried = tried;
     }
@@ -1974,7 +2081,8 @@ struct SpecArgs {
 template <class L>
 __device__ __forceinline__ unsigned patch_sum_u(unsigned v) {
     v += (unsigned)L::template view_xor<0>((int)v); v += (unsigned)L::template view_xor<1>((int)v);
-    if (L::NV == 8) v += (unsigned)L::template view_xor<2>((int)v);
+    if (L::NV >= 8) v += (unsigned)L::template view_xor<2>((int)v);
+    if (L::NV == 16) v += (unsigned)L::template view_xor<3>((int)v);
     return v;
 }
 template <class L>
@@ -3051,7 +3159,9 @@ struct ApplyArgs {
     int phase;                       /* seeds: 0 = vote, 1 = write */
 };
 
-__device__ __forceinline__ void write_pixel(const DevJob* job, int pix, const DevResult& r, int round) {
+/* e: the result's entry in the round's list (its view slots 8..15 are DevJob::results_x[2 e ..], sixteen-slot sets only) */
+__device__ __forceinline__ void write_pixel(const DevJob* job, int pix, const DevResult& r, int round, unsigned e) {
+    if (job->views_x) { job->views_x[2 * (size_t)pix] = job->results_x[2 * (size_t)e]; job->views_x[2 * (size_t)pix + 1] = job->results_x[2 * (size_t)e + 1]; }
     job->depth[pix] = r.depth;
     job->dz[2 * pix] = r.dzI; job->dz[2 * pix + 1] = r.dzJ;
     job->normal[3 * pix] = r.nx; job->normal[3 * pix + 1] = r.ny; job->normal[3 * pix + 2] = r.nz;
@@ -3078,7 +3188,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyArgs a) {
                 myjob = ent.job;
                 const int pix = (ent.xy >> 16) * job->w + (ent.xy & 0xFFFF);
                 newly = job->conf[pix] <= 0.f;
-                write_pixel(job, pix, r, a.round);
+                write_pixel(job, pix, r, a.round, e);
             }
         }
         filled += (unsigned)__popcll(__ballot(newly));
@@ -3150,7 +3260,7 @@ __global__ __launch_bounds__(256) void k_apply_spec(ApplyArgs a) {
                     r.conf = f.conf; r.depth = f.depth; r.dzI = f.dzI; r.dzJ = f.dzJ; r.nx = f.nx; r.ny = f.ny; r.nz = f.nz;
                     r.views = f.views; r.views_hi = f.views_hi; r.iters = f.iters; r.accepted = 1; r.tried = 0;
                     newly = own <= 0.f;
-                    write_pixel(job, pix, r, a.round);
+                    write_pixel(job, pix, r, a.round, e);
                 }
             }
         }
@@ -3206,7 +3316,7 @@ __global__ __launch_bounds__(256) void k_apply_seeds(ApplyArgs a) {
                 okseed = true;
             } else if (*slot == key) {
                 newly = job->conf[pix] <= 0.f;
-                write_pixel(job, pix, r, a.round);
+                write_pixel(job, pix, r, a.round, e);
                 if (newly) atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u);
             }
         }
@@ -3342,6 +3452,16 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     a.follow_out = follow_out; a.follow_out_n = follow_out_n;
     /* lanes_per_view: 1 = throughput layout, anything else = latency layout; st.K > 4: the eight-slot layouts */
     const bool lat = lanes_per_view != 1, eight = st.K > 4;
+    if (st.K > 8) {
+        /* sixteen view slots: the general kernel of the throughput layout is all there is (Lay<1, 16>) -- the entries'
+         * attempts in a row, or one each where the caller keeps follow-up lists or gives explicit hypotheses */
+        if (lat) return;
+        const unsigned ncc16 = (unsigned)(Lay<1, 16>::PATCHES * st.ncc_stride * sizeof(float));
+        const bool single16 = hyp != nullptr || follow_out != nullptr;
+        if (single16) hipLaunchKernelGGL((k_optimize<Lay<1, 16>, false, true>), dim3(grid_blocks), dim3(WAVE), ncc16, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<1, 16>, false>), dim3(grid_blocks), dim3(WAVE), ncc16, s, a);
+        return;
+    }
     /* the first launch of a bulk round (one attempt per entry, a follow-up list for the rest) runs the FAST kernel: no
      * view selection code in it -- a patch that needs one goes to the follow-up launch, which is the general kernel */
     const bool fast = !lat && follow_out != nullptr && follow_in == nullptr && hyp == nullptr;
@@ -3349,6 +3469,8 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
      * (process_entry_single), and so do the seeds (one hypothesis each); only a propagation launch without a follow-up list
      * of its own runs an entry's attempts in a row */
     const bool single = !lat && (hyp != nullptr || (follow_out != nullptr && follow_in != nullptr));
+    /* the throughput kernels with a view selection in them: its NCC table in dynamic shared memory (lds_ncc) */
+    const unsigned ncc4 = (unsigned)(Lay<1, 4>::PATCHES * st.ncc_stride * sizeof(float)), ncc8 = (unsigned)(Lay<1, 8>::PATCHES * st.ncc_stride * sizeof(float));
     if (lat) {
         if (eight) hipLaunchKernelGGL((k_optimize<Lay<8, 8>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
         else hipLaunchKernelGGL((k_optimize<Lay<16, 4>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
@@ -3356,11 +3478,11 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
         if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
         else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
     } else if (single) {
-        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, false, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, false, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, false, true>), dim3(grid_blocks), dim3(WAVE), ncc8, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, false, true>), dim3(grid_blocks), dim3(WAVE), ncc4, s, a);
     } else {
-        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
-        else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, false>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, false>), dim3(grid_blocks), dim3(WAVE), ncc8, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, false>), dim3(grid_blocks), dim3(WAVE), ncc4, s, a);
     }
 }
 
@@ -3376,8 +3498,8 @@ static void launch_optimize_spec(hipStream_t s, unsigned grid_blocks, const DevJ
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
     t.o.max_attempts = 1; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
     t.spec = spec; t.items = items; t.n_items = n_items;
-    if (st.K > 4) hipLaunchKernelGGL((k_optimize_spec<Lay<1, 8> >), dim3(grid_blocks), dim3(WAVE), 0, s, t);
-    else hipLaunchKernelGGL((k_optimize_spec<Lay<1, 4> >), dim3(grid_blocks), dim3(WAVE), 0, s, t);
+    if (st.K > 4) hipLaunchKernelGGL((k_optimize_spec<Lay<1, 8> >), dim3(grid_blocks), dim3(WAVE), (unsigned)(Lay<1, 8>::PATCHES * st.ncc_stride * sizeof(float)), s, t);
+    else hipLaunchKernelGGL((k_optimize_spec<Lay<1, 4> >), dim3(grid_blocks), dim3(WAVE), (unsigned)(Lay<1, 4>::PATCHES * st.ncc_stride * sizeof(float)), s, t);
 }
 
 static void launch_patch_eval(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,

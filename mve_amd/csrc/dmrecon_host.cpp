@@ -313,6 +313,7 @@ struct BatchScratch {
     DevBuf<DevResult> d_results2;            /* ping-pong partner of d_results in the tail rounds */
     DevBuf<float> d_maps;                    /* depth | dz | conf | normal per batch */
     DevBuf<uint32_t> d_imaps;                /* views | upd */
+    DevBuf<uint32_t> d_xviews;               /* nrReconNeighbors > 8 only: view slots 8..15 of the sets -- per pixel | per list entry | per explicit hypothesis, two words each (DevJob::views_x) */
     DevBuf<unsigned long long> d_keys;
     DevBuf<unsigned> d_keyoff;
     DevBuf<unsigned> d_round_work;           /* [MI_MAX_ROUNDS] per round: size of the list of the views in the latency layout (host-visible
@@ -368,14 +369,14 @@ struct BatchScratch {
         return reserve_pixels(px, n_imaps);                           /* (DevBuf::reserve adds the headroom) */
     }
     bool holds_anything() const {
-        return d_maps.cap || d_work.cap || d_jobs.cap || d_results.cap || d_hyp.cap || d_spec.cap || d_gvs_out.cap || d_gvs_feat.cap
+        return d_maps.cap || d_work.cap || d_jobs.cap || d_results.cap || d_hyp.cap || d_spec.cap || d_xviews.cap || d_gvs_out.cap || d_gvs_feat.cap
             || h_poll || h_dyn || h_gvs || h_up || h_done || h_sparse || h_emit_end || !events.empty();
     }
     void release() {
         for (size_t i = 0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
         events.clear();
         d_jobs.release(); d_work.release(); d_work2.release(); d_hyp.release(); d_results.release(); d_results2.release();
-        d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_keys.release(); d_keyoff.release();
+        d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_xviews.release(); d_keys.release(); d_keyoff.release();
         d_round_work.release(); d_round_work_t.release(); d_round_items.release(); d_view.release(); d_front.release(); d_front_resume.release();
         d_front_mail.release(); d_front_flags.release(); d_front_map.release(); d_front_order.release();
         d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release(); d_sparse_count.release();
@@ -1192,8 +1193,8 @@ void fill_job(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost const& j
     }
 }
 
-/* patches per wavefront of the throughput layout: a quad per patch, or an octet for nrReconNeighbors > 4 */
-unsigned patches_per_wave(const mi_dmrecon_settings* st) { return st->nrReconNeighbors > 4 ? 8u : (unsigned)MI_PATCHES_PER_WAVE; }
+/* patches per wavefront of the throughput layout: a quad per patch, an octet for nrReconNeighbors > 4, a row of 16 lanes above 8 */
+unsigned patches_per_wave(const mi_dmrecon_settings* st) { return st->nrReconNeighbors > 8 ? 4u : st->nrReconNeighbors > 4 ? 8u : (unsigned)MI_PATCHES_PER_WAVE; }
 
 DevSettings dev_settings(const mi_dmrecon_settings* st) {
     DevSettings d;
@@ -1201,11 +1202,13 @@ DevSettings dev_settings(const mi_dmrecon_settings* st) {
     d.minRefineDiff = st->minRefineDiff; d.maxIterations = st->maxIterations; d.K = st->nrReconNeighbors;
     d.useColorScale = st->useColorScale;
     d.self_round = 0;
+    d.ncc_stride = st->globalVSMax > 64 ? MI_MAX_GLOBAL : 64;
     return d;
 }
 
 /* Lays the per-pixel state maps of a batch out in the two map buffers and points the jobs at them. */
-int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px, size_t n_list, bool eight_views) {
+int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px, size_t n_list, int K) {
+    const bool eight_views = K > 4, wide = K > 8;
     total_px = 0;
     for (size_t j = 0; j < jobs.size(); ++j) { jobs[j].pix_off = total_px; total_px += (size_t)jobs[j].w * jobs[j].h; }
     /* two state slots per pixel (dmrecon_types.h: DevJob): 2 x 7 floats; views, upd + views1, upd1 (+ views_hi,
@@ -1234,6 +1237,16 @@ int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob
         dj[j].upd1 = (int32_t*)(ibase + 3 * total_px + o);
         dj[j].views_hi = eight_views ? ibase + 4 * total_px + o : nullptr;
         dj[j].views1_hi = eight_views ? ibase + 5 * total_px + o : nullptr;
+        dj[j].views_x = nullptr; dj[j].results_x = nullptr; dj[j].hyp_x = nullptr;
+    }
+    if (wide) {
+        /* sixteen view slots: slots 8..15 of the sets, two words per pixel | per entry of a round's list (the batch's) | per
+         * explicit hypothesis (only the parity hook has any: it points hyp_x at the third part) */
+        const size_t cap = std::max(total_px, n_list);
+        if (c->bs.d_xviews.reserve(2 * total_px + 4 * cap)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(view sets) failed");
+        uint32_t* xb = c->bs.d_xviews.p;
+        for (size_t j = 0; j < jobs.size(); ++j) { dj[j].views_x = xb + 2 * jobs[j].pix_off; dj[j].results_x = xb + 2 * total_px; }
+        HIP_TRY(hipMemsetAsync(xb, 0xFF, (2 * total_px + 4 * cap) * sizeof(uint32_t), c->stream));
     }
     /* slot 1 is only ever read where its stamp says so: the stamps (0xFF.. = -1) are all it needs */
     HIP_TRY(hipMemsetAsync(c->bs.d_maps.p, 0, total_px * 7 * sizeof(float), c->stream));
@@ -1258,7 +1271,7 @@ int mi_dmrecon_device_count(void) {
 
 const char* mi_dmrecon_last_error(void) { return g_err.c_str(); }
 
-int mi_dmrecon_local_view_channels(int32_t nrReconNeighbors) { return nrReconNeighbors > 4 ? 8 : 4; }
+int mi_dmrecon_local_view_channels(int32_t nrReconNeighbors) { return nrReconNeighbors > 8 ? 16 : nrReconNeighbors > 4 ? 8 : 4; }
 
 void mi_dmrecon_settings_default(mi_dmrecon_settings* s) {          /* libs/dmrecon/settings.h:25-51 */
     s->filterWidth = 5; s->minNCC = 0.3f; s->minParallax = 10.f; s->acceptNCC = 0.6f; s->minRefineDiff = 0.001f;
@@ -1739,7 +1752,7 @@ int BatchRun::upload() {
     }
     n_seeds_total = seed_off[nj];
     mark("  upload: job records");
-    rc = alloc_maps(c, jobs, dj, total_px, n_seeds_total, st->nrReconNeighbors > 4);
+    rc = alloc_maps(c, jobs, dj, total_px, n_seeds_total, st->nrReconNeighbors);
     if (rc) return rc;
     mark("  upload: state maps");
     work_cap = std::max(total_px, n_seeds_total);
@@ -1786,6 +1799,9 @@ int BatchRun::upload() {
      * layout for good (k_generate decides, per view, on the device); 0 = never, 1000000000 = from the first round on */
     if (const char* e = std::getenv("MI_DMRECON_VIEW_HANDOVER")) handover = (unsigned)std::max(0L, std::atol(e));
     host_rounds_only = [] { const char* e = std::getenv("MI_DMRECON_HOST_ROUNDS"); return e && std::atoi(e) != 0; }();
+    /* sixteen view slots (nrReconNeighbors > 8) exist in the throughput layout only: the views never hand over, every round is a
+     * host-visible one (bulk_rounds: one launch of the general kernel per round) */
+    if (st->nrReconNeighbors > 8) handover = 0;
     /* per-view counts of "the round before round 1": none yet -- unless every view starts in the latency layout */
     HIP_TRY(hipMemsetAsync(c->bs.d_view.p, 0, 4 * (size_t)nj * sizeof(unsigned), S));
     if (handover < 1000000000u) HIP_TRY(hipMemsetAsync(c->bs.d_view.p, 0xFF, (size_t)nj * sizeof(unsigned), S));
@@ -1863,7 +1879,8 @@ int BatchRun::bulk_rounds(bool& to_tail) {
     to_tail = false;
     /* MI_DMRECON_ONE_LAUNCH=<entries> (read per call): rounds below this many entries in the throughput layout run as one
      * launch of the general kernel (below) */
-    const unsigned ONE_LAUNCH_MAX = [] { const char* e = std::getenv("MI_DMRECON_ONE_LAUNCH"); return e ? (unsigned)std::max(0L, std::atol(e)) : MI_ONE_LAUNCH_MAX; }();
+    const bool wide = st->nrReconNeighbors > 8;      /* sixteen view slots: the general kernel, one launch per round, nothing speculative */
+    const unsigned ONE_LAUNCH_MAX = wide ? 0xFFFFFFFFu : [] { const char* e = std::getenv("MI_DMRECON_ONE_LAUNCH"); return e ? (unsigned)std::max(0L, std::atol(e)) : MI_ONE_LAUNCH_MAX; }();
     const int max_rounds = MI_MAX_ROUNDS - 2 * (int)MI_TAIL_CHUNK - 2;
     unsigned* d_vcount = c->bs.d_view.p; unsigned* d_vmode = d_vcount + 3 * (size_t)nj;
     const unsigned ppw = patches_per_wave(st);
@@ -1872,7 +1889,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
      * every (entry, rank) pair gets a quad of its own (k_optimize_spec / k_apply_spec: same maps, same counters).  The
      * records are sized for twice the threshold; a round that turns out larger than that runs the plain launches, which
      * are enqueued next to the speculative ones and look at the size on the device. */
-    const unsigned SPEC_MAX = [] { const char* e = std::getenv("MI_DMRECON_SPEC_ROUNDS"); return e ? (unsigned)std::max(0L, std::atol(e)) : MI_SPEC_ROUNDS; }();
+    const unsigned SPEC_MAX = wide ? 0u : [] { const char* e = std::getenv("MI_DMRECON_SPEC_ROUNDS"); return e ? (unsigned)std::max(0L, std::atol(e)) : MI_SPEC_ROUNDS; }();
     const unsigned spec_cap = 2u * SPEC_MAX;
     /* MI_DMRECON_SINGLE_FOLLOW=<n> (read per call): 0 = the follow-up list of a large round in ONE launch, all remaining attempts
      * of an entry in a row (round 4's form); n = 1 .. 3: n single-attempt follow-up launches, then one for the rest; 4: every
@@ -1912,7 +1929,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         const unsigned waves = (est + ppw - 1) / ppw;
         /* a view can be in the latency layout from round 2 on (from round 1 if told so): which rounds have such entries is
          * decided on the device -- the launches for them are part of every round (empty ones cost microseconds) */
-        const bool any_lat = r >= 2 || handover >= 1000000000u;
+        const bool any_lat = !wide && (r >= 2 || handover >= 1000000000u);
         ev.begin(S, EventLog::BULK, 0);                              /* (entries: filled in at the read-back) */
         const size_t ev_thr = ev.items.size() - 1;
         size_t ev_lat = (size_t)-1;
@@ -2585,7 +2602,7 @@ int BatchRun::download() {
         if (m.normal) HIP_TRY(hipMemcpyAsync(m.normal, dj[j].normal, np * 12, hipMemcpyDeviceToHost, S));
         if (m.views) {
             const int nch = mi_dmrecon_local_view_channels(st->nrReconNeighbors);
-            for (int half = 0; half < nch / 4; ++half) {
+            for (int half = 0; half < std::min(nch, 8) / 4; ++half) {
                 packed.resize(np);
                 HIP_TRY(hipMemcpyAsync(packed.data(), half ? dj[j].views_hi : dj[j].views, np * 4, hipMemcpyDeviceToHost, S));
                 HIP_TRY(wait_stream(S));
@@ -2593,6 +2610,16 @@ int BatchRun::download() {
                     for (int k = 0; k < 4; ++k) {
                         const unsigned g = (packed[p] >> (8 * k)) & 0xFFu;
                         m.views[(size_t)nch * p + 4 * half + k] = (g == MI_VIEW_NONE || g >= jobs[j].global.size()) ? -1 : jobs[j].global[g];
+                    }
+            }
+            if (nch == 16) {                                      /* view slots 8..15: two words per pixel (DevJob::views_x) */
+                packed.resize(2 * np);
+                HIP_TRY(hipMemcpyAsync(packed.data(), dj[j].views_x, np * 8, hipMemcpyDeviceToHost, S));
+                HIP_TRY(wait_stream(S));
+                for (size_t p = 0; p < np; ++p)
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned g = (packed[2 * p + (k >> 2)] >> (8 * (k & 3))) & 0xFFu;
+                        m.views[(size_t)nch * p + 8 + k] = (g == MI_VIEW_NONE || g >= jobs[j].global.size()) ? -1 : jobs[j].global[g];
                     }
             }
         }
@@ -2961,10 +2988,10 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
     std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
     fill_job(c, st, jobs[0], dj[0]);
     size_t total_px = 0;
-    rc = alloc_maps(c, jobs, dj, total_px, (size_t)std::max(n, 0), st->nrReconNeighbors > 4);
+    rc = alloc_maps(c, jobs, dj, total_px, (size_t)std::max(n, 0), st->nrReconNeighbors);
     if (rc) return rc;
     if (n == 0) return 0;
-    std::vector<DevEntry> ent(n); std::vector<DevHyp> hy(n);
+    std::vector<DevEntry> ent(n); std::vector<DevHyp> hy(n); std::vector<uint32_t> hyx(2 * (size_t)n, 0xFFFFFFFFu);
     const int nch = mi_dmrecon_local_view_channels(st->nrReconNeighbors);
     for (int i = 0; i < n; ++i) {
         ent[i].job = 0;
@@ -2972,17 +2999,24 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
         if (x < 0 || y < 0 || x >= L.w || y >= L.h) { x = 0; y = 0; }     /* fails the border test -> conf 0 */
         ent[i].xy = x | (y << 16);
         hy[i].depth = hyp[3 * i]; hy[i].dzI = hyp[3 * i + 1]; hy[i].dzJ = hyp[3 * i + 2];
-        unsigned long long packed = 0; int cnt = 0;
+        unsigned long long packed[2] = {0, 0}; int cnt = 0;
         for (int k = 0; k < nch; ++k) {
             int id = local ? local[nch * i + k] : -1;
             if (id < 0) continue;
             std::vector<int>::const_iterator it = std::lower_bound(jh.global.begin(), jh.global.end(), id);
             if (it == jh.global.end() || *it != id) return fail(MI_DMRECON_EINVAL, "local view %d is not a global view", id);
-            packed |= (unsigned long long)(it - jh.global.begin()) << (8 * cnt);
+            packed[cnt >> 3] |= (unsigned long long)(it - jh.global.begin()) << (8 * (cnt & 7));
             ++cnt;
         }
-        for (; cnt < 8; ++cnt) packed |= (unsigned long long)MI_VIEW_NONE << (8 * cnt);
-        hy[i].views = (uint32_t)packed; hy[i].views_hi = (uint32_t)(packed >> 32);
+        for (; cnt < 16; ++cnt) packed[cnt >> 3] |= (unsigned long long)MI_VIEW_NONE << (8 * (cnt & 7));
+        hy[i].views = (uint32_t)packed[0]; hy[i].views_hi = (uint32_t)(packed[0] >> 32);
+        if (nch == 16) { hyx[2 * (size_t)i] = (uint32_t)packed[1]; hyx[2 * (size_t)i + 1] = (uint32_t)(packed[1] >> 32); }
+    }
+    if (nch == 16) {
+        /* view slots 8..15 of the propagated sets: the third part of the batch's d_xviews (alloc_maps) */
+        uint32_t* d_hx = dj[0].results_x + 2 * std::max(total_px, (size_t)n);
+        dj[0].hyp_x = d_hx;
+        HIP_TRY(hipMemcpyAsync(d_hx, hyx.data(), 2 * (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     }
     if (c->bs.d_jobs.reserve(1) || c->bs.d_work.reserve(n) || c->bs.d_hyp.reserve(n) || c->bs.d_results.reserve(n))
         return fail(MI_DMRECON_EDEVICE, "hipMalloc failed");
@@ -2997,15 +3031,17 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
                c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
                nullptr, nullptr, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
-    std::vector<DevResult> res(n);
+    std::vector<DevResult> res(n); std::vector<uint32_t> resx(2 * (size_t)n, 0xFFFFFFFFu);
     HIP_TRY(hipMemcpyAsync(res.data(), c->bs.d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
+    if (nch == 16) HIP_TRY(hipMemcpyAsync(resx.data(), dj[0].results_x, 2 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(wait_stream(c->stream));
     for (int i = 0; i < n; ++i) {
         float* o = out + 8 * i;
         o[0] = res[i].conf; o[1] = res[i].depth; o[2] = res[i].dzI; o[3] = res[i].dzJ;
         o[4] = res[i].nx; o[5] = res[i].ny; o[6] = res[i].nz; o[7] = (float)res[i].iters;
         for (int k = 0; k < nch; ++k) {
-            const unsigned g = ((k < 4 ? res[i].views : res[i].views_hi) >> (8 * (k & 3))) & 0xFFu;
+            const unsigned word = k < 4 ? res[i].views : k < 8 ? res[i].views_hi : resx[2 * (size_t)i + ((k - 8) >> 2)];
+            const unsigned g = (word >> (8 * (k & 3))) & 0xFFu;
             out_local[nch * i + k] = (g == MI_VIEW_NONE || g >= jh.global.size()) ? -1 : jh.global[g];
         }
     }
@@ -3031,7 +3067,7 @@ static int mi_dmrecon_patch_eval_impl(mi_dmrecon_ctx* c, const mi_dmrecon_settin
     std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
     fill_job(c, st, jobs[0], dj[0]);
     size_t total_px = 0;
-    rc = alloc_maps(c, jobs, dj, total_px, 0, st->nrReconNeighbors > 4);
+    rc = alloc_maps(c, jobs, dj, total_px, 0, st->nrReconNeighbors);
     if (rc) return rc;
     const int G = (int)jh.global.size();
     const size_t NS3 = 3 * (size_t)st->filterWidth * st->filterWidth;       /* floats per view: fw x fw samples, 3 channels */

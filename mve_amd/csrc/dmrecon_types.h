@@ -8,8 +8,10 @@
 #include <stdint.h>
 
 #define MI_MAX_LEVELS 16
-#define MI_MAX_GLOBAL 64        /* global views per reference view (Settings::globalVSMax): one bit each in the 64-bit availability mask */
-#define MI_MAX_LOCAL 8          /* local views per patch (Settings::nrReconNeighbors): four or eight view slots */
+#define MI_MAX_GLOBAL 128       /* global views per reference view (Settings::globalVSMax): one bit each in the availability mask
+                                 * (MI_AVAIL_WORDS 64-bit words per patch); a view set holds 8-bit indices into the list */
+#define MI_AVAIL_WORDS (MI_MAX_GLOBAL / 64)
+#define MI_MAX_LOCAL 16         /* local views per patch (Settings::nrReconNeighbors): four, eight or sixteen view slots */
 #define MI_MAX_FW 7         /* filter widths 3, 5, 7: the device code is compiled once per width (dmrecon_device.hip) */
 #define MI_PATCHES_PER_WAVE 16
 #define MI_VIEW_NONE 0xFFu
@@ -85,6 +87,13 @@ struct DevJob {
     uint32_t* views1;
     int32_t* upd1;
     uint32_t* views1_hi;
+    /* Sixteen view slots (nrReconNeighbors > 8; else all three null): slots 8..15 of a set live apart from the rest, two words
+     * each -- per pixel, per entry of the round's list (what an optimisation found, k_apply / k_apply_seeds copy it to the
+     * pixel), per explicit hypothesis (null: none propagated).  The last two are the batch's, the same in every job.  Such
+     * views stay in the throughput layout: there is no second state slot of them. */
+    uint32_t* views_x;
+    uint32_t* results_x;
+    const uint32_t* hyp_x;
 };
 
 #define MI_JOB_EFOOTPRINT 1u   /* device: non-positive master footprint in this view (patch_sampler.cc:78-82 throws) */
@@ -98,6 +107,9 @@ struct DevSettings {
      * converged state, as the reference does when it pops a seed (it pushes the seed's OWN pixel, dmrecon.cc:316-326, and
      * propagates from it only if that re-optimisation strictly raised its confidence, :365-398) -- MI_DMRECON_SEED_REOPT. */
     int32_t self_round;
+    /* (not settings either) floats per patch of the view selection's NCC table in the throughput kernels' dynamic shared memory:
+     * 64, or MI_MAX_GLOBAL when globalVSMax is above 64 */
+    int32_t ncc_stride;
 };
 
 /* Work list entry + result of one patch optimisation attempt chain. */

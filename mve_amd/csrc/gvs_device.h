@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define MI_GVS_MAX_OUT 64          /* = MI_MAX_GLOBAL: ids written per reference view */
+#define MI_GVS_MAX_OUT 128         /* = MI_MAX_GLOBAL: ids written per reference view */
 
 /* The scene tables of SceneGeom (dmrecon_host.cpp) in device memory, plus what benefitFromView needs per view. */
 struct GvsScene {

@@ -53,8 +53,10 @@ int orc_global_vs(void* scene, const orc_settings* st, int32_t* ids_out);
 int orc_reconstruct(void* scene, const orc_settings* st, float* depth, float* normal, float* dz,
                     float* conf, orc_stats* stats);
 
-/* n hypotheses: xy[2n], hyp[3n] = depth,dzI,dzJ, local[8n] view ids (-1 = none; nrReconNeighbors <= 8).
- * out[8n] = conf, depth, dzI, dzJ, nx, ny, nz, iterations; out_local[8n]. */
+/* n hypotheses: xy[2n], hyp[3n] = depth,dzI,dzJ, local[ORC_MAX_LOCAL n] view ids (-1 = none; the hook carries up to
+ * ORC_MAX_LOCAL local views, the algorithm itself has no limit).
+ * out[8n] = conf, depth, dzI, dzJ, nx, ny, nz, iterations; out_local[ORC_MAX_LOCAL n]. */
+#define ORC_MAX_LOCAL 16
 int orc_patch_optimize(void* scene, const orc_settings* st, int n, const int32_t* xy, const float* hyp,
                        const int32_t* local, float* out, int32_t* out_local);
 

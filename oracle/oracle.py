@@ -147,16 +147,16 @@ class OracleScene:
         xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
         n = len(xy)
         hyp = np.ascontiguousarray(hyp, np.float32).reshape(n, 3)
-        loc = np.full((n, 8), -1, np.int32)                     # up to eight local views (nrReconNeighbors <= 8)
+        loc = np.full((n, 16), -1, np.int32)                    # the hook carries up to sixteen local views (ORC_MAX_LOCAL)
         if local is not None:
             local = np.ascontiguousarray(local, np.int32).reshape(n, -1)
             loc[:, :local.shape[1]] = local
         out = np.zeros((n, 8), np.float32)
-        out_local = np.zeros((n, 8), np.int32)
+        out_local = np.zeros((n, 16), np.int32)
         rc = lib().orc_patch_optimize(self.h, ctypes.byref(st), n, _ptr(xy), _ptr(hyp), _ptr(loc), _ptr(out), _ptr(out_local))
         if rc != 0:
             raise RuntimeError("oracle patch_optimize failed")
-        return out, out_local[:, :(8 if st.nrReconNeighbors > 4 else 4)]
+        return out, out_local[:, :(16 if st.nrReconNeighbors > 8 else 8 if st.nrReconNeighbors > 4 else 4)]
 
     def patch_eval(self, st: OrcSettings, x, y, depth, dzi=0.0, dzj=0.0):
         g = max(self.n_views, 1)

@@ -70,6 +70,17 @@ def w1_scene(w1):
 
 
 @pytest.fixture(scope="session")
+def w2():
+    """Scene W2 (100 views): the reference with 80 global views / ten and sixteen local views (make_golden_wide2.py)."""
+    return dict(np.load(os.path.join(GOLDEN, "w2_wider_100views_96x72.npz")))
+
+
+@pytest.fixture(scope="session")
+def w2_scene(w2):
+    return scene_from_golden(w2)
+
+
+@pytest.fixture(scope="session")
 def g1_scene(g1):
     return scene_from_golden(g1)
 

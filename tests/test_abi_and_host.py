@@ -201,7 +201,7 @@ def _host_views(scene, ref, tables, **kw):
     return api.plan_views_host(scene, api.Settings(refViewNr=ref, **kw), ref, tables=tables)[0]
 
 
-def test_host_view_selection_is_the_references(g1, g1_scene, h1_scene, w1, w1_scene):
+def test_host_view_selection_is_the_references(g1, g1_scene, h1_scene, w1, w1_scene, w2, w2_scene):
     """GlobalViewSelection as a reconstruct call runs it on the host (plan_global_views: from the scene tables -- dense
     score arrays, factor rows shared per scene, eight in-order sums side by side -- and directly, the form for bundles too
     large for tables) against the restatement, which is bit-identical to the reference: the same views for every
@@ -221,6 +221,14 @@ def test_host_view_selection_is_the_references(g1, g1_scene, h1_scene, w1, w1_sc
                 for tables in (True, False):
                     assert _host_views(scene, ref, tables, **kw) == want, (n, kw, ref, tables)
     assert _host_views(w1_scene, 0, True, globalVSMax=40) == list(w1["gvs40"])          # the reference binary's own list
+    # more than 64 global views (scene W2, 100 views; apps/dmrecon -n 80): the reference binary's own list, both paths, and
+    # the library's limit itself (MI_DMRECON_MAX_GLOBAL_VIEWS = 128: every other view of the scene)
+    S2 = orc.OracleScene(w2_scene)
+    for tables in (True, False):
+        assert _host_views(w2_scene, 0, tables, globalVSMax=80) == list(w2["gvs80"]) and len(w2["gvs80"]) == 80
+    for ref in (37, 99):
+        want = S2.global_vs(orc.make_settings(ref_view=ref, global_max=128))
+        assert len(want) > 64 and _host_views(w2_scene, ref, True, globalVSMax=128) == want
     # a bounding box that cuts the features (dmrecon.cc:190-193)
     pos = np.array([f.pos for f in g1_scene.features], np.float32)
     lo, hi = np.percentile(pos, 20, axis=0), np.percentile(pos, 85, axis=0)

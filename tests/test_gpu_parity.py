@@ -699,9 +699,9 @@ def test_edge_cases(gpu_ctx, g1_scene):
     with pytest.raises(ValueError):
         gpu_ctx.reconstruct(api.Settings(filterWidth=13), [0])                # compiled for the odd widths 3..11
     with pytest.raises(ValueError):
-        gpu_ctx.reconstruct(api.Settings(nrReconNeighbors=9), [0])       # more than MI_DMRECON_MAX_LOCAL_VIEWS
+        gpu_ctx.reconstruct(api.Settings(nrReconNeighbors=17), [0])      # more than MI_DMRECON_MAX_LOCAL_VIEWS
     with pytest.raises(ValueError):
-        gpu_ctx.reconstruct(api.Settings(globalVSMax=65), [0])           # more than MI_DMRECON_MAX_GLOBAL_VIEWS
+        gpu_ctx.reconstruct(api.Settings(globalVSMax=129), [0])          # more than MI_DMRECON_MAX_GLOBAL_VIEWS
     # more local neighbours than the scene has other views: no patch finds them, nothing is filled (the reference
     # needs exactly K selected views, local_view_selection.cc:144-146), the call itself succeeds
     r = gpu_ctx.reconstruct(api.Settings(nrReconNeighbors=5), [0], want_views=True)[0]
@@ -959,4 +959,93 @@ def test_wide_view_sets_vs_reference(gpu_ctx, w1, w1_scene, g1_scene, monkeypatc
             for key in ("depth", "conf", "dz", "normal", "views"):
                 assert np.array_equal(a[key], b[key]), (front, key)
     monkeypatch.delenv("MI_DMRECON_FRONT"); monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER")
+    gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)
+
+
+# ---- scene W2: 100 views -- more than 64 global views, more than eight local views (tests/golden/make_golden_wide2.py) ----
+
+def test_wider_view_sets_vs_reference(gpu_ctx, w2, w2_scene, g1_scene, monkeypatch):
+    """apps/dmrecon -n 80 --local-neighbors=10, --local-neighbors=16 and -n 80 with the default four local views against
+    the reference's own output (the reference accepts any value of either, libs/dmrecon/settings.h:37-38): the global view
+    selection of 80 views on the host and on the device, a second word of the availability mask and the larger NCC table of
+    the view selection in every lane layout (K = 4: quads, fused tail rounds, front kernel), maps with ten and sixteen local
+    views per patch (the sixteen-slot lane layout: a row of 16 lanes per patch, host-visible rounds only), and the
+    reference's own PatchOptimization on 160 hypotheses, half of them with a propagated set of ten."""
+    gpu_ctx.load_scene(w2_scene)
+    st10 = api.Settings(refViewNr=0, nrReconNeighbors=10, globalVSMax=80)
+    assert gpu_ctx.global_view_selection(st10) == list(w2["gvs80"]) and len(w2["gvs80"]) == 80
+    monkeypatch.setenv("MI_DMRECON_GVS_DEVICE", "1")
+    assert gpu_ctx.global_view_selection(st10) == list(w2["gvs80"])
+    monkeypatch.delenv("MI_DMRECON_GVS_DEVICE")
+    for tag, st in (("k10n80", st10), ("k16n20", api.Settings(refViewNr=0, nrReconNeighbors=16, globalVSMax=20)),
+                    ("k4n80", api.Settings(refViewNr=0, nrReconNeighbors=4, globalVSMax=80))):
+        r = gpu_ctx.reconstruct(st, [0], want_views=True)[0]
+        m = map_parity(r["depth"], r["conf"], w2[tag + "_depth"], w2[tag + "_conf"])
+        print("W2", tag, m)
+        # 96 x 72 images, up to 80 near-by views: the reference ALGORITHM against itself under four other queue orders
+        # (its restatement with ORC_QUEUE_ORDER = reverse / random:1 / random:2 / jitter:1, measured when the fixture was
+        # made) reaches, at worst: k10n80 IoU 1.0, rel_med 7.2e-4, rel_p99 8.3e-3, conf_med 1.4e-2, conf_p99 0.106; k16n20
+        # IoU 0.9977, 3.1e-4, 3.2e-3, 2.3e-3, 0.048; k4n80 IoU 0.9960, 1.08e-3, 1.0e-2, 1.7e-2, 0.134 -- bounds at ~1.5 x the
+        # worst of them, the fill mask at the smooth-scene bound
+        assert m["iou"] >= 0.99 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2, (tag, m)
+        assert m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (tag, m)
+        filled = r["conf"] > 0
+        v = r["views"][filled]
+        k = st.nrReconNeighbors
+        assert v.shape[1] == api.local_view_channels(k) and ((v >= 0).sum(1) == k).all()          # exactly K views, ...
+        assert (np.diff(v[:, :k], axis=1) > 0).all() and (v[:, k:] == -1).all() and not (v == 0).any()   # ascending, never the reference view
+        assert set(np.unique(v[:, :k])) <= set(int(g) for g in gpu_ctx.global_view_selection(st))
+        both = filled & (w2[tag + "_depth"] > 0)
+        assert np.percentile(np.abs(r["dz"][both] - w2[tag + "_dz"][both]), 99) < 0.05
+    # local views with indices 64..79 of the global list (the second word of the availability mask, the upper half of the
+    # NCC table) are in every set of ten and in a quarter of the sets of four; another reference view, here against the
+    # restatement (bit-identical to the reference on this scene: tests/test_oracle_golden.py)
+    from oracle import oracle as orc
+    S = orc.OracleScene(w2_scene)
+    for k in (4,):
+        st = api.Settings(refViewNr=99, nrReconNeighbors=k, globalVSMax=80)
+        r = gpu_ctx.reconstruct(st, [99], want_views=True)[0]
+        o = S.reconstruct(orc.make_settings(ref_view=99, local_neighbors=k, global_max=80))
+        m = map_parity(r["depth"], r["conf"], o["depth"], o["conf"])
+        print("W2 view 99, K = %d" % k, m)
+        assert m["iou"] >= 0.99 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2 and m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (k, m)
+        gl = np.asarray(gpu_ctx.global_view_selection(st))
+        assert len(gl) == 80 and list(gl) == S.global_vs(orc.make_settings(ref_view=99, global_max=80))
+        v = r["views"][r["conf"] > 0][:, :k]
+        assert (np.searchsorted(gl, v) >= 64).any(1).mean() > 0.1, np.bincount(np.searchsorted(gl, v).ravel(), minlength=80)
+    # patch level: ten local views, half of the hypotheses with a propagated set of ten (view slots 8, 9 travel in
+    # DevJob::hyp_x / results_x)
+    ref, ref_loc = w2["opt"], w2["opt_local"]
+    out, loc = gpu_ctx.patch_optimize(st10, 0, w2["seeds_xy"], w2["seeds_hyp"], w2["seeds_local"], lanes_per_view=1)
+    assert loc.shape == (160, 16)
+    assert ((out[:, 0] > 0) == (ref[:, 0] > 0)).mean() >= 0.97
+    ok = (out[:, 0] > 0) & (ref[:, 0] > 0)
+    assert ok.sum() >= 100
+    rel, dconf = np.abs(out[ok, 1] - ref[ok, 1]) / ref[ok, 1], np.abs(out[ok, 0] - ref[ok, 0])
+    print("W2 patches: ok %d, rel depth <= 1e-3: %.4f, |dconf| <= 5e-3: %.4f, same views %.4f"
+          % (ok.sum(), (rel <= 1e-3).mean(), (dconf <= 5e-3).mean(), (loc[ok] == ref_loc[ok]).all(1).mean()))
+    assert (rel <= 1e-3).mean() >= 0.97 and (dconf <= 5e-3).mean() >= 0.97
+    assert (loc[ok] == ref_loc[ok]).all(1).mean() >= 0.97
+    # four local views out of 80 global ones, three reference views in one call: the fused tail rounds and the front kernel
+    # write what host-visible rounds in the same lane layout write (the two-word availability mask in every kernel)
+    st4 = api.Settings(refViewNr=0, nrReconNeighbors=4, globalVSMax=80)
+    refs = [0, 41, 77]
+    monkeypatch.setenv("MI_DMRECON_FRONT", "0")
+    monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", "1000000000")
+    monkeypatch.setenv("MI_DMRECON_HOST_ROUNDS", "1")
+    seq = gpu_ctx.reconstruct(st4, refs, want_views=True)
+    monkeypatch.delenv("MI_DMRECON_HOST_ROUNDS")
+    for front in ("0", "1000000"):
+        monkeypatch.setenv("MI_DMRECON_FRONT", front)
+        got = gpu_ctx.reconstruct(st4, refs, want_views=True)
+        for a, b in zip(seq, got):
+            for key in ("depth", "conf", "dz", "normal", "views"):
+                assert np.array_equal(a[key], b[key]), (front, key)
+    monkeypatch.delenv("MI_DMRECON_FRONT"); monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER")
+    # sixteen slots: a batch of three views writes what the views write alone (nothing of a call's plan shows in a view's maps)
+    alone = [gpu_ctx.reconstruct(st10, [v], want_views=True)[0] for v in refs]
+    batch = gpu_ctx.reconstruct(st10, refs, want_views=True)
+    for a, b in zip(alone, batch):
+        for key in ("depth", "conf", "dz", "normal", "views"):
+            assert np.array_equal(a[key], b[key]), key
     gpu_ctx.load_scene(g1_scene)                             # the scene the module's other tests expect (ctx_g1)

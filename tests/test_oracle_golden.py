@@ -180,6 +180,24 @@ def test_more_than_four_local_and_32_global_views(w1, w1_scene):
     assert ((w1["opt_local"][ok] >= 0).sum(1) == 6).all()
 
 
+def test_more_than_eight_local_and_64_global_views(w2, w2_scene):
+    """apps/dmrecon -n 80 --local-neighbors=10, --local-neighbors=16 and -n 80 alone on scene W2 (100 views): the reference
+    accepts any number of either (libs/dmrecon/settings.h:37-38, local_view_selection.cc:144-146); the restatement is bit for
+    bit the reference there too."""
+    S = orc.OracleScene(w2_scene)
+    st = orc.make_settings(ref_view=0, local_neighbors=10, global_max=80)
+    assert S.global_vs(st) == list(w2["gvs80"]) and len(w2["gvs80"]) == 80
+    for tag, k, ng in (("k10n80", 10, 80), ("k16n20", 16, 20), ("k4n80", 4, 80)):
+        r = S.reconstruct(orc.make_settings(ref_view=0, local_neighbors=k, global_max=ng))
+        assert np.array_equal(r["depth"], w2[tag + "_depth"]) and np.array_equal(r["conf"], w2[tag + "_conf"]), tag
+        assert np.array_equal(r["dz"], w2[tag + "_dz"]), tag
+    out, loc = S.patch_optimize(st, w2["seeds_xy"], w2["seeds_hyp"], w2["seeds_local"])
+    ok = w2["opt"][:, 0] > 0
+    assert ok.sum() >= 100 and np.array_equal(out[:, 0] > 0, ok) and loc.shape == (160, 16)
+    assert np.array_equal(out[ok, :7], w2["opt"][ok, :7]) and np.array_equal(loc[ok], w2["opt_local"][ok])
+    assert ((w2["opt_local"][ok] >= 0).sum(1) == 10).all()
+
+
 def test_order_sensitivity_floor_on_wide_scene(w1):
     """The reference algorithm against itself with its queue popped worst-first on scene W1 (small images, 40 near-by
     global views, six local views): the floor behind the bounds of tests/test_gpu_parity.py::
