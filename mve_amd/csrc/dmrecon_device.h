@@ -114,6 +114,9 @@ void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* wo
  * view_count[job] or 0) -> out_dyn (12 bytes per job); the out pointers are page-locked host memory */
 void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const unsigned* b, int n_b, const DevCounters* counters,
                             const DevJob* jobs, int n_jobs, unsigned* out_rw, DevCounters* out_hc, void* out_dyn, const unsigned* view_count);
+/* the job records of a batch from their packed upload (words_per_job 32-bit words each: the part of DevJob in use, the
+ * same for every job of the batch) to their places in jobs[] */
+void mi_launch_unpack_jobs(hipStream_t s, const uint32_t* packed, unsigned words_per_job, DevJob* jobs, int n_jobs);
 /* dst: w*h records of 16 bytes (texels (x,y) (x+1,y) (x,y+1) (x+1,y+1), edge-clamped) */
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h);
 void mi_launch_pack_rgba(hipStream_t s, const uint8_t* src, uint32_t* dst, int n, int channels);

@@ -571,7 +571,9 @@ struct PatchState {
     float mfp;                   /* footPrintScaled(centre point) at the current state */
     float inrm_c;                /* geo[MI_MID]: 1 / |K_s^-1 (x + .5, y + .5, 1)| of the centre pixel */
     float jinv0;                 /* invproj[0] of the reference level */
-    Avail avail;                 /* LocalViewSelection::available over global indices */
+    Avail avail;                 /* LocalViewSelection::available over global indices -- once a view selection has asked for it
+                                  * (avail_ready); until then the words hold the propagated view set it will be made from */
+    bool avail_ready;
     /* per view slot */
     int sel;                     /* my view: index into job->global_ids, or -1 */
     float cs0, cs1, cs2;         /* PatchOptimization::colorScale[my view] */
@@ -1145,6 +1147,20 @@ __device__ __forceinline__ bool local_view_selection(PatchState& ps, const DevSe
     if (__popc(selmask) == K) return true;
     const DevJob* J = ps.job;
     const int G = J->n_global;
+    if (!ps.avail_ready) {
+        /* LocalViewSelection ctor (local_view_selection.cc:19-54): every global view but the propagated ones.  Made here, at the
+         * first selection a patch runs -- one patch in thousands does, and the two-word mask is a few dozen dependent
+         * instructions that every attempt of the latency-bound kernels would otherwise pay in run_begin */
+        static_assert(MI_AVAIL_WORDS >= 2, "the words park a propagated set of up to sixteen 8-bit indices");
+        const unsigned long long hv = ps.avail.w[0], hx = ps.avail.w[1];
+        ps.avail.first(G);
+#pragma unroll
+        for (int k = 0; k < L::NV; ++k) {
+            const unsigned g = (unsigned)((k < 8 ? hv : hx) >> (8 * (k & 7))) & 0xFFu;
+            if (g != MI_VIEW_NONE) ps.avail.clear((int)g);
+        }
+        ps.avail_ready = true;
+    }
     /* NCC of every available candidate at the current state; drop those below minNCC */
     Avail drop;
     drop.first(0);
@@ -1495,13 +1511,15 @@ __device__ __forceinline__ bool run_begin(Run& R, const DevJob* job, const DevSe
 
     TSTAMP(11);
     /* --- LocalViewSelection ctor (local_view_selection.cc:19-54) */
-    ps.avail.first(job->n_global);
+    /* (the availability mask itself is made by the first view selection the patch runs, from the set parked here) */
+    ps.avail.first(0);
+    ps.avail.w[0] = hyp_views; ps.avail.w[1] = L::NV == 16 ? hyp_x : ~0ull; ps.avail_ready = false;
     {
         int nprop = 0;
 #pragma unroll
         for (int k = 0; k < L::NV; ++k) {
             const unsigned g = (unsigned)((k < 8 ? hyp_views : hyp_x) >> (8 * (k & 7))) & 0xFFu;
-            if (g != MI_VIEW_NONE) { ++nprop; ps.avail.clear((int)g); if (k == slot) ps.sel = (int)g; }
+            if (g != MI_VIEW_NONE) { ++nprop; if (k == slot) ps.sel = (int)g; }
         }
         if (nprop > st.K) { ps.sel = -1; }          /* "Too many local neighbors propagated" */
         if (slot >= st.K) ps.sel = -1;
@@ -3332,6 +3350,14 @@ __global__ __launch_bounds__(256) void k_apply_seeds(ApplyArgs a) {
 /* ------------------------------------------------------------------------- */
 /* Image staging.                                                              */
 
+/* The job records of a batch as they were uploaded -- packed, words_per_job words each: the part of DevJob its global views use
+ * (BatchRun::upload) -- to their places in the job array. */
+__global__ __launch_bounds__(256) void k_unpack_jobs(const uint32_t* __restrict__ packed, unsigned words_per_job, uint32_t* __restrict__ jobs, unsigned words_per_slot) {
+    const unsigned j = blockIdx.y;
+    for (unsigned w = blockIdx.x * 256 + threadIdx.x; w < words_per_job; w += gridDim.x * 256)
+        jobs[(size_t)j * words_per_slot + w] = packed[(size_t)j * words_per_job + w];
+}
+
 /* interleaved 1..4 channel uint8 -> RGBA8 (grey expanded, alpha dropped; image_pyramid.cc:65-73) */
 __global__ __launch_bounds__(256) void k_pack_rgba(const uint8_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                   int n, int channels) {
@@ -3651,6 +3677,12 @@ void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const uns
                             const DevJob* jobs, int n_jobs, unsigned* out_rw, DevCounters* out_hc, void* out_dyn, const unsigned* view_count) {
     hipLaunchKernelGGL(k_round_report, dim3(1), dim3(256), 0, s, a, n_a, b, n_b, counters, jobs, n_jobs, out_rw,
                        reinterpret_cast<unsigned*>(out_hc), static_cast<unsigned*>(out_dyn), view_count);
+}
+void mi_launch_unpack_jobs(hipStream_t s, const uint32_t* packed, unsigned words_per_job, DevJob* jobs, int n_jobs) {
+    if (n_jobs <= 0 || words_per_job == 0) return;
+    static_assert(sizeof(DevJob) % 4 == 0, "job records are copied word by word");
+    hipLaunchKernelGGL(k_unpack_jobs, dim3(words_per_job > 768u ? 4u : (words_per_job + 255u) / 256u, (unsigned)n_jobs), dim3(256), 0, s,
+                       packed, words_per_job, reinterpret_cast<uint32_t*>(jobs), (unsigned)(sizeof(DevJob) / 4));
 }
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h) {
     hipLaunchKernelGGL(k_quadify, dim3((w * h + 255) / 256), dim3(256), 0, s, src, (u32x4*)dst, w, h);

@@ -313,6 +313,7 @@ struct BatchScratch {
     DevBuf<DevResult> d_results2;            /* ping-pong partner of d_results in the tail rounds */
     DevBuf<float> d_maps;                    /* depth | dz | conf | normal per batch */
     DevBuf<uint32_t> d_imaps;                /* views | upd */
+    DevBuf<uint32_t> d_jobs_packed;          /* the used parts of a batch's job records as they come up, before mi_launch_unpack_jobs spreads them */
     DevBuf<uint32_t> d_xviews;               /* nrReconNeighbors > 8 only: view slots 8..15 of the sets -- per pixel | per list entry | per explicit hypothesis, two words each (DevJob::views_x) */
     DevBuf<unsigned long long> d_keys;
     DevBuf<unsigned> d_keyoff;
@@ -376,7 +377,7 @@ struct BatchScratch {
         for (size_t i = 0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
         events.clear();
         d_jobs.release(); d_work.release(); d_work2.release(); d_hyp.release(); d_results.release(); d_results2.release();
-        d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_xviews.release(); d_keys.release(); d_keyoff.release();
+        d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_xviews.release(); d_jobs_packed.release(); d_keys.release(); d_keyoff.release();
         d_round_work.release(); d_round_work_t.release(); d_round_items.release(); d_view.release(); d_front.release(); d_front_resume.release();
         d_front_mail.release(); d_front_flags.release(); d_front_map.release(); d_front_order.release();
         d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release(); d_sparse_count.release();
@@ -1155,10 +1156,23 @@ void plan_seeds(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost& job, 
     }
 }
 
+/* The job records of a batch: 13 KB each (128 global views), of which a job with the default 20 uses 3 -- a vector that does not
+ * zero what fill_job is about to write (value-initialising 400 of them was half a millisecond of one thread per batch) */
+template <class T> struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef DefaultInitAlloc<U> other; };
+    DefaultInitAlloc() = default;
+    template <class U> DefaultInitAlloc(const DefaultInitAlloc<U>&) {}
+    template <class U> void construct(U* p) { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<DevJob, DefaultInitAlloc<DevJob> > JobVec;
+/* the part of a job record that is in use: everything up to its last global view (the view records are the struct's tail) */
+size_t job_prefix_bytes(int n_global) { return offsetof(DevJob, gv) + (size_t)std::min(std::max(n_global, 0), MI_MAX_GLOBAL) * sizeof(DevJobView); }
+
 void fill_job(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost const& jh, DevJob& d) {
     HostView const& R = c->sc->views[jh.ref_view];
     HostLevel const& L = R.levels[st->scale];
-    std::memset(&d, 0, sizeof(d));
+    std::memset(&d, 0, job_prefix_bytes((int)jh.global.size()));
     d.ref_view = jh.ref_view; d.scale = st->scale; d.w = L.w; d.h = L.h;
     d.inv_a = L.invproj[0]; d.inv_c = L.invproj[2]; d.inv_b = L.invproj[4]; d.inv_d = L.invproj[5];
     const float* r = R.cam.rot;
@@ -1207,7 +1221,7 @@ DevSettings dev_settings(const mi_dmrecon_settings* st) {
 }
 
 /* Lays the per-pixel state maps of a batch out in the two map buffers and points the jobs at them. */
-int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, std::vector<DevJob>& dj, size_t& total_px, size_t n_list, int K) {
+int alloc_maps(mi_dmrecon_ctx* c, std::vector<JobHost>& jobs, JobVec& dj, size_t& total_px, size_t n_list, int K) {
     const bool eight_views = K > 4, wide = K > 8;
     total_px = 0;
     for (size_t j = 0; j < jobs.size(); ++j) { jobs[j].pix_off = total_px; total_px += (size_t)jobs[j].w * jobs[j].h; }
@@ -1595,10 +1609,11 @@ struct BatchRun {
     /* the plan: one job per reference view that got through the host planning */
     std::vector<int> view_rc, job_of, ref_of_job;
     std::vector<std::string> plan_err;
-    std::vector<JobHost> jobs; std::vector<DevJob> dj;
+    std::vector<JobHost> jobs; JobVec dj;
     int nj = 0, n_alive = 0, max_tiles = 0;
     size_t total_px = 0, work_cap = 0, n_seed_feats = 0;
     size_t up_jobs = 0, up_keyoff = 0, up_seeds = 0, up_hyps = 0;   /* offsets into the pinned upload staging (BatchScratch::h_up) */
+    size_t job_bytes = sizeof(DevJob);         /* the part of a job record that is uploaded (DevJob: up to the last global view in use) */
     size_t n_seeds_total = 0;                  /* seeds of all views of the batch (they go from the plans straight into the pinned staging) */
     std::vector<unsigned> keyoff;
     /* the rounds */
@@ -1762,7 +1777,12 @@ int BatchRun::upload() {
     {
         /* everything the call uploads, through ONE page-locked staging buffer: asynchronous for real */
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-        up_jobs = 0; up_keyoff = al(up_jobs + (size_t)nj * sizeof(DevJob)); up_seeds = al(up_keyoff + (size_t)nj * sizeof(unsigned));
+        /* of a job record only the part its global views use goes up (the records of the views are its tail: DevJob), packed;
+         * a kernel spreads the records to their places (mi_launch_unpack_jobs) */
+        int max_global = 1;
+        for (int j = 0; j < nj; ++j) max_global = std::max(max_global, (int)dj[j].n_global);
+        job_bytes = job_prefix_bytes(max_global);
+        up_jobs = 0; up_keyoff = al(up_jobs + (size_t)nj * job_bytes); up_seeds = al(up_keyoff + (size_t)nj * sizeof(unsigned));
         up_hyps = al(up_seeds + n_seeds_total * sizeof(DevEntry));
         const size_t need = al(up_hyps + n_seeds_total * sizeof(DevHyp));
         if (c->bs.h_up_cap < need) {
@@ -1774,9 +1794,10 @@ int BatchRun::upload() {
         }
         std::memcpy(c->bs.h_up + up_keyoff, keyoff.data(), (size_t)nj * sizeof(unsigned));
         uint8_t* const hu = c->bs.h_up;
+        const size_t jb = job_bytes;
 #pragma omp parallel for schedule(static) num_threads(n_threads) if (n_threads > 1)
         for (int j = 0; j < nj; ++j) {
-            std::memcpy(hu + up_jobs + (size_t)j * sizeof(DevJob), &dj[j], sizeof(DevJob));
+            std::memcpy(hu + up_jobs + (size_t)j * jb, &dj[j], job_prefix_bytes(dj[j].n_global));
             const size_t n = jobs[j].seeds.size();
             if (n) {
                 std::memcpy(hu + up_seeds + seed_off[j] * sizeof(DevEntry), jobs[j].seeds.data(), n * sizeof(DevEntry));
@@ -1785,7 +1806,9 @@ int BatchRun::upload() {
         }
     }
     mark("  upload: staging");
-    HIP_TRY(hipMemcpyAsync(c->bs.d_jobs.p, c->bs.h_up + up_jobs, nj * sizeof(DevJob), hipMemcpyHostToDevice, S));
+    if (c->bs.d_jobs_packed.reserve(((size_t)nj * job_bytes + 3) / 4)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(jobs) failed");
+    HIP_TRY(hipMemcpyAsync(c->bs.d_jobs_packed.p, c->bs.h_up + up_jobs, (size_t)nj * job_bytes, hipMemcpyHostToDevice, S));
+    mi_launch_unpack_jobs(S, c->bs.d_jobs_packed.p, (unsigned)(job_bytes / 4), c->bs.d_jobs.p, nj);
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), S));
     if (c->bs.d_hyp.reserve(std::max<size_t>(n_seeds_total, 1)) || c->bs.d_keyoff.reserve(nj)
         || c->bs.d_round_work.reserve(MI_MAX_ROUNDS) || c->bs.d_round_work_t.reserve(MI_MAX_ROUNDS) || c->bs.d_round_items.reserve(MI_MAX_ROUNDS)
@@ -2985,7 +3008,7 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
     if (rc) return rc;
     HostLevel const& L = c->sc->views[ref_view].levels[st->scale];
     jh.w = L.w; jh.h = L.h;
-    std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
+    std::vector<JobHost> jobs(1, jh); JobVec dj(1);
     fill_job(c, st, jobs[0], dj[0]);
     size_t total_px = 0;
     rc = alloc_maps(c, jobs, dj, total_px, (size_t)std::max(n, 0), st->nrReconNeighbors);
@@ -3064,7 +3087,7 @@ static int mi_dmrecon_patch_eval_impl(mi_dmrecon_ctx* c, const mi_dmrecon_settin
     if (rc) return rc;
     HostLevel const& L = c->sc->views[ref_view].levels[st->scale];
     jh.w = L.w; jh.h = L.h;
-    std::vector<JobHost> jobs(1, jh); std::vector<DevJob> dj(1);
+    std::vector<JobHost> jobs(1, jh); JobVec dj(1);
     fill_job(c, st, jobs[0], dj[0]);
     size_t total_px = 0;
     rc = alloc_maps(c, jobs, dj, total_px, 0, st->nrReconNeighbors);

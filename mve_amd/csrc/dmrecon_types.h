@@ -54,7 +54,8 @@ struct DevJobView {
     int32_t pad[2];
 };
 
-/* One reference view being reconstructed (one mvs::DMRecon instance). */
+/* One reference view being reconstructed (one mvs::DMRecon instance).  The per-view records of its global views come LAST:
+ * a batch uploads, per job, only the part of the struct its views use (BatchRun::upload: the bytes up to gv[max n_global]). */
 struct DevJob {
     /* the two words the device writes and the host polls (copied back as a strided 8-byte column) */
     int32_t flags;                      /* MI_JOB_* */
@@ -66,8 +67,6 @@ struct DevJob {
     float w2c_z[4];                     /* third row of [R|t] of the reference view */
     float inv0_s;                       /* footPrintScaled factor */
     int32_t n_global;
-    int32_t global_ids[MI_MAX_GLOBAL];  /* ascending view ids (GlobalViewSelection result) */
-    DevJobView gv[MI_MAX_GLOBAL];       /* ... and what the sampler needs of each of them */
     /* per-pixel state maps (device), zero = unfilled (single_view.cc:78-81) */
     float* depth;
     float* dz;        /* 2 ch */
@@ -76,6 +75,13 @@ struct DevJob {
     uint32_t* views;  /* 4 x 8-bit indices into global_ids, MI_VIEW_NONE padded */
     int32_t* upd;     /* round in which the pixel was last written, -1 = never */
     uint32_t* views_hi;   /* view slots 4..7 of the set (nrReconNeighbors > 4 only, else null) */
+    /* Sixteen view slots (nrReconNeighbors > 8; else all three null): slots 8..15 of a set live apart from the rest, two words
+     * each -- per pixel, per entry of the round's list (what an optimisation found, k_apply / k_apply_seeds copy it to the
+     * pixel), per explicit hypothesis (null: none propagated).  The last two are the batch's, the same in every job.  Such
+     * views stay in the throughput layout: there is no second state slot of them. */
+    uint32_t* views_x;
+    uint32_t* results_x;
+    const uint32_t* hyp_x;
     /* Second slot of the pixel state, used by the fused tail rounds only (k_tail): a write of round r goes to
      * the slot that does NOT hold the pixel's state as of the end of round r-1, so the optimisations of a round
      * keep reading the frozen state of the previous round without a separate write-back launch.  The state
@@ -87,13 +93,8 @@ struct DevJob {
     uint32_t* views1;
     int32_t* upd1;
     uint32_t* views1_hi;
-    /* Sixteen view slots (nrReconNeighbors > 8; else all three null): slots 8..15 of a set live apart from the rest, two words
-     * each -- per pixel, per entry of the round's list (what an optimisation found, k_apply / k_apply_seeds copy it to the
-     * pixel), per explicit hypothesis (null: none propagated).  The last two are the batch's, the same in every job.  Such
-     * views stay in the throughput layout: there is no second state slot of them. */
-    uint32_t* views_x;
-    uint32_t* results_x;
-    const uint32_t* hyp_x;
+    int32_t global_ids[MI_MAX_GLOBAL];  /* ascending view ids (GlobalViewSelection result) */
+    DevJobView gv[MI_MAX_GLOBAL];       /* ... and what the sampler needs of each of them */
 };
 
 #define MI_JOB_EFOOTPRINT 1u   /* device: non-positive master footprint in this view (patch_sampler.cc:78-82 throws) */

@@ -95,6 +95,15 @@ def g2_scene(g2):
     return scene_from_golden(g2)
 
 
+@pytest.fixture(autouse=True)
+def _no_fault_injection_left_behind(request):
+    """A GPU test that fails half-way must not leave its injected fault (mi_dmrecon_debug_inject_footprint) to the tests after it."""
+    yield
+    if "gpu" in request.keywords:
+        from mve_amd import api
+        api.debug_inject_footprint(-1)
+
+
 @pytest.fixture(scope="session")
 def gpu_ctx():
     """One HIP context for the whole GPU test session (fails loudly without the library / a GPU)."""

