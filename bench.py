@@ -601,6 +601,7 @@ def main():
     ap.add_argument("--distinct-scenes", type=int, default=-1,
                     help="after the timed regions, the same plan once more on this many differently seeded scenes "
                          "(config.distinct_scenes_variant); -1 = 20 for config C3 on one GPU, else none; 0 = none")
+    ap.add_argument("--no-seed-variant", action="store_true", help="skip the two extra regions with MI_DMRECON_SEED_REOPT=0 (config.all_seeds_propagate_variant)")
     ap.add_argument("--no-one-call", action="store_true",
                     help="skip the `one_call` object (one 20-view library call on one host thread, measured after the timed region)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -680,6 +681,23 @@ def main():
                   "note": "BASELINE config 4: the %d reference views of ONE scene dealt round-robin over the %d ranks, "
                           "same steps / warm-up / call plan; depth maps of all ranks / slowest rank" % (p.n_views, world)}
 
+    # The same plan with the sweep's former seed rule (MI_DMRECON_SEED_REOPT=0: every seed propagates at once -- faster, but it
+    # can fill pixels the reference's queue never reaches; the default since round 5 is the reference's rule): reported next to
+    # `value`, never as `value`.  Only where the default is in force and the run is the plain one-GPU line.
+    seed_env = os.environ.get("MI_DMRECON_SEED_REOPT")
+    seed_variant = None
+    if world == 1 and seed_env is None and not args.no_seed_variant:
+        os.environ["MI_DMRECON_SEED_REOPT"] = "0"
+        try:
+            mine = rank_views(all_views, rank, world, "weak")
+            v_el, _, _ = timed_region(coll, ctxs, st, mine * spc, n_calls, min(args.warmup, 1), repeats=2, n_keep=len(mine))
+            seed_variant = {"value": len(mine) * spc * n_calls / float(np.median(v_el)), "unit": "depth-maps/s",
+                            "repeats": [len(mine) * spc * n_calls / e for e in v_el],
+                            "what": "MI_DMRECON_SEED_REOPT=0: every seed propagates at once (the sweep's rule until round 5; not the "
+                                    "reference's: on some scenes it fills pixels the reference does not, DESIGN section 2)"}
+        finally:
+            del os.environ["MI_DMRECON_SEED_REOPT"]
+
     one_call = None
     if rank == 0 and world == 1 and not args.no_one_call:
         one_call = run_one_call(ctx, st, all_views, scene, cfg, n_timed=max(1, args.one_call_n))
@@ -728,7 +746,11 @@ def main():
                        "maps_changed_pixels_per_depth_map": round(max(0, acc.get("n_sparse_records", 0)) / max(1, n_maps_rank * n_rep), 1),
                        # what `value` batches: every timed step reconstructs the SAME scene's reference views (one resident
                        # scene: a saturated-throughput figure whose concurrent jobs share one image set) ...
-                       "distinct_scenes": 1},
+                       "distinct_scenes": 1,
+                       # which seeds propagate (MI_DMRECON_SEED_REOPT): the reference's rule unless the environment says otherwise
+                       "seed_semantics": {None: "reference (a seed propagates only if re-optimising it raised its confidence; in the seed launch)",
+                                          "2": "reference (a seed propagates only if re-optimising it raised its confidence; in the seed launch)",
+                                          "1": "reference (as a round of its own)", "0": "every seed propagates at once (not the reference's rule)"}.get(seed_env, "reference")},
             "roofline": roof,
             # the scene's way into HBM, timed by itself before the timed regions (never part of `value`): host images ->
             # page-locked staging -> PCIe -> RGBA pack, pyramid and footprint records on the device
@@ -747,6 +769,8 @@ def main():
         if distinct is not None:
             # ... and the same plan on distinct data: every step another scene
             out["config"]["distinct_scenes_variant"] = distinct
+        if seed_variant is not None:
+            out["config"]["all_seeds_propagate_variant"] = seed_variant
         if strong is not None:
             out["strong_scaling"] = strong
         if args.config == "C3":

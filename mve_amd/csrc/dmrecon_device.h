@@ -107,9 +107,12 @@ void mi_launch_flatten(hipStream_t s, float* maps, uint32_t* imaps, size_t total
  * them all, also those that did not fit) */
 void mi_launch_emit_changed(hipStream_t s, const float* maps, const uint32_t* imaps, size_t total_px, size_t first, size_t count,
                             int r0, unsigned view, unsigned stride, unsigned* d_count, unsigned cap, uint32_t* out);
+/* seed_reopt: the records come from the re-optimising seed launch (DevSettings::seed_reopt: first confidence in `accepted`,
+ * "propagates" in `tried`) -- the pixels are stamped round 1 / round 0 accordingly, and seed_count[job] (zeroed by the caller)
+ * counts the pixels written: the propagation then starts with round 2 */
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
-                           const unsigned* key_off);
+                           const unsigned* key_off, int seed_reopt = 0, unsigned* seed_count = nullptr);
 /* one dispatch instead of four small copies: a[0..n_a) | b[0..n_b) -> out_rw, *counters -> *out_hc, per job (flags, n_filled,
  * view_count[job] or 0) -> out_dyn (12 bytes per job); the out pointers are page-locked host memory */
 void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const unsigned* b, int n_b, const DevCounters* counters,

@@ -1891,7 +1891,7 @@ __device__ __forceinline__ bool process_entry(const OptArgs& a, unsigned e, cons
  * loop around optimize_patch, hence none of the 260-300 bytes of scratch per lane the loop form needs.
  * more: the entry has a further candidate the rule still asks for (or its attempt was abandoned: FAST).
  */
-template <class L, bool FAST>
+template <class L, bool FAST, bool SEED = false>
 __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned e, const DevJob* job, int x, int y, int lane,
                                                      unsigned& n_eval, unsigned& n_pass, unsigned& n_patch, unsigned& err, bool& more) {
     const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
@@ -1906,11 +1906,25 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
                                  nullptr, L::NV == 16 ? load_x(job->hyp_x, e) : ~0ull, &rx);
         ++n_patch;
         more = false;
+        /* The SEED launch with the reference's seed semantics (DevSettings::seed_reopt): the reference pushes a seed's OWN pixel
+         * (dmrecon.cc:316-326) and, when it pops it, optimises it once more from its converged state and view set; only if that
+         * strictly raises the confidence is the pixel rewritten and are its neighbours pushed (:365-398).  Done here, in the
+         * seed's own launch: the record carries the result that stands, the FIRST confidence (what processFeatures compared
+         * when several features fall on one pixel: k_apply_seeds arbitrates by it) in `accepted`, and "propagates" in `tried`. */
+        float c1 = r.conf; bool propagates = false;
+        if (SEED && a.st.seed_reopt && r.conf > 0.f) {
+            PatchResult r2; unsigned long long rx2 = ~0ull;
+            optimize_patch<L, false>(job, a.st, a.views, x, y, r.depth, r.dzI, r.dzJ, view_set(r.views, r.views_hi), lane, r2, n_eval, n_pass, err, a.counters,
+                                     nullptr, rx, &rx2);
+            ++n_patch;
+            if (r2.conf > 0.f && c1 < r2.conf) { r = r2; rx = rx2; propagates = true; }
+        }
         if (writer) {
             DevResult o;
             o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ;
             o.nx = r.nx; o.ny = r.ny; o.nz = r.nz; o.views = r.views; o.views_hi = r.views_hi; o.iters = r.iters;
             o.accepted = r.conf > 0.f ? 1 : 0; o.tried = 0;
+            if (SEED && a.st.seed_reopt) { o.accepted = c1 > 0.f ? (int32_t)__float_as_uint(c1) : 0; o.tried = propagates ? 1u : 0u; }
             a.results[e] = o;
             if (L::NV == 16 && job->results_x) { job->results_x[2 * (size_t)e] = (unsigned)rx; job->results_x[2 * (size_t)e + 1] = (unsigned)(rx >> 32); }
         }
@@ -2032,9 +2046,10 @@ __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, 
  * The hot kernel.  L::LPV = 1: 16 patches per wavefront (throughput); L::LPV = 16: one patch per
  * wavefront (latency).  Grid-stride over the work list, so the grid need not match its size.
  */
-template <class L, bool FAST, bool SINGLE = FAST>
+template <class L, bool FAST, bool SINGLE = FAST, bool SEED = false>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 2 : MI_BULK_WAVES), (L::LAT ? 2 : MI_WAVES_PER_SIMD)))) void k_optimize(OptArgs a) {
     static_assert(SINGLE || !FAST, "the FAST kernel runs one attempt per entry");
+    static_assert(!SEED || (SINGLE && !FAST), "the seed launch is the single-attempt form of the general kernel");
     const int lane = threadIdx.x;
     const unsigned n = a.follow_in ? *a.follow_in_n : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
     if (n < a.min_work || n >= a.max_work) return;
@@ -2057,7 +2072,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
             /* the view failed (footprint exception) or was cancelled: nothing of it is touched any more */
             if (L::vslot(lane) == 0 && L::sub(lane) == 0) a.results[e].accepted = 0;
         } else if (SINGLE)
-            process_entry_single<L, FAST>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
+            process_entry_single<L, FAST, SEED>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
         else
             process_entry<L, false>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
         }
@@ -3175,6 +3190,8 @@ struct ApplyArgs {
     unsigned long long* seed_keys;   /* seeds only: per job pixel arbitration keys */
     const unsigned* key_off;         /* seeds only: per job offset into seed_keys */
     int phase;                       /* seeds: 0 = vote, 1 = write */
+    int seed_reopt;                  /* seeds: the records come from the re-optimising seed launch (DevSettings::seed_reopt) */
+    unsigned* seed_count;            /* ... per job: the pixels the seeds wrote (what k_generate takes for the size of "round 1") */
 };
 
 /* e: the result's entry in the round's list (its view slots 8..15 are DevJob::results_x[2 e ..], sixteen-slot sets only) */
@@ -3323,18 +3340,25 @@ __global__ __launch_bounds__(256) void k_apply_seeds(ApplyArgs a) {
     bool newly = false, okseed = false;
     if (e < a.n_work) {
         const DevResult r = a.results[e];
-        if (r.conf > 0.f) {
+        /* the confidence the features of a pixel are compared by is the one processFeatures saw: of the seed's FIRST optimisation
+         * (with the re-optimising launch it travels in `accepted`, the record's own may be the re-optimised one) */
+        const float c1 = a.seed_reopt ? __uint_as_float((unsigned)r.accepted) : r.conf;
+        if (c1 > 0.f) {
             const DevEntry ent = a.work[e];
             const DevJob* job = a.jobs + ent.job;
             const int pix = (ent.xy >> 16) * job->w + (ent.xy & 0xFFFF);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(r.conf) << 32) | (0xFFFFFFFFu - e);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(c1) << 32) | (0xFFFFFFFFu - e);
             unsigned long long* slot = a.seed_keys + a.key_off[ent.job] + pix;
             if (a.phase == 0) {
                 atomicMax(slot, key);
                 okseed = true;
             } else if (*slot == key) {
                 newly = job->conf[pix] <= 0.f;
-                write_pixel(job, pix, r, a.round, e);
+                /* a seed whose re-optimisation did not raise its confidence keeps the stamp of round 0 and the propagation starts
+                 * with round 2: it is nobody's source; the ones that propagate are stamped as written in round 1, which is where
+                 * the reference's pop would have rewritten them */
+                write_pixel(job, pix, r, a.seed_reopt ? (r.tried ? 1 : 0) : a.round, e);
+                if (a.seed_reopt && a.seed_count) atomicAdd(a.seed_count + ent.job, 1u);
                 if (newly) atomicAdd(const_cast<uint32_t*>(&job->n_filled), 1u);
             }
         }
@@ -3484,7 +3508,8 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
         if (lat) return;
         const unsigned ncc16 = (unsigned)(Lay<1, 16>::PATCHES * st.ncc_stride * sizeof(float));
         const bool single16 = hyp != nullptr || follow_out != nullptr;
-        if (single16) hipLaunchKernelGGL((k_optimize<Lay<1, 16>, false, true>), dim3(grid_blocks), dim3(WAVE), ncc16, s, a);
+        if (hyp != nullptr && st.seed_reopt) hipLaunchKernelGGL((k_optimize<Lay<1, 16>, false, true, true>), dim3(grid_blocks), dim3(WAVE), ncc16, s, a);
+        else if (single16) hipLaunchKernelGGL((k_optimize<Lay<1, 16>, false, true>), dim3(grid_blocks), dim3(WAVE), ncc16, s, a);
         else hipLaunchKernelGGL((k_optimize<Lay<1, 16>, false>), dim3(grid_blocks), dim3(WAVE), ncc16, s, a);
         return;
     }
@@ -3503,6 +3528,11 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     } else if (fast) {
         if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
         else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, true>), dim3(grid_blocks), dim3(WAVE), 0, s, a);
+    } else if (single && hyp != nullptr && st.seed_reopt) {
+        /* the seeds, each re-optimised once from its own result (the reference's seed semantics): a kernel of its own, so that
+         * the single-attempt kernel of the propagation rounds stays what it is */
+        if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, false, true, true>), dim3(grid_blocks), dim3(WAVE), ncc8, s, a);
+        else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, false, true, true>), dim3(grid_blocks), dim3(WAVE), ncc4, s, a);
     } else if (single) {
         if (eight) hipLaunchKernelGGL((k_optimize<Lay<1, 8>, false, true>), dim3(grid_blocks), dim3(WAVE), ncc8, s, a);
         else hipLaunchKernelGGL((k_optimize<Lay<1, 4>, false, true>), dim3(grid_blocks), dim3(WAVE), ncc4, s, a);
@@ -3555,7 +3585,7 @@ void mi_launch_apply(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, co
     ApplyArgs a;
     a.jobs = jobs; a.work = work; a.results = results; a.spec = nullptr; a.items = nullptr; a.n_items = nullptr; a.n_work_ptr = n_work_ptr; a.n_work = n_work;
     a.min_work = min_work; a.max_work = max_work; a.round = round;
-    a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0;
+    a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0; a.seed_reopt = 0; a.seed_count = nullptr;
     hipLaunchKernelGGL(k_apply, dim3(grid_blocks), dim3(256), 0, s, a);
 }
 void mi_launch_apply_spec(hipStream_t s, unsigned grid_blocks, const DevJob* jobs, const DevEntry* work, const DevSpec* spec,
@@ -3565,7 +3595,7 @@ void mi_launch_apply_spec(hipStream_t s, unsigned grid_blocks, const DevJob* job
     ApplyArgs a;
     a.jobs = jobs; a.work = work; a.results = nullptr; a.spec = spec; a.items = items; a.n_items = n_items; a.n_work_ptr = n_work_ptr; a.n_work = n_work;
     a.min_work = min_work; a.max_work = max_work; a.round = round;
-    a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0;
+    a.counters = counters; a.seed_keys = nullptr; a.key_off = nullptr; a.phase = 0; a.seed_reopt = 0; a.seed_count = nullptr;
     hipLaunchKernelGGL(k_apply_spec, dim3(grid_blocks), dim3(256), 0, s, a);
 }
 
@@ -3661,9 +3691,10 @@ void mi_launch_emit_changed(hipStream_t s, const float* maps, const uint32_t* im
 
 void mi_launch_apply_seeds(hipStream_t s, const DevJob* jobs, const DevEntry* work, const DevResult* results,
                            unsigned n_work, DevCounters* counters, unsigned long long* seed_keys,
-                           const unsigned* key_off) {
+                           const unsigned* key_off, int seed_reopt, unsigned* seed_count) {
     if (n_work == 0) return;
     ApplyArgs a;
+    a.seed_reopt = seed_reopt; a.seed_count = seed_count;
     a.jobs = jobs; a.work = work; a.results = results; a.spec = nullptr; a.items = nullptr; a.n_items = nullptr; a.n_work_ptr = nullptr; a.n_work = n_work; a.round = 0;
     a.min_work = 0; a.max_work = 0xFFFFFFFFu;
     a.counters = counters; a.seed_keys = seed_keys; a.key_off = key_off;

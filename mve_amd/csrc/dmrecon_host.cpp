@@ -1217,6 +1217,7 @@ DevSettings dev_settings(const mi_dmrecon_settings* st) {
     d.useColorScale = st->useColorScale;
     d.self_round = 0;
     d.ncc_stride = st->globalVSMax > 64 ? MI_MAX_GLOBAL : 64;
+    d.seed_reopt = 0;
     return d;
 }
 
@@ -1644,6 +1645,7 @@ struct BatchRun {
     std::vector<unsigned> view_list;         /* entries of every view's list in the last host-visible round read back (0: not known) */
     std::vector<unsigned> front_order;       /* one workgroup per view: the views in the order their workgroups start (FrontArgs::job_order) */
     std::vector<unsigned> front_map; unsigned front_grid = 0;   /* teams: what every block of the front launch is (FrontArgs::block_map) */
+    int seed_mode = 2;                         /* MI_DMRECON_SEED_REOPT: 0 every seed propagates at once, 1 re-optimisation as round 1, 2 (default) in the seed launch */
     unsigned handover = MI_VIEW_HANDOVER;      /* k_generate: a view's own list size below which it leaves the throughput layout */
     bool host_rounds_only = false;             /* diagnostic: every round host-visible (MI_DMRECON_HOST_ROUNDS) */
     int n_lat_rounds = 0;                      /* host-visible rounds that had entries in the latency layout */
@@ -1853,20 +1855,33 @@ int BatchRun::upload() {
 
 /* ---- round 0: DMRecon::processFeatures (dmrecon.cc:243-331), every SfM feature of every view in one launch */
 int BatchRun::seed_round() {
+    /* MI_DMRECON_SEED_REOPT (read per call): 2 / unset = the reference's seed semantics, in the seed launch itself; 1 = the same
+     * as a round of its own (round 1; same maps, the form the other one is tested against); 0 = every seed propagates at once
+     * (the default until round 5: a deviation that can fill pixels the reference's queue never reaches) */
+    seed_mode = [] { const char* e = std::getenv("MI_DMRECON_SEED_REOPT"); const int v = e ? std::atoi(e) : 2; return v < 0 || v > 2 ? 2 : v; }();
     if (n_seeds_total == 0) return 0;
     HIP_TRY(hipMemcpyAsync(c->bs.d_work.p, c->bs.h_up + up_seeds, n_seeds_total * sizeof(DevEntry), hipMemcpyHostToDevice, S));
     HIP_TRY(hipMemcpyAsync(c->bs.d_hyp.p, c->bs.h_up + up_hyps, n_seeds_total * sizeof(DevHyp), hipMemcpyHostToDevice, S));
     HIP_TRY(hipMemsetAsync(c->bs.d_keys.p, 0, total_px * sizeof(unsigned long long), S));
     ev.begin(S, EventLog::BULK, (unsigned)n_seeds_total);
     const unsigned ppw = patches_per_wave(st);
+    /* The reference's seed semantics (seed_mode 2, the default): every seed that succeeds is optimised once more from its own
+     * result in the seed launch itself, and only those whose confidence that strictly raises propagate -- they are stamped as
+     * written in round 1, the others as round 0's, k_apply_seeds counts the pixels per view as the size of "round 1", and the
+     * propagation starts with round 2: the maps of the two-round form (seed_mode 1: round 1 re-optimises the pixels the seeds
+     * wrote), bit for bit, without a round of its own. */
+    DevSettings sds = ds;
+    sds.seed_reopt = seed_mode == 2 ? 1 : 0;
     D->optimize(S, 1, ((unsigned)n_seeds_total + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p,
-                c->sc->d_lut, ds, c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n_seeds_total, 0u, 0xFFFFFFFFu, 0,
+                c->sc->d_lut, sds, c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n_seeds_total, 0u, 0xFFFFFFFFu, 0,
                 c->d_counters, nullptr, nullptr, nullptr, nullptr);
     ev.end(S);
     ++n_launch;
     ev.begin(S, EventLog::SWEEP, 0);
-    mi_launch_apply_seeds(S, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, (unsigned)n_seeds_total, c->d_counters, c->bs.d_keys.p, c->bs.d_keyoff.p);
+    mi_launch_apply_seeds(S, c->bs.d_jobs.p, c->bs.d_work.p, c->bs.d_results.p, (unsigned)n_seeds_total, c->d_counters, c->bs.d_keys.p, c->bs.d_keyoff.p,
+                          sds.seed_reopt, c->bs.d_view.p + (size_t)nj);
     ev.end(S);
+    if (sds.seed_reopt) round = 2;
     return 0;
 }
 
@@ -1929,13 +1944,13 @@ int BatchRun::bulk_rounds(bool& to_tail) {
     struct Pending { int round; size_t ev_thr, ev_lat; };
     Pending pend[2]; int n_pend = 0;
     bool stop = false;
-    /* MI_DMRECON_SEED_REOPT=1 (read per call; default 0): the reference pushes a seed's OWN pixel (dmrecon.cc:316-326) and, when it
+    /* MI_DMRECON_SEED_REOPT=1 (seed_round): the reference pushes a seed's OWN pixel (dmrecon.cc:316-326) and, when it
      * pops it, re-optimises it from its converged state; only if that strictly raises its confidence is the pixel rewritten
-     * and its four neighbours pushed (:365-398).  With the switch, round 1 is that re-optimisation for every pixel the seeds
+     * and its four neighbours pushed (:365-398).  In this form round 1 is that re-optimisation for every pixel the seeds
      * wrote (the entries are those pixels themselves, their own state the hypothesis, the same strict acceptance), and
-     * only the pixels it rewrites are sources of round 2.  Default: every seed propagates at once (measured parity-neutral
-     * in round 2 and again here, tests/test_gpu_parity.py::test_seed_reoptimisation_round). */
-    const bool SEED_REOPT = [] { const char* e = std::getenv("MI_DMRECON_SEED_REOPT"); return e && std::atoi(e) != 0; }();
+     * only the pixels it rewrites are sources of round 2.  (The default does the same inside the seed launch and starts
+     * here with round 2: tests/test_gpu_parity.py::test_seed_reoptimisation_round compares the two.) */
+    const bool SEED_REOPT = seed_mode == 1;
     auto enqueue = [&](int r) -> int {
         /* a round that will not fill the GPU several times over: speculative launches for lists below spec_cap, the plain
          * ones (below) only above it */

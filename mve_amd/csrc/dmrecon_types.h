@@ -111,6 +111,10 @@ struct DevSettings {
     /* (not settings either) floats per patch of the view selection's NCC table in the throughput kernels' dynamic shared memory:
      * 64, or MI_MAX_GLOBAL when globalVSMax is above 64 */
     int32_t ncc_stride;
+    /* (nor this) 1 in the launch of the SEEDS when every seed that succeeds is re-optimised from its own converged state in the
+     * same launch -- what the reference does when it pops the seed (dmrecon.cc:365-398) -- and propagates only if that strictly
+     * raised its confidence (k_optimize<..., SEED>; the default form of the reference's seed semantics) */
+    int32_t seed_reopt;
 };
 
 /* Work list entry + result of one patch optimisation attempt chain. */

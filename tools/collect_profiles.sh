@@ -38,6 +38,7 @@ du -sh $OUT
 cat $OUT/bench_driver.json $OUT/bench_1thread.json | cut -c1-300
 # a round trace of one lone C3 call, lone calls of a rank's share, the other configurations' lines
 timeout -s KILL 120 python tools/trace_c3.py > $OUT/round_trace_c3.txt 2>&1
+[ -n "$SKIP_EXTRAS" ] && exit 0                     # (a short collection: the C3 lines, kernel stats and counters only)
 timeout -s KILL 300 python tools/lone_calls.py C3 12 > $OUT/lone_calls.json 2> $OUT/lone_calls.err
 timeout -s KILL 300 python bench.py --config C2 --steps 20 --warmup 3 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 timeout -s KILL 600 python bench.py --config C5 --steps 4 --warmup 1 --repeats 3 --streams 2 --steps-per-call 1 > $OUT/bench_c5.json 2> $OUT/bench_c5.err

@@ -16,12 +16,12 @@ ctx = api.Context(0); ctx.load_scene(sc)
 S = orc.OracleScene(sc)
 for tag, k, ng in (("k10n80", 10, 80), ("k16n20", 16, 20), ("k4n80", 4, 80), ("k8n80", 8, 80)):
     st = api.Settings(refViewNr=0, nrReconNeighbors=k, globalVSMax=ng)
-    os.environ["MI_DMRECON_SEED_REOPT"] = "1"
+    r = ctx.reconstruct(st, [0], want_views=True)[0]
+    if tag + "_depth" in g:
+        print(tag, "default (the reference's seed semantics)", map_parity(r["depth"], r["conf"], g[tag + "_depth"], g[tag + "_conf"]), flush=True)
+    os.environ["MI_DMRECON_SEED_REOPT"] = "0"                   # every seed propagates at once: the rest of the probe looks at that form
     r = ctx.reconstruct(st, [0], want_views=True)[0]
     del os.environ["MI_DMRECON_SEED_REOPT"]
-    if tag + "_depth" in g:
-        print(tag, "MI_DMRECON_SEED_REOPT=1", map_parity(r["depth"], r["conf"], g[tag + "_depth"], g[tag + "_conf"]), flush=True)
-    r = ctx.reconstruct(st, [0], want_views=True)[0]
     if tag + "_depth" in g:
         rd, rc = g[tag + "_depth"], g[tag + "_conf"]
     else:
