@@ -11,8 +11,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 MI_BENCH_REGION_LOG=1 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err      # the driver's command
-python bench.py --streams 1 --steps-per-call 1 --steps 20 --repeats 3 --no-cpu-baseline --no-one-call --distinct-scenes 0 > $OUT/bench_1thread.json 2> $OUT/bench_1thread.err
-NOX="--no-cpu-baseline --no-one-call --distinct-scenes 0"
+python bench.py --streams 1 --steps-per-call 1 --steps 20 --repeats 3 --no-cpu-baseline --no-one-call --distinct-scenes 0 --no-seed-variant > $OUT/bench_1thread.json 2> $OUT/bench_1thread.err
+NOX="--no-cpu-baseline --no-one-call --distinct-scenes 0 --no-seed-variant"      # (the plain line only: nothing but the default form in a profiled run)
 B1="python $R/bench.py --steps 6 --warmup 1 --repeats 1 --streams 1 --steps-per-call 1 $NOX"
 B3="python $R/bench.py --steps 20 --warmup 5 --repeats 2 $NOX"
 cd /tmp
