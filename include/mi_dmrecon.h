@@ -246,7 +246,8 @@ int  mi_dmrecon_reconstruct(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, 
  * reference view ref_view: xy[2n]; hyp[3n] = depth,dzI,dzJ; local[Cn] view ids (-1 = none, may be NULL),
  * C = mi_dmrecon_local_view_channels(nrReconNeighbors).
  * lanes_per_view: the lane layout to run them in (1 = throughput layout, 16 patches per wavefront; 16 = latency
- * layout, one patch per wavefront -- the two layouts of the product path, same mathematics).
+ * layout, one patch per wavefront -- the two layouts of the product path, same mathematics; more than eight local views
+ * exist in the throughput layout only: 16 is MI_DMRECON_EINVAL then).
  * out[8n] = conf, depth, dzI, dzJ, nx, ny, nz, iterationCount; out_local[Cn] ascending ids, -1 padded. */
 int  mi_dmrecon_patch_optimize(mi_dmrecon_ctx* ctx, const mi_dmrecon_settings* st, int32_t ref_view, int32_t n,
                                const int32_t* xy, const float* hyp, const int32_t* local, int32_t lanes_per_view,

@@ -3064,6 +3064,8 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
     /* lanes_per_view = 16 runs the hook through the latency layout, anything else through the throughput layout */
     const int lpv = lanes_per_view == 16 ? 16 : 1;
+    if (lpv == 16 && st->nrReconNeighbors > 8)
+        return fail(MI_DMRECON_EINVAL, "more than eight local views run in the throughput layout only (lanes_per_view = 1)");
     const unsigned ppw = lpv == 16 ? 1u : patches_per_wave(st);
     D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st),
                c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,

@@ -1063,6 +1063,8 @@ def test_wider_view_sets_vs_reference(gpu_ctx, w2, w2_scene, g1_scene, monkeypat
     ref, ref_loc = w2["opt"], w2["opt_local"]
     out, loc = gpu_ctx.patch_optimize(st10, 0, w2["seeds_xy"], w2["seeds_hyp"], w2["seeds_local"], lanes_per_view=1)
     assert loc.shape == (160, 16)
+    with pytest.raises(ValueError):                          # (more than eight local views: the throughput layout only)
+        gpu_ctx.patch_optimize(st10, 0, w2["seeds_xy"], w2["seeds_hyp"], w2["seeds_local"], lanes_per_view=16)
     assert ((out[:, 0] > 0) == (ref[:, 0] > 0)).mean() >= 0.97
     ok = (out[:, 0] > 0) & (ref[:, 0] > 0)
     assert ok.sum() >= 100
