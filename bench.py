@@ -353,6 +353,9 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1, n_keep=None):
     warmed.wait()
     elapsed = []
     for rep in range(repeats):
+        # (a mark kernel on either side of the region, outside its clock: where a rocprofv3 kernel trace of this command is cut
+        # to the timed regions -- tools/trace_regions.py; the warm-up calls and everything after the regions stay out)
+        ctxs[0].debug_region_mark(2 * rep)
         coll.barrier()
         t0 = time.perf_counter()
         t_go[0] = t0
@@ -360,6 +363,7 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1, n_keep=None):
         fin.wait()
         coll.barrier()
         elapsed.append(coll.max(time.perf_counter() - t0))
+        ctxs[0].debug_region_mark(2 * rep + 1)
     for t in threads:
         t.join()
     # the maps of the LAST timed call: still in the output buffers of the host thread that finished last

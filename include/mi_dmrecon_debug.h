@@ -1,7 +1,7 @@
 /*
  * mi_dmrecon_debug.h -- test and development hooks of libmi_dmrecon.so.
  *
- * NOT part of the drop-in boundary (include/mi_dmrecon.h is; nothing here replaces anything of the reference): these five
+ * NOT part of the drop-in boundary (include/mi_dmrecon.h is; nothing here replaces anything of the reference): these six
  * entry points exist for tests/ and tools/ -- fault injection, the host-only halves of the planning (so that they can be
  * checked against the oracle without a GPU), pool introspection and the probe buffer of -DMI_PROBE builds.  They are
  * declared here so that the library exports nothing that no header declares (the link uses a version script: only
@@ -40,6 +40,10 @@ int mi_dmrecon_debug_plan_views_host(int32_t n_views, const mi_dmrecon_camera* c
 /* The scratch sets of the context's scene that no call holds at the moment (return value) and the pixel capacity of the
  * largest of them. */
 int mi_dmrecon_debug_scratch_sets(mi_dmrecon_ctx* ctx, long long* pixels_max);
+
+/* Launches an empty one-lane kernel (`k_region_mark`) on the context's stream and waits for it: bench.py brackets every timed
+ * region with one, so that a rocprofv3 kernel trace can be cut to the timed regions (tools/trace_regions.py). */
+int mi_dmrecon_debug_region_mark(mi_dmrecon_ctx* ctx, int tag);
 
 /* The debug buffer of -DMI_PROBE builds (tools/patch_probe.py): the first call allocates n 8-byte words on the device; later
  * calls copy up to n words out and clear the buffer. */

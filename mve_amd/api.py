@@ -145,6 +145,7 @@ def load_library() -> ctypes.CDLL:
     L.mi_dmrecon_debug_inject_footprint.argtypes = [ctypes.c_int]          # test hook, not in the public header
     L.mi_dmrecon_debug_inject_footprint.restype = None
     L.mi_dmrecon_debug_scratch_sets.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]  # test hook, not in the public header
+    L.mi_dmrecon_debug_region_mark.argtypes = [vp, ctypes.c_int]                        # profiling hook (mi_dmrecon_debug.h)
     L.mi_dmrecon_debug_plan_views_host.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, ctypes.POINTER(CSettings), i32, i32, i32, vp,
                                                    ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double), i32, vp, vp,
                                                    ctypes.POINTER(i32)]                                     # test hook
@@ -319,6 +320,13 @@ class Context:
         px = ctypes.c_longlong(0)
         n = self._L.mi_dmrecon_debug_scratch_sets(self._h, ctypes.byref(px))
         return int(n), int(px.value)
+
+    def debug_region_mark(self, tag=0):
+        """Profiling hook: an empty one-lane kernel (k_region_mark) on this context's stream, waited for -- where
+        tools/trace_regions.py cuts a rocprofv3 kernel trace."""
+        rc = self._L.mi_dmrecon_debug_region_mark(self._h, int(tag))
+        if rc != 0:
+            _raise(rc)
 
     def close(self):
         if getattr(self, "_h", None):

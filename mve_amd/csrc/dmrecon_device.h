@@ -120,6 +120,8 @@ void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const uns
 /* the job records of a batch from their packed upload (words_per_job 32-bit words each: the part of DevJob in use, the
  * same for every job of the batch) to their places in jobs[] */
 void mi_launch_unpack_jobs(hipStream_t s, const uint32_t* packed, unsigned words_per_job, DevJob* jobs, int n_jobs);
+/* an empty one-lane kernel: where profiles are cut (mi_dmrecon_debug_region_mark) */
+void mi_launch_region_mark(hipStream_t s, unsigned tag);
 /* dst: w*h records of 16 bytes (texels (x,y) (x+1,y) (x,y+1) (x+1,y+1), edge-clamped) */
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h);
 void mi_launch_pack_rgba(hipStream_t s, const uint8_t* src, uint32_t* dst, int n, int channels);

@@ -3476,6 +3476,11 @@ __global__ __launch_bounds__(256) void k_quadify(const uint32_t* __restrict__ sr
 #endif
 }
 
+#if MI_FW == 5
+/* A one-lane kernel that does nothing: profiles are cut at its dispatches (mi_dmrecon_debug_region_mark: bench.py brackets every
+ * timed region with one, tools/trace_regions.py keeps the dispatches between the marks of a rocprofv3 kernel trace). */
+__global__ void k_region_mark(unsigned tag) { (void)tag; }
+#endif
 
 }  /* namespace MI_FWNS */
 using namespace MI_FWNS;
@@ -3709,6 +3714,7 @@ void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const uns
     hipLaunchKernelGGL(k_round_report, dim3(1), dim3(256), 0, s, a, n_a, b, n_b, counters, jobs, n_jobs, out_rw,
                        reinterpret_cast<unsigned*>(out_hc), static_cast<unsigned*>(out_dyn), view_count);
 }
+void mi_launch_region_mark(hipStream_t s, unsigned tag) { hipLaunchKernelGGL(k_region_mark, dim3(1), dim3(1), 0, s, tag); }
 void mi_launch_unpack_jobs(hipStream_t s, const uint32_t* packed, unsigned words_per_job, DevJob* jobs, int n_jobs) {
     if (n_jobs <= 0 || words_per_job == 0) return;
     static_assert(sizeof(DevJob) % 4 == 0, "job records are copied word by word");

@@ -2875,7 +2875,9 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
     /* Batches of one scene in flight at a time.  Two, measured: their host-visible rounds interleave (a launch of one
      * fills the drain of the other's and its host round trip) -- taking turns in phase A instead costs 15 % at the
      * bench's plan, four in flight 30 % */
-    const int MAX_RUNNING = 2;
+    const int MAX_RUNNING = [] { const char* e = std::getenv("MI_DMRECON_MERGE_RUNNING"); return e ? std::max(1, std::atoi(e)) : 2; }();
+    /* MI_DMRECON_MERGE_SPLIT=<g> (read per call; experiment): a leader takes at most 1/g of the calls that are there */
+    const int SPLIT = [] { const char* e = std::getenv("MI_DMRECON_MERGE_SPLIT"); return e ? std::max(1, std::atoi(e)) : 1; }();
     const int WINDOW_ENV = [] { const char* e = std::getenv("MI_DMRECON_MERGE_WINDOW_US"); return e ? std::max(0, std::atoi(e)) : -1; }();
     /* A call gains from company: the launches of a larger batch fill the GPU better, the latency-bound tail is paid once
      * per batch, and ONE batch of all the callers' views beats two batches side by side (round 4, the bench's plan of four
@@ -2929,7 +2931,8 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
          * next to a running batch (two half-size batches side by side afterwards: 970-1 040 against 1 095-1 210 at the
          * bench's plan), and taking half of them with both slots free (2 + 2 calls instead of 1 + 1 + 2: 1 050-1 290,
          * mean below 1 + 1 + 2) */
-        for (size_t i = 0; i < Q.pending.size();) {
+        const size_t take_max = SPLIT > 1 ? (Q.pending.size() + 1 + (size_t)SPLIT - 1) / (size_t)SPLIT : (size_t)-1;
+        for (size_t i = 0; i < Q.pending.size() && batch.size() < take_max;) {
             MergeReq* r = Q.pending[i];
             if (std::memcmp(r->st, st, sizeof(*st)) == 0) { r->taken = true; batch.push_back(r); Q.pending.erase(Q.pending.begin() + i); }
             else ++i;
@@ -3272,6 +3275,14 @@ int mi_dmrecon_debug_scratch_sets(mi_dmrecon_ctx* c, long long* pixels_max) {
 
 /* development aid (include/mi_dmrecon_debug.h): the debug buffer of MI_PROBE builds (tools/patch_probe.py).  The first
  * call allocates `n` words on the device; later calls copy up to n words out and clear the buffer. */
+int mi_dmrecon_debug_region_mark(mi_dmrecon_ctx* c, int tag) {
+    if (!c || c->device < 0 || !c->stream) return fail(MI_DMRECON_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    mi_launch_region_mark(c->stream, (unsigned)tag);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int mi_dmrecon_debug_buffer(unsigned long long* out, int n) {
     static int cap = 0;
     if (!mi_debug_tbuf) {

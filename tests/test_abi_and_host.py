@@ -36,7 +36,7 @@ def test_library_exports_nothing_undeclared():
     out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH], text=True)
     exported = sorted({l.split()[-1].split("@")[0] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in "TDBRW"})
     hooks = header_functions("mi_dmrecon_debug.h")
-    assert len(hooks) == 5 and all(h.startswith("mi_dmrecon_debug_") for h in hooks)
+    assert len(hooks) == 6 and all(h.startswith("mi_dmrecon_debug_") for h in hooks)
     assert exported == sorted(header_functions() + hooks), sorted(set(exported) ^ set(header_functions() + hooks))
 
 
