@@ -589,6 +589,20 @@ def run_distinct_scenes(coll, device, cfg, st, n_scenes, spc, n_calls, n_streams
             "calls_per_library_batch_by_region": last.get("batch_shapes", [])}
 
 
+def self_launch(n_ranks):
+    """Re-executes this command line under torch.distributed.run with n_ranks processes on this node (MASTER_ADDR 127.0.0.1, a
+    port nobody holds) and returns its exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # (RCCL across processes: the host driver supports dmabuf IPC only)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -622,9 +636,14 @@ def main():
                          "0 = the largest divisor of --steps that is <= 5")
     args = ap.parse_args()
     rank, world, local_rank = rank_world()
+    if world == 1 and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: start the N ranks (one process per GPU, rank r on device r) the way the driver's
+        # N > 1 command does -- torch.distributed.run on this node, rendezvous on 127.0.0.1 at a free port -- and hand its exit
+        # code on; the ranks find WORLD_SIZE = N and take the branch below.  rank 0 prints the JSON line.
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it as `python bench.py --gpus N` or as "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     cfg = dict(CONFIGS[args.config], name=args.config)
     p = cfg["params"]
     # MI_BENCH_SHARE_GPU=1 (development only, never the driver's command): all ranks of an N > 1 launch use GPU 0 and

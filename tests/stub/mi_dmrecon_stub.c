@@ -1,0 +1,104 @@
+/*
+ * tests/stub/mi_dmrecon_stub.c -- TEST INFRASTRUCTURE, not a product path and not a CPU fallback.
+ *
+ * A stand-in for libmi_dmrecon.so that computes NOTHING: it keeps the sizes of the views it is given, and a "reconstruction"
+ * sleeps a millisecond per view and writes a constant pattern.  It exists so that the multi-process plumbing of bench.py
+ * (`python bench.py --gpus N`: self-launch of N ranks, barriers, shares of the views, the JSON line) can run end to end in a
+ * container without a GPU (tests/test_multi_rank.py builds it with gcc into a temporary directory and points
+ * MI_DMRECON_LIB at it).  Nothing in mve_amd/ or bench.py refers to it; the product library fails loudly without a GPU.
+ * It exports the entry points of include/mi_dmrecon.h that mve_amd/api.py binds, with the same signatures.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "mi_dmrecon.h"
+#include "mi_dmrecon_debug.h"
+
+#define STUB_MAX_VIEWS 4096
+typedef struct scene { int w[STUB_MAX_VIEWS], h[STUB_MAX_VIEWS]; int refs; } scene;
+struct mi_dmrecon_ctx { scene* sc; int owner; int device; };
+
+static void level_dims(int w, int h, int level, int* ow, int* oh) { while (level-- > 0) { w = (w + 1) / 2; h = (h + 1) / 2; } *ow = w; *oh = h; }
+
+int mi_dmrecon_device_count(void) { return 1; }
+int mi_dmrecon_local_view_channels(int32_t k) { return k > 8 ? 16 : k > 4 ? 8 : 4; }
+const char* mi_dmrecon_last_error(void) { return "stub"; }
+void mi_dmrecon_settings_default(mi_dmrecon_settings* s) {
+    memset(s, 0, sizeof(*s));
+    s->filterWidth = 5; s->minNCC = 0.3f; s->minParallax = 10.f; s->acceptNCC = 0.6f; s->minRefineDiff = 0.001f;
+    s->maxIterations = 20; s->nrReconNeighbors = 4; s->globalVSMax = 20; s->useColorScale = 1;
+    for (int i = 0; i < 3; ++i) { s->aabbMin[i] = -3.4e38f; s->aabbMax[i] = 3.4e38f; }
+}
+int mi_dmrecon_ctx_create(int device, mi_dmrecon_ctx** out) {
+    mi_dmrecon_ctx* c = (mi_dmrecon_ctx*)calloc(1, sizeof(*c));
+    c->sc = (scene*)calloc(1, sizeof(scene)); c->sc->refs = 1; c->owner = 1; c->device = device;
+    *out = c; return 0;
+}
+int mi_dmrecon_ctx_fork(mi_dmrecon_ctx* p, mi_dmrecon_ctx** out) {
+    mi_dmrecon_ctx* c = (mi_dmrecon_ctx*)calloc(1, sizeof(*c));
+    c->sc = p->sc; __sync_fetch_and_add(&p->sc->refs, 1); c->device = p->device;
+    *out = c; return 0;
+}
+void mi_dmrecon_ctx_destroy(mi_dmrecon_ctx* c) { if (!c) return; if (__sync_sub_and_fetch(&c->sc->refs, 1) == 0) free(c->sc); free(c); }
+void* mi_dmrecon_host_alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
+void mi_dmrecon_host_free(void* p) { free(p); }
+void* mi_dmrecon_ctx_stream(mi_dmrecon_ctx* c) { (void)c; return 0; }
+int mi_dmrecon_set_view(mi_dmrecon_ctx* c, int32_t id, const mi_dmrecon_camera* cam, int32_t w, int32_t h, int32_t ch, const uint8_t* px) {
+    (void)cam; (void)ch; (void)px;
+    if (id < 0 || id >= STUB_MAX_VIEWS) return MI_DMRECON_EINVAL;
+    c->sc->w[id] = w; c->sc->h[id] = h; return 0;
+}
+int mi_dmrecon_set_view_async(mi_dmrecon_ctx* c, int32_t id, const mi_dmrecon_camera* cam, int32_t w, int32_t h, int32_t ch, const uint8_t* px) {
+    return mi_dmrecon_set_view(c, id, cam, w, h, ch, px);
+}
+int mi_dmrecon_sync(mi_dmrecon_ctx* c) { (void)c; return 0; }
+int mi_dmrecon_evict_view(mi_dmrecon_ctx* c, int32_t id) { (void)c; (void)id; return 0; }
+int mi_dmrecon_set_features(mi_dmrecon_ctx* c, int32_t n, const float* pos, const int32_t* off, const int32_t* ids) { (void)c; (void)n; (void)pos; (void)off; (void)ids; return 0; }
+int mi_dmrecon_num_levels(mi_dmrecon_ctx* c, int32_t id) { (void)c; (void)id; return 4; }
+int mi_dmrecon_level_size(mi_dmrecon_ctx* c, int32_t id, int32_t level, int32_t* w, int32_t* h) {
+    if (id < 0 || id >= STUB_MAX_VIEWS || c->sc->w[id] == 0) return MI_DMRECON_EINVAL;
+    int ow, oh; level_dims(c->sc->w[id], c->sc->h[id], level, &ow, &oh); *w = ow; *h = oh; return 0;
+}
+int mi_dmrecon_get_level(mi_dmrecon_ctx* c, int32_t id, int32_t level, uint8_t* rgb, float* proj, float* invproj) { (void)c; (void)id; (void)level; (void)rgb; (void)proj; (void)invproj; return MI_DMRECON_EDEVICE; }
+int mi_dmrecon_global_view_selection(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref, int32_t* ids, int32_t* n) { (void)c; (void)st; (void)ref; (void)ids; *n = 0; return 0; }
+int mi_dmrecon_reconstruct(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t n_refs, const int32_t* refs, mi_dmrecon_maps* maps,
+                           mi_dmrecon_progress* progress, int32_t* status_out, mi_dmrecon_stats* stats) {
+    (void)progress;
+    struct timespec ts = {0, 1000000L * (n_refs > 0 ? n_refs : 0)};        /* a millisecond per view */
+    nanosleep(&ts, 0);
+    int64_t px_total = 0;
+    for (int i = 0; i < n_refs; ++i) {
+        int w, h; level_dims(c->sc->w[refs[i]], c->sc->h[refs[i]], st->scale, &w, &h);
+        const int64_t px = (int64_t)w * h; px_total += px;
+        for (int64_t p = 0; p < px; ++p) {
+            if (maps[i].depth) maps[i].depth[p] = 10.f + (float)refs[i];
+            if (maps[i].conf) maps[i].conf[p] = 0.5f;
+        }
+        if (status_out) status_out[i] = 0;
+    }
+    if (stats) {
+        const int64_t sz = stats->struct_size < (int64_t)sizeof(*stats) ? stats->struct_size : (int64_t)sizeof(*stats);
+        mi_dmrecon_stats s; memset(&s, 0, sizeof(s));
+        s.n_patch = px_total; s.n_eval = 32 * px_total; s.n_pass = 24 * px_total; s.n_filled = px_total; s.n_rounds = 1; s.n_launches = 1;
+        s.ms_total = 1.0 * n_refs; s.ms_opt_kernel = 0.5 * n_refs; s.ms_bulk_kernel = 0.5 * n_refs; s.n_bulk_launches = 1;
+        s.n_eval_bulk = s.n_eval; s.n_patch_bulk = s.n_patch; s.n_filled_bulk = s.n_filled; s.n_merged_calls = 1;
+        s.struct_size = sz;
+        memcpy(stats, &s, (size_t)sz);
+    }
+    return 0;
+}
+int mi_dmrecon_patch_optimize(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref, int32_t n, const int32_t* xy, const float* hyp, const int32_t* local, int32_t lpv, float* out, int32_t* out_local) {
+    (void)c; (void)st; (void)ref; (void)n; (void)xy; (void)hyp; (void)local; (void)lpv; (void)out; (void)out_local; return MI_DMRECON_EDEVICE; }
+int mi_dmrecon_patch_eval(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int32_t ref, int32_t x, int32_t y, float d, float di, float dj, float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level) {
+    (void)c; (void)st; (void)ref; (void)x; (void)y; (void)d; (void)di; (void)dj; (void)master; (void)ncc; (void)ok; (void)col; (void)deriv; (void)level; return MI_DMRECON_EDEVICE; }
+int mi_dmrecon_pointset(mi_dmrecon_ctx* c, const mi_dmrecon_camera* cam, int32_t w, int32_t h, const float* depth, const uint8_t* color, int32_t cc, const mi_dmrecon_pointset_options* opt, int32_t cap, int32_t* pixel, float* pos, float* normal, float* color_out, float* scale, float* conf, int32_t* n_out) {
+    (void)c; (void)cam; (void)w; (void)h; (void)depth; (void)color; (void)cc; (void)opt; (void)cap; (void)pixel; (void)pos; (void)normal; (void)color_out; (void)scale; (void)conf; (void)n_out; return MI_DMRECON_EDEVICE; }
+void mi_dmrecon_debug_inject_footprint(int v) { (void)v; }
+int mi_dmrecon_debug_front_teams(int32_t a, int32_t b, int32_t c, const int64_t* d, uint32_t* e, int32_t f, int32_t* g, int32_t* h, int32_t* i) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; return MI_DMRECON_EDEVICE; }
+int mi_dmrecon_debug_plan_views_host(int32_t a, const mi_dmrecon_camera* b, const int32_t* c, const int32_t* d, int32_t e, const float* f, const int32_t* g, const int32_t* h,
+                                     const mi_dmrecon_settings* i, int32_t j, int32_t k, int32_t l, int32_t* m, int32_t* n, double* o, int32_t p, int32_t* q, float* r, int32_t* s) {
+    (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; (void)k; (void)l; (void)m; (void)n; (void)o; (void)p; (void)q; (void)r; (void)s; return MI_DMRECON_EDEVICE; }
+int mi_dmrecon_debug_scratch_sets(mi_dmrecon_ctx* c, long long* px) { (void)c; if (px) *px = 0; return 0; }
+int mi_dmrecon_debug_region_mark(mi_dmrecon_ctx* c, int tag) { (void)c; (void)tag; return 0; }
+int mi_dmrecon_debug_buffer(unsigned long long* out, int n) { (void)out; (void)n; return 0; }

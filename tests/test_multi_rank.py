@@ -80,3 +80,57 @@ def test_two_rank_gloo_strong_and_weak_modes(tmp_path):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "MODES_OK" in out.stdout
+
+
+def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` as the driver types it (no torchrun around it) must start its two ranks itself, bind rank r to
+    device r and print ONE JSON line with n_gpus = 2, the weak value and the strong-scaling sub-object with the ranks' shares.
+    No GPU here: the ranks load tests/stub/mi_dmrecon_stub.c (a stand-in that computes nothing -- test infrastructure, built
+    into a temporary directory; MI_DMRECON_LIB) and share "device 0" over gloo (MI_BENCH_SHARE_GPU=1)."""
+    import json
+    lib = tmp_path / "libmi_dmrecon_stub.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "stub", "mi_dmrecon_stub.c"), "-o", str(lib)])
+    env = dict(os.environ, MI_DMRECON_LIB=str(lib), MI_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1",
+                          "--repeats", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and d["warmup"] == 1
+    assert d["value"] > 0 and len(d["repeats"]) == 2
+    assert d["config"]["ranks_share_one_gpu"] is True
+    ss = d["strong_scaling"]
+    assert ss["value"] > 0 and ss["views_per_rank"] == [1, 1]            # C1: two reference views, one per rank
+    # weak: both ranks reconstruct both views per step; strong: one view each -- twice the weak maps per rank-second at best
+    assert d["value"] > ss["value"] * 0.5
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_collective_on_rccl_one_rank(tmp_path):
+    """The backend the N > 1 bench runs on -- "nccl" = RCCL -- on the one GPU a test box has: a one-rank process group
+    (MI_FORCE_DIST=1), barrier + max + sum through Collective exactly as bench.py's timed region uses them."""
+    script = tmp_path / "rccl1.py"
+    script.write_text(textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        from mve_amd.dist import Collective
+        c = Collective("nccl", 0)
+        assert c.dist is not None and c.device.type == "cuda"
+        c.barrier()
+        assert c.max(1.25) == 1.25 and c.sum(3.0) == 3.0
+        c.barrier()
+        c.close()
+        print("RCCL_OK")
+    """ % ROOT))
+    env = dict(os.environ, MI_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RCCL_OK" in out.stdout
