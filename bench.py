@@ -72,7 +72,7 @@ def plan_calls(steps, streams, steps_per_call=0):
     return spc, n_calls, max(1, min(int(streams), n_calls))
 
 
-TRAFFIC_PROFILES = ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json")     # newest first
+TRAFFIC_PROFILES = ("r6_traffic.json",)     # this round's PMC passes only: without them `traffic` is null (no silent fall-back to older trees)
 # executed VALU wave-instructions per wavefront pass (16 patches x 4 views x 25 samples) of the bulk kernel: SQ_INSTS_VALU of a
 # PMC pass / (device-counted passes / 64); a STORED profile value like `traffic` (profiles/r<N>_traffic.json:
 # "valu_wave_insts_per_wave_pass"), r3's figure when the newest profile does not carry one
@@ -94,7 +94,7 @@ def stored_valu_per_wave_pass(lone=False):
             v = j.get("valu_wave_insts_per_wave_pass")
             if v:
                 return float(v), "profiles/" + name
-    return VALU_PER_WAVE_PASS_R3, "profiles/r3_pmc.md (1.42e8 VALU wave-instructions per FAST launch / its passes)"
+    return None, None
 
 
 def measured_traffic(n_streams, spc, config_is_c3=True):
@@ -146,6 +146,7 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None, global_views=Non
     # (a scene of gigabytes -- C5: 100 x 36.6 MB -- is not written to disk as PNGs for the reference binary inside a
     # bench run: the restatement on one view stands in, `kind` says so)
     big = sum(im.nbytes for im in scene.images) >= (1 << 30)
+    ref_failure = None
     if os.path.exists(ref_exe) and (not big or global_views is not None):
         from mve_amd.scene_io import SceneData, read_mvei, view_dir, write_scene
         work = tempfile.mkdtemp(prefix="bench_ref_")
@@ -174,13 +175,30 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None, global_views=Non
             cmd = [ref_exe, "-s%d" % s, "--local-neighbors=%d" % k, "--force", "--progress=silent", "--keep-conf",
                    "--list-view=%s" % ",".join(str(v) for v in sample), sdir]
             t0 = time.time()
-            out = subprocess.run(cmd, check=True, env=env, capture_output=True, text=True).stdout
+            run = subprocess.run(cmd, check=True, env=env, capture_output=True, text=True)
+            out = run.stdout
             wall = time.time() - t0
+            # The reference ends a view that throws and goes on with the others (apps/dmrecon/dmrecon.cc:314-317): exit code 0 and
+            # one view of the 20 without a depth map has been seen once on a GPU box (round 6; the cause is not established -- its
+            # threads share mve::View objects without locks).  Such a view is run again by itself (the same maps as in the
+            # all-views run, SURVEY App. B run 3; the time of the retry is added and the line says so); what is still missing
+            # afterwards fails this leg, not the bench line.
+            missing = [v for v in sample if not os.path.exists(os.path.join(view_dir(sdir, v), "depth-L%d.mvei" % s))]
+            retried = list(missing)
+            for v in missing:
+                sys.stderr.write("cpu_baseline: the reference wrote no depth map for view %d (its messages: %s); running it again by itself\n"
+                                 % (v, run.stderr.strip()[-300:]))
+                t1 = time.time()
+                subprocess.run(cmd[:-2] + ["--list-view=%d" % v, sdir], check=True, env=env, capture_output=True, text=True)
+                wall += time.time() - t1
+            missing = [v for v in sample if not os.path.exists(os.path.join(view_dir(sdir, v), "depth-L%d.mvei" % s))]
+            if missing:
+                raise RuntimeError("the reference binary wrote no depth map for views %s: %s" % (missing, run.stderr.strip()[-500:]))
             app_ms = None
             for ln in out.splitlines():
                 if ln.startswith("Reconstruction took"):
                     app_ms = float(ln.split()[2].rstrip("ms.").rstrip("ms"))
-            t = (app_ms / 1000.0) if app_ms else wall
+            t = (app_ms / 1000.0) if (app_ms and not retried) else wall
             quota = cpu_quota()
             base = {"value": n_sample / t, "unit": "depth-maps/s", "cores": min(cores, n_sample), "kind": "reference",
                     "cpu_quota": quota,
@@ -190,6 +208,8 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None, global_views=Non
                               "%d host cores visible%s, one thread per view" % (
                                   which, s, t, cores,
                                   "" if quota is None else " (the container's CPU quota: the time of %.0f)" % quota)}
+            if retried:
+                base["views_run_again_alone"] = retried
             parity = None
             if gpu_maps is not None:
                 ref_maps = [(read_mvei(os.path.join(view_dir(sdir, v), "depth-L%d.mvei" % s)),
@@ -205,6 +225,10 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None, global_views=Non
                         np.array_equal(gpu_maps[v][0], gpu_maps_last[v][0]) and np.array_equal(gpu_maps[v][1], gpu_maps_last[v][1]) for v in sample))
                     parity["within_bounds"] = bool(parity["within_bounds"] and pl["within_bounds"])
             return base, parity
+        except (OSError, RuntimeError, subprocess.SubprocessError, ValueError) as e:
+            # (the restatement below stands in: a bench line with a "port" baseline instead of no line)
+            ref_failure = "%s: %s" % (type(e).__name__, str(e)[:400])
+            sys.stderr.write("cpu_baseline: the reference leg failed (%s); falling back to the restatement\n" % ref_failure)
         finally:
             shutil.rmtree(work, ignore_errors=True)
     from oracle import oracle as orc
@@ -227,9 +251,12 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None, global_views=Non
             parity["last_timed_call"]["bit_identical_to_first"] = bool(all(
                 np.array_equal(gpu_maps[v][0], gpu_maps_last[v][0]) and np.array_equal(gpu_maps[v][1], gpu_maps_last[v][1]) for v in sample))
             parity["within_bounds"] = bool(parity["within_bounds"] and pl["within_bounds"])
-    return {"value": len(sample) / t, "unit": "depth-maps/s", "cores": 1, "kind": "port",
+    base = {"value": len(sample) / t, "unit": "depth-maps/s", "cores": 1, "kind": "port",
             "sample": "oracle/dmrecon_oracle.cc restatement, views %s one after the other, single thread (%.1f s; "
-                      "the reference binary needs the scene on disk as PNGs: not written for a scene of gigabytes)" % (sample, t)}, parity
+                      "the reference binary needs the scene on disk as PNGs: not written for a scene of gigabytes)" % (sample, t)}
+    if ref_failure:
+        base["reference_leg_failed"] = ref_failure
+    return base, parity
 
 
 def parity_bounds(config_name):
@@ -332,6 +359,8 @@ def timed_region(coll, ctxs, st, refs, n_calls, warmup, repeats=1, n_keep=None):
                     done_at[i] = time.perf_counter()
                     for k, v in c.last_stats.items():
                         acc[k] = acc.get(k, 0) + v
+                    if c.last_stats.get("clk_real_ticks", 0):
+                        acc["_calls"] = acc.get("_calls", 0) + 1          # (calls that carry clk_real_mhz: a constant, averaged back)
                     # how the library batched the timed calls: (calls merged into the batch this call ran, its host clock)
                     if rep == 0:
                         acc.setdefault("_batches", []).append((int(c.last_stats.get("n_merged_calls", 0)), round(c.last_stats.get("ms_total", 0.0), 1),
@@ -421,8 +450,23 @@ def roofline(acc, n_maps, scene, cfg, n_streams, spc, elapsed):
     if ms_bulk > 0 and acc["n_eval"] > 0:
         # the bulk kernel's share of the executed passes follows its share of the evaluations
         bulk_pass_frac = (b_bulk - 300.0 * bulk_stats["n_eval"] * (1.0 - n_pass / acc["n_eval"])) / (ms_bulk / 1e3) / 1e9 / HBM_PEAK_GBS
+    # the same counts per kernel TEMPLATE (mi_dmrecon_stats::*_by_kernel), per step: what the per-kernel times of a rocprofv3
+    # trace of this command are divided by (tools/roofline_check.py -> profiles/r6_roofline_check.md)
+    from mve_amd.api import KERNEL_KINDS
+    by_template = {}
+    for kind in KERNEL_KINDS:
+        ne, npass, npatch, nex = (acc.get("%s.%s" % (f, kind), 0) for f in ("n_eval_by_kernel", "n_pass_by_kernel", "n_patch_by_kernel", "n_pass_executed_by_kernel"))
+        if ne or npass or npatch or nex:
+            by_template[kind] = {"n_eval_per_step": ne / steps_rank, "n_pass_per_step": npass / steps_rank, "n_patch_per_step": npatch / steps_rank,
+                                 "n_pass_executed_per_step": nex / steps_rank,
+                                 "algorithmic_bytes_per_step": (300.0 * ne + 75.0 * npatch) / steps_rank}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            "per_kernel_template": by_template,
+            # host-visible rounds in the latency layout (views that have handed over while others of their batch have not): part of
+            # the bulk kernels' time
+            "latency_layout_rounds": {"ms_per_step": acc.get("ms_latency_rounds", 0.0) / steps_rank, "entries_per_step": acc.get("n_latency_entries", 0) / steps_rank,
+                                      "share_of_bulk_kernel_time": (acc.get("ms_latency_rounds", 0.0) / ms_bulk) if ms_bulk > 0 else None},
             "frac_on_passes": (b_pass / opt_s / 1e9 / HBM_PEAK_GBS) if opt_s > 0 else None,
             "bulk_kernel_frac": per_kernel["k_optimize<1> (host-visible rounds)"]["frac"],
             "bulk_kernel_frac_on_passes": bulk_pass_frac,
@@ -489,12 +533,25 @@ def valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps, lone=False):
     if not acc.get("n_eval") or ms_bulk <= 0:
         return None
     per_wave_pass, src = stored_valu_per_wave_pass(lone)
+    if per_wave_pass is None:
+        return None
     passes_bulk = n_pass * (bulk_stats["n_eval"] / acc["n_eval"])           # the bulk kernel's share of the executed passes
     insts = per_wave_pass * passes_bulk / 64.0                              # a wavefront pass = 64 patch-view passes
     rate = N_SIMDS * SHADER_CLOCK_HZ / CYCLES_PER_VALU_INST                 # wave-instructions per second, whole chip
     floor_ms = 1000.0 * insts / rate
     alg = ALGORITHMIC_VALU_PER_SAMPLE * 25.0 * passes_bulk / 64.0
-    return {"bound": "valu_issue", "kernel": "k_optimize<1> (host-visible rounds)",
+    # the shader clock the kernels actually ran at (mi_dmrecon_stats::clk_*: shader cycles over constant-rate ticks, sampled
+    # inside the k_optimize launches of THIS run): the roof above is priced at the data sheet's 2.4 GHz
+    clk = (acc["clk_shader_cycles"] / acc["clk_real_ticks"] * (acc.get("clk_real_mhz", 0.0) / max(acc.get("_calls", 1), 1))
+           if acc.get("clk_real_ticks") else None)
+    measured = None
+    if clk:
+        rate_m = N_SIMDS * clk * 1e6 / CYCLES_PER_VALU_INST
+        measured = {"shader_clock_mhz": clk, "peak": rate_m / 1e9, "floor_ms_per_step": 1000.0 * insts / rate_m / max(steps, 1),
+                    "frac": 1000.0 * insts / rate_m / ms_bulk,
+                    "what": "the same roof priced at the shader clock sampled inside this run's k_optimize launches "
+                            "(shader cycles / constant-rate ticks of every 1024th wavefront)"}
+    return {"bound": "valu_issue", "kernel": "k_optimize<1> (host-visible rounds)", "at_measured_clock": measured,
             "executed_valu_wave_insts_per_step": insts / max(steps, 1), "valu_wave_insts_per_wave_pass": per_wave_pass,
             "source": {"file": src, "stored_profile": True},
             "peak": rate / 1e9, "unit": "G wave-instructions/s", "cycles_per_valu_wave_inst": CYCLES_PER_VALU_INST,
@@ -519,6 +576,8 @@ def run_one_call(ctx, st, views, scene, cfg, n_timed=50):
         ts.append(time.perf_counter() - t0)
         for k, v in ctx.last_stats.items():
             acc[k] = acc.get(k, 0) + v
+        if ctx.last_stats.get("clk_real_ticks", 0):
+            acc["_calls"] = acc.get("_calls", 0) + 1
     med = float(np.median(ts))
     roof = roofline(acc, len(views) * n_timed, scene, cfg, 1, 1, float(np.sum(ts)))
     pk = roof["per_kernel"]

@@ -154,6 +154,20 @@ typedef struct mi_dmrecon_stats {
     int64_t n_sparse_records;    /* large batches: the maps went back as a snapshot taken at the hand-over (copied while the front
                                   * kernel ran) plus this many pixels the front changed afterwards (0: the maps were copied in
                                   * full; -1: the list outgrew its buffer and they were copied in full after all) */
+    /* (round 6) the work counts once more, per KERNEL TEMPLATE -- index: 0 k_optimize<.., FAST> (first attempts of the large rounds,
+     * and the follow-up launches that run in it), 1 k_optimize<.., SINGLE> (single-attempt follow-up launches of the general
+     * kernel), 2 the seed launch, 3 k_optimize general (an entry's attempts in a row), 4 k_optimize_spec, 5 k_optimize in the latency
+     * layout on a host-visible list, 6 k_tail, 7 k_front: what a profile's per-kernel time is divided by (profiles/r6_roofline_check.md) */
+    int64_t n_eval_by_kernel[8], n_pass_by_kernel[8], n_patch_by_kernel[8];
+    int64_t n_pass_executed_by_kernel[8];   /* ... and the passes a template EXECUTED: for k_optimize_spec the attempts the rule discards
+                                             * included; elsewhere = n_pass_by_kernel (k_tail / k_front: the counted passes only) */
+    double  ms_latency_rounds;   /* hipEvent durations of the latency-layout launches of the host-visible rounds (part of ms_bulk_kernel):
+                                  * views that have handed over while others of the batch have not */
+    int64_t n_latency_entries;   /* ... and the list entries they ran */
+    double  shader_clock_mhz;    /* the shader clock the k_optimize launches of this call ran at: shader cycles over constant-rate
+                                  * ticks of every 1024th wavefront's life (0: none sampled) -- the clock the VALU-issue roof is priced at */
+    int64_t clk_shader_cycles, clk_real_ticks;   /* ... its two sums (they add up over calls) and the rate of the constant clock */
+    double  clk_real_mhz;
 } mi_dmrecon_stats;
 
 int  mi_dmrecon_device_count(void);
@@ -222,7 +236,13 @@ int  mi_dmrecon_global_view_selection(mi_dmrecon_ctx* ctx, const mi_dmrecon_sett
  * outcome -- 0, MI_DMRECON_EGVS, MI_DMRECON_ENOIMAGE (a selected view was registered without pixels),
  * MI_DMRECON_EFOOTPRINT (patch_sampler.cc:78-82 throws for that view only) or
  * MI_DMRECON_ECANCELLED (progress[i].cancelled was set, before or during the run: dmrecon.cc:101-105,353) -- and
- * the maps of a view that did not finish are left untouched.  progress[i].filled counts that view's pixels.
+ * the maps of a view that did not finish are left untouched (a view is only ever written once it has ended well), with ONE
+ * exception: a call of 48 or more views without a progress array copies the state of its views as of the hand-over to the
+ * per-view front kernel into the callers' buffers while that kernel runs (and the pixels it changed afterwards); a view that
+ * ends with an error AFTER that point -- with valid cameras only a device error can make one: a propagated hypothesis has a
+ * positive depth, and there is no progress array to cancel through -- has had that intermediate state written to its buffers.
+ * Its status says so: maps of a view whose status is not 0 are void, whatever they hold (MI_DMRECON_SPARSE_MAPS=0 keeps the
+ * strict form).  progress[i].filled counts that view's pixels.
  * Return value: 0 if at least one view finished; with a single view (or when every view failed) the failing
  * view's own code.
  * Calls without a progress array that arrive at the same time on contexts of one scene (ctx_fork) with equal

@@ -95,7 +95,14 @@ class CStats(ctypes.Structure):
                 ("front_fallbacks", ctypes.c_int64), ("n_latency_rounds", ctypes.c_int64),
                 ("ms_wall_setup", ctypes.c_double), ("ms_wall_rounds", ctypes.c_double), ("ms_wall_front", ctypes.c_double), ("ms_wall_download", ctypes.c_double),
                 ("n_patch_turns", ctypes.c_int64), ("n_wave_turns", ctypes.c_int64),
-                ("front_team_max", ctypes.c_int64), ("n_sparse_records", ctypes.c_int64)]
+                ("front_team_max", ctypes.c_int64), ("n_sparse_records", ctypes.c_int64),
+                ("n_eval_by_kernel", ctypes.c_int64 * 8), ("n_pass_by_kernel", ctypes.c_int64 * 8), ("n_patch_by_kernel", ctypes.c_int64 * 8),
+                ("n_pass_executed_by_kernel", ctypes.c_int64 * 8),
+                ("ms_latency_rounds", ctypes.c_double), ("n_latency_entries", ctypes.c_int64), ("shader_clock_mhz", ctypes.c_double),
+                ("clk_shader_cycles", ctypes.c_int64), ("clk_real_ticks", ctypes.c_int64), ("clk_real_mhz", ctypes.c_double)]
+
+
+KERNEL_KINDS = ("fast", "follow", "seed", "loop", "spec", "latency", "tail", "front")      # index of the *_by_kernel arrays
 
 
 _lib = None
@@ -489,7 +496,14 @@ class Context:
                                             _ptr(status), ctypes.byref(stats))
         if rc != 0:
             _raise(rc)
-        self.last_stats = {k: getattr(stats, k) for k, _ in CStats._fields_}
+        self.last_stats = {}
+        for k, _ in CStats._fields_:
+            v = getattr(stats, k)
+            if isinstance(v, ctypes.Array):               # the per-kernel-template arrays: one key per template (KERNEL_KINDS)
+                for name, x in zip(KERNEL_KINDS, v):
+                    self.last_stats["%s.%s" % (k, name)] = x
+            else:
+                self.last_stats[k] = v
         for i in range(n):
             out[i]["status"] = int(status[i])
         return out

@@ -2023,7 +2023,7 @@ struct XcdRange {
  * the patch counter in the first lane of each patch) */
 template <class L>
 __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, unsigned n_eval, unsigned n_pass,
-                                               unsigned n_patch, unsigned n_filled, unsigned err) {
+                                               unsigned n_patch, unsigned n_filled, unsigned err, int kind) {
     if (L::sub(lane) != 0) { n_eval = 0; n_pass = 0; }
     if (L::vslot(lane) != 0 || L::sub(lane) != 0) { n_patch = 0; n_filled = 0; }
     for (int off = 32; off > 0; off >>= 1) {
@@ -2034,9 +2034,10 @@ __device__ __forceinline__ void flush_counters(DevCounters* counters, int lane, 
         err |= __shfl_down(err, off);
     }
     if (lane == 0) {
-        if (n_eval) atomicAdd(&counters->n_eval, (unsigned long long)n_eval);
-        if (n_pass) atomicAdd(&counters->n_pass, (unsigned long long)n_pass);
-        if (n_patch) atomicAdd(&counters->n_patch, (unsigned long long)n_patch);
+        if (n_eval) { atomicAdd(&counters->n_eval, (unsigned long long)n_eval); atomicAdd(&counters->k_eval[kind], (unsigned long long)n_eval); }
+        if (n_pass) { atomicAdd(&counters->n_pass, (unsigned long long)n_pass); atomicAdd(&counters->k_pass[kind], (unsigned long long)n_pass);
+                      atomicAdd(&counters->k_pass_exec[kind], (unsigned long long)n_pass); }
+        if (n_patch) { atomicAdd(&counters->n_patch, (unsigned long long)n_patch); atomicAdd(&counters->k_patch[kind], (unsigned long long)n_patch); }
         if (n_filled) atomicAdd(&counters->n_filled, (unsigned long long)n_filled);
         if (err) atomicOr(&counters->error_flags, err);
     }
@@ -2058,6 +2059,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
     if (lane < 2) g_act[lane] = 0;
 #endif
     __syncthreads();
+    /* (DevCounters::clk_shader / clk_real: the shader clock this launch runs at, sampled by every 1024th wavefront) */
+    const bool clk_probe = (blockIdx.x & 1023u) == 0u;
+    const unsigned long long clk_s0 = clk_probe ? (unsigned long long)clock64() : 0ull, clk_r0 = clk_probe ? (unsigned long long)wall_clock64() : 0ull;
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
     unsigned unit;
     for (XcdRange xr((n + L::PATCHES - 1) / L::PATCHES); xr.next(unit); ) {
@@ -2089,7 +2093,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
             }
         }
     }
-    flush_counters<L>(a.counters, lane, n_eval, n_pass, n_patch, 0u, err);
+    flush_counters<L>(a.counters, lane, n_eval, n_pass, n_patch, 0u, err,
+                      L::LAT ? MI_KIND_LAT : SEED ? MI_KIND_SEED : FAST ? MI_KIND_FAST : SINGLE ? MI_KIND_FOLLOW : MI_KIND_LOOP);
+    if (clk_probe && lane == 0) {
+        const unsigned long long ds = (unsigned long long)clock64() - clk_s0, dr = (unsigned long long)wall_clock64() - clk_r0;
+        if (dr > 100ull) { atomicAdd(&a.counters->clk_shader, ds); atomicAdd(&a.counters->clk_real, dr); }   /* (wavefronts that found no work: too short to say anything) */
+    }
 #ifdef MI_ACTIVITY
     __syncthreads();
     if (lane == 0 && !L::LAT) { atomicAdd(&a.counters->n_stage, (unsigned long long)g_act[0]); atomicAdd(&a.counters->n_gather_pass, (unsigned long long)g_act[1] * L::PATCHES); }
@@ -2130,7 +2139,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((MI_FW >= 
     for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
     __syncthreads();
     const bool writer = L::vslot(lane) == 0 && L::sub(lane) == 0;
-    unsigned err = 0;
+    unsigned err = 0, n_exec = 0;                         /* n_exec: passes this wavefront executed (DevCounters::k_pass_exec) */
     const unsigned n_items = *t.n_items;
     unsigned unit;
     for (XcdRange xr((n_items + L::PATCHES - 1) / L::PATCHES); xr.next(unit); ) {
@@ -2179,6 +2188,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((MI_FW >= 
         optimize_patch<L, false, true>(job, a.st, a.views, x, y, hd, hi, hj, hv, lane, r, ne, np, err, a.counters, &deferred);
         if (L::sub(lane) != 0) { ne = 0; np = 0; }
         ne = patch_sum_u<L>(ne); np = patch_sum_u<L>(np);
+        if (writer) n_exec += np;
         if (writer) {
             DevSpec o;
             o.conf = r.conf; o.depth = r.depth; o.dzI = r.dzI; o.dzJ = r.dzJ; o.nx = r.nx; o.ny = r.ny; o.nz = r.nz;
@@ -2187,8 +2197,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((MI_FW >= 
             *rec = o;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) err |= __shfl_down(err, off);
+    for (int off = 32; off > 0; off >>= 1) { err |= __shfl_down(err, off); n_exec += __shfl_down(n_exec, off); }
     if (lane == 0 && err) atomicOr(&a.counters->error_flags, err);
+    if (lane == 0 && n_exec) atomicAdd(&a.counters->k_pass_exec[MI_KIND_SPEC], (unsigned long long)n_exec);
 }
 
 /*
@@ -2388,9 +2399,10 @@ __global__ __launch_bounds__((SPEC ? MI_TAIL_WAVES : 1) * WAVE) __attribute__((a
     }
     /* n_eval / n_pass / n_patch / n_filled were kept by lane 0 of wavefront 0 only */
     if (threadIdx.x == 0) {
-        if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
-        if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
-        if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
+        if (n_eval) { atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval); atomicAdd(&a.counters->k_eval[MI_KIND_TAIL], (unsigned long long)n_eval); }
+        if (n_pass) { atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass); atomicAdd(&a.counters->k_pass[MI_KIND_TAIL], (unsigned long long)n_pass);
+                      atomicAdd(&a.counters->k_pass_exec[MI_KIND_TAIL], (unsigned long long)n_pass); }
+        if (n_patch) { atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch); atomicAdd(&a.counters->k_patch[MI_KIND_TAIL], (unsigned long long)n_patch); }
         if (n_filled) atomicAdd(&a.counters->n_filled, (unsigned long long)n_filled);
     }
     for (int off = 32; off > 0; off >>= 1) err |= __shfl_down(err, off);
@@ -2881,9 +2893,10 @@ __global__ __launch_bounds__(MI_FRONT_WAVES * WAVE) __attribute__((amdgpu_waves_
         err |= __shfl_down(err, off2); st_att += __shfl_down(st_att, off2);
     }
     if (lane == 0) {
-        if (n_eval) atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval);
-        if (n_pass) atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass);
-        if (n_patch) atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch);
+        if (n_eval) { atomicAdd(&a.counters->n_eval, (unsigned long long)n_eval); atomicAdd(&a.counters->k_eval[MI_KIND_FRONT], (unsigned long long)n_eval); }
+        if (n_pass) { atomicAdd(&a.counters->n_pass, (unsigned long long)n_pass); atomicAdd(&a.counters->k_pass[MI_KIND_FRONT], (unsigned long long)n_pass);
+                      atomicAdd(&a.counters->k_pass_exec[MI_KIND_FRONT], (unsigned long long)n_pass); }
+        if (n_patch) { atomicAdd(&a.counters->n_patch, (unsigned long long)n_patch); atomicAdd(&a.counters->k_patch[MI_KIND_FRONT], (unsigned long long)n_patch); }
         if (n_filled) atomicAdd(&a.counters->n_filled, (unsigned long long)n_filled);
         if (err) atomicOr(&a.counters->error_flags, err);
         if (st_att) atomicAdd(&t.job_stats[4 * jobi + 1], st_att);
@@ -3326,9 +3339,9 @@ __global__ __launch_bounds__(256) void k_apply_spec(ApplyArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_red[0]) atomicAdd(&a.counters->n_filled, (unsigned long long)s_red[0]);
-        if (s_red[1]) atomicAdd(&a.counters->n_eval, (unsigned long long)s_red[1]);
-        if (s_red[2]) atomicAdd(&a.counters->n_pass, (unsigned long long)s_red[2]);
-        if (s_red[3]) atomicAdd(&a.counters->n_patch, (unsigned long long)s_red[3]);
+        if (s_red[1]) { atomicAdd(&a.counters->n_eval, (unsigned long long)s_red[1]); atomicAdd(&a.counters->k_eval[MI_KIND_SPEC], (unsigned long long)s_red[1]); }
+        if (s_red[2]) { atomicAdd(&a.counters->n_pass, (unsigned long long)s_red[2]); atomicAdd(&a.counters->k_pass[MI_KIND_SPEC], (unsigned long long)s_red[2]); }
+        if (s_red[3]) { atomicAdd(&a.counters->n_patch, (unsigned long long)s_red[3]); atomicAdd(&a.counters->k_patch[MI_KIND_SPEC], (unsigned long long)s_red[3]); }
     }
 }
 
@@ -3505,8 +3518,9 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
     a.max_attempts = follow_out ? 1 : 4; a.follow_in = follow_in; a.follow_in_n = follow_in_n;
     a.follow_out = follow_out; a.follow_out_n = follow_out_n;
-    /* lanes_per_view: 1 = throughput layout, anything else = latency layout; st.K > 4: the eight-slot layouts */
-    const bool lat = lanes_per_view != 1, eight = st.K > 4;
+    /* lanes_per_view: 1 = throughput layout, 2 = throughput layout and the FAST kernel for a launch that CONTINUES a follow-up list
+     * (below), anything else = latency layout; st.K > 4: the eight-slot layouts */
+    const bool lat = lanes_per_view != 1 && lanes_per_view != 2, eight = st.K > 4;
     if (st.K > 8) {
         /* sixteen view slots: the general kernel of the throughput layout is all there is (Lay<1, 16>) -- the entries'
          * attempts in a row, or one each where the caller keeps follow-up lists or gives explicit hypotheses */
@@ -3520,11 +3534,13 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     }
     /* the first launch of a bulk round (one attempt per entry, a follow-up list for the rest) runs the FAST kernel: no
      * view selection code in it -- a patch that needs one goes to the follow-up launch, which is the general kernel */
-    const bool fast = !lat && follow_out != nullptr && follow_in == nullptr && hyp == nullptr;
+    /* (lanes_per_view 2: second attempts in the FAST kernel as well -- same arithmetic, a patch that needs a view selection is
+     * abandoned once more and goes on to the next list, which the general kernel takes) */
+    const bool fast = !lat && follow_out != nullptr && (follow_in == nullptr || lanes_per_view == 2) && hyp == nullptr && st.K <= 8;
     /* ... a launch that continues a follow-up list AND leaves one runs one attempt per entry as well, in the general kernel
      * (process_entry_single), and so do the seeds (one hypothesis each); only a propagation launch without a follow-up list
      * of its own runs an entry's attempts in a row */
-    const bool single = !lat && (hyp != nullptr || (follow_out != nullptr && follow_in != nullptr));
+    const bool single = !lat && !fast && (hyp != nullptr || (follow_out != nullptr && follow_in != nullptr));
     /* the throughput kernels with a view selection in them: its NCC table in dynamic shared memory (lds_ncc) */
     const unsigned ncc4 = (unsigned)(Lay<1, 4>::PATCHES * st.ncc_stride * sizeof(float)), ncc8 = (unsigned)(Lay<1, 8>::PATCHES * st.ncc_stride * sizeof(float));
     if (lat) {

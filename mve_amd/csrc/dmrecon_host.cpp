@@ -226,6 +226,7 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 #define MI_MERGE_WINDOW_US 1000
 #define MI_MERGE_WINDOW_BIG_US 3000 /* ... from this size on this long: ~2 % of such a call's own time (see mi_dmrecon_reconstruct) */
 #define MI_SINGLE_FOLLOW 4         /* follow-up launches of one attempt per entry in a large round (BatchRun::bulk_rounds) */
+#define MI_FAST_FOLLOW 0           /* of them, the first n in the FAST kernel (MI_DMRECON_FAST_FOLLOW) */
 #define MI_FOLLOW_LISTS 8          /* follow-up list counters per round (five in use: BatchRun::bulk_rounds) */
 #define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
 #define MI_SPEC_ROUNDS 400000u      /* throughput rounds below this many entries try an entry's candidate hypotheses at the same time */
@@ -448,6 +449,7 @@ struct SceneStore {
 struct mi_dmrecon_ctx {
     int device = 0;
     int n_cus = 64;                          /* compute units (queried at creation) */
+    double wall_clock_khz = 100000.0;        /* rate of the constant clock wall_clock64() reads (hipDeviceAttributeWallClockRate) */
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;           /* copies of finished views back to the host while the front kernel still runs */
     std::shared_ptr<SceneStore> sc;
@@ -1311,6 +1313,9 @@ static int create_streams(mi_dmrecon_ctx* c) {
     /* compute units of this device (a partitioned GPU has fewer than 256): what a front launch with teams may occupy */
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->n_cus = cus;
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
+    else (void)hipGetLastError();
     return 0;
 }
 
@@ -1580,7 +1585,7 @@ struct JobDyn { int32_t flags; uint32_t n_filled; uint32_t list; /* the view's l
 
 /* hipEvent pairs around the timed launches of a call, recorded on the stream the launch goes to */
 struct EventLog {
-    enum { BULK = 0, SWEEP = 1, TAIL = 2, FRONT = 3 };
+    enum { BULK = 0, SWEEP = 1, TAIL = 2, FRONT = 3, LAT = 4 /* a bulk launch in the latency layout */ };
     struct Item { size_t first; int kind; unsigned work; bool ok; };
     mi_dmrecon_ctx* c = nullptr;
     size_t n_ev = 0;
@@ -1933,6 +1938,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
      * of an entry in a row (round 4's form); n = 1 .. 3: n single-attempt follow-up launches, then one for the rest; 4: every
      * further attempt a launch of its own.  Same maps and counters. */
     const int SINGLE_FOLLOW = [] { const char* e = std::getenv("MI_DMRECON_SINGLE_FOLLOW"); return e ? std::atoi(e) : MI_SINGLE_FOLLOW; }();
+    const int FAST_FOLLOW = wide ? 0 : [] { const char* e = std::getenv("MI_DMRECON_FAST_FOLLOW"); return e ? std::max(0, std::min(3, std::atoi(e))) : MI_FAST_FOLLOW; }();
     if (SPEC_MAX > 0 && c->bs.d_spec.reserve(4 * (size_t)spec_cap)) return fail(MI_DMRECON_EDEVICE, "hipMalloc(speculative records) failed");
     /* The rounds are enqueued WITHOUT waiting for their list sizes: every kernel of a round reads its size on the device
      * (k_generate also decides there which layout a view's entries go to), the grids come from the sizes of the last round
@@ -2014,8 +2020,17 @@ int BatchRun::bulk_rounds(bool& to_tail) {
                  * third and fourth attempts are a few thousandths of the list) */
                 const int n_single = SINGLE_FOLLOW >= 4 ? 4 : std::max(1, SINGLE_FOLLOW);
                 for (int k = 0; k < n_single; ++k, div *= 4) {
-                    D->optimize(S, 1, std::max(64u, waves / div), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
+                    /* MI_DMRECON_FAST_FOLLOW=<n>: the first n follow-up launches run the FAST kernel too (second attempts rarely need a
+                     * view selection; the ones that do are abandoned again and go on to the next list) */
+                    D->optimize(S, k < FAST_FOLLOW ? 2 : 1, std::max(64u, waves / div), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
                                 c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[k], fcnt + k, fl[k + 1], fcnt + k + 1);
+                    ++n_launch;
+                }
+                if (n_single == 4 && FAST_FOLLOW > 0) {
+                    /* an entry abandoned by FAST launches can have attempts left after the four single-attempt launches: what the
+                     * last of them appended (to the first list's buffer, consumed long ago) runs its remaining attempts in a row */
+                    D->optimize(S, 1, 64u, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
+                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[4], fcnt + 4, nullptr, nullptr);
                     ++n_launch;
                 }
                 if (n_single < 4) {
@@ -2033,7 +2048,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         ++n_launch;
         if (any_lat) {
             /* the views that have handed over: one wavefront per patch, an entry's attempts one after the other */
-            ev.begin(S, EventLog::BULK, 0);
+            ev.begin(S, EventLog::LAT, 0);
             ev_lat = ev.items.size() - 1;
             /* (the latency list can jump from nothing to a few hundred entries per view in one round, when the views of a batch
              * hand over together: a grid sized from the last list the host has seen would leave a thousand wavefronts striding
@@ -2479,6 +2494,17 @@ int BatchRun::front_rounds() {
              * enqueued behind the kernel before this loop: a strided or pageable read-back holds the host in its call.) */
             HIP_TRY(hipEventRecord(c->bs.poll_ev[0], S));
             if (sparse && !again) if (int rc = snapshot_views()) return rc;
+            /* test hook, MI_DMRECON_DEBUG_FRONT_EFOOTPRINT=<reference view id>: that view fails DURING the front phase (its footprint
+             * flag is raised behind the snapshot copies; the front kernel looks at the flags every few rounds) -- the one way to see
+             * what mi_dmrecon.h says about the buffers of a view that ends with an error after the snapshot was taken */
+            if (const char* e = std::getenv("MI_DMRECON_DEBUG_FRONT_EFOOTPRINT")) if (*e && !again && sparse) {
+                const int want = std::atoi(e);
+                for (int j = 0; j < nj; ++j) if (jobs[j].ref_view == want) {
+                    c->bs.h_jobdyn[2 * j] = (int32_t)MI_JOB_EFOOTPRINT;      /* (stays valid: the stream is synchronised before the call ends) */
+                    HIP_TRY(hipMemcpyAsync((char*)(c->bs.d_jobs.p + j) + offsetof(DevJob, flags), &c->bs.h_jobdyn[2 * j], sizeof(int32_t),
+                                           hipMemcpyHostToDevice, c->stream2));
+                }
+            }
             for (;;) {
                 const bool over = hipEventQuery(c->bs.poll_ev[0]) != hipErrorNotReady;
                 for (int j = 0; j < nj; ++j)
@@ -2675,6 +2701,13 @@ void BatchRun::fill_stats() {
         stats->n_seeds = (int64_t)n_seed_feats; stats->n_seeds_ok = (int64_t)hc.n_seeds_ok;
         stats->n_rounds = round; stats->n_launches = n_launch; stats->truncated = truncated ? 1 : 0;
         stats->n_view_replaced = (int64_t)hc.n_view_replaced; stats->n_iter14 = (int64_t)hc.n_iter14;
+        for (int k = 0; k < 8; ++k) {
+            stats->n_eval_by_kernel[k] = (int64_t)hc.k_eval[k]; stats->n_pass_by_kernel[k] = (int64_t)hc.k_pass[k];
+            stats->n_patch_by_kernel[k] = (int64_t)hc.k_patch[k]; stats->n_pass_executed_by_kernel[k] = (int64_t)hc.k_pass_exec[k];
+        }
+        stats->clk_shader_cycles = (int64_t)hc.clk_shader; stats->clk_real_ticks = (int64_t)hc.clk_real;
+        stats->clk_real_mhz = c->wall_clock_khz * 1e-3;
+        stats->shader_clock_mhz = hc.clk_real ? (double)hc.clk_shader / (double)hc.clk_real * stats->clk_real_mhz : 0.0;
         double tail_ms = 0.0; int64_t tail_timed = 0;
         for (const EventLog::Item& it : ev.items) {
             float ms = 0.f;
@@ -2682,6 +2715,7 @@ void BatchRun::fill_stats() {
             switch (it.kind) {
                 case EventLog::SWEEP: stats->ms_sweep_kernels += ms; break;
                 case EventLog::BULK: stats->ms_bulk_kernel += ms; if (it.work) ++stats->n_bulk_launches; break;   /* (empty launches of blind rounds: their microseconds count, they do not) */
+                case EventLog::LAT: stats->ms_bulk_kernel += ms; stats->ms_latency_rounds += ms; stats->n_latency_entries += it.work; if (it.work) ++stats->n_bulk_launches; break;
                 case EventLog::TAIL: if (it.work > 0) { tail_ms += ms; ++tail_timed; } break;
                 case EventLog::FRONT: stats->ms_front_kernel += ms; break;
             }

@@ -160,6 +160,15 @@ struct DevCounters {
     unsigned long long n_iter14;        /* ... of which only because they were still moving at iteration 14 */
     unsigned int error_flags;  /* bit0: non-positive master footprint (patch_sampler.cc:78-82) */
     unsigned int pad;
+    /* The same work counts per KERNEL TEMPLATE (mi_dmrecon_stats::n_eval_by_kernel ...; MI_KIND_*): evaluations / passes / patches as
+     * counted for n_eval / n_pass / n_patch (speculative forms: the attempts the reference's rule consumes), and the passes a
+     * template EXECUTED (the attempts a speculative form runs and discards included) -- what a profile's per-kernel time is
+     * divided by. */
+    unsigned long long k_eval[8], k_pass[8], k_patch[8], k_pass_exec[8];
+    /* shader clock while the patch kernels run: every 1024th wavefront of a k_optimize launch adds the shader cycles
+     * (s_memtime) and the constant-rate ticks (s_memrealtime) of its own life: their ratio is the clock the kernels ran at */
+    unsigned long long clk_shader, clk_real;
 };
+enum { MI_KIND_FAST = 0, MI_KIND_FOLLOW = 1, MI_KIND_SEED = 2, MI_KIND_LOOP = 3, MI_KIND_SPEC = 4, MI_KIND_LAT = 5, MI_KIND_TAIL = 6, MI_KIND_FRONT = 7 };
 
 #endif

@@ -93,7 +93,9 @@ def test_ctypes_mirrors_match_the_header_field_for_field():
             arr = re.match(r"(\w+)\[(\d+)\]", ct)
             expect = C[arr.group(1)] * int(arr.group(2)) if arr else C[ct]
             assert ctypes.sizeof(gt) == ctypes.sizeof(expect) and gt._type_ == expect._type_, (cname, f)
-    assert ctypes.sizeof(api.CStats) == 8 * len(api.CStats._fields_)
+    # every field of the statistics is 8 bytes wide, or an array of such (the per-kernel-template counts): no padding anywhere
+    assert ctypes.sizeof(api.CStats) == sum(ctypes.sizeof(t) for _, t in api.CStats._fields_)
+    assert all(ctypes.sizeof(t) % 8 == 0 for _, t in api.CStats._fields_)
 
 
 def test_settings_defaults_match_reference():

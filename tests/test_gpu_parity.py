@@ -262,6 +262,42 @@ def test_sparse_maps_equal_full_copies(gpu_ctx, g1_scene, h1_scene, monkeypatch)
     monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER")
 
 
+def test_a_view_that_fails_in_the_front_phase_on_the_sparse_path(gpu_ctx, g1_scene, monkeypatch):
+    """mi_dmrecon.h: the maps of a view that does not finish stay untouched -- except in a large batch (the snapshot + changed
+    pixels path), where a view that ends with an error AFTER the hand-over has had the snapshot written: its status says the
+    maps are void, and the other views of the batch are what they are without the failure.  Test hook
+    MI_DMRECON_DEBUG_FRONT_EFOOTPRINT: the view's footprint flag is raised behind the snapshot copies."""
+    st = api.Settings()
+    gpu_ctx.load_scene(g1_scene)
+    monkeypatch.setenv("MI_DMRECON_VIEW_HANDOVER", "40")
+    monkeypatch.setenv("MI_DMRECON_SPARSE_MAPS", "1")
+    refs = [0, 1, 2, 3, 4]
+    clean = gpu_ctx.reconstruct(st, refs, want_normal=False)
+    assert gpu_ctx.last_stats["n_sparse_records"] > 5 and all(m["status"] == 0 for m in clean)
+    monkeypatch.setenv("MI_DMRECON_DEBUG_FRONT_EFOOTPRINT", "2")
+    out = gpu_ctx.alloc_outputs(st, refs, want_normal=False)
+    for m in out:
+        m["depth"][:] = -7.0                                   # a canary: what "untouched" would look like
+    got = gpu_ctx.reconstruct(st, refs, want_normal=False, out=out)
+    monkeypatch.delenv("MI_DMRECON_DEBUG_FRONT_EFOOTPRINT")
+    assert [m["status"] for m in got] == [0, 0, api.E_FOOTPRINT, 0, 0]
+    for i in (0, 1, 3, 4):
+        for k in ("depth", "conf", "dz"):
+            assert np.array_equal(got[i][k], clean[i][k]), (i, k)
+    # the failed view: documented as void; what it holds is the state at the hand-over (no canary left, no pixel of a later round
+    # is required) -- with the strict form (MI_DMRECON_SPARSE_MAPS=0) it is untouched
+    assert not np.any(got[2]["depth"] == -7.0)
+    monkeypatch.setenv("MI_DMRECON_SPARSE_MAPS", "0")
+    monkeypatch.setenv("MI_DMRECON_DEBUG_FRONT_EFOOTPRINT", "2")       # (no snapshot: the hook has nothing to stand behind and is not reached)
+    for m in out:
+        m["depth"][:] = -7.0
+    got = gpu_ctx.reconstruct(st, refs, want_normal=False, out=out)
+    assert all(m["status"] == 0 for m in got)
+    monkeypatch.delenv("MI_DMRECON_DEBUG_FRONT_EFOOTPRINT")
+    monkeypatch.delenv("MI_DMRECON_SPARSE_MAPS")
+    monkeypatch.delenv("MI_DMRECON_VIEW_HANDOVER")
+
+
 @pytest.mark.parametrize("per_view,team", [("all", "1"), ("1000000", "1"), ("2", "1"), (None, None),
                                            ("all", "8"), ("all", "3"), ("1000000", "25"), ("2", "2")])
 def test_front_kernel_equals_one_launch_per_round(gpu_ctx, g1_scene, h1_scene, monkeypatch, per_view, team):
