@@ -463,6 +463,9 @@ def roofline(acc, n_maps, scene, cfg, n_streams, spc, elapsed):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "per_kernel_template": by_template,
+            # the shader clock the k_optimize launches of this run ran at (mi_dmrecon_stats::clk_*: shader cycles over constant-rate
+            # ticks of every 1024th wavefront's life, summed over the timed calls) -- the data sheet says 2400 MHz
+            "shader_clock_mhz_measured": measured_shader_clock(acc),
             # host-visible rounds in the latency layout (views that have handed over while others of their batch have not): part of
             # the bulk kernels' time
             "latency_layout_rounds": {"ms_per_step": acc.get("ms_latency_rounds", 0.0) / steps_rank, "entries_per_step": acc.get("n_latency_entries", 0) / steps_rank,
@@ -523,6 +526,14 @@ def predicted_strong_scaling(n_views):
     return None
 
 
+def measured_shader_clock(acc):
+    """MHz, or None: the summed shader cycles over the summed constant-rate ticks x the rate of the constant clock (a per-call
+    constant that the sums carry once per call that sampled it: _calls)."""
+    if not acc.get("clk_real_ticks"):
+        return None
+    return acc["clk_shader_cycles"] / acc["clk_real_ticks"] * (acc.get("clk_real_mhz", 0.0) / max(acc.get("_calls", 1), 1))
+
+
 def valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps, lone=False):
     """The ceiling the bulk kernel is actually under (its wavefronts are limited by how fast a SIMD
     issues their VALU instructions, not by memory): the VALU wave-instructions it EXECUTES -- a stored SQ_INSTS_VALU
@@ -542,8 +553,7 @@ def valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps, lone=False):
     alg = ALGORITHMIC_VALU_PER_SAMPLE * 25.0 * passes_bulk / 64.0
     # the shader clock the kernels actually ran at (mi_dmrecon_stats::clk_*: shader cycles over constant-rate ticks, sampled
     # inside the k_optimize launches of THIS run): the roof above is priced at the data sheet's 2.4 GHz
-    clk = (acc["clk_shader_cycles"] / acc["clk_real_ticks"] * (acc.get("clk_real_mhz", 0.0) / max(acc.get("_calls", 1), 1))
-           if acc.get("clk_real_ticks") else None)
+    clk = measured_shader_clock(acc)
     measured = None
     if clk:
         rate_m = N_SIMDS * clk * 1e6 / CYCLES_PER_VALU_INST

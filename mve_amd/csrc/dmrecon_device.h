@@ -13,8 +13,9 @@
  * optimize -- lanes_per_view: 1 = 16 patches per wavefront (throughput), 16 = one patch per wavefront (latency).
  *   The launch only acts if min_work <= n < max_work, n = *n_work_ptr (if given) or n_work.
  *   follow_out != null: one optimisation attempt per entry; entries with further candidate hypotheses are appended to
- *   follow_out (count *follow_out_n).  follow_in != null: continue the entries work[follow_in[0 .. *follow_in_n)] -- with
- *   ONE more attempt each if the launch has a follow_out of its own, else with all the attempts they have left.
+ *   follow_out.  follow_in != null: continue the entries work[follow_in[..]] -- with ONE more attempt each if the launch has a
+ *   follow_out of its own, else with all the attempts they have left.  A follow-up list is MI_FOLLOW_SEGS segments of follow_seg
+ *   entries, one per XCD (workgroups b with equal b % 8), each with its own counter follow_*_n[segment] (OptArgs::follow_seg).
  * generate -- k_generate scans MI_GEN_TILE_W x MI_GEN_TILE_H pixel tiles; max_tiles = max over the jobs of their tile count.
  *   A view's entries go to `work` (count round_work[round]) while the view is in the throughput layout, to `work_lat`
  *   (round_work_lat[round]) once it has handed over: for good, from the round after the first one in which the VIEW's
@@ -40,6 +41,7 @@
  *   | list buffer, or >= MI_FRONT_DONE_HOST for a view that ran to its end.  A second launch with job_start = that array
  *   (no dealing out, the views start where it says) and team = 1 finishes them; same maps either way.
  */
+#define MI_FOLLOW_SEGS 8            /* segments of a follow-up list = XCDs (MI_XCDS of dmrecon_device.hip) */
 #define MI_FRONT_DONE_HOST 0xFFFFFFFF00000000ull
 #define MI_FRONT_TEAM_MAX 32
 #define MI_FRONT_FLAG_STRIDE 40     /* team_flags words per view: MI_FRONT_TEAM_MAX pass flags, the XCC registration word, "several XCDs" */
@@ -50,7 +52,7 @@ struct MiDeviceApi {
                      const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                      DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                      unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                     const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n);
+                     const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, unsigned follow_seg);
     void (*patch_eval)(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                        const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
                        float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);

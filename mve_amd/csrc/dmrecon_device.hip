@@ -1785,6 +1785,13 @@ struct OptArgs {
     const unsigned* follow_in_n;
     unsigned* follow_out;         /* entries that still have untried candidates after this launch */
     unsigned* follow_out_n;
+    /* A follow-up list is MI_XCDS SEGMENTS of follow_seg entries, each with a counter of its own (follow_*_n[segment]): the
+     * workgroups b with equal b % MI_XCDS -- one XCD's, XcdRange -- append to their segment and, in the next launch, continue
+     * it.  The first launch walks XCD x through the x-th eighth of the round's list (ordered by reference view and image tile);
+     * its segment then holds entries of that eighth only, in roughly the order of the list -- where ONE list appended to by all
+     * XCDs interleaved the eight ranges and mixed the views: the second attempts then ran 1.7 x slower per sampling pass than
+     * the first ones (L2 hits 63 % against 85 %; profiles/r6_ab_experiments.txt). */
+    unsigned follow_seg;
 };
 
 /*
@@ -2007,10 +2014,11 @@ __device__ __forceinline__ void process_entry_single(const OptArgs& a, unsigned 
 #endif
 struct XcdRange {
     unsigned per_x, base, j, jn;
-    __device__ __forceinline__ explicit XcdRange(unsigned n_units) {
+    /* own_segment: n_units are the units of THIS XCD's own list (a follow-up segment), not of a list shared by all */
+    __device__ __forceinline__ explicit XcdRange(unsigned n_units, bool own_segment = false) {
         const unsigned nx = (gridDim.x % MI_XCDS == 0 && gridDim.x >= MI_XCDS) ? MI_XCDS : 1u;   /* (a grid that is no multiple: block order) */
-        per_x = (n_units + nx - 1) / nx;
-        base = (blockIdx.x % nx) * per_x; j = blockIdx.x / nx; jn = gridDim.x / nx;
+        per_x = own_segment ? n_units : (n_units + nx - 1) / nx;
+        base = own_segment ? 0u : (blockIdx.x % nx) * per_x; j = blockIdx.x / nx; jn = gridDim.x / nx;
     }
     __device__ __forceinline__ bool next(unsigned& unit) {
         if (j >= per_x) return false;
@@ -2052,8 +2060,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
     static_assert(SINGLE || !FAST, "the FAST kernel runs one attempt per entry");
     static_assert(!SEED || (SINGLE && !FAST), "the seed launch is the single-attempt form of the general kernel");
     const int lane = threadIdx.x;
-    const unsigned n = a.follow_in ? *a.follow_in_n : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
-    if (n < a.min_work || n >= a.max_work) return;
+    /* (follow-up lists: the segment of this workgroup's XCD, see OptArgs::follow_seg) */
+    const unsigned seg_n = (a.follow_seg != 0u && gridDim.x % MI_XCDS == 0 && gridDim.x >= MI_XCDS) ? MI_XCDS : 1u, seg = blockIdx.x % seg_n;   /* (follow_seg 0: one list for all) */
+    const unsigned n = a.follow_in ? a.follow_in_n[seg] : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
+    if (!a.follow_in && (n < a.min_work || n >= a.max_work)) return;
     for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
 #ifdef MI_ACTIVITY
     if (lane < 2) g_act[lane] = 0;
@@ -2064,10 +2074,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
     const unsigned long long clk_s0 = clk_probe ? (unsigned long long)clock64() : 0ull, clk_r0 = clk_probe ? (unsigned long long)wall_clock64() : 0ull;
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
     unsigned unit;
-    for (XcdRange xr((n + L::PATCHES - 1) / L::PATCHES); xr.next(unit); ) {
+    const unsigned* const fin = a.follow_in ? a.follow_in + (size_t)seg * a.follow_seg : nullptr;
+    for (XcdRange xr((n + L::PATCHES - 1) / L::PATCHES, a.follow_in != nullptr && seg_n > 1u); xr.next(unit); ) {
         const unsigned i = unit * L::PATCHES + L::patch(lane);
         const bool live = i < n;                             /* (the last wavefront of the list: lanes without an entry idle) */
-        const unsigned e = !live ? 0u : (a.follow_in ? a.follow_in[i] : i);
+        const unsigned e = !live ? 0u : (fin ? fin[i] : i);
         bool more = false;
         if (live) {
         const DevEntry ent = a.work[e];
@@ -2087,9 +2098,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
             if (m) {
                 const int leader = __ffsll((long long)__ballot(true)) - 1;
                 unsigned base = 0;
-                if (lane == leader) base = atomicAdd(a.follow_out_n, (unsigned)__popcll(m));
+                if (lane == leader) base = atomicAdd(a.follow_out_n + seg, (unsigned)__popcll(m));
                 base = (unsigned)__shfl((int)base, leader);
-                if (mine) a.follow_out[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = e;
+                if (mine) a.follow_out[(size_t)seg * a.follow_seg + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = e;
             }
         }
     }
@@ -3509,10 +3520,11 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n) {
+                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, unsigned follow_seg) {
     if (grid_blocks == 0) return;
     grid_blocks = (grid_blocks + MI_XCDS - 1) / MI_XCDS * MI_XCDS;      /* (XcdRange: every XCD the same number of workgroups) */
     OptArgs a;
+    a.follow_seg = follow_seg;
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
     a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
@@ -3573,7 +3585,7 @@ static void launch_optimize_spec(hipStream_t s, unsigned grid_blocks, const DevJ
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = nullptr;
     t.o.n_work_ptr = n_work_ptr; t.o.n_work = n_work; t.o.min_work = min_work; t.o.max_work = max_work; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.max_attempts = 1; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
+    t.o.max_attempts = 1; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0;
     t.spec = spec; t.items = items; t.n_items = n_items;
     if (st.K > 4) hipLaunchKernelGGL((k_optimize_spec<Lay<1, 8> >), dim3(grid_blocks), dim3(WAVE), (unsigned)(Lay<1, 8>::PATCHES * st.ncc_stride * sizeof(float)), s, t);
     else hipLaunchKernelGGL((k_optimize_spec<Lay<1, 4> >), dim3(grid_blocks), dim3(WAVE), (unsigned)(Lay<1, 4>::PATCHES * st.ncc_stride * sizeof(float)), s, t);
@@ -3629,7 +3641,7 @@ static void launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs,
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
+    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
     if (st.K > 4) {
         if (speculative) hipLaunchKernelGGL((k_tail<true, 8>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
@@ -3659,7 +3671,7 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = nullptr; t.o.hyp = nullptr; t.o.results = nullptr;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = first_round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr;
+    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0;
     t.work[0] = work0; t.work[1] = work1; t.results[0] = results0; t.results[1] = results1;
     t.job_off = job_off; t.job_count = job_count; t.job_start = job_start; t.job_resume = job_resume;
     t.job_stats = job_stats; t.max_rounds = max_rounds;

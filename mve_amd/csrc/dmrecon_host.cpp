@@ -227,7 +227,7 @@ std::atomic<int> g_inject_footprint(-1);     /* test hook, see fill_job */
 #define MI_MERGE_WINDOW_BIG_US 3000 /* ... from this size on this long: ~2 % of such a call's own time (see mi_dmrecon_reconstruct) */
 #define MI_SINGLE_FOLLOW 4         /* follow-up launches of one attempt per entry in a large round (BatchRun::bulk_rounds) */
 #define MI_FAST_FOLLOW 0           /* of them, the first n in the FAST kernel (MI_DMRECON_FAST_FOLLOW) */
-#define MI_FOLLOW_LISTS 8          /* follow-up list counters per round (five in use: BatchRun::bulk_rounds) */
+#define MI_FOLLOW_LISTS 64         /* follow-up list counters per round: five lists x MI_FOLLOW_SEGS segments in use (BatchRun::bulk_rounds) */
 #define MI_ONE_LAUNCH_MAX 100000u  /* host-visible rounds below this many entries: one launch instead of first + follow-up */
 #define MI_SPEC_ROUNDS 400000u      /* throughput rounds below this many entries try an entry's candidate hypotheses at the same time */
 #define MI_VIEW_HANDOVER 320u      /* a view leaves the throughput layout once a round's list of its own is shorter than this */
@@ -360,13 +360,13 @@ struct BatchScratch {
     /* the buffers whose size goes with the pixels of a batch (imaps: 4 words per pixel, 6 with eight view slots) */
     int reserve_pixels(size_t px, size_t n_imaps) {
         return d_maps.reserve(px * 14) || d_imaps.reserve(px * n_imaps) || d_work.reserve(px) || d_work2.reserve(px)
-            || d_results.reserve(px) || d_results2.reserve(px) || d_keys.reserve(px) || d_follow.reserve(4 * px);
+            || d_results.reserve(px) || d_results2.reserve(px) || d_keys.reserve(px) || d_follow.reserve(4 * px + 4096);
     }
     /* room for a batch of `px` pixels: all pixel-proportional buffers together, so that a set is either large enough or
      * grows once */
     int ensure_pixels(size_t px, size_t n_imaps) {
         if (d_maps.cap >= px * 14 && d_imaps.cap >= px * n_imaps && d_work.cap >= px && d_work2.cap >= px && d_results.cap >= px
-            && d_results2.cap >= px && d_keys.cap >= px && d_follow.cap >= 4 * px)
+            && d_results2.cap >= px && d_keys.cap >= px && d_follow.cap >= 4 * px + 4096)
             return 0;
         return reserve_pixels(px, n_imaps);                           /* (DevBuf::reserve adds the headroom) */
     }
@@ -1707,14 +1707,37 @@ int BatchRun::plan() {
             }
         }
     }
+    /* A reference view that is listed several times in one call (a merged batch whose callers ask for the same views; a
+     * caller that reconstructs a scene's views repeatedly) is planned ONCE: its global view set and its seeds are functions of
+     * the scene, the view and the settings alone (dmrecon.cc:178-331 reads nothing else), so the later entries copy the first
+     * one's plan (same_as[i]: the first entry with this view, i itself for that one). */
+    std::vector<int> same_as((size_t)n_refs);
+    {
+        std::unordered_map<int32_t, int> first;
+        for (int i = 0; i < n_refs; ++i) same_as[i] = first.emplace(ref_views[i], i).first->second;
+    }
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
     for (int i = 0; i < n_refs; ++i) {
-        if (gvs_done || view_rc[i]) continue;
+        if (gvs_done || view_rc[i] || same_as[i] != i) continue;
         plans[i].ref_view = ref_views[i];
         int r = plan_global_views(c, st, ref_views[i], plans[i].global);
         if (r == 0 && plans[i].global.empty()) r = fail(MI_DMRECON_EGVS, "Global View Selection failed");
         view_rc[i] = r;
         if (r) plan_err[i] = g_err;
+    }
+    for (int i = 0; i < n_refs && !gvs_done; ++i) {
+        const int k = same_as[i];
+        if (k == i || view_rc[i]) continue;                     /* (cancelled before it began: stays cancelled) */
+        plans[i].ref_view = ref_views[i];
+        if (view_rc[k] == MI_DMRECON_ECANCELLED) {              /* the first entry was cancelled, this one is not: its own selection */
+            int r = plan_global_views(c, st, ref_views[i], plans[i].global);
+            if (r == 0 && plans[i].global.empty()) r = fail(MI_DMRECON_EGVS, "Global View Selection failed");
+            view_rc[i] = r;
+            if (r) plan_err[i] = g_err;
+            same_as[i] = i;
+            continue;
+        }
+        plans[i].global = plans[k].global; view_rc[i] = view_rc[k]; plan_err[i] = plan_err[k];
     }
     /* a selected view that was registered without pixels (mi_dmrecon_set_view with a null image: its image could not be loaded
      * by the caller): the reference fails here, when it loads the selected views (dmrecon.cc:236-240) */
@@ -1747,8 +1770,21 @@ int BatchRun::plan() {
         return fail(MI_DMRECON_ECANCELLED, "cancelled");
     }
     for (int i = 0; progress && i < n_refs; ++i) if (view_rc[i] == 0) progress[i].status = MI_RECON_FEATURES;
+    /* (seeds: once per distinct reference view of the call, as above -- a copy only differs in the job its entries name) */
+    std::vector<int> job_same((size_t)jobs.size());
+    for (int j = 0; j < (int)jobs.size(); ++j) {
+        const int k = same_as[ref_of_job[j]];
+        job_same[j] = (k != ref_of_job[j] && job_of[k] >= 0 && job_of[k] < j) ? job_of[k] : j;
+    }
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
-    for (int j = 0; j < (int)jobs.size(); ++j) plan_seeds(c, st, jobs[j], j);
+    for (int j = 0; j < (int)jobs.size(); ++j) if (job_same[j] == j) plan_seeds(c, st, jobs[j], j);
+#pragma omp parallel for schedule(static) num_threads(n_threads) if (jobs.size() >= 64)
+    for (int j = 0; j < (int)jobs.size(); ++j) {
+        const int k = job_same[j];
+        if (k == j) continue;
+        jobs[j].seeds = jobs[k].seeds; jobs[j].seed_hyp = jobs[k].seed_hyp; jobs[j].n_seeds = jobs[k].n_seeds;
+        for (DevEntry& e : jobs[j].seeds) e.job = j;
+    }
     mark("seed planning");
     if (stats) stats->ms_plan_seeds = now_ms() - t_gvs_done;
     return 0;
@@ -1879,7 +1915,7 @@ int BatchRun::seed_round() {
     sds.seed_reopt = seed_mode == 2 ? 1 : 0;
     D->optimize(S, 1, ((unsigned)n_seeds_total + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p,
                 c->sc->d_lut, sds, c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n_seeds_total, 0u, 0xFFFFFFFFu, 0,
-                c->d_counters, nullptr, nullptr, nullptr, nullptr);
+                c->d_counters, nullptr, nullptr, nullptr, nullptr, 0u);
     ev.end(S);
     ++n_launch;
     ev.begin(S, EventLog::SWEEP, 0);
@@ -1998,14 +2034,23 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         if (!need_plain) { }
         else if (known_thr < ONE_LAUNCH_MAX)
             D->optimize(S, 1, spec ? std::max(1u, waves / 2) : waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
-                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr);
+                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr, 0u);
         else {
             /* one optimisation attempt per entry and launch; the entries whose pixel has further candidate hypotheses
              * (about one in five) continue in a follow-up launch over a compacted list (its size stays on the device),
              * so that the wavefronts of both launches are full; the follow-up launch runs all remaining attempts of its
              * entries back to back (third and fourth attempts are rare) */
+            /* the follow-up lists: four buffers (the last launch appends to the first one's, consumed by then), each of
+             * MI_FOLLOW_SEGS segments -- one per XCD, with a counter of its own (OptArgs::follow_seg) -- of an eighth of the
+             * batch's pixels (+ slack: an XCD's eighth of a list is rounded up to whole wavefronts) */
+            /* (MI_DMRECON_FOLLOW_SEGMENTS=0, read per call: one list for all XCDs, as until round 6 -- the A/B switch; same maps) */
+            const bool segs = [] { const char* e = std::getenv("MI_DMRECON_FOLLOW_SEGMENTS"); return !e || std::atoi(e) != 0; }();
+            const unsigned fseg_full = (unsigned)((total_px + MI_FOLLOW_SEGS - 1) / MI_FOLLOW_SEGS) + 64u;
+            const unsigned fseg = segs ? fseg_full : 0u;
+            const size_t fstride = (size_t)fseg_full * MI_FOLLOW_SEGS;
+            unsigned* fl[5] = {c->bs.d_follow.p, c->bs.d_follow.p + fstride, c->bs.d_follow.p + 2 * fstride, c->bs.d_follow.p + 3 * fstride, c->bs.d_follow.p};
             D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
-                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, c->bs.d_follow.p, fcnt);
+                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, fl[0], fcnt, fseg);
             if (SINGLE_FOLLOW) {
                 /* every further attempt as a launch of its own over the entries the reference's rule still asks one of (about
                  * a fifth, a thirtieth, ... of the list), again ONE attempt per entry: no chain of attempts is live across an
@@ -2013,7 +2058,6 @@ int BatchRun::bulk_rounds(bool& to_tail) {
                  * An entry has at most four candidates, and its first attempt may have been abandoned by the FAST kernel:
                  * four follow-up launches (d_follow holds four lists of a round's entries: BatchScratch::reserve_pixels; the
                  * last launch's own list stays empty) */
-                unsigned* fl[5] = {c->bs.d_follow.p, c->bs.d_follow.p + total_px, c->bs.d_follow.p + 2 * total_px, c->bs.d_follow.p + 3 * total_px, c->bs.d_follow.p};
                 unsigned div = 4;
                 /* (MI_DMRECON_SINGLE_FOLLOW=<n>, 1 <= n < 4: n single-attempt follow-up launches, then ONE launch that runs what
                  * is left of its entries' attempts in a row -- a launch lasts a wavefront-life however few entries it has, and the
@@ -2023,24 +2067,24 @@ int BatchRun::bulk_rounds(bool& to_tail) {
                     /* MI_DMRECON_FAST_FOLLOW=<n>: the first n follow-up launches run the FAST kernel too (second attempts rarely need a
                      * view selection; the ones that do are abandoned again and go on to the next list) */
                     D->optimize(S, k < FAST_FOLLOW ? 2 : 1, std::max(64u, waves / div), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[k], fcnt + k, fl[k + 1], fcnt + k + 1);
+                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[k], fcnt + MI_FOLLOW_SEGS * k, fl[k + 1], fcnt + MI_FOLLOW_SEGS * (k + 1), fseg);
                     ++n_launch;
                 }
                 if (n_single == 4 && FAST_FOLLOW > 0) {
                     /* an entry abandoned by FAST launches can have attempts left after the four single-attempt launches: what the
                      * last of them appended (to the first list's buffer, consumed long ago) runs its remaining attempts in a row */
                     D->optimize(S, 1, 64u, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[4], fcnt + 4, nullptr, nullptr);
+                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[4], fcnt + MI_FOLLOW_SEGS * 4, nullptr, nullptr, fseg);
                     ++n_launch;
                 }
                 if (n_single < 4) {
                     D->optimize(S, 1, std::max(64u, waves / div), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[n_single], fcnt + n_single, nullptr, nullptr);
+                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[n_single], fcnt + MI_FOLLOW_SEGS * n_single, nullptr, nullptr, fseg);
                     ++n_launch;
                 }
             } else {
                 D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                            c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, c->bs.d_follow.p, fcnt, nullptr, nullptr);
+                            c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[0], fcnt, nullptr, nullptr, fseg);
                 ++n_launch;
             }
         }
@@ -2055,7 +2099,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
              * over it -- measured: 8 ms for such a round in a 200-view batch.  Wavefronts without an entry end at once.) */
             const unsigned lat_grid = std::min(std::max(std::max(4u * known_lat, (unsigned)nj * std::min(handover, 1024u)), 4096u), 32768u);
             D->optimize(S, 16, lat_grid, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work2.p,
-                        nullptr, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr);
+                        nullptr, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr, 0u);
             ev.end(S);
             ++n_launch;
         }
@@ -3106,7 +3150,7 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
     const unsigned ppw = lpv == 16 ? 1u : patches_per_wave(st);
     D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st),
                c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
-               nullptr, nullptr, nullptr, nullptr);
+               nullptr, nullptr, nullptr, nullptr, 0u);
     HIP_TRY(hipGetLastError());
     std::vector<DevResult> res(n); std::vector<uint32_t> resx(2 * (size_t)n, 0xFFFFFFFFu);
     HIP_TRY(hipMemcpyAsync(res.data(), c->bs.d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));
