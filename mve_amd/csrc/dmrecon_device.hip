@@ -35,6 +35,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "dmrecon_types.h"
 #include "dmrecon_device.h"
@@ -1792,6 +1793,9 @@ struct OptArgs {
      * XCDs interleaved the eight ranges and mixed the views: the second attempts then ran 1.7 x slower per sampling pass than
      * the first ones (L2 hits 63 % against 85 %; profiles/r6_ab_experiments.txt). */
     unsigned follow_seg;
+    unsigned scramble;            /* experiment (MI_DMRECON_DEBUG_SCRAMBLE, first attempts only): 1 = the entries of a list are dealt to the
+                                   * wavefronts in a scrambled order (a wavefront's 16 patches are no neighbours any more), 2 = whole
+                                   * wavefront units in a scrambled order (neighbours within a wavefront, strangers across); same maps */
 };
 
 /*
@@ -2078,7 +2082,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
     for (XcdRange xr((n + L::PATCHES - 1) / L::PATCHES, a.follow_in != nullptr && seg_n > 1u); xr.next(unit); ) {
         const unsigned i = unit * L::PATCHES + L::patch(lane);
         const bool live = i < n;                             /* (the last wavefront of the list: lanes without an entry idle) */
-        const unsigned e = !live ? 0u : (fin ? fin[i] : i);
+        unsigned e = !live ? 0u : (fin ? fin[i] : i);
+        if (a.scramble && !fin && live) {
+            /* (a bijection of [0, n) resp. of the full units: multiplication by a prime modulo the size) */
+            const unsigned n_full = n / L::PATCHES;
+            if (a.scramble == 1u) e = (unsigned)(((unsigned long long)i * 1000003ull) % n);
+            else if (unit < n_full) e = (unsigned)(((unsigned long long)unit * 1000003ull) % n_full) * L::PATCHES + L::patch(lane);
+        }
         bool more = false;
         if (live) {
         const DevEntry ent = a.work[e];
@@ -3525,6 +3535,7 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
     grid_blocks = (grid_blocks + MI_XCDS - 1) / MI_XCDS * MI_XCDS;      /* (XcdRange: every XCD the same number of workgroups) */
     OptArgs a;
     a.follow_seg = follow_seg;
+    { const char* e = getenv("MI_DMRECON_DEBUG_SCRAMBLE"); a.scramble = (e && follow_in == nullptr && hyp == nullptr) ? (unsigned)atoi(e) : 0u; }
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
     a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
@@ -3585,7 +3596,7 @@ static void launch_optimize_spec(hipStream_t s, unsigned grid_blocks, const DevJ
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = nullptr;
     t.o.n_work_ptr = n_work_ptr; t.o.n_work = n_work; t.o.min_work = min_work; t.o.max_work = max_work; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.max_attempts = 1; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0;
+    t.o.max_attempts = 1; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0; t.o.scramble = 0;
     t.spec = spec; t.items = items; t.n_items = n_items;
     if (st.K > 4) hipLaunchKernelGGL((k_optimize_spec<Lay<1, 8> >), dim3(grid_blocks), dim3(WAVE), (unsigned)(Lay<1, 8>::PATCHES * st.ncc_stride * sizeof(float)), s, t);
     else hipLaunchKernelGGL((k_optimize_spec<Lay<1, 4> >), dim3(grid_blocks), dim3(WAVE), (unsigned)(Lay<1, 4>::PATCHES * st.ncc_stride * sizeof(float)), s, t);
@@ -3641,7 +3652,7 @@ static void launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs,
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0;
+    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0; t.o.scramble = 0;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
     if (st.K > 4) {
         if (speculative) hipLaunchKernelGGL((k_tail<true, 8>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
@@ -3671,7 +3682,7 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = nullptr; t.o.hyp = nullptr; t.o.results = nullptr;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = first_round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0;
+    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0; t.o.scramble = 0;
     t.work[0] = work0; t.work[1] = work1; t.results[0] = results0; t.results[1] = results1;
     t.job_off = job_off; t.job_count = job_count; t.job_start = job_start; t.job_resume = job_resume;
     t.job_stats = job_stats; t.max_rounds = max_rounds;

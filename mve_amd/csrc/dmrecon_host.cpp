@@ -294,6 +294,11 @@ struct SceneGeom {
                                               * minParallax: most pairs) -- multiplying by the row changes nothing */
     };
     std::vector<std::pair<float, std::shared_ptr<const PairFactors> > > pen;
+    /* A COMPONENT's tables (SceneStore::sub): the views and features of one connected component of the bundle's view-feature
+     * graph, ascending -- local index -> scene index; empty = the tables are the whole scene's (identity) */
+    std::vector<int> vmap, fmap;
+    size_t view(size_t local) const { return vmap.empty() ? local : (size_t)vmap[local]; }
+    size_t feat(size_t local) const { return fmap.empty() ? local : (size_t)fmap[local]; }
 };
 
 /*
@@ -422,6 +427,13 @@ struct SceneStore {
     std::mutex pool_mu;                      /* guards scratch_pool */
     std::vector<BatchScratch> scratch_pool;  /* the scratch sets no call holds at the moment */
     SceneGeom geom;                          /* guarded by mu; dropped with views_dirty / set_features */
+    /* A bundle too large for the dense tables of `geom` that falls apart into components which share no feature (several
+     * scenes resident in one context; a large reconstruction in disconnected parts): tables PER COMPONENT, where a component is
+     * small enough for them.  A reference view's candidates are the views that share a feature with it -- views of its own
+     * component --, so its selection from the component's tables is the selection from the scene's (global_view_selection.cc:
+     * 62-101: a benefit is a sum over shared features; only a benefit above zero is ever selected, :44-52).  Built with `geom`. */
+    std::vector<std::unique_ptr<SceneGeom> > sub;
+    std::vector<int> sub_of_view, local_of_view;     /* per view: its component's tables (-1: none -- the direct path) and its index there */
     std::mutex mu;                           /* guards the lazy upload of the DevView table */
     std::vector<HostView> views;
     std::vector<Feature> features;
@@ -531,47 +543,36 @@ inline float parallax(V3 const& p, HostView const& v1, HostView const& v2) {   /
     return std::acos(dp) * 180.f / kPi;
 }
 
-/* Builds SceneStore::geom (see SceneGeom).  Called with the scene mutex held. */
-void build_scene_geom(SceneStore& sc) {
-    SceneGeom& g = sc.geom;
-    const size_t nv = sc.views.size(), nf = sc.features.size();
-    g.nv = nv; g.nf = nf; g.built = true; g.on_device = false;
-    g.pen.clear();
-    /* the size guard first: a bundle too large for the parallax table (1000 views x 1M features would need 4 TB) gets
-     * no tables at all -- the direct path (plan_global_views) needs O(features of the reference view) */
-    g.has_plx = nv * nv * nf <= ((size_t)1 << 26);                         /* 256 MB of floats at most */
-    g.pairs.reset();
-    if (!g.has_plx) {
-        g.pairs = std::make_shared<PairCache>();
-        std::vector<uint8_t>().swap(g.sees); std::vector<float>().swap(g.zcam); std::vector<float>().swap(g.plx);
-        std::vector<uint8_t>().swap(g.refs);
-        return;
-    }
+/* The dense tables of `g` over its views and features (g.nv, g.nf; g.vmap / g.fmap: a component's, else the scene's);
+ * vloc: scene view index -> index in g (-1: not in it), or null for the identity.  nt: threads. */
+static void build_geom_tables(SceneStore& sc, SceneGeom& g, const int* vloc, int nt) {
+    const size_t nv = g.nv, nf = g.nf;
     g.sees.assign(nv * nf, 0);
     g.refs.assign(nv * nf, 0);
     g.zcam.assign(nv * nf, 0.f);
     /* unit directions camera -> feature (parallax(), mvs_tools.h:46-56), only needed while building */
     std::vector<V3> dir(nv * nf);
-    const int nt = std::max(1, std::min(host_threads_cap(), 32));
-#pragma omp parallel for schedule(static) num_threads(nt)
+#pragma omp parallel for schedule(static) num_threads(nt) if (nt > 1)
     for (long f = 0; f < (long)nf; ++f) {
-        Feature const& ft = sc.features[f];
+        Feature const& ft = sc.features[g.feat((size_t)f)];
         const V3 p = mk(ft.pos[0], ft.pos[1], ft.pos[2]);
         for (int j = ft.ref_begin; j < ft.ref_end; ++j) {
-            const int v = sc.feat_refs[j];
+            const int vs = sc.feat_refs[j];                                /* the scene's view ... */
+            if (vs < 0 || vs >= (int)sc.views.size()) continue;
+            const int v = vloc ? vloc[vs] : vs;                            /* ... and its index in these tables */
             if (v < 0 || v >= (int)nv) continue;
             g.refs[(size_t)v * nf + f] = 1;
-            if (!sc.views[v].valid) continue;
-            if (!sc.views[v].pointInFrustum(p)) continue;                  /* dmrecon.cc:190,203 */
+            if (!sc.views[vs].valid) continue;
+            if (!sc.views[vs].pointInFrustum(p)) continue;                 /* dmrecon.cc:190,203 */
             g.sees[(size_t)v * nf + f] = 1;
-            g.zcam[(size_t)v * nf + f] = xform(sc.views[v].w2c, p)[2];     /* SingleView::footPrint's depth */
-            dir[(size_t)v * nf + f] = normalized(sub(p, sc.views[v].pos()));
+            g.zcam[(size_t)v * nf + f] = xform(sc.views[vs].w2c, p)[2];    /* SingleView::footPrint's depth */
+            dir[(size_t)v * nf + f] = normalized(sub(p, sc.views[vs].pos()));
         }
     }
     /* (+inf where the two views do not both see the feature: "parallax < minParallax" is false there, which is what
      * benefitFromView's seesFeature test amounts to, global_view_selection.cc:93-98) */
     g.plx.assign(nv * nv * nf, std::numeric_limits<float>::infinity());
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt) if (nt > 1)
     for (long v1 = 0; v1 < (long)nv; ++v1)
         for (size_t v2 = (size_t)v1 + 1; v2 < nv; ++v2)
             for (size_t f = 0; f < nf; ++f) {
@@ -583,10 +584,75 @@ void build_scene_geom(SceneStore& sc) {
             }
 }
 
-/* The pair factors of the scene for one minParallax (SceneGeom::pen); built on first use. */
-std::shared_ptr<const SceneGeom::PairFactors> scene_pair_factors(SceneStore& sc, float minP) {
-    std::lock_guard<std::mutex> lock(sc.mu);
+/* Builds SceneStore::geom (see SceneGeom) and, for a bundle too large for it, SceneStore::sub.  Called with the scene mutex held. */
+void build_scene_geom(SceneStore& sc) {
     SceneGeom& g = sc.geom;
+    const size_t nv = sc.views.size(), nf = sc.features.size();
+    g.nv = nv; g.nf = nf; g.built = true; g.on_device = false;
+    g.pen.clear();
+    g.vmap.clear(); g.fmap.clear();
+    sc.sub.clear(); sc.sub_of_view.clear(); sc.local_of_view.clear();
+    /* the size guard first: a bundle too large for the parallax table (1000 views x 1M features would need 4 TB) gets
+     * no tables of the whole -- the direct path (plan_global_views) needs O(features of the reference view) */
+    g.has_plx = nv * nv * nf <= ((size_t)1 << 26);                         /* 256 MB of floats at most */
+    g.pairs.reset();
+    const int nt = std::max(1, std::min(host_threads_cap(), 32));
+    if (g.has_plx) { build_geom_tables(sc, g, nullptr, nt); return; }
+    g.pairs = std::make_shared<PairCache>();
+    std::vector<uint8_t>().swap(g.sees); std::vector<float>().swap(g.zcam); std::vector<float>().swap(g.plx);
+    std::vector<uint8_t>().swap(g.refs);
+    /* ... but tables per connected component of the view-feature graph (SceneStore::sub): union-find over the features' view
+     * lists; a component gets tables if they fit the same bound, all of them together 1 GB */
+    std::vector<int> parent(nv);
+    for (size_t v = 0; v < nv; ++v) parent[v] = (int)v;
+    auto find = [&](int v) { while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; } return v; };
+    for (size_t f = 0; f < nf; ++f) {
+        int first = -1;
+        for (int j = sc.features[f].ref_begin; j < sc.features[f].ref_end; ++j) {
+            const int v = sc.feat_refs[j];
+            if (v < 0 || v >= (int)nv) continue;
+            if (first < 0) first = find(v);
+            else { const int r = find(v); if (r != first) parent[r] = first; }
+        }
+    }
+    std::vector<int> comp_id(nv, -1);
+    std::vector<std::vector<int> > cviews, cfeats;
+    for (size_t v = 0; v < nv; ++v) {
+        const int r = find((int)v);
+        if (comp_id[r] < 0) { comp_id[r] = (int)cviews.size(); cviews.emplace_back(); cfeats.emplace_back(); }
+        comp_id[v] = comp_id[r];
+        cviews[(size_t)comp_id[v]].push_back((int)v);                      /* ascending */
+    }
+    if (cviews.size() < 2) return;                                          /* one component: it is the scene, too large */
+    for (size_t f = 0; f < nf; ++f)
+        for (int j = sc.features[f].ref_begin; j < sc.features[f].ref_end; ++j) {
+            const int v = sc.feat_refs[j];
+            if (v < 0 || v >= (int)nv) continue;
+            cfeats[(size_t)comp_id[v]].push_back((int)f);                  /* ascending; a feature belongs to one component */
+            break;
+        }
+    sc.sub_of_view.assign(nv, -1); sc.local_of_view.assign(nv, -1);
+    size_t budget = (size_t)1 << 28;                                        /* floats of parallax tables over all components */
+    std::vector<size_t> todo;
+    for (size_t k = 0; k < cviews.size(); ++k) {
+        const size_t cv = cviews[k].size(), cf = cfeats[k].size();
+        if (cv < 2 || cf == 0 || cv * cv * cf > ((size_t)1 << 26) || cv * cv * cf > budget) continue;
+        budget -= cv * cv * cf;
+        std::unique_ptr<SceneGeom> sg(new SceneGeom());
+        sg->nv = cv; sg->nf = cf; sg->built = true; sg->has_plx = true; sg->vmap = cviews[k]; sg->fmap = cfeats[k];
+        for (size_t l = 0; l < cv; ++l) { sc.sub_of_view[(size_t)cviews[k][l]] = (int)sc.sub.size(); sc.local_of_view[(size_t)cviews[k][l]] = (int)l; }
+        todo.push_back(sc.sub.size());
+        sc.sub.push_back(std::move(sg));
+    }
+    /* (the components side by side, each single-threaded: many small tables) */
+    const int* vloc = sc.local_of_view.data();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt) if (todo.size() > 1)
+    for (long t = 0; t < (long)todo.size(); ++t) build_geom_tables(sc, *sc.sub[todo[(size_t)t]], vloc, 1);
+}
+
+/* The pair factors of the scene for one minParallax (SceneGeom::pen); built on first use. */
+std::shared_ptr<const SceneGeom::PairFactors> scene_pair_factors(SceneStore& sc, SceneGeom& g, float minP) {
+    std::lock_guard<std::mutex> lock(sc.mu);
     for (size_t i = 0; i < g.pen.size(); ++i) if (g.pen[i].first == minP) return g.pen[i].second;
     auto tab = std::make_shared<SceneGeom::PairFactors>();
     tab->f.resize(g.plx.size());
@@ -653,13 +719,15 @@ static void sum_rows8(const float* const p[8], size_t n, float out[8]) {
  * floats changes nothing, so the benefit is the reference's sum over the candidate's features in their order (:66-99)
  * bit for bit, and every loop below is a contiguous one.  The arrays live with the calling thread (GvsScratch). */
 struct GvsScratch { std::vector<float> base, prod; std::vector<uint8_t> attached; };
-int plan_global_views_tables(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref, std::vector<int>& global) {
+/* g: the scene's tables, or those of the reference view's component (SceneStore::sub: local indices, mapped by g.view / g.feat);
+ * ref_scene: the reference view's index in the scene. */
+int plan_global_views_tables(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, SceneGeom& g, int ref_scene, std::vector<int>& global) {
     static thread_local GvsScratch W;
-    SceneGeom const& g = c->sc->geom;
     const size_t nv = g.nv, nf = g.nf;
-    HostView const& R = c->sc->views[ref];
+    const int ref = g.vmap.empty() ? ref_scene : c->sc->local_of_view[(size_t)ref_scene];
+    HostView const& R = c->sc->views[ref_scene];
     const float minP = st->minParallax;
-    const std::shared_ptr<const SceneGeom::PairFactors> pen_tab = scene_pair_factors(*c->sc, minP);
+    const std::shared_ptr<const SceneGeom::PairFactors> pen_tab = scene_pair_factors(*c->sc, g, minP);
     const float* P = pen_tab->f.data();
     const uint8_t* plain = pen_tab->plain.data();
     const bool no_box = st->aabbMin[0] == -std::numeric_limits<float>::max() && st->aabbMax[0] == std::numeric_limits<float>::max()
@@ -672,14 +740,14 @@ int plan_global_views_tables(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
     for (size_t f = 0; f < nf; ++f) {
         if (!sees_ref[f]) continue;
         if (!no_box) {
-            Feature const& ft = c->sc->features[f];
+            Feature const& ft = c->sc->features[g.feat(f)];
             if (!in_box(mk(ft.pos[0], ft.pos[1], ft.pos[2]), st->aabbMin, st->aabbMax)) continue;
         }
         att[f] = 1;
     }
     std::vector<char> available(nv, 1);                                     /* global_view_selection.cc:23-30 */
     available[ref] = 0;
-    for (size_t i = 0; i < nv; ++i) if (!c->sc->views[i].valid) available[i] = 0;
+    for (size_t i = 0; i < nv; ++i) if (!c->sc->views[g.view(i)].valid) available[i] = 0;
     /* the part of benefitFromView's score that does not depend on the selected set (:76-89); 0 where the candidate
      * does not see an attached feature (dmrecon.cc:198-206) */
     W.base.resize(nv * nf); W.prod.resize(nv * nf);
@@ -687,7 +755,7 @@ int plan_global_views_tables(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
     const float* z_ref = &g.zcam[(size_t)ref * nf];
     for (size_t i = 0; i < nv; ++i) {
         if (!available[i]) continue;
-        const float inv_n = c->sc->views[i].levels[0].invproj[0];
+        const float inv_n = c->sc->views[g.view(i)].levels[0].invproj[0];
         const float* p_ri = P + ((size_t)ref * nv + i) * nf;
         const float* z_i = &g.zcam[i * nf];
         const uint8_t* sv = &g.sees[i * nf];
@@ -749,7 +817,9 @@ int plan_global_views_tables(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, i
             available[maxView] = 0;
         }
     }
-    global = selected;
+    /* (a component's views ascend with the scene's: the order of the selection and its tie-breaks are the scene's) */
+    global.resize(selected.size());
+    for (size_t k = 0; k < selected.size(); ++k) global[k] = (int)g.view((size_t)selected[k]);
     return 0;
 }
 
@@ -931,7 +1001,10 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
                 std::lock_guard<std::mutex> lock(c->sc->mu);
                 if (!c->sc->geom.built) build_scene_geom(*c->sc);
             }
-            if (c->sc->geom.has_plx) return plan_global_views_tables(c, st, ref, global);
+            if (c->sc->geom.has_plx) return plan_global_views_tables(c, st, c->sc->geom, ref, global);
+            /* (a bundle in several parts: the tables of the reference view's component) */
+            if ((size_t)ref < c->sc->sub_of_view.size() && c->sc->sub_of_view[(size_t)ref] >= 0)
+                return plan_global_views_tables(c, st, *c->sc->sub[(size_t)c->sc->sub_of_view[(size_t)ref]], ref, global);
         }
     }
     /* The direct form (a bundle too large for the scene tables: hundreds of views).  Everything below is kept to the views
@@ -1116,6 +1189,39 @@ void plan_seeds(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, JobHost& job, 
     /* without the tables (a scene too large for them): the candidates are the features the reference view or one of its
      * global views is referenced by (dmrecon.cc:262-270: useFeature), in the order of the bundle -- the union of their
      * by-view lists instead of a scan of every feature's view list for every one of those views */
+    /* (a bundle in several parts: the byte tables of the reference view's component, its features in the order of the bundle) */
+    const SceneGeom* SG = nullptr;
+    if (!tab && G.built && (size_t)job.ref_view < c->sc->sub_of_view.size() && c->sc->sub_of_view[(size_t)job.ref_view] >= 0)
+        SG = c->sc->sub[(size_t)c->sc->sub_of_view[(size_t)job.ref_view]].get();
+    if (SG) {
+        const size_t cf = SG->nf;
+        const int* loc = c->sc->local_of_view.data();
+        const int subk = c->sc->sub_of_view[(size_t)job.ref_view];
+        std::vector<const uint8_t*> rows;
+        rows.push_back(&SG->refs[(size_t)loc[job.ref_view] * cf]);
+        for (size_t g = 0; g < job.global.size(); ++g)
+            if (c->sc->sub_of_view[(size_t)job.global[g]] == subk) rows.push_back(&SG->refs[(size_t)loc[job.global[g]] * cf]);
+        for (size_t it = 0; it < cf; ++it) {
+            bool use = false;
+            for (size_t r = 0; !use && r < rows.size(); ++r) use = rows[r][it] != 0;
+            if (!use) continue;
+            Feature const& f = c->sc->features[(size_t)SG->fmap[it]];
+            V3 p = mk(f.pos[0], f.pos[1], f.pos[2]);
+            if (!R.pointInFrustum(p)) continue;
+            if (!in_box(p, st->aabbMin, st->aabbMax)) continue;
+            ++job.n_seeds;
+            V3 cp = xform(R.w2c, p);                                            /* worldToScreenScaled */
+            float sx = dot3(L.proj, cp.v), sy = dot3(L.proj + 3, cp.v), sz = dot3(L.proj + 6, cp.v);
+            int const x = (int)mround(sx / sz - 0.5f);
+            int const y = (int)mround(sy / sz - 0.5f);
+            if (x < 0 || y < 0 || x >= L.w || y >= L.h) continue;              /* the sampler's border test fails anyway */
+            DevEntry e; e.job = job_index; e.xy = x | (y << 16);
+            DevHyp h; h.depth = norm3(sub(p, R.pos())); h.dzI = 0.f; h.dzJ = 0.f; h.views = 0xFFFFFFFFu; h.views_hi = 0xFFFFFFFFu;
+            job.seeds.push_back(e);
+            job.seed_hyp.push_back(h);
+        }
+        return;
+    }
     std::vector<int> cand;
     const bool by_view = !tab && c->sc->by_view_off.size() > 1;
     if (by_view) {
