@@ -52,7 +52,10 @@ struct MiDeviceApi {
                      const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                      DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                      unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                     const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, unsigned follow_seg);
+                     const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, unsigned follow_seg,
+                     unsigned follow_seg_in /* the segments of follow_in (0: one list) */,
+                     unsigned long long* follow_mask /* first launch of a large round: a mask per wavefront unit instead of
+                                                      * appending (OptArgs::follow_mask; mi_launch_follow_compact makes the list) */);
     void (*patch_eval)(hipStream_t s, const DevJob* job, const DevView* views, const float* lut,
                        const DevSettings& st, int x, int y, float depth, float dzI, float dzJ,
                        float* master, float* ncc, int32_t* ok, float* col, float* deriv, int32_t* level);
@@ -124,6 +127,10 @@ void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const uns
 void mi_launch_unpack_jobs(hipStream_t s, const uint32_t* packed, unsigned words_per_job, DevJob* jobs, int n_jobs);
 /* an empty one-lane kernel: where profiles are cut (mi_dmrecon_debug_region_mark) */
 void mi_launch_region_mark(hipStream_t s, unsigned tag);
+/* the first follow-up list of a round from the masks of its first launch, in list order (k_follow_count + k_follow_scatter);
+ * blk_sum: 1024 words of scratch; acts like the launches of the round only if min_work <= *n_work_ptr < max_work */
+void mi_launch_follow_compact(hipStream_t s, const unsigned long long* mask, const unsigned* n_work_ptr, unsigned min_work, unsigned max_work,
+                              unsigned ppw, unsigned lpp, unsigned* blk_sum, unsigned* out, unsigned* out_n);
 /* dst: w*h records of 16 bytes (texels (x,y) (x+1,y) (x,y+1) (x+1,y+1), edge-clamped) */
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h);
 void mi_launch_pack_rgba(hipStream_t s, const uint8_t* src, uint32_t* dst, int n, int channels);

@@ -1793,6 +1793,15 @@ struct OptArgs {
      * XCDs interleaved the eight ranges and mixed the views: the second attempts then ran 1.7 x slower per sampling pass than
      * the first ones (L2 hits 63 % against 85 %; profiles/r6_ab_experiments.txt). */
     unsigned follow_seg;
+    unsigned follow_seg_in;       /* ... the same of the list this launch CONTINUES (0: one list with one counter, walked in eighths) */
+    /* The FIRST follow-up list of a round in the ORDER of the round's list (the first launch of a large round): instead of appending,
+     * every wavefront leaves the ballot of its patches that go on (bit = the patch's first lane) in follow_mask[unit];
+     * k_follow_count / k_follow_scatter turn the masks into the list.  Appended by atomics a wavefront of that list held 16
+     * strangers -- entries from all over an XCD's eighth --, whose footprint gathers share no cache line: such wavefronts run
+     * 1.76 x slower per sampling pass than wavefronts of 16 neighbouring patches (measured by scrambling the first launch's own
+     * entries: profiles/r6_ab_experiments.txt); in list order the 16 entries of a follow-up wavefront come from ~80 consecutive
+     * ones: the same views, the same image rows. */
+    unsigned long long* follow_mask;
     unsigned scramble;            /* experiment (MI_DMRECON_DEBUG_SCRAMBLE, first attempts only): 1 = the entries of a list are dealt to the
                                    * wavefronts in a scrambled order (a wavefront's 16 patches are no neighbours any more), 2 = whole
                                    * wavefront units in a scrambled order (neighbours within a wavefront, strangers across); same maps */
@@ -2065,8 +2074,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
     static_assert(!SEED || (SINGLE && !FAST), "the seed launch is the single-attempt form of the general kernel");
     const int lane = threadIdx.x;
     /* (follow-up lists: the segment of this workgroup's XCD, see OptArgs::follow_seg) */
-    const unsigned seg_n = (a.follow_seg != 0u && gridDim.x % MI_XCDS == 0 && gridDim.x >= MI_XCDS) ? MI_XCDS : 1u, seg = blockIdx.x % seg_n;   /* (follow_seg 0: one list for all) */
-    const unsigned n = a.follow_in ? a.follow_in_n[seg] : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
+    const bool grid8 = gridDim.x % MI_XCDS == 0 && gridDim.x >= MI_XCDS;
+    const unsigned seg_n = (a.follow_seg != 0u && grid8) ? MI_XCDS : 1u, seg = blockIdx.x % seg_n;   /* (follow_seg 0: one list for all) */
+    const unsigned seg_in_n = (a.follow_seg_in != 0u && grid8) ? MI_XCDS : 1u, seg_in = blockIdx.x % seg_in_n;
+    const unsigned n = a.follow_in ? a.follow_in_n[seg_in] : (a.n_work_ptr ? *a.n_work_ptr : a.n_work);
     if (!a.follow_in && (n < a.min_work || n >= a.max_work)) return;
     for (int i = lane; i < 256; i += WAVE) g_lut[i] = a.lut[i];
 #ifdef MI_ACTIVITY
@@ -2078,12 +2089,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
     const unsigned long long clk_s0 = clk_probe ? (unsigned long long)clock64() : 0ull, clk_r0 = clk_probe ? (unsigned long long)wall_clock64() : 0ull;
     unsigned n_eval = 0, n_pass = 0, n_patch = 0, err = 0;
     unsigned unit;
-    const unsigned* const fin = a.follow_in ? a.follow_in + (size_t)seg * a.follow_seg : nullptr;
-    for (XcdRange xr((n + L::PATCHES - 1) / L::PATCHES, a.follow_in != nullptr && seg_n > 1u); xr.next(unit); ) {
+    const unsigned* const fin = a.follow_in ? a.follow_in + (size_t)seg_in * a.follow_seg_in : nullptr;
+    for (XcdRange xr((n + L::PATCHES - 1) / L::PATCHES, a.follow_in != nullptr && seg_in_n > 1u); xr.next(unit); ) {
         const unsigned i = unit * L::PATCHES + L::patch(lane);
         const bool live = i < n;                             /* (the last wavefront of the list: lanes without an entry idle) */
         unsigned e = !live ? 0u : (fin ? fin[i] : i);
-        if (a.scramble && !fin && live) {
+        if (a.scramble && !fin && live && !a.follow_mask) {
             /* (a bijection of [0, n) resp. of the full units: multiplication by a prime modulo the size) */
             const unsigned n_full = n / L::PATCHES;
             if (a.scramble == 1u) e = (unsigned)(((unsigned long long)i * 1000003ull) % n);
@@ -2101,7 +2112,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
         else
             process_entry<L, false>(a, e, job, ent.xy & 0xFFFF, ent.xy >> 16, lane, n_eval, n_pass, n_patch, err, more);
         }
-        if (a.follow_out) {
+        if (a.follow_mask) {
+            /* (the entries that go on, as a mask per wavefront unit: the list is made in list order afterwards, see OptArgs) */
+            const unsigned long long m = __ballot(more && L::vslot(lane) == 0 && L::sub(lane) == 0);
+            if (lane == 0) a.follow_mask[unit] = m;
+        } else if (a.follow_out) {
             /* wave-aggregated append of the entries that still have candidates (one atomic per wavefront) */
             const bool mine = more && L::vslot(lane) == 0 && L::sub(lane) == 0;
             const unsigned long long m = __ballot(mine);
@@ -3511,6 +3526,72 @@ __global__ __launch_bounds__(256) void k_quadify(const uint32_t* __restrict__ sr
 }
 
 #if MI_FW == 5
+/* The first follow-up list of a round from the masks its first launch left (OptArgs::follow_mask), in the order of the round's
+ * list.  MI_FOLLOW_BLOCKS workgroups, each with a contiguous run of wavefront units; k_follow_count: the entries of every run;
+ * k_follow_scatter: a run's offset = the sum of the runs before it, then the entries, ascending.  lpp: lanes per patch (a set
+ * bit i of a mask = patch i / lpp of the unit), ppw: patches per wavefront. */
+#define MI_FOLLOW_BLOCKS 1024
+struct FollowArgs {
+    const unsigned long long* mask; const unsigned* n_work_ptr; unsigned min_work, max_work;
+    unsigned ppw, lpp; unsigned* blk_sum; unsigned* out; unsigned* out_n;
+};
+__device__ __forceinline__ bool follow_run(const FollowArgs& a, unsigned& first, unsigned& last) {
+    const unsigned n = *a.n_work_ptr;
+    if (n < a.min_work || n >= a.max_work) return false;
+    const unsigned n_units = (n + a.ppw - 1) / a.ppw;
+    const unsigned per = ((n_units + MI_FOLLOW_BLOCKS - 1) / MI_FOLLOW_BLOCKS + 255u) & ~255u;      /* whole tiles of 256 units */
+    first = blockIdx.x * per; last = first + per < n_units ? first + per : n_units;
+    return true;
+}
+__global__ __launch_bounds__(256) void k_follow_count(FollowArgs a) {
+    __shared__ unsigned s_sum;
+    unsigned first = 0, last = 0;
+    const bool on = follow_run(a, first, last);
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    unsigned c = 0;
+    if (on) for (unsigned u = first + threadIdx.x; u < last; u += 256) c += (unsigned)__popcll(a.mask[u]);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_sum, c);
+    __syncthreads();
+    if (threadIdx.x == 0) a.blk_sum[blockIdx.x] = s_sum;
+}
+__global__ __launch_bounds__(256) void k_follow_scatter(FollowArgs a) {
+    __shared__ unsigned s_part[4], s_wave[4], s_base;
+    unsigned first = 0, last = 0;
+    const bool on = follow_run(a, first, last);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    /* this run's offset: the entries of the runs before it (1024 words: four per thread) */
+    unsigned before = 0, total = 0;
+    for (unsigned b = (unsigned)tid; b < MI_FOLLOW_BLOCKS; b += 256) { const unsigned v = a.blk_sum[b]; total += v; if (b < blockIdx.x) before += v; }
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_down(before, off); total += __shfl_down(total, off); }
+    if (lane == 0) { s_part[wave] = before; s_wave[wave] = total; }
+    __syncthreads();
+    if (tid == 0) {
+        s_base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (blockIdx.x == 0) *a.out_n = on ? s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3] : 0u;
+    }
+    __syncthreads();
+    if (!on) return;
+    unsigned run = s_base;
+    for (unsigned u0 = first; u0 < last; u0 += 256) {
+        const unsigned u = u0 + (unsigned)tid;
+        const unsigned long long m = u < last ? a.mask[u] : 0ull;
+        const unsigned c = (unsigned)__popcll(m);
+        /* exclusive prefix of c over the tile: inside the wavefront, then across the four */
+        unsigned inc = c;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+        __syncthreads();                                   /* (s_wave of the tile before has been read) */
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        unsigned pre = inc - c;
+        for (int w = 0; w < wave; ++w) pre += s_wave[w];
+        unsigned o = run + pre;
+        for (unsigned long long r = m; r; r &= r - 1ull) a.out[o++] = u * a.ppw + (unsigned)(__ffsll((long long)r) - 1) / a.lpp;
+        run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    }
+}
+
 /* A one-lane kernel that does nothing: profiles are cut at its dispatches (mi_dmrecon_debug_region_mark: bench.py brackets every
  * timed region with one, tools/trace_regions.py keeps the dispatches between the marks of a rocprofv3 kernel trace). */
 __global__ void k_region_mark(unsigned tag) { (void)tag; }
@@ -3530,16 +3611,17 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
                         const float* lut, const DevSettings& st, const DevEntry* work, const DevHyp* hyp,
                         DevResult* results, const unsigned* n_work_ptr, unsigned n_work, unsigned min_work,
                         unsigned max_work, int round, DevCounters* counters, const unsigned* follow_in,
-                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, unsigned follow_seg) {
+                        const unsigned* follow_in_n, unsigned* follow_out, unsigned* follow_out_n, unsigned follow_seg,
+                        unsigned follow_seg_in, unsigned long long* follow_mask) {
     if (grid_blocks == 0) return;
     grid_blocks = (grid_blocks + MI_XCDS - 1) / MI_XCDS * MI_XCDS;      /* (XcdRange: every XCD the same number of workgroups) */
     OptArgs a;
-    a.follow_seg = follow_seg;
+    a.follow_seg = follow_seg; a.follow_seg_in = follow_seg_in; a.follow_mask = follow_mask;
     { const char* e = getenv("MI_DMRECON_DEBUG_SCRAMBLE"); a.scramble = (e && follow_in == nullptr && hyp == nullptr) ? (unsigned)atoi(e) : 0u; }
     a.jobs = jobs; a.views = views; a.lut = lut; a.st = st; a.work = work; a.hyp = hyp; a.results = results;
     a.n_work_ptr = n_work_ptr; a.n_work = n_work; a.min_work = min_work; a.max_work = max_work;
     a.round = round; a.counters = counters; a.tbuf = mi_debug_tbuf;
-    a.max_attempts = follow_out ? 1 : 4; a.follow_in = follow_in; a.follow_in_n = follow_in_n;
+    a.max_attempts = (follow_out || follow_mask) ? 1 : 4; a.follow_in = follow_in; a.follow_in_n = follow_in_n;
     a.follow_out = follow_out; a.follow_out_n = follow_out_n;
     /* lanes_per_view: 1 = throughput layout, 2 = throughput layout and the FAST kernel for a launch that CONTINUES a follow-up list
      * (below), anything else = latency layout; st.K > 4: the eight-slot layouts */
@@ -3559,7 +3641,7 @@ static void launch_optimize(hipStream_t s, int lanes_per_view, unsigned grid_blo
      * view selection code in it -- a patch that needs one goes to the follow-up launch, which is the general kernel */
     /* (lanes_per_view 2: second attempts in the FAST kernel as well -- same arithmetic, a patch that needs a view selection is
      * abandoned once more and goes on to the next list, which the general kernel takes) */
-    const bool fast = !lat && follow_out != nullptr && (follow_in == nullptr || lanes_per_view == 2) && hyp == nullptr && st.K <= 8;
+    const bool fast = !lat && (follow_out != nullptr || follow_mask != nullptr) && (follow_in == nullptr || lanes_per_view == 2) && hyp == nullptr && st.K <= 8;
     /* ... a launch that continues a follow-up list AND leaves one runs one attempt per entry as well, in the general kernel
      * (process_entry_single), and so do the seeds (one hypothesis each); only a propagation launch without a follow-up list
      * of its own runs an entry's attempts in a row */
@@ -3596,7 +3678,7 @@ static void launch_optimize_spec(hipStream_t s, unsigned grid_blocks, const DevJ
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = nullptr;
     t.o.n_work_ptr = n_work_ptr; t.o.n_work = n_work; t.o.min_work = min_work; t.o.max_work = max_work; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.max_attempts = 1; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0; t.o.scramble = 0;
+    t.o.max_attempts = 1; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0; t.o.follow_seg_in = 0; t.o.follow_mask = nullptr; t.o.scramble = 0;
     t.spec = spec; t.items = items; t.n_items = n_items;
     if (st.K > 4) hipLaunchKernelGGL((k_optimize_spec<Lay<1, 8> >), dim3(grid_blocks), dim3(WAVE), (unsigned)(Lay<1, 8>::PATCHES * st.ncc_stride * sizeof(float)), s, t);
     else hipLaunchKernelGGL((k_optimize_spec<Lay<1, 4> >), dim3(grid_blocks), dim3(WAVE), (unsigned)(Lay<1, 4>::PATCHES * st.ncc_stride * sizeof(float)), s, t);
@@ -3652,7 +3734,7 @@ static void launch_tail(hipStream_t s, unsigned grid_blocks, const DevJob* jobs,
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = work; t.o.hyp = nullptr; t.o.results = results;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0; t.o.scramble = 0;
+    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0; t.o.follow_seg_in = 0; t.o.follow_mask = nullptr; t.o.scramble = 0;
     t.prev_work = prev_work; t.prev_results = prev_results; t.round_work = round_work;
     if (st.K > 4) {
         if (speculative) hipLaunchKernelGGL((k_tail<true, 8>), dim3(grid_blocks), dim3(MI_TAIL_WAVES * WAVE), 0, s, t);
@@ -3682,7 +3764,7 @@ static void launch_front(hipStream_t s, int n_jobs, const DevJob* jobs, const De
     t.o.jobs = jobs; t.o.views = views; t.o.lut = lut; t.o.st = st; t.o.work = nullptr; t.o.hyp = nullptr; t.o.results = nullptr;
     t.o.n_work_ptr = nullptr; t.o.n_work = 0; t.o.min_work = 0; t.o.max_work = 0xFFFFFFFFu; t.o.round = first_round;
     t.o.counters = counters; t.o.tbuf = mi_debug_tbuf;
-    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0; t.o.scramble = 0;
+    t.o.max_attempts = 4; t.o.follow_in = nullptr; t.o.follow_in_n = nullptr; t.o.follow_out = nullptr; t.o.follow_out_n = nullptr; t.o.follow_seg = 0; t.o.follow_seg_in = 0; t.o.follow_mask = nullptr; t.o.scramble = 0;
     t.work[0] = work0; t.work[1] = work1; t.results[0] = results0; t.results[1] = results1;
     t.job_off = job_off; t.job_count = job_count; t.job_start = job_start; t.job_resume = job_resume;
     t.job_stats = job_stats; t.max_rounds = max_rounds;
@@ -3752,6 +3834,14 @@ void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const uns
                             const DevJob* jobs, int n_jobs, unsigned* out_rw, DevCounters* out_hc, void* out_dyn, const unsigned* view_count) {
     hipLaunchKernelGGL(k_round_report, dim3(1), dim3(256), 0, s, a, n_a, b, n_b, counters, jobs, n_jobs, out_rw,
                        reinterpret_cast<unsigned*>(out_hc), static_cast<unsigned*>(out_dyn), view_count);
+}
+void mi_launch_follow_compact(hipStream_t s, const unsigned long long* mask, const unsigned* n_work_ptr, unsigned min_work, unsigned max_work,
+                              unsigned ppw, unsigned lpp, unsigned* blk_sum, unsigned* out, unsigned* out_n) {
+    FollowArgs a;
+    a.mask = mask; a.n_work_ptr = n_work_ptr; a.min_work = min_work; a.max_work = max_work; a.ppw = ppw; a.lpp = lpp;
+    a.blk_sum = blk_sum; a.out = out; a.out_n = out_n;
+    hipLaunchKernelGGL(k_follow_count, dim3(MI_FOLLOW_BLOCKS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_follow_scatter, dim3(MI_FOLLOW_BLOCKS), dim3(256), 0, s, a);
 }
 void mi_launch_region_mark(hipStream_t s, unsigned tag) { hipLaunchKernelGGL(k_region_mark, dim3(1), dim3(1), 0, s, tag); }
 void mi_launch_unpack_jobs(hipStream_t s, const uint32_t* packed, unsigned words_per_job, DevJob* jobs, int n_jobs) {

@@ -338,6 +338,8 @@ struct BatchScratch {
     DevBuf<unsigned> d_follow;               /* 4 x work-list capacity: entries that continue with their next hypothesis (two-launch
                                               * rounds) / the (entry, candidate) items of a speculative round (at most four per entry) */
     DevBuf<unsigned> d_follow_cnt;           /* [MI_MAX_ROUNDS][MI_FOLLOW_LISTS] sizes of the follow-up lists */
+    DevBuf<unsigned long long> d_fmask;      /* per wavefront unit of a large round's first launch: the patches that go on (OptArgs::follow_mask) */
+    DevBuf<unsigned> d_fblk;                 /* k_follow_count's sums */
     DevBuf<DevSpec> d_spec;                  /* speculative small rounds: four attempt records per entry (BatchRun::bulk_rounds) */
     TailPoll* h_poll = nullptr;              /* pinned: read-back of two tail chunks in flight */
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
@@ -383,7 +385,7 @@ struct BatchScratch {
         for (size_t i = 0; i < events.size(); ++i) (void)hipEventDestroy(events[i]);
         events.clear();
         d_jobs.release(); d_work.release(); d_work2.release(); d_hyp.release(); d_results.release(); d_results2.release();
-        d_follow.release(); d_follow_cnt.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_xviews.release(); d_jobs_packed.release(); d_keys.release(); d_keyoff.release();
+        d_follow.release(); d_follow_cnt.release(); d_fmask.release(); d_fblk.release(); d_spec.release(); d_maps.release(); d_imaps.release(); d_xviews.release(); d_jobs_packed.release(); d_keys.release(); d_keyoff.release();
         d_round_work.release(); d_round_work_t.release(); d_round_items.release(); d_view.release(); d_front.release(); d_front_resume.release();
         d_front_mail.release(); d_front_flags.release(); d_front_map.release(); d_front_order.release();
         d_gvs_feat.release(); d_gvs_out.release(); d_gvs_base.release(); d_gvs_benefit.release(); d_gvs_refs.release(); d_sparse_count.release();
@@ -594,7 +596,9 @@ void build_scene_geom(SceneStore& sc) {
     sc.sub.clear(); sc.sub_of_view.clear(); sc.local_of_view.clear();
     /* the size guard first: a bundle too large for the parallax table (1000 views x 1M features would need 4 TB) gets
      * no tables of the whole -- the direct path (plan_global_views) needs O(features of the reference view) */
-    g.has_plx = nv * nv * nf <= ((size_t)1 << 26);                         /* 256 MB of floats at most */
+    /* (test hook MI_DMRECON_DEBUG_TABLE_LIMIT=<floats>: the bound, so that a small merged scene counts as "too large") */
+    const size_t limit = [] { const char* e = std::getenv("MI_DMRECON_DEBUG_TABLE_LIMIT"); return e && std::atoll(e) > 0 ? (size_t)std::atoll(e) : ((size_t)1 << 26); }();
+    g.has_plx = nv * nv * nf <= limit;                                      /* 256 MB of floats at most */
     g.pairs.reset();
     const int nt = std::max(1, std::min(host_threads_cap(), 32));
     if (g.has_plx) { build_geom_tables(sc, g, nullptr, nt); return; }
@@ -636,7 +640,7 @@ void build_scene_geom(SceneStore& sc) {
     std::vector<size_t> todo;
     for (size_t k = 0; k < cviews.size(); ++k) {
         const size_t cv = cviews[k].size(), cf = cfeats[k].size();
-        if (cv < 2 || cf == 0 || cv * cv * cf > ((size_t)1 << 26) || cv * cv * cf > budget) continue;
+        if (cv < 2 || cf == 0 || cv * cv * cf > limit || cv * cv * cf > budget) continue;
         budget -= cv * cv * cf;
         std::unique_ptr<SceneGeom> sg(new SceneGeom());
         sg->nv = cv; sg->nf = cf; sg->built = true; sg->has_plx = true; sg->vmap = cviews[k]; sg->fmap = cfeats[k];
@@ -648,6 +652,9 @@ void build_scene_geom(SceneStore& sc) {
     const int* vloc = sc.local_of_view.data();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nt) if (todo.size() > 1)
     for (long t = 0; t < (long)todo.size(); ++t) build_geom_tables(sc, *sc.sub[todo[(size_t)t]], vloc, 1);
+    if (std::getenv("MI_DMRECON_TRACE"))
+        fprintf(stderr, "[mi_dmrecon] view selection tables: the bundle (%zu views, %zu features) in %zu parts, %zu of them with tables of their own\n",
+                nv, nf, cviews.size(), sc.sub.size());
 }
 
 /* The pair factors of the scene for one minParallax (SceneGeom::pen); built on first use. */
@@ -2021,7 +2028,7 @@ int BatchRun::seed_round() {
     sds.seed_reopt = seed_mode == 2 ? 1 : 0;
     D->optimize(S, 1, ((unsigned)n_seeds_total + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p,
                 c->sc->d_lut, sds, c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n_seeds_total, 0u, 0xFFFFFFFFu, 0,
-                c->d_counters, nullptr, nullptr, nullptr, nullptr, 0u);
+                c->d_counters, nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr);
     ev.end(S);
     ++n_launch;
     ev.begin(S, EventLog::SWEEP, 0);
@@ -2140,7 +2147,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
         if (!need_plain) { }
         else if (known_thr < ONE_LAUNCH_MAX)
             D->optimize(S, 1, spec ? std::max(1u, waves / 2) : waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
-                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr, 0u);
+                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr);
         else {
             /* one optimisation attempt per entry and launch; the entries whose pixel has further candidate hypotheses
              * (about one in five) continue in a follow-up launch over a compacted list (its size stays on the device),
@@ -2155,8 +2162,17 @@ int BatchRun::bulk_rounds(bool& to_tail) {
             const unsigned fseg = segs ? fseg_full : 0u;
             const size_t fstride = (size_t)fseg_full * MI_FOLLOW_SEGS;
             unsigned* fl[5] = {c->bs.d_follow.p, c->bs.d_follow.p + fstride, c->bs.d_follow.p + 2 * fstride, c->bs.d_follow.p + 3 * fstride, c->bs.d_follow.p};
+            /* The FIRST follow-up list in the order of the round's list (MI_DMRECON_FOLLOW_ORDERED=0: appended by atomics like the
+             * later ones -- the A/B switch; same maps): the first launch leaves a mask per wavefront unit, two small kernels make the
+             * list from the masks -- a wavefront of it then holds entries of one view and a few image rows instead of 16 strangers,
+             * whose footprint gathers share no cache line (1.76 x slower per sampling pass: OptArgs::follow_mask). */
+            const bool ordered = SINGLE_FOLLOW && !std::getenv("MI_DMRECON_DEBUG_SCRAMBLE")
+                && [] { const char* e = std::getenv("MI_DMRECON_FOLLOW_ORDERED"); return !e || std::atoi(e) != 0; }();
+            if (ordered && (c->bs.d_fmask.reserve(total_px / ppw + 4096) || c->bs.d_fblk.reserve(1024)))
+                return fail(MI_DMRECON_EDEVICE, "hipMalloc(follow-up masks) failed");
             D->optimize(S, 1, waves, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr, c->bs.d_results.p, n_thr_p,
-                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, fl[0], fcnt, fseg);
+                        0u, plain_min, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, ordered ? nullptr : fl[0], fcnt, fseg, 0u, ordered ? c->bs.d_fmask.p : nullptr);
+            if (ordered) mi_launch_follow_compact(S, c->bs.d_fmask.p, n_thr_p, plain_min, 0xFFFFFFFFu, ppw, 64u / ppw, c->bs.d_fblk.p, fl[0], fcnt);
             if (SINGLE_FOLLOW) {
                 /* every further attempt as a launch of its own over the entries the reference's rule still asks one of (about
                  * a fifth, a thirtieth, ... of the list), again ONE attempt per entry: no chain of attempts is live across an
@@ -2173,24 +2189,25 @@ int BatchRun::bulk_rounds(bool& to_tail) {
                     /* MI_DMRECON_FAST_FOLLOW=<n>: the first n follow-up launches run the FAST kernel too (second attempts rarely need a
                      * view selection; the ones that do are abandoned again and go on to the next list) */
                     D->optimize(S, k < FAST_FOLLOW ? 2 : 1, std::max(64u, waves / div), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[k], fcnt + MI_FOLLOW_SEGS * k, fl[k + 1], fcnt + MI_FOLLOW_SEGS * (k + 1), fseg);
+                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[k], fcnt + MI_FOLLOW_SEGS * k, fl[k + 1], fcnt + MI_FOLLOW_SEGS * (k + 1), fseg,
+                                (k == 0 && ordered) ? 0u : fseg, nullptr);
                     ++n_launch;
                 }
                 if (n_single == 4 && FAST_FOLLOW > 0) {
                     /* an entry abandoned by FAST launches can have attempts left after the four single-attempt launches: what the
                      * last of them appended (to the first list's buffer, consumed long ago) runs its remaining attempts in a row */
                     D->optimize(S, 1, 64u, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[4], fcnt + MI_FOLLOW_SEGS * 4, nullptr, nullptr, fseg);
+                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[4], fcnt + MI_FOLLOW_SEGS * 4, nullptr, nullptr, fseg, fseg, nullptr);
                     ++n_launch;
                 }
                 if (n_single < 4) {
                     D->optimize(S, 1, std::max(64u, waves / div), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[n_single], fcnt + MI_FOLLOW_SEGS * n_single, nullptr, nullptr, fseg);
+                                c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[n_single], fcnt + MI_FOLLOW_SEGS * n_single, nullptr, nullptr, fseg, fseg, nullptr);
                     ++n_launch;
                 }
             } else {
                 D->optimize(S, 1, std::max(1u, waves / 4), c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work.p, nullptr,
-                            c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[0], fcnt, nullptr, nullptr, fseg);
+                            c->bs.d_results.p, n_thr_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, fl[0], fcnt, nullptr, nullptr, fseg, fseg, nullptr);
                 ++n_launch;
             }
         }
@@ -2205,7 +2222,7 @@ int BatchRun::bulk_rounds(bool& to_tail) {
              * over it -- measured: 8 ms for such a round in a 200-view batch.  Wavefronts without an entry end at once.) */
             const unsigned lat_grid = std::min(std::max(std::max(4u * known_lat, (unsigned)nj * std::min(handover, 1024u)), 4096u), 32768u);
             D->optimize(S, 16, lat_grid, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, ds, c->bs.d_work2.p,
-                        nullptr, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr, 0u);
+                        nullptr, c->bs.d_results2.p, n_lat_p, 0u, 0u, 0xFFFFFFFFu, r, c->d_counters, nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr);
             ev.end(S);
             ++n_launch;
         }
@@ -3256,7 +3273,7 @@ static int mi_dmrecon_patch_optimize_impl(mi_dmrecon_ctx* c, const mi_dmrecon_se
     const unsigned ppw = lpv == 16 ? 1u : patches_per_wave(st);
     D.optimize(c->stream, lpv, ((unsigned)n + ppw - 1) / ppw, c->bs.d_jobs.p, c->sc->d_views.p, c->sc->d_lut, dev_settings(st),
                c->bs.d_work.p, c->bs.d_hyp.p, c->bs.d_results.p, nullptr, (unsigned)n, 0u, 0xFFFFFFFFu, 0, c->d_counters,
-               nullptr, nullptr, nullptr, nullptr, 0u);
+               nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr);
     HIP_TRY(hipGetLastError());
     std::vector<DevResult> res(n); std::vector<uint32_t> resx(2 * (size_t)n, 0xFFFFFFFFu);
     HIP_TRY(hipMemcpyAsync(res.data(), c->bs.d_results.p, n * sizeof(DevResult), hipMemcpyDeviceToHost, c->stream));

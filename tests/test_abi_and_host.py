@@ -251,6 +251,39 @@ def test_host_view_selection_is_the_references(g1, g1_scene, h1_scene, w1, w1_sc
             assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
 
 
+def test_view_selection_of_a_bundle_in_several_parts(g1_scene, h1_scene, w1_scene, monkeypatch):
+    """A bundle too large for the dense tables of the whole that falls apart into parts which share no feature (several
+    scenes resident in one context: the bench's distinct-scenes variant) gets tables per connected component
+    (SceneStore::sub).  A reference view's selection and seeds from its component's tables = the direct form on the merged
+    bundle = the restatement on the view's own scene (ids shifted): a view of another part shares no feature with it and is
+    never a candidate (global_view_selection.cc:62-101, :44-52)."""
+    from oracle import oracle as orc
+    from mve_amd.synth import merge_scenes
+    parts = [g1_scene, h1_scene, w1_scene]
+    big = merge_scenes(parts)
+    # (the parts are small: the bound is lowered so that the merged bundle counts as too large, each part does not)
+    nv, nf = len(big.cameras), len(big.features)
+    limit = max(len(p.cameras) ** 2 * len(p.features) for p in parts) + 1
+    assert nv * nv * nf > limit
+    monkeypatch.setenv("MI_DMRECON_DEBUG_TABLE_LIMIT", str(limit))
+    off = 0
+    for part, kw in zip(parts, (dict(), dict(minParallax=4.0), dict(globalVSMax=40))):
+        S = orc.OracleScene(part)
+        n = len(part.cameras)
+        for ref in sorted(set([0, n // 2, n - 1])):
+            okw = dict(global_max=kw.get("globalVSMax", 20))
+            if "minParallax" in kw:
+                okw["minParallax"] = kw["minParallax"]
+            want = [v + off for v in S.global_vs(orc.make_settings(ref_view=ref, **okw))]
+            got_sub = _host_views(big, ref + off, True, **kw)             # tables of the view's component
+            got_dir = _host_views(big, ref + off, False, **kw)            # the direct form
+            assert got_sub == want and got_dir == want, (off, ref)
+            a = api.plan_views_host(big, api.Settings(refViewNr=ref + off, **kw), ref + off, tables=True, seeds=True)
+            b = api.plan_views_host(big, api.Settings(refViewNr=ref + off, **kw), ref + off, tables=False, seeds=True)
+            assert a[0] == b[0] and np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1]) and len(a[2][0]) > 20
+        off += n
+
+
 def test_front_teams_block_map():
     """The block map of a front launch with teams (k_front reads job | member | team size per block): every view has
     exactly its team's members, all on blocks with the same b % n_xcd (one XCD: one L2), an XCD is never asked for more
