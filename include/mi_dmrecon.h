@@ -93,7 +93,8 @@ typedef struct mi_dmrecon_maps {
                          * for nrReconNeighbors <= 4, 8 channels up to 8, 16 above (mi_dmrecon_local_view_channels) */
 } mi_dmrecon_maps;
 
-/* Work counters (device-counted) and timings of the last reconstruct call.  The struct only ever grows at its end, and
+/* Work counters (device-counted) and timings of the last reconstruct call.  The struct only ever grows at its end (from the
+ * layout of mi_dmrecon_abi_version() 5 on: that one put struct_size in front of everything), and
  * it carries its own size: the CALLER sets struct_size = sizeof(mi_dmrecon_stats) of the header it was built with before
  * every call, the library fills min(struct_size, its own sizeof) bytes and writes that number back -- a caller built
  * against an older (shorter) header is never overrun, one built against a newer header sees from struct_size which
@@ -170,6 +171,15 @@ typedef struct mi_dmrecon_stats {
     double  clk_real_mhz;
 } mi_dmrecon_stats;
 
+/* The version of this header's binary interface (MI_DMRECON_ABI_VERSION of the header the library was built from).  It changes
+ * whenever a struct changes in a way `struct_size` cannot express or a function changes its signature: 5 = the layout in which
+ * mi_dmrecon_stats gained `struct_size` as its FIRST member (round 5: every other field moved by 8 bytes -- a caller built against
+ * the header before that must be recompiled; the append-only rule of mi_dmrecon_stats holds from that layout on); 6 = this header
+ * (statistics appended: the per-kernel-template counts, the latency-round and shader-clock fields).  A caller compares it with the
+ * MI_DMRECON_ABI_VERSION it was compiled with: a library that reports less than 5, or that does not export the function, has the
+ * old statistics layout. */
+#define MI_DMRECON_ABI_VERSION 6
+int  mi_dmrecon_abi_version(void);
 int  mi_dmrecon_device_count(void);
 /* channels of mi_dmrecon_maps::views / of the local-view arguments of mi_dmrecon_patch_optimize: 4 or 8 */
 int  mi_dmrecon_local_view_channels(int32_t nrReconNeighbors);

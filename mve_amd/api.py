@@ -24,6 +24,7 @@ from .scene_io import SceneData
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_DMRECON_LIB") or os.path.join(_HERE, "csrc", "libmi_dmrecon.so")   # env: another build of the same ABI
 
+ABI_VERSION = 6                # MI_DMRECON_ABI_VERSION of the header the ctypes mirrors below restate
 MAX_GLOBAL_VIEWS = 128
 MAX_LOCAL_VIEWS = 16
 
@@ -37,7 +38,7 @@ def local_view_channels(n_local: int) -> int:
 E_INVAL, E_GVS, E_DEVICE, E_CANCELLED, E_FOOTPRINT, E_NOIMAGE = -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
-    "mi_dmrecon_device_count", "mi_dmrecon_local_view_channels", "mi_dmrecon_last_error", "mi_dmrecon_settings_default",
+    "mi_dmrecon_abi_version", "mi_dmrecon_device_count", "mi_dmrecon_local_view_channels", "mi_dmrecon_last_error", "mi_dmrecon_settings_default",
     "mi_dmrecon_ctx_create", "mi_dmrecon_ctx_destroy", "mi_dmrecon_ctx_fork", "mi_dmrecon_ctx_stream",
     "mi_dmrecon_host_alloc", "mi_dmrecon_host_free",
     "mi_dmrecon_set_view", "mi_dmrecon_set_view_async", "mi_dmrecon_sync", "mi_dmrecon_evict_view", "mi_dmrecon_set_features",
@@ -119,6 +120,10 @@ def load_library() -> ctypes.CDLL:
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
     L.mi_dmrecon_device_count.restype = ctypes.c_int
+    L.mi_dmrecon_abi_version.restype = ctypes.c_int
+    if L.mi_dmrecon_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s has ABI version %d, mve_amd/api.py mirrors version %d of include/mi_dmrecon.h: rebuild the library"
+                           % (LIB_PATH, L.mi_dmrecon_abi_version(), ABI_VERSION))
     L.mi_dmrecon_last_error.restype = ctypes.c_char_p
     L.mi_dmrecon_settings_default.argtypes = [ctypes.POINTER(CSettings)]
     L.mi_dmrecon_settings_default.restype = None

@@ -61,6 +61,16 @@
 /* wavefronts per SIMD the bulk kernels aim for: width 7 needs 18.8 KB of rays / master colours per wavefront in LDS,
  * which caps the occupancy anyway -- let the compiler use the registers */
 #define MI_BULK_WAVES (MI_FW >= 7 ? 1 : MI_WAVES_PER_SIMD)
+/* Words per footprint record.  -DMI_EMU_LIN48 (an experiment, `make variant`): 12 -- the MEMORY side of a record that would hold
+ * the footprint's bilinear coefficients as twelve f32 (c00, d1, d2, d3 per channel: no table look-up, no differences in the
+ * sampler) instead of four RGBA8 texels: records of 48 bytes, of which the sampler still computes with the first 16 but
+ * gathers all 48 (three 16-byte loads kept alive), so that the arithmetic is unchanged and the run shows what the three-fold
+ * gather costs by itself (profiles/r6_ab_experiments.txt). */
+#ifdef MI_EMU_LIN48
+#define MI_QUAD_WORDS 12
+#else
+#define MI_QUAD_WORDS 4
+#endif
 
 namespace MI_FWNS {
 
@@ -653,7 +663,7 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, co
     const DevLevel& L = V->lv[mm];
     premultiply(nv, L.ax, L.ay, L.cx, L.cy);
     nv.w = L.w; nv.h = L.h;
-    nv.img = V->quad + 4 * (size_t)L.tex_off;      /* 16-byte footprint records of this level */
+    nv.img = V->quad + MI_QUAD_WORDS * (size_t)L.tex_off;      /* 16-byte footprint records of this level */
     return true;
 }
 
@@ -802,7 +812,17 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
 #else
         const unsigned rec = __umul24((unsigned)vc, (unsigned)nv.w) + (unsigned)uc;
 #endif
+#ifdef MI_EMU_LIN48
+        {
+            /* (the other 32 bytes of the 48-byte record: loaded, kept alive, not used) */
+            const u32x4 r1 = *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec + 4), r2 = *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec + 8);
+            u32x4 r0 = *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec);
+            asm volatile("" : "+v"(r0) : "v"(r1), "v"(r2));
+            return r0;
+        }
+#else
         return *(gtex4_t)(nv.img + 4 * (size_t)rec);
+#endif
     };
     auto geom = [&](int it) -> Pre {
         Pre q;
@@ -1317,7 +1337,7 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
         const DevLevel& Lv = DV->lv[mm];
         premultiply(nv, Lv.ax, Lv.ay, Lv.cx, Lv.cy);
         nv.w = Lv.w; nv.h = Lv.h;
-        nv.img = DV->quad + 4 * (size_t)Lv.tex_off;
+        nv.img = DV->quad + MI_QUAD_WORDS * (size_t)Lv.tex_off;
     }
     return true;
 }
@@ -3521,7 +3541,10 @@ __global__ __launch_bounds__(256) void k_quadify(const uint32_t* __restrict__ sr
 #ifdef MI_TILED_QUADS
     dst[(((unsigned)(y >> 3) * ((unsigned)(w + 7) >> 3) + (unsigned)(x >> 3)) << 6) | ((unsigned)(y & 7) << 3) | (unsigned)(x & 7)] = o;
 #else
-    dst[i] = o;
+    dst[(size_t)i * (MI_QUAD_WORDS / 4)] = o;
+#if MI_QUAD_WORDS > 4
+    dst[(size_t)i * (MI_QUAD_WORDS / 4) + 1] = o; dst[(size_t)i * (MI_QUAD_WORDS / 4) + 2] = o;
+#endif
 #endif
 }
 
@@ -3850,6 +3873,7 @@ void mi_launch_unpack_jobs(hipStream_t s, const uint32_t* packed, unsigned words
     hipLaunchKernelGGL(k_unpack_jobs, dim3(words_per_job > 768u ? 4u : (words_per_job + 255u) / 256u, (unsigned)n_jobs), dim3(256), 0, s,
                        packed, words_per_job, reinterpret_cast<uint32_t*>(jobs), (unsigned)(sizeof(DevJob) / 4));
 }
+unsigned mi_quad_words(void) { return MI_QUAD_WORDS; }      /* words per footprint record of this build (the host sizes the views by it) */
 void mi_launch_quadify(hipStream_t s, const uint32_t* src, uint32_t* dst, int w, int h) {
     hipLaunchKernelGGL(k_quadify, dim3((w * h + 255) / 256), dim3(256), 0, s, src, (u32x4*)dst, w, h);
 }

@@ -1074,12 +1074,15 @@ int plan_global_views(mi_dmrecon_ctx* c, const mi_dmrecon_settings* st, int ref,
      * (plx / 10)^2 (:76-79, :91-98) -- comes from the scene's pair cache: the features two views share with their angles,
      * computed once per pair and scene instead of once per selected view, candidate, feature AND reference view (the arc
      * cosines were 5.5 of the 7 ms a reference view of a 400-view bundle took).  Both lists ascend: one walk per pair. */
-    PairCache* pc = nullptr;
+    /* (held for the whole selection: a rebuild of the scene's tables from another context of the scene -- set_view, set_features --
+     * drops the scene's pointer, not the cache this planner is walking) */
+    std::shared_ptr<PairCache> pc_hold;
     {
         std::lock_guard<std::mutex> lock(c->sc->mu);
         if (!c->sc->geom.pairs) c->sc->geom.pairs = std::make_shared<PairCache>();
-        pc = c->sc->geom.pairs.get();
+        pc_hold = c->sc->geom.pairs;
     }
+    PairCache* const pc = pc_hold.get();
     auto factor = [&](float plx) -> float { return plx < st->minParallax ? (plx / 10.f) * (plx / 10.f) : 1.f; };
     /* the parallax of feature `gid` in the pair's list, the cursor moving on (a feature both views are attached to is in it) */
     auto lookup = [&](PairList const& PL, size_t& cur, int gid, int v1, int v2) -> float {
@@ -1393,6 +1396,8 @@ double now_ms() {
 /* =========================================================================== */
 extern "C" {
 
+int mi_dmrecon_abi_version(void) { return MI_DMRECON_ABI_VERSION; }
+
 int mi_dmrecon_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1566,7 +1571,7 @@ static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_ca
     v.n_texels = off;
     /* RGBA8 levels, then (16-byte aligned) the same levels as 2x2 footprint records: 4 + 16 bytes per texel */
     v.quad_off = (off + 3) & ~(size_t)3;
-    HIP_TRY(hipMalloc((void**)&v.d_img, (v.quad_off + 4 * off) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.d_img, (v.quad_off + (size_t)mi_quad_words() * off) * sizeof(uint32_t)));
     /* ensureImages, image_pyramid.cc:55-95: upload, strip alpha / expand grey, then the Gaussian levels */
     const size_t nbytes = (size_t)width * height * channels;
     /* two device staging buffers used alternately: the copy of view i+1 (from pinned memory) can start
@@ -1585,7 +1590,7 @@ static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_ca
     }
     for (size_t l = 0; l < v.levels.size(); ++l) {
         HostLevel const& a = v.levels[l];
-        mi_launch_quadify(c->stream, v.d_img + a.tex_off, v.d_img + v.quad_off + 4 * (size_t)a.tex_off, a.w, a.h);
+        mi_launch_quadify(c->stream, v.d_img + a.tex_off, v.d_img + v.quad_off + (size_t)mi_quad_words() * (size_t)a.tex_off, a.w, a.h);
     }
     HIP_TRY(hipGetLastError());
     if (!async) HIP_TRY(wait_stream(c->stream));

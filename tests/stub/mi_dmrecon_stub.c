@@ -21,6 +21,7 @@ struct mi_dmrecon_ctx { scene* sc; int owner; int device; };
 
 static void level_dims(int w, int h, int level, int* ow, int* oh) { while (level-- > 0) { w = (w + 1) / 2; h = (h + 1) / 2; } *ow = w; *oh = h; }
 
+int mi_dmrecon_abi_version(void) { return MI_DMRECON_ABI_VERSION; }
 int mi_dmrecon_device_count(void) { return 1; }
 int mi_dmrecon_local_view_channels(int32_t k) { return k > 8 ? 16 : k > 4 ? 8 : 4; }
 const char* mi_dmrecon_last_error(void) { return "stub"; }

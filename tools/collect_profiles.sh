@@ -5,7 +5,7 @@
 # tools/summarize_profiles.py turns it into profiles/<tag>_*.
 # --pmc passes are separate runs with --kernel-trace only (never with sys/runtime/hip traces), each under its own timeout: a
 # counter group the hardware cannot collect makes rocprofv3 abort and then hang in its finalisation.
-TAG=${1:-r5}
+TAG=${1:-r6}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -16,8 +16,23 @@ NOX="--no-cpu-baseline --no-one-call --distinct-scenes 0 --no-seed-variant"     
 B1="python $R/bench.py --steps 6 --warmup 1 --repeats 1 --streams 1 --steps-per-call 1 $NOX"
 B3="python $R/bench.py --steps 20 --warmup 5 --repeats 2 $NOX"
 cd /tmp
-timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/s1 -o bench -- $B1 > $R/$OUT/s1.log 2>&1
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/s3 -o bench -- $B3 > $R/$OUT/s3.log 2>&1
+# kernel traces (no --stats: its summary would count the warm-up calls, which run as differently shaped batches) -- cut to the TIMED
+# REGIONS by the k_region_mark dispatches bench.py brackets them with (tools/trace_regions.py), the bench line of the same run next
+# to them, and the roofline fractions recomputed from both (tools/roofline_check.py)
+timeout -s KILL 150 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/s1 -o bench -- $B1 > $R/$OUT/s1.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/s3 -o bench -- $B3 > $R/$OUT/s3.log 2>&1
+cd $R
+for S in s1 s3; do
+  F=$(find $OUT/$S -name "*kernel_trace.csv" | head -1)
+  [ "$S" = s1 ] && ST=6 || ST=20
+  if [ -n "$F" ]; then
+    python tools/trace_regions.py $F $ST --csv=$OUT/${S}_timed_regions_stats.csv > $OUT/${S}_timed_regions.json 2> $OUT/${S}_timed_regions.err
+    grep "^{" $OUT/$S.log | tail -1 > $OUT/${S}_line.json
+    python tools/roofline_check.py $OUT/${S}_timed_regions_stats.csv $OUT/${S}_line.json > $OUT/${S}_roofline_check.md 2> $OUT/${S}_roofline_check.err
+  fi
+done
+tail -8 $OUT/s3_roofline_check.md
+cd /tmp
 # PMC at the plan of the lone call (one step per call, one host thread: 3 calls) ...
 BP="python $R/bench.py --steps 2 --warmup 1 --repeats 1 --streams 1 --steps-per-call 1 $NOX"
 # ... and at the DRIVER's plan: 4 host threads x 5 steps per call = one 400-view batch per region (warm-up: one more)
@@ -32,7 +47,7 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCL
 done
 cd $R
 # keep the merge small: drop the per-dispatch traces of the stats runs (the stats CSV is the summary)
-rm -f $OUT/s1/bench_kernel_trace.csv $OUT/s3/bench_kernel_trace.csv
+find $OUT/s1 $OUT/s3 -name "*kernel_trace.csv" -delete
 find $OUT -name "*_kernel_trace.csv" -path "*pmc*" -delete
 du -sh $OUT
 cat $OUT/bench_driver.json $OUT/bench_1thread.json | cut -c1-300

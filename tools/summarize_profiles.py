@@ -13,7 +13,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 FETCH_CORR = 2.0
@@ -34,9 +34,16 @@ for name, dstname in (("lone_calls.json", "lone_calls.json"), ("valu_rate.txt", 
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, "%s_%s" % (tag, dstname)))
 for s in ("s1", "s3"):
-    f = os.path.join(src, s, "bench_kernel_stats.csv")
-    if os.path.exists(f):
-        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, "1thread_1step" if s == "s1" else "4threads_5steps")))
+    # kernel statistics of the TIMED REGIONS only (tools/trace_regions.py --csv), their per-family summary, the bench line of that
+    # profiled run and the roofline fractions recomputed from the two (tools/roofline_check.py)
+    plan = "1thread_1step" if s == "s1" else "4threads_5steps"
+    for name, dstname in (("%s_timed_regions_stats.csv" % s, "%s_kernel_stats_timed_regions_%s.csv" % (tag, plan)),
+                          ("%s_timed_regions.json" % s, "%s_kernel_regions_%s.json" % (tag, plan)),
+                          ("%s_line.json" % s, "%s_bench_profiled_%s.json" % (tag, plan)),
+                          ("%s_roofline_check.md" % s, "%s_roofline_check%s.md" % (tag, "" if s == "s3" else "_1thread"))):
+        f = os.path.join(src, name)
+        if os.path.exists(f) and os.path.getsize(f):
+            shutil.copy(f, os.path.join(dst, dstname))
 
 
 def short(name):

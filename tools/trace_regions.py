@@ -48,9 +48,11 @@ def family(k):
 
 
 def main():
-    path = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    keep = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    args = [a for a in sys.argv[1:] if not a.startswith("--csv=")]
+    csv_out = next((a[6:] for a in sys.argv[1:] if a.startswith("--csv=")), None)   # --csv=FILE: per-kernel stats of the timed regions
+    path = args[0]
+    steps = int(args[1]) if len(args) > 1 else 20
+    keep = int(args[2]) if len(args) > 2 else 0
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", ""), r.get("Stream_Id", "")))
@@ -61,11 +63,14 @@ def main():
         regions = regions[:keep]
     out = {"trace": path, "steps_per_region": steps, "regions": []}
     tot = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    by_name = collections.defaultdict(lambda: [0, 0, 1 << 62, 0])          # kernel name -> calls, total ns, min, max (timed regions only)
     for (t0, t1) in regions:
         inside = [r for r in rows if r[0] >= t0 and r[1] <= t1]
         fam = collections.defaultdict(lambda: [0, 0.0, 0.0])
         ev = []
         for (a, b, k, q, s) in inside:
+            bn = by_name[k]
+            bn[0] += 1; bn[1] += b - a; bn[2] = min(bn[2], b - a); bn[3] = max(bn[3], b - a)
             f = fam[family(k)]
             f[0] += 1; f[1] += (b - a) / 1e6; f[2] = max(f[2], (b - a) / 1e6)
             ev.append((a, 1)); ev.append((b, -1))
@@ -97,6 +102,13 @@ def main():
                           "no_kernel_running_ms_per_step": sum(r["no_kernel_running_ms"] for r in out["regions"]) / (steps * n),
                           "families_ms_per_step": {k: round(v[1] / (steps * n), 4) for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1])},
                           "families_launches_per_region": {k: v[0] / n for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1])}}
+    if csv_out:
+        # the layout of rocprofv3's own kernel_stats.csv, over the dispatches BETWEEN the region marks only
+        total = sum(v[1] for v in by_name.values()) or 1
+        with open(csv_out, "w") as f:
+            f.write('"Name","Family","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","TimedRegions","StepsPerRegion"\n')
+            for k, v in sorted(by_name.items(), key=lambda kv: -kv[1][1]):
+                f.write('"%s","%s",%d,%d,%.1f,%.2f,%d,%d,%d,%d\n' % (k, family(k), v[0], v[1], v[1] / max(v[0], 1), 100.0 * v[1] / total, v[2], v[3], len(regions), steps))
     print(json.dumps(out, indent=1))
 
 
