@@ -224,6 +224,23 @@ def cpu_baseline(scene, cfg, gpu_maps=None, gpu_maps_last=None, global_views=Non
                     parity["last_timed_call"]["bit_identical_to_first"] = bool(all(
                         np.array_equal(gpu_maps[v][0], gpu_maps_last[v][0]) and np.array_equal(gpu_maps[v][1], gpu_maps_last[v][1]) for v in sample))
                     parity["within_bounds"] = bool(parity["within_bounds"] and pl["within_bounds"])
+            # The same scene directory once through the DROP-IN binary (MVE's unmodified apps/dmrecon linked against the shim,
+            # build/dmrecon_mi; a cold process: HIP start-up, PNG decode, staging, one batch, image hand-back) -- the reference-compatible
+            # entry point.  `value` above is measured through the C ABI WITHOUT a progress array (mve_amd/api.py): calls that meet are
+            # merged and large batches send their maps back as snapshot + changed pixels; the shim passes progress arrays (it batches
+            # its instances itself) and takes neither path.  Run after the reference's maps have been read (it overwrites them).
+            app = os.path.join(ROOT, "build", "dmrecon_mi")
+            if os.path.exists(app) and not big:
+                try:
+                    ra = subprocess.run([app] + cmd[1:-2] + [sdir], check=True, env=env, capture_output=True, text=True, timeout=300)
+                    ms = [float(ln.split()[2].rstrip("ms.").rstrip("ms")) for ln in ra.stdout.splitlines() if ln.startswith("Reconstruction took")]
+                    if ms:
+                        base["drop_in_app_same_scene"] = {
+                            "reconstruction_took_ms": ms[-1], "depth_maps_per_s": 1000.0 * n_sample / ms[-1],
+                            "what": "build/dmrecon_mi (apps/dmrecon unmodified + the mvs::DMRecon shim) on the same scene directory, one cold "
+                                    "process, its own 'Reconstruction took': HIP start-up, PNG decode, staging, the batch, image hand-back"}
+                except (OSError, subprocess.SubprocessError, ValueError) as e:
+                    base["drop_in_app_same_scene"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             return base, parity
         except (OSError, RuntimeError, subprocess.SubprocessError, ValueError) as e:
             # (the restatement below stands in: a bench line with a "port" baseline instead of no line)
@@ -839,6 +856,10 @@ def main():
                        # what `value` batches: every timed step reconstructs the SAME scene's reference views (one resident
                        # scene: a saturated-throughput figure whose concurrent jobs share one image set) ...
                        "distinct_scenes": 1,
+                       # which entry point `value` is measured through (the drop-in binary's own figure: cpu_baseline.drop_in_app_same_scene)
+                       "entry_point": "mi_dmrecon_reconstruct through mve_amd/api.py, no progress array: concurrent calls are merged into one "
+                                      "batch, batches of 48+ views return their maps as snapshot + changed pixels; the mvs::DMRecon shim passes "
+                                      "progress arrays and batches its instances itself (neither path)",
                        # which seeds propagate (MI_DMRECON_SEED_REOPT): the reference's rule unless the environment says otherwise
                        "seed_semantics": {None: "reference (a seed propagates only if re-optimising it raised its confidence; in the seed launch)",
                                           "2": "reference (a seed propagates only if re-optimising it raised its confidence; in the seed launch)",

@@ -697,7 +697,8 @@ struct ColorSums {               /* shifted one-pass sums of the colours of one 
     float ba0, ba1, ba2;         /* sum (m - xbar)(n - s) */
 };
 
-enum { PASS_COLOR = 0, PASS_DEPTH = 1, PASS_NORMAL = 2, PASS_DUMP = 3, PASS_DEPTH_FIXED = 4 };
+enum { PASS_COLOR = 0, PASS_DEPTH = 1, PASS_NORMAL = 2, PASS_DUMP = 3, PASS_DEPTH_FIXED = 4,
+       PASS_DEPTH_FIXED_NC = 5 /* PASS_DEPTH_FIXED without the colour sums: the passes of iterations 1..3, whose NCC nobody asks for */ };
 
 template <int LPV> struct NormalAcc { typedef float type; };     /* 2 terms per lane: float partial sums */
 template <> struct NormalAcc<1> { typedef double type; };          /* 25 terms per lane: accumulate in double as the reference */
@@ -722,6 +723,9 @@ struct GNSums {
  *   PASS_DEPTH  the colour-scale independent sums of optimizeDepthOnly (used when computeColorScale may
  *               still change the scale between this pass and the step: ctor, after a normal step),
  *   PASS_DEPTH_FIXED  optimizeDepthOnly's numerator / denominator directly (colour scale fixed until the step),
+ *   PASS_DEPTH_FIXED_NC  the same WITHOUT the colour sums: the reference first asks for NCCs when its main loop starts
+ *               (patch_optimization.cc:184-192) -- the passes that lead to the depth-only steps of iterations 1, 2, 3 feed no NCC,
+ *               no colour scale and no convergence test (12 of a sample's ~107 VALU instructions, three of a patch's six passes),
  *   PASS_NORMAL the normal equations of optimizeDepthAndNormal (with the current colour scale),
  *   PASS_DUMP   the raw samples (parity hook, L::LPV = 1).
  * The reference samples the same texels twice per Gauss-Newton iteration -- computeNeighColorSamples
@@ -785,6 +789,8 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     f2 PB0 = sp2(0.f), PB1 = sp2(0.f), PB2 = sp2(0.f);
     /* per-channel colour sums are only needed when computeColorScale may follow this pass */
     constexpr bool PER_CHANNEL = (MODE == PASS_COLOR || MODE == PASS_DEPTH);
+    constexpr bool WANT_S = MODE != PASS_DEPTH_FIXED_NC;                         /* the colour sums (NCC, colour scale) */
+    constexpr bool FIXED = MODE == PASS_DEPTH_FIXED || MODE == PASS_DEPTH_FIXED_NC;
 
     constexpr int NITER = (MI_NS + L::LPV - 1) / L::LPV;
     const f2 Ss0 = sp2(S.s0), Ss1 = sp2(S.s1), Ss2 = sp2(S.s2);
@@ -795,8 +801,13 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
      *   fetched before the first is consumed -- one exposed memory latency per pass instead of two;
      *   throughput layout: a whole row of the 5 x 5 window per gather round (see below).
      * geom2() / consume2() are the same for two samples at once, in packed arithmetic. */
+#ifdef MI_EMU_LIN48
+    struct Pre { int i; bool live; float fx, fy, gu, gv; u32x4 t, e1, e2; };
+    struct Pre2 { int i0, i1; f2 wgt, fx, fy, gu, gv; u32x4 tA, tB, eA1, eA2, eB1, eB2; };
+#else
     struct Pre { int i; bool live; float fx, fy, gu, gv; u32x4 t; };
     struct Pre2 { int i0, i1; f2 wgt, fx, fy, gu, gv; u32x4 tA, tB; };
+#endif
     auto record = [&](float uc, float vc) -> u32x4 {
         /* one aligned 16-byte gather = the sample's 2 x 2 texel footprint (DevView::quad).  The L1 processes a
          * gather lane by lane when the lanes' addresses do not form one contiguous run, and that access rate is what
@@ -812,18 +823,16 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
 #else
         const unsigned rec = __umul24((unsigned)vc, (unsigned)nv.w) + (unsigned)uc;
 #endif
-#ifdef MI_EMU_LIN48
-        {
-            /* (the other 32 bytes of the 48-byte record: loaded, kept alive, not used) */
-            const u32x4 r1 = *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec + 4), r2 = *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec + 8);
-            u32x4 r0 = *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec);
-            asm volatile("" : "+v"(r0) : "v"(r1), "v"(r2));
-            return r0;
-        }
-#else
-        return *(gtex4_t)(nv.img + 4 * (size_t)rec);
-#endif
+        return *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec);
     };
+#ifdef MI_EMU_LIN48
+    /* (the other 32 bytes of the 48-byte record: gathered with the first 16, carried to where the sample is consumed -- as twelve
+     * coefficients would be -- and touched there, so that the loads stay in flight as long as the real ones would) */
+    auto record_more = [&](float uc, float vc, int part) -> u32x4 {
+        const unsigned rec = __umul24((unsigned)vc, (unsigned)nv.w) + (unsigned)uc;
+        return *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec + 4 * part);
+    };
+#endif
     auto geom = [&](int it) -> Pre {
         Pre q;
         const int iraw = sub + it * L::LPV;
@@ -854,6 +863,9 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
          * exact) */
         q.fx = __builtin_amdgcn_fractf(uc); q.fy = __builtin_amdgcn_fractf(vc);
         q.t = record(uc, vc);
+#ifdef MI_EMU_LIN48
+        q.e1 = record_more(uc, vc, 1); q.e2 = record_more(uc, vc, 2);
+#endif
         return q;
     };
     auto geom2 = [&](int ita, int itb) -> Pre2 {
@@ -887,9 +899,15 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         q.fx = mk2(__builtin_amdgcn_fractf(uc.x), __builtin_amdgcn_fractf(uc.y));
         q.fy = mk2(__builtin_amdgcn_fractf(vc.x), __builtin_amdgcn_fractf(vc.y));
         q.tA = record(uc.x, vc.x); q.tB = record(uc.y, vc.y);
+#ifdef MI_EMU_LIN48
+        q.eA1 = record_more(uc.x, vc.x, 1); q.eA2 = record_more(uc.x, vc.x, 2); q.eB1 = record_more(uc.y, vc.y, 1); q.eB2 = record_more(uc.y, vc.y, 2);
+#endif
         return q;
     };
     auto consume = [&](const Pre& q) {
+#ifdef MI_EMU_LIN48
+        asm volatile("" : : "v"(q.e1), "v"(q.e2));
+#endif
         const int i = q.i;
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const float fx = q.fx, fy = q.fy, gu = q.gu, gv = q.gv;
@@ -912,6 +930,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             dump_col[3 * i] = n[0]; dump_col[3 * i + 1] = n[1]; dump_col[3 * i + 2] = n[2];
             dump_der[3 * i] = dr[0]; dump_der[3 * i + 1] = dr[1]; dump_der[3 * i + 2] = dr[2];
         } else {
+            if (WANT_S) {
             const float a0 = (n[0] - S.s0) * wgt, a1 = (n[1] - S.s1) * wgt, a2 = (n[2] - S.s2) * wgt;
             Pa0.x += a0; Pa1.x += a1; Pa2.x += a2;
             /* ba: sum m (n - s) here, - xbar sum (n - s) after the loop */
@@ -922,7 +941,8 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
                 Paa0.x += a0 * a0 + a1 * a1 + a2 * a2;
                 Pba0.x += m0 * a0 + m1 * a1 + m2 * a2;
             }
-            if (MODE == PASS_DEPTH_FIXED) {
+            }
+            if (FIXED) {
                 const float g0 = ps.cs0 * dr[0], g1 = ps.cs1 * dr[1], g2 = ps.cs2 * dr[2];
                 Pnum.x += wgt * (g0 * (m0 - ps.cs0 * n[0]) + g1 * (m1 - ps.cs1 * n[1]) + g2 * (m2 - ps.cs2 * n[2]));
                 Pden.x += wgt * (g0 * g0 + g1 * g1 + g2 * g2);
@@ -944,6 +964,9 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         }
     };
     auto consume2 = [&](const Pre2& q) {
+#ifdef MI_EMU_LIN48
+        asm volatile("" : : "v"(q.eA1), "v"(q.eA2), "v"(q.eB1), "v"(q.eB2));
+#endif
         const int i0 = q.i0, i1 = q.i1;
         const f2 fx = q.fx, fy = q.fy, gu = q.gu, gv = q.gv;
         const f2 fxy = fx * fy, gm = gv * fx + gu * fy;
@@ -965,6 +988,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             dump_col[3 * i1] = n[0].y; dump_col[3 * i1 + 1] = n[1].y; dump_col[3 * i1 + 2] = n[2].y;
             dump_der[3 * i1] = dr[0].y; dump_der[3 * i1 + 1] = dr[1].y; dump_der[3 * i1 + 2] = dr[2].y;
         } else {
+            if (WANT_S) {
             f2 a0 = n[0] - Ss0, a1 = n[1] - Ss1, a2 = n[2] - Ss2;
             if (L::LPV != 1) { a0 *= q.wgt; a1 *= q.wgt; a2 *= q.wgt; }      /* dead trips (L::LPV > 1 only) contribute nothing */
             Pa0 += a0; Pa1 += a1; Pa2 += a2;
@@ -975,7 +999,8 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
                 Paa0 += a0 * a0 + a1 * a1 + a2 * a2;
                 Pba0 += m0 * a0 + m1 * a1 + m2 * a2;
             }
-            if (MODE == PASS_DEPTH_FIXED) {
+            }
+            if (FIXED) {
                 const f2 g0 = Cs0 * dr[0], g1 = Cs1 * dr[1], g2 = Cs2 * dr[2];
                 f2 tn = g0 * (m0 - Cs0 * n[0]) + g1 * (m1 - Cs1 * n[1]) + g2 * (m2 - Cs2 * n[2]);
                 f2 td = g0 * g0 + g1 * g1 + g2 * g2;
@@ -1030,7 +1055,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
     }
     /* the two halves of a pair accumulator (the throughput layout only ever used half x) */
     auto hs = [](f2 p) -> float { return L::LPV == 1 ? p.x : p.x + p.y; };
-    if (MODE != PASS_DUMP) {
+    if (MODE != PASS_DUMP && WANT_S) {
         S.a0 = L::view_sum(hs(Pa0)); S.a1 = L::view_sum(hs(Pa1)); S.a2 = L::view_sum(hs(Pa2));
         S.aa0 = L::view_sum(hs(Paa0)); S.ba0 = L::view_sum(hs(Pba0));
         if (PER_CHANNEL) {
@@ -1041,7 +1066,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             S.ba0 -= ps.xbar0 * S.a0 + ps.xbar1 * S.a1 + ps.xbar2 * S.a2;
         cs_out = S;
     }
-    if (MODE == PASS_DEPTH_FIXED) { gn.num = L::view_sum(hs(Pnum)); gn.den = L::view_sum(hs(Pden)); }
+    if (FIXED) { gn.num = L::view_sum(hs(Pnum)); gn.den = L::view_sum(hs(Pden)); }
     if (MODE == PASS_DEPTH) {
         gn.dr0 = L::view_sum(hs(Pdr0)); gn.dr1 = L::view_sum(hs(Pdr1)); gn.dr2 = L::view_sum(hs(Pdr2));
         gn.dn0 = L::view_sum(hs(Pdn0)); gn.dn1 = L::view_sum(hs(Pdn1)); gn.dn2 = L::view_sum(hs(Pdn2));
@@ -1356,7 +1381,7 @@ __device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevVie
         TSTAMP(52);
         if (okv) okv = sample_pass<MODE, L>(ps, vc.nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
         ps.n_pass++;
-        if (okv) {
+        if (okv && MODE != PASS_DEPTH_FIXED_NC) {
             ps.ncc = ncc_from_sums(ps, S);
             if (count_color) ps.n_eval++;
         }
@@ -1580,6 +1605,10 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     bool okv;
     TSTAMP(20 + R.need);
     if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    /* (the passes behind the depth-only steps of iterations 1..3: nobody asks for their NCC -- the reference's main loop, which
+     * does, starts at iteration 4, patch_optimization.cc:177-192 --, so they carry no colour sums) */
+    else if (R.need == PASS_DEPTH_FIXED && R.ctx == CTX_FIRST4 && !R.count_color)
+        okv = run_pass<PASS_DEPTH_FIXED_NC, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, false, sub);
     else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
     else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
     else okv = run_pass<PASS_COLOR, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
@@ -1674,8 +1703,11 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
         R.ctx = CTX_FIRST4;
         R.count_color = (R.iter == 4);             /* the reference first asks for NCCs when the main loop starts */
     } else {
-        /* after a normal step computeColorScale follows: that pass must carry per-channel colour sums */
-        R.need = R.step_was_normal ? PASS_DEPTH : (((R.iter + 1) % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED);
+        /* after a normal step computeColorScale follows: that pass must carry per-channel colour sums -- and it is a COLOUR pass:
+         * 94 % of the patches converge right there (their sixth and last pass), and a patch that goes on runs the pass of its
+         * next step with the new colour scale baked in (the REPASS below: optimizeDepthOnly's sums as the reference forms them,
+         * patch_optimization.cc:283-290) instead of carrying colour-scale independent Gauss-Newton sums through every such pass */
+        R.need = R.step_was_normal ? PASS_COLOR : (((R.iter + 1) % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED);
         R.ctx = CTX_STEP;
         R.count_color = true;
     }

@@ -3129,8 +3129,12 @@ static int mi_dmrecon_reconstruct_impl(mi_dmrecon_ctx* c, const mi_dmrecon_setti
             Q.gathering = true;                              /* (nobody else starts to lead meanwhile) */
             /* ... until the window has run out, or every call that can come is there (MergeQueue::expect; the four callers of
              * the bench's plan arrive within a few hundred microseconds of each other: the rest of the 3 ms was 1 % of a batch) */
+            /* (test hook MI_DMRECON_DEBUG_MERGE_WAIT_FOR=<calls>: the leader gathers until that many calls -- its own included, of
+             * any settings -- are there, or the window runs out: a deterministic batch for tests/test_gpu_parity.py) */
+            const int WAIT_FOR = [] { const char* e = std::getenv("MI_DMRECON_DEBUG_MERGE_WAIT_FOR"); return e ? std::atoi(e) : 0; }();
             (void)Q.cv.wait_for(lock, std::chrono::microseconds(WINDOW_US),
-                                [&] { return Q.expect > 1 && (int)Q.pending.size() + 1 >= Q.expect - Q.running_calls; });
+                                [&] { return WAIT_FOR > 0 ? (int)Q.pending.size() + 1 >= WAIT_FOR
+                                                          : (Q.expect > 1 && (int)Q.pending.size() + 1 >= Q.expect - Q.running_calls); });
             Q.gathering = false;
         }
         /* take every pending request with my settings, in arrival order.  Measured and dropped: taking only half of them

@@ -16,6 +16,7 @@ queue order is median 3.5e-4 / p99 2.3e-3 relative depth, fill IoU 0.9999):
       confidence abs diff median <= 1e-3, p99 <= 5e-3
   pyramid: byte-exact; global view selection: identical
 """
+import os
 import numpy as np
 import pytest
 
@@ -608,6 +609,24 @@ def test_concurrent_calls_are_merged_and_keep_their_own_results(gpu_ctx, g1_scen
         # call, whose two or more followers then do
         assert max(served) <= 5 and followers >= 1 and (rep == 0 or max(served) >= 3 or followers >= 2), (rep, served, followers)
         assert out[4][2]["n_merged_calls"] <= 1                                   # other settings: its own batch
+    # ... and deterministically: the leader gathers until all six calls are there (test hook; the window is 50 ms) -- the five calls
+    # with equal settings are ONE batch: the leader shows five served calls, or -- if the failing call leads, which shows no
+    # statistics -- all four others are followers
+    monkeypatch.setenv("MI_DMRECON_DEBUG_MERGE_WAIT_FOR", str(len(plans)))
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(plans))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    monkeypatch.delenv("MI_DMRECON_DEBUG_MERGE_WAIT_FOR")
+    ok5 = [o for i, o in enumerate(out) if i != 4 and o[0] == "ok"]
+    served = sorted(o[2]["n_merged_calls"] for o in ok5)
+    followers = sum(o[2]["merged_into_other_call"] for o in ok5)
+    if out[4][2]["n_merged_calls"] == 1:          # (unless the call with other settings happened to lead the gathering: then the five
+        assert (served[-1] == 5 and followers == 3) or (served[-1] == 0 and followers == 4), (served, followers)   # form by themselves)
+    for i in (0, 1, 2, 5):
+        for v, r in zip(plans[i][1], out[i][1]):
+            if v != 4:
+                for k in ("depth", "conf", "dz"):
+                    assert np.array_equal(r[k], alone[v][k]), (i, v, k)
     monkeypatch.setenv("MI_DMRECON_MERGE_CALLS", "0")
     ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(plans))]
     [t.start() for t in ths]
@@ -672,7 +691,10 @@ def test_maps_vs_reference_scale1_odd(gpu_ctx, g1b, g1b_scene):
     # relative depth p99 on this fixture (161 x 120 at scale 1): the reference ALGORITHM against itself under six other queue
     # orders (the restatement, ORC_QUEUE_ORDER = reverse / random:1-3 / jitter:1-2) reaches 4.2e-3 ... 6.1e-3 -- the general
     # 5e-3 sits inside that spread here; bound at 1.5 x the worst of them
-    assert_map_parity(map_parity(r["depth"], r["conf"], g1b["s1v2_depth"], g1b["s1v2_conf"]), rel_p99=9e-3)
+    m = map_parity(r["depth"], r["conf"], g1b["s1v2_depth"], g1b["s1v2_conf"])
+    if os.environ.get("MI_TEST_PRINT"):
+        print("G1b scale 1 view 2:", m)
+    assert_map_parity(m, rel_p99=9e-3)
 
 
 def test_two_views_local_neighbors_1(gpu_ctx, g2, g2_scene):
