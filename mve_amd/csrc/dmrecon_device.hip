@@ -908,6 +908,22 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
 #ifdef MI_EMU_LIN48
         asm volatile("" : : "v"(q.e1), "v"(q.e2));
 #endif
+#ifdef MI_EXTRA_LDS
+        /* experiment (make variant VFLAGS=-DMI_EXTRA_LDS=6): that many more look-ups in the sRGB table per sample (addresses as
+         * scattered as the real ones), their values thrown away -- is it the LDS the throughput layout waits for? */
+        {
+#pragma unroll
+          for (int k = 0; k < MI_EXTRA_LDS; ++k) { const float xl = s_lut[(q.t.x >> (3 + k)) & 255u]; asm volatile("" : : "v"(xl)); }
+        }
+#endif
+#ifdef MI_EXTRA_VALU
+        /* experiment (make variant VFLAGS=-DMI_EXTRA_VALU=12): that many VALU instructions per sample that compute nothing -- is the
+         * throughput layout's time the time of its VALU instructions? */
+        { float dummy = q.fx;
+#pragma unroll
+          for (int k = 0; k < MI_EXTRA_VALU; ++k) asm volatile("v_mov_b32 %0, %0" : "+v"(dummy));
+        }
+#endif
         const int i = q.i;
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const float fx = q.fx, fy = q.fy, gu = q.gu, gv = q.gv;
@@ -1703,11 +1719,14 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
         R.ctx = CTX_FIRST4;
         R.count_color = (R.iter == 4);             /* the reference first asks for NCCs when the main loop starts */
     } else {
-        /* after a normal step computeColorScale follows: that pass must carry per-channel colour sums -- and it is a COLOUR pass:
-         * 94 % of the patches converge right there (their sixth and last pass), and a patch that goes on runs the pass of its
-         * next step with the new colour scale baked in (the REPASS below: optimizeDepthOnly's sums as the reference forms them,
-         * patch_optimization.cc:283-290) instead of carrying colour-scale independent Gauss-Newton sums through every such pass */
-        R.need = R.step_was_normal ? PASS_COLOR : (((R.iter + 1) % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED);
+        /* after a normal step computeColorScale follows: that pass must carry per-channel colour sums.  In the LATENCY layouts it is
+         * a COLOUR pass: 94 % of the patches converge right there (their sixth and last pass: a third fewer instructions in it),
+         * and a patch that goes on runs the pass of its next step with the new colour scale baked in (the REPASS above:
+         * optimizeDepthOnly's sums as the reference forms them, patch_optimization.cc:283-290).  In the THROUGHPUT layouts it stays a
+         * depth pass with colour-scale independent Gauss-Newton sums: a wavefront's 16 patches run in lockstep and two waves in
+         * three hold a patch that goes on -- the extra pass of that one patch would cost the wavefront more than the lighter pass
+         * of the fifteen others saves (measured: no gain from both changes together, profiles/r6_ab_experiments.txt G). */
+        R.need = R.step_was_normal ? (L::LAT ? PASS_COLOR : PASS_DEPTH) : (((R.iter + 1) % 5 == 4) ? PASS_NORMAL : PASS_DEPTH_FIXED);
         R.ctx = CTX_STEP;
         R.count_color = true;
     }

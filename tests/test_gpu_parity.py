@@ -690,11 +690,12 @@ def test_maps_vs_reference_scale1_odd(gpu_ctx, g1b, g1b_scene):
     assert r["depth"].shape == g1b["s1v2_depth"].shape
     # relative depth p99 on this fixture (161 x 120 at scale 1): the reference ALGORITHM against itself under six other queue
     # orders (the restatement, ORC_QUEUE_ORDER = reverse / random:1-3 / jitter:1-2) reaches 4.2e-3 ... 6.1e-3 -- the general
-    # 5e-3 sits inside that spread here; bound at 1.5 x the worst of them
+    # 5e-3 sits inside that spread here.  Measured (round 6): 5.04e-3; bound at 1.2 x that -- a regression that doubles the depth
+    # error does not pass (round 5 had 9e-3 = 1.5 x the worst order probe here)
     m = map_parity(r["depth"], r["conf"], g1b["s1v2_depth"], g1b["s1v2_conf"])
     if os.environ.get("MI_TEST_PRINT"):
         print("G1b scale 1 view 2:", m)
-    assert_map_parity(m, rel_p99=9e-3)
+    assert_map_parity(m, rel_p99=6.2e-3)
 
 
 def test_two_views_local_neighbors_1(gpu_ctx, g2, g2_scene):
