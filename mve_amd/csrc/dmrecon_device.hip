@@ -1048,6 +1048,51 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
          * cache lines fetched once, five gathers in flight).  One sample at a time: in this layout the packed form measured
          * SLOWER (profiles/r5_ab_experiments.txt P: three wavefronts per SIMD already fill the issue slots, a packed
          * instruction costs more than half of two plain ones, and the register pairs spill) */
+#ifdef MI_TOUCH_ROWS
+        /* experiment: the cache lines of the window's LATER rows are asked for before the first row is sampled -- one 4-byte load at
+         * the middle sample of each of those rows, its value thrown away at the end of the pass: the rows' own 16-byte gathers then
+         * find their lines on the way or there.  (What the throughput layout waits for, r6_ab_experiments.txt H: neither its VALU
+         * instructions nor the LDS -- 24 more of the one, 6 more look-ups of the other per sample cost nothing / 5 % -- but the
+         * slowest line of every row's gathers.) */
+        uint32_t touch[MI_FW];
+        touch[0] = 0u;
+#pragma unroll
+        for (int row = 1; row < MI_FW; ++row) {
+            const int i = row * MI_FW + MI_HALF;
+            const float fj = (float)(row - MI_HALF);
+            const float lam = (ps.depth + fj * ps.dzJ) * geo[i];
+            const float vx = nv.ax + fj * nv.dx, vy = nv.ay + fj * nv.dy, vz = nv.az + fj * nv.dz;
+            const float iz = fast_rcp(nv.sz + lam * vz);
+            const float uc = __builtin_amdgcn_fmed3f((nv.sx + lam * vx) * iz - 0.5f, kLo, wlim), vc = __builtin_amdgcn_fmed3f((nv.sy + lam * vy) * iz - 0.5f, kLo, hlim);
+            touch[row] = GU(nv.img + MI_QUAD_WORDS * (size_t)(__umul24((unsigned)vc, (unsigned)nv.w) + (unsigned)uc));
+        }
+#endif
+#ifdef MI_ROW2
+        /* experiment: the gathers of the NEXT row are issued before this row's samples are consumed (ten in flight instead of five;
+         * needs the registers of two wavefronts per SIMD: -DMI_WAVES_PER_SIMD=2) */
+        {
+            Pre qa[MI_FW], qb[MI_FW];
+#pragma unroll
+            for (int k = 0; k < MI_FW; ++k) qa[k] = geom(k);
+#pragma unroll 1
+            for (int row = 0; row < MI_FW; row += 2) {
+                if (row + 1 < MI_FW) {
+#pragma unroll
+                    for (int k = 0; k < MI_FW; ++k) qb[k] = geom((row + 1) * MI_FW + k);
+                }
+#pragma unroll
+                for (int k = 0; k < MI_FW; ++k) consume(qa[k]);
+                if (row + 2 < MI_FW) {
+#pragma unroll
+                    for (int k = 0; k < MI_FW; ++k) qa[k] = geom((row + 2) * MI_FW + k);
+                }
+                if (row + 1 < MI_FW) {
+#pragma unroll
+                    for (int k = 0; k < MI_FW; ++k) consume(qb[k]);
+                }
+            }
+        }
+#else
 #pragma unroll 1
         for (int row = 0; row < MI_FW; ++row) {
             Pre q[MI_FW];
@@ -1056,6 +1101,11 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
 #pragma unroll
             for (int k = 0; k < MI_FW; ++k) consume(q[k]);
         }
+#endif
+#ifdef MI_TOUCH_ROWS
+#pragma unroll
+        for (int row = 1; row < MI_FW; ++row) asm volatile("" : : "v"(touch[row]));
+#endif
     } else {
         constexpr int NP = NITER / 2;
         Pre2 q[NP > 0 ? NP : 1];
