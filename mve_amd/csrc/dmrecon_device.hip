@@ -68,6 +68,11 @@
  * gather costs by itself (profiles/r6_ab_experiments.txt). */
 #ifdef MI_EMU_LIN48
 #define MI_QUAD_WORDS 12
+#elif defined(MI_PAIR_RECORDS)
+/* Column pairs: element (x, y) = texels (x, y), (x, y + 1) -- 8 bytes; a sample's 2 x 2 footprint = elements x and x + 1 = ONE 16-byte
+ * gather from an 8-byte aligned address.  Half the bytes per texel position of the 16-byte footprint records (every texel twice instead
+ * of four times): the footprints of a wavefront's 16 neighbouring patches cover half as many cache lines. */
+#define MI_QUAD_WORDS 2
 #else
 #define MI_QUAD_WORDS 4
 #endif
@@ -823,7 +828,17 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
 #else
         const unsigned rec = __umul24((unsigned)vc, (unsigned)nv.w) + (unsigned)uc;
 #endif
+#ifdef MI_PAIR_RECORDS
+        {
+            /* (x, y) (x, y+1) (x+1, y) (x+1, y+1) as they lie in memory -> the order the sampler names them in: x = (x, y), y = (x+1, y),
+             * z = (x, y+1), w = (x+1, y+1) */
+            const u32x4 r = *(gtex4u_t)(nv.img + MI_QUAD_WORDS * (size_t)rec);
+            u32x4 o; o.x = r.x; o.y = r.z; o.z = r.y; o.w = r.w;
+            return o;
+        }
+#else
         return *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec);
+#endif
     };
 #ifdef MI_EMU_LIN48
     /* (the other 32 bytes of the 48-byte record: gathered with the first 16, carried to where the sample is consumed -- as twelve
@@ -3641,6 +3656,8 @@ __global__ __launch_bounds__(256) void k_quadify(const uint32_t* __restrict__ sr
     o.x = src[y * w + x]; o.y = src[y * w + x1]; o.z = src[y1 * w + x]; o.w = src[y1 * w + x1];
 #ifdef MI_TILED_QUADS
     dst[(((unsigned)(y >> 3) * ((unsigned)(w + 7) >> 3) + (unsigned)(x >> 3)) << 6) | ((unsigned)(y & 7) << 3) | (unsigned)(x & 7)] = o;
+#elif defined(MI_PAIR_RECORDS)
+    reinterpret_cast<uint32_t*>(dst)[2 * (size_t)i] = o.x; reinterpret_cast<uint32_t*>(dst)[2 * (size_t)i + 1] = o.z;   /* (x, y), (x, y + 1) */
 #else
     dst[(size_t)i * (MI_QUAD_WORDS / 4)] = o;
 #if MI_QUAD_WORDS > 4
