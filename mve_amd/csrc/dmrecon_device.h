@@ -127,7 +127,7 @@ void mi_launch_round_report(hipStream_t s, const unsigned* a, int n_a, const uns
 void mi_launch_unpack_jobs(hipStream_t s, const uint32_t* packed, unsigned words_per_job, DevJob* jobs, int n_jobs);
 /* an empty one-lane kernel: where profiles are cut (mi_dmrecon_debug_region_mark) */
 void mi_launch_region_mark(hipStream_t s, unsigned tag);
-unsigned mi_quad_words(void);     /* 32-bit words per footprint record (4; 12 in the -DMI_EMU_LIN48 experiment build) */
+unsigned mi_quad_words(void);     /* 32-bit words per footprint element (2: column pairs; 4 / 12 in the -DMI_QUAD_RECORDS / -DMI_EMU_LIN48 experiment builds) */
 /* the first follow-up list of a round from the masks of its first launch, in list order (k_follow_count + k_follow_scatter);
  * blk_sum: 1024 words of scratch; acts like the launches of the round only if min_work <= *n_work_ptr < max_work */
 void mi_launch_follow_compact(hipStream_t s, const unsigned long long* mask, const unsigned* n_work_ptr, unsigned min_work, unsigned max_work,

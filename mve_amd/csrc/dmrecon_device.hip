@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <type_traits>
 
 #include "dmrecon_types.h"
 #include "dmrecon_device.h"
@@ -68,13 +69,18 @@
  * gather costs by itself (profiles/r6_ab_experiments.txt). */
 #ifdef MI_EMU_LIN48
 #define MI_QUAD_WORDS 12
-#elif defined(MI_PAIR_RECORDS)
-/* Column pairs: element (x, y) = texels (x, y), (x, y + 1) -- 8 bytes; a sample's 2 x 2 footprint = elements x and x + 1 = ONE 16-byte
- * gather from an 8-byte aligned address.  Half the bytes per texel position of the 16-byte footprint records (every texel twice instead
- * of four times): the footprints of a wavefront's 16 neighbouring patches cover half as many cache lines. */
-#define MI_QUAD_WORDS 2
-#else
+#elif defined(MI_QUAD_RECORDS)
+/* the layout of rounds 2-5 (an experiment build now): one 16-byte record per texel position = its 2 x 2 footprint, every texel
+ * four times */
 #define MI_QUAD_WORDS 4
+#else
+/* Column pairs (the default since round 6): element (x, y) = texels (x, y), (x, y + 1) -- 8 bytes; a sample's 2 x 2 footprint =
+ * elements x and x + 1 of row y = ONE 16-byte gather from an 8-byte aligned address.  Half the bytes per texel position of the
+ * 16-byte footprint records (every texel twice instead of four times): the footprints of a wavefront's 16 neighbouring patches cover
+ * half as many cache lines, and that -- the lines a wavefront's gathers touch in the vector L1 -- is what the throughput layout's
+ * time goes with (profiles/r6_ab_experiments.txt D, I, J: bulk kernels - 4 %, a view's images 12 instead of 20 bytes per texel). */
+#define MI_PAIR_RECORDS 1
+#define MI_QUAD_WORDS 2
 #endif
 
 namespace MI_FWNS {
@@ -124,6 +130,28 @@ __device__ __forceinline__ void probe_stamp(unsigned id) {
 __shared__ float g_lut[256];                                   /* sRGB -> linear, mvs_tools.cc:22-93 */
 __shared__ float g_geo[MI_PATCHES_PER_WAVE][MI_NS];            /* 1 / |K^-1 (pixel of sample i)|: the unit-ray scale of PatchSampler::masterViewDirs */
 __shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::masterColorSamples */
+#ifdef MI_LDS_WINDOW
+/*
+ * LDS windows (north_star: "neighbour-view pixels staged through LDS"; an experiment build, `make variant VFLAGS=-DMI_LDS_WINDOW`).
+ * A wavefront of the throughput layout holds 16 neighbouring patches x 4 view slots; the 25 x 16 footprints a pass gathers from one
+ * neighbour image lie in a box of a few hundred texels.  Per pass and view slot the wavefront's active lanes find that box (the four
+ * window corners of every patch, reduced with LDS atomics -- the lanes of a pass are an arbitrary subset of the wavefront), copy it
+ * from the level's plain RGBA8 plane into a tile of MI_WIN_TP x MI_WIN_TH texels with coalesced 16-byte loads, and the samples read
+ * their 2 x 2 footprints from the tile (two ds_read2_b32) instead of gathering them from memory.  Whenever the four slots' patches do
+ * not share one image and level each, a box does not fit, or a sample falls outside its box (the box comes from the corners), the
+ * pass runs on the global gathers -- decided per wavefront and pass; same texels, same arithmetic, same bits either way.
+ */
+#ifndef MI_WIN_TP
+#define MI_WIN_TP 28          /* tile pitch = largest box width, texels (a multiple of 4: rows are filled in 16-byte pieces) */
+#endif
+#ifndef MI_WIN_TH
+#define MI_WIN_TH 24          /* largest box height */
+#endif
+__shared__ __attribute__((aligned(16))) uint32_t g_win[4][MI_WIN_TH * MI_WIN_TP];
+__shared__ __attribute__((aligned(16))) int g_wbox[4][4];          /* per view slot: min x, min y, max x, max y (texel indices, inclusive) */
+__shared__ __attribute__((aligned(16))) unsigned g_wimg[4][4];     /* per view slot: the level's plane (address lo, hi), its width, unused */
+__shared__ unsigned g_wstat[2];                                    /* passes of this workgroup that ran on windows / that fell back */
+#endif
 /* LocalViewSelection ncc[] of the throughput layouts: L::PATCHES x DevSettings::ncc_stride floats of DYNAMIC shared memory, sized
  * by the launcher -- 64 per patch unless globalVSMax asks for more (MI_MAX_GLOBAL = 128): the 4 KB a wavefront of 16 patches has
  * always had; 8 KB per wavefront would cost the general kernels a wavefront per SIMD (160 KB per CU, 12 wavefronts) */
@@ -617,7 +645,10 @@ struct NView {                   /* my neighbour view at the selected mip level 
     float bx, by, bz;            /* B: one pixel to the right */
     float dx, dy, dz;            /* D: one pixel down */
     int w, h;
-    const uint32_t* img;         /* 16-byte footprint records of the level (DevView::quad) */
+    const uint32_t* img;         /* footprint elements of the level (DevView::quad) */
+#ifdef MI_LDS_WINDOW
+    const uint32_t* raw;         /* the level's plain RGBA8 texels (DevView::img): what a wavefront's LDS windows are filled from */
+#endif
 };
 
 /* fold the level's calibration into rows 0, 1: x' = ax.x + cx.z, y' = ay.y + cy.z */
@@ -668,7 +699,10 @@ __device__ __forceinline__ bool setup_view(const DevView* __restrict__ views, co
     const DevLevel& L = V->lv[mm];
     premultiply(nv, L.ax, L.ay, L.cx, L.cy);
     nv.w = L.w; nv.h = L.h;
-    nv.img = V->quad + MI_QUAD_WORDS * (size_t)L.tex_off;      /* 16-byte footprint records of this level */
+    nv.img = V->quad + MI_QUAD_WORDS * (size_t)L.tex_off;      /* footprint elements of this level */
+#ifdef MI_LDS_WINDOW
+    nv.raw = V->img + L.tex_off;
+#endif
     return true;
 }
 
@@ -690,6 +724,9 @@ struct ViewC {
 __device__ __forceinline__ void viewc_reset(ViewC& vc) {
     vc.sel = -2; vc.lvl = -1; vc.V = nullptr; vc.inv0 = 0.f; vc.maxl = 0;
     vc.nv.w = 0; vc.nv.h = 0; vc.nv.img = nullptr;
+#ifdef MI_LDS_WINDOW
+    vc.nv.raw = nullptr;
+#endif
     vc.nv.sx = vc.nv.sy = vc.nv.sz = vc.nv.ax = vc.nv.ay = vc.nv.az = 0.f;
     vc.nv.bx = vc.nv.by = vc.nv.bz = vc.nv.dx = vc.nv.dy = vc.nv.dz = 0.f;
 }
@@ -721,6 +758,72 @@ struct GNSums {
     double A00, A01, A02, A11, A12, A22, B0, B1, B2;   /* optimizeDepthAndNormal (:312-343), colour scale baked in */
 };
 
+#ifdef MI_LDS_WINDOW
+struct Win { int x0, y0; unsigned limx, limy; const uint32_t* tile; };
+/* Builds the LDS windows of the pass the calling lanes are about to run (see g_win).  Called by an arbitrary subset of a
+ * wavefront's lanes; returns the same value in all of them: true = every caller's samples can be read from its slot's tile. */
+__device__ __forceinline__ bool window_build(const PatchState& ps, const NView& nv, const float* __restrict__ geo, int lane, Win& W) {
+    const int slot = lane & 3;
+    const unsigned long long act = __ballot(true);
+    const float wlim = __uint_as_float(__float_as_uint((float)(nv.w - 1)) - 1u), hlim = __uint_as_float(__float_as_uint((float)(nv.h - 1)) - 1u);
+    constexpr float kLo = 1.17549435e-38f;
+    float umin = 3.0e38f, vmin = 3.0e38f, umax = 0.f, vmax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int di = (c & 1) ? MI_HALF : -MI_HALF, dj = (c & 2) ? MI_HALF : -MI_HALF;
+        const int i = (dj + MI_HALF) * MI_FW + (di + MI_HALF);
+        const float fi = (float)di, fj = (float)dj;
+        const float lam = (ps.depth + fi * ps.dzI + fj * ps.dzJ) * geo[i];
+        const float vx = nv.ax + fi * nv.bx + fj * nv.dx, vy = nv.ay + fi * nv.by + fj * nv.dy, vz = nv.az + fi * nv.bz + fj * nv.dz;
+        const float iz = fast_rcp(nv.sz + lam * vz);
+        const float u = __builtin_amdgcn_fmed3f((nv.sx + lam * vx) * iz - 0.5f, kLo, wlim), v = __builtin_amdgcn_fmed3f((nv.sy + lam * vy) * iz - 0.5f, kLo, hlim);
+        umin = fminf(umin, u); umax = fmaxf(umax, u); vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+    }
+    /* texel indices, inclusive, one texel of margin (the box of the corners is the box of the window only as far as the patch
+     * projects as a plane; the unit-ray scales bend it by a fraction of a texel); x + 1 / y + 1 = the footprint's far side */
+    int x0 = (int)umin - 1, y0 = (int)vmin - 1, x1 = (int)umax + 2, y1 = (int)vmax + 2;
+    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > nv.w - 1 ? nv.w - 1 : x1; y1 = y1 > nv.h - 1 ? nv.h - 1 : y1;
+    /* the slot's box and image over the calling lanes */
+    const int4 init = make_int4(0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000);
+    *reinterpret_cast<int4*>(g_wbox[slot]) = init;
+    const unsigned rlo = (unsigned)(uintptr_t)nv.raw, rhi = (unsigned)((uintptr_t)nv.raw >> 32);
+    *reinterpret_cast<uint4*>(g_wimg[slot]) = make_uint4(rlo, rhi, (unsigned)nv.w, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    atomicMin(&g_wbox[slot][0], x0); atomicMin(&g_wbox[slot][1], y0); atomicMax(&g_wbox[slot][2], x1); atomicMax(&g_wbox[slot][3], y1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int4 box = *reinterpret_cast<const int4*>(g_wbox[slot]);
+    const uint4 im = *reinterpret_cast<const uint4*>(g_wimg[slot]);
+    const int bw = box.z - box.x + 1, bh = box.w - box.y + 1;
+    const bool bad = im.x != rlo || im.y != rhi || im.z != (unsigned)nv.w || bw > MI_WIN_TP || bh > MI_WIN_TH;
+    if (__ballot(bad) != 0ull) return false;
+    /* fill: eight lanes per tile row, 16 bytes each (a row's last piece may reach past the box: it stays inside the pitch, and
+     * inside the view's allocation -- the footprint elements follow the planes) */
+    const unsigned nact = (unsigned)__popcll(act);
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+    const unsigned rstep = nact >= 8u ? nact >> 3 : 1u;
+    const unsigned c4 = (rank & 7u) * 4u;
+    const bool filler = rank < rstep * 8u;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        if (!(act & (0x1111111111111111ull << sl))) continue;               /* no caller has a view in this slot */
+        const int4 b = *reinterpret_cast<const int4*>(g_wbox[sl]);
+        const uint4 m = *reinterpret_cast<const uint4*>(g_wimg[sl]);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(((uintptr_t)m.y << 32) | (uintptr_t)m.x);
+        const int sw = (int)m.z, sbw = b.z - b.x + 1, sbh = b.w - b.y + 1;
+        if (filler && (int)c4 < sbw) {
+            for (unsigned r = rank >> 3; (int)r < sbh; r += rstep) {
+                const u32x4 t = *(gtex4u_t)(src + (size_t)(b.y + (int)r) * (size_t)sw + (size_t)(b.x + (int)c4));
+                *reinterpret_cast<u32x4*>(&g_win[sl][r * MI_WIN_TP + c4]) = t;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    W.x0 = box.x; W.y0 = box.y; W.limx = (unsigned)(bw - 2); W.limy = (unsigned)(bh - 2);
+    W.tile = g_win[slot];
+    return true;
+}
+#endif
+
 /*
  * One pass over the 25 samples of my view (split over the L::LPV lanes of my view slot) at the current
  * patch state.  It always yields the colour sums that getFastNCC / computeColorScale need
@@ -738,7 +841,7 @@ struct GNSums {
  * mvs_tools.cc:97-145); one fused pass here gathers them once.
  * Returns PatchSampler::success[v]; sums are complete (reduced over the view slot) on return.
  */
-template <int MODE, class L>
+template <int MODE, class L, bool WIN = false>
 __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& nv, const float* __restrict__ s_lut,
                                             const float* __restrict__ geo, const float* __restrict__ mcol,
                                             ColorSums& cs_out, GNSums& gn, float* dump_col, float* dump_der, int sub) {
@@ -848,7 +951,19 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         return *(gtex4_t)(nv.img + MI_QUAD_WORDS * (size_t)rec + 4 * part);
     };
 #endif
-    auto geom = [&](int it) -> Pre {
+#ifdef MI_LDS_WINDOW
+    Win win; win.x0 = win.y0 = 0; win.limx = win.limy = 0u; win.tile = nullptr;
+    unsigned win_mx = 0u, win_my = 0u;            /* the largest tile coordinates a sample asked for (unsigned: below the box = huge) */
+    auto record_win = [&](float uc, float vc) -> u32x4 {
+        const unsigned lx = (unsigned)((int)uc - win.x0), ly = (unsigned)((int)vc - win.y0);
+        win_mx = lx > win_mx ? lx : win_mx; win_my = ly > win_my ? ly : win_my;
+        const unsigned cx = lx < win.limx ? lx : win.limx, cy = ly < win.limy ? ly : win.limy;      /* memory-safe; a miss redoes the pass */
+        const uint32_t* t = win.tile + (__umul24(cy, (unsigned)MI_WIN_TP) + cx);
+        u32x4 o; o.x = t[0]; o.y = t[1]; o.z = t[MI_WIN_TP]; o.w = t[MI_WIN_TP + 1];
+        return o;
+    };
+#endif
+    auto geom_w = [&](int it, auto use_win) -> Pre {
         Pre q;
         const int iraw = sub + it * L::LPV;
         q.live = iraw < MI_NS;                         /* L::LPV = 16: second trip only for lanes 0..8 */
@@ -877,12 +992,16 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
         /* the bilinear weights: x - floor(x) in one instruction (v_fract_f32: the same value as the subtraction, which is
          * exact) */
         q.fx = __builtin_amdgcn_fractf(uc); q.fy = __builtin_amdgcn_fractf(vc);
+#ifdef MI_LDS_WINDOW
+        if constexpr (decltype(use_win)::value) q.t = record_win(uc, vc); else
+#endif
         q.t = record(uc, vc);
 #ifdef MI_EMU_LIN48
         q.e1 = record_more(uc, vc, 1); q.e2 = record_more(uc, vc, 2);
 #endif
         return q;
     };
+    auto geom = [&](int it) -> Pre { return geom_w(it, std::false_type{}); };
     auto geom2 = [&](int ita, int itb) -> Pre2 {
         Pre2 q;
         const int ra = sub + ita * L::LPV, rb = sub + itb * L::LPV;
@@ -1108,6 +1227,34 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             }
         }
 #else
+        bool on_window = false;
+#ifdef MI_LDS_WINDOW
+        if constexpr (WIN) {
+            const bool ok_in = ok;
+            on_window = window_build(ps, nv, geo, (int)(threadIdx.x & 63u), win);
+            if (on_window) {
+#pragma unroll 1
+                for (int row = 0; row < MI_FW; ++row) {
+                    Pre q[MI_FW];
+#pragma unroll
+                    for (int k = 0; k < MI_FW; ++k) q[k] = geom_w(row * MI_FW + k, std::true_type{});
+#pragma unroll
+                    for (int k = 0; k < MI_FW; ++k) consume(q[k]);
+                }
+                if (__ballot(win_mx > win.limx || win_my > win.limy) != 0ull) {
+                    /* a sample outside its box (its texels were read from the box's edge): the pass is redone on the global gathers */
+                    on_window = false; ok = ok_in;
+                    Pa0 = Pa1 = Pa2 = Paa0 = Paa1 = Paa2 = Pba0 = Pba1 = Pba2 = sp2(0.f);
+                    Pdr0 = Pdr1 = Pdr2 = Pdn0 = Pdn1 = Pdn2 = Pdd0 = Pdd1 = Pdd2 = sp2(0.f);
+                    Pnum = Pden = sp2(0.f);
+                    A00 = A01 = A02 = A11 = A12 = A22 = B0 = B1 = B2 = 0;
+                }
+            }
+            const unsigned long long actw = __ballot(true);
+            if ((int)(threadIdx.x & 63u) == __ffsll((long long)actw) - 1) atomicAdd(&g_wstat[on_window ? 0 : 1], 1u);
+        }
+#endif
+        if (!on_window) {
 #pragma unroll 1
         for (int row = 0; row < MI_FW; ++row) {
             Pre q[MI_FW];
@@ -1115,6 +1262,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
             for (int k = 0; k < MI_FW; ++k) q[k] = geom(row * MI_FW + k);
 #pragma unroll
             for (int k = 0; k < MI_FW; ++k) consume(q[k]);
+        }
         }
 #endif
 #ifdef MI_TOUCH_ROWS
@@ -1444,12 +1592,15 @@ __device__ __forceinline__ bool view_prepare(const PatchState& ps, ViewC& vc, co
         premultiply(nv, Lv.ax, Lv.ay, Lv.cx, Lv.cy);
         nv.w = Lv.w; nv.h = Lv.h;
         nv.img = DV->quad + MI_QUAD_WORDS * (size_t)Lv.tex_off;
+#ifdef MI_LDS_WINDOW
+        nv.raw = DV->img + Lv.tex_off;
+#endif
     }
     return true;
 }
 
 /* One fused pass of my view at the current state; sets ps.ncc (getFastNCC).  Returns success[v]. */
-template <int MODE, class L>
+template <int MODE, class L, bool WIN = false>
 __device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevView* views, const float* s_lut, const float* geo,
                                          const float* mcol, ColorSums& S, GNSums& gn, bool count_color, int sub) {
     bool okv = true;
@@ -1460,7 +1611,7 @@ __device__ __forceinline__ bool run_pass(PatchState& ps, ViewC& vc, const DevVie
     if (ps.sel >= 0) {
         okv = view_prepare(ps, vc, views);
         TSTAMP(52);
-        if (okv) okv = sample_pass<MODE, L>(ps, vc.nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
+        if (okv) okv = sample_pass<MODE, L, WIN>(ps, vc.nv, s_lut, geo, mcol, S, gn, nullptr, nullptr, sub);
         ps.n_pass++;
         if (okv && MODE != PASS_DEPTH_FIXED_NC) {
             ps.ncc = ncc_from_sums(ps, S);
@@ -1685,14 +1836,19 @@ __device__ __forceinline__ bool run_turn(Run& R, const DevSettings& st, const De
     }
     bool okv;
     TSTAMP(20 + R.need);
-    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+#ifdef MI_LDS_WINDOW
+    constexpr bool WIN = FAST && !L::LAT && L::NV == 4 && MI_FW == 5;      /* the first attempts of the large rounds (see g_win) */
+#else
+    constexpr bool WIN = false;
+#endif
+    if (R.need == PASS_DEPTH) okv = run_pass<PASS_DEPTH, L, WIN>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
     /* (the passes behind the depth-only steps of iterations 1..3: nobody asks for their NCC -- the reference's main loop, which
      * does, starts at iteration 4, patch_optimization.cc:177-192 --, so they carry no colour sums) */
     else if (R.need == PASS_DEPTH_FIXED && R.ctx == CTX_FIRST4 && !R.count_color)
-        okv = run_pass<PASS_DEPTH_FIXED_NC, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, false, sub);
-    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
-    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
-    else okv = run_pass<PASS_COLOR, L>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+        okv = run_pass<PASS_DEPTH_FIXED_NC, L, WIN>(ps, R.vc, views, s_lut, geo, mcol, S, gn, false, sub);
+    else if (R.need == PASS_DEPTH_FIXED) okv = run_pass<PASS_DEPTH_FIXED, L, WIN>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    else if (R.need == PASS_NORMAL) okv = run_pass<PASS_NORMAL, L, WIN>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
+    else okv = run_pass<PASS_COLOR, L, WIN>(ps, R.vc, views, s_lut, geo, mcol, S, gn, R.count_color, sub);
     TSTAMP(30);
     /* ---- finish what led to this pass */
     if (R.ctx == CTX_CTOR || R.ctx == CTX_REPLACED) {
@@ -2219,6 +2375,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
 #ifdef MI_ACTIVITY
     if (lane < 2) g_act[lane] = 0;
 #endif
+#ifdef MI_LDS_WINDOW
+    if (FAST && !L::LAT && L::NV == 4 && lane < 2) g_wstat[lane] = 0;
+#endif
     __syncthreads();
     /* (DevCounters::clk_shader / clk_real: the shader clock this launch runs at, sampled by every 1024th wavefront) */
     const bool clk_probe = (blockIdx.x & 1023u) == 0u;
@@ -2271,6 +2430,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
         const unsigned long long ds = (unsigned long long)clock64() - clk_s0, dr = (unsigned long long)wall_clock64() - clk_r0;
         if (dr > 100ull) { atomicAdd(&a.counters->clk_shader, ds); atomicAdd(&a.counters->clk_real, dr); }   /* (wavefronts that found no work: too short to say anything) */
     }
+#ifdef MI_LDS_WINDOW
+    if constexpr (FAST && !L::LAT && L::NV == 4) {
+        /* (wavefront-passes on LDS windows / on global gathers, reported as mi_dmrecon_stats::n_patch_turns / n_wave_turns) */
+        __syncthreads();
+        if (lane == 0) { atomicAdd(&a.counters->n_stage, (unsigned long long)g_wstat[0]); atomicAdd(&a.counters->n_gather_pass, (unsigned long long)g_wstat[1]); }
+    }
+#endif
 #ifdef MI_ACTIVITY
     __syncthreads();
     if (lane == 0 && !L::LAT) { atomicAdd(&a.counters->n_stage, (unsigned long long)g_act[0]); atomicAdd(&a.counters->n_gather_pass, (unsigned long long)g_act[1] * L::PATCHES); }

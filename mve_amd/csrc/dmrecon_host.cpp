@@ -1569,9 +1569,11 @@ static int set_view_impl(mi_dmrecon_ctx* c, int32_t view_id, const mi_dmrecon_ca
         return 0;
     }
     v.n_texels = off;
-    /* RGBA8 levels, then (16-byte aligned) the same levels as 2x2 footprint records: 4 + 16 bytes per texel */
+    /* RGBA8 levels, then (16-byte aligned) the same levels as footprint elements (column pairs, 8 bytes per texel position: a
+     * sample's 2 x 2 footprint is one 16-byte gather over two of them; the last gather of the last level ends 8 bytes past its
+     * elements, hence the pad): 4 + 8 bytes per texel */
     v.quad_off = (off + 3) & ~(size_t)3;
-    HIP_TRY(hipMalloc((void**)&v.d_img, (v.quad_off + (size_t)mi_quad_words() * off) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.d_img, (v.quad_off + (size_t)mi_quad_words() * off + 4) * sizeof(uint32_t)));
     /* ensureImages, image_pyramid.cc:55-95: upload, strip alpha / expand grey, then the Gaussian levels */
     const size_t nbytes = (size_t)width * height * channels;
     /* two device staging buffers used alternately: the copy of view i+1 (from pinned memory) can start

@@ -32,8 +32,9 @@ struct DevView {
     float w2c[12];           /* rows of [R|t] */
     int32_t n_levels;
     const uint32_t* img;     /* all levels back to back, RGBA8 (A unused), row-major */
-    const uint32_t* quad;    /* same levels as 16-byte records: record (x, y) = texels (x,y) (x+1,y) (x,y+1) (x+1,y+1),
-                              * edge-clamped -- the whole bilinear footprint of a sample in ONE aligned gather */
+    const uint32_t* quad;    /* same levels as footprint elements: element (x, y) = texels (x,y) (x,y+1), 8 bytes, edge-clamped --
+                              * the whole bilinear footprint of a sample = elements x, x + 1 of row y in ONE 16-byte gather
+                              * (mi_quad_words() words per element: 2; the 16-byte records of rounds 2-5 with -DMI_QUAD_RECORDS) */
     DevLevel lv[MI_MAX_LEVELS];
 };
 
