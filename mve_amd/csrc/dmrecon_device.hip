@@ -150,7 +150,7 @@ __shared__ float g_mcol[MI_PATCHES_PER_WAVE][3 * MI_NS];       /* PatchSampler::
 __shared__ __attribute__((aligned(16))) uint32_t g_win[4][MI_WIN_TH * MI_WIN_TP];
 __shared__ __attribute__((aligned(16))) int g_wbox[4][4];          /* per view slot: min x, min y, max x, max y (texel indices, inclusive) */
 __shared__ __attribute__((aligned(16))) unsigned g_wimg[4][4];     /* per view slot: the level's plane (address lo, hi), its width, unused */
-__shared__ unsigned g_wstat[2];                                    /* passes of this workgroup that ran on windows / that fell back */
+__shared__ unsigned g_wstat[4];                                    /* wavefront-passes of this workgroup: on windows, redone after a miss, other images, box too large */
 #endif
 /* LocalViewSelection ncc[] of the throughput layouts: L::PATCHES x DevSettings::ncc_stride floats of DYNAMIC shared memory, sized
  * by the launcher -- 64 per patch unless globalVSMax asks for more (MI_MAX_GLOBAL = 128): the 4 KB a wavefront of 16 patches has
@@ -794,15 +794,18 @@ __device__ __forceinline__ bool window_build(const PatchState& ps, const NView& 
     const int4 box = *reinterpret_cast<const int4*>(g_wbox[slot]);
     const uint4 im = *reinterpret_cast<const uint4*>(g_wimg[slot]);
     const int bw = box.z - box.x + 1, bh = box.w - box.y + 1;
-    const bool bad = im.x != rlo || im.y != rhi || im.z != (unsigned)nv.w || bw > MI_WIN_TP || bh > MI_WIN_TH;
-    if (__ballot(bad) != 0ull) return false;
-    /* fill: eight lanes per tile row, 16 bytes each (a row's last piece may reach past the box: it stays inside the pitch, and
-     * inside the view's allocation -- the footprint elements follow the planes) */
+    const bool other = im.x != rlo || im.y != rhi || im.z != (unsigned)nv.w;
+    const bool large = bw > MI_WIN_TP || bh > MI_WIN_TH;
+    const unsigned long long m_other = __ballot(other), m_large = __ballot(large);
+    if ((m_other | m_large) != 0ull) {
+        /* (why not, per wavefront-pass: g_wstat[2] the slots' patches sample different images or levels, [3] a box does not fit) */
+        if ((int)lane == __ffsll((long long)act) - 1) atomicAdd(&g_wstat[m_other ? 2 : 3], 1u);
+        return false;
+    }
+    /* fill: the boxes' rows in 16-byte pieces, eight pieces per tile row, dealt over the calling lanes (a row's last piece may reach
+     * past the box: it stays inside the pitch, and inside the view's allocation -- the footprint elements follow the planes) */
     const unsigned nact = (unsigned)__popcll(act);
     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-    const unsigned rstep = nact >= 8u ? nact >> 3 : 1u;
-    const unsigned c4 = (rank & 7u) * 4u;
-    const bool filler = rank < rstep * 8u;
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
         if (!(act & (0x1111111111111111ull << sl))) continue;               /* no caller has a view in this slot */
@@ -810,8 +813,9 @@ __device__ __forceinline__ bool window_build(const PatchState& ps, const NView& 
         const uint4 m = *reinterpret_cast<const uint4*>(g_wimg[sl]);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(((uintptr_t)m.y << 32) | (uintptr_t)m.x);
         const int sw = (int)m.z, sbw = b.z - b.x + 1, sbh = b.w - b.y + 1;
-        if (filler && (int)c4 < sbw) {
-            for (unsigned r = rank >> 3; (int)r < sbh; r += rstep) {
+        for (unsigned idx = rank; idx < (unsigned)sbh * (MI_WIN_TP / 4u); idx += nact) {
+            const unsigned r = idx / (MI_WIN_TP / 4u), c4 = (idx - r * (MI_WIN_TP / 4u)) * 4u;
+            if ((int)c4 < sbw) {
                 const u32x4 t = *(gtex4u_t)(src + (size_t)(b.y + (int)r) * (size_t)sw + (size_t)(b.x + (int)c4));
                 *reinterpret_cast<u32x4*>(&g_win[sl][r * MI_WIN_TP + c4]) = t;
             }
@@ -1244,6 +1248,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
                 if (__ballot(win_mx > win.limx || win_my > win.limy) != 0ull) {
                     /* a sample outside its box (its texels were read from the box's edge): the pass is redone on the global gathers */
                     on_window = false; ok = ok_in;
+                    if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_wstat[1], 1u);
                     Pa0 = Pa1 = Pa2 = Paa0 = Paa1 = Paa2 = Pba0 = Pba1 = Pba2 = sp2(0.f);
                     Pdr0 = Pdr1 = Pdr2 = Pdn0 = Pdn1 = Pdn2 = Pdd0 = Pdd1 = Pdd2 = sp2(0.f);
                     Pnum = Pden = sp2(0.f);
@@ -1251,7 +1256,7 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
                 }
             }
             const unsigned long long actw = __ballot(true);
-            if ((int)(threadIdx.x & 63u) == __ffsll((long long)actw) - 1) atomicAdd(&g_wstat[on_window ? 0 : 1], 1u);
+            if (on_window && (int)(threadIdx.x & 63u) == __ffsll((long long)actw) - 1) atomicAdd(&g_wstat[0], 1u);
         }
 #endif
         if (!on_window) {
@@ -2376,7 +2381,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
     if (lane < 2) g_act[lane] = 0;
 #endif
 #ifdef MI_LDS_WINDOW
-    if (FAST && !L::LAT && L::NV == 4 && lane < 2) g_wstat[lane] = 0;
+    if (FAST && !L::LAT && L::NV == 4 && lane < 4) g_wstat[lane] = 0;
 #endif
     __syncthreads();
     /* (DevCounters::clk_shader / clk_real: the shader clock this launch runs at, sampled by every 1024th wavefront) */
@@ -2434,7 +2439,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu((L::LAT ? 
     if constexpr (FAST && !L::LAT && L::NV == 4) {
         /* (wavefront-passes on LDS windows / on global gathers, reported as mi_dmrecon_stats::n_patch_turns / n_wave_turns) */
         __syncthreads();
-        if (lane == 0) { atomicAdd(&a.counters->n_stage, (unsigned long long)g_wstat[0]); atomicAdd(&a.counters->n_gather_pass, (unsigned long long)g_wstat[1]); }
+        if (lane == 0) { atomicAdd(&a.counters->n_stage, (unsigned long long)g_wstat[0] | ((unsigned long long)g_wstat[1] << 32));
+                         atomicAdd(&a.counters->n_gather_pass, (unsigned long long)g_wstat[2] | ((unsigned long long)g_wstat[3] << 32)); }
     }
 #endif
 #ifdef MI_ACTIVITY
