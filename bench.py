@@ -522,7 +522,7 @@ def predicted_strong_scaling(n_views):
     scene's reference views per step, one library call; lone calls of exactly those sizes were timed on one MI355X
     (tools/lone_calls.py -> profiles/r<N>_lone_calls.json, a STORED profile).  The floor: one view's dependent propagation
     rounds do not shrink with the share."""
-    for tag in ("r5", "r4", "r3"):
+    for tag in ("r6",):                                  # this round's collection only (no silent fall-back to older trees)
         f = os.path.join(ROOT, "profiles", "%s_lone_calls.json" % tag)
         if not os.path.exists(f):
             continue

@@ -3473,6 +3473,26 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
     const int tx0 = tcol * MI_GEN_TILE_W, ty0 = trow * MI_GEN_TILE_H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = lane & 7, ly = lane >> 3;
+    /* The stamps of the tile and a one-pixel rim, once, through LDS: a row of 66 stamps per load instruction of the workgroup --
+     * nine coalesced loads per lane instead of four scattered ones per pixel (32 per lane): the kernel is bound by the NUMBER of
+     * its load instructions (0.48 of a step's 12 ms; a bit per pixel in front of the same four loads made it slower,
+     * profiles/r6_ab_experiments.txt M), and the own confidence is only read where a neighbour's stamp says so.  Outside the
+     * image: -1, the stamp of a pixel never written. */
+    constexpr int SW = MI_GEN_TILE_W + 2, SH = MI_GEN_TILE_H + 2;
+    __shared__ int s_upd[SH * SW];
+    static_assert(SW == 66 && SH * SW <= 65536 / 993 * 66, "i / 66 below is (i * 993) >> 16: exact for i < 4356");
+#ifndef MI_GEN_GLOBAL_STAMPS           /* (-DMI_GEN_GLOBAL_STAMPS: the stamps straight from memory, as until round 6 -- the A/B build) */
+    for (int i = (int)threadIdx.x; i < SH * SW; i += 256) {
+        const int r = (i * 993) >> 16, c = i - r * SW;
+        const int y = ty0 - 1 + r, x = tx0 - 1 + c;
+        s_upd[i] = (y >= 0 && y < H && x >= 0 && x < W) ? job->upd[(size_t)y * W + x] : -1;
+    }
+    __syncthreads();
+#define MI_STAMP(si, gi) s_upd[si]
+#else
+    (void)s_upd;
+#define MI_STAMP(si, gi) job->upd[gi]
+#endif
     unsigned hits = 0;                       /* bit t = my pixel of sub-tile t is a hit */
     unsigned before[GEN_PER_THREAD];         /* hits of lower lanes of my wave in trip t */
     unsigned wave_total = 0;
@@ -3490,16 +3510,23 @@ __global__ __launch_bounds__(256) void k_generate(SweepArgs a) {
         /* a patch needs a 2-pixel margin (patch_sampler.cc:47-50) */
         if (x >= MI_HALF && y >= MI_HALF && x < W - MI_HALF && y < H - MI_HALF) {
             const int pix = y * W + x;
-            const float own = job->conf[pix];
             const int nb[4] = {pix - 1, pix + 1, pix - W, pix + W};
-            if (a.self_round) { if (job->upd[pix] == a.round - 1) { any = true; cnt = 1; } }
+            const int sc = (wave * 8 + ly + 1) * SW + (t * 8 + lx + 1);                   /* my pixel in s_upd */
+            const int snb[4] = {sc - 1, sc + 1, sc - SW, sc + SW};
+            if (a.self_round) { if (MI_STAMP(sc, pix) == a.round - 1) { any = true; cnt = 1; } }
             else {
+                unsigned fresh = 0;                                                        /* bit k: neighbour k was written last round */
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (job->upd[nb[k]] == a.round - 1) {
-                        const float c = job->conf[nb[k]];
-                        if (own < c - 0.05f || own == 0.f) { any = true; ++cnt; }
-                    }
+                for (int k = 0; k < 4; ++k) fresh |= (MI_STAMP(snb[k], nb[k]) == a.round - 1 ? 1u : 0u) << k;
+                if (fresh) {
+                    const float own = job->conf[pix];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((fresh >> k) & 1u) {
+                            const float c = job->conf[nb[k]];
+                            if (own < c - 0.05f || own == 0.f) { any = true; ++cnt; }
+                        }
+                }
             }
         }
         if (want_items && any) { ipos[t] = atomicAdd(&s_items, cnt); cands |= cnt << (3 * t); }
