@@ -119,6 +119,12 @@ def map_parity(a_depth, a_conf, b_depth, b_conf):
     iou = both.sum() / max((ma | mb).sum(), 1)
     rel = np.abs(a_depth[both] - b_depth[both]) / b_depth[both]
     cd = np.abs(a_conf[both] - b_conf[both])
-    return dict(iou=float(iou), rel_med=float(np.median(rel)), rel_p99=float(np.percentile(rel, 99)),
-                conf_med=float(np.median(cd)), conf_p99=float(np.percentile(cd, 99)),
-                n_a=int(ma.sum()), n_b=int(mb.sum()))
+    m = dict(iou=float(iou), rel_med=float(np.median(rel)), rel_p99=float(np.percentile(rel, 99)),
+             conf_med=float(np.median(cd)), conf_p99=float(np.percentile(cd, 99)),
+             n_a=int(ma.sum()), n_b=int(mb.sum()))
+    log = os.environ.get("MI_TEST_LOG_METRICS")          # (a file to append every measured metric set to: how far the bounds are)
+    if log:
+        import json
+        with open(log, "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), **m}) + "\n")
+    return m
