@@ -337,6 +337,8 @@ def test_config5_full_size_views_vs_oracle(tmp_path):
             m = map_parity(res[v]["depth"], res[v]["conf"], o["d%d" % v], o["c%d" % v])
             print("C5 view", v, m)
             assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_p99"] <= 1e-2, (v, m)
+            # regression guard (round 6): 1.25 x the worst of the three views as this build measures them (the maps are deterministic)
+            assert m["iou"] >= 0.998 and m["rel_p99"] <= 2.9e-3 and m["conf_p99"] <= 8.9e-3, (v, m)
         ctx.close()
     finally:
         if proc is not None and proc.poll() is None:

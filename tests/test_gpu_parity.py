@@ -706,6 +706,7 @@ def test_two_views_local_neighbors_1(gpu_ctx, g2, g2_scene):
     # sensitivity is about twice as large, so the p99 bound on conf is 1e-2 here
     assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3, m
     assert m["conf_med"] <= 1e-3 and m["conf_p99"] <= 1e-2, m
+    assert m["conf_p99"] <= 7.9e-3, m                                 # (regression guard: 1.25 x the value measured in round 6)
 
 
 def test_batch_equals_single_and_is_deterministic(ctx_g1, g1_scene):
@@ -835,6 +836,9 @@ def test_hard_scene_maps_vs_reference(gpu_ctx, h1, h1_scene):
         print("H1 view %d:" % v, m)
         assert m["iou"] >= 0.985 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 3e-2, m
         assert m["conf_med"] <= 2e-3 and m["conf_p99"] <= 0.15, m
+        # regression guard (round 6): 1.25 x what this build measures here -- a view's maps are deterministic, so a change that moves
+        # them further from the reference shows long before the floor-derived bounds above
+        assert m["iou"] >= 0.997 and m["rel_p99"] <= 1.4e-2 and m["conf_med"] <= 5.5e-4 and m["conf_p99"] <= 7.5e-2, m
         # the occluder's silhouette and the empty part of the low-overlap view are where the reference has them
         empty_ref = h1["s0v%d_depth" % v] == 0
         assert ((r["depth"] == 0) & empty_ref).sum() >= 0.9 * empty_ref.sum()
@@ -950,6 +954,7 @@ def test_filter_widths_vs_reference(gpu_ctx, g1, g1_fw, g1_scene, fw, monkeypatc
     print("filter width %d maps:" % fw, m)
     assert m["iou"] >= 0.98 and m["rel_med"] <= 1e-3 and m["rel_p99"] <= 5e-3 and m["conf_med"] <= 1e-3, m
     assert m["conf_p99"] <= (2e-2 if fw == 3 else 5e-3), m
+    assert m["conf_p99"] <= (1.7e-2 if fw == 3 else 5e-3), m          # (width 3: regression guard, 1.25 x the value measured in round 6)
     half = fw // 2                                                           # the border that is never filled (Q11)
     assert (r["depth"][:half] == 0).all() and (r["depth"][-half:] == 0).all() and (r["depth"][:, :half] == 0).all()
     S = orc.OracleScene(g1_scene)
@@ -1003,6 +1008,9 @@ def test_wide_view_sets_vs_reference(gpu_ctx, w1, w1_scene, g1_scene, monkeypatc
         # the fill mask at the smooth-scene bound
         assert m["iou"] >= 0.99 and m["rel_med"] <= 1.5e-3 and m["rel_p99"] <= 1.3e-2, (tag, m)
         assert m["conf_med"] <= 2.2e-2 and m["conf_p99"] <= 0.18, (tag, m)
+        # regression guard (round 6): 1.25 x what this build measures here -- a view's maps are deterministic, so a change that moves
+        # them further from the reference shows long before the floor-derived bounds above
+        assert m["rel_med"] <= 4.3e-4 and m["rel_p99"] <= 9.6e-3 and m["conf_med"] <= 2.8e-3 and m["conf_p99"] <= 0.126, (tag, m)
         filled = r["conf"] > 0
         v = r["views"][filled]
         assert v.shape[1] == 8 and ((v >= 0).sum(1) == st.nrReconNeighbors).all()           # exactly K views, ...
@@ -1073,6 +1081,9 @@ def test_wider_view_sets_vs_reference(gpu_ctx, w2, w2_scene, g1_scene, monkeypat
         print("W2", tag, m)
         assert m["iou"] >= 0.99 and m["rel_med"] <= 1.6e-3 and m["rel_p99"] <= 1.5e-2, (tag, m)
         assert m["conf_med"] <= 2.6e-2 and m["conf_p99"] <= 0.2, (tag, m)
+        # regression guard (round 6): 1.25 x what this build measures here -- a view's maps are deterministic, so a change that moves
+        # them further from the reference shows long before the floor-derived bounds above
+        assert m["rel_med"] <= 4e-4 and m["rel_p99"] <= 1.15e-2 and m["conf_med"] <= 1.2e-3 and m["conf_p99"] <= 0.165, (tag, m)
         if tag == "k4n80":
             # The FILL MASK of this scene depends on the seed semantics ("Seeds"): a strip along the right
             # border is out of sight of the view sets that propagate towards it, so the region grown from the rest of the
