@@ -505,6 +505,7 @@ def roofline(acc, n_maps, scene, cfg, n_streams, spc, elapsed):
             # per colour evaluation, mix 19.9 : 11.9), and the L2 with the bytes the passes request from it
             "secondary_roofs": {
                 "valu_issue": valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps_rank, lone=(n_streams == 1 and spc == 1)),
+                "l1_gather": l1_gather_roof(acc, bulk_stats, n_pass, ms_bulk, steps_rank, lone=(n_streams == 1 and spc == 1)),
                 "valu_fp32": {"algorithmic_flop": 2.85e3 * acc["n_eval"], "achieved": 2.85e3 * acc["n_eval"] / opt_s / 1e12 if opt_s > 0 else None,
                               "peak": 157.3, "unit": "TFLOP/s", "frac": 2.85e3 * acc["n_eval"] / opt_s / 1e12 / 157.3 if opt_s > 0 else None},
                 "l2": {"requested_bytes": 400.0 * n_pass, "achieved": 400.0 * n_pass / opt_s / 1e9 if opt_s > 0 else None,
@@ -551,9 +552,49 @@ def measured_shader_clock(acc):
     return acc["clk_shader_cycles"] / acc["clk_real_ticks"] * (acc.get("clk_real_mhz", 0.0) / max(acc.get("_calls", 1), 1))
 
 
+# what a compute unit's vector L1 serves of the bulk kernels' access pattern -- 64-lane 16-byte gathers from 8-byte aligned
+# addresses, five in flight per wavefront, 12 wavefronts per CU -- while the L1 / L2 hold the lines: measured by
+# tools/ubench/gather_rate.hip on the MI355X (profiles/r6_gather_rate.txt: 37.1 gathers per microsecond and CU = 62 shader
+# cycles per gather = 1.03 lane accesses per cycle), a STORED figure like the PMC ones
+L1_LANE_ACCESSES_PER_US_PER_CU = 37.1 * 64.0
+N_CUS = 256
+
+
+def stored_l1_per_wave_pass(lone=False):
+    for name in TRAFFIC_PROFILES:
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            by = json.load(open(f)).get("l1_accesses_per_wave_pass_by_plan", {})
+            for plan, v in by.items():
+                if plan.startswith("1 host thread") == bool(lone) and v:
+                    return float(v), "profiles/%s (profiled plan: %s)" % (name, plan)
+    return None, None
+
+
+def l1_gather_roof(acc, bulk_stats, n_pass, ms_bulk, steps, lone=False):
+    """The vector L1's rate on the bulk kernels' gathers as a third ceiling: the L1 accesses the kernels make (one per lane of a
+    gather; a stored TCP_TOTAL_CACHE_ACCESSES figure per wavefront pass x the passes this run counted) over what the L1s of
+    all CUs serve of this access pattern by the micro-benchmark's measure.  `frac` well below 1 says the kernels are not
+    bound by the L1's rate either (no single ceiling is saturated; the time follows the lines touched)."""
+    if not acc.get("n_eval") or ms_bulk <= 0:
+        return None
+    per_wave_pass, src = stored_l1_per_wave_pass(lone)
+    if per_wave_pass is None:
+        return None
+    passes_bulk = n_pass * (bulk_stats["n_eval"] / acc["n_eval"])
+    accesses = per_wave_pass * passes_bulk / 64.0
+    peak = L1_LANE_ACCESSES_PER_US_PER_CU * N_CUS * 1e6                     # lane accesses per second, whole chip
+    floor_ms = 1000.0 * accesses / peak
+    return {"bound": "l1_gather", "kernel": "k_optimize<1> (host-visible rounds)", "l1_accesses_per_step": accesses / max(steps, 1),
+            "l1_accesses_per_wave_pass": per_wave_pass, "l1_accesses_per_sample_and_lane": per_wave_pass / 25.0 / 64.0,
+            "source": {"file": src, "stored_profile": True, "peak_from": "profiles/r6_gather_rate.txt (tools/ubench/gather_rate.hip)"},
+            "peak": peak / 1e9, "unit": "G lane accesses/s", "achieved": accesses / (ms_bulk / 1e3) / 1e9,
+            "floor_ms_per_step": floor_ms / max(steps, 1), "measured_ms_per_step": ms_bulk / max(steps, 1), "frac": floor_ms / ms_bulk}
+
+
 def valu_issue_roof(acc, bulk_stats, n_pass, ms_bulk, steps, lone=False):
-    """The ceiling the bulk kernel is actually under (its wavefronts are limited by how fast a SIMD
-    issues their VALU instructions, not by memory): the VALU wave-instructions it EXECUTES -- a stored SQ_INSTS_VALU
+    """A second ceiling next to the HBM one (round 5 took it for the binding one; round 6's experiments say it is not: DESIGN.md
+    section 5): how fast the SIMDs could issue the VALU wave-instructions the bulk kernel EXECUTES -- a stored SQ_INSTS_VALU
     figure per wavefront pass x the passes this run counted on the device -- over the chip's issue rate, SIMDs x shader
     clock / 4 cycles per instruction.  `frac` = that floor / the kernel's measured time: 1.0 = every SIMD issues a VALU
     instruction whenever it can.  `executed_per_algorithmic`: the instructions executed per f32 operation the reference's

@@ -154,6 +154,27 @@ for prefix, plan in (("pmc", PLAN["pmc"]), ("pmcd", PLAN["pmcd"])):
                   % (plan, valu, passes, per, per / 25.0)]
     except Exception as e:
         lines += ["", "(no VALU-per-pass figure for %s: %r)" % (plan, e)]
+# the same for the vector L1: TCP_TOTAL_CACHE_ACCESSES (one per lane of a gather) of the bulk kernels per wavefront pass --
+# bench.py's `l1_gather` roof (the L1's rate on this access pattern: tools/ubench/gather_rate.hip) reads them here
+def l1_per_wave_pass(prefix, steps_all):
+    log = os.path.join(src, "%s_TCP_TOTAL_CACHE_ACCESSES_sum+TCP_TCC_READ_REQ_sum+TCP_PENDING_STALL_CYCLES_sum.log" % prefix)
+    bl = [l for l in open(log).read().splitlines() if l.startswith("{")]
+    jb = json.loads(bl[-1])
+    r = jb["roofline"]
+    pk = r["per_kernel"]["k_optimize<1> (host-visible rounds)"]
+    share = (pk["algorithmic_bytes_per_launch"] * pk["launches"]) / (r["algorithmic_bytes_per_launch"] * r["launches"])
+    passes_bulk_per_step = r["n_pass"] * share / (jb["steps"] * len(jb.get("repeats", [1])))
+    a2, _ = (acc, regs) if prefix == "pmc" else collect(prefix)
+    l1 = sum(a2[k]["TCP_TOTAL_CACHE_ACCESSES_sum"][0] for k in a2 if family(k) == "k_optimize<1> (host-visible rounds)" and "TCP_TOTAL_CACHE_ACCESSES_sum" in a2[k]) / steps_all
+    return l1, passes_bulk_per_step, l1 / (passes_bulk_per_step / 64.0)
+traffic["l1_accesses_per_wave_pass_by_plan"] = {}
+for prefix, plan in (("pmc", PLAN["pmc"]), ("pmcd", PLAN["pmcd"])):
+    try:
+        l1, passes, per = l1_per_wave_pass(prefix, STEPS[prefix])
+        traffic["l1_accesses_per_wave_pass_by_plan"][plan] = per
+        lines += ["", "Bulk kernels, %s: %.3e L1 accesses per step -> %.0f per wavefront pass (%.1f per sample: a 64-lane gather is 64)" % (plan, l1, per, per / 25.0)]
+    except Exception as e:
+        lines += ["", "(no L1-accesses-per-pass figure for %s: %r)" % (plan, e)]
 if PLAN["pmc"] in traffic["valu_wave_insts_per_wave_pass_by_plan"]:
     traffic["valu_wave_insts_per_wave_pass"] = traffic["valu_wave_insts_per_wave_pass_by_plan"][PLAN["pmc"]]
 if traffic["plans"]:
