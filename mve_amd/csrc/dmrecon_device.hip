@@ -1062,6 +1062,15 @@ __device__ __forceinline__ bool sample_pass(const PatchState& ps, const NView& n
           for (int k = 0; k < MI_EXTRA_VALU; ++k) asm volatile("v_mov_b32 %0, %0" : "+v"(dummy));
         }
 #endif
+#ifdef MI_EXTRA_FMA
+        /* the same question with instructions that are certainly executed at the plain rate: a dependent chain of v_fma_f32 (the
+         * micro-benchmark's instruction, 3.7 cycles each at three wavefronts per SIMD) on a live value */
+        { float dummy = q.fx;
+#pragma unroll
+          for (int k = 0; k < MI_EXTRA_FMA; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy));
+          asm volatile("" : : "v"(dummy));
+        }
+#endif
         const int i = q.i;
         const int dj = i / MI_FW - MI_HALF, di = i - (i / MI_FW) * MI_FW - MI_HALF;
         const float fx = q.fx, fy = q.fy, gu = q.gu, gv = q.gv;
